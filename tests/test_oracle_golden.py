@@ -1,0 +1,148 @@
+"""CPU: the oracle (plain-torch restatement) against fixtures produced by the REFERENCE classes
+(tests/golden/make_golden.py, run in the build container).  This is what pins the oracle."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import detweights, sequence
+from oracle.config import OracleConfig
+from oracle.eye_net import EyeNet
+from oracle.refine_net import CGRUCell, CLSTMCell, CRNNCell, RefineNet
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EYE_JSON = os.path.join(REPO, 'tests', 'golden', 'eye_net.json')
+
+
+def load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name), allow_pickle=False)
+
+
+def eye_cfg():
+    # the values of /root/reference/src/configs/eye_net.json that reach the hot path
+    return OracleConfig(batch_size=16, weight_decay=0.005, base_learning_rate=0.001)
+
+
+def test_eyenet_param_contract():
+    net = EyeNet(eye_cfg())
+    sd = net.state_dict()
+    assert len(sd) == 37
+    assert sum(p.numel() for p in net.parameters()) == 11398337
+    assert 'cnn_layers.layer2.0.downsample.0.weight' in sd and 'fc_to_gaze.2.weight' in sd
+    assert float(sd['fc_to_gaze.2.weight'].abs().max()) == 0.0     # eye_net.py:96
+
+
+def test_eyenet_frame_and_sequence_match_reference(golden_dir):
+    fx = load(golden_dir, 'eyenet.npz')
+    B, T = int(fx['B']), int(fx['T'])
+    batch = detweights.eyenet_batch(B, T, seed=int(fx['seed']), invalid_fraction=float(fx['invalid_fraction']))
+    net = detweights.fill_module(EyeNet(eye_cfg()), seed=0)
+    with torch.no_grad():
+        sub_in = {k: v[:, 0] for k, v in batch.items()}
+        out = {}
+        net(sub_in, out, side='left')
+        net(sub_in, out, side='right')
+        for k, v in out.items():
+            np.testing.assert_allclose(v.numpy(), fx['frame0_' + k], atol=2e-6, rtol=0)
+        seq = sequence.eyenet_sequence(net, batch)
+    for k, v in seq.items():
+        np.testing.assert_allclose(v.numpy(), fx['seq_' + k], atol=5e-6, rtol=0)
+    # the vacuous-parity trap: outputs must not be identically zero
+    assert np.abs(fx['seq_left_g_initial']).max() > 0.05
+
+
+def test_eyenet_train_step_matches_reference_eve(golden_dir):
+    fx = load(golden_dir, 'eyenet.npz')
+    cfg = eye_cfg()
+    B, T = int(fx['B']), int(fx['T'])
+    batch = detweights.eyenet_batch(B, T, seed=0, invalid_fraction=float(fx['invalid_fraction']))
+    net = detweights.fill_module(EyeNet(cfg), seed=0)
+    opt = sequence.make_optimizer(net.parameters(), cfg)
+    opt.zero_grad()
+    out = sequence.eyenet_sequence(net, batch)
+    terms = sequence.eyenet_losses(out, batch, cfg)
+    for k in ('loss_ang_left_g_initial', 'loss_ang_right_g_initial', 'loss_l1_left_pupil_size',
+              'loss_l1_right_pupil_size', 'full_loss'):
+        np.testing.assert_allclose(float(terms[k]), float(fx['eve_' + k]), rtol=2e-6)
+    terms['full_loss'].backward()
+    names = [str(n) for n in fx['grad_names']]
+    params = dict(net.named_parameters())
+    for n, ref_norm, head in zip(names, fx['grad_norms'], fx['grad_heads']):
+        g = params[n].grad.reshape(-1)
+        np.testing.assert_allclose(float(g.double().norm()), ref_norm, rtol=2e-4, atol=1e-7)
+        np.testing.assert_allclose(g[:8].numpy(), head[:min(8, g.numel())], rtol=2e-3, atol=2e-5)
+    total = torch.nn.utils.clip_grad_norm_(net.parameters(), cfg.gradient_clip_amount)
+    np.testing.assert_allclose(float(total), float(fx['clip_total_norm']), rtol=2e-4)
+    opt.step()
+    sd = net.state_dict()
+    for k in fx.files:
+        if k.startswith('updated_'):
+            np.testing.assert_allclose(sd[k[len('updated_'):]].reshape(-1)[:16].numpy(), fx[k],
+                                       rtol=1e-4, atol=2e-6)
+
+
+@pytest.mark.parametrize('kind,cls', [('CGRU', CGRUCell), ('CLSTM', CLSTMCell), ('CRNN', CRNNCell)])
+def test_cells_match_reference(golden_dir, kind, cls):
+    fx = load(golden_dir, 'cells.npz')
+    cell = detweights.fill_module(cls(64, 64), seed=3)
+    x = torch.from_numpy(fx[kind + '_x']).requires_grad_()
+    h = torch.from_numpy(fx[kind + '_h']).requires_grad_()
+    if kind == 'CLSTM':
+        c = torch.from_numpy(fx[kind + '_c']).requires_grad_()
+        hn, cn = cell(x, (h, c))
+        (hn.sum() + 0.5 * (cn * cn).sum()).backward()
+        np.testing.assert_allclose(cn.detach().numpy(), fx[kind + '_c_new'], atol=2e-6)
+        np.testing.assert_allclose(c.grad.numpy(), fx[kind + '_dc'], atol=1e-5)
+    else:
+        hn = cell(x, h)
+        (hn * hn).sum().backward()
+    np.testing.assert_allclose(hn.detach().numpy(), fx[kind + '_h_new'], atol=2e-6)
+    np.testing.assert_allclose(x.grad.numpy(), fx[kind + '_dx'], atol=2e-5)
+    np.testing.assert_allclose(h.grad.numpy(), fx[kind + '_dh'], atol=2e-5)
+    h0 = cell(x.detach())
+    h0 = h0[0] if isinstance(h0, tuple) else h0
+    np.testing.assert_allclose(h0.detach().numpy(), fx[kind + '_h_new_from_none'], atol=2e-6)
+
+
+@pytest.mark.parametrize('kind', ['CGRU', 'CLSTM', 'CRNN'])
+def test_refinenet_matches_reference(golden_dir, kind):
+    fx = load(golden_dir, 'refinenet.npz')
+    cfg = OracleConfig(load_screen_content=True, refine_net_enabled=True, refine_net_rnn_type=kind)
+    rb = detweights.refinenet_batch(int(fx['B']), int(fx['T']), seed=0,
+                                    invalid_fraction=float(fx['invalid_fraction']))
+    net = detweights.fill_module(RefineNet(cfg), seed=1)
+    hf, states = sequence.refinenet_sequence(net, rb['heatmap_initial'], rb['screen_frame'])
+    want = fx[kind + '_heatmap_final']
+    got = hf.detach().numpy() if kind == 'CGRU' else hf.detach().numpy()[..., ::4, ::4]
+    np.testing.assert_allclose(got, want, atol=3e-6)
+    assert want.std() > 1e-3          # not the constant-0.5 vacuous case
+    last = states[-1]
+    np.testing.assert_allclose((last[0] if isinstance(last, tuple) else last).detach().numpy(),
+                               fx[kind + '_state_last'], atol=3e-6)
+    terms = sequence.refinenet_losses(hf, rb['heatmap_final_gt'], rb['validity'], cfg)
+    np.testing.assert_allclose(float(terms['loss_ce_heatmap_final']), float(fx[kind + '_loss_ce']), rtol=3e-6)
+    np.testing.assert_allclose(float(terms['loss_mse_heatmap_final']), float(fx[kind + '_loss_mse']), rtol=3e-6)
+    terms['full_loss'].backward()
+    params = dict(net.named_parameters())
+    dead = 0
+    for n, ref_norm in zip(fx[kind + '_grad_names'], fx[kind + '_grad_norms']):
+        p = params[str(n)]
+        if ref_norm < 0:                     # CLSTM dead-output quirk (refine_net.py:168-174)
+            assert p.grad is None
+            dead += 1
+        else:
+            np.testing.assert_allclose(float(p.grad.double().norm()), ref_norm, rtol=5e-4, atol=2e-5)  # conv biases feeding an IN have ~0 grad
+    assert dead == (2 if kind == 'CLSTM' else 0)
+
+
+def test_refinenet_without_screen_content(golden_dir):
+    fx = load(golden_dir, 'refinenet.npz')
+    cfg = OracleConfig(load_screen_content=False, refine_net_enabled=True)
+    rb = detweights.refinenet_batch(2, 3, seed=0, invalid_fraction=0.25)
+    net = detweights.fill_module(RefineNet(cfg), seed=1)
+    out = {'heatmap_initial': rb['heatmap_initial'][:, 0]}
+    with torch.no_grad():
+        net({}, out)
+    np.testing.assert_allclose(out['heatmap_final'].numpy()[..., ::4, ::4],
+                               fx['noscreen_heatmap_final'], atol=3e-6)
