@@ -1,0 +1,90 @@
+"""ctypes binding of libeve_hip.so (include/eve_hip.h).  No fallback: if the library is missing the
+product path raises -- there is no CPU implementation of the hot path in this package."""
+import ctypes
+import os
+from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_longlong, c_void_p
+
+from .build import LIB_PATH
+
+
+class EveLibraryError(RuntimeError):
+    pass
+
+
+class ConvDesc(Structure):
+    _fields_ = [(n, c_int) for n in ('dtype', 'N', 'IH', 'IW', 'Cin', 'OH', 'OW', 'Cout',
+                                     'KH', 'KW', 'stride', 'pad')]
+
+
+P = c_void_p
+I = c_int
+L = c_longlong
+F = c_float
+
+# name -> argtypes; every function returns int (0 = ok) except the two noted below
+SIGNATURES = {
+    'eve_conv2d_fwd': [POINTER(ConvDesc), P, P, P, I, P, I, P, P],
+    'eve_conv2d_dgrad': [POINTER(ConvDesc), P, P, P, P],
+    'eve_conv2d_wgrad': [POINTER(ConvDesc), P, P, P, I, P, P],
+    'eve_bias_grad': [I, L, I, P, P, P],
+    'eve_instnorm_stats': [I, I, I, I, P, F, P, P],
+    'eve_instnorm_act_fwd': [I, I, I, I, P, P, P, P, P, I, P, P],
+    'eve_instnorm_act_bwd': [I, I, I, I, P, P, P, P, P, I, P, P, P, P],
+    'eve_act_bwd': [I, L, P, P, I, P, P],
+    'eve_add': [I, L, P, P, P, P],
+    'eve_maxpool3x3s2_fwd': [I, I, I, I, I, P, P, P, P],
+    'eve_maxpool3x3s2_bwd': [I, I, I, I, I, P, P, P, P],
+    'eve_avgpool_fwd': [I, I, I, I, P, P, P],
+    'eve_avgpool_bwd': [I, I, I, I, P, P, P],
+    'eve_adaptive_maxpool_fwd': [I, I, I, I, I, I, I, P, P, P, P],
+    'eve_adaptive_maxpool_bwd': [I, I, I, I, I, I, I, P, P, P, P],
+    'eve_bilinear_fwd': [I, I, I, I, I, I, I, P, P, P],
+    'eve_bilinear_bwd': [I, I, I, I, I, I, I, P, P, P],
+    'eve_nchw_to_nhwc': [I, I, I, I, I, I, P, P, P],
+    'eve_nhwc_to_nchw': [I, I, I, I, I, I, P, P, P],
+    'eve_cast': [I, I, L, P, P, P],
+    'eve_pack_weights': [I, I, I, I, P, P, P, P],
+    'eve_gru_scan_fwd': [I, I, I, P, P, P, P, P, P, P, P],
+    'eve_gru_scan_bwd': [I, I, I, P, P, P, P, P, P, P, P, P, P],
+    'eve_cgru_gates1': [I, L, I, P, P, P, P, P],
+    'eve_cgru_gates2': [I, L, I, P, P, P, P, P, P],
+    'eve_cgru_gates2_bwd': [I, L, I, P, P, P, P, P, P, P, P],
+    'eve_cgru_gates1_bwd': [I, L, I, P, P, P, P, P, P, P],
+    'eve_clstm_gates_fwd': [I, L, I, P, P, P, P, P],
+    'eve_sumsq': [L, P, P, P],
+    'eve_adam_step': [L, P, P, P, P, P, F, F, F, F, F, F, F, I, P],
+}
+EXPORTS = sorted(list(SIGNATURES) + ['eve_abi_version', 'eve_last_error'])
+
+_lib = None
+
+
+def load(path=None):
+    """Load (once) and type the library.  Raises EveLibraryError when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = path or os.environ.get('EVE_HIP_LIB', LIB_PATH)
+    if not os.path.isfile(path):
+        raise EveLibraryError(
+            'libeve_hip.so not found at %s -- build it with `python -m eve_amd.build` '
+            '(hipcc, gfx950).  eve_amd has no CPU fallback for the hot path.' % path)
+    lib = ctypes.CDLL(path)
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.argtypes = argtypes
+        fn.restype = c_int
+    lib.eve_abi_version.argtypes = []
+    lib.eve_abi_version.restype = c_int
+    lib.eve_last_error.argtypes = []
+    lib.eve_last_error.restype = c_char_p
+    if lib.eve_abi_version() != 1:
+        raise EveLibraryError('libeve_hip.so ABI version %d, expected 1' % lib.eve_abi_version())
+    _lib = lib
+    return lib
+
+
+def check(status, lib=None):
+    if status != 0:
+        lib = lib or load()
+        raise RuntimeError('libeve_hip: ' + lib.eve_last_error().decode('utf-8', 'replace'))

@@ -1,0 +1,141 @@
+// Shared device/host helpers for the gfx950 (CDNA4, wave64) kernels of the EVE hot path.
+// Everything here is written for MI355X only: 64-lane wavefronts, MFMA 16x16 tiles,
+// 16-byte vector memory accesses, fp32 accumulation.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/eve_hip.h"
+
+namespace eve {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+
+// ---------------------------------------------------------------------------------------------
+// element types: `float` and `bf16_t` (raw 16-bit storage, round-to-nearest-even conversions)
+// ---------------------------------------------------------------------------------------------
+struct bf16_t { uint16_t v; };
+
+__device__ __forceinline__ float bf16_bits_to_f32(uint32_t bits16) {
+    return __builtin_bit_cast(float, bits16 << 16);
+}
+__device__ __forceinline__ uint32_t f32_to_bf16_bits(float f) {
+    uint32_t u = __builtin_bit_cast(uint32_t, f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40u;   // quiet NaN
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return u >> 16;
+}
+
+template <typename T> struct Elem;
+template <> struct Elem<float> {
+    static constexpr int VEC = 4;                     // elements per 16-byte vector
+    static constexpr int DT = EVE_DT_F32;
+    __device__ static __forceinline__ float ld(const float* p) { return *p; }
+    __device__ static __forceinline__ void st(float* p, float v) { *p = v; }
+    // unpack a 16-byte vector into VEC floats / pack back
+    __device__ static __forceinline__ void unpack(const uint4& q, float* f) {
+        f[0] = __builtin_bit_cast(float, q.x); f[1] = __builtin_bit_cast(float, q.y);
+        f[2] = __builtin_bit_cast(float, q.z); f[3] = __builtin_bit_cast(float, q.w);
+    }
+    __device__ static __forceinline__ uint4 pack(const float* f) {
+        return make_uint4(__builtin_bit_cast(uint32_t, f[0]), __builtin_bit_cast(uint32_t, f[1]),
+                          __builtin_bit_cast(uint32_t, f[2]), __builtin_bit_cast(uint32_t, f[3]));
+    }
+};
+template <> struct Elem<bf16_t> {
+    static constexpr int VEC = 8;
+    static constexpr int DT = EVE_DT_BF16;
+    __device__ static __forceinline__ float ld(const bf16_t* p) { return bf16_bits_to_f32(p->v); }
+    __device__ static __forceinline__ void st(bf16_t* p, float v) { p->v = (uint16_t)f32_to_bf16_bits(v); }
+    __device__ static __forceinline__ void unpack(const uint4& q, float* f) {
+        f[0] = bf16_bits_to_f32(q.x & 0xffffu); f[1] = __builtin_bit_cast(float, q.x & 0xffff0000u);
+        f[2] = bf16_bits_to_f32(q.y & 0xffffu); f[3] = __builtin_bit_cast(float, q.y & 0xffff0000u);
+        f[4] = bf16_bits_to_f32(q.z & 0xffffu); f[5] = __builtin_bit_cast(float, q.z & 0xffff0000u);
+        f[6] = bf16_bits_to_f32(q.w & 0xffffu); f[7] = __builtin_bit_cast(float, q.w & 0xffff0000u);
+    }
+    __device__ static __forceinline__ uint4 pack(const float* f) {
+        return make_uint4(f32_to_bf16_bits(f[0]) | (f32_to_bf16_bits(f[1]) << 16),
+                          f32_to_bf16_bits(f[2]) | (f32_to_bf16_bits(f[3]) << 16),
+                          f32_to_bf16_bits(f[4]) | (f32_to_bf16_bits(f[5]) << 16),
+                          f32_to_bf16_bits(f[6]) | (f32_to_bf16_bits(f[7]) << 16));
+    }
+};
+
+// ---------------------------------------------------------------------------------------------
+// activations (the set the reference uses: ReLU, LeakyReLU(0.01), SELU, tanh, sigmoid)
+// ---------------------------------------------------------------------------------------------
+#define EVE_SELU_ALPHA 1.6732632423543772f
+#define EVE_SELU_SCALE 1.0507009873554805f
+
+__device__ __forceinline__ float act_fwd(float z, int act) {
+    switch (act) {
+        case EVE_ACT_RELU:    return z > 0.f ? z : 0.f;
+        case EVE_ACT_LEAKY:   return z > 0.f ? z : 0.01f * z;
+        case EVE_ACT_SELU:    return EVE_SELU_SCALE * (z > 0.f ? z : EVE_SELU_ALPHA * (__expf(z) - 1.f));
+        case EVE_ACT_TANH:    return tanhf(z);
+        case EVE_ACT_SIGMOID: return 1.f / (1.f + __expf(-z));
+        default:              return z;
+    }
+}
+// derivative expressed through the OUTPUT y = act(z) (all five are invertible enough for that)
+__device__ __forceinline__ float act_grad_from_out(float y, int act) {
+    switch (act) {
+        case EVE_ACT_RELU:    return y > 0.f ? 1.f : 0.f;
+        case EVE_ACT_LEAKY:   return y > 0.f ? 1.f : 0.01f;
+        case EVE_ACT_SELU:    return y > 0.f ? EVE_SELU_SCALE : y + EVE_SELU_SCALE * EVE_SELU_ALPHA;
+        case EVE_ACT_TANH:    return 1.f - y * y;
+        case EVE_ACT_SIGMOID: return y * (1.f - y);
+        default:              return 1.f;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// division by a run-time constant (pixel index -> (n, y, x)); valid for dividends < 2^31
+// ---------------------------------------------------------------------------------------------
+struct FastDiv {
+    uint32_t d, mul, shr;
+};
+inline FastDiv make_fastdiv(uint32_t d) {
+    FastDiv f;
+    f.d = d;
+    if (d <= 1) { f.mul = 0; f.shr = 0; return f; }
+    uint32_t lg = 0;
+    while ((1u << lg) < d) ++lg;                  // ceil(log2 d)
+    uint32_t p = 31 + lg;
+    f.mul = (uint32_t)(((1ull << p) + d - 1) / d);
+    f.shr = p - 32;
+    return f;
+}
+__device__ __forceinline__ uint32_t fd_div(uint32_t x, const FastDiv& f) {
+    return f.d <= 1 ? x : (__umulhi(x, f.mul) >> f.shr);
+}
+
+// ---------------------------------------------------------------------------------------------
+// wave64 reductions
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// XCD-aware, bijective block-id remap (8 XCDs, block b is dispatched to XCD b % 8): gives each XCD
+// a contiguous run of logical tiles so neighbouring tiles share that XCD's L2.
+__device__ __forceinline__ uint32_t xcd_remap(uint32_t bid, uint32_t nblk) {
+    const uint32_t q = nblk >> 3, r = nblk & 7u, xcd = bid & 7u, idx = bid >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
+}  // namespace eve
+
+#define EVE_CHECK_LAUNCH()                                             \
+    do {                                                               \
+        hipError_t e__ = hipGetLastError();                            \
+        if (e__ != hipSuccess) return eve::set_error(e__, __func__);   \
+    } while (0)
+
+namespace eve {
+int set_error(hipError_t e, const char* where);
+int set_error_msg(const char* msg);
+}  // namespace eve

@@ -1,0 +1,588 @@
+// Implicit-GEMM convolution on MFMA for gfx950: forward, data gradient and weight gradient.
+//
+// One gather formulation serves forward and dgrad:
+//     out[n, oy, ox, co] = sum_{kh,kw,c} src[n, sy, sx, c] * W[co][(kh,kw,c)]
+//     sy = (oy*o_mul + kh*k_mul + off) / div     (tap skipped unless divisible and in range)
+// forward: o_mul = stride, k_mul = 1, off = -pad, div = 1       (src = x,  W = [Cout][KH][KW][Cin])
+// dgrad  : o_mul = 1, k_mul = -1, off = +pad, div = stride      (src = dy, W = [Cin][KH][KW][Cout])
+//
+// Tiling (both dtypes share it because everything is expressed in 16-byte vectors):
+//   workgroup = 256 threads = 4 waves (2 x 2), tile 128 pixels x (64|128) output channels,
+//   K step = 8 vectors = 128 bytes per row (64 bf16 / 32 f32), LDS double-buffered, one barrier per
+//   K step, next tile's global loads in flight (in registers) while the current tile is multiplied.
+//   LDS rows are 128 B with the 16-B slot index XOR-swizzled by (row & 7): ds_read_b128 fragment reads
+//   and ds_write_b128 staging writes are both bank-conflict free.
+//   MFMA: v_mfma_f32_16x16x32_bf16 (one per 16-B fragment pair) or 4 x v_mfma_f32_16x16x4_f32 with the
+//   K permutation "MFMA s takes element s of every lane group's 4-float vector" (a sum is order-free).
+//   Operands are swapped (A = weights, B = pixels) so a lane ends up with 4 CONSECUTIVE output
+//   channels of one pixel -> 8/16-byte NHWC stores.
+//
+// The optional prologue x' = act(x*scale[n,c] + shift[n,c]) is applied between the global load and the
+// LDS write, i.e. the consumer normalises InstanceNorm'ed inputs on the fly (padding stays exactly 0).
+#include "common.h"
+
+namespace eve {
+
+struct GatherParams {
+    int N, IH, IW, Cin;     // source tensor [N][IH][IW][Cin]
+    int OH, OW, Cout;       // output tensor [N][OH][OW][Cout]
+    int KH, KW;
+    int o_mul, k_mul, off, div;
+    int K;                  // KH*KW*Cin
+    uint32_t M;             // N*OH*OW
+    FastDiv fd_ohw, fd_ow, fd_cin, fd_kw;
+};
+
+template <typename T>
+__device__ __forceinline__ uint4 prologue_vec(uint4 q, const float* __restrict__ ssp, int act) {
+    constexpr int VEC = Elem<T>::VEC;
+    float f[VEC];
+    Elem<T>::unpack(q, f);
+    const float4* s4 = reinterpret_cast<const float4*>(ssp);   // (scale, shift) pairs, VEC of them
+#pragma unroll
+    for (int e = 0; e < VEC / 2; ++e) {
+        float4 s = s4[e];
+        f[2 * e] = act_fwd(f[2 * e] * s.x + s.y, act);
+        f[2 * e + 1] = act_fwd(f[2 * e + 1] * s.z + s.w, act);
+    }
+    return Elem<T>::pack(f);
+}
+
+template <typename T> struct Mma;
+template <> struct Mma<bf16_t> {
+    // acc(16 x 16) += A(16 rows x 32 k) * B(32 k x 16 cols); a/b are the lane's 8 consecutive k
+    __device__ static __forceinline__ void run(f32x4_t& acc, const uint4& a, const uint4& b) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a),
+                                                      __builtin_bit_cast(bf16x8_t, b), acc, 0, 0, 0);
+    }
+};
+template <> struct Mma<float> {
+    __device__ static __forceinline__ void run(f32x4_t& acc, const uint4& a, const uint4& b) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__builtin_bit_cast(float, a.x), __builtin_bit_cast(float, b.x), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__builtin_bit_cast(float, a.y), __builtin_bit_cast(float, b.y), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__builtin_bit_cast(float, a.z), __builtin_bit_cast(float, b.z), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__builtin_bit_cast(float, a.w), __builtin_bit_cast(float, b.w), acc, 0, 0, 0);
+    }
+};
+
+// =================================================================================================
+// forward / dgrad kernel
+// =================================================================================================
+template <typename T, int NT, bool PRO>
+__global__ __launch_bounds__(256) void igemm_kernel(const GatherParams p, const T* __restrict__ src,
+                                                    const T* __restrict__ w,
+                                                    const float* __restrict__ bias,
+                                                    const float* __restrict__ ss, const int pro_act,
+                                                    const int epi_act, T* __restrict__ out) {
+    constexpr int VEC = Elem<T>::VEC;
+    constexpr int BM = 128, BN = 32 * NT, BK = 8 * VEC;
+    __shared__ uint4 lds[2 * (BM + BN) * 8];
+
+    const int tid = threadIdx.x;
+    const uint32_t tiles_n = (p.Cout + BN - 1) / BN;
+    const uint32_t lid = xcd_remap(blockIdx.x, gridDim.x);
+    const uint32_t m0 = (lid / tiles_n) * BM;
+    const uint32_t n0 = (lid % tiles_n) * BN;
+
+    // ---- per-thread staging coordinates (fixed across the K loop) ----
+    const int v = tid & 7;       // 16-byte slot inside the 128-byte K row
+    const int r0 = tid >> 3;     // 0..31
+    int a_y0[4], a_x0[4], a_pix[4], a_n[4];
+    bool a_ok[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const uint32_t m = m0 + r0 + 32 * j;
+        a_ok[j] = m < p.M;
+        const uint32_t mm = a_ok[j] ? m : 0;
+        const uint32_t n = fd_div(mm, p.fd_ohw);
+        const uint32_t rem = mm - n * (uint32_t)(p.OH * p.OW);
+        const uint32_t oy = fd_div(rem, p.fd_ow);
+        const uint32_t ox = rem - oy * (uint32_t)p.OW;
+        a_y0[j] = (int)oy * p.o_mul + p.off;
+        a_x0[j] = (int)ox * p.o_mul + p.off;
+        a_pix[j] = (int)n * p.IH * p.IW;
+        a_n[j] = (int)n;
+    }
+
+    uint4 ra[4], rb[NT];
+
+    auto load_tile = [&](int kt) {
+        const uint32_t kvec = (uint32_t)kt * BK + (uint32_t)v * VEC;
+        const bool kvalid = kvec < (uint32_t)p.K;
+        const uint32_t tap = fd_div(kvec, p.fd_cin);
+        const int ci = (int)(kvec - tap * (uint32_t)p.Cin);
+        const uint32_t kh = fd_div(tap, p.fd_kw);
+        const int kw = (int)(tap - kh * (uint32_t)p.KW);
+        const int dy = (int)kh * p.k_mul, dx = kw * p.k_mul;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int sy = a_y0[j] + dy, sx = a_x0[j] + dx;
+            bool ok = a_ok[j] && kvalid && sy >= 0 && sx >= 0;
+            if (p.div > 1) {
+                ok = ok && (sy % p.div == 0) && (sx % p.div == 0);
+                sy /= p.div;
+                sx /= p.div;
+            }
+            ok = ok && sy < p.IH && sx < p.IW;
+            uint4 q = make_uint4(0, 0, 0, 0);
+            if (ok) {
+                const size_t e = ((size_t)(a_pix[j] + sy * p.IW + sx)) * (size_t)p.Cin + (size_t)ci;
+                q = *reinterpret_cast<const uint4*>(src + e);
+                if (PRO) q = prologue_vec<T>(q, ss + ((size_t)a_n[j] * p.Cin + ci) * 2, pro_act);
+            }
+            ra[j] = q;
+        }
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const uint32_t co = n0 + r0 + 32 * j;
+            uint4 q = make_uint4(0, 0, 0, 0);
+            if (kvalid && co < (uint32_t)p.Cout)
+                q = *reinterpret_cast<const uint4*>(w + (size_t)co * p.K + kvec);
+            rb[j] = q;
+        }
+    };
+    auto store_tile = [&](int buf) {
+        uint4* base = lds + buf * (BM + BN) * 8;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int row = r0 + 32 * j;
+            base[row * 8 + (v ^ (row & 7))] = ra[j];
+        }
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int row = r0 + 32 * j;
+            base[BM * 8 + row * 8 + (v ^ (row & 7))] = rb[j];
+        }
+    };
+
+    const int lane = tid & 63, wv = tid >> 6;
+    const int wm = wv >> 1, wn = wv & 1;
+    const int li = lane & 15, lg = lane >> 4;
+
+    f32x4_t acc[4][NT];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < NT; ++b) acc[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    const int nk = (p.K + BK - 1) / BK;
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        const bool more = kt + 1 < nk;
+        if (more) load_tile(kt + 1);
+        const uint4* la = lds + cur * (BM + BN) * 8;
+        const uint4* lb = la + BM * 8;
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const int vc = c * 4 + lg;
+            uint4 fx[4], fw[NT];
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                const int row = wm * 64 + mt * 16 + li;
+                fx[mt] = la[row * 8 + (vc ^ (row & 7))];
+            }
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int row = wn * 16 * NT + nt * 16 + li;
+                fw[nt] = lb[row * 8 + (vc ^ (row & 7))];
+            }
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) Mma<T>::run(acc[mt][nt], fw[nt], fx[mt]);
+        }
+        if (more) store_tile(cur ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: lane holds channels co..co+3 (rows of D) of pixel m (column of D) ----
+    const bool vec_ok = (p.Cout & 3) == 0;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const uint32_t co = n0 + wn * 16 * NT + nt * 16 + lg * 4;
+        float bv[4] = {0.f, 0.f, 0.f, 0.f};
+        if (bias) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (co + r < (uint32_t)p.Cout) bv[r] = bias[co + r];
+        }
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            const uint32_t m = m0 + wm * 64 + mt * 16 + li;
+            if (m >= p.M || co >= (uint32_t)p.Cout) continue;
+            float o[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] = act_fwd(acc[mt][nt][r] + bv[r], epi_act);
+            T* dst = out + (size_t)m * p.Cout + co;
+            if (vec_ok) {
+                if (sizeof(T) == 4) {
+                    *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
+                } else {
+                    uint2 pk;
+                    pk.x = f32_to_bf16_bits(o[0]) | (f32_to_bf16_bits(o[1]) << 16);
+                    pk.y = f32_to_bf16_bits(o[2]) | (f32_to_bf16_bits(o[3]) << 16);
+                    *reinterpret_cast<uint2*>(dst) = pk;
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (co + r < (uint32_t)p.Cout) Elem<T>::st(dst + r, o[r]);
+            }
+        }
+    }
+}
+
+// =================================================================================================
+// weight-gradient kernel:  dw[co][k] += sum_m dy[m][co] * x'[m][k]   (k = (kh,kw,ci))
+// The reduction index m is the strided one for both operands, so tiles are staged in LDS as
+// [row][channel word] with one 32-bit word per (row, channel): for bf16 a row is a PAIR of pixels
+// (even pixel in the low half-word) so 4 words from rows 4g..4g+3 are exactly a lane's 8-deep MFMA
+// fragment; for f32 a row is one pixel and the 4 words feed the 4 K-permuted 16x16x4 MFMAs.
+// Fragment reads are 4 x ds_read_b32 (row stride = tile width + 4 words -> conflict free).
+// Grid: (k tiles of 128) x (co tiles of 32*MT) x (splits of the pixel range); float atomics at the end.
+// =================================================================================================
+template <typename T, int MT, bool PRO>
+__global__ __launch_bounds__(256) void wgrad_kernel(const GatherParams p, const T* __restrict__ x,
+                                                    const T* __restrict__ dy,
+                                                    const float* __restrict__ ss, const int pro_act,
+                                                    float* __restrict__ dw, const uint32_t rows_per_split) {
+    constexpr int VEC = Elem<T>::VEC;          // channels per 16-byte global vector
+    constexpr int G = (sizeof(T) == 2) ? 2 : 1;  // pixels per LDS row
+    constexpr int BCO = 32 * MT, BKK = 128;
+    constexpr int PS = BCO + 4, QS = BKK + 4;  // row strides in words
+    constexpr int ROWS = 32;                   // LDS rows per step  (= 32*G pixels)
+    constexpr int P_ITEMS = ROWS * (BCO / VEC) / 256;   // bf16: MT/2 ... computed below
+    constexpr int Q_ITEMS = ROWS * (BKK / VEC) / 256;
+    static_assert(ROWS * (BCO / VEC) % 256 == 0 && ROWS * (BKK / VEC) % 256 == 0, "tile/threads");
+    __shared__ uint32_t lds[2 * ROWS * (PS + QS)];
+
+    const int tid = threadIdx.x;
+    const uint32_t k0 = blockIdx.x * BKK;
+    const uint32_t co0 = blockIdx.y * BCO;
+    const uint32_t m_begin = blockIdx.z * rows_per_split;
+    const uint32_t m_end = min(p.M, m_begin + rows_per_split);
+    const uint32_t ohw = (uint32_t)(p.OH * p.OW);
+
+    // ---- per-item constants ----
+    int q_row[Q_ITEMS], q_col[Q_ITEMS], q_ci[Q_ITEMS], q_dy[Q_ITEMS], q_dx[Q_ITEMS];
+    bool q_kvalid[Q_ITEMS];
+#pragma unroll
+    for (int j = 0; j < Q_ITEMS; ++j) {
+        const int it = tid + 256 * j;
+        q_row[j] = it / (BKK / VEC);
+        q_col[j] = (it % (BKK / VEC)) * VEC;
+        const uint32_t kvec = k0 + q_col[j];
+        q_kvalid[j] = kvec < (uint32_t)p.K;
+        const uint32_t tap = fd_div(kvec, p.fd_cin);
+        q_ci[j] = (int)(kvec - tap * (uint32_t)p.Cin);
+        const uint32_t kh = fd_div(tap, p.fd_kw);
+        q_dy[j] = (int)kh * p.k_mul + p.off;
+        q_dx[j] = (int)(tap - kh * (uint32_t)p.KW) * p.k_mul + p.off;
+    }
+    int p_row[P_ITEMS], p_col[P_ITEMS];
+#pragma unroll
+    for (int j = 0; j < P_ITEMS; ++j) {
+        const int it = tid + 256 * j;
+        p_row[j] = it / (BCO / VEC);
+        p_col[j] = (it % (BCO / VEC)) * VEC;
+    }
+
+    uint4 rq[Q_ITEMS][G], rp[P_ITEMS][G];
+
+    auto load_tile = [&](uint32_t mbase) {
+#pragma unroll
+        for (int j = 0; j < Q_ITEMS; ++j) {
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                const uint32_t m = mbase + q_row[j] * G + g;
+                uint4 q = make_uint4(0, 0, 0, 0);
+                if (m < m_end && q_kvalid[j]) {
+                    const uint32_t n = fd_div(m, p.fd_ohw);
+                    const uint32_t rem = m - n * ohw;
+                    const uint32_t oy = fd_div(rem, p.fd_ow);
+                    const uint32_t ox = rem - oy * (uint32_t)p.OW;
+                    const int sy = (int)oy * p.o_mul + q_dy[j];
+                    const int sx = (int)ox * p.o_mul + q_dx[j];
+                    if (sy >= 0 && sy < p.IH && sx >= 0 && sx < p.IW) {
+                        const size_t e = ((size_t)n * p.IH * p.IW + (size_t)(sy * p.IW + sx)) * p.Cin + q_ci[j];
+                        q = *reinterpret_cast<const uint4*>(x + e);
+                        if (PRO) q = prologue_vec<T>(q, ss + ((size_t)n * p.Cin + q_ci[j]) * 2, pro_act);
+                    }
+                }
+                rq[j][g] = q;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < P_ITEMS; ++j) {
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                const uint32_t m = mbase + p_row[j] * G + g;
+                const uint32_t co = co0 + p_col[j];
+                uint4 q = make_uint4(0, 0, 0, 0);
+                if (m < m_end && co < (uint32_t)p.Cout)
+                    q = *reinterpret_cast<const uint4*>(dy + (size_t)m * p.Cout + co);
+                rp[j][g] = q;
+            }
+        }
+    };
+    // write a (row, 8|4 channels) item as words; bf16: interleave the even/odd pixel
+    auto put = [&](uint32_t* dst, const uint4* r) {
+        if (G == 2) {
+            const uint4 a = r[0], b = r[G - 1];
+            uint4 lo, hi;
+            lo.x = (a.x & 0xffffu) | (b.x << 16);  lo.y = (a.x >> 16) | (b.x & 0xffff0000u);
+            lo.z = (a.y & 0xffffu) | (b.y << 16);  lo.w = (a.y >> 16) | (b.y & 0xffff0000u);
+            hi.x = (a.z & 0xffffu) | (b.z << 16);  hi.y = (a.z >> 16) | (b.z & 0xffff0000u);
+            hi.z = (a.w & 0xffffu) | (b.w << 16);  hi.w = (a.w >> 16) | (b.w & 0xffff0000u);
+            reinterpret_cast<uint4*>(dst)[0] = lo;
+            reinterpret_cast<uint4*>(dst)[1] = hi;
+        } else {
+            reinterpret_cast<uint4*>(dst)[0] = r[0];
+        }
+    };
+    auto store_tile = [&](int buf) {
+        uint32_t* pb = lds + buf * ROWS * (PS + QS);
+        uint32_t* qb = pb + ROWS * PS;
+#pragma unroll
+        for (int j = 0; j < P_ITEMS; ++j) put(pb + p_row[j] * PS + p_col[j], rp[j]);
+#pragma unroll
+        for (int j = 0; j < Q_ITEMS; ++j) put(qb + q_row[j] * QS + q_col[j], rq[j]);
+    };
+
+    const int lane = tid & 63, wv = tid >> 6;
+    const int wm = wv >> 1, wn = wv & 1;
+    const int li = lane & 15, lg = lane >> 4;
+
+    f32x4_t acc[MT][4];
+#pragma unroll
+    for (int a = 0; a < MT; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    constexpr uint32_t STEP = ROWS * G;    // pixels per step
+    if (m_begin < m_end) {
+        const int nsteps = (int)((m_end - m_begin + STEP - 1) / STEP);
+        load_tile(m_begin);
+        store_tile(0);
+        __syncthreads();
+        for (int st = 0; st < nsteps; ++st) {
+            const int cur = st & 1;
+            const bool more = st + 1 < nsteps;
+            if (more) load_tile(m_begin + (uint32_t)(st + 1) * STEP);
+            const uint32_t* pb = lds + cur * ROWS * (PS + QS);
+            const uint32_t* qb = pb + ROWS * PS;
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const int rbase = c * 16 + lg * 4;
+                uint4 fp[MT], fq[4];
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    const uint32_t* s = pb + rbase * PS + wm * 16 * MT + mt * 16 + li;
+                    fp[mt] = make_uint4(s[0], s[PS], s[2 * PS], s[3 * PS]);
+                }
+#pragma unroll
+                for (int kt = 0; kt < 4; ++kt) {
+                    const uint32_t* s = qb + rbase * QS + wn * 64 + kt * 16 + li;
+                    fq[kt] = make_uint4(s[0], s[QS], s[2 * QS], s[3 * QS]);
+                }
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int kt = 0; kt < 4; ++kt) Mma<T>::run(acc[mt][kt], fp[mt], fq[kt]);
+            }
+            if (more) store_tile(cur ^ 1);
+            __syncthreads();
+        }
+    }
+    // D rows = co (4*lg + r), cols = k (li)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+            const uint32_t k = k0 + wn * 64 + kt * 16 + li;
+            if (k >= (uint32_t)p.K) continue;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const uint32_t co = co0 + wm * 16 * MT + mt * 16 + lg * 4 + r;
+                if (co < (uint32_t)p.Cout) atomicAdd(dw + (size_t)co * p.K + k, acc[mt][kt][r]);
+            }
+        }
+}
+
+// column sums of dy[M][C] accumulated into db[C]
+template <typename T>
+__global__ __launch_bounds__(256) void bias_grad_kernel(const T* __restrict__ dy, float* __restrict__ db,
+                                                        long long M, int C, long long rows_per_block) {
+    constexpr int VEC = Elem<T>::VEC;
+    const int cvecs = C / VEC;                 // <= 256 assumed by the launcher
+    const int phases = 256 / cvecs;
+    const int tid = threadIdx.x;
+    const int cv = tid % cvecs, ph = tid / cvecs;
+    float s[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) s[e] = 0.f;
+    const long long r_begin = (long long)blockIdx.x * rows_per_block;
+    const long long r_end = min(M, r_begin + rows_per_block);
+    if (ph < phases) {
+        for (long long r = r_begin + ph; r < r_end; r += phases) {
+            float f[VEC];
+            Elem<T>::unpack(*reinterpret_cast<const uint4*>(dy + r * C + cv * VEC), f);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) s[e] += f[e];
+        }
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) atomicAdd(db + cv * VEC + e, s[e]);
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
+// host side
+// -------------------------------------------------------------------------------------------------
+static int check_desc(const eve_conv_desc* d, int vec) {
+    if (!d) return set_error_msg("conv: null descriptor");
+    if (d->dtype != EVE_DT_F32 && d->dtype != EVE_DT_BF16) return set_error_msg("conv: bad dtype");
+    if (d->N <= 0 || d->IH <= 0 || d->IW <= 0 || d->OH <= 0 || d->OW <= 0 || d->Cin <= 0 || d->Cout <= 0 ||
+        d->KH <= 0 || d->KW <= 0 || d->stride <= 0 || d->pad < 0)
+        return set_error_msg("conv: non-positive dimension");
+    if (d->OH != (d->IH + 2 * d->pad - d->KH) / d->stride + 1 || d->OW != (d->IW + 2 * d->pad - d->KW) / d->stride + 1)
+        return set_error_msg("conv: OH/OW inconsistent with IH/IW, kernel, stride, pad");
+    if (d->Cin % vec) return set_error_msg("conv: Cin must be a multiple of the 16-byte vector (4 f32 / 8 bf16)");
+    if ((long long)d->N * d->OH * d->OW >= (1ll << 31) || (long long)d->N * d->IH * d->IW >= (1ll << 31))
+        return set_error_msg("conv: more than 2^31 pixels");
+    return 0;
+}
+
+static GatherParams fwd_params(const eve_conv_desc* d) {
+    GatherParams p;
+    p.N = d->N; p.IH = d->IH; p.IW = d->IW; p.Cin = d->Cin;
+    p.OH = d->OH; p.OW = d->OW; p.Cout = d->Cout; p.KH = d->KH; p.KW = d->KW;
+    p.o_mul = d->stride; p.k_mul = 1; p.off = -d->pad; p.div = 1;
+    p.K = d->KH * d->KW * d->Cin;
+    p.M = (uint32_t)((long long)d->N * d->OH * d->OW);
+    p.fd_ohw = make_fastdiv(d->OH * d->OW); p.fd_ow = make_fastdiv(d->OW);
+    p.fd_cin = make_fastdiv(d->Cin); p.fd_kw = make_fastdiv(d->KW);
+    return p;
+}
+static GatherParams dgrad_params(const eve_conv_desc* d) {
+    GatherParams p;   // source = dy [N][OH][OW][Cout], output = dx [N][IH][IW][Cin]
+    p.N = d->N; p.IH = d->OH; p.IW = d->OW; p.Cin = d->Cout;
+    p.OH = d->IH; p.OW = d->IW; p.Cout = d->Cin; p.KH = d->KH; p.KW = d->KW;
+    p.o_mul = 1; p.k_mul = -1; p.off = d->pad; p.div = d->stride;
+    p.K = d->KH * d->KW * d->Cout;
+    p.M = (uint32_t)((long long)d->N * d->IH * d->IW);
+    p.fd_ohw = make_fastdiv(d->IH * d->IW); p.fd_ow = make_fastdiv(d->IW);
+    p.fd_cin = make_fastdiv(d->Cout); p.fd_kw = make_fastdiv(d->KW);
+    return p;
+}
+
+template <typename T>
+static int launch_igemm(const GatherParams& p, const void* src, const void* w, const float* bias,
+                        const float* ss, int pro_act, int epi_act, void* out, hipStream_t s) {
+    const bool wide = p.Cout > 64;
+    const uint32_t bn = wide ? 128 : 64;
+    const uint32_t tiles = ((p.M + 127) / 128) * ((p.Cout + bn - 1) / bn);
+    dim3 grid(tiles), block(256);
+    const T* a = (const T*)src; const T* b = (const T*)w; T* o = (T*)out;
+    if (wide) {
+        if (ss) hipLaunchKernelGGL((igemm_kernel<T, 4, true>), grid, block, 0, s, p, a, b, bias, ss, pro_act, epi_act, o);
+        else    hipLaunchKernelGGL((igemm_kernel<T, 4, false>), grid, block, 0, s, p, a, b, bias, ss, pro_act, epi_act, o);
+    } else {
+        if (ss) hipLaunchKernelGGL((igemm_kernel<T, 2, true>), grid, block, 0, s, p, a, b, bias, ss, pro_act, epi_act, o);
+        else    hipLaunchKernelGGL((igemm_kernel<T, 2, false>), grid, block, 0, s, p, a, b, bias, ss, pro_act, epi_act, o);
+    }
+    return 0;
+}
+
+template <typename T>
+static int launch_wgrad(const GatherParams& p, const void* x, const void* dy, const float* ss, int pro_act,
+                        float* dw, hipStream_t s) {
+    const bool wide = p.Cout > 64;
+    const uint32_t bco = wide ? 128 : 64;
+    const uint32_t tk = (p.K + 127) / 128, tc = (p.Cout + bco - 1) / bco;
+    // enough splits of the pixel range for ~4 workgroups per CU, each a multiple of 64 pixels
+    uint32_t want = (1024 + tk * tc - 1) / (tk * tc);
+    uint32_t max_splits = (p.M + 255) / 256;
+    uint32_t splits = want < 1 ? 1 : (want > max_splits ? max_splits : want);
+    if (splits < 1) splits = 1;
+    if (splits > 65535) splits = 65535;
+    uint32_t rows = (p.M + splits - 1) / splits;
+    rows = (rows + 63) / 64 * 64;
+    splits = (p.M + rows - 1) / rows;
+    dim3 grid(tk, tc, splits), block(256);
+    const T* a = (const T*)x; const T* b = (const T*)dy;
+    if (wide) {
+        if (ss) hipLaunchKernelGGL((wgrad_kernel<T, 4, true>), grid, block, 0, s, p, a, b, ss, pro_act, dw, rows);
+        else    hipLaunchKernelGGL((wgrad_kernel<T, 4, false>), grid, block, 0, s, p, a, b, ss, pro_act, dw, rows);
+    } else {
+        if (ss) hipLaunchKernelGGL((wgrad_kernel<T, 2, true>), grid, block, 0, s, p, a, b, ss, pro_act, dw, rows);
+        else    hipLaunchKernelGGL((wgrad_kernel<T, 2, false>), grid, block, 0, s, p, a, b, ss, pro_act, dw, rows);
+    }
+    return 0;
+}
+
+}  // namespace eve
+
+using namespace eve;
+
+extern "C" int eve_conv2d_fwd(const eve_conv_desc* d, const void* x, const void* w_ohwi, const float* bias,
+                              int epi_act, const float* in_scale_shift, int pro_act, void* y,
+                              eve_stream_t stream) {
+    const int vec = (d && d->dtype == EVE_DT_BF16) ? 8 : 4;
+    if (int e = check_desc(d, vec)) return e;
+    if (!x || !w_ohwi || !y) return set_error_msg("conv2d_fwd: null pointer");
+    GatherParams p = fwd_params(d);
+    hipStream_t s = (hipStream_t)stream;
+    if (d->dtype == EVE_DT_BF16) launch_igemm<bf16_t>(p, x, w_ohwi, bias, in_scale_shift, pro_act, epi_act, y, s);
+    else                         launch_igemm<float>(p, x, w_ohwi, bias, in_scale_shift, pro_act, epi_act, y, s);
+    EVE_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int eve_conv2d_dgrad(const eve_conv_desc* d, const void* dy, const void* w_ihwo, void* dx,
+                                eve_stream_t stream) {
+    const int vec = (d && d->dtype == EVE_DT_BF16) ? 8 : 4;
+    if (int e = check_desc(d, vec)) return e;
+    if (d->Cout % vec) return set_error_msg("conv2d_dgrad: Cout must be a multiple of the 16-byte vector");
+    if (!dy || !w_ihwo || !dx) return set_error_msg("conv2d_dgrad: null pointer");
+    GatherParams p = dgrad_params(d);
+    hipStream_t s = (hipStream_t)stream;
+    if (d->dtype == EVE_DT_BF16) launch_igemm<bf16_t>(p, dy, w_ihwo, nullptr, nullptr, 0, 0, dx, s);
+    else                         launch_igemm<float>(p, dy, w_ihwo, nullptr, nullptr, 0, 0, dx, s);
+    EVE_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int eve_conv2d_wgrad(const eve_conv_desc* d, const void* x, const void* dy,
+                                const float* in_scale_shift, int pro_act, float* dw_ohwi,
+                                eve_stream_t stream) {
+    const int vec = (d && d->dtype == EVE_DT_BF16) ? 8 : 4;
+    if (int e = check_desc(d, vec)) return e;
+    if (d->Cout % vec) return set_error_msg("conv2d_wgrad: Cout must be a multiple of the 16-byte vector");
+    if (!x || !dy || !dw_ohwi) return set_error_msg("conv2d_wgrad: null pointer");
+    GatherParams p = fwd_params(d);
+    hipStream_t s = (hipStream_t)stream;
+    if (d->dtype == EVE_DT_BF16) launch_wgrad<bf16_t>(p, x, dy, in_scale_shift, pro_act, dw_ohwi, s);
+    else                         launch_wgrad<float>(p, x, dy, in_scale_shift, pro_act, dw_ohwi, s);
+    EVE_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int eve_bias_grad(int dtype, long long M, int C, const void* dy, float* db, eve_stream_t stream) {
+    const int vec = dtype == EVE_DT_BF16 ? 8 : 4;
+    if (M <= 0 || C <= 0 || C % vec || C / vec > 256) return set_error_msg("bias_grad: bad shape");
+    if (!dy || !db) return set_error_msg("bias_grad: null pointer");
+    long long blocks = (M + 2047) / 2048;
+    if (blocks > 1024) blocks = 1024;
+    const long long rows = (M + blocks - 1) / blocks;
+    blocks = (M + rows - 1) / rows;
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == EVE_DT_BF16)
+        hipLaunchKernelGGL(bias_grad_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, s, (const bf16_t*)dy, db, M, C, rows);
+    else
+        hipLaunchKernelGGL(bias_grad_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, s, (const float*)dy, db, M, C, rows);
+    EVE_CHECK_LAUNCH();
+    return 0;
+}

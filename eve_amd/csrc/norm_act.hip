@@ -1,0 +1,311 @@
+// InstanceNorm statistics / apply / backward and small element-wise kernels, NHWC, gfx950.
+// All of these are HBM-bound streaming kernels: 16-byte vector accesses, one workgroup per image
+// plane-set (n) for the reductions so the second pass over the plane hits L2.
+#include "common.h"
+
+namespace eve {
+
+// ---- statistics: two passes (mean, then centred second moment), one workgroup per image ----
+template <typename T>
+__global__ __launch_bounds__(256) void in_stats_kernel(const T* __restrict__ x, float* __restrict__ mr,
+                                                       int HW, int C, float eps) {
+    constexpr int VEC = Elem<T>::VEC;
+    __shared__ float sh[256 * VEC];
+    __shared__ float sh_mean[1024];
+    const int cvecs = C / VEC, phases = 256 / cvecs;
+    const int tid = threadIdx.x, cv = tid % cvecs, ph = tid / cvecs;
+    const bool act = ph < phases;
+    const T* xp = x + (size_t)blockIdx.x * HW * C + cv * VEC;
+    float s[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) s[e] = 0.f;
+    if (act)
+        for (int px = ph; px < HW; px += phases) {
+            float f[VEC];
+            Elem<T>::unpack(*reinterpret_cast<const uint4*>(xp + (size_t)px * C), f);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) s[e] += f[e];
+        }
+    if (!act) { for (int e = 0; e < VEC; ++e) s[e] = 0.f; }
+    // inactive threads (ph >= phases) still take part in the barriers with a dummy slot
+    const int phc = act ? ph : 0, cvc = act ? cv : 0;
+    if (act) {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) sh[(phc * cvecs + cvc) * VEC + e] = s[e];
+    }
+    __syncthreads();
+    if (act && ph == 0) {
+        for (int q = 1; q < phases; ++q)
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) s[e] += sh[(q * cvecs + cv) * VEC + e];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) sh_mean[cv * VEC + e] = s[e] / (float)HW;
+    }
+    __syncthreads();
+    float mean[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) { mean[e] = sh_mean[cvc * VEC + e]; s[e] = 0.f; }
+    if (act)
+        for (int px = ph; px < HW; px += phases) {
+            float f[VEC];
+            Elem<T>::unpack(*reinterpret_cast<const uint4*>(xp + (size_t)px * C), f);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) { const float d = f[e] - mean[e]; s[e] += d * d; }
+        }
+    if (act) {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) sh[(phc * cvecs + cvc) * VEC + e] = s[e];
+    }
+    __syncthreads();
+    if (act && ph == 0) {
+        for (int q = 1; q < phases; ++q)
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) s[e] += sh[(q * cvecs + cv) * VEC + e];
+        float* o = mr + ((size_t)blockIdx.x * C + cv * VEC) * 2;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            o[2 * e] = mean[e];
+            o[2 * e + 1] = rsqrtf(s[e] / (float)HW + eps);
+        }
+    }
+}
+
+// ---- y = act(gamma*(x-mean)*rstd + beta + res) ----
+template <typename T>
+__global__ __launch_bounds__(256) void in_act_fwd_kernel(const T* __restrict__ x, const float* __restrict__ mr,
+                                                         const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta,
+                                                         const T* __restrict__ res, int act,
+                                                         T* __restrict__ y, int HW, int C, long long nvec) {
+    constexpr int VEC = Elem<T>::VEC;
+    const int cvecs = C / VEC;
+    const long long per_img = (long long)HW * cvecs;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (long long)gridDim.x * 256) {
+        const long long n = i / per_img;
+        const int cv = (int)(i % cvecs);
+        const float* m = mr + ((size_t)n * C + cv * VEC) * 2;
+        float f[VEC], r[VEC];
+        Elem<T>::unpack(reinterpret_cast<const uint4*>(x)[i], f);
+        if (res) Elem<T>::unpack(reinterpret_cast<const uint4*>(res)[i], r);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            const int c = cv * VEC + e;
+            float a = m[2 * e + 1], b = -m[2 * e] * a;
+            if (gamma) { a *= gamma[c]; b = b * gamma[c] + beta[c]; }
+            float z = f[e] * a + b;
+            if (res) z += r[e];
+            f[e] = act_fwd(z, act);
+        }
+        reinterpret_cast<uint4*>(y)[i] = Elem<T>::pack(f);
+    }
+}
+
+// ---- backward: one workgroup per image; pass 1 reduces (sum g, sum g*xhat), pass 2 writes dx ----
+template <typename T>
+__global__ __launch_bounds__(256) void in_act_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ y,
+                                                         const T* __restrict__ x, const float* __restrict__ mr,
+                                                         const float* __restrict__ gamma, int act,
+                                                         T* __restrict__ dx, T* __restrict__ dres,
+                                                         float* __restrict__ sums, int HW, int C) {
+    constexpr int VEC = Elem<T>::VEC;
+    __shared__ float sh[2 * 256 * VEC];
+    __shared__ float sh_tot[2 * 1024];
+    const int cvecs = C / VEC, phases = 256 / cvecs;
+    const int tid = threadIdx.x, cv = tid % cvecs, ph = tid / cvecs;
+    const bool on = ph < phases;
+    const int cvc = on ? cv : 0;
+    const size_t base = (size_t)blockIdx.x * HW * C + cvc * VEC;
+    float mean[VEC], rstd[VEC];
+    {
+        const float* m = mr + ((size_t)blockIdx.x * C + cvc * VEC) * 2;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) { mean[e] = m[2 * e]; rstd[e] = m[2 * e + 1]; }
+    }
+    float s1[VEC], s2[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
+    if (on)
+        for (int px = ph; px < HW; px += phases) {
+            const size_t o = base + (size_t)px * C;
+            float g[VEC], yy[VEC], xx[VEC];
+            Elem<T>::unpack(*reinterpret_cast<const uint4*>(dy + o), g);
+            Elem<T>::unpack(*reinterpret_cast<const uint4*>(x + o), xx);
+            if (act != EVE_ACT_NONE) {
+                Elem<T>::unpack(*reinterpret_cast<const uint4*>(y + o), yy);
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) g[e] *= act_grad_from_out(yy[e], act);
+            }
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                s1[e] += g[e];
+                s2[e] += g[e] * (xx[e] - mean[e]) * rstd[e];
+            }
+        }
+    if (on) {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            sh[(ph * cvecs + cv) * VEC + e] = s1[e];
+            sh[256 * VEC + (ph * cvecs + cv) * VEC + e] = s2[e];
+        }
+    }
+    __syncthreads();
+    if (on && ph == 0) {
+        for (int q = 1; q < phases; ++q)
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                s1[e] += sh[(q * cvecs + cv) * VEC + e];
+                s2[e] += sh[256 * VEC + (q * cvecs + cv) * VEC + e];
+            }
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            sh_tot[cv * VEC + e] = s1[e];
+            sh_tot[1024 + cv * VEC + e] = s2[e];
+        }
+        if (sums) {
+            float* o = sums + ((size_t)blockIdx.x * C + cv * VEC) * 2;
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) { o[2 * e] = s1[e]; o[2 * e + 1] = s2[e]; }
+        }
+    }
+    __syncthreads();
+    float k[VEC];
+    const float inv = 1.f / (float)HW;
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+        s1[e] = sh_tot[cvc * VEC + e] * inv;
+        s2[e] = sh_tot[1024 + cvc * VEC + e] * inv;
+        k[e] = rstd[e] * (gamma ? gamma[cvc * VEC + e] : 1.f);
+    }
+    if (on)
+        for (int px = ph; px < HW; px += phases) {
+            const size_t o = base + (size_t)px * C;
+            float g[VEC], yy[VEC], xx[VEC];
+            Elem<T>::unpack(*reinterpret_cast<const uint4*>(dy + o), g);
+            Elem<T>::unpack(*reinterpret_cast<const uint4*>(x + o), xx);
+            if (act != EVE_ACT_NONE) {
+                Elem<T>::unpack(*reinterpret_cast<const uint4*>(y + o), yy);
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) g[e] *= act_grad_from_out(yy[e], act);
+            }
+            if (dres) *reinterpret_cast<uint4*>(dres + o) = Elem<T>::pack(g);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e)
+                g[e] = k[e] * (g[e] - s1[e] - (xx[e] - mean[e]) * rstd[e] * s2[e]);
+            *reinterpret_cast<uint4*>(dx + o) = Elem<T>::pack(g);
+        }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void act_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ y, int act,
+                                                      T* __restrict__ dx, long long n) {
+    constexpr int VEC = Elem<T>::VEC;
+    const long long nvec = n / VEC;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (long long)gridDim.x * 256) {
+        float g[VEC], yy[VEC];
+        Elem<T>::unpack(reinterpret_cast<const uint4*>(dy)[i], g);
+        Elem<T>::unpack(reinterpret_cast<const uint4*>(y)[i], yy);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) g[e] *= act_grad_from_out(yy[e], act);
+        reinterpret_cast<uint4*>(dx)[i] = Elem<T>::pack(g);
+    }
+    // scalar tail
+    for (long long i = nvec * VEC + (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
+        Elem<T>::st(dx + i, Elem<T>::ld(dy + i) * act_grad_from_out(Elem<T>::ld(y + i), act));
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void add_kernel(const T* __restrict__ a, const T* __restrict__ b,
+                                                  T* __restrict__ o, long long n) {
+    constexpr int VEC = Elem<T>::VEC;
+    const long long nvec = n / VEC;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (long long)gridDim.x * 256) {
+        float fa[VEC], fb[VEC];
+        Elem<T>::unpack(reinterpret_cast<const uint4*>(a)[i], fa);
+        Elem<T>::unpack(reinterpret_cast<const uint4*>(b)[i], fb);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) fa[e] += fb[e];
+        reinterpret_cast<uint4*>(o)[i] = Elem<T>::pack(fa);
+    }
+    for (long long i = nvec * VEC + (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
+        Elem<T>::st(o + i, Elem<T>::ld(a + i) + Elem<T>::ld(b + i));
+}
+
+static inline unsigned stream_grid(long long nvec) {
+    long long b = (nvec + 255) / 256;
+    if (b > 256 * 8) b = 256 * 8;     // 8 workgroups per CU, grid-stride the rest
+    if (b < 1) b = 1;
+    return (unsigned)b;
+}
+
+static int check_plane(int dtype, int N, int HW, int C, const char* who) {
+    const int vec = dtype == EVE_DT_BF16 ? 8 : 4;
+    if (dtype != EVE_DT_F32 && dtype != EVE_DT_BF16) return set_error_msg("instnorm: bad dtype");
+    if (N <= 0 || HW <= 0 || C <= 0 || C % vec || C / vec > 256 || C > 1024) return set_error_msg(who);
+    return 0;
+}
+
+}  // namespace eve
+
+using namespace eve;
+
+extern "C" int eve_instnorm_stats(int dtype, int N, int HW, int C, const void* x, float eps, float* mean_rstd,
+                                  eve_stream_t stream) {
+    if (int e = check_plane(dtype, N, HW, C, "instnorm_stats: bad shape")) return e;
+    if (!x || !mean_rstd) return set_error_msg("instnorm_stats: null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == EVE_DT_BF16) hipLaunchKernelGGL(in_stats_kernel<bf16_t>, dim3(N), dim3(256), 0, s, (const bf16_t*)x, mean_rstd, HW, C, eps);
+    else                      hipLaunchKernelGGL(in_stats_kernel<float>, dim3(N), dim3(256), 0, s, (const float*)x, mean_rstd, HW, C, eps);
+    EVE_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int eve_instnorm_act_fwd(int dtype, int N, int HW, int C, const void* x, const float* mean_rstd,
+                                    const float* gamma, const float* beta, const void* res, int act, void* y,
+                                    eve_stream_t stream) {
+    if (int e = check_plane(dtype, N, HW, C, "instnorm_act_fwd: bad shape")) return e;
+    if (!x || !mean_rstd || !y || ((gamma == nullptr) != (beta == nullptr)))
+        return set_error_msg("instnorm_act_fwd: null pointer / gamma-beta mismatch");
+    const int vec = dtype == EVE_DT_BF16 ? 8 : 4;
+    const long long nvec = (long long)N * HW * (C / vec);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == EVE_DT_BF16)
+        hipLaunchKernelGGL(in_act_fwd_kernel<bf16_t>, dim3(stream_grid(nvec)), dim3(256), 0, s, (const bf16_t*)x, mean_rstd, gamma, beta, (const bf16_t*)res, act, (bf16_t*)y, HW, C, nvec);
+    else
+        hipLaunchKernelGGL(in_act_fwd_kernel<float>, dim3(stream_grid(nvec)), dim3(256), 0, s, (const float*)x, mean_rstd, gamma, beta, (const float*)res, act, (float*)y, HW, C, nvec);
+    EVE_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int eve_instnorm_act_bwd(int dtype, int N, int HW, int C, const void* dy, const void* y, const void* x,
+                                    const float* mean_rstd, const float* gamma, int act, void* dx, void* dres,
+                                    float* sums, eve_stream_t stream) {
+    if (int e = check_plane(dtype, N, HW, C, "instnorm_act_bwd: bad shape")) return e;
+    if (!dy || !x || !mean_rstd || !dx || (act != EVE_ACT_NONE && !y))
+        return set_error_msg("instnorm_act_bwd: null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == EVE_DT_BF16)
+        hipLaunchKernelGGL(in_act_bwd_kernel<bf16_t>, dim3(N), dim3(256), 0, s, (const bf16_t*)dy, (const bf16_t*)y, (const bf16_t*)x, mean_rstd, gamma, act, (bf16_t*)dx, (bf16_t*)dres, sums, HW, C);
+    else
+        hipLaunchKernelGGL(in_act_bwd_kernel<float>, dim3(N), dim3(256), 0, s, (const float*)dy, (const float*)y, (const float*)x, mean_rstd, gamma, act, (float*)dx, (float*)dres, sums, HW, C);
+    EVE_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int eve_act_bwd(int dtype, long long n, const void* dy, const void* y, int act, void* dx,
+                           eve_stream_t stream) {
+    if (n <= 0 || !dy || !y || !dx) return set_error_msg("act_bwd: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == EVE_DT_BF16) hipLaunchKernelGGL(act_bwd_kernel<bf16_t>, dim3(stream_grid(n / 8 + 1)), dim3(256), 0, s, (const bf16_t*)dy, (const bf16_t*)y, act, (bf16_t*)dx, n);
+    else                      hipLaunchKernelGGL(act_bwd_kernel<float>, dim3(stream_grid(n / 4 + 1)), dim3(256), 0, s, (const float*)dy, (const float*)y, act, (float*)dx, n);
+    EVE_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int eve_add(int dtype, long long n, const void* a, const void* b, void* out, eve_stream_t stream) {
+    if (n <= 0 || !a || !b || !out) return set_error_msg("add: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == EVE_DT_BF16) hipLaunchKernelGGL(add_kernel<bf16_t>, dim3(stream_grid(n / 8 + 1)), dim3(256), 0, s, (const bf16_t*)a, (const bf16_t*)b, (bf16_t*)out, n);
+    else                      hipLaunchKernelGGL(add_kernel<float>, dim3(stream_grid(n / 4 + 1)), dim3(256), 0, s, (const float*)a, (const float*)b, (float*)out, n);
+    EVE_CHECK_LAUNCH();
+    return 0;
+}

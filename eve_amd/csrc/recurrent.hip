@@ -1,0 +1,297 @@
+// Recurrent pieces of the hot path, gfx950.
+//   * GRU scan: nn.GRUCell over T steps (reference: src/models/eye_net.py:69,116-134).  The input-side
+//     GEMM (W_ih x + b_ih) for ALL steps is done up front by the batched linear kernel; what is left is a
+//     strictly sequential H x 3H mat-vec per step and sequence, so one persistent workgroup owns one
+//     sequence for all T steps (sequences are independent): h lives in LDS, W_hh streams from L2.
+//   * conv-GRU gate math (reference: src/models/common.py:409-414) as fused element-wise kernels around
+//     the two 3x3 gate convolutions.
+#include "common.h"
+
+namespace eve {
+
+__device__ __forceinline__ float sigmoidf_(float z) { return 1.f / (1.f + __expf(-z)); }
+
+// grid = S sequences, block = 3H threads (H <= 256).  whh_t is [H][3H] (transposed for coalescing).
+__global__ void gru_scan_fwd_kernel(int T, int H, const float* __restrict__ gi, const float* __restrict__ whh_t,
+                                    const float* __restrict__ bhh, const float* __restrict__ h0,
+                                    float* __restrict__ hs, float* __restrict__ gates, float* __restrict__ hn_pre) {
+    extern __shared__ float sm[];
+    float* h = sm;            // [H]
+    float* gh = sm + H;       // [3H]
+    const int s = blockIdx.x, j = threadIdx.x, H3 = 3 * H;
+    if (j < H) h[j] = h0 ? h0[(size_t)s * H + j] : 0.f;
+    __syncthreads();
+    for (int t = 0; t < T; ++t) {
+        if (j < H3) {
+            float a = bhh[j];
+            for (int k = 0; k < H; ++k) a = fmaf(whh_t[(size_t)k * H3 + j], h[k], a);
+            gh[j] = a;
+        }
+        __syncthreads();
+        float hnew = 0.f;
+        if (j < H) {
+            const float* g = gi + ((size_t)s * T + t) * H3;
+            const float r = sigmoidf_(g[j] + gh[j]);
+            const float z = sigmoidf_(g[H + j] + gh[H + j]);
+            const float n = tanhf(g[2 * H + j] + r * gh[2 * H + j]);
+            hnew = (1.f - z) * n + z * h[j];
+            float* go = gates + ((size_t)s * T + t) * H3;
+            go[j] = r; go[H + j] = z; go[2 * H + j] = n;
+            hn_pre[((size_t)s * T + t) * H + j] = gh[2 * H + j];
+            hs[((size_t)s * T + t) * H + j] = hnew;
+        }
+        __syncthreads();
+        if (j < H) h[j] = hnew;
+        __syncthreads();
+    }
+}
+
+// grid = S, block = 3H.  whh is the original [3H][H].
+__global__ void gru_scan_bwd_kernel(int T, int H, const float* __restrict__ dhs, const float* __restrict__ whh,
+                                    const float* __restrict__ h0, const float* __restrict__ hs,
+                                    const float* __restrict__ gates, const float* __restrict__ hn_pre,
+                                    float* __restrict__ dgi, float* __restrict__ dgh, float* __restrict__ dh0) {
+    extern __shared__ float sm[];
+    float* dh = sm;           // [H]   carried gradient on h_t
+    float* dg = sm + H;       // [3H]  dgh of the current step
+    const int s = blockIdx.x, j = threadIdx.x, H3 = 3 * H;
+    if (j < H) dh[j] = 0.f;
+    __syncthreads();
+    for (int t = T - 1; t >= 0; --t) {
+        float direct = 0.f;
+        if (j < H) {
+            const size_t o = ((size_t)s * T + t);
+            const float d = dh[j] + dhs[o * H + j];
+            const float* g = gates + o * H3;
+            const float r = g[j], z = g[H + j], n = g[2 * H + j];
+            const float hp = t > 0 ? hs[(o - 1) * H + j] : (h0 ? h0[(size_t)s * H + j] : 0.f);
+            const float dn_pre = d * (1.f - z) * (1.f - n * n);
+            const float dz_pre = d * (hp - n) * z * (1.f - z);
+            const float dr_pre = dn_pre * hn_pre[o * H + j] * r * (1.f - r);
+            float* gi_o = dgi + o * H3;
+            float* gh_o = dgh + o * H3;
+            gi_o[j] = dr_pre; gi_o[H + j] = dz_pre; gi_o[2 * H + j] = dn_pre;
+            gh_o[j] = dr_pre; gh_o[H + j] = dz_pre; gh_o[2 * H + j] = dn_pre * r;
+            dg[j] = dr_pre; dg[H + j] = dz_pre; dg[2 * H + j] = dn_pre * r;
+            direct = d * z;
+        }
+        __syncthreads();
+        if (j < H) {
+            float a = direct;
+            for (int q = 0; q < H3; ++q) a = fmaf(whh[(size_t)q * H + j], dg[q], a);
+            dh[j] = a;
+        }
+        __syncthreads();
+    }
+    if (dh0 && j < H) dh0[(size_t)s * H + j] = dh[j];
+}
+
+// ---------------------------------------------------------------------------------------------------
+// conv-GRU element-wise gate kernels; P pixels, C hidden channels, NHWC
+// ---------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void cgru_gates1_kernel(const T* __restrict__ g1, const T* __restrict__ h,
+                                                          T* __restrict__ ru, T* __restrict__ rh, int C,
+                                                          long long items) {
+    constexpr int VEC = Elem<T>::VEC;
+    const int cvecs = C / VEC;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < items; i += (long long)gridDim.x * 256) {
+        const int cv = (int)(i % cvecs);
+        const long long p = i / cvecs;
+        float r[VEC], u[VEC], hh[VEC];
+        Elem<T>::unpack(*reinterpret_cast<const uint4*>(g1 + p * 2 * C + cv * VEC), r);
+        Elem<T>::unpack(*reinterpret_cast<const uint4*>(g1 + p * 2 * C + C + cv * VEC), u);
+        Elem<T>::unpack(*reinterpret_cast<const uint4*>(h + p * C + cv * VEC), hh);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) { r[e] = sigmoidf_(r[e]); u[e] = sigmoidf_(u[e]); hh[e] *= r[e]; }
+        *reinterpret_cast<uint4*>(ru + p * 2 * C + cv * VEC) = Elem<T>::pack(r);
+        *reinterpret_cast<uint4*>(ru + p * 2 * C + C + cv * VEC) = Elem<T>::pack(u);
+        *reinterpret_cast<uint4*>(rh + p * C + cv * VEC) = Elem<T>::pack(hh);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void cgru_gates2_kernel(const T* __restrict__ g2, const T* __restrict__ ru,
+                                                          const T* __restrict__ h, T* __restrict__ o,
+                                                          T* __restrict__ hnew, int C, long long items) {
+    constexpr int VEC = Elem<T>::VEC;
+    const int cvecs = C / VEC;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < items; i += (long long)gridDim.x * 256) {
+        const int cv = (int)(i % cvecs);
+        const long long p = i / cvecs;
+        float og[VEC], u[VEC], hh[VEC];
+        Elem<T>::unpack(*reinterpret_cast<const uint4*>(g2 + p * C + cv * VEC), og);
+        Elem<T>::unpack(*reinterpret_cast<const uint4*>(ru + p * 2 * C + C + cv * VEC), u);
+        Elem<T>::unpack(*reinterpret_cast<const uint4*>(h + p * C + cv * VEC), hh);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) { og[e] = tanhf(og[e]); hh[e] = (1.f - u[e]) * og[e] + u[e] * hh[e]; }
+        *reinterpret_cast<uint4*>(o + p * C + cv * VEC) = Elem<T>::pack(og);
+        *reinterpret_cast<uint4*>(hnew + p * C + cv * VEC) = Elem<T>::pack(hh);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void cgru_gates2_bwd_kernel(const T* __restrict__ dhnew, const T* __restrict__ ru,
+                                                              const T* __restrict__ h, const T* __restrict__ o,
+                                                              T* __restrict__ dg2, T* __restrict__ du,
+                                                              T* __restrict__ dh, int C, long long items) {
+    constexpr int VEC = Elem<T>::VEC;
+    const int cvecs = C / VEC;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < items; i += (long long)gridDim.x * 256) {
+        const int cv = (int)(i % cvecs);
+        const long long p = i / cvecs;
+        float d[VEC], u[VEC], hh[VEC], og[VEC], a[VEC], b[VEC], c[VEC];
+        Elem<T>::unpack(*reinterpret_cast<const uint4*>(dhnew + p * C + cv * VEC), d);
+        Elem<T>::unpack(*reinterpret_cast<const uint4*>(ru + p * 2 * C + C + cv * VEC), u);
+        Elem<T>::unpack(*reinterpret_cast<const uint4*>(h + p * C + cv * VEC), hh);
+        Elem<T>::unpack(*reinterpret_cast<const uint4*>(o + p * C + cv * VEC), og);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            a[e] = d[e] * (1.f - u[e]) * (1.f - og[e] * og[e]);   // d(pre-tanh)
+            b[e] = d[e] * (hh[e] - og[e]);                         // d(u), post-sigmoid
+            c[e] = d[e] * u[e];                                    // direct path to h
+        }
+        *reinterpret_cast<uint4*>(dg2 + p * C + cv * VEC) = Elem<T>::pack(a);
+        *reinterpret_cast<uint4*>(du + p * 2 * C + cv * VEC) = make_uint4(0, 0, 0, 0);
+        *reinterpret_cast<uint4*>(du + p * 2 * C + C + cv * VEC) = Elem<T>::pack(b);
+        *reinterpret_cast<uint4*>(dh + p * C + cv * VEC) = Elem<T>::pack(c);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void cgru_gates1_bwd_kernel(const T* __restrict__ drh, const T* __restrict__ du,
+                                                              const T* __restrict__ ru, const T* __restrict__ h,
+                                                              T* __restrict__ dg1, T* __restrict__ dh_accum, int C,
+                                                              long long items) {
+    constexpr int VEC = Elem<T>::VEC;
+    const int cvecs = C / VEC;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < items; i += (long long)gridDim.x * 256) {
+        const int cv = (int)(i % cvecs);
+        const long long p = i / cvecs;
+        float d[VEC], dU[VEC], r[VEC], u[VEC], hh[VEC], acc[VEC];
+        Elem<T>::unpack(*reinterpret_cast<const uint4*>(drh + p * C + cv * VEC), d);
+        Elem<T>::unpack(*reinterpret_cast<const uint4*>(du + p * 2 * C + C + cv * VEC), dU);
+        Elem<T>::unpack(*reinterpret_cast<const uint4*>(ru + p * 2 * C + cv * VEC), r);
+        Elem<T>::unpack(*reinterpret_cast<const uint4*>(ru + p * 2 * C + C + cv * VEC), u);
+        Elem<T>::unpack(*reinterpret_cast<const uint4*>(h + p * C + cv * VEC), hh);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            acc[e] = d[e] * r[e];                                   // d(rh) -> h
+            d[e] = d[e] * hh[e] * r[e] * (1.f - r[e]);              // -> pre-sigmoid reset gate
+            dU[e] = dU[e] * u[e] * (1.f - u[e]);                    // -> pre-sigmoid update gate
+        }
+        *reinterpret_cast<uint4*>(dg1 + p * 2 * C + cv * VEC) = Elem<T>::pack(d);
+        *reinterpret_cast<uint4*>(dg1 + p * 2 * C + C + cv * VEC) = Elem<T>::pack(dU);
+        *reinterpret_cast<uint4*>(dh_accum + p * C + cv * VEC) = Elem<T>::pack(acc);
+    }
+}
+
+// conv-LSTM gate math of CLSTMCell.forward (reference: src/models/common.py:376-385), forward only:
+// the reference never propagates a gradient through it (Bottleneck drops tuple states, refine_net.py:168-174).
+template <typename T>
+__global__ __launch_bounds__(256) void clstm_gates_kernel(const T* __restrict__ g, const T* __restrict__ c_prev,
+                                                          T* __restrict__ h, T* __restrict__ c, int C,
+                                                          long long items) {
+    constexpr int VEC = Elem<T>::VEC;
+    const int cvecs = C / VEC;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < items; i += (long long)gridDim.x * 256) {
+        const int cv = (int)(i % cvecs);
+        const long long p = i / cvecs;
+        float gi[VEC], gf[VEC], go[VEC], gc[VEC], cp[VEC], hh[VEC];
+        const T* gp = g + p * 4 * C + cv * VEC;
+        Elem<T>::unpack(*reinterpret_cast<const uint4*>(gp), gi);
+        Elem<T>::unpack(*reinterpret_cast<const uint4*>(gp + C), gf);
+        Elem<T>::unpack(*reinterpret_cast<const uint4*>(gp + 2 * C), go);
+        Elem<T>::unpack(*reinterpret_cast<const uint4*>(gp + 3 * C), gc);
+        Elem<T>::unpack(*reinterpret_cast<const uint4*>(c_prev + p * C + cv * VEC), cp);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            cp[e] = sigmoidf_(gf[e]) * cp[e] + sigmoidf_(gi[e]) * tanhf(gc[e]);
+            hh[e] = sigmoidf_(go[e]) * tanhf(cp[e]);
+        }
+        *reinterpret_cast<uint4*>(c + p * C + cv * VEC) = Elem<T>::pack(cp);
+        *reinterpret_cast<uint4*>(h + p * C + cv * VEC) = Elem<T>::pack(hh);
+    }
+}
+
+static inline unsigned rgrid(long long items) {
+    long long b = (items + 255) / 256;
+    if (b > 2048) b = 2048;
+    if (b < 1) b = 1;
+    return (unsigned)b;
+}
+
+}  // namespace eve
+
+using namespace eve;
+
+extern "C" int eve_gru_scan_fwd(int S, int T, int H, const float* gi, const float* whh_t, const float* bhh,
+                                const float* h0, float* hs, float* gates, float* hn_pre, eve_stream_t stream) {
+    if (S <= 0 || T <= 0 || H <= 0 || H > 256 || !gi || !whh_t || !bhh || !hs || !gates || !hn_pre)
+        return set_error_msg("gru_scan_fwd: bad arguments (H <= 256)");
+    const int threads = ((3 * H + 63) / 64) * 64;
+    hipLaunchKernelGGL(gru_scan_fwd_kernel, dim3(S), dim3(threads), 4 * H * sizeof(float), (hipStream_t)stream,
+                       T, H, gi, whh_t, bhh, h0, hs, gates, hn_pre);
+    EVE_CHECK_LAUNCH();
+    return 0;
+}
+extern "C" int eve_gru_scan_bwd(int S, int T, int H, const float* dhs, const float* whh, const float* h0,
+                                const float* hs, const float* gates, const float* hn_pre, float* dgi, float* dgh,
+                                float* dh0, eve_stream_t stream) {
+    if (S <= 0 || T <= 0 || H <= 0 || H > 256 || !dhs || !whh || !hs || !gates || !hn_pre || !dgi || !dgh)
+        return set_error_msg("gru_scan_bwd: bad arguments (H <= 256)");
+    const int threads = ((3 * H + 63) / 64) * 64;
+    hipLaunchKernelGGL(gru_scan_bwd_kernel, dim3(S), dim3(threads), 4 * H * sizeof(float), (hipStream_t)stream,
+                       T, H, dhs, whh, h0, hs, gates, hn_pre, dgi, dgh, dh0);
+    EVE_CHECK_LAUNCH();
+    return 0;
+}
+
+#define CG_CHECK(who)                                                                     \
+    const int vec = dtype == EVE_DT_BF16 ? 8 : 4;                                         \
+    if ((dtype != EVE_DT_F32 && dtype != EVE_DT_BF16) || P <= 0 || C <= 0 || C % vec)    \
+        return set_error_msg(who ": bad arguments");                                      \
+    const long long items = P * (C / vec);                                                \
+    hipStream_t s = (hipStream_t)stream;
+
+extern "C" int eve_cgru_gates1(int dtype, long long P, int C, const void* g1, const void* h, void* ru, void* rh,
+                               eve_stream_t stream) {
+    CG_CHECK("cgru_gates1")
+    if (dtype == EVE_DT_BF16) hipLaunchKernelGGL(cgru_gates1_kernel<bf16_t>, dim3(rgrid(items)), dim3(256), 0, s, (const bf16_t*)g1, (const bf16_t*)h, (bf16_t*)ru, (bf16_t*)rh, C, items);
+    else                      hipLaunchKernelGGL(cgru_gates1_kernel<float>, dim3(rgrid(items)), dim3(256), 0, s, (const float*)g1, (const float*)h, (float*)ru, (float*)rh, C, items);
+    EVE_CHECK_LAUNCH();
+    return 0;
+}
+extern "C" int eve_cgru_gates2(int dtype, long long P, int C, const void* g2, const void* ru, const void* h, void* o,
+                               void* hnew, eve_stream_t stream) {
+    CG_CHECK("cgru_gates2")
+    if (dtype == EVE_DT_BF16) hipLaunchKernelGGL(cgru_gates2_kernel<bf16_t>, dim3(rgrid(items)), dim3(256), 0, s, (const bf16_t*)g2, (const bf16_t*)ru, (const bf16_t*)h, (bf16_t*)o, (bf16_t*)hnew, C, items);
+    else                      hipLaunchKernelGGL(cgru_gates2_kernel<float>, dim3(rgrid(items)), dim3(256), 0, s, (const float*)g2, (const float*)ru, (const float*)h, (float*)o, (float*)hnew, C, items);
+    EVE_CHECK_LAUNCH();
+    return 0;
+}
+extern "C" int eve_cgru_gates2_bwd(int dtype, long long P, int C, const void* dhnew, const void* ru, const void* h,
+                                   const void* o, void* dg2, void* du, void* dh, eve_stream_t stream) {
+    CG_CHECK("cgru_gates2_bwd")
+    if (dtype == EVE_DT_BF16) hipLaunchKernelGGL(cgru_gates2_bwd_kernel<bf16_t>, dim3(rgrid(items)), dim3(256), 0, s, (const bf16_t*)dhnew, (const bf16_t*)ru, (const bf16_t*)h, (const bf16_t*)o, (bf16_t*)dg2, (bf16_t*)du, (bf16_t*)dh, C, items);
+    else                      hipLaunchKernelGGL(cgru_gates2_bwd_kernel<float>, dim3(rgrid(items)), dim3(256), 0, s, (const float*)dhnew, (const float*)ru, (const float*)h, (const float*)o, (float*)dg2, (float*)du, (float*)dh, C, items);
+    EVE_CHECK_LAUNCH();
+    return 0;
+}
+extern "C" int eve_cgru_gates1_bwd(int dtype, long long P, int C, const void* drh, const void* du, const void* ru,
+                                   const void* h, void* dg1, void* dh_accum, eve_stream_t stream) {
+    CG_CHECK("cgru_gates1_bwd")
+    if (dtype == EVE_DT_BF16) hipLaunchKernelGGL(cgru_gates1_bwd_kernel<bf16_t>, dim3(rgrid(items)), dim3(256), 0, s, (const bf16_t*)drh, (const bf16_t*)du, (const bf16_t*)ru, (const bf16_t*)h, (bf16_t*)dg1, (bf16_t*)dh_accum, C, items);
+    else                      hipLaunchKernelGGL(cgru_gates1_bwd_kernel<float>, dim3(rgrid(items)), dim3(256), 0, s, (const float*)drh, (const float*)du, (const float*)ru, (const float*)h, (float*)dg1, (float*)dh_accum, C, items);
+    EVE_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int eve_clstm_gates_fwd(int dtype, long long P, int C, const void* gates, const void* c_prev, void* h,
+                                   void* c, eve_stream_t stream) {
+    CG_CHECK("clstm_gates_fwd")
+    if (dtype == EVE_DT_BF16) hipLaunchKernelGGL(clstm_gates_kernel<bf16_t>, dim3(rgrid(items)), dim3(256), 0, s, (const bf16_t*)gates, (const bf16_t*)c_prev, (bf16_t*)h, (bf16_t*)c, C, items);
+    else                      hipLaunchKernelGGL(clstm_gates_kernel<float>, dim3(rgrid(items)), dim3(256), 0, s, (const float*)gates, (const float*)c_prev, (float*)h, (float*)c, C, items);
+    EVE_CHECK_LAUNCH();
+    return 0;
+}

@@ -1,0 +1,261 @@
+"""EyeNet drop-in: per-eye, per-frame ResNet-18(InstanceNorm) encoder -> GRU -> gaze / pupil heads,
+computed by the gfx950 HIP kernels of libeve_hip.so.
+
+Mirrors /root/reference/src/models/eye_net.py:
+  * constructor signature `EyeNet()` (:38) reading the config singleton, same sub-module / parameter
+    names, so `state_dict()` keys equal the reference's (checkpoints split per first prefix by
+    src/core/checkpoint_manager.py:56-67 and released weights load with strict=True);
+  * `forward(input_dict, output_dict, side, previous_output_dict=None) -> None` (:98) writing
+    `<side>_g_initial`, `<side>_pupil_size`, `<side>_eye_rnn_states_0` into `output_dict` and reading
+    the previous state from `previous_output_dict` (:116-133); frozen => detached gaze (:149-150);
+  * same error behaviour: ValueError for an unknown RNN type (:72), KeyError for missing dict entries.
+
+In addition `forward_sequence` runs all T steps and both eyes of a clip batch in ONE pass: InstanceNorm
+has no cross-sample coupling, so folding T and left/right into the image batch is numerically the same
+as the reference's per-time-step loop (src/models/eve.py:91-111); only the GRU is sequential, and that
+runs as one persistent scan kernel.
+
+The nn.Conv2d / nn.Linear / nn.GRUCell objects below are PARAMETER HOLDERS (names, shapes, init); their
+ATen forward is never called.
+"""
+import math
+import os
+
+import torch
+from torch import nn
+
+from . import ops
+from .config import get_config
+from .kernels import ACT_NONE, ACT_RELU, ACT_SELU, ACT_TANH, default_kernels, pad_channels
+from .ops import PackedWeight
+
+half_pi = 0.5 * math.pi
+
+
+def default_compute_dtype():
+    name = os.environ.get('EVE_AMD_DTYPE', 'fp32').lower()
+    if name in ('bf16', 'bfloat16'):
+        return torch.bfloat16
+    if name in ('fp32', 'float32', 'f32'):
+        return torch.float32
+    raise ValueError('EVE_AMD_DTYPE must be fp32 or bf16, got %r' % name)
+
+
+class _Block(nn.Module):
+    """Parameter holder for one torchvision BasicBlock (conv1, conv2, optional downsample.0)."""
+
+    def __init__(self, cin, cout, stride):
+        super().__init__()
+        self.stride = stride
+        self.conv1 = nn.Conv2d(cin, cout, 3, stride, 1, bias=False)
+        self.conv2 = nn.Conv2d(cout, cout, 3, 1, 1, bias=False)
+        self.downsample = None
+        if stride != 1 or cin != cout:
+            self.downsample = nn.Sequential(nn.Conv2d(cin, cout, 1, stride, bias=False),
+                                            nn.InstanceNorm2d(cout))
+
+
+class _ResNet18IN(nn.Module):
+    """Parameter holder with torchvision ResNet-18 names (conv1, layer1..4, fc)."""
+
+    def __init__(self, num_classes):
+        super().__init__()
+        self.conv1 = nn.Conv2d(3, 64, 7, 2, 3, bias=False)
+        cin = 64
+        for li, (cout, stride) in enumerate([(64, 1), (128, 2), (256, 2), (512, 2)], start=1):
+            setattr(self, 'layer%d' % li, nn.Sequential(_Block(cin, cout, stride), _Block(cout, cout, 1)))
+            cin = cout
+        self.fc = nn.Linear(512, num_classes)
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode='fan_out', nonlinearity='relu')
+
+    def blocks(self):
+        for li in range(1, 5):
+            for bi, blk in enumerate(getattr(self, 'layer%d' % li)):
+                yield 'layer%d.%d' % (li, bi), blk
+
+
+class EyeNet(nn.Module):
+    def __init__(self):
+        super(EyeNet, self).__init__()
+        config = get_config()
+        self.config = config
+        self.compute_dtype = default_compute_dtype()
+        nf = (config.eye_net_rnn_num_features if config.eye_net_use_rnn
+              else config.eye_net_static_num_features)
+        self.num_features = nf
+        self.cnn_layers = _ResNet18IN(nf)
+        self.fc_common = nn.Sequential(
+            nn.Linear(nf + (2 if config.eye_net_use_head_pose_input else 0), nf),
+            nn.SELU(inplace=True),
+            nn.Linear(nf, nf),
+        )
+        if config.eye_net_use_rnn:
+            cells = []
+            for _ in range(config.eye_net_rnn_num_cells):
+                kind = config.eye_net_rnn_type
+                n = config.eye_net_rnn_num_features
+                if kind == 'RNN':
+                    cells.append(nn.RNNCell(input_size=n, hidden_size=n))
+                elif kind == 'LSTM':
+                    cells.append(nn.LSTMCell(input_size=n, hidden_size=n))
+                elif kind == 'GRU':
+                    cells.append(nn.GRUCell(input_size=n, hidden_size=n))
+                else:
+                    raise ValueError('Unknown RNN type for EyeNet: %s' % kind)
+            self.rnn_cells = nn.ModuleList(cells)
+        else:
+            self.static_fc = nn.Sequential(nn.Linear(nf, nf), nn.SELU(inplace=True))
+        self.fc_to_gaze = nn.Sequential(
+            nn.Linear(nf, nf), nn.SELU(inplace=True), nn.Linear(nf, 2, bias=False), nn.Tanh())
+        self.fc_to_pupil = nn.Sequential(
+            nn.Linear(nf, nf), nn.SELU(inplace=True), nn.Linear(nf, 1), nn.ReLU(inplace=True))
+        nn.init.zeros_(self.fc_to_gaze[-2].weight)
+        self._packs = None
+        self._packs_key = None
+
+    # ------------------------------------------------------------------ packed weights
+    def invalidate_packs(self):
+        """Call after the parameters were updated behind torch's back (the fused Adam kernel)."""
+        self._packs = None
+
+    def _get_packs(self):
+        dt = self.compute_dtype
+        key = (dt,) + tuple((p.data_ptr(), p._version) for p in self.parameters())
+        if self._packs is not None and self._packs_key == key:
+            return self._packs
+        f32 = torch.float32
+        P = {}
+        cnn = self.cnn_layers
+        P['conv1'] = PackedWeight(cnn.conv1.weight, dt, cin_pad=pad_channels(3, dt), want_ihwo=False)
+        for name, blk in cnn.blocks():
+            P[name + '.conv1'] = PackedWeight(blk.conv1.weight, dt)
+            P[name + '.conv2'] = PackedWeight(blk.conv2.weight, dt)
+            if blk.downsample is not None:
+                P[name + '.downsample.0'] = PackedWeight(blk.downsample[0].weight, dt)
+        # the tail (linears + GRU) always runs in float32: < 0.03 % of the FLOPs, and it carries the recurrence
+        P['fc'] = PackedWeight(cnn.fc.weight, f32)
+        P['fc_common.0'] = PackedWeight(self.fc_common[0].weight, f32,
+                                        cin_pad=pad_channels(self.fc_common[0].in_features, f32))
+        P['fc_common.2'] = PackedWeight(self.fc_common[2].weight, f32)
+        if self.config.eye_net_use_rnn:
+            for i, cell in enumerate(self.rnn_cells):
+                P['rnn.%d.ih' % i] = PackedWeight(cell.weight_ih, f32)
+        else:
+            P['static_fc.0'] = PackedWeight(self.static_fc[0].weight, f32)
+        P['fc_to_gaze.0'] = PackedWeight(self.fc_to_gaze[0].weight, f32)
+        P['fc_to_gaze.2'] = PackedWeight(self.fc_to_gaze[2].weight, f32, cout_pad=4)
+        P['fc_to_pupil.0'] = PackedWeight(self.fc_to_pupil[0].weight, f32)
+        P['fc_to_pupil.2'] = PackedWeight(self.fc_to_pupil[2].weight, f32, cout_pad=4)
+        self._packs, self._packs_key = P, key
+        return P
+
+    # ------------------------------------------------------------------ trunk
+    def _trunk(self, x, P):
+        """x: [N, H, W, Cpad] NHWC compute dtype -> [N, 512] float32 (torchvision ResNet._forward_impl)."""
+        cnn = self.cnn_layers
+        y = ops.conv2d(x, cnn.conv1.weight, None, P['conv1'], stride=2, pad=3)
+        y = ops.instnorm_act(y, act=ACT_RELU)
+        y = ops.MaxPool3x3s2Fn.apply(y)
+        for name, blk in cnn.blocks():
+            out = ops.conv2d(y, blk.conv1.weight, None, P[name + '.conv1'], stride=blk.stride, pad=1)
+            out = ops.instnorm_act(out, act=ACT_RELU)
+            out = ops.conv2d(out, blk.conv2.weight, None, P[name + '.conv2'], stride=1, pad=1)
+            identity = y
+            if blk.downsample is not None:
+                identity = ops.conv2d(y, blk.downsample[0].weight, None, P[name + '.downsample.0'],
+                                      stride=blk.stride, pad=0)
+                identity = ops.instnorm_act(identity, act=ACT_NONE)
+            y = ops.instnorm_act(out, res=identity, act=ACT_RELU)
+        feats = ops.AvgPoolFn.apply(y)
+        return ops.cast(feats, torch.float32)
+
+    # ------------------------------------------------------------------ tail: fc -> fc_common -> GRU -> heads
+    def _tail(self, feats, head_pose, S, T, h0, P):
+        """feats [S*T, 512] float32 ordered (sequence, time); head_pose [S*T, 2] or None; h0 [S, H] or None.
+        Returns gaze [S*T, 2] (rad), pupil [S*T], states [S, T, H]."""
+        cfg = self.config
+        cnn = self.cnn_layers
+        f = ops.linear(feats, cnn.fc.weight, cnn.fc.bias, P['fc'])
+        if cfg.eye_net_use_head_pose_input:
+            f = torch.cat([f, head_pose.to(f.dtype)], dim=1)
+        cin_p = P['fc_common.0'].ohwi.shape[3]
+        if f.shape[1] != cin_p:
+            f = torch.nn.functional.pad(f, (0, cin_p - f.shape[1]))
+        f = ops.linear(f.contiguous(), self.fc_common[0].weight, self.fc_common[0].bias, P['fc_common.0'],
+                       act=ACT_SELU)
+        f = ops.linear(f, self.fc_common[2].weight, self.fc_common[2].bias, P['fc_common.2'])
+        states = None
+        if cfg.eye_net_use_rnn:
+            if cfg.eye_net_rnn_type != 'GRU' or len(self.rnn_cells) != 1:
+                raise NotImplementedError(
+                    'eve_amd.EyeNet: only eye_net_rnn_type="GRU" with one cell has a HIP scan kernel so far '
+                    '(SURVEY 8 f3); got %s x %d' % (cfg.eye_net_rnn_type, len(self.rnn_cells)))
+            cell = self.rnn_cells[0]
+            gi = ops.linear(f, cell.weight_ih, cell.bias_ih, P['rnn.0.ih'])
+            H = cell.hidden_size
+            states = ops.GRUScanFn.apply(gi.view(S, T, 3 * H), cell.weight_hh, cell.bias_hh, h0)
+            f = states.reshape(S * T, H)
+        else:
+            f = ops.linear(f, self.static_fc[0].weight, self.static_fc[0].bias, P['static_fc.0'], act=ACT_SELU)
+        g = ops.linear(f, self.fc_to_gaze[0].weight, self.fc_to_gaze[0].bias, P['fc_to_gaze.0'], act=ACT_SELU)
+        g = ops.linear(g, self.fc_to_gaze[2].weight, None, P['fc_to_gaze.2'], act=ACT_TANH)
+        gaze = half_pi * g[:, :2]
+        p = ops.linear(f, self.fc_to_pupil[0].weight, self.fc_to_pupil[0].bias, P['fc_to_pupil.0'], act=ACT_SELU)
+        p = ops.linear(p, self.fc_to_pupil[2].weight, self.fc_to_pupil[2].bias, P['fc_to_pupil.2'], act=ACT_RELU)
+        return gaze, p[:, 0], states
+
+    # ------------------------------------------------------------------ reference per-step contract
+    def forward(self, input_dict, output_dict, side, previous_output_dict=None):
+        key = side + '_eye_patch'
+        image = output_dict[key] if key in output_dict else input_dict[key]
+        P = self._get_packs()
+        dt = self.compute_dtype
+        x = ops.ToNHWCFn.apply(image, dt, pad_channels(image.shape[1], dt))
+        feats = self._trunk(x, P)
+        head_pose = input_dict[side + '_h'] if self.config.eye_net_use_head_pose_input else None
+        h0 = None
+        skey = side + '_eye_rnn_states_0'
+        if self.config.eye_net_use_rnn and previous_output_dict is not None:
+            h0 = previous_output_dict[skey]
+        B = image.shape[0]
+        gaze, pupil, states = self._tail(feats, head_pose, B, 1, h0, P)
+        if states is not None:
+            output_dict[skey] = states[:, 0]
+        output_dict[side + '_g_initial'] = gaze
+        output_dict[side + '_pupil_size'] = pupil.reshape(-1)
+        if self.config.eye_net_frozen:
+            output_dict[side + '_g_initial'] = output_dict[side + '_g_initial'].detach()
+
+    # ------------------------------------------------------------------ whole clips, both eyes, one pass
+    def forward_sequence(self, batch, initial_states=None):
+        """batch: {left,right}_eye_patch [B, T, 3, H, W] float, {left,right}_h [B, T, 2].
+        Returns the B x T x ... tensors eve.py:174-182 would stack: <side>_g_initial [B,T,2],
+        <side>_pupil_size [B,T], <side>_eye_rnn_states_0 [B,T,H]."""
+        k = default_kernels()
+        P = self._get_packs()
+        dt = self.compute_dtype
+        left, right = batch['left_eye_patch'], batch['right_eye_patch']
+        B, T, C, Hh, Ww = left.shape
+        cpad = pad_channels(C, dt)
+        x = torch.empty((2 * B * T, Hh, Ww, cpad), dtype=dt, device=left.device)
+        k.nchw_to_nhwc(left.reshape(B * T, C, Hh, Ww), dt, cpad, out=x[:B * T])
+        k.nchw_to_nhwc(right.reshape(B * T, C, Hh, Ww), dt, cpad, out=x[B * T:])
+        feats = self._trunk(x, P)
+        head_pose = None
+        if self.config.eye_net_use_head_pose_input:
+            head_pose = torch.cat([batch['left_h'].reshape(B * T, 2), batch['right_h'].reshape(B * T, 2)], dim=0)
+        h0 = None
+        if initial_states is not None:
+            h0 = torch.cat([initial_states['left'], initial_states['right']], dim=0)
+        gaze, pupil, states = self._tail(feats, head_pose, 2 * B, T, h0, P)
+        out = {}
+        for si, side in enumerate(('left', 'right')):
+            sl = slice(si * B * T, (si + 1) * B * T)
+            g = gaze[sl].reshape(B, T, 2)
+            out[side + '_g_initial'] = g.detach() if self.config.eye_net_frozen else g
+            out[side + '_pupil_size'] = pupil[sl].reshape(B, T)
+            if states is not None:
+                out[side + '_eye_rnn_states_0'] = states[si * B:(si + 1) * B]
+        return out

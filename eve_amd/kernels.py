@@ -1,0 +1,364 @@
+"""Tensor-level launcher over the C ABI of libeve_hip.so.
+
+`HipKernels` takes torch tensors (device memory owned by torch's allocator), checks layout/dtype,
+and calls the `extern "C"` entry points of include/eve_hip.h with raw pointers, explicit shapes and
+torch's current HIP stream.  PyTorch is plumbing here: allocation and stream only.
+
+Activations are NHWC (`[N, H, W, C]` contiguous) in the compute dtype (float32 or bfloat16).
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import ConvDesc
+
+ACT_NONE, ACT_RELU, ACT_LEAKY, ACT_SELU, ACT_TANH, ACT_SIGMOID = range(6)
+DT_F32, DT_BF16 = 0, 1
+
+
+def dt_code(dtype):
+    if dtype == torch.float32:
+        return DT_F32
+    if dtype == torch.bfloat16:
+        return DT_BF16
+    raise TypeError('eve_amd kernels support float32 and bfloat16, got %s' % dtype)
+
+
+def vec_of(dtype):
+    return 4 if dtype == torch.float32 else 8
+
+
+def pad_channels(c, dtype):
+    v = vec_of(dtype)
+    return (c + v - 1) // v * v
+
+
+def conv_out_size(i, k, stride, pad):
+    return (i + 2 * pad - k) // stride + 1
+
+
+class HipKernels(object):
+    """One instance per process; loads the library lazily and fails loudly if it is absent."""
+
+    name = 'hip'
+
+    def __init__(self):
+        self.lib = _lib.load()
+
+    # ------------------------------------------------------------------ helpers
+    @staticmethod
+    def _p(t):
+        if t is None:
+            return None
+        if not t.is_cuda:
+            raise RuntimeError('eve_amd: tensor is not on the GPU (the hot path has no CPU fallback)')
+        if not t.is_contiguous():
+            raise RuntimeError('eve_amd: non-contiguous tensor handed to a kernel')
+        return ctypes.c_void_p(t.data_ptr())
+
+    @staticmethod
+    def _stream():
+        return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def _ck(self, status):
+        if status != 0:
+            _lib.check(status, self.lib)
+
+    @staticmethod
+    def _f32(t, what):
+        if t is not None and t.dtype != torch.float32:
+            raise TypeError('%s must be float32' % what)
+        return t
+
+    @staticmethod
+    def _desc(dtype, N, IH, IW, Cin, Cout, KH, KW, stride, pad):
+        d = ConvDesc()
+        d.dtype = dt_code(dtype)
+        d.N, d.IH, d.IW, d.Cin = N, IH, IW, Cin
+        d.OH, d.OW, d.Cout = conv_out_size(IH, KH, stride, pad), conv_out_size(IW, KW, stride, pad), Cout
+        d.KH, d.KW, d.stride, d.pad = KH, KW, stride, pad
+        return d
+
+    # ------------------------------------------------------------------ convolution
+    def conv2d_fwd(self, x, w_ohwi, bias, stride, pad, epi_act=ACT_NONE, ss=None, pro_act=ACT_NONE):
+        N, IH, IW, Cin = x.shape
+        Cout, KH, KW, Cin2 = w_ohwi.shape
+        assert Cin2 == Cin and w_ohwi.dtype == x.dtype
+        d = self._desc(x.dtype, N, IH, IW, Cin, Cout, KH, KW, stride, pad)
+        y = torch.empty((N, d.OH, d.OW, Cout), dtype=x.dtype, device=x.device)
+        self._ck(self.lib.eve_conv2d_fwd(ctypes.byref(d), self._p(x), self._p(w_ohwi),
+                                         self._p(self._f32(bias, 'bias')), epi_act,
+                                         self._p(self._f32(ss, 'scale/shift')), pro_act, self._p(y),
+                                         self._stream()))
+        return y
+
+    def conv2d_dgrad(self, dy, w_ihwo, in_hw, stride, pad):
+        N, OH, OW, Cout = dy.shape
+        Cin, KH, KW, Cout2 = w_ihwo.shape
+        assert Cout2 == Cout and w_ihwo.dtype == dy.dtype
+        IH, IW = in_hw
+        d = self._desc(dy.dtype, N, IH, IW, Cin, Cout, KH, KW, stride, pad)
+        assert (d.OH, d.OW) == (OH, OW)
+        dx = torch.empty((N, IH, IW, Cin), dtype=dy.dtype, device=dy.device)
+        self._ck(self.lib.eve_conv2d_dgrad(ctypes.byref(d), self._p(dy), self._p(w_ihwo), self._p(dx),
+                                           self._stream()))
+        return dx
+
+    def conv2d_wgrad(self, x, dy, KH, KW, stride, pad, dw_ohwi, ss=None, pro_act=ACT_NONE):
+        """Accumulates into dw_ohwi (float32 [Cout, KH, KW, Cin])."""
+        N, IH, IW, Cin = x.shape
+        Cout = dy.shape[3]
+        assert dw_ohwi.shape == (Cout, KH, KW, Cin) and dw_ohwi.dtype == torch.float32
+        d = self._desc(x.dtype, N, IH, IW, Cin, Cout, KH, KW, stride, pad)
+        assert tuple(dy.shape) == (N, d.OH, d.OW, Cout) and dy.dtype == x.dtype
+        self._ck(self.lib.eve_conv2d_wgrad(ctypes.byref(d), self._p(x), self._p(dy),
+                                           self._p(self._f32(ss, 'scale/shift')), pro_act,
+                                           self._p(dw_ohwi), self._stream()))
+        return dw_ohwi
+
+    def bias_grad(self, dy, db):
+        C = dy.shape[-1]
+        M = dy.numel() // C
+        assert db.dtype == torch.float32 and db.numel() == C
+        self._ck(self.lib.eve_bias_grad(dt_code(dy.dtype), M, C, self._p(dy), self._p(db), self._stream()))
+        return db
+
+    # ------------------------------------------------------------------ instance norm
+    def instnorm_stats(self, x, eps=1e-5):
+        N, H, W, C = x.shape
+        mr = torch.empty((N, C, 2), dtype=torch.float32, device=x.device)
+        self._ck(self.lib.eve_instnorm_stats(dt_code(x.dtype), N, H * W, C, self._p(x), eps, self._p(mr),
+                                             self._stream()))
+        return mr
+
+    def instnorm_act_fwd(self, x, mr, gamma, beta, res, act):
+        N, H, W, C = x.shape
+        y = torch.empty_like(x)
+        self._ck(self.lib.eve_instnorm_act_fwd(dt_code(x.dtype), N, H * W, C, self._p(x), self._p(mr),
+                                               self._p(self._f32(gamma, 'gamma')),
+                                               self._p(self._f32(beta, 'beta')), self._p(res), act,
+                                               self._p(y), self._stream()))
+        return y
+
+    def instnorm_act_bwd(self, dy, y, x, mr, gamma, act, want_dres):
+        N, H, W, C = x.shape
+        dx = torch.empty_like(x)
+        dres = torch.empty_like(x) if want_dres else None
+        sums = torch.empty((N, C, 2), dtype=torch.float32, device=x.device)
+        self._ck(self.lib.eve_instnorm_act_bwd(dt_code(x.dtype), N, H * W, C, self._p(dy), self._p(y),
+                                               self._p(x), self._p(mr), self._p(self._f32(gamma, 'gamma')),
+                                               act, self._p(dx), self._p(dres), self._p(sums),
+                                               self._stream()))
+        return dx, dres, sums
+
+    # ------------------------------------------------------------------ element-wise
+    def act_bwd(self, dy, y, act):
+        dx = torch.empty_like(dy)
+        self._ck(self.lib.eve_act_bwd(dt_code(dy.dtype), dy.numel(), self._p(dy), self._p(y), act,
+                                      self._p(dx), self._stream()))
+        return dx
+
+    def add(self, a, b):
+        out = torch.empty_like(a)
+        self._ck(self.lib.eve_add(dt_code(a.dtype), a.numel(), self._p(a), self._p(b), self._p(out),
+                                  self._stream()))
+        return out
+
+    # ------------------------------------------------------------------ pooling / resampling
+    def maxpool3x3s2_fwd(self, x):
+        N, IH, IW, C = x.shape
+        OH, OW = (IH - 1) // 2 + 1, (IW - 1) // 2 + 1
+        y = torch.empty((N, OH, OW, C), dtype=x.dtype, device=x.device)
+        idx = torch.empty((N, OH, OW, C), dtype=torch.uint8, device=x.device)
+        self._ck(self.lib.eve_maxpool3x3s2_fwd(dt_code(x.dtype), N, IH, IW, C, self._p(x), self._p(y),
+                                               self._p(idx), self._stream()))
+        return y, idx
+
+    def maxpool3x3s2_bwd(self, dy, idx, in_hw):
+        N, OH, OW, C = dy.shape
+        IH, IW = in_hw
+        dx = torch.empty((N, IH, IW, C), dtype=dy.dtype, device=dy.device)
+        self._ck(self.lib.eve_maxpool3x3s2_bwd(dt_code(dy.dtype), N, IH, IW, C, self._p(dy), self._p(idx),
+                                               self._p(dx), self._stream()))
+        return dx
+
+    def avgpool_fwd(self, x):
+        N, H, W, C = x.shape
+        y = torch.empty((N, C), dtype=x.dtype, device=x.device)
+        self._ck(self.lib.eve_avgpool_fwd(dt_code(x.dtype), N, H * W, C, self._p(x), self._p(y),
+                                          self._stream()))
+        return y
+
+    def avgpool_bwd(self, dy, hw):
+        N, C = dy.shape
+        dx = torch.empty((N, hw[0], hw[1], C), dtype=dy.dtype, device=dy.device)
+        self._ck(self.lib.eve_avgpool_bwd(dt_code(dy.dtype), N, hw[0] * hw[1], C, self._p(dy), self._p(dx),
+                                          self._stream()))
+        return dx
+
+    def adaptive_maxpool_fwd(self, x, out_hw):
+        N, IH, IW, C = x.shape
+        OH, OW = out_hw
+        y = torch.empty((N, OH, OW, C), dtype=x.dtype, device=x.device)
+        idx = torch.empty((N, OH, OW, C), dtype=torch.int32, device=x.device)
+        self._ck(self.lib.eve_adaptive_maxpool_fwd(dt_code(x.dtype), N, IH, IW, OH, OW, C, self._p(x),
+                                                   self._p(y), self._p(idx), self._stream()))
+        return y, idx
+
+    def adaptive_maxpool_bwd(self, dy, idx, in_hw):
+        N, OH, OW, C = dy.shape
+        IH, IW = in_hw
+        dx = torch.empty((N, IH, IW, C), dtype=dy.dtype, device=dy.device)
+        self._ck(self.lib.eve_adaptive_maxpool_bwd(dt_code(dy.dtype), N, IH, IW, OH, OW, C, self._p(dy),
+                                                   self._p(idx), self._p(dx), self._stream()))
+        return dx
+
+    def bilinear_fwd(self, x, out_hw):
+        N, IH, IW, C = x.shape
+        OH, OW = out_hw
+        y = torch.empty((N, OH, OW, C), dtype=x.dtype, device=x.device)
+        self._ck(self.lib.eve_bilinear_fwd(dt_code(x.dtype), N, IH, IW, OH, OW, C, self._p(x), self._p(y),
+                                           self._stream()))
+        return y
+
+    def bilinear_bwd(self, dy, in_hw):
+        N, OH, OW, C = dy.shape
+        IH, IW = in_hw
+        dx = torch.empty((N, IH, IW, C), dtype=dy.dtype, device=dy.device)
+        self._ck(self.lib.eve_bilinear_bwd(dt_code(dy.dtype), N, IH, IW, OH, OW, C, self._p(dy), self._p(dx),
+                                           self._stream()))
+        return dx
+
+    # ------------------------------------------------------------------ layout / dtype
+    def nchw_to_nhwc(self, src, dtype, cpad=None, out=None):
+        N, C, H, W = src.shape
+        cpad = cpad or pad_channels(C, dtype)
+        src = src.contiguous()
+        dst = out if out is not None else torch.empty((N, H, W, cpad), dtype=dtype, device=src.device)
+        assert tuple(dst.shape) == (N, H, W, cpad) and dst.dtype == dtype
+        self._ck(self.lib.eve_nchw_to_nhwc(dt_code(dtype), N, C, H, W, cpad, self._p(self._f32(src, 'src')),
+                                           self._p(dst), self._stream()))
+        return dst
+
+    def nhwc_to_nchw(self, src, C):
+        N, H, W, cpad = src.shape
+        dst = torch.empty((N, C, H, W), dtype=torch.float32, device=src.device)
+        self._ck(self.lib.eve_nhwc_to_nchw(dt_code(src.dtype), N, C, H, W, cpad, self._p(src), self._p(dst),
+                                           self._stream()))
+        return dst
+
+    def cast(self, src, dtype):
+        if src.dtype == dtype:
+            return src
+        dst = torch.empty(src.shape, dtype=dtype, device=src.device)
+        self._ck(self.lib.eve_cast(dt_code(src.dtype), dt_code(dtype), src.numel(), self._p(src), self._p(dst),
+                                   self._stream()))
+        return dst
+
+    def pack_weights(self, w_ohwi_f32, dtype, want_ihwo=True):
+        Cout, KH, KW, Cin = w_ohwi_f32.shape
+        ohwi = torch.empty((Cout, KH, KW, Cin), dtype=dtype, device=w_ohwi_f32.device)
+        ihwo = torch.empty((Cin, KH, KW, Cout), dtype=dtype, device=w_ohwi_f32.device) if want_ihwo else None
+        self._ck(self.lib.eve_pack_weights(dt_code(dtype), Cout, KH * KW, Cin,
+                                           self._p(self._f32(w_ohwi_f32, 'weights')), self._p(ohwi),
+                                           self._p(ihwo), self._stream()))
+        return ohwi, ihwo
+
+    # ------------------------------------------------------------------ recurrent
+    def gru_scan_fwd(self, gi, whh_t, bhh, h0):
+        S, T, H3 = gi.shape
+        H = H3 // 3
+        dev = gi.device
+        hs = torch.empty((S, T, H), dtype=torch.float32, device=dev)
+        gates = torch.empty((S, T, H3), dtype=torch.float32, device=dev)
+        hn_pre = torch.empty((S, T, H), dtype=torch.float32, device=dev)
+        self._ck(self.lib.eve_gru_scan_fwd(S, T, H, self._p(self._f32(gi, 'gi')), self._p(whh_t), self._p(bhh),
+                                           self._p(h0), self._p(hs), self._p(gates), self._p(hn_pre),
+                                           self._stream()))
+        return hs, gates, hn_pre
+
+    def gru_scan_bwd(self, dhs, whh, h0, hs, gates, hn_pre, want_dh0):
+        S, T, H = dhs.shape
+        dev = dhs.device
+        dgi = torch.empty((S, T, 3 * H), dtype=torch.float32, device=dev)
+        dgh = torch.empty((S, T, 3 * H), dtype=torch.float32, device=dev)
+        dh0 = torch.empty((S, H), dtype=torch.float32, device=dev) if want_dh0 else None
+        self._ck(self.lib.eve_gru_scan_bwd(S, T, H, self._p(dhs), self._p(whh), self._p(h0), self._p(hs),
+                                           self._p(gates), self._p(hn_pre), self._p(dgi), self._p(dgh),
+                                           self._p(dh0), self._stream()))
+        return dgi, dgh, dh0
+
+    def cgru_gates1(self, g1, h):
+        C = h.shape[-1]
+        P = h.numel() // C
+        ru = torch.empty_like(g1)
+        rh = torch.empty_like(h)
+        self._ck(self.lib.eve_cgru_gates1(dt_code(h.dtype), P, C, self._p(g1), self._p(h), self._p(ru),
+                                          self._p(rh), self._stream()))
+        return ru, rh
+
+    def cgru_gates2(self, g2, ru, h):
+        C = h.shape[-1]
+        P = h.numel() // C
+        o = torch.empty_like(h)
+        hnew = torch.empty_like(h)
+        self._ck(self.lib.eve_cgru_gates2(dt_code(h.dtype), P, C, self._p(g2), self._p(ru), self._p(h),
+                                          self._p(o), self._p(hnew), self._stream()))
+        return o, hnew
+
+    def cgru_gates2_bwd(self, dhnew, ru, h, o):
+        C = h.shape[-1]
+        P = h.numel() // C
+        dg2 = torch.empty_like(h)
+        dru = torch.empty_like(ru)
+        dh = torch.empty_like(h)
+        self._ck(self.lib.eve_cgru_gates2_bwd(dt_code(h.dtype), P, C, self._p(dhnew), self._p(ru), self._p(h),
+                                              self._p(o), self._p(dg2), self._p(dru), self._p(dh),
+                                              self._stream()))
+        return dg2, dru, dh
+
+    def cgru_gates1_bwd(self, drh, dru, ru, h):
+        C = h.shape[-1]
+        P = h.numel() // C
+        dg1 = torch.empty_like(ru)
+        dh = torch.empty_like(h)
+        self._ck(self.lib.eve_cgru_gates1_bwd(dt_code(h.dtype), P, C, self._p(drh), self._p(dru), self._p(ru),
+                                              self._p(h), self._p(dg1), self._p(dh), self._stream()))
+        return dg1, dh
+
+    def clstm_gates_fwd(self, gates, c_prev):
+        C = c_prev.shape[-1]
+        P = c_prev.numel() // C
+        h = torch.empty_like(c_prev)
+        c = torch.empty_like(c_prev)
+        self._ck(self.lib.eve_clstm_gates_fwd(dt_code(c_prev.dtype), P, C, self._p(gates), self._p(c_prev),
+                                              self._p(h), self._p(c), self._stream()))
+        return h, c
+
+    # ------------------------------------------------------------------ optimiser
+    def sumsq(self, g, out):
+        self._ck(self.lib.eve_sumsq(g.numel(), self._p(self._f32(g, 'g')), self._p(out), self._stream()))
+        return out
+
+    def adam_step(self, p, g, m, v, sumsq, max_norm, gscale, lr, beta1, beta2, eps, weight_decay, step):
+        self._ck(self.lib.eve_adam_step(p.numel(), self._p(p), self._p(g), self._p(m), self._p(v),
+                                        self._p(sumsq), max_norm, gscale, lr, beta1, beta2, eps,
+                                        weight_decay, step, self._stream()))
+
+
+_default = None
+
+
+def default_kernels():
+    """The process-wide HipKernels; raises (no fallback) if libeve_hip.so is not built."""
+    global _default
+    if _default is None:
+        _default = HipKernels()
+    return _default
+
+
+def set_default_kernels(k):
+    """Test hook: tests/ installs a torch-CPU stand-in to exercise the HOST logic without a GPU."""
+    global _default
+    _default = k

@@ -1,0 +1,298 @@
+"""Differentiable operators of the hot path: torch.autograd.Function shells whose forward AND
+backward are HIP kernels launched through the C ABI (eve_amd/kernels.py -> include/eve_hip.h).
+
+All activations here are NHWC in the compute dtype.  Autograd is used only to order the backward
+launches and to sum gradient fan-in; no arithmetic on the path is done by ATen.
+"""
+import torch
+
+from . import kernels as K
+from .kernels import (ACT_LEAKY, ACT_NONE, ACT_RELU, ACT_SELU, ACT_SIGMOID, ACT_TANH,  # noqa: F401
+                      default_kernels)
+
+
+class PackedWeight(object):
+    """Compute-dtype copies of one conv/linear weight: OHWI for forward/wgrad, IHWO for dgrad.
+
+    `param` has the reference's OIHW (or [out, in]) SHAPE; its memory may already be OHWI (the
+    flat-parameter harness stores it that way), in which case no permute copy is made."""
+
+    __slots__ = ('ohwi', 'ihwo', 'shape_oihw')
+
+    def __init__(self, param, dtype, cin_pad=None, cout_pad=None, want_ihwo=True):
+        k = default_kernels()
+        w = param.detach()
+        if w.dim() == 2:
+            w = w.view(w.shape[0], w.shape[1], 1, 1)
+        self.shape_oihw = tuple(w.shape)
+        w = w.permute(0, 2, 3, 1)                      # OHWI view
+        if cin_pad is not None and cin_pad != w.shape[3]:
+            w = torch.nn.functional.pad(w, (0, cin_pad - w.shape[3]))
+        if cout_pad is not None and cout_pad != w.shape[0]:
+            w = torch.nn.functional.pad(w, (0, 0, 0, 0, 0, 0, 0, cout_pad - w.shape[0]))
+        w = w.contiguous().float()
+        self.ohwi, self.ihwo = k.pack_weights(w, dtype, want_ihwo=want_ihwo)
+
+
+class Conv2dFn(torch.autograd.Function):
+    """y = act(conv(x, W) + b).  x NHWC; `weight` has shape [Cout, Cin, KH, KW] (or [out, in]);
+    `pack` holds the packed copies (possibly with zero-padded Cin/Cout)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, pack, stride, pad, epi_act):
+        k = default_kernels()
+        b = bias
+        cout_p = pack.ohwi.shape[0]
+        if bias is not None:
+            b = bias.detach().float()
+            if b.numel() != cout_p:
+                b = torch.nn.functional.pad(b, (0, cout_p - b.numel()))
+            b = b.contiguous()
+        y = k.conv2d_fwd(x, pack.ohwi, b, stride, pad, epi_act)
+        ctx.pack, ctx.stride, ctx.pad, ctx.epi_act = pack, stride, pad, epi_act
+        ctx.has_bias = bias is not None
+        ctx.wshape = tuple(weight.shape)
+        ctx.save_for_backward(x, y if epi_act != ACT_NONE else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        k = default_kernels()
+        x, y = ctx.saved_tensors
+        pack = ctx.pack
+        dy = dy.contiguous()
+        if ctx.epi_act != ACT_NONE:
+            dy = k.act_bwd(dy, y, ctx.epi_act)
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = k.conv2d_dgrad(dy, pack.ihwo, (x.shape[1], x.shape[2]), ctx.stride, ctx.pad)
+        if ctx.needs_input_grad[1]:
+            cout_p, KH, KW, cin_p = pack.ohwi.shape
+            dwp = torch.zeros((cout_p, KH, KW, cin_p), dtype=torch.float32, device=x.device)
+            k.conv2d_wgrad(x, dy, KH, KW, ctx.stride, ctx.pad, dwp)
+            O, I = pack.shape_oihw[0], pack.shape_oihw[1]
+            dw = dwp[:O, :, :, :I].permute(0, 3, 1, 2)          # OIHW-shaped view of OHWI memory
+            if len(ctx.wshape) == 2:
+                dw = dw.reshape(ctx.wshape)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            cout_p = pack.ohwi.shape[0]
+            dbp = torch.zeros((cout_p,), dtype=torch.float32, device=x.device)
+            k.bias_grad(dy, dbp)
+            db = dbp[:pack.shape_oihw[0]]
+        return dx, dw, db, None, None, None, None
+
+
+def conv2d(x, weight, bias, pack, stride=1, pad=0, act=ACT_NONE):
+    return Conv2dFn.apply(x, weight, bias, pack, stride, pad, act)
+
+
+def linear(x2d, weight, bias, pack, act=ACT_NONE):
+    """x2d: [M, Cin_padded] -> [M, Cout_padded] through the same implicit-GEMM kernel (1x1 conv)."""
+    M, C = x2d.shape
+    y = Conv2dFn.apply(x2d.view(M, 1, 1, C), weight, bias, pack, 1, 0, act)
+    return y.view(M, y.shape[-1])
+
+
+class InstNormActFn(torch.autograd.Function):
+    """y = act(gamma * IN(x) + beta + res);  gamma/beta/res optional.  eps 1e-5, biased variance."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, res, act, eps):
+        k = default_kernels()
+        mr = k.instnorm_stats(x, eps)
+        g = gamma.detach().float().contiguous() if gamma is not None else None
+        b = beta.detach().float().contiguous() if beta is not None else None
+        y = k.instnorm_act_fwd(x, mr, g, b, res, act)
+        ctx.act, ctx.has_res, ctx.has_affine = act, res is not None, gamma is not None
+        ctx.save_for_backward(x, y, mr, g)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        k = default_kernels()
+        x, y, mr, g = ctx.saved_tensors
+        dx, dres, sums = k.instnorm_act_bwd(dy.contiguous(), y, x, mr, g, ctx.act,
+                                            ctx.has_res and ctx.needs_input_grad[3])
+        dgamma = dbeta = None
+        if ctx.has_affine:
+            s = sums.sum(dim=0)                 # [C, 2]: tiny N-reduction of per-plane partials
+            dbeta, dgamma = s[:, 0], s[:, 1]
+        return dx, dgamma, dbeta, dres, None, None
+
+
+def instnorm_act(x, gamma=None, beta=None, res=None, act=ACT_NONE, eps=1e-5):
+    return InstNormActFn.apply(x, gamma, beta, res, act, eps)
+
+
+class AddFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        return default_kernels().add(a, b)
+
+    @staticmethod
+    def backward(ctx, d):
+        return d, d
+
+
+def add(a, b):
+    return AddFn.apply(a, b)
+
+
+class MaxPool3x3s2Fn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        y, idx = default_kernels().maxpool3x3s2_fwd(x)
+        ctx.in_hw = (x.shape[1], x.shape[2])
+        ctx.save_for_backward(idx)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (idx,) = ctx.saved_tensors
+        return default_kernels().maxpool3x3s2_bwd(dy.contiguous(), idx, ctx.in_hw)
+
+
+class AvgPoolFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        ctx.hw = (x.shape[1], x.shape[2])
+        return default_kernels().avgpool_fwd(x)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return default_kernels().avgpool_bwd(dy.contiguous(), ctx.hw)
+
+
+class AdaptiveMaxPoolFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, out_hw):
+        y, idx = default_kernels().adaptive_maxpool_fwd(x, out_hw)
+        ctx.in_hw = (x.shape[1], x.shape[2])
+        ctx.save_for_backward(idx)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (idx,) = ctx.saved_tensors
+        return default_kernels().adaptive_maxpool_bwd(dy.contiguous(), idx, ctx.in_hw), None
+
+
+class BilinearFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, out_hw):
+        ctx.in_hw = (x.shape[1], x.shape[2])
+        return default_kernels().bilinear_fwd(x, out_hw)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return default_kernels().bilinear_bwd(dy.contiguous(), ctx.in_hw), None
+
+
+class ToNHWCFn(torch.autograd.Function):
+    """float NCHW (the reference's layout at the module boundary) -> NHWC compute dtype, channels
+    zero-padded to a 16-byte multiple."""
+
+    @staticmethod
+    def forward(ctx, x_nchw, dtype, cpad):
+        ctx.C = x_nchw.shape[1]
+        return default_kernels().nchw_to_nhwc(x_nchw.contiguous().float(), dtype, cpad)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return default_kernels().nhwc_to_nchw(dy.contiguous(), ctx.C), None, None
+
+
+class FromNHWCFn(torch.autograd.Function):
+    """NHWC compute dtype -> float NCHW, keeping the first C channels."""
+
+    @staticmethod
+    def forward(ctx, x, C):
+        ctx.dtype, ctx.cpad = x.dtype, x.shape[3]
+        return default_kernels().nhwc_to_nchw(x, C)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return default_kernels().nchw_to_nhwc(dy.contiguous().float(), ctx.dtype, ctx.cpad), None
+
+
+class CastFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, dtype):
+        ctx.src = x.dtype
+        return default_kernels().cast(x.contiguous(), dtype)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return default_kernels().cast(dy.contiguous(), ctx.src), None
+
+
+def cast(x, dtype):
+    return x if x.dtype == dtype else CastFn.apply(x, dtype)
+
+
+class GRUScanFn(torch.autograd.Function):
+    """hs[s, t] = GRUCell step over t for every sequence s, given gi = W_ih x + b_ih for all steps.
+    dW_hh / db_hh come from the batched wgrad / bias-grad kernels over all (s, t)."""
+
+    @staticmethod
+    def forward(ctx, gi, w_hh, b_hh, h0):
+        k = default_kernels()
+        whh = w_hh.detach().float().contiguous()
+        whh_t = whh.t().contiguous()
+        bhh = b_hh.detach().float().contiguous()
+        h0c = h0.detach().float().contiguous() if h0 is not None else None
+        hs, gates, hn_pre = k.gru_scan_fwd(gi.contiguous(), whh_t, bhh, h0c)
+        ctx.has_h0 = h0 is not None
+        ctx.save_for_backward(whh, h0c, hs, gates, hn_pre)
+        return hs
+
+    @staticmethod
+    def backward(ctx, dhs):
+        k = default_kernels()
+        whh, h0, hs, gates, hn_pre = ctx.saved_tensors
+        S, T, H = hs.shape
+        dgi, dgh, dh0 = k.gru_scan_bwd(dhs.contiguous().float(), whh, h0, hs, gates, hn_pre,
+                                       ctx.has_h0 and ctx.needs_input_grad[3])
+        dw = db = None
+        if ctx.needs_input_grad[1]:
+            first = h0 if h0 is not None else torch.zeros((S, H), dtype=torch.float32, device=hs.device)
+            h_prev = torch.cat([first.unsqueeze(1), hs[:, :-1]], dim=1).contiguous()   # [S, T, H]
+            dwp = torch.zeros((3 * H, 1, 1, H), dtype=torch.float32, device=hs.device)
+            k.conv2d_wgrad(h_prev.view(S * T, 1, 1, H), dgh.view(S * T, 1, 1, 3 * H), 1, 1, 1, 0, dwp)
+            dw = dwp.view(3 * H, H)
+        if ctx.needs_input_grad[2]:
+            db = torch.zeros((3 * H,), dtype=torch.float32, device=hs.device)
+            k.bias_grad(dgh.view(S * T, 3 * H), db)
+        return dgi, dw, db, dh0
+
+
+class CGRUGates1Fn(torch.autograd.Function):
+    """(ru, rh) = (sigmoid(g1), sigmoid(g1[..., :C]) * h)   -- common.py:410-411"""
+
+    @staticmethod
+    def forward(ctx, g1, h):
+        ru, rh = default_kernels().cgru_gates1(g1, h)
+        ctx.save_for_backward(ru, h)
+        return ru, rh
+
+    @staticmethod
+    def backward(ctx, dru, drh):
+        ru, h = ctx.saved_tensors
+        dg1, dh = default_kernels().cgru_gates1_bwd(drh.contiguous(), dru.contiguous(), ru, h)
+        return dg1, dh
+
+
+class CGRUGates2Fn(torch.autograd.Function):
+    """h' = (1 - u) * tanh(g2) + u * h   -- common.py:413-414.  `ru` only contributes through u."""
+
+    @staticmethod
+    def forward(ctx, g2, ru, h):
+        o, hnew = default_kernels().cgru_gates2(g2, ru, h)
+        ctx.save_for_backward(ru, h, o)
+        return hnew
+
+    @staticmethod
+    def backward(ctx, dhnew):
+        ru, h, o = ctx.saved_tensors
+        dg2, dru, dh = default_kernels().cgru_gates2_bwd(dhnew.contiguous(), ru, h, o)
+        return dg2, dru, dh

@@ -1,0 +1,196 @@
+/* eve_hip.h -- C ABI of libeve_hip.so: the MI355X (gfx950) kernels behind the EVE hot path
+ * (EyeNet encoder + RefineNet point-of-gaze refiner, /root/reference/src/models/).
+ *
+ * The reference has no native layer (it is 100% PyTorch); what each entry point replaces is
+ * therefore an ATen op site inside the reference's Python modules, cited per function as
+ * `file:line` relative to /root/reference.  A binding (ctypes / cffi / a torch extension) passes
+ *   - raw DEVICE pointers (activations NHWC, element type selected by `dtype`),
+ *   - explicit shapes,
+ *   - the HIP stream to launch on (a hipStream_t passed as void*; NULL = the null stream).
+ * No entry point allocates, synchronises the device, or keeps global state.  Every function
+ * returns 0 on success and a non-zero code on failure; eve_last_error() returns a thread-local
+ * message for the last failure.  The Python side (eve_amd/_lib.py) raises RuntimeError from it.
+ *
+ * Layout conventions
+ *   activations   [N][H][W][C]   (NHWC), C a multiple of 4 (f32) / 8 (bf16): 16-byte channel vectors
+ *   conv weights  forward : [Cout][KH][KW][Cin]  ("OHWI", K = KH*KW*Cin contiguous per output channel)
+ *                 dgrad   : [Cin][KH][KW][Cout]  ("IHWO")
+ *   statistics    float [N][C][2] = (mean, rstd) per instance-norm plane
+ *   weight / bias / affine gradients are always float and are ACCUMULATED into (caller zeroes them)
+ */
+#ifndef EVE_HIP_H_
+#define EVE_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EVE_ABI_VERSION 1
+
+typedef void* eve_stream_t; /* hipStream_t */
+
+enum { EVE_DT_F32 = 0, EVE_DT_BF16 = 1 };
+enum {
+    EVE_ACT_NONE = 0,
+    EVE_ACT_RELU = 1,    /* nn.ReLU          (eye_net trunk; refine_net.py:38 encoder blocks)   */
+    EVE_ACT_LEAKY = 2,   /* nn.LeakyReLU(.01) (refine_net.py:108,113,221)                        */
+    EVE_ACT_SELU = 3,    /* nn.SELU          (eye_net.py:54,77,83,89)                            */
+    EVE_ACT_TANH = 4,    /* nn.Tanh / torch.tanh (eye_net.py:85; common.py:351,380,413)          */
+    EVE_ACT_SIGMOID = 5  /* nn.Sigmoid / torch.sigmoid (refine_net.py:223; common.py:377-379,410) */
+};
+
+int eve_abi_version(void);
+const char* eve_last_error(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * Convolution as implicit GEMM on MFMA.  Replaces every nn.Conv2d / nn.Linear forward on the path:
+ * torchvision ResNet convs built at src/models/eye_net.py:48-50 and run at :106; nn.Linear at
+ * eye_net.py:51-56,81-92; nn.Conv2d at src/models/refine_net.py:48,52,61,214,217,221-222 and
+ * src/models/common.py:338,362,395-398.  A Linear is the KH=KW=1, IH=IW=1 case.
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct eve_conv_desc {
+    int dtype;               /* EVE_DT_* of x / w / y                                   */
+    int N, IH, IW, Cin;      /* x  : [N][IH][IW][Cin]                                   */
+    int OH, OW, Cout;        /* y  : [N][OH][OW][Cout]                                  */
+    int KH, KW, stride, pad; /* cross-correlation, zero padding                         */
+} eve_conv_desc;
+
+/* y = act(conv(x', w) + bias),  x' = pro_act(x * scale[n,c] + shift[n,c]) when in_scale_shift != NULL
+ * (float [N][Cin][2]; padding stays zero AFTER the transform), else x' = x.  bias may be NULL.    */
+int eve_conv2d_fwd(const eve_conv_desc* d, const void* x, const void* w_ohwi, const float* bias,
+                   int epi_act, const float* in_scale_shift, int pro_act, void* y,
+                   eve_stream_t stream);
+/* dx = conv_transpose(dy, w): gradient w.r.t. the conv INPUT.  w_ihwo is [Cin][KH][KW][Cout].    */
+int eve_conv2d_dgrad(const eve_conv_desc* d, const void* dy, const void* w_ihwo, void* dx,
+                     eve_stream_t stream);
+/* dw[Cout][KH][KW][Cin] (float, accumulated) += sum_m dy[m][co] * x'[m][(kh,kw,ci)]              */
+int eve_conv2d_wgrad(const eve_conv_desc* d, const void* x, const void* dy,
+                     const float* in_scale_shift, int pro_act, float* dw_ohwi, eve_stream_t stream);
+/* db[C] (float, accumulated) += sum over the M = N*OH*OW rows of dy[M][C]                         */
+int eve_bias_grad(int dtype, long long M, int C, const void* dy, float* db, eve_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Instance normalisation (+ optional affine, residual add, activation).  Replaces
+ * nn.InstanceNorm2d inside the ResNet (norm_layer at eye_net.py:50: eps 1e-5, biased variance, no
+ * affine, no running stats) with the following ReLU / residual add of BasicBlock.forward, and the
+ * affine InstanceNorm2d + activation pairs of refine_net.py:46-47,50-51,59-60,215-216.
+ * ------------------------------------------------------------------------------------------------ */
+/* mean_rstd[n][c] = (mean, 1/sqrt(var_biased + eps)) over the HW plane                            */
+int eve_instnorm_stats(int dtype, int N, int HW, int C, const void* x, float eps, float* mean_rstd,
+                       eve_stream_t stream);
+/* y = act(gamma[c] * (x - mean) * rstd + beta[c] + res);  gamma/beta/res may be NULL              */
+int eve_instnorm_act_fwd(int dtype, int N, int HW, int C, const void* x, const float* mean_rstd,
+                         const float* gamma, const float* beta, const void* res, int act, void* y,
+                         eve_stream_t stream);
+/* g = dy * act'(y);  dx = gamma*rstd*(g - mean_hw(g) - xhat*mean_hw(g*xhat));  dres = g (if != NULL);
+ * sums[n][c] = (sum_hw g, sum_hw g*xhat)  (reduce over n for dbeta / dgamma)                      */
+int eve_instnorm_act_bwd(int dtype, int N, int HW, int C, const void* dy, const void* y,
+                         const void* x, const float* mean_rstd, const float* gamma, int act,
+                         void* dx, void* dres, float* sums, eve_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Element-wise activation gradient: dx = dy * act'(y)  (for Linear/conv epilogue activations).
+ * ------------------------------------------------------------------------------------------------ */
+int eve_act_bwd(int dtype, long long n, const void* dy, const void* y, int act, void* dx,
+                eve_stream_t stream);
+/* out = a + b (same dtype), used for gradient fan-in of the residual / skip branches.             */
+int eve_add(int dtype, long long n, const void* a, const void* b, void* out, eve_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Pooling / resampling.  nn.MaxPool2d(3,2,1) and AdaptiveAvgPool2d(1) of the torchvision ResNet
+ * (eye_net.py:48,106); nn.AdaptiveMaxPool2d (refine_net.py:93) and nn.Upsample(bilinear,
+ * align_corners=False) (refine_net.py:101).
+ * ------------------------------------------------------------------------------------------------ */
+/* 3x3 / stride 2 / pad 1 max-pool; idx[n][oh][ow][c] (uint8) = kh*3+kw of the first maximum       */
+int eve_maxpool3x3s2_fwd(int dtype, int N, int IH, int IW, int C, const void* x, void* y,
+                         uint8_t* idx, eve_stream_t stream);
+int eve_maxpool3x3s2_bwd(int dtype, int N, int IH, int IW, int C, const void* dy,
+                         const uint8_t* idx, void* dx, eve_stream_t stream);
+/* mean over the HW plane: y[N][C]; and its gradient dx[n][hw][c] = dy[n][c] / HW                  */
+int eve_avgpool_fwd(int dtype, int N, int HW, int C, const void* x, void* y, eve_stream_t stream);
+int eve_avgpool_bwd(int dtype, int N, int HW, int C, const void* dy, void* dx, eve_stream_t stream);
+/* adaptive max-pool, window i = [floor(i*I/O), ceil((i+1)*I/O)); idx = flat ih*IW+iw (int32)       */
+int eve_adaptive_maxpool_fwd(int dtype, int N, int IH, int IW, int OH, int OW, int C, const void* x,
+                             void* y, int32_t* idx, eve_stream_t stream);
+int eve_adaptive_maxpool_bwd(int dtype, int N, int IH, int IW, int OH, int OW, int C,
+                             const void* dy, const int32_t* idx, void* dx, eve_stream_t stream);
+/* bilinear resize, align_corners=False, and its adjoint                                            */
+int eve_bilinear_fwd(int dtype, int N, int IH, int IW, int OH, int OW, int C, const void* x, void* y,
+                     eve_stream_t stream);
+int eve_bilinear_bwd(int dtype, int N, int IH, int IW, int OH, int OW, int C, const void* dy,
+                     void* dx, eve_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Layout / dtype plumbing at the module boundary (the reference hands NCHW float tensors:
+ * eye_net.py:100-103, refine_net.py:239-248).
+ * ------------------------------------------------------------------------------------------------ */
+/* dst[n][h][w][c < Cpad] = c < C ? src[n][c][h][w] : 0                                             */
+int eve_nchw_to_nhwc(int dtype_dst, int N, int C, int H, int W, int Cpad, const float* src_nchw,
+                     void* dst_nhwc, eve_stream_t stream);
+int eve_nhwc_to_nchw(int dtype_src, int N, int C, int H, int W, int Cpad, const void* src_nhwc,
+                     float* dst_nchw, eve_stream_t stream);
+/* float <-> dtype casts of flat buffers (weights to the compute dtype)                             */
+int eve_cast(int dtype_src, int dtype_dst, long long n, const void* src, void* dst,
+             eve_stream_t stream);
+/* OHWI float master weights -> OHWI and IHWO copies in the compute dtype (one pass)                */
+int eve_pack_weights(int dtype_dst, int Cout, int taps, int Cin, const float* w_ohwi, void* dst_ohwi,
+                     void* dst_ihwo, eve_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Recurrent cells.
+ * GRU scan: torch.nn.GRUCell applied over T steps (eye_net.py:69,125; state hand-over :116-133).
+ *   gi  : float [S][T][3H]  = W_ih x_t + b_ih for every step (batched GEMM done by the caller)
+ *   whh : float [3H][H] (the forward scan takes its transpose whh_t [H][3H]); bhh float [3H];
+ *   h0 float [S][H] or NULL (= zeros, eye_net.py:120-122)
+ *   hs  : float [S][T][H] all hidden states;  work: float [S][T][3H] (r, z, n) + [S][T][H] (hn) saved
+ * ------------------------------------------------------------------------------------------------ */
+int eve_gru_scan_fwd(int S, int T, int H, const float* gi, const float* whh_t, const float* bhh,
+                     const float* h0, float* hs, float* gates, float* hn_pre, eve_stream_t stream);
+/* given dhs [S][T][H] (gradient on every h_t): dgi [S][T][3H], dgh [S][T][3H] (for dW_hh/db_hh by
+ * GEMM), dh0 [S][H] (may be NULL)                                                                  */
+int eve_gru_scan_bwd(int S, int T, int H, const float* dhs, const float* whh, const float* h0,
+                     const float* hs, const float* gates, const float* hn_pre, float* dgi, float* dgh,
+                     float* dh0, eve_stream_t stream);
+
+/* conv-GRU gate math of CGRUCell.forward (common.py:409-414), NHWC, C = hidden size:
+ *   step 1: (r, u) = sigmoid(g1[..., 0:C], g1[..., C:2C]);  rh = r * h
+ *   step 2: o = tanh(g2);  h' = (1 - u) * o + u * h                                                */
+int eve_cgru_gates1(int dtype, long long P, int C, const void* g1, const void* h, void* ru, void* rh,
+                    eve_stream_t stream);
+int eve_cgru_gates2(int dtype, long long P, int C, const void* g2, const void* ru, const void* h,
+                    void* o, void* hnew, eve_stream_t stream);
+/* backward of step 2: given dh' -> dg2 (pre-tanh, [P][C]); dru [P][2C] = (0, gradient on the
+ * post-sigmoid update gate); dh [P][C] = direct path u * dh'                                        */
+int eve_cgru_gates2_bwd(int dtype, long long P, int C, const void* dhnew, const void* ru,
+                        const void* h, const void* o, void* dg2, void* dru, void* dh,
+                        eve_stream_t stream);
+/* backward of step 1: given d(rh) [P][C], dru [P][2C] and saved ru, h -> dg1 (pre-sigmoid, [P][2C])
+ * and dh [P][C] = d(rh) * r                                                                         */
+int eve_cgru_gates1_bwd(int dtype, long long P, int C, const void* drh, const void* dru,
+                        const void* ru, const void* h, void* dg1, void* dh, eve_stream_t stream);
+
+/* conv-LSTM gate math of CLSTMCell.forward (common.py:376-385), forward only: gates [P][4C] in the
+ * reference's chunk order (in, forget, out, cell); c' = sig(f)*c + sig(i)*tanh(g); h' = sig(o)*tanh(c').
+ * The reference never back-propagates through it (refine_net.py:168-174 drops tuple states).         */
+int eve_clstm_gates_fwd(int dtype, long long P, int C, const void* gates, const void* c_prev, void* h,
+                        void* c, eve_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Optimiser step over flat float buffers.  torch.optim.Adam with coupled L2 weight decay
+ * (src/train.py:49-55) after nn.utils.clip_grad_norm_ (src/core/training.py:492-498).
+ * ------------------------------------------------------------------------------------------------ */
+/* out[0] += sum g^2 (caller zeroes out[0]; take sqrt on the host or in eve_adam_step)              */
+int eve_sumsq(long long n, const float* g, float* out, eve_stream_t stream);
+/* clip factor c = min(1, max_norm / (sqrt(*sumsq) * gscale + 1e-6)) if sumsq != NULL else 1;
+ * g' = c * gscale * g + wd * p;  m,v Adam moments;  p -= lr * mhat / (sqrt(vhat) + eps)           */
+int eve_adam_step(long long n, float* p, const float* g, float* m, float* v, const float* sumsq,
+                  float max_norm, float gscale, float lr, float beta1, float beta2, float eps,
+                  float weight_decay, int step, eve_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EVE_HIP_H_ */

@@ -1,0 +1,233 @@
+"""A torch-CPU stand-in with the SAME tensor-level interface as eve_amd.kernels.HipKernels.
+
+TEST INFRASTRUCTURE ONLY.  It lets the `-m "not gpu"` suite exercise the HOST logic of eve_amd
+(autograd wiring, weight packing, padding, module plumbing, state_dict contract, data-parallel
+bucketing) in a container without a GPU.  It is never importable from the product package and is not
+a fallback: eve_amd raises when libeve_hip.so is missing.  Each method restates, with ATen ops, the
+contract documented in include/eve_hip.h; the GPU suite checks the HIP kernels against the same
+contracts independently.
+"""
+import torch
+import torch.nn.functional as F
+
+ACT_NONE, ACT_RELU, ACT_LEAKY, ACT_SELU, ACT_TANH, ACT_SIGMOID = range(6)
+
+
+def act_fwd(z, act):
+    return {ACT_NONE: lambda v: v, ACT_RELU: torch.relu, ACT_LEAKY: lambda v: F.leaky_relu(v, 0.01),
+            ACT_SELU: F.selu, ACT_TANH: torch.tanh, ACT_SIGMOID: torch.sigmoid}[act](z)
+
+
+def act_grad_from_out(y, act):
+    a, s = 1.6732632423543772, 1.0507009873554805
+    if act == ACT_RELU:
+        return (y > 0).to(y.dtype)
+    if act == ACT_LEAKY:
+        return torch.where(y > 0, torch.ones_like(y), torch.full_like(y, 0.01))
+    if act == ACT_SELU:
+        return torch.where(y > 0, torch.full_like(y, s), y + s * a)
+    if act == ACT_TANH:
+        return 1 - y * y
+    if act == ACT_SIGMOID:
+        return y * (1 - y)
+    return torch.ones_like(y)
+
+
+def nchw(x):
+    return x.permute(0, 3, 1, 2).float()
+
+
+def nhwc(x, dtype):
+    return x.permute(0, 2, 3, 1).contiguous().to(dtype)
+
+
+class FakeKernels(object):
+    name = 'fake-cpu'
+
+    def _pro(self, x, ss, pro_act):
+        if ss is None:
+            return x.float()
+        return act_fwd(x.float() * ss[:, None, None, :, 0] + ss[:, None, None, :, 1], pro_act)
+
+    def conv2d_fwd(self, x, w_ohwi, bias, stride, pad, epi_act=ACT_NONE, ss=None, pro_act=ACT_NONE):
+        xin = self._pro(x, ss, pro_act).to(x.dtype)
+        y = F.conv2d(nchw(xin), w_ohwi.permute(0, 3, 1, 2).float(), bias, stride, pad)
+        return nhwc(act_fwd(y, epi_act), x.dtype)
+
+    def conv2d_dgrad(self, dy, w_ihwo, in_hw, stride, pad):
+        w = w_ihwo.permute(3, 0, 1, 2).float()          # [Cout, Cin, KH, KW]
+        N = dy.shape[0]
+        dx = torch.nn.grad.conv2d_input((N, w.shape[1], in_hw[0], in_hw[1]), w, nchw(dy), stride, pad)
+        return nhwc(dx, dy.dtype)
+
+    def conv2d_wgrad(self, x, dy, KH, KW, stride, pad, dw_ohwi, ss=None, pro_act=ACT_NONE):
+        xin = self._pro(x, ss, pro_act).to(x.dtype)
+        Cout, Cin = dy.shape[3], x.shape[3]
+        dw = torch.nn.grad.conv2d_weight(nchw(xin), (Cout, Cin, KH, KW), nchw(dy), stride, pad)
+        dw_ohwi += dw.permute(0, 2, 3, 1)
+        return dw_ohwi
+
+    def bias_grad(self, dy, db):
+        db += dy.float().reshape(-1, dy.shape[-1]).sum(0)
+        return db
+
+    def instnorm_stats(self, x, eps=1e-5):
+        xf = x.float()
+        mean = xf.mean(dim=(1, 2))
+        var = xf.var(dim=(1, 2), unbiased=False)
+        return torch.stack([mean, torch.rsqrt(var + eps)], dim=-1)
+
+    def instnorm_act_fwd(self, x, mr, gamma, beta, res, act):
+        z = (x.float() - mr[:, None, None, :, 0]) * mr[:, None, None, :, 1]
+        if gamma is not None:
+            z = z * gamma + beta
+        if res is not None:
+            z = z + res.float()
+        return act_fwd(z, act).to(x.dtype)
+
+    def instnorm_act_bwd(self, dy, y, x, mr, gamma, act, want_dres):
+        g = dy.float()
+        if act != ACT_NONE:
+            g = g * act_grad_from_out(y.float(), act)
+        xhat = (x.float() - mr[:, None, None, :, 0]) * mr[:, None, None, :, 1]
+        s1 = g.sum(dim=(1, 2))
+        s2 = (g * xhat).sum(dim=(1, 2))
+        hw = x.shape[1] * x.shape[2]
+        k = mr[:, None, None, :, 1] * (gamma if gamma is not None else 1.0)
+        dx = k * (g - s1[:, None, None] / hw - xhat * s2[:, None, None] / hw)
+        return dx.to(x.dtype), (g.to(x.dtype) if want_dres else None), torch.stack([s1, s2], dim=-1)
+
+    def act_bwd(self, dy, y, act):
+        return (dy.float() * act_grad_from_out(y.float(), act)).to(dy.dtype)
+
+    def add(self, a, b):
+        return (a.float() + b.float()).to(a.dtype)
+
+    def maxpool3x3s2_fwd(self, x):
+        y, idx = F.max_pool2d(nchw(x), 3, 2, 1, return_indices=True)
+        return nhwc(y, x.dtype), nhwc(idx, torch.int64)
+
+    def maxpool3x3s2_bwd(self, dy, idx, in_hw):
+        N, OH, OW, C = dy.shape
+        dx = torch.zeros((N, C, in_hw[0] * in_hw[1]))
+        dx.scatter_add_(2, idx.permute(0, 3, 1, 2).reshape(N, C, -1), nchw(dy).reshape(N, C, -1))
+        return nhwc(dx.view(N, C, in_hw[0], in_hw[1]), dy.dtype)
+
+    def avgpool_fwd(self, x):
+        return x.float().mean(dim=(1, 2)).to(x.dtype)
+
+    def avgpool_bwd(self, dy, hw):
+        N, C = dy.shape
+        return (dy.float()[:, None, None, :] / (hw[0] * hw[1])).expand(N, hw[0], hw[1], C).contiguous().to(dy.dtype)
+
+    def adaptive_maxpool_fwd(self, x, out_hw):
+        y, idx = F.adaptive_max_pool2d(nchw(x), out_hw, return_indices=True)
+        return nhwc(y, x.dtype), nhwc(idx, torch.int64)
+
+    def adaptive_maxpool_bwd(self, dy, idx, in_hw):
+        return self.maxpool3x3s2_bwd(dy, idx, in_hw)
+
+    def bilinear_fwd(self, x, out_hw):
+        return nhwc(F.interpolate(nchw(x), size=out_hw, mode='bilinear', align_corners=False), x.dtype)
+
+    def bilinear_bwd(self, dy, in_hw):
+        N, OH, OW, C = dy.shape
+        probe = torch.zeros((N, C, in_hw[0], in_hw[1]), requires_grad=True)
+        out = F.interpolate(probe, size=(OH, OW), mode='bilinear', align_corners=False)
+        (dx,) = torch.autograd.grad(out, probe, nchw(dy))
+        return nhwc(dx, dy.dtype)
+
+    def nchw_to_nhwc(self, src, dtype, cpad=None, out=None):
+        N, C, H, W = src.shape
+        cpad = cpad or C
+        dst = torch.zeros((N, H, W, cpad), dtype=dtype) if out is None else out
+        dst.zero_()
+        dst[..., :C] = src.permute(0, 2, 3, 1).to(dtype)
+        return dst
+
+    def nhwc_to_nchw(self, src, C):
+        return src[..., :C].permute(0, 3, 1, 2).float().contiguous()
+
+    def cast(self, src, dtype):
+        return src.to(dtype)
+
+    def pack_weights(self, w_ohwi_f32, dtype, want_ihwo=True):
+        ohwi = w_ohwi_f32.to(dtype).contiguous()
+        ihwo = w_ohwi_f32.permute(3, 1, 2, 0).to(dtype).contiguous() if want_ihwo else None
+        return ohwi, ihwo
+
+    def gru_scan_fwd(self, gi, whh_t, bhh, h0):
+        S, T, H3 = gi.shape
+        H = H3 // 3
+        h = torch.zeros((S, H)) if h0 is None else h0
+        hs, gates, hn_pre = [], [], []
+        for t in range(T):
+            gh = h @ whh_t + bhh
+            r = torch.sigmoid(gi[:, t, :H] + gh[:, :H])
+            z = torch.sigmoid(gi[:, t, H:2 * H] + gh[:, H:2 * H])
+            n = torch.tanh(gi[:, t, 2 * H:] + r * gh[:, 2 * H:])
+            h = (1 - z) * n + z * h
+            hs.append(h); gates.append(torch.cat([r, z, n], 1)); hn_pre.append(gh[:, 2 * H:])
+        return torch.stack(hs, 1), torch.stack(gates, 1), torch.stack(hn_pre, 1)
+
+    def gru_scan_bwd(self, dhs, whh, h0, hs, gates, hn_pre, want_dh0):
+        S, T, H = dhs.shape
+        dh = torch.zeros((S, H))
+        dgi = torch.zeros((S, T, 3 * H)); dgh = torch.zeros((S, T, 3 * H))
+        for t in range(T - 1, -1, -1):
+            d = dh + dhs[:, t]
+            r, z, n = gates[:, t, :H], gates[:, t, H:2 * H], gates[:, t, 2 * H:]
+            hp = hs[:, t - 1] if t > 0 else (h0 if h0 is not None else torch.zeros((S, H)))
+            dn = d * (1 - z) * (1 - n * n)
+            dz = d * (hp - n) * z * (1 - z)
+            dr = dn * hn_pre[:, t] * r * (1 - r)
+            dgi[:, t] = torch.cat([dr, dz, dn], 1)
+            dgh[:, t] = torch.cat([dr, dz, dn * r], 1)
+            dh = d * z + dgh[:, t] @ whh
+        return dgi, dgh, (dh if want_dh0 else None)
+
+    def cgru_gates1(self, g1, h):
+        C = h.shape[-1]
+        ru = torch.sigmoid(g1.float())
+        return ru.to(h.dtype), (ru[..., :C] * h.float()).to(h.dtype)
+
+    def cgru_gates2(self, g2, ru, h):
+        C = h.shape[-1]
+        o = torch.tanh(g2.float())
+        u = ru.float()[..., C:]
+        return o.to(h.dtype), ((1 - u) * o + u * h.float()).to(h.dtype)
+
+    def cgru_gates2_bwd(self, dhnew, ru, h, o):
+        C = h.shape[-1]
+        d, u, of = dhnew.float(), ru.float()[..., C:], o.float()
+        dg2 = d * (1 - u) * (1 - of * of)
+        dru = torch.cat([torch.zeros_like(d), d * (h.float() - of)], dim=-1)
+        return dg2.to(h.dtype), dru.to(h.dtype), (d * u).to(h.dtype)
+
+    def cgru_gates1_bwd(self, drh, dru, ru, h):
+        C = h.shape[-1]
+        r, u = ru.float()[..., :C], ru.float()[..., C:]
+        d = drh.float()
+        dg1 = torch.cat([d * h.float() * r * (1 - r), dru.float()[..., C:] * u * (1 - u)], dim=-1)
+        return dg1.to(h.dtype), (d * r).to(h.dtype)
+
+    def clstm_gates_fwd(self, gates, c_prev):
+        i, f, o, g = gates.float().chunk(4, dim=-1)
+        c = torch.sigmoid(f) * c_prev.float() + torch.sigmoid(i) * torch.tanh(g)
+        return (torch.sigmoid(o) * torch.tanh(c)).to(c_prev.dtype), c.to(c_prev.dtype)
+
+    def sumsq(self, g, out):
+        out += (g.double() ** 2).sum().float()
+        return out
+
+    def adam_step(self, p, g, m, v, sumsq, max_norm, gscale, lr, beta1, beta2, eps, weight_decay, step):
+        clip = gscale
+        if sumsq is not None:
+            total = float(sumsq.sqrt()) * gscale
+            clip = gscale * min(1.0, max_norm / (total + 1e-6))
+        gi = clip * g + weight_decay * p
+        m.mul_(beta1).add_(gi, alpha=1 - beta1)
+        v.mul_(beta2).addcmul_(gi, gi, value=1 - beta2)
+        bc1 = 1 - beta1 ** step
+        bc2 = (1 - beta2 ** step) ** 0.5
+        p.sub_((lr / bc1) * m / (v.sqrt() / bc2 + eps))

@@ -1,0 +1,270 @@
+"""GPU: every HIP kernel, called through the C ABI (eve_amd.kernels.HipKernels -> libeve_hip.so),
+against an independent ATen restatement of its contract (tests/fake_kernels.py run on the CPU).
+
+float32 kernels must agree to float32 round-off (the f32 MFMA is an exact fmaf chain);
+bfloat16 kernels are compared at bf16 resolution with inputs pre-rounded to bf16 on both sides.
+"""
+import pytest
+import torch
+
+from fake_kernels import FakeKernels
+
+pytestmark = pytest.mark.gpu
+
+DTYPES = [torch.float32, torch.bfloat16]
+
+
+@pytest.fixture(scope='module')
+def hip():
+    from eve_amd.kernels import HipKernels
+    assert torch.cuda.is_available(), 'GPU suite needs a GPU'
+    return HipKernels()
+
+
+@pytest.fixture(scope='module')
+def ref():
+    return FakeKernels()
+
+
+def rnd(shape, dtype, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(shape, generator=g) * scale).to(dtype)
+
+
+def dev(t):
+    return None if t is None else t.cuda()
+
+
+def close(got, want, dtype, what, scale=None):
+    got, want = got.detach().float().cpu(), want.detach().float().cpu()
+    assert got.shape == want.shape, '%s: shape %s vs %s' % (what, got.shape, want.shape)
+    assert torch.isfinite(got).all(), '%s: non-finite values' % what
+    s = float(want.abs().max()) if scale is None else scale
+    tol = (3e-5 if dtype == torch.float32 else 1.6e-2) * max(s, 1e-6)
+    err = float((got - want).abs().max())
+    assert err <= tol, '%s: max|diff| %.3e > tol %.3e (scale %.3e)' % (what, err, tol, s)
+
+
+CONV_CASES = [
+    # N, IH, IW, Cin, Cout, K, stride, pad
+    (3, 32, 32, 64, 64, 3, 1, 1),       # layer1
+    (2, 32, 32, 64, 128, 3, 2, 1),      # layerX.0 conv1 (stride 2)
+    (2, 32, 32, 64, 128, 1, 2, 0),      # down-sample 1x1 / 2
+    (5, 4, 4, 512, 512, 3, 1, 1),       # layer4 (16 pixels per image, M = 80: ragged tile)
+    (2, 128, 128, 8, 64, 7, 2, 3),      # stem (Cin 3 padded)
+    (3, 5, 8, 128, 128, 3, 1, 1),       # conv-GRU gates on the 5x8 map
+    (2, 9, 16, 512, 128, 3, 1, 1),      # RefineNet decoder (concatenated input)
+    (1, 72, 128, 16, 16, 3, 1, 1),      # RefineNet outer level
+    (2, 72, 128, 16, 8, 1, 1, 0),       # RefineNet final 1x1 (Cout padded)
+    (37, 1, 1, 512, 128, 1, 1, 0),      # Linear 512 -> 128
+    (37, 1, 1, 128, 384, 1, 1, 0),      # GRU input GEMM
+]
+
+
+def conv_case_id(c):
+    return 'N%d_%dx%d_c%d-%d_k%d_s%d' % c[:7]
+
+
+@pytest.mark.parametrize('dtype', DTYPES, ids=['f32', 'bf16'])
+@pytest.mark.parametrize('case', CONV_CASES, ids=conv_case_id)
+def test_conv_fwd_dgrad_wgrad(hip, ref, dtype, case):
+    N, IH, IW, Cin, Cout, K, stride, pad = case
+    if dtype == torch.bfloat16 and (Cin % 8 or Cout % 8):
+        pytest.skip('bf16 needs 8-channel vectors')
+    x = rnd((N, IH, IW, Cin), dtype, 1)
+    w = rnd((Cout, K, K, Cin), dtype, 2, scale=(2.0 / (K * K * Cin)) ** 0.5)
+    bias = rnd((Cout,), torch.float32, 3)
+    want = ref.conv2d_fwd(x, w, bias, stride, pad)
+    got = hip.conv2d_fwd(dev(x), dev(w), dev(bias), stride, pad)
+    close(got, want, dtype, 'conv fwd')
+    dy = rnd(tuple(want.shape), dtype, 4)
+    w_ihwo = w.permute(3, 1, 2, 0).contiguous()
+    want_dx = ref.conv2d_dgrad(dy, w_ihwo, (IH, IW), stride, pad)
+    got_dx = hip.conv2d_dgrad(dev(dy), dev(w_ihwo), (IH, IW), stride, pad)
+    close(got_dx, want_dx, dtype, 'conv dgrad')
+    want_dw = ref.conv2d_wgrad(x, dy, K, K, stride, pad, torch.zeros((Cout, K, K, Cin)))
+    got_dw = hip.conv2d_wgrad(dev(x), dev(dy), K, K, stride, pad,
+                              torch.zeros((Cout, K, K, Cin), device='cuda'))
+    close(got_dw, want_dw, dtype, 'conv wgrad')
+    want_db = ref.bias_grad(dy, torch.zeros(Cout))
+    got_db = hip.bias_grad(dev(dy), torch.zeros(Cout, device='cuda'))
+    close(got_db, want_db, dtype, 'bias grad')
+
+
+@pytest.mark.parametrize('dtype', DTYPES, ids=['f32', 'bf16'])
+def test_conv_small_cout_and_epilogues(hip, ref, dtype):
+    if dtype == torch.bfloat16:
+        pytest.skip('tail runs in float32')
+    for Cout, act in ((2, 4), (1, 1), (4, 3), (6, 5), (12, 2)):
+        x = rnd((19, 1, 1, 128), dtype, 5)
+        w = rnd((Cout, 1, 1, 128), dtype, 6, scale=0.1)
+        b = rnd((Cout,), torch.float32, 7)
+        close(hip.conv2d_fwd(dev(x), dev(w), dev(b), 1, 0, epi_act=act),
+              ref.conv2d_fwd(x, w, b, 1, 0, epi_act=act), dtype, 'conv Cout=%d act=%d' % (Cout, act))
+
+
+@pytest.mark.parametrize('dtype', DTYPES, ids=['f32', 'bf16'])
+def test_conv_prologue_fused_instnorm(hip, ref, dtype):
+    N, H, W, Cin, Cout = 3, 16, 16, 64, 128
+    x = rnd((N, H, W, Cin), dtype, 8)
+    w = rnd((Cout, 3, 3, Cin), dtype, 9, scale=0.05)
+    ss = torch.stack([1.0 + 0.2 * rnd((N, Cin), torch.float32, 10), 0.3 * rnd((N, Cin), torch.float32, 11)], -1)
+    for act in (0, 1, 2):
+        # the staged operand is rounded to the compute dtype on both sides
+        close(hip.conv2d_fwd(dev(x), dev(w), None, 1, 1, ss=dev(ss), pro_act=act),
+              ref.conv2d_fwd(x, w, None, 1, 1, ss=ss, pro_act=act), dtype, 'conv prologue act=%d' % act)
+    dy = rnd((N, H, W, Cout), dtype, 12)
+    close(hip.conv2d_wgrad(dev(x), dev(dy), 3, 3, 1, 1, torch.zeros((Cout, 3, 3, Cin), device='cuda'),
+                           ss=dev(ss), pro_act=1),
+          ref.conv2d_wgrad(x, dy, 3, 3, 1, 1, torch.zeros((Cout, 3, 3, Cin)), ss=ss, pro_act=1),
+          dtype, 'wgrad prologue')
+
+
+def test_conv_rejects_bad_shapes(hip):
+    x = torch.zeros((1, 8, 8, 6), device='cuda')
+    w = torch.zeros((8, 3, 3, 6), device='cuda')
+    with pytest.raises(RuntimeError, match='multiple of the 16-byte vector'):
+        hip.conv2d_fwd(x, w, None, 1, 1)
+    with pytest.raises(RuntimeError, match='not on the GPU'):
+        hip.conv2d_fwd(torch.zeros((1, 8, 8, 8)), torch.zeros((8, 3, 3, 8)), None, 1, 1)
+
+
+PLANE_CASES = [(3, 32, 32, 64), (2, 4, 4, 512), (2, 5, 8, 64), (2, 72, 128, 16), (2, 9, 16, 256), (1, 7, 5, 8)]
+
+
+@pytest.mark.parametrize('dtype', DTYPES, ids=['f32', 'bf16'])
+@pytest.mark.parametrize('shape', PLANE_CASES, ids=lambda s: 'x'.join(map(str, s)))
+def test_instnorm_fwd_bwd(hip, ref, dtype, shape):
+    N, H, W, C = shape
+    x = (rnd(shape, torch.float32, 13) * 1.7 + 0.4 * rnd((N, 1, 1, C), torch.float32, 14)).to(dtype)
+    mr_w = ref.instnorm_stats(x)
+    mr_g = hip.instnorm_stats(dev(x))
+    close(mr_g[..., 0], mr_w[..., 0], torch.float32, 'mean', scale=1.0)
+    close(mr_g[..., 1], mr_w[..., 1], torch.float32, 'rstd', scale=float(mr_w[..., 1].max()) * 3)
+    gamma = 1 + 0.2 * rnd((C,), torch.float32, 15)
+    beta = 0.1 * rnd((C,), torch.float32, 16)
+    res = rnd(shape, dtype, 17)
+    dy = rnd(shape, dtype, 18)
+    for (g, b, r, act) in ((None, None, None, 1), (None, None, res, 1), (None, None, None, 0),
+                           (gamma, beta, None, 1), (gamma, beta, None, 2)):
+        y_w = ref.instnorm_act_fwd(x, mr_w, g, b, r, act)
+        y_g = hip.instnorm_act_fwd(dev(x), dev(mr_w), dev(g), dev(b), dev(r), act)
+        close(y_g, y_w, dtype, 'instnorm_act fwd act=%d' % act)
+        dx_w, dres_w, s_w = ref.instnorm_act_bwd(dy, y_w, x, mr_w, g, act, r is not None)
+        dx_g, dres_g, s_g = hip.instnorm_act_bwd(dev(dy), dev(y_w), dev(x), dev(mr_w), dev(g), act, r is not None)
+        close(dx_g, dx_w, dtype, 'instnorm_act bwd dx act=%d' % act, scale=float(dx_w.abs().max()) + 0.05)
+        close(s_g, s_w, torch.float32, 'instnorm_act bwd sums', scale=float(s_w.abs().max()) * 4)
+        if r is not None:
+            close(dres_g, dres_w, dtype, 'instnorm_act bwd dres')
+
+
+@pytest.mark.parametrize('dtype', DTYPES, ids=['f32', 'bf16'])
+def test_elementwise(hip, ref, dtype):
+    for n in (8 * 1000, 8 * 1000 + 3):
+        a, b = rnd((n,), dtype, 19), rnd((n,), dtype, 20)
+        close(hip.add(dev(a), dev(b)), ref.add(a, b), dtype, 'add')
+        for act in range(6):
+            y = torch.tanh(a.float()).to(dtype) if act in (4, 5) else a
+            close(hip.act_bwd(dev(b), dev(y), act), ref.act_bwd(b, y, act), dtype, 'act_bwd %d' % act)
+
+
+@pytest.mark.parametrize('dtype', DTYPES, ids=['f32', 'bf16'])
+def test_pooling_and_resize(hip, ref, dtype):
+    x = torch.relu(rnd((2, 64, 64, 64), dtype, 21))          # post-ReLU: many exact ties at 0
+    y_w, idx_w = ref.maxpool3x3s2_fwd(x)
+    y_g, idx_g = hip.maxpool3x3s2_fwd(dev(x))
+    close(y_g, y_w, dtype, 'maxpool fwd')
+    dy = rnd(tuple(y_w.shape), dtype, 22)
+    close(hip.maxpool3x3s2_bwd(dev(dy), idx_g, (64, 64)), ref.maxpool3x3s2_bwd(dy, idx_w, (64, 64)),
+          dtype, 'maxpool bwd')
+    x = rnd((3, 4, 4, 512), dtype, 23)
+    close(hip.avgpool_fwd(dev(x)), ref.avgpool_fwd(x), dtype, 'avgpool fwd')
+    dy = rnd((3, 512), dtype, 24)
+    close(hip.avgpool_bwd(dev(dy), (4, 4)), ref.avgpool_bwd(dy, (4, 4)), dtype, 'avgpool bwd')
+    for (ih, iw, oh, ow, c) in ((72, 128, 36, 64, 32), (9, 16, 5, 8, 256), (18, 32, 9, 16, 128)):
+        x = rnd((2, ih, iw, c), dtype, 25)
+        y_w, idx_w = ref.adaptive_maxpool_fwd(x, (oh, ow))
+        y_g, idx_g = hip.adaptive_maxpool_fwd(dev(x), (oh, ow))
+        close(y_g, y_w, dtype, 'adaptive maxpool fwd')
+        assert (idx_g.cpu().long() == idx_w).all(), 'adaptive maxpool indices'
+        dy = rnd(tuple(y_w.shape), dtype, 26)
+        close(hip.adaptive_maxpool_bwd(dev(dy), idx_g, (ih, iw)), ref.adaptive_maxpool_bwd(dy, idx_w, (ih, iw)),
+              dtype, 'adaptive maxpool bwd')
+        xs = rnd((2, oh, ow, c), dtype, 27)
+        close(hip.bilinear_fwd(dev(xs), (ih, iw)), ref.bilinear_fwd(xs, (ih, iw)), dtype, 'bilinear fwd')
+        dyu = rnd((2, ih, iw, c), dtype, 28)
+        close(hip.bilinear_bwd(dev(dyu), (oh, ow)), ref.bilinear_bwd(dyu, (oh, ow)), dtype, 'bilinear bwd')
+
+
+@pytest.mark.parametrize('dtype', DTYPES, ids=['f32', 'bf16'])
+def test_layout_and_pack(hip, ref, dtype):
+    src = rnd((3, 3, 16, 24), torch.float32, 29)
+    cpad = 4 if dtype == torch.float32 else 8
+    got = hip.nchw_to_nhwc(dev(src), dtype, cpad)
+    close(got, ref.nchw_to_nhwc(src, dtype, cpad), dtype, 'nchw->nhwc')
+    close(hip.nhwc_to_nchw(got, 3), ref.nhwc_to_nchw(got.cpu(), 3), dtype, 'nhwc->nchw')
+    w = rnd((16, 3, 3, 8), torch.float32, 30)
+    a_g, b_g = hip.pack_weights(dev(w), dtype)
+    a_w, b_w = ref.pack_weights(w, dtype)
+    close(a_g, a_w, dtype, 'pack ohwi')
+    close(b_g, b_w, dtype, 'pack ihwo')
+    close(hip.cast(dev(w), dtype), w.to(dtype), dtype, 'cast')
+
+
+def test_gru_scan(hip, ref):
+    S, T, H = 5, 7, 128
+    gi = rnd((S, T, 3 * H), torch.float32, 31)
+    whh = rnd((3 * H, H), torch.float32, 32, scale=H ** -0.5)
+    bhh = rnd((3 * H,), torch.float32, 33, scale=0.1)
+    for h0 in (None, rnd((S, H), torch.float32, 34, scale=0.5)):
+        hs_w, g_w, hn_w = ref.gru_scan_fwd(gi, whh.t().contiguous(), bhh, h0)
+        hs_g, g_g, hn_g = hip.gru_scan_fwd(dev(gi), dev(whh.t().contiguous()), dev(bhh), dev(h0))
+        close(hs_g, hs_w, torch.float32, 'gru hs')
+        close(g_g, g_w, torch.float32, 'gru gates')
+        close(hn_g, hn_w, torch.float32, 'gru hn_pre')
+        dhs = rnd((S, T, H), torch.float32, 35)
+        w_ = ref.gru_scan_bwd(dhs, whh, h0, hs_w, g_w, hn_w, h0 is not None)
+        g_ = hip.gru_scan_bwd(dev(dhs), dev(whh), dev(h0), dev(hs_w), dev(g_w), dev(hn_w), h0 is not None)
+        close(g_[0], w_[0], torch.float32, 'gru dgi')
+        close(g_[1], w_[1], torch.float32, 'gru dgh')
+        if h0 is not None:
+            close(g_[2], w_[2], torch.float32, 'gru dh0')
+
+
+@pytest.mark.parametrize('dtype', DTYPES, ids=['f32', 'bf16'])
+def test_cgru_gates(hip, ref, dtype):
+    P, C = (3, 5, 8), 64
+    g1, g2 = rnd(P + (2 * C,), dtype, 36), rnd(P + (C,), dtype, 37)
+    h = rnd(P + (C,), dtype, 38, scale=0.5)
+    ru_w, rh_w = ref.cgru_gates1(g1, h)
+    ru_g, rh_g = hip.cgru_gates1(dev(g1), dev(h))
+    close(ru_g, ru_w, dtype, 'gates1 ru')
+    close(rh_g, rh_w, dtype, 'gates1 rh')
+    o_w, hn_w = ref.cgru_gates2(g2, ru_w, h)
+    o_g, hn_g = hip.cgru_gates2(dev(g2), dev(ru_w), dev(h))
+    close(o_g, o_w, dtype, 'gates2 o')
+    close(hn_g, hn_w, dtype, 'gates2 hnew')
+    d = rnd(P + (C,), dtype, 39)
+    for a, b, nm in zip(hip.cgru_gates2_bwd(dev(d), dev(ru_w), dev(h), dev(o_w)),
+                        ref.cgru_gates2_bwd(d, ru_w, h, o_w), ('dg2', 'dru', 'dh')):
+        close(a, b, dtype, 'gates2 bwd ' + nm)
+    dru = rnd(P + (2 * C,), dtype, 40)
+    for a, b, nm in zip(hip.cgru_gates1_bwd(dev(d), dev(dru), dev(ru_w), dev(h)),
+                        ref.cgru_gates1_bwd(d, dru, ru_w, h), ('dg1', 'dh')):
+        close(a, b, dtype, 'gates1 bwd ' + nm)
+
+
+def test_adam_and_sumsq(hip, ref):
+    n = 100003
+    p, g = rnd((n,), torch.float32, 41), rnd((n,), torch.float32, 42, scale=3.0)
+    m, v = 0.1 * rnd((n,), torch.float32, 43), rnd((n,), torch.float32, 44).abs()
+    ss_w = ref.sumsq(g, torch.zeros(1))
+    ss_g = hip.sumsq(dev(g), torch.zeros(1, device='cuda'))
+    close(ss_g, ss_w, torch.float32, 'sumsq', scale=float(ss_w) * 4)
+    pw, mw, vw = p.clone(), m.clone(), v.clone()
+    ref.adam_step(pw, g, mw, vw, ss_w, 5.0, 1.0, 0.016, 0.9, 0.999, 1e-8, 0.005, 3)
+    pg, mg, vg = dev(p.clone()), dev(m.clone()), dev(v.clone())
+    hip.adam_step(pg, dev(g), mg, vg, ss_g, 5.0, 1.0, 0.016, 0.9, 0.999, 1e-8, 0.005, 3)
+    close(pg, pw, torch.float32, 'adam p')
+    close(mg, mw, torch.float32, 'adam m')
+    close(vg, vw, torch.float32, 'adam v')
