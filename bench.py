@@ -1,0 +1,173 @@
+#!/usr/bin/env python
+"""bench.py -- train-step frames/s of the EVE hot path on MI355X (BASELINE.json metric).
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+          --master-port P bench.py --gpus N --steps K --warmup W)
+
+One step = one optimiser step over one batch of synthetic clips already resident in HBM:
+NCHW->NHWC/bf16 conversion, EyeNet forward for all T frames and both eyes, the masked losses,
+backward, [gradient all-reduce], global-norm clip and Adam.  The workload is BASELINE.json configs[1]
+("EyeNet training on 1xMI355X, bf16, B=32 clips of T=30 synthetic frames"), weak scaling: every rank
+processes its own B=32 clips.  frames/s = world * B * T / max-over-ranks step time.
+
+Printed JSON (rank 0, one line) also carries
+  roofline     -- the dominant kernel group, its algorithmic FLOP/s from HIP events recorded around
+                  every launch in the timed region, against the dense bf16 MFMA peak;
+  cpu_baseline -- the CPU oracle (plain-torch restatement of the reference, oracle/) running the same
+                  train step on this host's cores on a bounded sample (B=2 clips), reported only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+
+MFMA_PEAK_TFLOPS = {'bf16': 2500.0, 'fp32': 157.3}     # /opt/skills/guides/MI355X_MICROARCH.md:41-42 (dense)
+HBM_PEAK_GBS = 8000.0
+# algorithmic FLOP per frame (one time step of one clip = 2 eye patches), SURVEY.md 8(d) / BASELINE.md 2
+EYENET_TRAIN_GFLOP_PER_FRAME_128 = 6.955
+
+
+def synthetic_eyenet_batch(B, T, size, device, seed):
+    g = torch.Generator(device='cpu').manual_seed(seed)
+    b = {}
+    for side in ('left', 'right'):
+        b[side + '_eye_patch'] = (torch.rand((B, T, 3, size, size), generator=g) * 2 - 1)
+        b[side + '_h'] = 0.1 * torch.randn((B, T, 2), generator=g)
+        b[side + '_g_tobii'] = 0.2 * torch.randn((B, T, 2), generator=g)
+        b[side + '_p'] = 2 + 3 * torch.rand((B, T), generator=g)
+        b[side + '_g_tobii_validity'] = torch.ones((B, T), dtype=torch.bool)
+        b[side + '_p_validity'] = torch.ones((B, T), dtype=torch.bool)
+    return {k: v.to(device) for k, v in b.items()}
+
+
+def cpu_baseline(T, size, steps=2):
+    """The oracle's train step on the host cores (bounded sample: B=2 clips of T frames)."""
+    from oracle import sequence
+    from oracle.config import OracleConfig
+    from oracle.eye_net import EyeNet as OracleEyeNet
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    cfg = OracleConfig(batch_size=16, weight_decay=0.005, base_learning_rate=0.001)
+    torch.manual_seed(0)
+    net = OracleEyeNet(cfg)
+    opt = sequence.make_optimizer(net.parameters(), cfg)
+    B = 2
+    batch = synthetic_eyenet_batch(B, T, size, 'cpu', 123)
+    sequence.eyenet_train_step(net, opt, batch, cfg)           # warm-up
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        sequence.eyenet_train_step(net, opt, batch, cfg)
+    dt = (time.perf_counter() - t0) / steps
+    return {'value': B * T / dt, 'unit': 'frames/s', 'cores': cores, 'kind': 'port',
+            'sample': 'oracle (plain-torch fp32 restatement) EyeNet train step, B=%d clips x T=%d, %dx%d, '
+                      '%d timed steps after 1 warm-up' % (B, T, size, size, steps)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--batch', type=int, default=32, help='clips per GPU')
+    ap.add_argument('--seq', type=int, default=30)
+    ap.add_argument('--size', type=int, default=128)
+    ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp32'])
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-roofline', action='store_true')
+    args = ap.parse_args()
+
+    import eve_amd
+    from eve_amd import parallel, train
+    from eve_amd.kernels import default_kernels
+
+    rank, local_rank, world = parallel.init_distributed()
+    if world != args.gpus:
+        raise SystemExit('bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)' % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs a GPU: the hot path has no CPU fallback')
+    torch.cuda.set_device(local_rank)
+    device = torch.device('cuda', local_rank)
+
+    cfg = eve_amd.reset_standalone_config()
+    cfg.import_json(os.path.join(HERE, 'configs', 'eye_net.json'))
+    torch.manual_seed(1234)
+    net = eve_amd.EyeNet()
+    net.compute_dtype = torch.bfloat16 if args.dtype == 'bf16' else torch.float32
+    net.to(device)
+    trainer = train.eyenet_trainer(net, cfg, distributed=world > 1)
+    batch = synthetic_eyenet_batch(args.batch, args.seq, args.size, device, 1000 * rank)
+    k = default_kernels()
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        terms = trainer.step(batch)
+    barrier()
+    if not args.no_roofline:
+        k.start_profile()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        terms = trainer.step(batch)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    prof = k.stop_profile() if not args.no_roofline else {}
+    loss = float(terms['full_loss'].detach())
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t)
+    ms_per_step = 1e3 * elapsed / args.steps
+    frames = world * args.batch * args.seq
+    value = frames / (elapsed / args.steps)
+
+    if rank == 0:
+        out = {
+            'metric': 'train-step frames/sec, 128x128 eye patches T=30',
+            'value': value, 'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': args.dtype, 'data': 'synthetic',
+            'config': {'workload': 'BASELINE configs[1]: EyeNet training (configs/eye_net.json: ResNet-18-IN + GRU-128, '
+                                   'angular + pupil L1 losses, clip 5.0, Adam wd 0.005), %dx%d patches, fwd+bwd+clip+Adam'
+                                   % (args.size, args.size),
+                       'global_batch': world * args.batch, 'batch_per_gpu': args.batch, 'seq_len': args.seq,
+                       'parallelism': 'dp%d' % world},
+            'final_loss': loss,
+        }
+        peak = MFMA_PEAK_TFLOPS[args.dtype]
+        if args.size == 128:
+            out['step_algorithmic_tflops'] = EYENET_TRAIN_GFLOP_PER_FRAME_128 * value / 1e3 / world
+            out['step_mfma_frac'] = out['step_algorithmic_tflops'] / peak
+        if prof:
+            dom = max(prof, key=lambda t: prof[t]['ms'])
+            d = prof[dom]
+            achieved = d['flops'] / (d['ms'] * 1e-3) / 1e12
+            sym = {'conv_fwd': 'eve::igemm_kernel (forward gather)', 'conv_dgrad': 'eve::igemm_kernel (dgrad gather)',
+                   'conv_wgrad': 'eve::wgrad_kernel'}[dom]
+            out['roofline'] = {'bound': 'mfma', 'kernel': sym, 'achieved': achieved, 'peak': peak,
+                               'unit': 'TFLOP/s', 'frac': achieved / peak, 'traffic': None,
+                               'launches_per_step': d['launches'] / args.steps,
+                               'avg_launch_ms': d['ms'] / d['launches'],
+                               'algorithmic_gflop_per_launch': d['flops'] / d['launches'] / 1e9}
+            out['kernel_groups_ms_per_step'] = {t: prof[t]['ms'] / args.steps for t in prof}
+            out['kernel_groups_tflops'] = {t: prof[t]['flops'] / (prof[t]['ms'] * 1e-3) / 1e12 for t in prof}
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(args.seq, args.size)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

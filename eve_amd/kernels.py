@@ -45,6 +45,34 @@ class HipKernels(object):
 
     def __init__(self):
         self.lib = _lib.load()
+        self.prof = None          # list of (tag, flops, start_event, end_event) while profiling
+
+    # ------------------------------------------------------------------ per-launch timing (bench roofline)
+    def start_profile(self):
+        """Record a HIP event pair around every conv launch on the stream it is launched on."""
+        self.prof = []
+
+    def stop_profile(self):
+        """-> {tag: {'launches', 'ms', 'flops'}}; synchronises the device."""
+        rec, self.prof = self.prof or [], None
+        torch.cuda.synchronize()
+        out = {}
+        for tag, flops, e0, e1 in rec:
+            d = out.setdefault(tag, {'launches': 0, 'ms': 0.0, 'flops': 0.0})
+            d['launches'] += 1
+            d['ms'] += e0.elapsed_time(e1)
+            d['flops'] += flops
+        return out
+
+    def _timed(self, tag, flops, fn):
+        if self.prof is None:
+            return fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        r = fn()
+        e1.record()
+        self.prof.append((tag, flops, e0, e1))
+        return r
 
     # ------------------------------------------------------------------ helpers
     @staticmethod
@@ -81,19 +109,20 @@ class HipKernels(object):
         return d
 
     # ------------------------------------------------------------------ convolution
-    def conv2d_fwd(self, x, w_ohwi, bias, stride, pad, epi_act=ACT_NONE, ss=None, pro_act=ACT_NONE):
+    def conv2d_fwd(self, x, w_ohwi, bias, stride, pad, epi_act=ACT_NONE, ss=None, pro_act=ACT_NONE, algo=None):
+        """algo = (true Cout, true KH*KW*Cin) when channels are zero-padded (algorithmic FLOP count)."""
         N, IH, IW, Cin = x.shape
         Cout, KH, KW, Cin2 = w_ohwi.shape
         assert Cin2 == Cin and w_ohwi.dtype == x.dtype
         d = self._desc(x.dtype, N, IH, IW, Cin, Cout, KH, KW, stride, pad)
         y = torch.empty((N, d.OH, d.OW, Cout), dtype=x.dtype, device=x.device)
-        self._ck(self.lib.eve_conv2d_fwd(ctypes.byref(d), self._p(x), self._p(w_ohwi),
-                                         self._p(self._f32(bias, 'bias')), epi_act,
-                                         self._p(self._f32(ss, 'scale/shift')), pro_act, self._p(y),
-                                         self._stream()))
+        co, kk = algo or (Cout, KH * KW * Cin)
+        self._timed('conv_fwd', 2.0 * N * d.OH * d.OW * co * kk, lambda: self._ck(self.lib.eve_conv2d_fwd(
+            ctypes.byref(d), self._p(x), self._p(w_ohwi), self._p(self._f32(bias, 'bias')), epi_act,
+            self._p(self._f32(ss, 'scale/shift')), pro_act, self._p(y), self._stream())))
         return y
 
-    def conv2d_dgrad(self, dy, w_ihwo, in_hw, stride, pad):
+    def conv2d_dgrad(self, dy, w_ihwo, in_hw, stride, pad, algo=None):
         N, OH, OW, Cout = dy.shape
         Cin, KH, KW, Cout2 = w_ihwo.shape
         assert Cout2 == Cout and w_ihwo.dtype == dy.dtype
@@ -101,20 +130,22 @@ class HipKernels(object):
         d = self._desc(dy.dtype, N, IH, IW, Cin, Cout, KH, KW, stride, pad)
         assert (d.OH, d.OW) == (OH, OW)
         dx = torch.empty((N, IH, IW, Cin), dtype=dy.dtype, device=dy.device)
-        self._ck(self.lib.eve_conv2d_dgrad(ctypes.byref(d), self._p(dy), self._p(w_ihwo), self._p(dx),
-                                           self._stream()))
+        co, kk = algo or (Cout, KH * KW * Cin)
+        self._timed('conv_dgrad', 2.0 * N * OH * OW * co * kk, lambda: self._ck(self.lib.eve_conv2d_dgrad(
+            ctypes.byref(d), self._p(dy), self._p(w_ihwo), self._p(dx), self._stream())))
         return dx
 
-    def conv2d_wgrad(self, x, dy, KH, KW, stride, pad, dw_ohwi, ss=None, pro_act=ACT_NONE):
+    def conv2d_wgrad(self, x, dy, KH, KW, stride, pad, dw_ohwi, ss=None, pro_act=ACT_NONE, algo=None):
         """Accumulates into dw_ohwi (float32 [Cout, KH, KW, Cin])."""
         N, IH, IW, Cin = x.shape
         Cout = dy.shape[3]
         assert dw_ohwi.shape == (Cout, KH, KW, Cin) and dw_ohwi.dtype == torch.float32
         d = self._desc(x.dtype, N, IH, IW, Cin, Cout, KH, KW, stride, pad)
         assert tuple(dy.shape) == (N, d.OH, d.OW, Cout) and dy.dtype == x.dtype
-        self._ck(self.lib.eve_conv2d_wgrad(ctypes.byref(d), self._p(x), self._p(dy),
-                                           self._p(self._f32(ss, 'scale/shift')), pro_act,
-                                           self._p(dw_ohwi), self._stream()))
+        co, kk = algo or (Cout, KH * KW * Cin)
+        self._timed('conv_wgrad', 2.0 * N * d.OH * d.OW * co * kk, lambda: self._ck(self.lib.eve_conv2d_wgrad(
+            ctypes.byref(d), self._p(x), self._p(dy), self._p(self._f32(ss, 'scale/shift')), pro_act,
+            self._p(dw_ohwi), self._stream())))
         return dw_ohwi
 
     def bias_grad(self, dy, db):

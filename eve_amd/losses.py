@@ -1,0 +1,72 @@
+"""Validity-masked sequence losses of the train step, batched over clips (device-side tensor ops on
+[B, T, ...] outputs -- a few KB; not part of the kernel hot path).
+
+Semantics of /root/reference/src/losses/: per clip, sum over valid time steps divided by the number
+of valid steps when that number exceeds one, then the mean over clips
+(base_loss_with_validity.py:64-73); angular error in degrees between pitch/yaw gaze vectors
+(angular.py:33-38, models/common.py:32-36); L1 / MSE reduced over the non-time dims (l1.py, mse.py);
+per-step binary cross-entropy of the heat-map (cross_entropy.py:31-35).
+The reference iterates clips in Python with a host sync per clip; here one masked reduction does it.
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+
+def _masked_clip_mean(per_step, validity):
+    v = validity.to(per_step.dtype)
+    count = v.sum(dim=1)
+    total = (per_step * v).sum(dim=1)
+    denom = torch.where(count > 1, count, torch.ones_like(count))
+    return (total / denom).mean()
+
+
+def gaze_vectors(pitchyaw):
+    pitch, yaw = pitchyaw[..., 0], pitchyaw[..., 1]
+    cp = torch.cos(pitch)
+    return torch.stack([cp * torch.sin(yaw), torch.sin(pitch), cp * torch.cos(yaw)], dim=-1)
+
+
+def angular_loss(pred, target, validity):
+    cos = F.cosine_similarity(gaze_vectors(pred), gaze_vectors(target), dim=-1, eps=1e-8)
+    cos = F.hardtanh(cos, min_val=-1 + 1e-8, max_val=1 - 1e-8)
+    return _masked_clip_mean(torch.acos(cos) * (180.0 / math.pi), validity)
+
+
+def _per_step(x):
+    return x if x.dim() == 2 else x.flatten(2).mean(dim=2)
+
+
+def l1_loss(pred, target, validity):
+    return _masked_clip_mean(_per_step((pred - target).abs()), validity)
+
+
+def mse_loss(pred, target, validity):
+    return _masked_clip_mean(_per_step((pred - target) ** 2), validity)
+
+
+def bce_loss(pred, target, validity):
+    return _masked_clip_mean(_per_step(F.binary_cross_entropy(pred, target, reduction='none')), validity)
+
+
+def eyenet_loss_terms(out, batch, config):
+    """The terms of eve.py:286-325 that carry weight in eye_net.json, and their weighted sum (:234-265)."""
+    terms = {}
+    for side in ('left', 'right'):
+        terms['loss_ang_%s_g_initial' % side] = angular_loss(
+            out[side + '_g_initial'], batch[side + '_g_tobii'], batch[side + '_g_tobii_validity'])
+        terms['loss_l1_%s_pupil_size' % side] = l1_loss(
+            out[side + '_pupil_size'], batch[side + '_p'], batch[side + '_p_validity'])
+    terms['full_loss'] = (
+        config.loss_coeff_g_ang_initial * (terms['loss_ang_left_g_initial'] + terms['loss_ang_right_g_initial']) +
+        config.loss_coeff_pupil_size * (terms['loss_l1_left_pupil_size'] + terms['loss_l1_right_pupil_size']))
+    return terms
+
+
+def refinenet_loss_terms(heatmap_final, heatmap_gt, validity, config):
+    terms = {'loss_ce_heatmap_final': bce_loss(heatmap_final, heatmap_gt, validity),
+             'loss_mse_heatmap_final': mse_loss(heatmap_final, heatmap_gt, validity)}
+    terms['full_loss'] = (config.loss_coeff_heatmap_ce_final * terms['loss_ce_heatmap_final'] +
+                          config.loss_coeff_heatmap_mse_final * terms['loss_mse_heatmap_final'])
+    return terms

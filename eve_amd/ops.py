@@ -17,7 +17,7 @@ class PackedWeight(object):
     `param` has the reference's OIHW (or [out, in]) SHAPE; its memory may already be OHWI (the
     flat-parameter harness stores it that way), in which case no permute copy is made."""
 
-    __slots__ = ('ohwi', 'ihwo', 'shape_oihw')
+    __slots__ = ('ohwi', 'ihwo', 'shape_oihw', 'algo')
 
     def __init__(self, param, dtype, cin_pad=None, cout_pad=None, want_ihwo=True):
         k = default_kernels()
@@ -25,6 +25,7 @@ class PackedWeight(object):
         if w.dim() == 2:
             w = w.view(w.shape[0], w.shape[1], 1, 1)
         self.shape_oihw = tuple(w.shape)
+        self.algo = (w.shape[0], w.shape[1] * w.shape[2] * w.shape[3])     # true Cout, true K
         w = w.permute(0, 2, 3, 1)                      # OHWI view
         if cin_pad is not None and cin_pad != w.shape[3]:
             w = torch.nn.functional.pad(w, (0, cin_pad - w.shape[3]))
@@ -48,7 +49,7 @@ class Conv2dFn(torch.autograd.Function):
             if b.numel() != cout_p:
                 b = torch.nn.functional.pad(b, (0, cout_p - b.numel()))
             b = b.contiguous()
-        y = k.conv2d_fwd(x, pack.ohwi, b, stride, pad, epi_act)
+        y = k.conv2d_fwd(x, pack.ohwi, b, stride, pad, epi_act, algo=pack.algo)
         ctx.pack, ctx.stride, ctx.pad, ctx.epi_act = pack, stride, pad, epi_act
         ctx.has_bias = bias is not None
         ctx.wshape = tuple(weight.shape)
@@ -65,11 +66,11 @@ class Conv2dFn(torch.autograd.Function):
             dy = k.act_bwd(dy, y, ctx.epi_act)
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            dx = k.conv2d_dgrad(dy, pack.ihwo, (x.shape[1], x.shape[2]), ctx.stride, ctx.pad)
+            dx = k.conv2d_dgrad(dy, pack.ihwo, (x.shape[1], x.shape[2]), ctx.stride, ctx.pad, algo=pack.algo)
         if ctx.needs_input_grad[1]:
             cout_p, KH, KW, cin_p = pack.ohwi.shape
             dwp = torch.zeros((cout_p, KH, KW, cin_p), dtype=torch.float32, device=x.device)
-            k.conv2d_wgrad(x, dy, KH, KW, ctx.stride, ctx.pad, dwp)
+            k.conv2d_wgrad(x, dy, KH, KW, ctx.stride, ctx.pad, dwp, algo=pack.algo)
             O, I = pack.shape_oihw[0], pack.shape_oihw[1]
             dw = dwp[:O, :, :, :I].permute(0, 3, 1, 2)          # OIHW-shaped view of OHWI memory
             if len(ctx.wshape) == 2:

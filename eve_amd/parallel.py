@@ -1,0 +1,110 @@
+"""Data parallelism for the clip batch: one process per GPU, gradients summed with RCCL
+(torch.distributed backend "nccl" on ROCm) over xGMI, bucketed and overlapped with backward.
+
+The reference is single-device (cuda:0 everywhere); clips are independent units (InstanceNorm is
+per-sample, losses are per-clip means), so the only exchange per step is the gradient all-reduce.
+Gradients live in ONE flat float buffer (eve_amd/train.py FlatParameters); buckets are contiguous
+slices of it, filled back-to-front because backward produces the last layers' gradients first
+(layer4 is ~74 % of EyeNet's bytes).  Each bucket's all-reduce is issued from a post-accumulate hook
+the moment its last gradient lands, so it rides under the remaining backward kernels; the 1/world
+scale is folded into the optimiser kernel's gradient scale instead of a separate pass.
+xGMI is point-to-point and ring collectives are per-link bound, so buckets are few and large.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_distributed(backend=None):
+    """Reads RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment (torch.distributed.run)."""
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    if world <= 1:
+        return 0, 0, 1
+    rank = int(os.environ['RANK'])
+    local_rank = int(os.environ.get('LOCAL_RANK', rank))
+    if backend is None:
+        backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+    if backend == 'nccl':
+        torch.cuda.set_device(local_rank)
+    if not dist.is_initialized():
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, local_rank, world
+
+
+class GradSync(object):
+    """Bucketed, backward-overlapped all-reduce(sum) of a flat gradient buffer."""
+
+    def __init__(self, flat_grad, entries, bucket_elems=None, group=None):
+        """entries: list of (param, offset, numel) in flat order (forward order of the network)."""
+        self.flat_grad = flat_grad
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        if bucket_elems is None:
+            bucket_elems = int(os.environ.get('EVE_AMD_BUCKET_ELEMS', str(4 * 1024 * 1024)))
+        # walk back-to-front, closing a bucket once it holds >= bucket_elems
+        self.buckets = []            # dicts: lo, hi, params, pending
+        hi = flat_grad.numel()
+        cur = {'lo': hi, 'hi': hi, 'params': []}
+        for p, off, n in reversed(entries):
+            cur['lo'] = off
+            cur['params'].append(p)
+            if cur['hi'] - cur['lo'] >= bucket_elems:
+                self.buckets.append(cur)
+                cur = {'lo': off, 'hi': off, 'params': []}
+        if cur['params']:
+            cur['lo'] = 0
+            self.buckets.append(cur)
+        elif self.buckets:
+            self.buckets[-1]['lo'] = 0
+        self._bucket_of = {}
+        for b in self.buckets:
+            for p in b['params']:
+                self._bucket_of[id(p)] = b
+        self._handles = []
+        self._hooks = []
+        self._armed = False
+        if self.world > 1:
+            for p, _, _ in entries:
+                if p.requires_grad:
+                    self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
+
+    def start_step(self):
+        for b in self.buckets:
+            b['pending'] = sum(1 for p in b['params'] if p.requires_grad)
+            b['launched'] = False
+        self._handles = []
+        self._armed = True
+
+    def _launch(self, b):
+        if b['launched'] or b['hi'] <= b['lo']:
+            return
+        b['launched'] = True
+        self._handles.append(dist.all_reduce(self.flat_grad[b['lo']:b['hi']], op=dist.ReduceOp.SUM,
+                                             group=self.group, async_op=True))
+
+    def _on_grad(self, p):
+        if not self._armed:
+            return
+        b = self._bucket_of[id(p)]
+        b['pending'] -= 1
+        if b['pending'] == 0:
+            self._launch(b)
+
+    def finish_step(self):
+        """Launch whatever never completed (parameters without a gradient this step) and wait.
+        Returns the factor the optimiser must scale the summed gradient by (1 / world)."""
+        self._armed = False
+        if self.world > 1:
+            for b in self.buckets:
+                self._launch(b)
+            for h in self._handles:
+                h.wait()
+        self._handles = []
+        return 1.0 / self.world
+
+    def remove_hooks(self):
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []

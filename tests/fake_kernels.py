@@ -49,18 +49,18 @@ class FakeKernels(object):
             return x.float()
         return act_fwd(x.float() * ss[:, None, None, :, 0] + ss[:, None, None, :, 1], pro_act)
 
-    def conv2d_fwd(self, x, w_ohwi, bias, stride, pad, epi_act=ACT_NONE, ss=None, pro_act=ACT_NONE):
+    def conv2d_fwd(self, x, w_ohwi, bias, stride, pad, epi_act=ACT_NONE, ss=None, pro_act=ACT_NONE, algo=None):
         xin = self._pro(x, ss, pro_act).to(x.dtype)
         y = F.conv2d(nchw(xin), w_ohwi.permute(0, 3, 1, 2).float(), bias, stride, pad)
         return nhwc(act_fwd(y, epi_act), x.dtype)
 
-    def conv2d_dgrad(self, dy, w_ihwo, in_hw, stride, pad):
+    def conv2d_dgrad(self, dy, w_ihwo, in_hw, stride, pad, algo=None):
         w = w_ihwo.permute(3, 0, 1, 2).float()          # [Cout, Cin, KH, KW]
         N = dy.shape[0]
         dx = torch.nn.grad.conv2d_input((N, w.shape[1], in_hw[0], in_hw[1]), w, nchw(dy), stride, pad)
         return nhwc(dx, dy.dtype)
 
-    def conv2d_wgrad(self, x, dy, KH, KW, stride, pad, dw_ohwi, ss=None, pro_act=ACT_NONE):
+    def conv2d_wgrad(self, x, dy, KH, KW, stride, pad, dw_ohwi, ss=None, pro_act=ACT_NONE, algo=None):
         xin = self._pro(x, ss, pro_act).to(x.dtype)
         Cout, Cin = dy.shape[3], x.shape[3]
         dw = torch.nn.grad.conv2d_weight(nchw(xin), (Cout, Cin, KH, KW), nchw(dy), stride, pad)
@@ -132,9 +132,10 @@ class FakeKernels(object):
 
     def bilinear_bwd(self, dy, in_hw):
         N, OH, OW, C = dy.shape
-        probe = torch.zeros((N, C, in_hw[0], in_hw[1]), requires_grad=True)
-        out = F.interpolate(probe, size=(OH, OW), mode='bilinear', align_corners=False)
-        (dx,) = torch.autograd.grad(out, probe, nchw(dy))
+        with torch.enable_grad():
+            probe = torch.zeros((N, C, in_hw[0], in_hw[1]), requires_grad=True)
+            out = F.interpolate(probe, size=(OH, OW), mode='bilinear', align_corners=False)
+            (dx,) = torch.autograd.grad(out, probe, nchw(dy))
         return nhwc(dx, dy.dtype)
 
     def nchw_to_nhwc(self, src, dtype, cpad=None, out=None):

@@ -1,0 +1,71 @@
+"""CPU, world_size 2 over gloo: the bucketed gradient all-reduce of eve_amd.parallel / the flat
+trainer gives the same update as one process on the concatenated batch (clips are independent units,
+losses are per-clip means, equal local batches)."""
+import os
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, tmp):
+    sys.path.insert(0, REPO)
+    sys.path.insert(0, os.path.join(REPO, 'tests'))
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank), EVE_AMD_BUCKET_ELEMS='2000000')
+    torch.set_num_threads(2)
+    import eve_amd
+    from eve_amd import kernels, parallel, train
+    from fake_kernels import FakeKernels
+    from oracle import detweights
+    kernels.set_default_kernels(FakeKernels())
+    r, lr, w = parallel.init_distributed(backend='gloo')
+    assert (r, w) == (rank, world)
+    cfg = eve_amd.reset_standalone_config()
+    cfg.import_json(os.path.join(REPO, 'configs', 'eye_net.json'))
+    net = detweights.fill_module(eve_amd.EyeNet())
+    tr = train.eyenet_trainer(net, cfg, distributed=True)
+    assert len(tr.sync.buckets) >= 3
+    assert tr.sync.buckets[0]['hi'] == tr.fp.flat.numel() and tr.sync.buckets[-1]['lo'] == 0
+    full = detweights.eyenet_batch(2, 2, seed=11, size=64)
+    mine = {k: v[rank:rank + 1] for k, v in full.items()}
+    tr.step(mine)
+    torch.save({'flat': tr.fp.flat.clone(), 'grad': tr.fp.grad.clone()}, os.path.join(tmp, 'rank%d.pt' % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_step_equals_single_process_on_the_global_batch(tmp_path):
+    port = 29500 + (os.getpid() % 2000)
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    a = torch.load(os.path.join(str(tmp_path), 'rank0.pt'))
+    b = torch.load(os.path.join(str(tmp_path), 'rank1.pt'))
+    assert torch.equal(a['flat'], b['flat']), 'ranks diverged'
+    assert torch.equal(a['grad'], b['grad'])
+    # single process, global batch of 2 clips
+    sys.path.insert(0, os.path.join(REPO, 'tests'))
+    import eve_amd
+    from eve_amd import kernels, train
+    from fake_kernels import FakeKernels
+    from oracle import detweights
+    kernels.set_default_kernels(FakeKernels())
+    try:
+        cfg = eve_amd.reset_standalone_config()
+        cfg.import_json(os.path.join(REPO, 'configs', 'eye_net.json'))
+        net = detweights.fill_module(eve_amd.EyeNet())
+        tr = train.eyenet_trainer(net, cfg, distributed=False)
+        tr.step(detweights.eyenet_batch(2, 2, seed=11, size=64))
+        # summed rank gradients / world == gradient of the mean-over-clips loss on the global batch
+        g_dp = a['grad'] / 2
+        rel = float((g_dp - tr.fp.grad).norm() / tr.fp.grad.norm())
+        assert rel < 1e-3, rel
+        # Adam's first step is ~ lr * sign(g): elements whose gradient is round-off noise may flip, so the
+        # update is compared in bulk rather than element by element
+        d = (a['flat'] - tr.fp.flat).abs()
+        assert float((d > 1e-4).float().mean()) < 2e-3, float((d > 1e-4).float().mean())
+    finally:
+        kernels.set_default_kernels(None)

@@ -1,0 +1,120 @@
+"""GPU parity: eve_amd.RefineNet (HIP kernels through the C ABI) against the golden fixtures made by the
+reference RefineNet / conv-RNN cells (tests/golden/refinenet.npz, cells.npz) and the CPU oracle."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import detweights, sequence
+from oracle.config import OracleConfig
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+HEAT_TOL = 1e-4
+
+
+def make_net(kind, dtype=torch.float32, screen=True):
+    import eve_amd
+    cfg = eve_amd.reset_standalone_config()
+    cfg.import_dict({'load_screen_content': screen, 'refine_net_enabled': True, 'refine_net_rnn_type': kind})
+    net = eve_amd.RefineNet()
+    net.compute_dtype = dtype
+    detweights.fill_module(net, seed=1)
+    return net.cuda(), cfg
+
+
+@pytest.mark.parametrize('kind', ['CGRU', 'CLSTM', 'CRNN'])
+def test_refinenet_sequence_and_per_step_match_reference_golden(kind):
+    fx = np.load(os.path.join(GOLDEN, 'refinenet.npz'))
+    B, T = int(fx['B']), int(fx['T'])
+    rb = detweights.refinenet_batch(B, T, seed=0, invalid_fraction=float(fx['invalid_fraction']))
+    drb = {k: v.cuda() for k, v in rb.items()}
+    net, cfg = make_net(kind)
+    hf, states = net.forward_sequence(drb['heatmap_initial'], drb['screen_frame'])
+    want = fx[kind + '_heatmap_final']
+    got = hf.detach().cpu().numpy()
+    got = got if kind == 'CGRU' else got[..., ::4, ::4]
+    assert np.abs(got - want).max() < HEAT_TOL
+    assert want.std() > 1e-3
+    st = states[0]
+    last = (st[0] if isinstance(st, tuple) else st)[:, -1]
+    assert np.abs(last.detach().cpu().numpy() - fx[kind + '_state_last']).max() < HEAT_TOL
+    if isinstance(st, tuple):
+        assert np.abs(st[1][:, -1].cpu().numpy() - fx[kind + '_cell_last']).max() < HEAT_TOL
+    # the reference's per-step dict contract (eve.py:145-147)
+    outs, prev = [], None
+    with torch.no_grad():
+        for t in range(T):
+            so = {'heatmap_initial': drb['heatmap_initial'][:, t]}
+            net({'screen_frame': drb['screen_frame'][:, t]}, so, previous_output_dict=prev)
+            outs.append(so['heatmap_final'])
+            prev = so
+    stepped = torch.stack(outs, dim=1).cpu().numpy()
+    stepped = stepped if kind == 'CGRU' else stepped[..., ::4, ::4]
+    assert np.abs(stepped - want).max() < HEAT_TOL
+    # losses + gradients
+    from eve_amd import losses
+    terms = losses.refinenet_loss_terms(hf, drb['heatmap_final_gt'], drb['validity'], cfg)
+    np.testing.assert_allclose(float(terms['loss_ce_heatmap_final'].detach()), float(fx[kind + '_loss_ce']), rtol=2e-5)
+    np.testing.assert_allclose(float(terms['loss_mse_heatmap_final'].detach()), float(fx[kind + '_loss_mse']), rtol=2e-5)
+    terms['full_loss'].backward()
+    params = dict(net.named_parameters())
+    dead = 0
+    for n, ref_norm in zip(fx[kind + '_grad_names'], fx[kind + '_grad_norms']):
+        p = params[str(n)]
+        if ref_norm < 0:
+            assert p.grad is None, n
+            dead += 1
+        else:
+            got = float(p.grad.double().norm())
+            assert abs(got - ref_norm) <= 2e-2 * ref_norm + 3e-5, '%s: %.6g vs %.6g' % (n, got, ref_norm)
+    assert dead == (2 if kind == 'CLSTM' else 0)
+
+
+def test_refinenet_without_screen_content():
+    fx = np.load(os.path.join(GOLDEN, 'refinenet.npz'))
+    rb = detweights.refinenet_batch(2, 3, seed=0, invalid_fraction=0.25)
+    net, _ = make_net('CGRU', screen=False)
+    out = {'heatmap_initial': rb['heatmap_initial'][:, 0].cuda()}
+    with torch.no_grad():
+        net({}, out)
+    assert np.abs(out['heatmap_final'].cpu().numpy()[..., ::4, ::4] - fx['noscreen_heatmap_final']).max() < HEAT_TOL
+
+
+def test_cgru_cell_matches_reference_golden_including_grads():
+    """The CGRU cell alone (common.py:388-415) through the module's own step function."""
+    fx = np.load(os.path.join(GOLDEN, 'cells.npz'))
+    net, _ = make_net('CGRU')
+    bott = net.network
+    prefix = 'network'
+    while hasattr(bott, 'between_module'):
+        bott, prefix = bott.between_module, prefix + '.between_module'
+    cell = bott.rnn_cells[0]
+    detweights.fill_module(cell, seed=3)
+    net.invalidate_packs()
+    P = net._get_packs()
+    from eve_amd import ops
+    x = torch.from_numpy(fx['CGRU_x']).cuda().requires_grad_()
+    h = torch.from_numpy(fx['CGRU_h']).cuda().requires_grad_()
+    xn = ops.ToNHWCFn.apply(x, torch.float32, 64)
+    hn = ops.ToNHWCFn.apply(h, torch.float32, 64)
+    out, _ = net._cell_step(xn, hn, cell, prefix + '.rnn_cells.0', P)
+    hnew = ops.FromNHWCFn.apply(out, 64)
+    assert np.abs(hnew.detach().cpu().numpy() - fx['CGRU_h_new']).max() < 2e-5
+    (hnew * hnew).sum().backward()
+    assert np.abs(x.grad.cpu().numpy() - fx['CGRU_dx']).max() < 2e-4
+    assert np.abs(h.grad.cpu().numpy() - fx['CGRU_dh']).max() < 2e-4
+    out0, _ = net._cell_step(xn.detach(), None, cell, prefix + '.rnn_cells.0', P)
+    assert np.abs(ops.FromNHWCFn.apply(out0, 64).detach().cpu().numpy() - fx['CGRU_h_new_from_none']).max() < 2e-5
+
+
+def test_refinenet_bf16_deviation_reported():
+    fx = np.load(os.path.join(GOLDEN, 'refinenet.npz'))
+    rb = detweights.refinenet_batch(2, 3, seed=0, invalid_fraction=0.25)
+    net, _ = make_net('CGRU', dtype=torch.bfloat16)
+    with torch.no_grad():
+        hf, _ = net.forward_sequence(rb['heatmap_initial'].cuda(), rb['screen_frame'].cuda())
+    dev = np.abs(hf.cpu().numpy() - fx['CGRU_heatmap_final']).max()
+    print('RefineNet bf16 max heat-map deviation vs reference fp32: %.4e' % dev)
+    assert dev < 0.1

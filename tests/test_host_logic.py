@@ -1,0 +1,171 @@
+"""CPU: host logic of eve_amd (autograd wiring, packing/padding, drop-in dict contract, state_dict keys,
+flat-parameter trainer) with the torch-CPU stand-in of tests/fake_kernels.py in place of the HIP library,
+checked against the oracle / the reference goldens.  Also: the C-ABI library loads and exports every
+symbol include/eve_hip.h declares, and the product path raises when the library is missing."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import eve_amd
+from eve_amd import _lib, kernels, train
+from fake_kernels import FakeKernels
+from oracle import detweights, sequence
+from oracle.config import OracleConfig
+from oracle.eye_net import EyeNet as OracleEyeNet
+from oracle.refine_net import RefineNet as OracleRefineNet
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture()
+def fake():
+    kernels.set_default_kernels(FakeKernels())
+    yield
+    kernels.set_default_kernels(None)
+
+
+def test_library_exports_every_declared_symbol():
+    header = open(os.path.join(REPO, 'include', 'eve_hip.h')).read()
+    declared = sorted(set(re.findall(r'\b(eve_[a-z0-9_]+)\s*\(', header)))
+    assert declared == _lib.EXPORTS, set(declared) ^ set(_lib.EXPORTS)
+    from eve_amd import build
+    if not os.path.isfile(build.LIB_PATH):
+        build.build()
+    lib = ctypes.CDLL(build.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), name
+    lib.eve_abi_version.restype = ctypes.c_int
+    assert lib.eve_abi_version() == 1
+
+
+def test_missing_library_fails_loudly(tmp_path, monkeypatch):
+    monkeypatch.setattr(_lib, '_lib', None)
+    monkeypatch.setenv('EVE_HIP_LIB', str(tmp_path / 'nope.so'))
+    with pytest.raises(_lib.EveLibraryError):
+        _lib.load()
+
+
+def test_product_path_has_no_cpu_fallback():
+    """Without a GPU the real kernels refuse CPU tensors instead of computing anything."""
+    kernels.set_default_kernels(None)
+    cfg = eve_amd.reset_standalone_config()
+    net = eve_amd.EyeNet()
+    batch = detweights.eyenet_batch(1, 1)
+    with pytest.raises(RuntimeError, match='not on the GPU|no CPU fallback|libeve_hip'):
+        net.forward_sequence(batch)
+    for mod in ('eye_net', 'refine_net', 'ops', 'kernels', 'train', 'losses', 'parallel'):
+        src = open(os.path.join(REPO, 'eve_amd', mod + '.py')).read()
+        assert 'import oracle' not in src and 'from oracle' not in src, mod
+
+
+def test_config_mirror_defaults_and_json():
+    cfg = eve_amd.reset_standalone_config()
+    assert cfg.refine_net_rnn_type == 'CGRU' and cfg.eye_net_rnn_type == 'GRU'      # config_default.py:101,120
+    cfg.import_json(os.path.join(REPO, 'configs', 'refine_net.json'))
+    assert cfg.refine_net_rnn_type == 'CLSTM' and cfg.load_screen_content is True    # refine_net.json:46,55
+    assert abs(cfg.learning_rate - 8 * 0.001) < 1e-12                                  # config_default.py:81-83
+    with pytest.raises(ValueError):
+        cfg.override('no_such_key', 1)
+    with pytest.raises(TypeError):
+        cfg.import_dict({'batch_size': 'x'})
+
+
+def test_unknown_rnn_type_raises_like_reference():
+    cfg = eve_amd.reset_standalone_config()
+    cfg.override('eye_net_rnn_type', 'XYZ')
+    with pytest.raises(ValueError, match='Unknown RNN type for EyeNet'):            # eye_net.py:72
+        eve_amd.EyeNet()
+    eve_amd.reset_standalone_config()
+
+
+def test_eyenet_host_logic_matches_oracle(fake):
+    cfg = eve_amd.reset_standalone_config()
+    net = eve_amd.EyeNet()
+    ref = OracleEyeNet(OracleConfig())
+    assert list(net.state_dict().keys()) == list(ref.state_dict().keys())
+    assert float(net.fc_to_gaze[2].weight.abs().max()) == 0.0
+    detweights.fill_module(net); detweights.fill_module(ref)
+    batch = detweights.eyenet_batch(2, 3, seed=2, invalid_fraction=0.2)
+    out = net.forward_sequence(batch)
+    want = sequence.eyenet_sequence(ref, batch)
+    for k in want:
+        assert float((out[k] - want[k]).abs().max()) < 1e-4, k
+    # the reference's per-step contract gives the same numbers as the folded pass
+    steps, prev = [], None
+    with torch.no_grad():
+        for t in range(3):
+            si = {k: v[:, t] for k, v in batch.items()}
+            so = {}
+            net(si, so, side='left', previous_output_dict=prev)
+            net(si, so, side='right', previous_output_dict=prev)
+            steps.append(so)
+            prev = so
+    for k in want:
+        got = torch.stack([s[k] for s in steps], dim=1)
+        assert float((got - want[k]).abs().max()) < 1e-4, k
+    with pytest.raises(KeyError):
+        net({}, {}, side='left')
+
+
+def test_eyenet_frozen_detaches(fake):
+    cfg = eve_amd.reset_standalone_config()
+    cfg.override('eye_net_frozen', True)
+    net = detweights.fill_module(eve_amd.EyeNet())
+    batch = detweights.eyenet_batch(1, 1)
+    out = {}
+    net({k: v[:, 0] for k, v in batch.items()}, out, side='left')
+    assert not out['left_g_initial'].requires_grad and out['left_pupil_size'].requires_grad
+    eve_amd.reset_standalone_config()
+
+
+def test_flat_trainer_reproduces_reference_train_step(fake):
+    fx = np.load(os.path.join(REPO, 'tests', 'golden', 'eyenet.npz'))
+    cfg = eve_amd.reset_standalone_config()
+    cfg.import_json(os.path.join(REPO, 'configs', 'eye_net.json'))
+    net = detweights.fill_module(eve_amd.EyeNet())
+    keys = list(net.state_dict().keys())
+    tr = train.eyenet_trainer(net, cfg)
+    assert list(net.state_dict().keys()) == keys
+    batch = detweights.eyenet_batch(int(fx['B']), int(fx['T']), seed=0, invalid_fraction=float(fx['invalid_fraction']))
+    terms = tr.step(batch)
+    np.testing.assert_allclose(float(terms['full_loss'].detach()), float(fx['eve_full_loss']), rtol=1e-5)
+    np.testing.assert_allclose(float(tr.sumsq.sqrt()), float(fx['clip_total_norm']), rtol=1e-3)
+    sd = net.state_dict()
+    for k in fx.files:
+        if k.startswith('updated_'):
+            np.testing.assert_allclose(sd[k[8:]].reshape(-1)[:16].numpy(), fx[k], rtol=1e-4, atol=2e-6)
+    # a second step keeps .grad inside the flat buffer and moves the weights again
+    before = tr.fp.flat.clone()
+    tr.step(batch)
+    assert float((tr.fp.flat - before).abs().max()) > 0
+    for p, off, n in tr.fp.entries:
+        assert p.grad.data_ptr() == tr.fp.grad.data_ptr() + 4 * off
+
+
+@pytest.mark.parametrize('kind', ['CGRU', 'CLSTM', 'CRNN'])
+def test_refinenet_host_logic_matches_oracle(fake, kind):
+    cfg = eve_amd.reset_standalone_config()
+    cfg.import_dict({'load_screen_content': True, 'refine_net_enabled': True, 'refine_net_rnn_type': kind})
+    ocfg = OracleConfig(load_screen_content=True, refine_net_enabled=True, refine_net_rnn_type=kind)
+    net, ref = eve_amd.RefineNet(), OracleRefineNet(ocfg)
+    assert list(net.state_dict().keys()) == list(ref.state_dict().keys())
+    assert float(net.final[2].weight.abs().max()) == 0.0                                # refine_net.py:235
+    detweights.fill_module(net, 1); detweights.fill_module(ref, 1)
+    rb = detweights.refinenet_batch(2, 2, seed=5)
+    hf, _ = net.forward_sequence(rb['heatmap_initial'], rb['screen_frame'])
+    want, _ = sequence.refinenet_sequence(ref, rb['heatmap_initial'], rb['screen_frame'])
+    assert float((hf - want).abs().max()) < 1e-4
+    sequence.refinenet_losses(hf, rb['heatmap_final_gt'], rb['validity'], ocfg)['full_loss'].backward()
+    sequence.refinenet_losses(want, rb['heatmap_final_gt'], rb['validity'], ocfg)['full_loss'].backward()
+    rp = dict(ref.named_parameters())
+    for n, p in net.named_parameters():
+        if rp[n].grad is None:
+            assert p.grad is None, n
+        else:
+            a, b = p.grad.double(), rp[n].grad.double()
+            assert float((a - b).norm()) <= 3e-2 * float(b.norm()) + 1e-5, n
+    eve_amd.reset_standalone_config()
