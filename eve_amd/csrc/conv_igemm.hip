@@ -574,8 +574,8 @@ extern "C" int eve_bias_grad(int dtype, long long M, int C, const void* dy, floa
     const int vec = dtype == EVE_DT_BF16 ? 8 : 4;
     if (M <= 0 || C <= 0 || C % vec || C / vec > 256) return set_error_msg("bias_grad: bad shape");
     if (!dy || !db) return set_error_msg("bias_grad: null pointer");
-    long long blocks = (M + 2047) / 2048;
-    if (blocks > 1024) blocks = 1024;
+    long long blocks = (M + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
     const long long rows = (M + blocks - 1) / blocks;
     blocks = (M + rows - 1) / rows;
     hipStream_t s = (hipStream_t)stream;
