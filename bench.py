@@ -128,6 +128,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     prof = k.stop_profile() if not args.no_roofline else {}
+    event_overhead = prof.pop('_event_overhead_ms', None)
     loss = float(terms['full_loss'].detach())
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
@@ -164,7 +165,8 @@ def main():
                                'unit': 'TFLOP/s', 'frac': achieved / peak, 'traffic': None,
                                'launches_per_step': d['launches'] / args.steps,
                                'avg_launch_ms': d['ms'] / d['launches'],
-                               'algorithmic_gflop_per_launch': d['flops'] / d['launches'] / 1e9}
+                               'algorithmic_gflop_per_launch': d['flops'] / d['launches'] / 1e9,
+                               'event_pair_overhead_ms_subtracted': event_overhead}
             out['kernel_groups_ms_per_step'] = {t: prof[t]['ms'] / args.steps for t in prof}
             out['kernel_groups_tflops'] = {t: prof[t]['flops'] / (prof[t]['ms'] * 1e-3) / 1e12 for t in prof}
         if world == 1 and not args.no_cpu_baseline:

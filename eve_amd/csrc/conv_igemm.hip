@@ -19,6 +19,8 @@
 //
 // The optional prologue x' = act(x*scale[n,c] + shift[n,c]) is applied between the global load and the
 // LDS write, i.e. the consumer normalises InstanceNorm'ed inputs on the fly (padding stays exactly 0).
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace eve {
@@ -64,6 +66,10 @@ template <> struct Mma<float> {
         acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__builtin_bit_cast(float, a.w), __builtin_bit_cast(float, b.w), acc, 0, 0, 0);
     }
 };
+
+}  // namespace eve
+#include "conv_fast.h"
+namespace eve {
 
 // =================================================================================================
 // forward / dgrad kernel
@@ -478,9 +484,34 @@ static GatherParams dgrad_params(const eve_conv_desc* d) {
     return p;
 }
 
+static bool use_v1() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("EVE_CONV_IMPL"); v = (e && e[0] == 'v' && e[1] == '1') ? 1 : 0; }
+    return v == 1;
+}
+
 template <typename T>
 static int launch_igemm(const GatherParams& p, const void* src, const void* w, const float* bias,
                         const float* ss, int pro_act, int epi_act, void* out, hipStream_t s) {
+    {   // LDS-DMA kernel: uniform tap per K step, no prologue, 32-bit byte offsets
+        constexpr int BK = 8 * Elem<T>::VEC;
+        const unsigned long long src_bytes = (unsigned long long)p.N * p.IH * p.IW * p.Cin * sizeof(T);
+        const unsigned long long w_bytes = (unsigned long long)p.Cout * p.K * sizeof(T);
+        if (!ss && !use_v1() && p.div == 1 && p.Cin % BK == 0 && p.KH * p.KW <= 32 && src_bytes < (1ull << 31) &&
+            w_bytes < (1ull << 31)) {
+            const T* a = (const T*)src; const T* b = (const T*)w; T* o = (T*)out;
+            if (p.Cout > 64) {
+                const uint32_t tiles = ((p.M + 127) / 128) * ((p.Cout + 127) / 128);
+                hipLaunchKernelGGL((igemm_dma_kernel<T, 2, 2>), dim3(tiles), dim3(256), 0, s, p, a, b, bias, epi_act, o,
+                                   (uint32_t)src_bytes, (uint32_t)w_bytes);
+            } else {
+                const uint32_t tiles = (p.M + 255) / 256;
+                hipLaunchKernelGGL((igemm_dma_kernel<T, 4, 1>), dim3(tiles), dim3(256), 0, s, p, a, b, bias, epi_act, o,
+                                   (uint32_t)src_bytes, (uint32_t)w_bytes);
+            }
+            return 0;
+        }
+    }
     const bool wide = p.Cout > 64;
     const uint32_t bn = wide ? 128 : 64;
     const uint32_t tiles = ((p.M + 127) / 128) * ((p.Cout + bn - 1) / bn);
@@ -496,9 +527,40 @@ static int launch_igemm(const GatherParams& p, const void* src, const void* w, c
     return 0;
 }
 
+static void wgrad_split(const GatherParams& p, uint32_t tk, uint32_t tc, uint32_t& splits, uint32_t& rows) {
+    // enough splits of the pixel range for ~4 workgroups per CU, each a multiple of 64 pixels
+    uint32_t want = (1024 + tk * tc - 1) / (tk * tc);
+    uint32_t max_splits = (p.M + 255) / 256;
+    splits = want < 1 ? 1 : (want > max_splits ? max_splits : want);
+    if (splits < 1) splits = 1;
+    if (splits > 65535) splits = 65535;
+    rows = (p.M + splits - 1) / splits;
+    rows = (rows + 63) / 64 * 64;
+    splits = (p.M + rows - 1) / rows;
+}
+
 template <typename T>
 static int launch_wgrad(const GatherParams& p, const void* x, const void* dy, const float* ss, int pro_act,
                         float* dw, hipStream_t s) {
+    if (sizeof(T) == 2 && !ss && !use_v1()) {   // bf16: LDS-DMA staging + hardware-transposing fragment reads
+        const unsigned long long x_bytes = (unsigned long long)p.N * p.IH * p.IW * p.Cin * 2;
+        const unsigned long long dy_bytes = (unsigned long long)p.M * p.Cout * 2;
+        if (x_bytes < (1ull << 31) && dy_bytes < (1ull << 31)) {
+            uint32_t splits, rows;
+            if (p.Cout > 64) {
+                const uint32_t tk = (p.K + 127) / 128, tc = (p.Cout + 127) / 128;
+                wgrad_split(p, tk, tc, splits, rows);
+                hipLaunchKernelGGL((wgrad_tr_kernel<2, 2>), dim3(tk, tc, splits), dim3(256), 0, s, p, (const bf16_t*)x,
+                                   (const bf16_t*)dy, dw, rows, (uint32_t)x_bytes, (uint32_t)dy_bytes);
+            } else {
+                const uint32_t tk = (p.K + 255) / 256, tc = 1;
+                wgrad_split(p, tk, tc, splits, rows);
+                hipLaunchKernelGGL((wgrad_tr_kernel<1, 4>), dim3(tk, tc, splits), dim3(256), 0, s, p, (const bf16_t*)x,
+                                   (const bf16_t*)dy, dw, rows, (uint32_t)x_bytes, (uint32_t)dy_bytes);
+            }
+            return 0;
+        }
+    }
     const bool wide = p.Cout > 64;
     const uint32_t bco = wide ? 128 : 64;
     const uint32_t tk = (p.K + 127) / 128, tc = (p.Cout + bco - 1) / bco;

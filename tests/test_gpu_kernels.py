@@ -58,6 +58,11 @@ CONV_CASES = [
     (2, 72, 128, 16, 8, 1, 1, 0),       # RefineNet final 1x1 (Cout padded)
     (37, 1, 1, 512, 128, 1, 1, 0),      # Linear 512 -> 128
     (37, 1, 1, 128, 384, 1, 1, 0),      # GRU input GEMM
+    (4, 16, 16, 128, 128, 3, 1, 1),     # layer2 (LDS-DMA kernel, 2x2 waves, several M tiles)
+    (3, 8, 8, 256, 256, 3, 1, 1),       # layer3
+    (7, 32, 32, 64, 64, 3, 1, 1),       # layer1, M = 7168 (28 tiles of 256, 4x1 waves)
+    (2, 16, 16, 128, 256, 3, 2, 1),     # stride-2 forward through the DMA kernel, generic dgrad
+    (3, 9, 16, 128, 64, 1, 1, 0),       # 1x1, Cout 64
 ]
 
 
