@@ -87,6 +87,8 @@ def main():
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp32'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--no-graph', action='store_true', help='launch every kernel eagerly instead of replaying a hipGraph')
+    ap.add_argument('--profile-steps', type=int, default=2)
     args = ap.parse_args()
 
     import eve_amd
@@ -107,7 +109,7 @@ def main():
     net = eve_amd.EyeNet()
     net.compute_dtype = torch.bfloat16 if args.dtype == 'bf16' else torch.float32
     net.to(device)
-    trainer = train.eyenet_trainer(net, cfg, distributed=world > 1)
+    trainer = train.eyenet_trainer(net, cfg, distributed=world > 1, use_graph=not args.no_graph)
     batch = synthetic_eyenet_batch(args.batch, args.seq, args.size, device, 1000 * rank)
     k = default_kernels()
 
@@ -120,15 +122,21 @@ def main():
     for _ in range(args.warmup):
         terms = trainer.step(batch)
     barrier()
-    if not args.no_roofline:
-        k.start_profile()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         terms = trainer.step(batch)
     barrier()
     elapsed = time.perf_counter() - t0
-    prof = k.stop_profile() if not args.no_roofline else {}
-    event_overhead = prof.pop('_event_overhead_ms', None)
+    # per-launch kernel durations for the roofline: the same step launched eagerly with a HIP event pair around
+    # every conv launch (a graph replay has no per-kernel events; the kernels and shapes are identical)
+    prof, event_overhead = {}, None
+    if not args.no_roofline:
+        k.start_profile()
+        for _ in range(args.profile_steps):
+            trainer._eager_step(batch)
+        prof = k.stop_profile()
+        event_overhead = prof.pop('_event_overhead_ms', None)
+        barrier()
     loss = float(terms['full_loss'].detach())
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
@@ -149,7 +157,7 @@ def main():
                                    % (args.size, args.size),
                        'global_batch': world * args.batch, 'batch_per_gpu': args.batch, 'seq_len': args.seq,
                        'parallelism': 'dp%d' % world},
-            'final_loss': loss,
+            'final_loss': loss, 'hip_graph': not args.no_graph,
         }
         peak = MFMA_PEAK_TFLOPS[args.dtype]
         if args.size == 128:
@@ -163,11 +171,11 @@ def main():
                    'conv_wgrad': 'eve::wgrad_kernel'}[dom]
             out['roofline'] = {'bound': 'mfma', 'kernel': sym, 'achieved': achieved, 'peak': peak,
                                'unit': 'TFLOP/s', 'frac': achieved / peak, 'traffic': None,
-                               'launches_per_step': d['launches'] / args.steps,
+                               'launches_per_step': d['launches'] / args.profile_steps,
                                'avg_launch_ms': d['ms'] / d['launches'],
                                'algorithmic_gflop_per_launch': d['flops'] / d['launches'] / 1e9,
                                'event_pair_overhead_ms_subtracted': event_overhead}
-            out['kernel_groups_ms_per_step'] = {t: prof[t]['ms'] / args.steps for t in prof}
+            out['kernel_groups_ms_per_step'] = {t: prof[t]['ms'] / args.profile_steps for t in prof}
             out['kernel_groups_tflops'] = {t: prof[t]['flops'] / (prof[t]['ms'] * 1e-3) / 1e12 for t in prof}
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(args.seq, args.size)

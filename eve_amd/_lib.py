@@ -30,6 +30,8 @@ SIGNATURES = {
     'eve_instnorm_stats': [I, I, I, I, P, F, P, P],
     'eve_instnorm_act_fwd': [I, I, I, I, P, P, P, P, P, I, P, P],
     'eve_instnorm_act_bwd': [I, I, I, I, P, P, P, P, P, I, P, P, P, P],
+    'eve_instnorm_fwd_fused': [I, I, I, I, P, P, P, P, I, F, P, P, P],
+    'eve_instnorm_bwd_fused': [I, I, I, I, P, P, P, P, P, I, P, P, P, P],
     'eve_act_bwd': [I, L, P, P, I, P, P],
     'eve_add': [I, L, P, P, P, P],
     'eve_maxpool3x3s2_fwd': [I, I, I, I, I, P, P, P, P],
@@ -52,7 +54,7 @@ SIGNATURES = {
     'eve_cgru_gates1_bwd': [I, L, I, P, P, P, P, P, P, P],
     'eve_clstm_gates_fwd': [I, L, I, P, P, P, P, P],
     'eve_sumsq': [L, P, P, P],
-    'eve_adam_step': [L, P, P, P, P, P, F, F, F, F, F, F, F, I, P],
+    'eve_adam_step': [L, P, P, P, P, P, F, F, F, F, F, F, F, I, P, P],
 }
 EXPORTS = sorted(list(SIGNATURES) + ['eve_abi_version', 'eve_last_error'])
 

@@ -26,12 +26,23 @@ __device__ __forceinline__ void lds_dma16(__amdgpu_buffer_rsrc_t rsrc, const voi
 }
 #define EVE_OOB ((int)0x80000000u)   // >= num_records for every tensor we accept (< 2^31 bytes)
 
+// The filter taps a launch iterates over (at most 32), as source-pixel displacements and weight tap ids, plus
+// the mapping from the launch's pixel grid to output pixels.  A plain convolution uses all KH*KW taps and the
+// identity mapping; the data gradient of a stride-s convolution is s*s launches, one per output parity class,
+// each a dense stride-1 problem over only the taps that are divisible for that class (4x fewer MFMAs at s=2).
+struct TapPlan {
+    int ntaps;
+    signed char dy[32], dx[32], wt[32];
+    int osy, oy0, osx, ox0, OHf, OWf;     // out pixel = (y'*osy + oy0, x'*osx + ox0) in an OHf x OWf image
+};
+
 // =================================================================================================
 template <typename T, int WM, int WN>
 __global__ __launch_bounds__(256) void igemm_dma_kernel(const GatherParams p, const T* __restrict__ src,
                                                         const T* __restrict__ w, const float* __restrict__ bias,
                                                         const int epi_act, T* __restrict__ out,
-                                                        const uint32_t src_bytes, const uint32_t w_bytes) {
+                                                        const uint32_t src_bytes, const uint32_t w_bytes,
+                                                        const TapPlan tp) {
     constexpr int VEC = Elem<T>::VEC, ES = (int)sizeof(T);
     constexpr int BM = 64 * WM, BN = 64 * WN, BK = 8 * VEC;
     constexpr int A_DMA = BM / 32, B_DMA = BN / 32;
@@ -49,28 +60,31 @@ __global__ __launch_bounds__(256) void igemm_dma_kernel(const GatherParams p, co
 
     const int v = tid & 7, r0 = tid >> 3;
     const int vs = v ^ (r0 & 7);                  // source slot (the LDS image is lane-linear)
-    const int ntaps = p.KH * p.KW;
-    int a_off[A_DMA];
+    int a_off[A_DMA], a_y0[A_DMA], a_x0[A_DMA];
     uint32_t a_mask[A_DMA];
+    bool a_ok[A_DMA];
 #pragma unroll
     for (int j = 0; j < A_DMA; ++j) {
         const uint32_t m = m0 + r0 + 32 * j;
-        const bool ok = m < p.M;
-        const uint32_t mm = ok ? m : 0;
+        a_ok[j] = m < p.M;
+        const uint32_t mm = a_ok[j] ? m : 0;
         const uint32_t n = fd_div(mm, p.fd_ohw);
         const uint32_t rem = mm - n * (uint32_t)(p.OH * p.OW);
         const uint32_t oy = fd_div(rem, p.fd_ow);
         const uint32_t ox = rem - oy * (uint32_t)p.OW;
-        const int y0 = (int)oy * p.o_mul + p.off, x0 = (int)ox * p.o_mul + p.off;
-        a_off[j] = (((int)n * p.IH + y0) * p.IW + x0) * p.Cin * ES + vs * 16;
-        uint32_t mask = 0;
-        if (ok)
-            for (int t = 0; t < ntaps; ++t) {
-                const int kh = t / p.KW, kw = t - kh * p.KW;
-                const int sy = y0 + kh * p.k_mul, sx = x0 + kw * p.k_mul;
-                if (sy >= 0 && sy < p.IH && sx >= 0 && sx < p.IW) mask |= 1u << t;
-            }
-        a_mask[j] = mask;
+        a_y0[j] = (int)oy * p.o_mul + p.off;
+        a_x0[j] = (int)ox * p.o_mul + p.off;
+        a_off[j] = (((int)n * p.IH + a_y0[j]) * p.IW + a_x0[j]) * p.Cin * ES + vs * 16;
+        a_mask[j] = 0;
+    }
+#pragma unroll 1
+    for (int t = 0; t < tp.ntaps; ++t) {            // one kernarg fetch per tap, all rows per fetch
+        const int ty = tp.dy[t], tx = tp.dx[t];
+#pragma unroll
+        for (int j = 0; j < A_DMA; ++j) {
+            const int sy = a_y0[j] + ty, sx = a_x0[j] + tx;
+            a_mask[j] |= (uint32_t)(a_ok[j] && sy >= 0 && sy < p.IH && sx >= 0 && sx < p.IW) << t;
+        }
     }
     int b_off[B_DMA];
 #pragma unroll
@@ -79,12 +93,16 @@ __global__ __launch_bounds__(256) void igemm_dma_kernel(const GatherParams p, co
         b_off[j] = co < (uint32_t)p.Cout ? (int)(co * (uint32_t)p.K) * ES + vs * 16 : EVE_OOB;
     }
 
-    auto issue = [&](int kt, int buf) {
-        const int k0 = kt * BK;                                  // uniform
-        const int tap = (int)fd_div((uint32_t)k0, p.fd_cin);
-        const int ci0 = k0 - tap * p.Cin;
-        const int kh = (int)fd_div((uint32_t)tap, p.fd_kw), kw = tap - kh * p.KW;
-        const int delta = ((kh * p.k_mul) * p.IW + kw * p.k_mul) * p.Cin * ES + ci0 * ES;
+    // scalar tap state: the tap's byte displacements are fetched one tap ahead of their use, so the kernarg
+    // load latency never sits between the barrier and the DMA issue
+    const int pix_bytes = p.Cin * ES;
+    int tap = 0, ci0 = 0;
+    int d_cur = ((int)tp.dy[0] * p.IW + (int)tp.dx[0]) * pix_bytes, w_cur = (int)tp.wt[0] * pix_bytes;
+    int tn = tp.ntaps > 1 ? 1 : 0;
+    int d_nxt = ((int)tp.dy[tn] * p.IW + (int)tp.dx[tn]) * pix_bytes, w_nxt = (int)tp.wt[tn] * pix_bytes;
+
+    auto issue = [&](int buf) {
+        const int delta = d_cur + ci0 * ES, wk = w_cur + ci0 * ES;
         const uint4* base = lds + buf * (BM + BN) * 8 + wave * 64;
 #pragma unroll
         for (int j = 0; j < A_DMA; ++j) {
@@ -93,8 +111,17 @@ __global__ __launch_bounds__(256) void igemm_dma_kernel(const GatherParams p, co
         }
 #pragma unroll
         for (int j = 0; j < B_DMA; ++j) {
-            const int voff = b_off[j] == EVE_OOB ? EVE_OOB : b_off[j] + k0 * ES;
+            const int voff = b_off[j] == EVE_OOB ? EVE_OOB : b_off[j] + wk;
             lds_dma16(rs_w, base + BM * 8 + j * 256, voff);
+        }
+        ci0 += BK;                                   // advance to the next K step (uniform)
+        if (ci0 == p.Cin) {
+            ci0 = 0;
+            ++tap;
+            d_cur = d_nxt; w_cur = w_nxt;
+            tn = tap + 1 < tp.ntaps ? tap + 1 : tap;
+            d_nxt = ((int)tp.dy[tn] * p.IW + (int)tp.dx[tn]) * pix_bytes;
+            w_nxt = (int)tp.wt[tn] * pix_bytes;
         }
     };
 
@@ -108,13 +135,13 @@ __global__ __launch_bounds__(256) void igemm_dma_kernel(const GatherParams p, co
 #pragma unroll
         for (int b = 0; b < 4; ++b) acc[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-    const int nk = p.K / BK;
-    issue(0, 0);
+    const int nk = tp.ntaps * p.Cin / BK;
+    issue(0);
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();                           // tile kt has landed for every wave; tile kt-1 fully consumed
-        if (kt + 1 < nk) issue(kt + 1, cur ^ 1);
+        if (kt + 1 < nk) issue(cur ^ 1);
         const uint4* la = lds + cur * (BM + BN) * 8;
         const uint4* lb = la + BM * 8;
 #pragma unroll
@@ -155,7 +182,15 @@ __global__ __launch_bounds__(256) void igemm_dma_kernel(const GatherParams p, co
             float o[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) o[r] = act_fwd(acc[mt][nt][r] + bv[r], epi_act);
-            T* dst = out + (size_t)m * p.Cout + co;
+            size_t opix = m;
+            if (tp.osy != 1 || tp.osx != 1) {       // uniform: only the strided-dgrad sub-problems remap pixels
+                const uint32_t n = fd_div(m, p.fd_ohw);
+                const uint32_t rem = m - n * (uint32_t)(p.OH * p.OW);
+                const uint32_t oy = fd_div(rem, p.fd_ow);
+                const uint32_t ox = rem - oy * (uint32_t)p.OW;
+                opix = ((size_t)n * tp.OHf + oy * tp.osy + tp.oy0) * tp.OWf + ox * tp.osx + tp.ox0;
+            }
+            T* dst = out + opix * p.Cout + co;
             if (vec_ok) {
                 if (sizeof(T) == 4) {
                     *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);

@@ -491,27 +491,82 @@ static bool use_v1() {
 }
 
 template <typename T>
+static void launch_dma_one(const GatherParams& p, const TapPlan& tp, const void* src, const void* w,
+                           const float* bias, int epi_act, void* out, uint32_t src_bytes, uint32_t w_bytes,
+                           hipStream_t s) {
+    const T* a = (const T*)src; const T* b = (const T*)w; T* o = (T*)out;
+    if (p.Cout > 64) {
+        const uint32_t tiles = ((p.M + 127) / 128) * ((p.Cout + 127) / 128);
+        hipLaunchKernelGGL((igemm_dma_kernel<T, 2, 2>), dim3(tiles), dim3(256), 0, s, p, a, b, bias, epi_act, o,
+                           src_bytes, w_bytes, tp);
+    } else {
+        const uint32_t tiles = (p.M + 255) / 256;
+        hipLaunchKernelGGL((igemm_dma_kernel<T, 4, 1>), dim3(tiles), dim3(256), 0, s, p, a, b, bias, epi_act, o,
+                           src_bytes, w_bytes, tp);
+    }
+}
+
+// LDS-DMA path: no prologue, channel count a multiple of the K step, 32-bit byte offsets.  Strided data
+// gradients are decomposed into stride*stride dense sub-problems (one per output parity class).
+template <typename T>
+static bool launch_igemm_dma(const GatherParams& p, const void* src, const void* w, const float* bias,
+                             int epi_act, void* out, hipStream_t s) {
+    constexpr int BK = 8 * Elem<T>::VEC;
+    const unsigned long long src_bytes = (unsigned long long)p.N * p.IH * p.IW * p.Cin * sizeof(T);
+    const unsigned long long w_bytes = (unsigned long long)p.Cout * p.K * sizeof(T);
+    if (p.Cin % BK != 0 || p.KH * p.KW > 32 || src_bytes >= (1ull << 31) || w_bytes >= (1ull << 31)) return false;
+    if (p.div == 1) {
+        TapPlan tp;
+        tp.ntaps = p.KH * p.KW;
+        for (int kh = 0; kh < p.KH; ++kh)
+            for (int kw = 0; kw < p.KW; ++kw) {
+                const int t = kh * p.KW + kw;
+                tp.dy[t] = (signed char)(kh * p.k_mul); tp.dx[t] = (signed char)(kw * p.k_mul); tp.wt[t] = (signed char)t;
+            }
+        tp.osy = tp.osx = 1; tp.oy0 = tp.ox0 = 0; tp.OHf = p.OH; tp.OWf = p.OW;
+        launch_dma_one<T>(p, tp, src, w, bias, epi_act, out, (uint32_t)src_bytes, (uint32_t)w_bytes, s);
+        return true;
+    }
+    // data gradient of a stride-`div` convolution (o_mul = 1, k_mul = -1, off = pad): output pixel iy = div*y' + py
+    // takes tap kh iff (py + pad - kh) % div == 0, from source row y' + (py + pad - kh) / div
+    if (p.o_mul != 1 || p.k_mul != -1 || bias || epi_act != EVE_ACT_NONE) return false;
+    const int sd = p.div;
+    bool need_zero = false;
+    for (int pass = 0; pass < 2; ++pass) {
+        for (int py = 0; py < sd; ++py)
+            for (int px = 0; px < sd; ++px) {
+                TapPlan tp;
+                tp.ntaps = 0;
+                for (int kh = 0; kh < p.KH; ++kh)
+                    for (int kw = 0; kw < p.KW; ++kw) {
+                        const int ny = py + p.off - kh, nx = px + p.off - kw;
+                        if (ny % sd != 0 || nx % sd != 0) continue;
+                        tp.dy[tp.ntaps] = (signed char)(ny / sd); tp.dx[tp.ntaps] = (signed char)(nx / sd);
+                        tp.wt[tp.ntaps] = (signed char)(kh * p.KW + kw);
+                        ++tp.ntaps;
+                    }
+                const int sub_h = (p.OH - py + sd - 1) / sd, sub_w = (p.OW - px + sd - 1) / sd;
+                if (sub_h <= 0 || sub_w <= 0) continue;
+                if (tp.ntaps == 0) { need_zero = true; continue; }
+                if (pass == 0) continue;
+                GatherParams q = p;
+                q.OH = sub_h; q.OW = sub_w;
+                q.o_mul = 1; q.off = 0; q.div = 1;
+                q.M = (uint32_t)((long long)p.N * sub_h * sub_w);
+                q.fd_ohw = make_fastdiv(sub_h * sub_w); q.fd_ow = make_fastdiv(sub_w);
+                tp.osy = tp.osx = sd; tp.oy0 = py; tp.ox0 = px; tp.OHf = p.OH; tp.OWf = p.OW;
+                launch_dma_one<T>(q, tp, src, w, bias, epi_act, out, (uint32_t)src_bytes, (uint32_t)w_bytes, s);
+            }
+        if (pass == 0 && need_zero)
+            (void)hipMemsetAsync(out, 0, (size_t)p.N * p.OH * p.OW * p.Cout * sizeof(T), s);
+    }
+    return true;
+}
+
+template <typename T>
 static int launch_igemm(const GatherParams& p, const void* src, const void* w, const float* bias,
                         const float* ss, int pro_act, int epi_act, void* out, hipStream_t s) {
-    {   // LDS-DMA kernel: uniform tap per K step, no prologue, 32-bit byte offsets
-        constexpr int BK = 8 * Elem<T>::VEC;
-        const unsigned long long src_bytes = (unsigned long long)p.N * p.IH * p.IW * p.Cin * sizeof(T);
-        const unsigned long long w_bytes = (unsigned long long)p.Cout * p.K * sizeof(T);
-        if (!ss && !use_v1() && p.div == 1 && p.Cin % BK == 0 && p.KH * p.KW <= 32 && src_bytes < (1ull << 31) &&
-            w_bytes < (1ull << 31)) {
-            const T* a = (const T*)src; const T* b = (const T*)w; T* o = (T*)out;
-            if (p.Cout > 64) {
-                const uint32_t tiles = ((p.M + 127) / 128) * ((p.Cout + 127) / 128);
-                hipLaunchKernelGGL((igemm_dma_kernel<T, 2, 2>), dim3(tiles), dim3(256), 0, s, p, a, b, bias, epi_act, o,
-                                   (uint32_t)src_bytes, (uint32_t)w_bytes);
-            } else {
-                const uint32_t tiles = (p.M + 255) / 256;
-                hipLaunchKernelGGL((igemm_dma_kernel<T, 4, 1>), dim3(tiles), dim3(256), 0, s, p, a, b, bias, epi_act, o,
-                                   (uint32_t)src_bytes, (uint32_t)w_bytes);
-            }
-            return 0;
-        }
-    }
+    if (!ss && !use_v1() && launch_igemm_dma<T>(p, src, w, bias, epi_act, out, s)) return 0;
     const bool wide = p.Cout > 64;
     const uint32_t bn = wide ? 128 : 64;
     const uint32_t tiles = ((p.M + 127) / 128) * ((p.Cout + bn - 1) / bn);

@@ -193,6 +193,33 @@ class HipKernels(object):
                                                self._stream()))
         return dx, dres, sums
 
+    def instnorm_fwd_fused(self, x, gamma, beta, res, act, eps=1e-5):
+        """Single-launch stats + apply; returns (y, mean_rstd) or None when the plane is too large."""
+        N, H, W, C = x.shape
+        y = torch.empty_like(x)
+        mr = torch.empty((N, C, 2), dtype=torch.float32, device=x.device)
+        st = self.lib.eve_instnorm_fwd_fused(dt_code(x.dtype), N, H * W, C, self._p(x),
+                                             self._p(self._f32(gamma, 'gamma')), self._p(self._f32(beta, 'beta')),
+                                             self._p(res), act, eps, self._p(y), self._p(mr), self._stream())
+        if st == -1:
+            return None
+        self._ck(st)
+        return y, mr
+
+    def instnorm_bwd_fused(self, dy, y, x, mr, gamma, act, want_dres):
+        """Single-launch backward; returns (dx, dres, sums) or None when the plane is too large."""
+        N, H, W, C = x.shape
+        dx = torch.empty_like(x)
+        dres = torch.empty_like(x) if want_dres else None
+        sums = torch.empty((N, C, 2), dtype=torch.float32, device=x.device)
+        st = self.lib.eve_instnorm_bwd_fused(dt_code(x.dtype), N, H * W, C, self._p(dy), self._p(y), self._p(x),
+                                             self._p(mr), self._p(self._f32(gamma, 'gamma')), act, self._p(dx),
+                                             self._p(dres), self._p(sums), self._stream())
+        if st == -1:
+            return None
+        self._ck(st)
+        return dx, dres, sums
+
     # ------------------------------------------------------------------ element-wise
     def act_bwd(self, dy, y, act):
         dx = torch.empty_like(dy)
@@ -382,10 +409,11 @@ class HipKernels(object):
         self._ck(self.lib.eve_sumsq(g.numel(), self._p(self._f32(g, 'g')), self._p(out), self._stream()))
         return out
 
-    def adam_step(self, p, g, m, v, sumsq, max_norm, gscale, lr, beta1, beta2, eps, weight_decay, step):
+    def adam_step(self, p, g, m, v, sumsq, max_norm, gscale, lr, beta1, beta2, eps, weight_decay, step,
+                  step_dev=None):
         self._ck(self.lib.eve_adam_step(p.numel(), self._p(p), self._p(g), self._p(m), self._p(v),
                                         self._p(sumsq), max_norm, gscale, lr, beta1, beta2, eps,
-                                        weight_decay, step, self._stream()))
+                                        weight_decay, step, self._p(step_dev), self._stream()))
 
 
 _default = None

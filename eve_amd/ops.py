@@ -100,10 +100,14 @@ class InstNormActFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, gamma, beta, res, act, eps):
         k = default_kernels()
-        mr = k.instnorm_stats(x, eps)
         g = gamma.detach().float().contiguous() if gamma is not None else None
         b = beta.detach().float().contiguous() if beta is not None else None
-        y = k.instnorm_act_fwd(x, mr, g, b, res, act)
+        fused = k.instnorm_fwd_fused(x, g, b, res, act, eps)     # one launch when the plane fits in registers
+        if fused is not None:
+            y, mr = fused
+        else:
+            mr = k.instnorm_stats(x, eps)
+            y = k.instnorm_act_fwd(x, mr, g, b, res, act)
         ctx.act, ctx.has_res, ctx.has_affine = act, res is not None, gamma is not None
         ctx.save_for_backward(x, y, mr, g)
         return y
@@ -112,8 +116,11 @@ class InstNormActFn(torch.autograd.Function):
     def backward(ctx, dy):
         k = default_kernels()
         x, y, mr, g = ctx.saved_tensors
-        dx, dres, sums = k.instnorm_act_bwd(dy.contiguous(), y, x, mr, g, ctx.act,
-                                            ctx.has_res and ctx.needs_input_grad[3])
+        want_dres = ctx.has_res and ctx.needs_input_grad[3]
+        out = k.instnorm_bwd_fused(dy.contiguous(), y, x, mr, g, ctx.act, want_dres)
+        if out is None:
+            out = k.instnorm_act_bwd(dy.contiguous(), y, x, mr, g, ctx.act, want_dres)
+        dx, dres, sums = out
         dgamma = dbeta = None
         if ctx.has_affine:
             s = sums.sum(dim=0)                 # [C, 2]: tiny N-reduction of per-plane partials

@@ -67,31 +67,48 @@ class FlatParameters(object):
 
 
 class Trainer(object):
-    """One optimiser step = `step(batch)`; `loss_fn(batch) -> dict with 'full_loss'` runs the forward."""
+    """One optimiser step = `step(batch)`; `loss_fn(batch) -> dict with 'full_loss'` runs the forward.
 
-    def __init__(self, modules, config, loss_fn, distributed=False, device=None):
+    use_graph=True captures the step into a hipGraph (torch.cuda.CUDAGraph over the stream our kernels are
+    launched on) after two eager warm-up steps and replays it afterwards: the step is ~600 launches, a third of
+    them tiny tail/loss kernels whose host-side enqueue would otherwise leave the GPU idle at the start of every
+    backward.  Shapes are static (B, T fixed), so a new batch is copied into the captured input buffers.
+    With data parallelism the graph holds forward+backward only; the gradient all-reduce, clip and Adam run
+    eagerly behind it (collectives are not captured)."""
+
+    def __init__(self, modules, config, loss_fn, distributed=False, device=None, use_graph=False):
         self.modules = list(modules)
         self.config = config
         self.loss_fn = loss_fn
         self.fp = FlatParameters(self.modules, device)
-        self.sumsq = torch.zeros(1, dtype=torch.float32, device=self.fp.flat.device)
+        dev = self.fp.flat.device
+        self.sumsq = torch.zeros(1, dtype=torch.float32, device=dev)
+        self.step_dev = torch.zeros(1, dtype=torch.int32, device=dev)
         self.sync = GradSync(self.fp.grad, self.fp.entries) if distributed else None
         self.step_count = 0
         self.beta1, self.beta2, self.eps = 0.9, 0.999, 1e-8      # torch.optim.Adam defaults (train.py:49-55)
+        self.use_graph = bool(use_graph)
+        self._graph = None
+        self._static_batch = None
+        self._static_terms = None
+        self._invalidate()
+
+    def _invalidate(self):
         for m in self.modules:
             if hasattr(m, 'invalidate_packs'):
                 m.invalidate_packs()
 
-    def step(self, batch):
-        k = default_kernels()
-        cfg = self.config
+    # ---- the two halves of a step ----
+    def _forward_backward(self, batch):
         self.fp.zero_grad()
-        if self.sync is not None:
-            self.sync.start_step()
         terms = self.loss_fn(batch)
         terms['full_loss'].backward()
-        gscale = self.sync.finish_step() if self.sync is not None else 1.0
-        self.step_count += 1
+        return terms
+
+    def _update(self, gscale):
+        k = default_kernels()
+        cfg = self.config
+        self.step_dev.add_(1)
         clip = cfg.do_gradient_clipping and cfg.gradient_clip_by == 'norm'
         if cfg.do_gradient_clipping and not clip:
             self.fp.grad.mul_(gscale).clamp_(-cfg.gradient_clip_amount, cfg.gradient_clip_amount)
@@ -101,21 +118,66 @@ class Trainer(object):
             k.sumsq(self.fp.grad, self.sumsq)
         k.adam_step(self.fp.flat, self.fp.grad, self.fp.m, self.fp.v, self.sumsq if clip else None,
                     float(cfg.gradient_clip_amount), gscale, float(cfg.learning_rate), self.beta1, self.beta2,
-                    self.eps, float(cfg.weight_decay), self.step_count)
-        for m in self.modules:
-            if hasattr(m, 'invalidate_packs'):
-                m.invalidate_packs()
+                    self.eps, float(cfg.weight_decay), 0, step_dev=self.step_dev)
+        self._invalidate()
+
+    def _eager_step(self, batch):
+        if self.sync is not None:
+            self.sync.start_step()
+        terms = self._forward_backward(batch)
+        gscale = self.sync.finish_step() if self.sync is not None else 1.0
+        self._update(gscale)
         return terms
 
+    def _capture(self, batch):
+        self._static_batch = {k: (v.clone() if isinstance(v, torch.Tensor) else v) for k, v in batch.items()}
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):                      # warm-up off the default stream, as capture requires
+            for _ in range(2):
+                if self.sync is not None:
+                    self._forward_backward(self._static_batch)
+                    self._collective_and_update()
+                else:
+                    self._eager_step(self._static_batch)
+                self.step_count += 1
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self._graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self._graph):
+            self._static_terms = self._forward_backward(self._static_batch)
+            if self.sync is None:
+                self._update(1.0)
 
-def eyenet_trainer(eye_net, config, distributed=False):
+    def _collective_and_update(self):
+        self.sync.start_step()
+        self._update(self.sync.finish_step())
+
+    def step(self, batch):
+        if not self.use_graph:
+            self.step_count += 1
+            return self._eager_step(batch)
+        if self._graph is None:
+            self._capture(batch)
+        else:
+            for k, v in batch.items():
+                if isinstance(v, torch.Tensor) and v.data_ptr() != self._static_batch[k].data_ptr():
+                    self._static_batch[k].copy_(v, non_blocking=True)
+        self._graph.replay()
+        if self.sync is not None:
+            self._collective_and_update()
+        self.step_count += 1
+        return self._static_terms
+
+
+def eyenet_trainer(eye_net, config, distributed=False, use_graph=False):
     def loss_fn(batch):
         return losses.eyenet_loss_terms(eye_net.forward_sequence(batch), batch, config)
-    return Trainer([eye_net], config, loss_fn, distributed=distributed)
+    return Trainer([eye_net], config, loss_fn, distributed=distributed, use_graph=use_graph)
 
 
-def refinenet_trainer(refine_net, config, distributed=False):
+def refinenet_trainer(refine_net, config, distributed=False, use_graph=False):
     def loss_fn(batch):
         hf, _ = refine_net.forward_sequence(batch['heatmap_initial'], batch.get('screen_frame'))
         return losses.refinenet_loss_terms(hf, batch['heatmap_final_gt'], batch['validity'], config)
-    return Trainer([refine_net], config, loss_fn, distributed=distributed)
+    return Trainer([refine_net], config, loss_fn, distributed=distributed, use_graph=use_graph)

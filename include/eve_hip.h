@@ -91,6 +91,17 @@ int eve_instnorm_act_bwd(int dtype, int N, int HW, int C, const void* dy, const 
                          const void* x, const float* mean_rstd, const float* gamma, int act,
                          void* dx, void* dres, float* sums, eve_stream_t stream);
 
+/* Single-pass variants for planes that fit one workgroup's registers (HW*C <= 64 Ki elements): statistics and
+ * apply in one launch (also writes mean_rstd), and the whole backward in one read of dy / y / x.
+ * Same arithmetic as the three entry points above.  Return -1 (no error text) when the plane does not fit;
+ * the caller then uses the multi-pass entry points.                                                 */
+int eve_instnorm_fwd_fused(int dtype, int N, int HW, int C, const void* x, const float* gamma,
+                           const float* beta, const void* res, int act, float eps, void* y,
+                           float* mean_rstd, eve_stream_t stream);
+int eve_instnorm_bwd_fused(int dtype, int N, int HW, int C, const void* dy, const void* y,
+                           const void* x, const float* mean_rstd, const float* gamma, int act,
+                           void* dx, void* dres, float* sums, eve_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Element-wise activation gradient: dx = dy * act'(y)  (for Linear/conv epilogue activations).
  * ------------------------------------------------------------------------------------------------ */
@@ -185,10 +196,12 @@ int eve_clstm_gates_fwd(int dtype, long long P, int C, const void* gates, const 
 /* out[0] += sum g^2 (caller zeroes out[0]; take sqrt on the host or in eve_adam_step)              */
 int eve_sumsq(long long n, const float* g, float* out, eve_stream_t stream);
 /* clip factor c = min(1, max_norm / (sqrt(*sumsq) * gscale + 1e-6)) if sumsq != NULL else 1;
- * g' = c * gscale * g + wd * p;  m,v Adam moments;  p -= lr * mhat / (sqrt(vhat) + eps)           */
+ * g' = c * gscale * g + wd * p;  m,v Adam moments;  p -= lr * mhat / (sqrt(vhat) + eps).
+ * The bias-correction step t is `step`, or *step_dev (device int) when step_dev != NULL -- the form a
+ * captured hipGraph needs, since a replay cannot change kernel arguments.                            */
 int eve_adam_step(long long n, float* p, const float* g, float* m, float* v, const float* sumsq,
                   float max_norm, float gscale, float lr, float beta1, float beta2, float eps,
-                  float weight_decay, int step, eve_stream_t stream);
+                  float weight_decay, int step, const int* step_dev, eve_stream_t stream);
 
 #ifdef __cplusplus
 }

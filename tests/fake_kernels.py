@@ -97,6 +97,17 @@ class FakeKernels(object):
         dx = k * (g - s1[:, None, None] / hw - xhat * s2[:, None, None] / hw)
         return dx.to(x.dtype), (g.to(x.dtype) if want_dres else None), torch.stack([s1, s2], dim=-1)
 
+    def instnorm_fwd_fused(self, x, gamma, beta, res, act, eps=1e-5):
+        if x.shape[1] * x.shape[2] * x.shape[3] > 65536:
+            return None
+        mr = self.instnorm_stats(x, eps)
+        return self.instnorm_act_fwd(x, mr, gamma, beta, res, act), mr
+
+    def instnorm_bwd_fused(self, dy, y, x, mr, gamma, act, want_dres):
+        if x.shape[1] * x.shape[2] * x.shape[3] > 65536:
+            return None
+        return self.instnorm_act_bwd(dy, y, x, mr, gamma, act, want_dres)
+
     def act_bwd(self, dy, y, act):
         return (dy.float() * act_grad_from_out(y.float(), act)).to(dy.dtype)
 
@@ -221,7 +232,10 @@ class FakeKernels(object):
         out += (g.double() ** 2).sum().float()
         return out
 
-    def adam_step(self, p, g, m, v, sumsq, max_norm, gscale, lr, beta1, beta2, eps, weight_decay, step):
+    def adam_step(self, p, g, m, v, sumsq, max_norm, gscale, lr, beta1, beta2, eps, weight_decay, step,
+                  step_dev=None):
+        if step_dev is not None:
+            step = int(step_dev)
         clip = gscale
         if sumsq is not None:
             total = float(sumsq.sqrt()) * gscale

@@ -134,7 +134,8 @@ def test_conv_rejects_bad_shapes(hip):
         hip.conv2d_fwd(torch.zeros((1, 8, 8, 8)), torch.zeros((8, 3, 3, 8)), None, 1, 1)
 
 
-PLANE_CASES = [(3, 32, 32, 64), (2, 4, 4, 512), (2, 5, 8, 64), (2, 72, 128, 16), (2, 9, 16, 256), (1, 7, 5, 8)]
+PLANE_CASES = [(3, 32, 32, 64), (2, 4, 4, 512), (2, 5, 8, 64), (2, 72, 128, 16), (2, 9, 16, 256), (1, 7, 5, 8),
+               (2, 16, 16, 128), (3, 8, 8, 256), (2, 18, 32, 64), (2, 36, 64, 32), (2, 64, 64, 64)]
 
 
 @pytest.mark.parametrize('dtype', DTYPES, ids=['f32', 'bf16'])
@@ -161,6 +162,18 @@ def test_instnorm_fwd_bwd(hip, ref, dtype, shape):
         close(s_g, s_w, torch.float32, 'instnorm_act bwd sums', scale=float(s_w.abs().max()) * 4)
         if r is not None:
             close(dres_g, dres_w, dtype, 'instnorm_act bwd dres')
+        fused = hip.instnorm_fwd_fused(dev(x), dev(g), dev(b), dev(r), act)
+        nvec = H * W * C // (4 if dtype == torch.float32 else 8)
+        assert (fused is None) == (nvec > 8192)          # 8 vectors per thread x 1024 threads
+        if fused is not None:
+            close(fused[0], y_w, dtype, 'fused instnorm fwd act=%d' % act)
+            close(fused[1][..., 0], mr_w[..., 0], torch.float32, 'fused mean', scale=1.0)
+            close(fused[1][..., 1], mr_w[..., 1], torch.float32, 'fused rstd', scale=float(mr_w[..., 1].max()) * 3)
+            fb = hip.instnorm_bwd_fused(dev(dy), dev(y_w), dev(x), dev(mr_w), dev(g), act, r is not None)
+            close(fb[0], dx_w, dtype, 'fused instnorm bwd dx act=%d' % act, scale=float(dx_w.abs().max()) + 0.05)
+            close(fb[2], s_w, torch.float32, 'fused instnorm bwd sums', scale=float(s_w.abs().max()) * 4)
+            if r is not None:
+                close(fb[1], dres_w, dtype, 'fused instnorm bwd dres')
 
 
 @pytest.mark.parametrize('dtype', DTYPES, ids=['f32', 'bf16'])
