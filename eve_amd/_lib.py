@@ -36,6 +36,8 @@ SIGNATURES = {
     'eve_add': [I, L, P, P, P, P],
     'eve_maxpool3x3s2_fwd': [I, I, I, I, I, P, P, P, P],
     'eve_maxpool3x3s2_bwd': [I, I, I, I, I, P, P, P, P],
+    'eve_in_relu_maxpool_fwd': [I, I, I, I, I, P, P, P, P, P],
+    'eve_in_relu_maxpool_bwd': [I, I, I, I, I, P, P, P, P, P, P, P],
     'eve_avgpool_fwd': [I, I, I, I, P, P, P],
     'eve_avgpool_bwd': [I, I, I, I, P, P, P],
     'eve_adaptive_maxpool_fwd': [I, I, I, I, I, I, I, P, P, P, P],

@@ -38,14 +38,15 @@ struct TapPlan {
 
 // =================================================================================================
 template <typename T, int WM, int WN>
-__global__ __launch_bounds__(256) void igemm_dma_kernel(const GatherParams p, const T* __restrict__ src,
+__global__ __launch_bounds__(64 * WM * WN) void igemm_dma_kernel(const GatherParams p, const T* __restrict__ src,
                                                         const T* __restrict__ w, const float* __restrict__ bias,
                                                         const int epi_act, T* __restrict__ out,
                                                         const uint32_t src_bytes, const uint32_t w_bytes,
                                                         const TapPlan tp) {
     constexpr int VEC = Elem<T>::VEC, ES = (int)sizeof(T);
     constexpr int BM = 64 * WM, BN = 64 * WN, BK = 8 * VEC;
-    constexpr int A_DMA = BM / 32, B_DMA = BN / 32;
+    constexpr int NTHR = 64 * WM * WN, RPP = NTHR / 8;       // threads, tile rows covered per DMA pass
+    constexpr int A_DMA = BM / RPP, B_DMA = BN / RPP;
     __shared__ uint4 lds[2 * (BM + BN) * 8];
 
     const int tid = threadIdx.x;
@@ -65,7 +66,7 @@ __global__ __launch_bounds__(256) void igemm_dma_kernel(const GatherParams p, co
     bool a_ok[A_DMA];
 #pragma unroll
     for (int j = 0; j < A_DMA; ++j) {
-        const uint32_t m = m0 + r0 + 32 * j;
+        const uint32_t m = m0 + r0 + RPP * j;
         a_ok[j] = m < p.M;
         const uint32_t mm = a_ok[j] ? m : 0;
         const uint32_t n = fd_div(mm, p.fd_ohw);
@@ -89,7 +90,7 @@ __global__ __launch_bounds__(256) void igemm_dma_kernel(const GatherParams p, co
     int b_off[B_DMA];
 #pragma unroll
     for (int j = 0; j < B_DMA; ++j) {
-        const uint32_t co = n0 + r0 + 32 * j;
+        const uint32_t co = n0 + r0 + RPP * j;
         b_off[j] = co < (uint32_t)p.Cout ? (int)(co * (uint32_t)p.K) * ES + vs * 16 : EVE_OOB;
     }
 
@@ -107,12 +108,12 @@ __global__ __launch_bounds__(256) void igemm_dma_kernel(const GatherParams p, co
 #pragma unroll
         for (int j = 0; j < A_DMA; ++j) {
             const int voff = ((a_mask[j] >> tap) & 1u) ? a_off[j] + delta : EVE_OOB;
-            lds_dma16(rs_src, base + j * 256, voff);
+            lds_dma16(rs_src, base + j * NTHR, voff);
         }
 #pragma unroll
         for (int j = 0; j < B_DMA; ++j) {
             const int voff = b_off[j] == EVE_OOB ? EVE_OOB : b_off[j] + wk;
-            lds_dma16(rs_w, base + BM * 8 + j * 256, voff);
+            lds_dma16(rs_w, base + BM * 8 + j * NTHR, voff);
         }
         ci0 += BK;                                   // advance to the next K step (uniform)
         if (ci0 == p.Cin) {

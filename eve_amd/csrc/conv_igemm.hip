@@ -495,7 +495,13 @@ static void launch_dma_one(const GatherParams& p, const TapPlan& tp, const void*
                            const float* bias, int epi_act, void* out, uint32_t src_bytes, uint32_t w_bytes,
                            hipStream_t s) {
     const T* a = (const T*)src; const T* b = (const T*)w; T* o = (T*)out;
-    if (p.Cout > 64) {
+    static int big = -1;
+    if (big < 0) { const char* e = getenv("EVE_CONV_TILE"); big = (e && e[0] == '2') ? 1 : 0; }
+    if (p.Cout > 64 && big && p.M >= 256 * 256) {
+        const uint32_t tiles = ((p.M + 255) / 256) * ((p.Cout + 127) / 128);
+        hipLaunchKernelGGL((igemm_dma_kernel<T, 4, 2>), dim3(tiles), dim3(512), 0, s, p, a, b, bias, epi_act, o,
+                           src_bytes, w_bytes, tp);
+    } else if (p.Cout > 64) {
         const uint32_t tiles = ((p.M + 127) / 128) * ((p.Cout + 127) / 128);
         hipLaunchKernelGGL((igemm_dma_kernel<T, 2, 2>), dim3(tiles), dim3(256), 0, s, p, a, b, bias, epi_act, o,
                            src_bytes, w_bytes, tp);

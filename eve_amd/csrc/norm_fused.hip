@@ -243,3 +243,176 @@ extern "C" int eve_instnorm_bwd_fused(int dtype, int N, int HW, int C, const voi
     EVE_CHECK_LAUNCH();
     return 0;
 }
+
+// =================================================================================================
+// ResNet stem tail: InstanceNorm (no affine) -> ReLU -> max-pool 3x3/2 pad 1 in ONE pass over the conv output
+// (torchvision ResNet._forward_impl bn1/relu/maxpool, reference src/models/eye_net.py:48-50,106).
+// relu(IN(.)) is monotone in the raw value (rstd > 0), so the window arg-max is taken on raw values and only
+// the winner is normalised.  The 64x64x64 normalised tensor (1 GB per step at N=1920) is never materialised.
+// Backward uses y = xhat wherever y > 0:  sum g = sum d*[y>0],  sum g*xhat = sum d*y  over the POOLED tensors,
+// then one dense pass writes d(conv out) = rstd * (g - mean g - xhat * mean(g xhat)).
+// =================================================================================================
+namespace eve {
+
+template <typename T>
+__global__ __launch_bounds__(256) void in_relu_pool_fwd_kernel(const T* __restrict__ x, const float* __restrict__ mr,
+                                                               T* __restrict__ y, uint8_t* __restrict__ idx,
+                                                               int IH, int IW, int OH, int OW, int C, long long items) {
+    constexpr int VEC = Elem<T>::VEC;
+    const int cvecs = C / VEC;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < items; i += (long long)gridDim.x * 256) {
+        const int cv = (int)(i % cvecs);
+        long long t = i / cvecs;
+        const int ow = (int)(t % OW); t /= OW;
+        const int oh = (int)(t % OH);
+        const long long n = t / OH;
+        float best[VEC];
+        uint32_t bi[VEC];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) { best[e] = -INFINITY; bi[e] = 0xffu; }
+        for (int kh = 0; kh < 3; ++kh) {
+            const int ih = oh * 2 - 1 + kh;
+            if (ih < 0 || ih >= IH) continue;
+            for (int kw = 0; kw < 3; ++kw) {
+                const int iw = ow * 2 - 1 + kw;
+                if (iw < 0 || iw >= IW) continue;
+                float f[VEC];
+                Elem<T>::unpack(*reinterpret_cast<const uint4*>(x + ((n * IH + ih) * IW + iw) * C + cv * VEC), f);
+#pragma unroll
+                for (int e = 0; e < VEC; ++e)
+                    if (f[e] > best[e] || bi[e] == 0xffu) { best[e] = f[e]; bi[e] = kh * 3 + kw; }
+            }
+        }
+        const float* m = mr + ((size_t)n * C + cv * VEC) * 2;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            const float z = (best[e] - m[2 * e]) * m[2 * e + 1];
+            best[e] = z > 0.f ? z : 0.f;
+        }
+        reinterpret_cast<uint4*>(y)[i] = Elem<T>::pack(best);
+        uint8_t* ip = idx + i * VEC;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) ip[e] = (uint8_t)bi[e];
+    }
+}
+
+// one workgroup per image: pass 1 over the pooled tensors (sums), pass 2 dense over the conv output
+template <typename T>
+__global__ __launch_bounds__(256) void in_relu_pool_bwd_kernel(const T* __restrict__ dyp, const T* __restrict__ yp,
+                                                               const uint8_t* __restrict__ idx,
+                                                               const T* __restrict__ x, const float* __restrict__ mr,
+                                                               T* __restrict__ dx, int IH, int IW, int OH, int OW,
+                                                               int C) {
+    constexpr int VEC = Elem<T>::VEC;
+    __shared__ float sh[2 * 256 * VEC];
+    __shared__ float sh_tot[2 * 1024];
+    const int cvecs = C / VEC, phases = 256 / cvecs;
+    const int tid = threadIdx.x, cv = tid % cvecs, ph = tid / cvecs;
+    const bool on = ph < phases;
+    const size_t n = blockIdx.x;
+    float s1[VEC], s2[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
+    if (on)
+        for (int px = ph; px < OH * OW; px += phases) {
+            const size_t o = (n * OH * OW + px) * C + cv * VEC;
+            float d[VEC], yy[VEC];
+            Elem<T>::unpack(*reinterpret_cast<const uint4*>(dyp + o), d);
+            Elem<T>::unpack(*reinterpret_cast<const uint4*>(yp + o), yy);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e)
+                if (yy[e] > 0.f) { s1[e] += d[e]; s2[e] += d[e] * yy[e]; }
+        }
+    if (on) {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            sh[(ph * cvecs + cv) * VEC + e] = s1[e];
+            sh[256 * VEC + (ph * cvecs + cv) * VEC + e] = s2[e];
+        }
+    }
+    __syncthreads();
+    if (on && ph == 0) {
+        for (int q = 1; q < phases; ++q)
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                s1[e] += sh[(q * cvecs + cv) * VEC + e];
+                s2[e] += sh[256 * VEC + (q * cvecs + cv) * VEC + e];
+            }
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) { sh_tot[cv * VEC + e] = s1[e]; sh_tot[1024 + cv * VEC + e] = s2[e]; }
+    }
+    __syncthreads();
+    if (!on) return;
+    float mean[VEC], rstd[VEC];
+    const float inv = 1.f / (float)(IH * IW);
+    {
+        const float* m = mr + (n * C + cv * VEC) * 2;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            mean[e] = m[2 * e]; rstd[e] = m[2 * e + 1];
+            s1[e] = sh_tot[cv * VEC + e] * inv; s2[e] = sh_tot[1024 + cv * VEC + e] * inv;
+        }
+    }
+    for (int px = ph; px < IH * IW; px += phases) {
+        const int ih = px / IW, iw = px - ih * IW;
+        float g[VEC];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) g[e] = 0.f;
+        for (int oh = ih / 2; oh <= (ih + 1) / 2; ++oh) {
+            if (oh >= OH) continue;
+            const int kh = ih - (oh * 2 - 1);
+            for (int ow = iw / 2; ow <= (iw + 1) / 2; ++ow) {
+                if (ow >= OW) continue;
+                const uint32_t code = kh * 3 + (iw - (ow * 2 - 1));
+                const size_t o = ((n * OH + oh) * OW + ow) * C + cv * VEC;
+                float d[VEC], yy[VEC];
+                Elem<T>::unpack(*reinterpret_cast<const uint4*>(dyp + o), d);
+                Elem<T>::unpack(*reinterpret_cast<const uint4*>(yp + o), yy);
+                const uint8_t* ip = idx + o;
+#pragma unroll
+                for (int e = 0; e < VEC; ++e)
+                    if (ip[e] == code && yy[e] > 0.f) g[e] += d[e];
+            }
+        }
+        const size_t xo = (n * IH * IW + px) * C + cv * VEC;
+        float xx[VEC];
+        Elem<T>::unpack(*reinterpret_cast<const uint4*>(x + xo), xx);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) g[e] = rstd[e] * (g[e] - s1[e] - (xx[e] - mean[e]) * rstd[e] * s2[e]);
+        *reinterpret_cast<uint4*>(dx + xo) = Elem<T>::pack(g);
+    }
+}
+
+}  // namespace eve
+
+extern "C" int eve_in_relu_maxpool_fwd(int dtype, int N, int IH, int IW, int C, const void* x, const float* mean_rstd,
+                                       void* y, uint8_t* idx, eve_stream_t stream) {
+    const int vec = dtype == EVE_DT_BF16 ? 8 : 4;
+    if ((dtype != EVE_DT_F32 && dtype != EVE_DT_BF16) || N <= 0 || IH <= 0 || IW <= 0 || C <= 0 || C % vec || !x ||
+        !mean_rstd || !y || !idx)
+        return set_error_msg("in_relu_maxpool_fwd: bad arguments");
+    const int OH = (IH - 1) / 2 + 1, OW = (IW - 1) / 2 + 1;
+    const long long items = (long long)N * OH * OW * (C / vec);
+    long long blocks = (items + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == EVE_DT_BF16) hipLaunchKernelGGL(in_relu_pool_fwd_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, s, (const bf16_t*)x, mean_rstd, (bf16_t*)y, idx, IH, IW, OH, OW, C, items);
+    else                      hipLaunchKernelGGL(in_relu_pool_fwd_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, s, (const float*)x, mean_rstd, (float*)y, idx, IH, IW, OH, OW, C, items);
+    EVE_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int eve_in_relu_maxpool_bwd(int dtype, int N, int IH, int IW, int C, const void* dy_pool, const void* y_pool,
+                                       const uint8_t* idx, const void* x, const float* mean_rstd, void* dx,
+                                       eve_stream_t stream) {
+    const int vec = dtype == EVE_DT_BF16 ? 8 : 4;
+    if ((dtype != EVE_DT_F32 && dtype != EVE_DT_BF16) || N <= 0 || IH <= 0 || IW <= 0 || C <= 0 || C % vec ||
+        C / vec > 256 || C > 1024 || !dy_pool || !y_pool || !idx || !x || !mean_rstd || !dx)
+        return set_error_msg("in_relu_maxpool_bwd: bad arguments");
+    const int OH = (IH - 1) / 2 + 1, OW = (IW - 1) / 2 + 1;
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == EVE_DT_BF16) hipLaunchKernelGGL(in_relu_pool_bwd_kernel<bf16_t>, dim3(N), dim3(256), 0, s, (const bf16_t*)dy_pool, (const bf16_t*)y_pool, idx, (const bf16_t*)x, mean_rstd, (bf16_t*)dx, IH, IW, OH, OW, C);
+    else                      hipLaunchKernelGGL(in_relu_pool_bwd_kernel<float>, dim3(N), dim3(256), 0, s, (const float*)dy_pool, (const float*)y_pool, idx, (const float*)x, mean_rstd, (float*)dx, IH, IW, OH, OW, C);
+    EVE_CHECK_LAUNCH();
+    return 0;
+}

@@ -156,8 +156,7 @@ class EyeNet(nn.Module):
         """x: [N, H, W, Cpad] NHWC compute dtype -> [N, 512] float32 (torchvision ResNet._forward_impl)."""
         cnn = self.cnn_layers
         y = ops.conv2d(x, cnn.conv1.weight, None, P['conv1'], stride=2, pad=3)
-        y = ops.instnorm_act(y, act=ACT_RELU)
-        y = ops.MaxPool3x3s2Fn.apply(y)
+        y = ops.InReluMaxPoolFn.apply(y, 1e-5)          # bn1 -> relu -> maxpool, fused
         for name, blk in cnn.blocks():
             out = ops.conv2d(y, blk.conv1.weight, None, P[name + '.conv1'], stride=blk.stride, pad=1)
             out = ops.instnorm_act(out, act=ACT_RELU)

@@ -251,6 +251,23 @@ class HipKernels(object):
                                                self._p(dx), self._stream()))
         return dx
 
+    def in_relu_maxpool_fwd(self, x, mr):
+        N, IH, IW, C = x.shape
+        OH, OW = (IH - 1) // 2 + 1, (IW - 1) // 2 + 1
+        y = torch.empty((N, OH, OW, C), dtype=x.dtype, device=x.device)
+        idx = torch.empty((N, OH, OW, C), dtype=torch.uint8, device=x.device)
+        self._ck(self.lib.eve_in_relu_maxpool_fwd(dt_code(x.dtype), N, IH, IW, C, self._p(x), self._p(mr),
+                                                  self._p(y), self._p(idx), self._stream()))
+        return y, idx
+
+    def in_relu_maxpool_bwd(self, dy_pool, y_pool, idx, x, mr):
+        N, IH, IW, C = x.shape
+        dx = torch.empty_like(x)
+        self._ck(self.lib.eve_in_relu_maxpool_bwd(dt_code(x.dtype), N, IH, IW, C, self._p(dy_pool), self._p(y_pool),
+                                                  self._p(idx), self._p(x), self._p(mr), self._p(dx),
+                                                  self._stream()))
+        return dx
+
     def avgpool_fwd(self, x):
         N, H, W, C = x.shape
         y = torch.empty((N, C), dtype=x.dtype, device=x.device)

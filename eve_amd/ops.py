@@ -160,6 +160,23 @@ class MaxPool3x3s2Fn(torch.autograd.Function):
         return default_kernels().maxpool3x3s2_bwd(dy.contiguous(), idx, ctx.in_hw)
 
 
+class InReluMaxPoolFn(torch.autograd.Function):
+    """maxpool3x3s2(relu(IN(x))), no affine: the ResNet stem tail in two launches (stats + fused pass)."""
+
+    @staticmethod
+    def forward(ctx, x, eps):
+        k = default_kernels()
+        mr = k.instnorm_stats(x, eps)
+        y, idx = k.in_relu_maxpool_fwd(x, mr)
+        ctx.save_for_backward(x, mr, y, idx)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, mr, y, idx = ctx.saved_tensors
+        return default_kernels().in_relu_maxpool_bwd(dy.contiguous(), y, idx, x, mr), None
+
+
 class AvgPoolFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x):

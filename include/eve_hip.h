@@ -120,6 +120,14 @@ int eve_maxpool3x3s2_fwd(int dtype, int N, int IH, int IW, int C, const void* x,
                          uint8_t* idx, eve_stream_t stream);
 int eve_maxpool3x3s2_bwd(int dtype, int N, int IH, int IW, int C, const void* dy,
                          const uint8_t* idx, void* dx, eve_stream_t stream);
+/* ResNet stem tail fused: y = maxpool3x3s2(relu(IN(x))) with no affine, given mean_rstd of x (statistics
+ * from eve_instnorm_stats); the normalised full-resolution tensor is never written.  idx as above.
+ * Backward: dx = d(loss)/dx through pool, ReLU and the instance norm, from the pooled tensors and x.  */
+int eve_in_relu_maxpool_fwd(int dtype, int N, int IH, int IW, int C, const void* x,
+                            const float* mean_rstd, void* y, uint8_t* idx, eve_stream_t stream);
+int eve_in_relu_maxpool_bwd(int dtype, int N, int IH, int IW, int C, const void* dy_pool,
+                            const void* y_pool, const uint8_t* idx, const void* x,
+                            const float* mean_rstd, void* dx, eve_stream_t stream);
 /* mean over the HW plane: y[N][C]; and its gradient dx[n][hw][c] = dy[n][c] / HW                  */
 int eve_avgpool_fwd(int dtype, int N, int HW, int C, const void* x, void* y, eve_stream_t stream);
 int eve_avgpool_bwd(int dtype, int N, int HW, int C, const void* dy, void* dx, eve_stream_t stream);

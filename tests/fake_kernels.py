@@ -124,6 +124,14 @@ class FakeKernels(object):
         dx.scatter_add_(2, idx.permute(0, 3, 1, 2).reshape(N, C, -1), nchw(dy).reshape(N, C, -1))
         return nhwc(dx.view(N, C, in_hw[0], in_hw[1]), dy.dtype)
 
+    def in_relu_maxpool_fwd(self, x, mr):
+        return self.maxpool3x3s2_fwd(self.instnorm_act_fwd(x, mr, None, None, None, ACT_RELU))
+
+    def in_relu_maxpool_bwd(self, dy_pool, y_pool, idx, x, mr):
+        d_act = self.maxpool3x3s2_bwd(dy_pool, idx, (x.shape[1], x.shape[2]))
+        y_act = self.instnorm_act_fwd(x, mr, None, None, None, ACT_RELU)
+        return self.instnorm_act_bwd(d_act, y_act, x, mr, None, ACT_RELU, False)[0]
+
     def avgpool_fwd(self, x):
         return x.float().mean(dim=(1, 2)).to(x.dtype)
 

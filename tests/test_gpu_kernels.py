@@ -195,6 +195,17 @@ def test_pooling_and_resize(hip, ref, dtype):
     dy = rnd(tuple(y_w.shape), dtype, 22)
     close(hip.maxpool3x3s2_bwd(dev(dy), idx_g, (64, 64)), ref.maxpool3x3s2_bwd(dy, idx_w, (64, 64)),
           dtype, 'maxpool bwd')
+    # stem tail fused: IN -> ReLU -> max-pool against the three separate reference steps.  The reference runs in
+    # float32 on the same (dtype-rounded) input: rounding the normalised tensor to bf16 first would create
+    # window ties whose arg-max choice (and gradient routing) is arbitrary.
+    xs = (rnd((2, 64, 64, 64), torch.float32, 50) * 1.3 + 0.2).to(dtype)
+    mr = ref.instnorm_stats(xs)
+    yp_w, idx_w = ref.in_relu_maxpool_fwd(xs.float(), mr)
+    yp_g, idx_g = hip.in_relu_maxpool_fwd(dev(xs), dev(mr))
+    close(yp_g, yp_w, dtype, 'in_relu_maxpool fwd')
+    dyp = rnd(tuple(yp_w.shape), dtype, 51)
+    close(hip.in_relu_maxpool_bwd(dev(dyp), yp_g, idx_g, dev(xs), dev(mr)),
+          ref.in_relu_maxpool_bwd(dyp.float(), yp_w, idx_w, xs.float(), mr), dtype, 'in_relu_maxpool bwd')
     x = rnd((3, 4, 4, 512), dtype, 23)
     close(hip.avgpool_fwd(dev(x)), ref.avgpool_fwd(x), dtype, 'avgpool fwd')
     dy = rnd((3, 512), dtype, 24)
