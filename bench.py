@@ -88,6 +88,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--no-graph', action='store_true', help='launch every kernel eagerly instead of replaying a hipGraph')
+    ap.add_argument('--graph', action='store_true', help='force hipGraph replay also with several ranks')
     ap.add_argument('--profile-steps', type=int, default=2)
     args = ap.parse_args()
 
@@ -100,8 +101,9 @@ def main():
         raise SystemExit('bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)' % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a GPU: the hot path has no CPU fallback')
-    torch.cuda.set_device(local_rank)
-    device = torch.device('cuda', local_rank)
+    dev_index = int(os.environ.get('EVE_AMD_FORCE_DEVICE', local_rank))
+    torch.cuda.set_device(dev_index)
+    device = torch.device('cuda', dev_index)
 
     cfg = eve_amd.reset_standalone_config()
     cfg.import_json(os.path.join(HERE, 'configs', 'eye_net.json'))
@@ -109,7 +111,10 @@ def main():
     net = eve_amd.EyeNet()
     net.compute_dtype = torch.bfloat16 if args.dtype == 'bf16' else torch.float32
     net.to(device)
-    trainer = train.eyenet_trainer(net, cfg, distributed=world > 1, use_graph=not args.no_graph)
+    # one rank: replay the captured step; several ranks: eager launches so each bucket's RCCL all-reduce is issued
+    # from its gradient hook and overlaps the rest of backward (the step is GPU-bound either way)
+    use_graph = args.graph or (world == 1 and not args.no_graph)
+    trainer = train.eyenet_trainer(net, cfg, distributed=world > 1, use_graph=use_graph)
     batch = synthetic_eyenet_batch(args.batch, args.seq, args.size, device, 1000 * rank)
     k = default_kernels()
 
@@ -131,6 +136,8 @@ def main():
     # every conv launch (a graph replay has no per-kernel events; the kernels and shapes are identical)
     prof, event_overhead = {}, None
     if not args.no_roofline:
+        trainer._eager_step(batch)           # settle the caching allocator outside the captured graph's pool
+        torch.cuda.synchronize()
         k.start_profile()
         for _ in range(args.profile_steps):
             trainer._eager_step(batch)
@@ -157,7 +164,7 @@ def main():
                                    % (args.size, args.size),
                        'global_batch': world * args.batch, 'batch_per_gpu': args.batch, 'seq_len': args.seq,
                        'parallelism': 'dp%d' % world},
-            'final_loss': loss, 'hip_graph': not args.no_graph,
+            'final_loss': loss, 'hip_graph': use_graph,
         }
         peak = MFMA_PEAK_TFLOPS[args.dtype]
         if args.size == 128:

@@ -26,6 +26,31 @@ __device__ __forceinline__ void lds_dma16(__amdgpu_buffer_rsrc_t rsrc, const voi
 }
 #define EVE_OOB ((int)0x80000000u)   // >= num_records for every tensor we accept (< 2^31 bytes)
 
+// The same LDS-DMA as inline asm.  hipcc treats the builtin as a store to LDS and protects every later ds_read
+// with s_waitcnt vmcnt(0), which drains a multi-stage prefetch ring at every step; an asm statement is opaque to
+// that bookkeeping, so the waits are exactly the counted s_waitcnt vmcnt(N) the kernel places itself.
+// M0 (the LDS destination base) is written and restored inside the statement.
+typedef int eve_int4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ eve_int4 make_rsrc_words(const void* base, uint32_t bytes) {
+    const uint64_t a = (uint64_t)base;
+    eve_int4 r;
+    r.x = (int)(uint32_t)a;
+    r.y = (int)(uint32_t)((a >> 32) & 0xffffu);      // stride 0
+    r.z = (int)bytes;
+    r.w = 0x00020000;
+    return r;
+}
+__device__ __forceinline__ uint32_t lds_addr_of(const void* generic_ptr) {
+    return (uint32_t)(uintptr_t)((EVE_LDS void*)generic_ptr);
+}
+__device__ __forceinline__ void lds_dma16_asm(const eve_int4& rsrc, uint32_t lds_byte_addr, int voffset) {
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "s"(lds_byte_addr), "v"(voffset), "s"(rsrc)
+                 : "memory");
+}
+
 // The filter taps a launch iterates over (at most 32), as source-pixel displacements and weight tap ids, plus
 // the mapping from the launch's pixel grid to output pixels.  A plain convolution uses all KH*KW taps and the
 // identity mapping; the data gradient of a stride-s convolution is s*s launches, one per output parity class,
@@ -210,6 +235,42 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_dma_kernel(const GatherPar
     }
 }
 
+// 16 MFMAs (4 x 4 accumulator tiles, one K=32 chunk) as ONE asm statement with every accumulator tied in place
+// ("+a": AGPR, D == C).  Left to itself hipcc ping-pongs loop-carried accumulators between two register sets
+// when each gets a single MFMA per trip, and copies them back with v_accvgpr_mov/read/write at the loop edge
+// (10 VALU per MFMA measured in the weight-gradient loop).  The leading s_nop covers a VALU-assembled operand
+// tuple; consecutive MFMAs here never share an accumulator.
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
+__device__ __forceinline__ void mma16_bf16_inplace(f32x4_t (&acc)[4][4], const uint4 (&a4)[4], const uint4 (&b4)[4]) {
+    u32x4_t a[4], b[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { a[i] = __builtin_bit_cast(u32x4_t, a4[i]); b[i] = __builtin_bit_cast(u32x4_t, b4[i]); }
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_mfma_f32_16x16x32_bf16 %0, %16, %20, %0\n\t"
+        "v_mfma_f32_16x16x32_bf16 %1, %16, %21, %1\n\t"
+        "v_mfma_f32_16x16x32_bf16 %2, %16, %22, %2\n\t"
+        "v_mfma_f32_16x16x32_bf16 %3, %16, %23, %3\n\t"
+        "v_mfma_f32_16x16x32_bf16 %4, %17, %20, %4\n\t"
+        "v_mfma_f32_16x16x32_bf16 %5, %17, %21, %5\n\t"
+        "v_mfma_f32_16x16x32_bf16 %6, %17, %22, %6\n\t"
+        "v_mfma_f32_16x16x32_bf16 %7, %17, %23, %7\n\t"
+        "v_mfma_f32_16x16x32_bf16 %8, %18, %20, %8\n\t"
+        "v_mfma_f32_16x16x32_bf16 %9, %18, %21, %9\n\t"
+        "v_mfma_f32_16x16x32_bf16 %10, %18, %22, %10\n\t"
+        "v_mfma_f32_16x16x32_bf16 %11, %18, %23, %11\n\t"
+        "v_mfma_f32_16x16x32_bf16 %12, %19, %20, %12\n\t"
+        "v_mfma_f32_16x16x32_bf16 %13, %19, %21, %13\n\t"
+        "v_mfma_f32_16x16x32_bf16 %14, %19, %22, %14\n\t"
+        "v_mfma_f32_16x16x32_bf16 %15, %19, %23, %15"
+        : "+a"(acc[0][0]), "+a"(acc[0][1]), "+a"(acc[0][2]), "+a"(acc[0][3]), "+a"(acc[1][0]), "+a"(acc[1][1]),
+          "+a"(acc[1][2]), "+a"(acc[1][3]), "+a"(acc[2][0]), "+a"(acc[2][1]), "+a"(acc[2][2]), "+a"(acc[2][3]),
+          "+a"(acc[3][0]), "+a"(acc[3][1]), "+a"(acc[3][2]), "+a"(acc[3][3])
+        : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]));
+}
+// wait states between the last asm MFMA and compiler-generated reads of the accumulators
+__device__ __forceinline__ void mma_drain() { asm volatile("s_nop 15\n\ts_nop 15" ::: "memory"); }
+
 // =================================================================================================
 // bf16 weight gradient.  Block tile = (64*WCO output channels) x (64*WK filter-K values); every wave owns
 // a 64 x 64 piece; each step consumes 64 pixels (two MFMA K=32 chunks).
@@ -220,12 +281,13 @@ __device__ __forceinline__ int tr_key(int row) {
     return ROWB == 128 ? (b1 | (b2 << 1)) : (b0 | (b1 << 1) | (b2 << 2));
 }
 
-__device__ __forceinline__ uint2 lds_tr_read(const char* lds_generic_ptr) {
-    bf16x4v_t r = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((EVE_LDS bf16x4v_t*)(EVE_LDS void*)(lds_generic_ptr));
+// takes a 32-bit LDS byte address: an integer -> LDS pointer cast is free, a generic -> LDS cast is ~6 VALU per read
+__device__ __forceinline__ uint2 lds_tr_read(uint32_t lds_byte_addr) {
+    bf16x4v_t r = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((EVE_LDS bf16x4v_t*)(size_t)lds_byte_addr);
     return __builtin_bit_cast(uint2, r);
 }
 
-template <int WCO, int WK>
+template <int WCO, int WK, bool POW2>
 __global__ __launch_bounds__(256) void wgrad_tr_kernel(const GatherParams p, const bf16_t* __restrict__ x,
                                                        const bf16_t* __restrict__ dy, float* __restrict__ dw,
                                                        const uint32_t rows_per_split, const uint32_t x_bytes,
@@ -233,9 +295,12 @@ __global__ __launch_bounds__(256) void wgrad_tr_kernel(const GatherParams p, con
     constexpr int BCO = 64 * WCO, BKK = 64 * WK;
     constexpr int PROW = BCO * 2, QROW = BKK * 2;            // bytes per pixel row
     constexpr int PSL = PROW / 16, QSL = QROW / 16;          // 16-byte slots per row
-    constexpr int P_DMA = 64 * PSL / 256, Q_DMA = 64 * QSL / 256;
-    constexpr int BUF = 64 * (PROW + QROW);                  // bytes per stage
-    __shared__ __attribute__((aligned(16))) char lds[2 * BUF];
+    constexpr int STEP = 32;                                 // pixels per stage = one MFMA K=32 chunk
+    constexpr int P_DMA = STEP * PSL / 256, Q_DMA = STEP * QSL / 256;
+    constexpr int NDMA = P_DMA + Q_DMA;                      // LDS-DMA instructions per thread and stage
+    constexpr int BUF = STEP * (PROW + QROW);                // bytes per stage (16 KB / 20 KB); ring of 4
+    static_assert(STEP * PSL % 256 == 0 && STEP * QSL % 256 == 0, "stage slots must tile the workgroup");
+    __shared__ __attribute__((aligned(16))) char lds[4 * BUF];
 
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -244,16 +309,17 @@ __global__ __launch_bounds__(256) void wgrad_tr_kernel(const GatherParams p, con
     const uint32_t m_end = min(p.M, m_begin + rows_per_split);
     const uint32_t ohw = (uint32_t)(p.OH * p.OW);
 
-    __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, x_bytes, 0x00020000);
-    __amdgpu_buffer_rsrc_t rs_dy = __builtin_amdgcn_make_buffer_rsrc((void*)dy, 0, dy_bytes, 0x00020000);
+    const eve_int4 rs_x = make_rsrc_words(x, x_bytes);
+    const eve_int4 rs_dy = make_rsrc_words(dy, dy_bytes);
+    const uint32_t lds0 = lds_addr_of(lds);
 
     // ---- loop-invariant slot coordinates ----
     int p_row[P_DMA], p_col[P_DMA];                 // row in the stage, byte offset of the channel in dy's row
 #pragma unroll
     for (int j = 0; j < P_DMA; ++j) {
         const int q = tid + 256 * j;
-        const int row = q / PSL, s = q % PSL;
-        const int sg = s ^ (tr_key<PROW>(row) << 1);
+        const int row = q / PSL, sl = q % PSL;
+        const int sg = sl ^ (tr_key<PROW>(row) << 1);
         const uint32_t co = co0 + sg * 8;
         p_row[j] = row;
         p_col[j] = co < (uint32_t)p.Cout ? (int)co * 2 : EVE_OOB;
@@ -262,8 +328,8 @@ __global__ __launch_bounds__(256) void wgrad_tr_kernel(const GatherParams p, con
 #pragma unroll
     for (int j = 0; j < Q_DMA; ++j) {
         const int q = tid + 256 * j;
-        const int row = q / QSL, s = q % QSL;
-        const int sg = s ^ (tr_key<QROW>(row) << 1);
+        const int row = q / QSL, sl = q % QSL;
+        const int sg = sl ^ (tr_key<QROW>(row) << 1);
         const uint32_t k = k0 + sg * 8;
         q_row[j] = row;
         if (k < (uint32_t)p.K) {
@@ -277,36 +343,47 @@ __global__ __launch_bounds__(256) void wgrad_tr_kernel(const GatherParams p, con
         }
     }
 
-    auto issue = [&](uint32_t mbase, int buf) {
-        const char* pb = lds + buf * BUF + wave * 1024;
-        const char* qb = lds + buf * BUF + 64 * PROW + wave * 1024;
+    // Source offsets of one stage.  Pixels past the end of the split get the out-of-range offset (zero fill).
+    // Power-of-two output sizes (every EyeNet stage) decode a pixel with shifts; others use the mul-hi division.
+    const int sh_w = __builtin_ctz((unsigned)p.OW), sh_hw = __builtin_ctz((unsigned)(p.OH * p.OW));
+    const int cin2 = p.Cin * 2, cout2 = p.Cout * 2;
+    auto offsets = [&](uint32_t mbase, int* vp, int* vq) {   // branch-free: selects only
 #pragma unroll
         for (int j = 0; j < P_DMA; ++j) {
             const uint32_t m = mbase + p_row[j];
-            const int voff = (m < m_end && p_col[j] != EVE_OOB) ? (int)(m * (uint32_t)p.Cout) * 2 + p_col[j] : EVE_OOB;
-            lds_dma16(rs_dy, pb + j * 4096, voff);
+            const int v = (int)m * cout2 + p_col[j];
+            vp[j] = (m < m_end) & (p_col[j] != EVE_OOB) ? v : EVE_OOB;
         }
 #pragma unroll
         for (int j = 0; j < Q_DMA; ++j) {
             const uint32_t m = mbase + q_row[j];
-            int voff = EVE_OOB;
-            if (m < m_end && q_col[j] != EVE_OOB) {
-                const uint32_t n = fd_div(m, p.fd_ohw);
+            uint32_t n, oy, ox;
+            if (POW2) {
+                n = m >> sh_hw; oy = (m >> sh_w) & (uint32_t)(p.OH - 1); ox = m & (uint32_t)(p.OW - 1);
+            } else {
+                n = fd_div(m, p.fd_ohw);
                 const uint32_t rem = m - n * ohw;
-                const uint32_t oy = fd_div(rem, p.fd_ow);
-                const uint32_t ox = rem - oy * (uint32_t)p.OW;
-                const int sy = (int)oy * p.o_mul + q_dy[j], sx = (int)ox * p.o_mul + q_dx[j];
-                if (sy >= 0 && sy < p.IH && sx >= 0 && sx < p.IW)
-                    voff = (((int)n * p.IH + sy) * p.IW + sx) * p.Cin * 2 + q_col[j];
+                oy = fd_div(rem, p.fd_ow); ox = rem - oy * (uint32_t)p.OW;
             }
-            lds_dma16(rs_x, qb + j * 4096, voff);
+            const int sy = (int)oy * p.o_mul + q_dy[j], sx = (int)ox * p.o_mul + q_dx[j];
+            const bool ok = (m < m_end) & (q_col[j] != EVE_OOB) & (sy >= 0) & (sy < p.IH) & (sx >= 0) & (sx < p.IW);
+            const int v = (((int)n * p.IH + sy) * p.IW + sx) * cin2 + q_col[j];
+            vq[j] = ok ? v : EVE_OOB;
         }
+    };
+    auto issue = [&](int slot, const int* vp, const int* vq) {      // always NDMA instructions
+        const uint32_t pb = lds0 + slot * BUF + wave * 1024;
+        const uint32_t qb = pb + STEP * PROW;
+#pragma unroll
+        for (int j = 0; j < P_DMA; ++j) lds_dma16_asm(rs_dy, pb + j * 4096, vp[j]);
+#pragma unroll
+        for (int j = 0; j < Q_DMA; ++j) lds_dma16_asm(rs_x, qb + j * 4096, vq[j]);
     };
 
     const int lane = tid & 63;
     const int wco = wave / WK, wk = wave % WK;
     const int t = lane & 15, g = lane >> 4;
-    // lane-constant parts of the transposing reads: row (8g + t/4) (+4 for the second read, +32 per chunk)
+    // lane-constant parts of the transposing reads: row (8g + t/4), +4 for the second read
     const int lrow = 8 * g + (t >> 2);
     const int keyp = tr_key<PROW>(lrow), keyq = tr_key<QROW>(lrow);     // bits 0,1,3 of the row only
     const int half = (t & 1) * 8, hs = (t & 3) >> 1;
@@ -314,7 +391,7 @@ __global__ __launch_bounds__(256) void wgrad_tr_kernel(const GatherParams p, con
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         poff[i] = lrow * PROW + (((wco * 8 + i * 2 + hs) ^ (keyp << 1)) * 16) + half;
-        qoff[i] = 64 * PROW + lrow * QROW + (((wk * 8 + i * 2 + hs) ^ (keyq << 1)) * 16) + half;
+        qoff[i] = STEP * PROW + lrow * QROW + (((wk * 8 + i * 2 + hs) ^ (keyq << 1)) * 16) + half;
     }
 
     f32x4_t acc[4][4];
@@ -324,32 +401,44 @@ __global__ __launch_bounds__(256) void wgrad_tr_kernel(const GatherParams p, con
         for (int b = 0; b < 4; ++b) acc[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
     if (m_begin < m_end) {
-        const int nsteps = (int)((m_end - m_begin + 63) / 64);
-        issue(m_begin, 0);
-        for (int st = 0; st < nsteps; ++st) {
-            const int cur = st & 1;
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            if (st + 1 < nsteps) issue(m_begin + (uint32_t)(st + 1) * 64, cur ^ 1);
-            const char* sb = lds + cur * BUF;
+        const int nsteps = (int)((m_end - m_begin + STEP - 1) / STEP);
+        int vp[P_DMA], vq[Q_DMA];
 #pragma unroll
-            for (int c = 0; c < 2; ++c) {
-                uint4 fp[4], fq[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const uint2 a0 = lds_tr_read(sb + poff[i] + (32 * c) * PROW);
-                    const uint2 a1 = lds_tr_read(sb + poff[i] + (32 * c + 4) * PROW);
-                    fp[i] = make_uint4(a0.x, a0.y, a1.x, a1.y);
-                    const uint2 b0 = lds_tr_read(sb + qoff[i] + (32 * c) * QROW);
-                    const uint2 b1 = lds_tr_read(sb + qoff[i] + (32 * c + 4) * QROW);
-                    fq[i] = make_uint4(b0.x, b0.y, b1.x, b1.y);
-                }
-#pragma unroll
-                for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-                    for (int kt = 0; kt < 4; ++kt) Mma<bf16_t>::run(acc[mt][kt], fp[mt], fq[kt]);
-            }
+        for (int pre = 0; pre < 3; ++pre) {
+            offsets(m_begin + pre * STEP, vp, vq);
+            issue(pre, vp, vq);
         }
+        offsets(m_begin + 3 * STEP, vp, vq);
+        auto do_step = [&](int st) {
+            // stage st has landed once at most the two newer stages are outstanding (loads return in order)
+            if (NDMA == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else           asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            issue((st + 3) & 3, vp, vq);                      // stage st+3 recycles the slot read in step st-1
+            const uint32_t sb = lds0 + (st & 3) * BUF;
+            uint4 fp[4], fq[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const uint2 a0 = lds_tr_read(sb + poff[i]);
+                const uint2 a1 = lds_tr_read(sb + poff[i] + 4 * PROW);
+                fp[i] = make_uint4(a0.x, a0.y, a1.x, a1.y);
+                const uint2 b0 = lds_tr_read(sb + qoff[i]);
+                const uint2 b1 = lds_tr_read(sb + qoff[i] + 4 * QROW);
+                fq[i] = make_uint4(b0.x, b0.y, b1.x, b1.y);
+            }
+            mma16_bf16_inplace(acc, fp, fq);                  // acc[mt][kt] += P[mt] x Q[kt]
+            // address arithmetic of stage st+4: independent VALU work the scheduler can slot between the MFMAs
+            offsets(m_begin + (uint32_t)(st + 4) * STEP, vp, vq);
+        };
+        // two stages per trip: with ONE MFMA per accumulator and trip hipcc ping-pongs every accumulator between two
+        // register sets and copies all 64 back at the loop edge (64 v_accvgpr_mov per 16 MFMAs); an even count
+        // returns in place.  An odd tail stage is all out-of-range, i.e. adds zeros.
+        for (int st = 0; st < nsteps; st += 2) {
+            do_step(st);
+            do_step(st + 1);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // drain the zero-fill DMAs before LDS is released
+        mma_drain();
     }
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt)
@@ -363,6 +452,212 @@ __global__ __launch_bounds__(256) void wgrad_tr_kernel(const GatherParams p, con
                 if (co < (uint32_t)p.Cout) atomicAdd(dw + (size_t)co * p.K + k, acc[mt][kt][r]);
             }
         }
+}
+
+}  // namespace eve
+
+namespace eve {
+
+// =================================================================================================
+// 3x3 / stride 1 / pad 1 convolution (forward and data gradient) with the INPUT HALO resident in LDS.
+//
+// The per-tap kernel above re-fetches the activation tile for each of the 9 taps and has to hide a full
+// L2/HBM round trip behind ONE K step of MFMA work; its waves spend half their time in s_waitcnt.  Here a
+// block of 128 output pixels (TI images x TH rows x full width W) loads, per 32-channel slice, the
+// (TH+2) x (W+2) halo patch ONCE (zero padding materialised by the DMA's out-of-range fill) and all 9 taps
+// read it at different offsets.  Only the 8 KB weight tile changes every step, and it runs 3 steps ahead
+// in a 4-slot ring; the next slice's halo streams in during the current slice.  Every step issues exactly
+// 3 LDS-DMA instructions per thread (2 weight + 1 halo or dummy), so one constant s_waitcnt vmcnt(6)
+// (loads return in order) is the whole synchronisation, plus one s_barrier per step.
+//
+// LDS rows are 128 B = TWO consecutive pixels (or output channels) x 32 channels; slot' = slot ^ (row & 7).
+// =================================================================================================
+struct HaloParams {
+    int N, H, W, Cin, Cout;       // x: [N][H][W][Cin]  out: [N][H][W][Cout]
+    int TH, TI;                   // tile = TI images x TH rows x W columns = 128 pixels
+    int bands;                    // ceil(H / TH) when TI == 1, else 1
+    int flip;                     // 0: forward taps (kh-1, kw-1);  1: dgrad taps (1-kh, 1-kw)
+    int K;                        // 9 * Cin (row stride of the weight matrix)
+    int a_pieces;                 // halo DMA instructions per thread and slice (<= 7)
+    uint32_t x_bytes, w_bytes;
+    uint32_t tiles_m, tiles_n;
+    FastDiv fd_w2, fd_hpi, fd_w;  // divisions by (W+2), (TH+2)*(W+2), W
+};
+
+template <int WM, int WN>
+__global__ __launch_bounds__(256) void conv3x3_halo_kernel(const HaloParams p, const bf16_t* __restrict__ x,
+                                                           const bf16_t* __restrict__ w,
+                                                           const float* __restrict__ bias, const int epi_act,
+                                                           bf16_t* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int W2 = p.W + 2, HPI = (p.TH + 2) * W2, HP = p.TI * HPI;
+    const int a_stage = p.a_pieces * 4096;                    // bytes per halo stage (256 slots x 16 B per piece)
+    char* const sA = smem;                                    // 2 halo stages
+    constexpr int BSLOT = 4096 * WN;                          // weight tile: 64*WN output channels x 64 B
+    char* const sB = smem + 2 * a_stage;                      // 4 weight slots
+    char* const sDummy = sB + 4 * BSLOT;                      // 4 KB sink for the padding DMAs
+
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t lid = xcd_remap(blockIdx.x, gridDim.x);
+    const uint32_t tm = lid / p.tiles_n, tn = lid % p.tiles_n;
+    const uint32_t n0 = (p.TI == 1 ? tm / p.bands : tm * p.TI);
+    const int y0 = p.TI == 1 ? (int)(tm % p.bands) * p.TH : 0;
+    const uint32_t co0 = tn * (64 * WN);
+
+    const eve_int4 rs_x = make_rsrc_words(x, p.x_bytes);
+    const eve_int4 rs_w = make_rsrc_words(w, p.w_bytes);
+    const uint32_t ldsA = lds_addr_of(sA), ldsB = lds_addr_of(sB), ldsD = lds_addr_of(sDummy);
+
+    // ---- halo DMA slots owned by this thread (loop invariant): global byte offset without the channel slice ----
+    int a_goff[7];
+#pragma unroll
+    for (int j = 0; j < 7; ++j) {
+        const int L = tid + 256 * j;                          // physical 16-byte slot in the stage
+        const int row = L >> 3, sp = L & 7;
+        const int ls = sp ^ (row & 7);
+        const int hp = 2 * row + (ls >> 2);
+        int off = EVE_OOB;
+        if (j < p.a_pieces && hp < HP) {
+            const int ti = (int)fd_div((uint32_t)hp, p.fd_hpi);
+            const int r = hp - ti * HPI;
+            const int hy = (int)fd_div((uint32_t)r, p.fd_w2), hx = r - hy * W2;
+            const int gy = y0 - 1 + hy, gx = hx - 1;
+            const uint32_t n = n0 + ti;
+            if (gy >= 0 && gy < p.H && gx >= 0 && gx < p.W && n < (uint32_t)p.N)
+                off = (int)((((n * p.H + gy) * p.W + gx) * p.Cin) * 2) + (ls & 3) * 16;
+        }
+        a_goff[j] = off;
+    }
+    // ---- weight DMA slots: 64*WN rows (output channels) x 64 B ----
+    int b_goff[WN];
+#pragma unroll
+    for (int j = 0; j < WN; ++j) {
+        const int L = tid + 256 * j;
+        const int row = L >> 3, sp = L & 7;
+        const int ls = sp ^ (row & 7);
+        const uint32_t co = co0 + 2 * row + (ls >> 2);
+        b_goff[j] = co < (uint32_t)p.Cout ? (int)(co * (uint32_t)p.K) * 2 + (ls & 3) * 16 : EVE_OOB;
+    }
+
+    const int nslices = p.Cin / 32;
+    const int wave_off = wave * 1024;
+    // weight tile of (slice sb, tap tb) into ring slot `slot`; zero-fill past the last slice
+    auto issue_b = [&](int sb, int tb, int slot) {
+        const int koff = (tb * p.Cin + sb * 32) * 2;
+        const uint32_t dst = ldsB + slot * BSLOT + wave_off;
+        const bool live = sb < nslices;
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+            lds_dma16_asm(rs_w, dst + j * 4096, (live && b_goff[j] != EVE_OOB) ? b_goff[j] + koff : EVE_OOB);
+    };
+    auto issue_dummy = [&]() { lds_dma16_asm(rs_x, ldsD + wave_off, EVE_OOB); };
+
+    // ---- fragment coordinates: every (tap, m-tile) LDS offset is a lane constant ----
+    const int lane = tid & 63, wm = wave / WN, wn = wave % WN;
+    const int li = lane & 15, lg = lane >> 4;
+    int aaddr[9][4];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+        const int m = wm * 64 + mt * 16 + li;                 // pixel in the tile: (ti, ty, tx)
+        const int rowi = (int)fd_div((uint32_t)m, p.fd_w), tx = m - rowi * p.W;
+        const int ti = rowi / p.TH, ty = rowi - ti * p.TH;
+        const int hp0 = ti * HPI + ty * W2 + tx;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int kh = t / 3, kw = t % 3;
+            const int hp = hp0 + (p.flip ? (2 - kh) * W2 + (2 - kw) : kh * W2 + kw);
+            const int row = hp >> 1;
+            aaddr[t][mt] = row * 128 + (((((hp & 1) << 2) + lg) ^ (row & 7)) << 4);
+        }
+    }
+    int brow[4];                                              // byte address of the weight fragment inside a ring slot
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+        const int c = wn * 64 + nt * 16 + li;
+        const int row = c >> 1;
+        brow[nt] = row * 128 + (((((c & 1) << 2) + lg) ^ (row & 7)) << 4);
+    }
+
+    f32x4_t acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    // ---- prologue: halo of slice 0 (all pieces), weights of steps 0..2, laid out as three virtual steps ----
+    // (issue order inside a step is [halo piece, weight a, weight b]; loads return in order, so "all but the
+    //  newest 6" always means: everything up to and including the weight tile of two steps ago)
+#pragma unroll
+    for (int j = 0; j < 7; ++j) {
+        if (j < p.a_pieces) lds_dma16_asm(rs_x, ldsA + j * 4096 + wave_off, a_goff[j]);
+        else issue_dummy();
+    }
+    issue_b(0, 0, 0);
+    issue_dummy(); issue_b(0, 1, 1);
+    issue_dummy(); issue_b(0, 2, 2);
+    if (WN == 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // halo of slice 0 and weight tile 0 have landed
+    else         asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    for (int s = 0; s < nslices; ++s) {
+        const char* la = sA + (s & 1) * a_stage;
+        const uint32_t na = ldsA + ((s + 1) & 1) * a_stage + wave_off;   // next slice's halo stage
+        const bool more = s + 1 < nslices;
+        const int nxt_c = (s + 1) * 64;                       // its channel byte offset
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            // exactly 3 DMAs per step: one halo piece of the next slice (taps 0..6) or a dummy, then weight tile i+3
+            if (t < 7 && more && t < p.a_pieces)
+                lds_dma16_asm(rs_x, na + t * 4096, a_goff[t < 7 ? t : 0] != EVE_OOB ? a_goff[t < 7 ? t : 0] + nxt_c : EVE_OOB);
+            else
+                issue_dummy();
+            issue_b(s + (t + 3) / 9, (t + 3) % 9, (s + t + 3) & 3);
+            const char* lb = sB + ((s + t) & 3) * BSLOT;
+            uint4 fx[4], fw[4];
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) fx[mt] = *reinterpret_cast<const uint4*>(la + aaddr[t][mt]);
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) fw[nt] = *reinterpret_cast<const uint4*>(lb + brow[nt]);
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) Mma<bf16_t>::run(acc[mt][nt], fw[nt], fx[mt]);
+            // weight tile i+1 (and any halo piece issued two or more steps ago) must have landed before step i+1
+            if (WN == 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else         asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
+    }
+
+    // ---- epilogue ----
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+        const uint32_t co = co0 + wn * 64 + nt * 16 + lg * 4;
+        float bv[4] = {0.f, 0.f, 0.f, 0.f};
+        if (bias) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (co + r < (uint32_t)p.Cout) bv[r] = bias[co + r];
+        }
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            const int m = wm * 64 + mt * 16 + li;
+            const int rowi = (int)fd_div((uint32_t)m, p.fd_w), tx = m - rowi * p.W;
+            const int ti = rowi / p.TH, ty = rowi - ti * p.TH;
+            const uint32_t n = n0 + ti;
+            const int y = y0 + ty;
+            if (n >= (uint32_t)p.N || y >= p.H || co >= (uint32_t)p.Cout) continue;
+            float o[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] = act_fwd(acc[mt][nt][r] + bv[r], epi_act);
+            bf16_t* dst = out + ((size_t)(n * p.H + y) * p.W + tx) * p.Cout + co;
+            uint2 pk;
+            pk.x = f32_to_bf16_bits(o[0]) | (f32_to_bf16_bits(o[1]) << 16);
+            pk.y = f32_to_bf16_bits(o[2]) | (f32_to_bf16_bits(o[3]) << 16);
+            *reinterpret_cast<uint2*>(dst) = pk;
+        }
+    }
 }
 
 }  // namespace eve

@@ -514,10 +514,54 @@ static void launch_dma_one(const GatherParams& p, const TapPlan& tp, const void*
 
 // LDS-DMA path: no prologue, channel count a multiple of the K step, 32-bit byte offsets.  Strided data
 // gradients are decomposed into stride*stride dense sub-problems (one per output parity class).
+// 3x3 / stride 1 / pad 1, bf16, halo-resident kernel.  Returns false when the shape does not qualify.
+static bool launch_halo(const GatherParams& p, const void* src, const void* w, const float* bias, int epi_act,
+                        void* out, hipStream_t s) {
+    static int enabled = -1;
+    if (enabled < 0) { const char* e = getenv("EVE_CONV_HALO"); enabled = (e && e[0] == '0') ? 0 : 1; }
+    if (!enabled) return false;
+    const bool fwd = p.k_mul == 1 && p.off == -1, bwd = p.k_mul == -1 && p.off == 1;
+    if (p.KH != 3 || p.KW != 3 || p.div != 1 || p.o_mul != 1 || !(fwd || bwd) || p.OH != p.IH || p.OW != p.IW) return false;
+    const int W = p.IW, H = p.IH;
+    if (p.Cin % 32 || W > 128 || (W & (W - 1)) || W < 4) return false;
+    HaloParams h;
+    h.N = p.N; h.H = H; h.W = W; h.Cin = p.Cin; h.Cout = p.Cout;
+    const bool narrow = p.Cout <= 64;               // 256 pixels x 64 channels (4x1 waves) instead of 128 x 128 (2x2)
+    const int BMp = narrow ? 256 : 128;
+    const int rows = BMp / W;
+    if (rows < 1) return false;
+    if (rows <= H) { h.TI = 1; h.TH = rows; h.bands = (H + rows - 1) / rows; }
+    else { if (rows % H) return false; h.TI = rows / H; h.TH = H; h.bands = 1; }
+    const int HP = h.TI * (h.TH + 2) * (W + 2);
+    h.a_pieces = (((HP + 1) / 2) * 8 + 255) / 256;
+    if (h.a_pieces > 7) return false;
+    const unsigned long long xb = (unsigned long long)p.N * H * W * p.Cin * 2, wb = (unsigned long long)p.Cout * p.K * 2;
+    if (xb >= (1ull << 31) || wb >= (1ull << 31)) return false;
+    h.flip = bwd ? 1 : 0; h.K = p.K; h.x_bytes = (uint32_t)xb; h.w_bytes = (uint32_t)wb;
+    h.tiles_m = h.TI == 1 ? (uint32_t)p.N * h.bands : (uint32_t)((p.N + h.TI - 1) / h.TI);
+    h.tiles_n = narrow ? 1 : (p.Cout + 127) / 128;
+    h.fd_w2 = make_fastdiv(W + 2); h.fd_hpi = make_fastdiv((h.TH + 2) * (W + 2)); h.fd_w = make_fastdiv(W);
+    const size_t lds = 2 * (size_t)h.a_pieces * 4096 + 4 * (narrow ? 4096 : 8192) + 4096;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)conv3x3_halo_kernel<2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv3x3_halo_kernel<4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    if (narrow)
+        hipLaunchKernelGGL((conv3x3_halo_kernel<4, 1>), dim3(h.tiles_m * h.tiles_n), dim3(256), lds, s, h, (const bf16_t*)src,
+                           (const bf16_t*)w, bias, epi_act, (bf16_t*)out);
+    else
+        hipLaunchKernelGGL((conv3x3_halo_kernel<2, 2>), dim3(h.tiles_m * h.tiles_n), dim3(256), lds, s, h, (const bf16_t*)src,
+                           (const bf16_t*)w, bias, epi_act, (bf16_t*)out);
+    return true;
+}
+
 template <typename T>
 static bool launch_igemm_dma(const GatherParams& p, const void* src, const void* w, const float* bias,
                              int epi_act, void* out, hipStream_t s) {
     constexpr int BK = 8 * Elem<T>::VEC;
+    if (sizeof(T) == 2 && launch_halo(p, src, w, bias, epi_act, out, s)) return true;
     const unsigned long long src_bytes = (unsigned long long)p.N * p.IH * p.IW * p.Cin * sizeof(T);
     const unsigned long long w_bytes = (unsigned long long)p.Cout * p.K * sizeof(T);
     if (p.Cin % BK != 0 || p.KH * p.KW > 32 || src_bytes >= (1ull << 31) || w_bytes >= (1ull << 31)) return false;
@@ -608,16 +652,21 @@ static int launch_wgrad(const GatherParams& p, const void* x, const void* dy, co
         const unsigned long long dy_bytes = (unsigned long long)p.M * p.Cout * 2;
         if (x_bytes < (1ull << 31) && dy_bytes < (1ull << 31)) {
             uint32_t splits, rows;
+            const bool pow2 = ((p.OW & (p.OW - 1)) == 0) && ((p.OH & (p.OH - 1)) == 0);
             if (p.Cout > 64) {
                 const uint32_t tk = (p.K + 127) / 128, tc = (p.Cout + 127) / 128;
                 wgrad_split(p, tk, tc, splits, rows);
-                hipLaunchKernelGGL((wgrad_tr_kernel<2, 2>), dim3(tk, tc, splits), dim3(256), 0, s, p, (const bf16_t*)x,
-                                   (const bf16_t*)dy, dw, rows, (uint32_t)x_bytes, (uint32_t)dy_bytes);
+                if (pow2) hipLaunchKernelGGL((wgrad_tr_kernel<2, 2, true>), dim3(tk, tc, splits), dim3(256), 0, s, p, (const bf16_t*)x,
+                                             (const bf16_t*)dy, dw, rows, (uint32_t)x_bytes, (uint32_t)dy_bytes);
+                else      hipLaunchKernelGGL((wgrad_tr_kernel<2, 2, false>), dim3(tk, tc, splits), dim3(256), 0, s, p, (const bf16_t*)x,
+                                             (const bf16_t*)dy, dw, rows, (uint32_t)x_bytes, (uint32_t)dy_bytes);
             } else {
                 const uint32_t tk = (p.K + 255) / 256, tc = 1;
                 wgrad_split(p, tk, tc, splits, rows);
-                hipLaunchKernelGGL((wgrad_tr_kernel<1, 4>), dim3(tk, tc, splits), dim3(256), 0, s, p, (const bf16_t*)x,
-                                   (const bf16_t*)dy, dw, rows, (uint32_t)x_bytes, (uint32_t)dy_bytes);
+                if (pow2) hipLaunchKernelGGL((wgrad_tr_kernel<1, 4, true>), dim3(tk, tc, splits), dim3(256), 0, s, p, (const bf16_t*)x,
+                                             (const bf16_t*)dy, dw, rows, (uint32_t)x_bytes, (uint32_t)dy_bytes);
+                else      hipLaunchKernelGGL((wgrad_tr_kernel<1, 4, false>), dim3(tk, tc, splits), dim3(256), 0, s, p, (const bf16_t*)x,
+                                             (const bf16_t*)dy, dw, rows, (uint32_t)x_bytes, (uint32_t)dy_bytes);
             }
             return 0;
         }

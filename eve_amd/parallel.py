@@ -24,9 +24,10 @@ def init_distributed(backend=None):
     rank = int(os.environ['RANK'])
     local_rank = int(os.environ.get('LOCAL_RANK', rank))
     if backend is None:
-        backend = 'nccl' if torch.cuda.is_available() else 'gloo'
-    if backend == 'nccl':
-        torch.cuda.set_device(local_rank)
+        backend = os.environ.get('EVE_AMD_DIST_BACKEND') or ('nccl' if torch.cuda.is_available() else 'gloo')
+    if torch.cuda.is_available():
+        # EVE_AMD_FORCE_DEVICE lets a 1-GPU box exercise the multi-rank code path (with gloo) on one device
+        torch.cuda.set_device(int(os.environ.get('EVE_AMD_FORCE_DEVICE', local_rank)))
     if not dist.is_initialized():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
