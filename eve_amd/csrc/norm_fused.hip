@@ -298,15 +298,16 @@ __global__ __launch_bounds__(256) void in_relu_pool_fwd_kernel(const T* __restri
 
 // one workgroup per image: pass 1 over the pooled tensors (sums), pass 2 dense over the conv output
 template <typename T>
-__global__ __launch_bounds__(256) void in_relu_pool_bwd_kernel(const T* __restrict__ dyp, const T* __restrict__ yp,
+__global__ __launch_bounds__(1024) void in_relu_pool_bwd_kernel(const T* __restrict__ dyp, const T* __restrict__ yp,
                                                                const uint8_t* __restrict__ idx,
                                                                const T* __restrict__ x, const float* __restrict__ mr,
                                                                T* __restrict__ dx, int IH, int IW, int OH, int OW,
                                                                int C) {
     constexpr int VEC = Elem<T>::VEC;
-    __shared__ float sh[2 * 256 * VEC];
+    constexpr int NT = 1024;             // 16 waves per image: the dense pass is latency-bound, parallelism pays
+    __shared__ float sh[2 * NT * VEC];
     __shared__ float sh_tot[2 * 1024];
-    const int cvecs = C / VEC, phases = 256 / cvecs;
+    const int cvecs = C / VEC, phases = NT / cvecs;
     const int tid = threadIdx.x, cv = tid % cvecs, ph = tid / cvecs;
     const bool on = ph < phases;
     const size_t n = blockIdx.x;
@@ -327,7 +328,7 @@ __global__ __launch_bounds__(256) void in_relu_pool_bwd_kernel(const T* __restri
 #pragma unroll
         for (int e = 0; e < VEC; ++e) {
             sh[(ph * cvecs + cv) * VEC + e] = s1[e];
-            sh[256 * VEC + (ph * cvecs + cv) * VEC + e] = s2[e];
+            sh[NT * VEC + (ph * cvecs + cv) * VEC + e] = s2[e];
         }
     }
     __syncthreads();
@@ -336,7 +337,7 @@ __global__ __launch_bounds__(256) void in_relu_pool_bwd_kernel(const T* __restri
 #pragma unroll
             for (int e = 0; e < VEC; ++e) {
                 s1[e] += sh[(q * cvecs + cv) * VEC + e];
-                s2[e] += sh[256 * VEC + (q * cvecs + cv) * VEC + e];
+                s2[e] += sh[NT * VEC + (q * cvecs + cv) * VEC + e];
             }
 #pragma unroll
         for (int e = 0; e < VEC; ++e) { sh_tot[cv * VEC + e] = s1[e]; sh_tot[1024 + cv * VEC + e] = s2[e]; }
@@ -411,8 +412,8 @@ extern "C" int eve_in_relu_maxpool_bwd(int dtype, int N, int IH, int IW, int C, 
         return set_error_msg("in_relu_maxpool_bwd: bad arguments");
     const int OH = (IH - 1) / 2 + 1, OW = (IW - 1) / 2 + 1;
     hipStream_t s = (hipStream_t)stream;
-    if (dtype == EVE_DT_BF16) hipLaunchKernelGGL(in_relu_pool_bwd_kernel<bf16_t>, dim3(N), dim3(256), 0, s, (const bf16_t*)dy_pool, (const bf16_t*)y_pool, idx, (const bf16_t*)x, mean_rstd, (bf16_t*)dx, IH, IW, OH, OW, C);
-    else                      hipLaunchKernelGGL(in_relu_pool_bwd_kernel<float>, dim3(N), dim3(256), 0, s, (const float*)dy_pool, (const float*)y_pool, idx, (const float*)x, mean_rstd, (float*)dx, IH, IW, OH, OW, C);
+    if (dtype == EVE_DT_BF16) hipLaunchKernelGGL(in_relu_pool_bwd_kernel<bf16_t>, dim3(N), dim3(1024), 0, s, (const bf16_t*)dy_pool, (const bf16_t*)y_pool, idx, (const bf16_t*)x, mean_rstd, (bf16_t*)dx, IH, IW, OH, OW, C);
+    else                      hipLaunchKernelGGL(in_relu_pool_bwd_kernel<float>, dim3(N), dim3(1024), 0, s, (const float*)dy_pool, (const float*)y_pool, idx, (const float*)x, mean_rstd, (float*)dx, IH, IW, OH, OW, C);
     EVE_CHECK_LAUNCH();
     return 0;
 }

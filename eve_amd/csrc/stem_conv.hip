@@ -1,0 +1,141 @@
+// ResNet stem: 7x7 / stride 2 / pad 3 convolution, 3 -> 64 channels, bf16 (torchvision ResNet.conv1, reference
+// src/models/eye_net.py:48-50,106).  K = 147 is too small and too ragged for the tiled implicit-GEMM kernels
+// (they pad Cin 3 -> 8 and decode a tap per 16-byte vector: 1.2 ms per step, 5 % of the MFMA peak).
+//
+// Formulation: the input is repacked once to [N][IH+6][IW+8][4] bf16 (3 channels + 1 zero, zero borders of
+// 3 rows / 4 columns), i.e. 8 bytes per pixel with the padding materialised.  One filter ROW is then a single
+// MFMA K step: 8 consecutive pixels x 4 channels = 32 K values (7 real taps + 1 zero-weight tap), and a lane's
+// fragment (2 pixels x 4 channels = 16 bytes) is ONE unpredicated global load -- no LDS staging for the
+// activations at all.  The 28 KB filter bank sits in LDS for the lifetime of the (persistent) workgroup.
+// Waves are independent after the filter load: no barriers, each wave walks its own 64-pixel row tiles and keeps
+// all 28 fragment loads of a tile in flight.  Output 64 px x 64 channels per wave tile, 112 MFMAs.
+#include "common.h"
+
+namespace eve {
+
+struct Mma16 {
+    __device__ static __forceinline__ void run(f32x4_t& acc, const uint4& a, const uint4& b) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b),
+                                                      acc, 0, 0, 0);
+    }
+};
+
+// dst[n][y+3][x+4][c] = c < C ? src[n][c][y][x] : 0, borders zero (dst is fully written)
+__global__ __launch_bounds__(256) void stem_pack_kernel(const float* __restrict__ src, uint2* __restrict__ dst, int C,
+                                                        int IH, int IW, long long items) {
+    const int IHp = IH + 6, IWp = IW + 8;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < items; i += (long long)gridDim.x * 256) {
+        const int xp = (int)(i % IWp);
+        long long t = i / IWp;
+        const int yp = (int)(t % IHp);
+        const long long n = t / IHp;
+        const int x = xp - 4, y = yp - 3;
+        uint2 q = make_uint2(0u, 0u);
+        if (x >= 0 && x < IW && y >= 0 && y < IH) {
+            float f[4] = {0.f, 0.f, 0.f, 0.f};
+            for (int c = 0; c < C && c < 4; ++c) f[c] = src[((n * C + c) * IH + y) * IW + x];
+            q.x = f32_to_bf16_bits(f[0]) | (f32_to_bf16_bits(f[1]) << 16);
+            q.y = f32_to_bf16_bits(f[2]) | (f32_to_bf16_bits(f[3]) << 16);
+        }
+        dst[i] = q;
+    }
+}
+
+__global__ __launch_bounds__(256) void stem7x7_kernel(const int N, const int IH, const int IW,
+                                                      const uint2* __restrict__ xp, const bf16_t* __restrict__ w8,
+                                                      bf16_t* __restrict__ y, const uint32_t ntiles) {
+    __shared__ uint4 sW[7 * 256];                              // 7 filter rows x (64 output channels x 64 B)
+    const int tid = threadIdx.x;
+    // ---- filter bank: w8 is [64][7][7][8] (Cin padded to 8); LDS row = 2 output channels x 64 B, slot ^= row & 7 ----
+    for (int e = tid; e < 64 * 7 * 8; e += 256) {
+        const int kw = e & 7, kh = (e >> 3) % 7, co = e / 56;
+        uint2 v = make_uint2(0u, 0u);
+        if (kw < 7) v = *reinterpret_cast<const uint2*>(w8 + ((co * 7 + kh) * 7 + kw) * 8);   // channels 0..3
+        const int row = co >> 1;
+        const int slot = (((co & 1) << 2) + (kw >> 1)) ^ (row & 7);
+        reinterpret_cast<uint2*>(sW)[(kh * 256 + row * 8 + slot) * 2 + (kw & 1)] = v;
+    }
+    __syncthreads();
+
+    const int lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, lg = lane >> 4;
+    const int OH = IH / 2, OW = IW / 2, IWp = IW + 8, IHp = IH + 6;
+    const int xblocks = OW / 64;
+    int brow[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+        const int c = nt * 16 + li;
+        const int row = c >> 1;
+        brow[nt] = row * 8 + ((((c & 1) << 2) + lg) ^ (row & 7));
+    }
+    const uint32_t gw = blockIdx.x * 4 + wave, nw = gridDim.x * 4;
+    for (uint32_t tile = gw; tile < ntiles; tile += nw) {
+        const uint32_t xb = tile % xblocks;
+        const uint32_t r = tile / xblocks;
+        const uint32_t oy = r % OH, n = r / OH;
+        // padded pixel index of the lane's first fragment pixel for filter row 0: (2*oy, 2*ox + 1 + 2*lg)
+        const uint2* base = xp + ((size_t)n * IHp + 2 * oy) * IWp + 2 * (xb * 64 + li) + 1 + 2 * lg;
+        uint4 fx[7][4];
+#pragma unroll
+        for (int kh = 0; kh < 7; ++kh)
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                const uint2* p = base + (size_t)kh * IWp + mt * 32;     // 16 output pixels = 32 input pixels further
+                const uint2 a = p[0], b = p[1];                          // 8-byte aligned pair (odd pixel index)
+                fx[kh][mt] = make_uint4(a.x, a.y, b.x, b.y);
+            }
+        f32x4_t acc[4][4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) acc[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kh = 0; kh < 7; ++kh) {
+            uint4 fw[4];
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) fw[nt] = sW[kh * 256 + brow[nt]];
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) Mma16::run(acc[mt][nt], fw[nt], fx[kh][mt]);
+        }
+        bf16_t* orow = y + (((size_t)n * OH + oy) * OW + xb * 64) * 64;
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                uint2 pk;
+                pk.x = f32_to_bf16_bits(acc[mt][nt][0]) | (f32_to_bf16_bits(acc[mt][nt][1]) << 16);
+                pk.y = f32_to_bf16_bits(acc[mt][nt][2]) | (f32_to_bf16_bits(acc[mt][nt][3]) << 16);
+                *reinterpret_cast<uint2*>(orow + (mt * 16 + li) * 64 + nt * 16 + lg * 4) = pk;
+            }
+    }
+}
+
+}  // namespace eve
+
+using namespace eve;
+
+extern "C" int eve_stem_pack_input(int N, int C, int IH, int IW, const float* src_nchw, void* dst, eve_stream_t stream) {
+    if (N <= 0 || C <= 0 || C > 4 || IH <= 0 || IW <= 0 || !src_nchw || !dst) return set_error_msg("stem_pack_input: bad arguments");
+    const long long items = (long long)N * (IH + 6) * (IW + 8);
+    long long blocks = (items + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(stem_pack_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, src_nchw, (uint2*)dst, C, IH, IW, items);
+    EVE_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int eve_stem7x7s2_fwd(int N, int IH, int IW, const void* x_padded, const void* w_ohwi8, void* y,
+                                 eve_stream_t stream) {
+    if (N <= 0 || IH <= 0 || IW <= 0 || (IH & 1) || (IW % 128) || !x_padded || !w_ohwi8 || !y)
+        return set_error_msg("stem7x7s2_fwd: needs even IH and IW a multiple of 128");
+    const unsigned long long tiles = (unsigned long long)N * (IH / 2) * (IW / 128);
+    if (tiles >= (1ull << 32)) return set_error_msg("stem7x7s2_fwd: too many tiles");
+    unsigned blocks = 512;
+    if ((tiles + 3) / 4 < blocks) blocks = (unsigned)((tiles + 3) / 4);
+    hipLaunchKernelGGL(stem7x7_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, N, IH, IW, (const uint2*)x_padded,
+                       (const bf16_t*)w_ohwi8, (bf16_t*)y, (uint32_t)tiles);
+    EVE_CHECK_LAUNCH();
+    return 0;
+}

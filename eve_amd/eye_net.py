@@ -152,10 +152,14 @@ class EyeNet(nn.Module):
         return P
 
     # ------------------------------------------------------------------ trunk
-    def _trunk(self, x, P):
-        """x: [N, H, W, Cpad] NHWC compute dtype -> [N, 512] float32 (torchvision ResNet._forward_impl)."""
+    def _trunk(self, x, P, x_padded=None):
+        """x: [N, H, W, Cpad] NHWC compute dtype -> [N, 512] float32 (torchvision ResNet._forward_impl).
+        x_padded: optional [N, H+6, W+8, 4] bf16 repack for the dedicated stem kernel."""
         cnn = self.cnn_layers
-        y = ops.conv2d(x, cnn.conv1.weight, None, P['conv1'], stride=2, pad=3)
+        if x_padded is not None:
+            y = ops.StemConvFn.apply(x, x_padded, cnn.conv1.weight, P['conv1'])
+        else:
+            y = ops.conv2d(x, cnn.conv1.weight, None, P['conv1'], stride=2, pad=3)
         y = ops.InReluMaxPoolFn.apply(y, 1e-5)          # bn1 -> relu -> maxpool, fused
         for name, blk in cnn.blocks():
             out = ops.conv2d(y, blk.conv1.weight, None, P[name + '.conv1'], stride=blk.stride, pad=1)
@@ -241,7 +245,12 @@ class EyeNet(nn.Module):
         x = torch.empty((2 * B * T, Hh, Ww, cpad), dtype=dt, device=left.device)
         k.nchw_to_nhwc(left.reshape(B * T, C, Hh, Ww), dt, cpad, out=x[:B * T])
         k.nchw_to_nhwc(right.reshape(B * T, C, Hh, Ww), dt, cpad, out=x[B * T:])
-        feats = self._trunk(x, P)
+        x_padded = None
+        if dt == torch.bfloat16 and C <= 4 and Hh % 2 == 0 and Ww % 128 == 0:      # dedicated stem kernel
+            x_padded = torch.empty((2 * B * T, Hh + 6, Ww + 8, 4), dtype=dt, device=left.device)
+            k.stem_pack_input(left.reshape(B * T, C, Hh, Ww), out=x_padded[:B * T])
+            k.stem_pack_input(right.reshape(B * T, C, Hh, Ww), out=x_padded[B * T:])
+        feats = self._trunk(x, P, x_padded)
         head_pose = None
         if self.config.eye_net_use_head_pose_input:
             head_pose = torch.cat([batch['left_h'].reshape(B * T, 2), batch['right_h'].reshape(B * T, 2)], dim=0)

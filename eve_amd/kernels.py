@@ -158,6 +158,24 @@ class HipKernels(object):
             self._p(dw_ohwi), self._stream())))
         return dw_ohwi
 
+    def stem_pack_input(self, src_nchw, out=None):
+        N, C, H, W = src_nchw.shape
+        src = self._f32(src_nchw.contiguous(), 'src')
+        dst = out if out is not None else torch.empty((N, H + 6, W + 8, 4), dtype=torch.bfloat16, device=src.device)
+        assert tuple(dst.shape) == (N, H + 6, W + 8, 4) and dst.dtype == torch.bfloat16
+        self._ck(self.lib.eve_stem_pack_input(N, C, H, W, self._p(src), self._p(dst), self._stream()))
+        return dst
+
+    def stem7x7s2_fwd(self, x_padded, w_ohwi8):
+        N, Hp, Wp, four = x_padded.shape
+        IH, IW = Hp - 6, Wp - 8
+        assert four == 4 and tuple(w_ohwi8.shape) == (64, 7, 7, 8) and w_ohwi8.dtype == torch.bfloat16
+        y = torch.empty((N, IH // 2, IW // 2, 64), dtype=torch.bfloat16, device=x_padded.device)
+        flops = 2.0 * N * (IH // 2) * (IW // 2) * 64 * 147
+        self._timed('conv_fwd', flops, lambda: self._ck(self.lib.eve_stem7x7s2_fwd(
+            N, IH, IW, self._p(x_padded), self._p(w_ohwi8), self._p(y), self._stream())))
+        return y
+
     def bias_grad(self, dy, db):
         C = dy.shape[-1]
         M = dy.numel() // C

@@ -83,6 +83,30 @@ class Conv2dFn(torch.autograd.Function):
         return dx, dw, db, None, None, None, None
 
 
+class StemConvFn(torch.autograd.Function):
+    """ResNet stem conv (7x7/2, 3 -> 64) through the dedicated bf16 kernel.  x8 is the NHWC patch batch with
+    channels padded to 8 (used by the weight gradient), x_padded the [N, H+6, W+8, 4] repack the forward kernel
+    reads.  The patches are inputs, so there is no data gradient."""
+
+    @staticmethod
+    def forward(ctx, x8, x_padded, weight, pack):
+        y = default_kernels().stem7x7s2_fwd(x_padded, pack.ohwi)
+        ctx.pack = pack
+        ctx.save_for_backward(x8)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        k = default_kernels()
+        (x8,) = ctx.saved_tensors
+        pack = ctx.pack
+        cout_p, KH, KW, cin_p = pack.ohwi.shape
+        dwp = torch.zeros((cout_p, KH, KW, cin_p), dtype=torch.float32, device=x8.device)
+        k.conv2d_wgrad(x8, dy.contiguous(), KH, KW, 2, 3, dwp, algo=pack.algo)
+        O, I = pack.shape_oihw[0], pack.shape_oihw[1]
+        return None, None, dwp[:O, :, :, :I].permute(0, 3, 1, 2), None
+
+
 def conv2d(x, weight, bias, pack, stride=1, pad=0, act=ACT_NONE):
     return Conv2dFn.apply(x, weight, bias, pack, stride, pad, act)
 

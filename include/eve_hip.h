@@ -69,6 +69,14 @@ int eve_conv2d_dgrad(const eve_conv_desc* d, const void* dy, const void* w_ihwo,
 /* dw[Cout][KH][KW][Cin] (float, accumulated) += sum_m dy[m][co] * x'[m][(kh,kw,ci)]              */
 int eve_conv2d_wgrad(const eve_conv_desc* d, const void* x, const void* dy,
                      const float* in_scale_shift, int pro_act, float* dw_ohwi, eve_stream_t stream);
+/* ResNet stem (torchvision ResNet.conv1: 7x7 / stride 2 / pad 3, 3 -> 64, no bias; eye_net.py:48-50), bf16:
+ * eve_stem_pack_input writes x_padded [N][IH+6][IW+8][4] bf16 (channels 0..C-1, zero 4th channel and borders)
+ * from the float NCHW patch; eve_stem7x7s2_fwd computes y [N][IH/2][IW/2][64] from it and the OHWI weights
+ * with Cin padded to 8 ([64][7][7][8] bf16).  IH even, IW a multiple of 128.                           */
+int eve_stem_pack_input(int N, int C, int IH, int IW, const float* src_nchw, void* x_padded,
+                        eve_stream_t stream);
+int eve_stem7x7s2_fwd(int N, int IH, int IW, const void* x_padded, const void* w_ohwi8, void* y,
+                      eve_stream_t stream);
 /* db[C] (float, accumulated) += sum over the M = N*OH*OW rows of dy[M][C]                         */
 int eve_bias_grad(int dtype, long long M, int C, const void* dy, float* db, eve_stream_t stream);
 

@@ -67,6 +67,18 @@ class FakeKernels(object):
         dw_ohwi += dw.permute(0, 2, 3, 1)
         return dw_ohwi
 
+    def stem_pack_input(self, src_nchw, out=None):
+        N, C, H, W = src_nchw.shape
+        dst = torch.zeros((N, H + 6, W + 8, 4), dtype=torch.bfloat16) if out is None else out
+        dst.zero_()
+        dst[:, 3:H + 3, 4:W + 4, :C] = src_nchw.permute(0, 2, 3, 1).to(torch.bfloat16)
+        return dst
+
+    def stem7x7s2_fwd(self, x_padded, w_ohwi8):
+        x = x_padded[:, 3:-3, 4:-4, :].float().permute(0, 3, 1, 2)
+        w = w_ohwi8[..., :4].float().permute(0, 3, 1, 2)
+        return nhwc(F.conv2d(x, w, None, 2, 3), torch.bfloat16)
+
     def bias_grad(self, dy, db):
         db += dy.float().reshape(-1, dy.shape[-1]).sum(0)
         return db

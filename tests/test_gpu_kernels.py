@@ -63,6 +63,10 @@ CONV_CASES = [
     (7, 32, 32, 64, 64, 3, 1, 1),       # layer1, M = 7168 (28 tiles of 256, 4x1 waves)
     (2, 16, 16, 128, 256, 3, 2, 1),     # stride-2 forward through the DMA kernel, generic dgrad
     (3, 9, 16, 128, 64, 1, 1, 0),       # 1x1, Cout 64
+    (2, 36, 64, 32, 32, 3, 1, 1),       # RefineNet 36x64 level: weights-stationary kernel, one 32-channel slice
+    (2, 18, 32, 64, 64, 3, 1, 1),       # RefineNet 18x32 level: ragged last band (18 rows, 8 per tile)
+    (5, 8, 8, 64, 48, 3, 1, 1),         # several whole images per tile, Cout not a multiple of 16
+    (300, 32, 32, 64, 64, 3, 1, 1),     # more tiles than persistent workgroups
 ]
 
 
@@ -123,6 +127,19 @@ def test_conv_prologue_fused_instnorm(hip, ref, dtype):
                            ss=dev(ss), pro_act=1),
           ref.conv2d_wgrad(x, dy, 3, 3, 1, 1, torch.zeros((Cout, 3, 3, Cin)), ss=ss, pro_act=1),
           dtype, 'wgrad prologue')
+
+
+def test_stem_conv_dedicated_kernel(hip, ref):
+    src = rnd((3, 3, 128, 128), torch.float32, 60)
+    xp_w = ref.stem_pack_input(src)
+    xp_g = hip.stem_pack_input(dev(src))
+    assert torch.equal(xp_g.cpu().view(torch.int16), xp_w.view(torch.int16))
+    w = rnd((64, 7, 7, 8), torch.bfloat16, 61, scale=0.08)
+    w[..., 3:] = 0
+    close(hip.stem7x7s2_fwd(xp_g, dev(w)), ref.stem7x7s2_fwd(xp_w, w), torch.bfloat16, 'stem 7x7/2')
+    # and against the generic implicit-GEMM path on the 8-channel NHWC input
+    x8 = hip.nchw_to_nhwc(dev(src), torch.bfloat16, 8)
+    close(hip.stem7x7s2_fwd(xp_g, dev(w)), hip.conv2d_fwd(x8, dev(w), None, 2, 3), torch.bfloat16, 'stem vs generic')
 
 
 def test_conv_rejects_bad_shapes(hip):
