@@ -298,9 +298,11 @@ __global__ __launch_bounds__(256) void wgrad_tr_kernel(const GatherParams p, con
     constexpr int STEP = 32;                                 // pixels per stage = one MFMA K=32 chunk
     constexpr int P_DMA = STEP * PSL / 256, Q_DMA = STEP * QSL / 256;
     constexpr int NDMA = P_DMA + Q_DMA;                      // LDS-DMA instructions per thread and stage
-    constexpr int BUF = STEP * (PROW + QROW);                // bytes per stage (16 KB / 20 KB); ring of 4
+    constexpr int BUF = STEP * (PROW + QROW);                // bytes per stage (16 KB / 20 KB)
+    constexpr int RING = 4;                                  // 64 / 80 KB of LDS, two workgroups per CU (a 3-deep ring with
+                                                             // three workgroups per CU measured 7 % slower)
     static_assert(STEP * PSL % 256 == 0 && STEP * QSL % 256 == 0, "stage slots must tile the workgroup");
-    __shared__ __attribute__((aligned(16))) char lds[4 * BUF];
+    __shared__ __attribute__((aligned(16))) char lds[RING * BUF];
 
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -404,18 +406,19 @@ __global__ __launch_bounds__(256) void wgrad_tr_kernel(const GatherParams p, con
         const int nsteps = (int)((m_end - m_begin + STEP - 1) / STEP);
         int vp[P_DMA], vq[Q_DMA];
 #pragma unroll
-        for (int pre = 0; pre < 3; ++pre) {
+        for (int pre = 0; pre < RING - 1; ++pre) {
             offsets(m_begin + pre * STEP, vp, vq);
             issue(pre, vp, vq);
         }
-        offsets(m_begin + 3 * STEP, vp, vq);
+        offsets(m_begin + (RING - 1) * STEP, vp, vq);
         auto do_step = [&](int st) {
-            // stage st has landed once at most the two newer stages are outstanding (loads return in order)
+            // stage st has landed once at most the RING-2 newer stages are outstanding (loads return in order)
+            static_assert(RING == 4, "the immediates below are (RING - 2) * NDMA");
             if (NDMA == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
             else           asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
             __builtin_amdgcn_s_barrier();
-            issue((st + 3) & 3, vp, vq);                      // stage st+3 recycles the slot read in step st-1
-            const uint32_t sb = lds0 + (st & 3) * BUF;
+            issue((st + RING - 1) % RING, vp, vq);            // stage st+RING-1 recycles the slot read in step st-1
+            const uint32_t sb = lds0 + (st % RING) * BUF;
             uint4 fp[4], fq[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -428,7 +431,7 @@ __global__ __launch_bounds__(256) void wgrad_tr_kernel(const GatherParams p, con
             }
             mma16_bf16_inplace(acc, fp, fq);                  // acc[mt][kt] += P[mt] x Q[kt]
             // address arithmetic of stage st+4: independent VALU work the scheduler can slot between the MFMAs
-            offsets(m_begin + (uint32_t)(st + 4) * STEP, vp, vq);
+            offsets(m_begin + (uint32_t)(st + RING) * STEP, vp, vq);
         };
         // two stages per trip: with ONE MFMA per accumulator and trip hipcc ping-pongs every accumulator between two
         // register sets and copies all 64 back at the loop edge (64 v_accvgpr_mov per 16 MFMAs); an even count

@@ -131,7 +131,12 @@ __global__ __launch_bounds__(256) void in_act_bwd_kernel(const T* __restrict__ d
             Elem<T>::unpack(*reinterpret_cast<const uint4*>(dy + o), g);
             Elem<T>::unpack(*reinterpret_cast<const uint4*>(x + o), xx);
             if (act != EVE_ACT_NONE) {
-                Elem<T>::unpack(*reinterpret_cast<const uint4*>(y + o), yy);
+                if (y) {
+                    Elem<T>::unpack(*reinterpret_cast<const uint4*>(y + o), yy);
+                } else {            // no affine, no residual: y = act(xhat)
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) yy[e] = act_fwd((xx[e] - mean[e]) * rstd[e], act);
+                }
 #pragma unroll
                 for (int e = 0; e < VEC; ++e) g[e] *= act_grad_from_out(yy[e], act);
             }
@@ -183,7 +188,12 @@ __global__ __launch_bounds__(256) void in_act_bwd_kernel(const T* __restrict__ d
             Elem<T>::unpack(*reinterpret_cast<const uint4*>(dy + o), g);
             Elem<T>::unpack(*reinterpret_cast<const uint4*>(x + o), xx);
             if (act != EVE_ACT_NONE) {
-                Elem<T>::unpack(*reinterpret_cast<const uint4*>(y + o), yy);
+                if (y) {
+                    Elem<T>::unpack(*reinterpret_cast<const uint4*>(y + o), yy);
+                } else {            // no affine, no residual: y = act(xhat)
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) yy[e] = act_fwd((xx[e] - mean[e]) * rstd[e], act);
+                }
 #pragma unroll
                 for (int e = 0; e < VEC; ++e) g[e] *= act_grad_from_out(yy[e], act);
             }
@@ -280,7 +290,7 @@ extern "C" int eve_instnorm_act_bwd(int dtype, int N, int HW, int C, const void*
                                     const float* mean_rstd, const float* gamma, int act, void* dx, void* dres,
                                     float* sums, eve_stream_t stream) {
     if (int e = check_plane(dtype, N, HW, C, "instnorm_act_bwd: bad shape")) return e;
-    if (!dy || !x || !mean_rstd || !dx || (act != EVE_ACT_NONE && !y))
+    if (!dy || !x || !mean_rstd || !dx || (act != EVE_ACT_NONE && !y && gamma))
         return set_error_msg("instnorm_act_bwd: null pointer");
     hipStream_t s = (hipStream_t)stream;
     if (dtype == EVE_DT_BF16)

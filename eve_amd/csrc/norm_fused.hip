@@ -132,7 +132,12 @@ __global__ __launch_bounds__(1024) void in_bwd_fused_kernel(const T* __restrict_
             Elem<T>::unpack(qx[j], xx);
             if (act != EVE_ACT_NONE) {
                 float yy[VEC];
-                Elem<T>::unpack(reinterpret_cast<const uint4*>(y)[base + i], yy);
+                if (y) {
+                    Elem<T>::unpack(reinterpret_cast<const uint4*>(y)[base + i], yy);
+                } else {            // no affine, no residual: y = act(xhat), and sign(xhat) = sign(x - mean)
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) yy[e] = act_fwd((xx[e] - mean[e]) * rstd[e], act);
+                }
 #pragma unroll
                 for (int e = 0; e < VEC; ++e) g[e] *= act_grad_from_out(yy[e], act);
                 qg[j] = Elem<T>::pack(g);
@@ -228,7 +233,7 @@ extern "C" int eve_instnorm_bwd_fused(int dtype, int N, int HW, int C, const voi
                                       float* sums, eve_stream_t stream) {
     const int vec = dtype == EVE_DT_BF16 ? 8 : 4;
     if ((dtype != EVE_DT_F32 && dtype != EVE_DT_BF16) || N <= 0 || HW <= 0 || C <= 0 || C % vec || !dy || !x ||
-        !mean_rstd || !dx || (act != EVE_ACT_NONE && !y))
+        !mean_rstd || !dx || (act != EVE_ACT_NONE && !y && gamma))
         return set_error_msg("instnorm_bwd_fused: bad arguments");
     int threads, vpt;
     if (!fused_plan(HW * (C / vec), C / vec, threads, vpt)) return -1;
@@ -354,30 +359,48 @@ __global__ __launch_bounds__(1024) void in_relu_pool_bwd_kernel(const T* __restr
             s1[e] = sh_tot[cv * VEC + e] * inv; s2[e] = sh_tot[1024 + cv * VEC + e] * inv;
         }
     }
+    // dense pass, written branch-free so all loads of a pixel are in flight together: an input pixel belongs to
+    // 1 (even coordinate) or 2 (odd coordinate) windows per axis
     for (int px = ph; px < IH * IW; px += phases) {
         const int ih = px / IW, iw = px - ih * IW;
+        const int oh0 = ih >> 1, oh1 = (ih + 1) >> 1, ow0 = iw >> 1, ow1 = (iw + 1) >> 1;
+        const int ohs[2] = {oh0, oh1 < OH ? oh1 : oh0}, ows[2] = {ow0, ow1 < OW ? ow1 : ow0};
+        const bool vh[2] = {true, oh1 != oh0 && oh1 < OH}, vw[2] = {true, ow1 != ow0 && ow1 < OW};
+        const size_t xo = (n * IH * IW + px) * C + cv * VEC;
+        const uint4 qx = *reinterpret_cast<const uint4*>(x + xo);
+        uint4 qd[4], qy[4];
+        uint2 qi[4];
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b2 = 0; b2 < 2; ++b2) {
+                const size_t o = ((n * OH + ohs[a]) * OW + ows[b2]) * C + cv * VEC;
+                qd[a * 2 + b2] = *reinterpret_cast<const uint4*>(dyp + o);
+                qy[a * 2 + b2] = *reinterpret_cast<const uint4*>(yp + o);
+                if (VEC == 8) qi[a * 2 + b2] = *reinterpret_cast<const uint2*>(idx + o);
+                else          qi[a * 2 + b2] = make_uint2(*reinterpret_cast<const uint32_t*>(idx + o), 0u);
+            }
         float g[VEC];
 #pragma unroll
         for (int e = 0; e < VEC; ++e) g[e] = 0.f;
-        for (int oh = ih / 2; oh <= (ih + 1) / 2; ++oh) {
-            if (oh >= OH) continue;
-            const int kh = ih - (oh * 2 - 1);
-            for (int ow = iw / 2; ow <= (iw + 1) / 2; ++ow) {
-                if (ow >= OW) continue;
-                const uint32_t code = kh * 3 + (iw - (ow * 2 - 1));
-                const size_t o = ((n * OH + oh) * OW + ow) * C + cv * VEC;
-                float d[VEC], yy[VEC];
-                Elem<T>::unpack(*reinterpret_cast<const uint4*>(dyp + o), d);
-                Elem<T>::unpack(*reinterpret_cast<const uint4*>(yp + o), yy);
-                const uint8_t* ip = idx + o;
 #pragma unroll
-                for (int e = 0; e < VEC; ++e)
-                    if (ip[e] == code && yy[e] > 0.f) g[e] += d[e];
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b2 = 0; b2 < 2; ++b2) {
+                const uint32_t code = (uint32_t)((ih - (ohs[a] * 2 - 1)) * 3 + (iw - (ows[b2] * 2 - 1)));
+                const bool live = vh[a] && vw[b2];
+                float d[VEC], yy[VEC];
+                Elem<T>::unpack(qd[a * 2 + b2], d);
+                Elem<T>::unpack(qy[a * 2 + b2], yy);
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) {
+                    const uint32_t w32 = e < 4 ? qi[a * 2 + b2].x : qi[a * 2 + b2].y;
+                    const uint32_t id = (w32 >> (8 * (e & 3))) & 0xffu;
+                    g[e] += (live && id == code && yy[e] > 0.f) ? d[e] : 0.f;
+                }
             }
-        }
-        const size_t xo = (n * IH * IW + px) * C + cv * VEC;
         float xx[VEC];
-        Elem<T>::unpack(*reinterpret_cast<const uint4*>(x + xo), xx);
+        Elem<T>::unpack(qx, xx);
 #pragma unroll
         for (int e = 0; e < VEC; ++e) g[e] = rstd[e] * (g[e] - s1[e] - (xx[e] - mean[e]) * rstd[e] * s2[e]);
         *reinterpret_cast<uint4*>(dx + xo) = Elem<T>::pack(g);

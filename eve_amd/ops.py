@@ -133,7 +133,9 @@ class InstNormActFn(torch.autograd.Function):
             mr = k.instnorm_stats(x, eps)
             y = k.instnorm_act_fwd(x, mr, g, b, res, act)
         ctx.act, ctx.has_res, ctx.has_affine = act, res is not None, gamma is not None
-        ctx.save_for_backward(x, y, mr, g)
+        # the backward needs y only to evaluate act'; without affine/residual it recomputes that from x
+        need_y = act != ACT_NONE and (res is not None or gamma is not None)
+        ctx.save_for_backward(x, y if need_y else None, mr, g)
         return y
 
     @staticmethod

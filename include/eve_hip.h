@@ -94,7 +94,8 @@ int eve_instnorm_act_fwd(int dtype, int N, int HW, int C, const void* x, const f
                          const float* gamma, const float* beta, const void* res, int act, void* y,
                          eve_stream_t stream);
 /* g = dy * act'(y);  dx = gamma*rstd*(g - mean_hw(g) - xhat*mean_hw(g*xhat));  dres = g (if != NULL);
- * sums[n][c] = (sum_hw g, sum_hw g*xhat)  (reduce over n for dbeta / dgamma)                      */
+ * sums[n][c] = (sum_hw g, sum_hw g*xhat)  (reduce over n for dbeta / dgamma).
+ * y may be NULL when there was neither affine nor residual: act'(.) is then recomputed from x (one read less). */
 int eve_instnorm_act_bwd(int dtype, int N, int HW, int C, const void* dy, const void* y,
                          const void* x, const float* mean_rstd, const float* gamma, int act,
                          void* dx, void* dres, float* sums, eve_stream_t stream);

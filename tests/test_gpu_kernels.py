@@ -191,6 +191,12 @@ def test_instnorm_fwd_bwd(hip, ref, dtype, shape):
             close(fb[2], s_w, torch.float32, 'fused instnorm bwd sums', scale=float(s_w.abs().max()) * 4)
             if r is not None:
                 close(fb[1], dres_w, dtype, 'fused instnorm bwd dres')
+            if r is None and g is None and act != 0:       # act' recomputed from x instead of reading y
+                fb2 = hip.instnorm_bwd_fused(dev(dy), None, dev(x), dev(mr_w), None, act, False)
+                close(fb2[0], dx_w, dtype, 'fused instnorm bwd dx without y', scale=float(dx_w.abs().max()) + 0.05)
+        if r is None and g is None and act != 0:
+            dx2 = hip.instnorm_act_bwd(dev(dy), None, dev(x), dev(mr_w), None, act, False)[0]
+            close(dx2, dx_w, dtype, 'instnorm_act bwd dx without y', scale=float(dx_w.abs().max()) + 0.05)
 
 
 @pytest.mark.parametrize('dtype', DTYPES, ids=['f32', 'bf16'])
