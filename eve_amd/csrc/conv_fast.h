@@ -306,8 +306,14 @@ __global__ __launch_bounds__(256) void wgrad_tr_kernel(const GatherParams p, con
 
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const uint32_t k0 = blockIdx.x * BKK, co0 = blockIdx.y * BCO;
-    const uint32_t m_begin = blockIdx.z * rows_per_split;
+    // 1-D grid, XCD-aware: all (k tile, channel tile) workgroups of one pixel range land on the SAME XCD, so the
+    // dy / x rows they share are fetched into one L2 once (a 3-D grid spreads them round-robin over the 8 XCDs and
+    // every L2 re-fetches them: 3-6x the algorithmic bytes measured with FETCH_SIZE)
+    const uint32_t tk = (p.K + BKK - 1) / BKK, tc = (p.Cout + BCO - 1) / BCO;
+    // (with fewer than 4 tiles per pixel range the plain order measured faster: nothing to share)
+    const uint32_t lid = tk * tc >= 4 ? xcd_remap(blockIdx.x, gridDim.x) : blockIdx.x;
+    const uint32_t k0 = (lid % tk) * BKK, co0 = ((lid / tk) % tc) * BCO;
+    const uint32_t m_begin = (lid / (tk * tc)) * rows_per_split;
     const uint32_t m_end = min(p.M, m_begin + rows_per_split);
     const uint32_t ohw = (uint32_t)(p.OH * p.OW);
 

@@ -656,16 +656,16 @@ static int launch_wgrad(const GatherParams& p, const void* x, const void* dy, co
             if (p.Cout > 64) {
                 const uint32_t tk = (p.K + 127) / 128, tc = (p.Cout + 127) / 128;
                 wgrad_split(p, tk, tc, splits, rows);
-                if (pow2) hipLaunchKernelGGL((wgrad_tr_kernel<2, 2, true>), dim3(tk, tc, splits), dim3(256), 0, s, p, (const bf16_t*)x,
+                if (pow2) hipLaunchKernelGGL((wgrad_tr_kernel<2, 2, true>), dim3(tk * tc * splits), dim3(256), 0, s, p, (const bf16_t*)x,
                                              (const bf16_t*)dy, dw, rows, (uint32_t)x_bytes, (uint32_t)dy_bytes);
-                else      hipLaunchKernelGGL((wgrad_tr_kernel<2, 2, false>), dim3(tk, tc, splits), dim3(256), 0, s, p, (const bf16_t*)x,
+                else      hipLaunchKernelGGL((wgrad_tr_kernel<2, 2, false>), dim3(tk * tc * splits), dim3(256), 0, s, p, (const bf16_t*)x,
                                              (const bf16_t*)dy, dw, rows, (uint32_t)x_bytes, (uint32_t)dy_bytes);
             } else {
                 const uint32_t tk = (p.K + 255) / 256, tc = 1;
                 wgrad_split(p, tk, tc, splits, rows);
-                if (pow2) hipLaunchKernelGGL((wgrad_tr_kernel<1, 4, true>), dim3(tk, tc, splits), dim3(256), 0, s, p, (const bf16_t*)x,
+                if (pow2) hipLaunchKernelGGL((wgrad_tr_kernel<1, 4, true>), dim3(tk * tc * splits), dim3(256), 0, s, p, (const bf16_t*)x,
                                              (const bf16_t*)dy, dw, rows, (uint32_t)x_bytes, (uint32_t)dy_bytes);
-                else      hipLaunchKernelGGL((wgrad_tr_kernel<1, 4, false>), dim3(tk, tc, splits), dim3(256), 0, s, p, (const bf16_t*)x,
+                else      hipLaunchKernelGGL((wgrad_tr_kernel<1, 4, false>), dim3(tk * tc * splits), dim3(256), 0, s, p, (const bf16_t*)x,
                                              (const bf16_t*)dy, dw, rows, (uint32_t)x_bytes, (uint32_t)dy_bytes);
             }
             return 0;
