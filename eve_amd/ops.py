@@ -35,6 +35,18 @@ class PackedWeight(object):
         self.ohwi, self.ihwo = k.pack_weights(w, dtype, want_ihwo=want_ihwo)
 
 
+def _direct_grad_ok(p):
+    """True for a parameter whose .grad is a persistent, contiguous (OHWI for conv weights) slice of the trainer's
+    flat gradient buffer and which is used ONCE per step (train.FlatParameters sets the flag)."""
+    return getattr(p, '_eve_flat_grad', False) and p.grad is not None and p.requires_grad
+
+
+def _notify_grad_ready(p):
+    cb = getattr(p, '_eve_grad_ready', None)        # data-parallel bucket bookkeeping (parallel.GradSync)
+    if cb is not None:
+        cb(p)
+
+
 class Conv2dFn(torch.autograd.Function):
     """y = act(conv(x, W) + b).  x NHWC; `weight` has shape [Cout, Cin, KH, KW] (or [out, in]);
     `pack` holds the packed copies (possibly with zero-padded Cin/Cout)."""
@@ -53,6 +65,9 @@ class Conv2dFn(torch.autograd.Function):
         ctx.pack, ctx.stride, ctx.pad, ctx.epi_act = pack, stride, pad, epi_act
         ctx.has_bias = bias is not None
         ctx.wshape = tuple(weight.shape)
+        # parameters re-homed by train.FlatParameters take their gradient straight into the flat buffer
+        ctx.w_direct = weight if _direct_grad_ok(weight) else None
+        ctx.b_direct = bias if (bias is not None and _direct_grad_ok(bias)) else None
         ctx.save_for_backward(x, y if epi_act != ACT_NONE else None)
         return y
 
@@ -69,17 +84,31 @@ class Conv2dFn(torch.autograd.Function):
             dx = k.conv2d_dgrad(dy, pack.ihwo, (x.shape[1], x.shape[2]), ctx.stride, ctx.pad, algo=pack.algo)
         if ctx.needs_input_grad[1]:
             cout_p, KH, KW, cin_p = pack.ohwi.shape
-            dwp = torch.zeros((cout_p, KH, KW, cin_p), dtype=torch.float32, device=x.device)
-            k.conv2d_wgrad(x, dy, KH, KW, ctx.stride, ctx.pad, dwp, algo=pack.algo)
             O, I = pack.shape_oihw[0], pack.shape_oihw[1]
-            dw = dwp[:O, :, :, :I].permute(0, 3, 1, 2)          # OIHW-shaped view of OHWI memory
-            if len(ctx.wshape) == 2:
-                dw = dw.reshape(ctx.wshape)
+            wp = ctx.w_direct
+            if wp is not None and (cout_p, cin_p) == (O, I):
+                # the wgrad kernel accumulates into the parameter's slice of the flat gradient buffer (already OHWI):
+                # no temporary, no zero-fill launch, no AccumulateGrad add
+                g = wp.grad
+                buf = g.permute(0, 2, 3, 1) if g.dim() == 4 else g.view(O, 1, 1, I)
+                k.conv2d_wgrad(x, dy, KH, KW, ctx.stride, ctx.pad, buf, algo=pack.algo)
+                _notify_grad_ready(wp)
+            else:
+                dwp = torch.zeros((cout_p, KH, KW, cin_p), dtype=torch.float32, device=x.device)
+                k.conv2d_wgrad(x, dy, KH, KW, ctx.stride, ctx.pad, dwp, algo=pack.algo)
+                dw = dwp[:O, :, :, :I].permute(0, 3, 1, 2)          # OIHW-shaped view of OHWI memory
+                if len(ctx.wshape) == 2:
+                    dw = dw.reshape(ctx.wshape)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             cout_p = pack.ohwi.shape[0]
-            dbp = torch.zeros((cout_p,), dtype=torch.float32, device=x.device)
-            k.bias_grad(dy, dbp)
-            db = dbp[:pack.shape_oihw[0]]
+            bp = ctx.b_direct
+            if bp is not None and cout_p == pack.shape_oihw[0]:
+                k.bias_grad(dy, bp.grad)
+                _notify_grad_ready(bp)
+            else:
+                dbp = torch.zeros((cout_p,), dtype=torch.float32, device=x.device)
+                k.bias_grad(dy, dbp)
+                db = dbp[:pack.shape_oihw[0]]
         return dx, dw, db, None, None, None, None
 
 

@@ -70,12 +70,14 @@ class GradSync(object):
             for p, _, _ in entries:
                 if p.requires_grad:
                     self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
+                    p._eve_grad_ready = self._on_grad      # gradients written in place never reach AccumulateGrad
 
     def start_step(self):
         for b in self.buckets:
             b['pending'] = sum(1 for p in b['params'] if p.requires_grad)
             b['launched'] = False
         self._handles = []
+        self._seen = set()
         self._armed = True
 
     def _launch(self, b):
@@ -86,8 +88,12 @@ class GradSync(object):
                                              group=self.group, async_op=True))
 
     def _on_grad(self, p):
-        if not self._armed:
+        # called from the post-accumulate hook and/or from ops.Conv2dFn for gradients written in place; a
+        # parameter counts once per step whichever route reports it (some torch versions run the hook even when
+        # backward returned no gradient for the parameter)
+        if not self._armed or id(p) in self._seen:
             return
+        self._seen.add(id(p))
         b = self._bucket_of[id(p)]
         b['pending'] -= 1
         if b['pending'] == 0:

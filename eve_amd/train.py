@@ -50,6 +50,7 @@ class FlatParameters(object):
                 pv.copy_(p.detach().to(device))
                 p.data = pv
                 p.grad = view(self.grad)
+                p._eve_flat_grad = True            # ops.Conv2dFn may accumulate wgrad / bias-grad in place
                 self.entries.append((p, off, n))
                 off += n
         self.numel = total
