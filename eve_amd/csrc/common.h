@@ -78,6 +78,23 @@ __device__ __forceinline__ float act_fwd(float z, int act) {
         default:              return z;
     }
 }
+// Conv epilogue activation on the four values a lane holds.  The selector is wave-uniform; a per-element
+// switch costs more scalar branches than the epilogue has vector work and bloats the kernel past the
+// instruction cache, so the kernels run the whole epilogue as one of two bodies: FAST (identity / ReLU, the
+// ResNet trunk) or the general one.
+__device__ __forceinline__ bool act_is_fast(int act) { return act == EVE_ACT_NONE || act == EVE_ACT_RELU; }
+template <bool FAST>
+__device__ __forceinline__ void act_fwd4(float* o, int act) {
+    if (FAST) {
+        if (act == EVE_ACT_RELU) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] = o[r] > 0.f ? o[r] : 0.f;
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = act_fwd(o[r], act);
+    }
+}
 // derivative expressed through the OUTPUT y = act(z) (all five are invertible enough for that)
 __device__ __forceinline__ float act_grad_from_out(float y, int act) {
     switch (act) {

@@ -14,6 +14,7 @@
 // LDS-DMA writes lane-linearly, so bank-conflict swizzles are applied to the SOURCE slot a lane fetches
 // and undone on the read (same XOR on both sides).
 #pragma once
+#include <type_traits>
 #include "common.h"
 
 namespace eve {
@@ -192,47 +193,52 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_dma_kernel(const GatherPar
     }
 
     const bool vec_ok = (p.Cout & 3) == 0;
-#pragma unroll
-    for (int nt = 0; nt < 4; ++nt) {
-        const uint32_t co = n0 + wn * 64 + nt * 16 + lg * 4;
-        float bv[4] = {0.f, 0.f, 0.f, 0.f};
-        if (bias) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                if (co + r < (uint32_t)p.Cout) bv[r] = bias[co + r];
-        }
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt) {
-            const uint32_t m = m0 + wm * 64 + mt * 16 + li;
-            if (m >= p.M || co >= (uint32_t)p.Cout) continue;
-            float o[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) o[r] = act_fwd(acc[mt][nt][r] + bv[r], epi_act);
-            size_t opix = m;
-            if (tp.osy != 1 || tp.osx != 1) {       // uniform: only the strided-dgrad sub-problems remap pixels
-                const uint32_t n = fd_div(m, p.fd_ohw);
-                const uint32_t rem = m - n * (uint32_t)(p.OH * p.OW);
-                const uint32_t oy = fd_div(rem, p.fd_ow);
-                const uint32_t ox = rem - oy * (uint32_t)p.OW;
-                opix = ((size_t)n * tp.OHf + oy * tp.osy + tp.oy0) * tp.OWf + ox * tp.osx + tp.ox0;
-            }
-            T* dst = out + opix * p.Cout + co;
-            if (vec_ok) {
-                if (sizeof(T) == 4) {
-                    *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
-                } else {
-                    uint2 pk;
-                    pk.x = f32_to_bf16_bits(o[0]) | (f32_to_bf16_bits(o[1]) << 16);
-                    pk.y = f32_to_bf16_bits(o[2]) | (f32_to_bf16_bits(o[3]) << 16);
-                    *reinterpret_cast<uint2*>(dst) = pk;
-                }
-            } else {
-#pragma unroll
+    auto epilogue = [&](auto fast) {
+    #pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            const uint32_t co = n0 + wn * 64 + nt * 16 + lg * 4;
+            float bv[4] = {0.f, 0.f, 0.f, 0.f};
+            if (bias) {
+    #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                    if (co + r < (uint32_t)p.Cout) Elem<T>::st(dst + r, o[r]);
+                    if (co + r < (uint32_t)p.Cout) bv[r] = bias[co + r];
+            }
+    #pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                const uint32_t m = m0 + wm * 64 + mt * 16 + li;
+                if (m >= p.M || co >= (uint32_t)p.Cout) continue;
+                float o[4];
+    #pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] = acc[mt][nt][r] + bv[r];
+                act_fwd4<decltype(fast)::value>(o, epi_act);
+                size_t opix = m;
+                if (tp.osy != 1 || tp.osx != 1) {       // uniform: only the strided-dgrad sub-problems remap pixels
+                    const uint32_t n = fd_div(m, p.fd_ohw);
+                    const uint32_t rem = m - n * (uint32_t)(p.OH * p.OW);
+                    const uint32_t oy = fd_div(rem, p.fd_ow);
+                    const uint32_t ox = rem - oy * (uint32_t)p.OW;
+                    opix = ((size_t)n * tp.OHf + oy * tp.osy + tp.oy0) * tp.OWf + ox * tp.osx + tp.ox0;
+                }
+                T* dst = out + opix * p.Cout + co;
+                if (vec_ok) {
+                    if (sizeof(T) == 4) {
+                        *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
+                    } else {
+                        uint2 pk;
+                        pk.x = f32_to_bf16_bits(o[0]) | (f32_to_bf16_bits(o[1]) << 16);
+                        pk.y = f32_to_bf16_bits(o[2]) | (f32_to_bf16_bits(o[3]) << 16);
+                        *reinterpret_cast<uint2*>(dst) = pk;
+                    }
+                } else {
+    #pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (co + r < (uint32_t)p.Cout) Elem<T>::st(dst + r, o[r]);
+                }
             }
         }
-    }
+    };
+    if (act_is_fast(epi_act)) epilogue(std::true_type{});
+    else epilogue(std::false_type{});
 }
 
 // 16 MFMAs (4 x 4 accumulator tiles, one K=32 chunk) as ONE asm statement with every accumulator tied in place
@@ -490,7 +496,7 @@ struct HaloParams {
     int a_pieces;                 // halo DMA instructions per thread and slice (<= 7)
     uint32_t x_bytes, w_bytes;
     uint32_t tiles_m, tiles_n;
-    FastDiv fd_w2, fd_hpi, fd_w;  // divisions by (W+2), (TH+2)*(W+2), W
+    FastDiv fd_w2, fd_hpi, fd_w, fd_th;  // divisions by (W+2), (TH+2)*(W+2), W, TH
 };
 
 template <int WM, int WN>
@@ -570,7 +576,7 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const HaloParams p, c
     for (int mt = 0; mt < 4; ++mt) {
         const int m = wm * 64 + mt * 16 + li;                 // pixel in the tile: (ti, ty, tx)
         const int rowi = (int)fd_div((uint32_t)m, p.fd_w), tx = m - rowi * p.W;
-        const int ti = rowi / p.TH, ty = rowi - ti * p.TH;
+        const int ti = (int)fd_div((uint32_t)rowi, p.fd_th), ty = rowi - ti * p.TH;
         const int hp0 = ti * HPI + ty * W2 + tx;
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
@@ -639,34 +645,39 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const HaloParams p, c
         }
     }
 
-    // ---- epilogue ----
-#pragma unroll
-    for (int nt = 0; nt < 4; ++nt) {
-        const uint32_t co = co0 + wn * 64 + nt * 16 + lg * 4;
-        float bv[4] = {0.f, 0.f, 0.f, 0.f};
-        if (bias) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                if (co + r < (uint32_t)p.Cout) bv[r] = bias[co + r];
+    // ---- epilogue (two bodies, see act_fwd4) ----
+    auto epilogue = [&](auto fast) {
+    #pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            const uint32_t co = co0 + wn * 64 + nt * 16 + lg * 4;
+            float bv[4] = {0.f, 0.f, 0.f, 0.f};
+            if (bias) {
+    #pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (co + r < (uint32_t)p.Cout) bv[r] = bias[co + r];
+            }
+    #pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                const int m = wm * 64 + mt * 16 + li;
+                const int rowi = (int)fd_div((uint32_t)m, p.fd_w), tx = m - rowi * p.W;
+                const int ti = (int)fd_div((uint32_t)rowi, p.fd_th), ty = rowi - ti * p.TH;
+                const uint32_t n = n0 + ti;
+                const int y = y0 + ty;
+                if (n >= (uint32_t)p.N || y >= p.H || co >= (uint32_t)p.Cout) continue;
+                float o[4];
+    #pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] = acc[mt][nt][r] + bv[r];
+                act_fwd4<decltype(fast)::value>(o, epi_act);
+                bf16_t* dst = out + ((size_t)(n * p.H + y) * p.W + tx) * p.Cout + co;
+                uint2 pk;
+                pk.x = f32_to_bf16_bits(o[0]) | (f32_to_bf16_bits(o[1]) << 16);
+                pk.y = f32_to_bf16_bits(o[2]) | (f32_to_bf16_bits(o[3]) << 16);
+                *reinterpret_cast<uint2*>(dst) = pk;
+            }
         }
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt) {
-            const int m = wm * 64 + mt * 16 + li;
-            const int rowi = (int)fd_div((uint32_t)m, p.fd_w), tx = m - rowi * p.W;
-            const int ti = rowi / p.TH, ty = rowi - ti * p.TH;
-            const uint32_t n = n0 + ti;
-            const int y = y0 + ty;
-            if (n >= (uint32_t)p.N || y >= p.H || co >= (uint32_t)p.Cout) continue;
-            float o[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) o[r] = act_fwd(acc[mt][nt][r] + bv[r], epi_act);
-            bf16_t* dst = out + ((size_t)(n * p.H + y) * p.W + tx) * p.Cout + co;
-            uint2 pk;
-            pk.x = f32_to_bf16_bits(o[0]) | (f32_to_bf16_bits(o[1]) << 16);
-            pk.y = f32_to_bf16_bits(o[2]) | (f32_to_bf16_bits(o[3]) << 16);
-            *reinterpret_cast<uint2*>(dst) = pk;
-        }
-    }
+    };
+    if (act_is_fast(epi_act)) epilogue(std::true_type{});
+    else epilogue(std::false_type{});
 }
 
 }  // namespace eve

@@ -21,6 +21,7 @@
 // LDS write, i.e. the consumer normalises InstanceNorm'ed inputs on the fly (padding stays exactly 0).
 #include <stdlib.h>
 
+#include <type_traits>
 #include "common.h"
 
 namespace eve {
@@ -206,39 +207,44 @@ __global__ __launch_bounds__(256) void igemm_kernel(const GatherParams p, const 
 
     // ---- epilogue: lane holds channels co..co+3 (rows of D) of pixel m (column of D) ----
     const bool vec_ok = (p.Cout & 3) == 0;
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-        const uint32_t co = n0 + wn * 16 * NT + nt * 16 + lg * 4;
-        float bv[4] = {0.f, 0.f, 0.f, 0.f};
-        if (bias) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                if (co + r < (uint32_t)p.Cout) bv[r] = bias[co + r];
-        }
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt) {
-            const uint32_t m = m0 + wm * 64 + mt * 16 + li;
-            if (m >= p.M || co >= (uint32_t)p.Cout) continue;
-            float o[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) o[r] = act_fwd(acc[mt][nt][r] + bv[r], epi_act);
-            T* dst = out + (size_t)m * p.Cout + co;
-            if (vec_ok) {
-                if (sizeof(T) == 4) {
-                    *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
-                } else {
-                    uint2 pk;
-                    pk.x = f32_to_bf16_bits(o[0]) | (f32_to_bf16_bits(o[1]) << 16);
-                    pk.y = f32_to_bf16_bits(o[2]) | (f32_to_bf16_bits(o[3]) << 16);
-                    *reinterpret_cast<uint2*>(dst) = pk;
-                }
-            } else {
-#pragma unroll
+    auto epilogue = [&](auto fast) {
+    #pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const uint32_t co = n0 + wn * 16 * NT + nt * 16 + lg * 4;
+            float bv[4] = {0.f, 0.f, 0.f, 0.f};
+            if (bias) {
+    #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                    if (co + r < (uint32_t)p.Cout) Elem<T>::st(dst + r, o[r]);
+                    if (co + r < (uint32_t)p.Cout) bv[r] = bias[co + r];
+            }
+    #pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                const uint32_t m = m0 + wm * 64 + mt * 16 + li;
+                if (m >= p.M || co >= (uint32_t)p.Cout) continue;
+                float o[4];
+    #pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] = acc[mt][nt][r] + bv[r];
+                act_fwd4<decltype(fast)::value>(o, epi_act);
+                T* dst = out + (size_t)m * p.Cout + co;
+                if (vec_ok) {
+                    if (sizeof(T) == 4) {
+                        *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
+                    } else {
+                        uint2 pk;
+                        pk.x = f32_to_bf16_bits(o[0]) | (f32_to_bf16_bits(o[1]) << 16);
+                        pk.y = f32_to_bf16_bits(o[2]) | (f32_to_bf16_bits(o[3]) << 16);
+                        *reinterpret_cast<uint2*>(dst) = pk;
+                    }
+                } else {
+    #pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (co + r < (uint32_t)p.Cout) Elem<T>::st(dst + r, o[r]);
+                }
             }
         }
-    }
+    };
+    if (act_is_fast(epi_act)) epilogue(std::true_type{});
+    else epilogue(std::false_type{});
 }
 
 // =================================================================================================
@@ -540,7 +546,7 @@ static bool launch_halo(const GatherParams& p, const void* src, const void* w, c
     h.flip = bwd ? 1 : 0; h.K = p.K; h.x_bytes = (uint32_t)xb; h.w_bytes = (uint32_t)wb;
     h.tiles_m = h.TI == 1 ? (uint32_t)p.N * h.bands : (uint32_t)((p.N + h.TI - 1) / h.TI);
     h.tiles_n = narrow ? 1 : (p.Cout + 127) / 128;
-    h.fd_w2 = make_fastdiv(W + 2); h.fd_hpi = make_fastdiv((h.TH + 2) * (W + 2)); h.fd_w = make_fastdiv(W);
+    h.fd_w2 = make_fastdiv(W + 2); h.fd_hpi = make_fastdiv((h.TH + 2) * (W + 2)); h.fd_w = make_fastdiv(W); h.fd_th = make_fastdiv(h.TH);
     const size_t lds = 2 * (size_t)h.a_pieces * 4096 + 4 * (narrow ? 4096 : 8192) + 4096;
     static bool attr_set = false;
     if (!attr_set) {

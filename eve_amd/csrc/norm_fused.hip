@@ -30,13 +30,14 @@ __device__ __forceinline__ void plane_allreduce(float* s, float* sh, int tid, in
         for (int e = 0; e < VEC; ++e) s[e] += sh[(w * 64 + src_lane) * VEC + e];
 }
 
-template <typename T, int VPT>
+template <typename T, int VPT, int ACT>
 __global__ __launch_bounds__(1024) void in_fwd_fused_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, const T* __restrict__ res,
-                                                            int act, T* __restrict__ y, float* __restrict__ mr,
+                                                            int act_rt, T* __restrict__ y, float* __restrict__ mr,
                                                             int HW, int C, float eps) {
     constexpr int VEC = Elem<T>::VEC;
     __shared__ float sh[1024 * VEC];
+    const int act = ACT >= 0 ? ACT : act_rt;        // ACT >= 0: activation known at compile time
     const int tid = threadIdx.x, nthreads = blockDim.x;
     const int cvecs = C / VEC, nvec = HW * cvecs;
     const int cv = tid % cvecs;
@@ -98,14 +99,15 @@ __global__ __launch_bounds__(1024) void in_fwd_fused_kernel(const T* __restrict_
     }
 }
 
-template <typename T, int VPT>
+template <typename T, int VPT, int ACT>
 __global__ __launch_bounds__(1024) void in_bwd_fused_kernel(const T* __restrict__ dy, const T* __restrict__ y,
                                                             const T* __restrict__ x, const float* __restrict__ mr,
-                                                            const float* __restrict__ gamma, int act,
+                                                            const float* __restrict__ gamma, int act_rt,
                                                             T* __restrict__ dx, T* __restrict__ dres,
                                                             float* __restrict__ sums, int HW, int C) {
     constexpr int VEC = Elem<T>::VEC;
     __shared__ float sh[1024 * VEC];
+    const int act = ACT >= 0 ? ACT : act_rt;        // ACT >= 0: activation known at compile time (no per-element switch)
     const int tid = threadIdx.x, nthreads = blockDim.x;
     const int cvecs = C / VEC, nvec = HW * cvecs;
     const int cv = tid % cvecs;
@@ -198,13 +200,18 @@ static bool fused_plan(int nvec, int cvecs, int& threads, int& vpt) {
 
 using namespace eve;
 
-#define LAUNCH_VPT(KERNEL, T, ...)                                                                        \
+#define LAUNCH_VPT_A(KERNEL, T, A, ...)                                                                   \
     switch (vpt) {                                                                                        \
-        case 1: hipLaunchKernelGGL((KERNEL<T, 1>), dim3(N), dim3(threads), 0, s, __VA_ARGS__); break;      \
-        case 2: hipLaunchKernelGGL((KERNEL<T, 2>), dim3(N), dim3(threads), 0, s, __VA_ARGS__); break;      \
-        case 4: hipLaunchKernelGGL((KERNEL<T, 4>), dim3(N), dim3(threads), 0, s, __VA_ARGS__); break;      \
-        default: hipLaunchKernelGGL((KERNEL<T, 8>), dim3(N), dim3(threads), 0, s, __VA_ARGS__); break;     \
+        case 1: hipLaunchKernelGGL((KERNEL<T, 1, A>), dim3(N), dim3(threads), 0, s, __VA_ARGS__); break;   \
+        case 2: hipLaunchKernelGGL((KERNEL<T, 2, A>), dim3(N), dim3(threads), 0, s, __VA_ARGS__); break;   \
+        case 4: hipLaunchKernelGGL((KERNEL<T, 4, A>), dim3(N), dim3(threads), 0, s, __VA_ARGS__); break;   \
+        default: hipLaunchKernelGGL((KERNEL<T, 8, A>), dim3(N), dim3(threads), 0, s, __VA_ARGS__); break;  \
     }
+// the two activations of the ResNet trunk get their own instantiation; everything else takes the run-time switch
+#define LAUNCH_VPT(KERNEL, T, ...)                                                                        \
+    if (act == EVE_ACT_NONE) { LAUNCH_VPT_A(KERNEL, T, EVE_ACT_NONE, __VA_ARGS__) }                       \
+    else if (act == EVE_ACT_RELU) { LAUNCH_VPT_A(KERNEL, T, EVE_ACT_RELU, __VA_ARGS__) }                  \
+    else { LAUNCH_VPT_A(KERNEL, T, -1, __VA_ARGS__) }
 
 /* returns 0 on launch, -1 if the plane does not fit the fused kernel (caller falls back), >0 on error */
 extern "C" int eve_instnorm_fwd_fused(int dtype, int N, int HW, int C, const void* x, const float* gamma,
