@@ -20,11 +20,15 @@ struct bf16_t { uint16_t v; };
 __device__ __forceinline__ float bf16_bits_to_f32(uint32_t bits16) {
     return __builtin_bit_cast(float, bits16 << 16);
 }
+// gfx950 converts in hardware (v_cvt_pk_bf16_f32, round-to-nearest-even, two values per instruction)
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
 __device__ __forceinline__ uint32_t f32_to_bf16_bits(float f) {
-    uint32_t u = __builtin_bit_cast(uint32_t, f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40u;   // quiet NaN
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return u >> 16;
+    return (uint32_t)__builtin_bit_cast(uint16_t, (__bf16)f);
+}
+__device__ __forceinline__ uint32_t pack2_bf16(float lo, float hi) {       // lo in bits 0..15
+    const f32x2_t f = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f, bf16x2_t));
 }
 
 template <typename T> struct Elem;
@@ -55,10 +59,10 @@ template <> struct Elem<bf16_t> {
         f[6] = bf16_bits_to_f32(q.w & 0xffffu); f[7] = __builtin_bit_cast(float, q.w & 0xffff0000u);
     }
     __device__ static __forceinline__ uint4 pack(const float* f) {
-        return make_uint4(f32_to_bf16_bits(f[0]) | (f32_to_bf16_bits(f[1]) << 16),
-                          f32_to_bf16_bits(f[2]) | (f32_to_bf16_bits(f[3]) << 16),
-                          f32_to_bf16_bits(f[4]) | (f32_to_bf16_bits(f[5]) << 16),
-                          f32_to_bf16_bits(f[6]) | (f32_to_bf16_bits(f[7]) << 16));
+        return make_uint4(pack2_bf16(f[0], f[1]),
+                          pack2_bf16(f[2], f[3]),
+                          pack2_bf16(f[4], f[5]),
+                          pack2_bf16(f[6], f[7]));
     }
 };
 

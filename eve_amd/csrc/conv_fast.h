@@ -225,8 +225,8 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_dma_kernel(const GatherPar
                         *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
                     } else {
                         uint2 pk;
-                        pk.x = f32_to_bf16_bits(o[0]) | (f32_to_bf16_bits(o[1]) << 16);
-                        pk.y = f32_to_bf16_bits(o[2]) | (f32_to_bf16_bits(o[3]) << 16);
+                        pk.x = pack2_bf16(o[0], o[1]);
+                        pk.y = pack2_bf16(o[2], o[3]);
                         *reinterpret_cast<uint2*>(dst) = pk;
                     }
                 } else {
@@ -481,11 +481,11 @@ namespace eve {
 // block of 128 output pixels (TI images x TH rows x full width W) loads, per 32-channel slice, the
 // (TH+2) x (W+2) halo patch ONCE (zero padding materialised by the DMA's out-of-range fill) and all 9 taps
 // read it at different offsets.  Only the 8 KB weight tile changes every step, and it runs 3 steps ahead
-// in a 4-slot ring; the next slice's halo streams in during the current slice.  Every step issues exactly
-// 3 LDS-DMA instructions per thread (2 weight + 1 halo or dummy), so one constant s_waitcnt vmcnt(6)
-// (loads return in order) is the whole synchronisation, plus one s_barrier per step.
+// in a 4-slot ring; the next slice's halo streams in during the current slice.  The DMA count of every step
+// is known (weight tile + at most one halo piece), so a counted s_waitcnt vmcnt(N) (loads return in order)
+// is the whole synchronisation, plus one s_barrier per step.
 //
-// LDS rows are 128 B = TWO consecutive pixels (or output channels) x 32 channels; slot' = slot ^ (row & 7).
+// LDS rows are 64 B = one pixel (or output channel) x 32 channels, chunk-swizzled (see the kernel body).
 // =================================================================================================
 struct HaloParams {
     int N, H, W, Cin, Cout;       // x: [N][H][W][Cin]  out: [N][H][W][Cout]
@@ -510,7 +510,6 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const HaloParams p, c
     char* const sA = smem;                                    // 2 halo stages
     constexpr int BSLOT = 4096 * WN;                          // weight tile: 64*WN output channels x 64 B
     char* const sB = smem + 2 * a_stage;                      // 4 weight slots
-    char* const sDummy = sB + 4 * BSLOT;                      // 4 KB sink for the padding DMAs
 
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -522,25 +521,29 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const HaloParams p, c
 
     const eve_int4 rs_x = make_rsrc_words(x, p.x_bytes);
     const eve_int4 rs_w = make_rsrc_words(w, p.w_bytes);
-    const uint32_t ldsA = lds_addr_of(sA), ldsB = lds_addr_of(sB), ldsD = lds_addr_of(sDummy);
+    const uint32_t ldsA = lds_addr_of(sA), ldsB = lds_addr_of(sB);
 
     // ---- halo DMA slots owned by this thread (loop invariant): global byte offset without the channel slice ----
+    // LDS layout (both operands): one 64-byte row per pixel / output channel = 32 channels as four 16-byte
+    // chunks; chunk' = chunk ^ (key << 1).  key = bit 2 of the halo column for W >= 16 (a 16-lane read group
+    // walks along one halo row) and the halo-row parity for W < 16 (the group spans 2..4 rows): every
+    // ds_read_b128 of every tap is then bank-conflict free (brute-forced over all taps, tools/lds_banks.py).
+    const bool wide = p.W >= 16;
     int a_goff[7];
 #pragma unroll
     for (int j = 0; j < 7; ++j) {
         const int L = tid + 256 * j;                          // physical 16-byte slot in the stage
-        const int row = L >> 3, sp = L & 7;
-        const int ls = sp ^ (row & 7);
-        const int hp = 2 * row + (ls >> 2);
+        const int hp = L >> 2, pc = L & 3;
         int off = EVE_OOB;
         if (j < p.a_pieces && hp < HP) {
             const int ti = (int)fd_div((uint32_t)hp, p.fd_hpi);
             const int r = hp - ti * HPI;
             const int hy = (int)fd_div((uint32_t)r, p.fd_w2), hx = r - hy * W2;
+            const int key = wide ? (hx >> 2) & 1 : (ti * (p.TH + 2) + hy) & 1;
             const int gy = y0 - 1 + hy, gx = hx - 1;
             const uint32_t n = n0 + ti;
             if (gy >= 0 && gy < p.H && gx >= 0 && gx < p.W && n < (uint32_t)p.N)
-                off = (int)((((n * p.H + gy) * p.W + gx) * p.Cin) * 2) + (ls & 3) * 16;
+                off = (int)((((n * p.H + gy) * p.W + gx) * p.Cin) * 2) + ((pc ^ (key << 1)) << 4);
         }
         a_goff[j] = off;
     }
@@ -549,10 +552,9 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const HaloParams p, c
 #pragma unroll
     for (int j = 0; j < WN; ++j) {
         const int L = tid + 256 * j;
-        const int row = L >> 3, sp = L & 7;
-        const int ls = sp ^ (row & 7);
-        const uint32_t co = co0 + 2 * row + (ls >> 2);
-        b_goff[j] = co < (uint32_t)p.Cout ? (int)(co * (uint32_t)p.K) * 2 + (ls & 3) * 16 : EVE_OOB;
+        const int cl = L >> 2, pc = L & 3;
+        const uint32_t co = co0 + cl;
+        b_goff[j] = co < (uint32_t)p.Cout ? (int)(co * (uint32_t)p.K) * 2 + ((pc ^ (((cl >> 2) & 1) << 1)) << 4) : EVE_OOB;
     }
 
     const int nslices = p.Cin / 32;
@@ -566,7 +568,6 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const HaloParams p, c
         for (int j = 0; j < WN; ++j)
             lds_dma16_asm(rs_w, dst + j * 4096, (live && b_goff[j] != EVE_OOB) ? b_goff[j] + koff : EVE_OOB);
     };
-    auto issue_dummy = [&]() { lds_dma16_asm(rs_x, ldsD + wave_off, EVE_OOB); };
 
     // ---- fragment coordinates: every (tap, m-tile) LDS offset is a lane constant ----
     const int lane = tid & 63, wm = wave / WN, wn = wave % WN;
@@ -577,21 +578,21 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const HaloParams p, c
         const int m = wm * 64 + mt * 16 + li;                 // pixel in the tile: (ti, ty, tx)
         const int rowi = (int)fd_div((uint32_t)m, p.fd_w), tx = m - rowi * p.W;
         const int ti = (int)fd_div((uint32_t)rowi, p.fd_th), ty = rowi - ti * p.TH;
-        const int hp0 = ti * HPI + ty * W2 + tx;
+        const int hr0 = ti * (p.TH + 2) + ty;                 // halo row of tap dy = 0
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
             const int kh = t / 3, kw = t % 3;
-            const int hp = hp0 + (p.flip ? (2 - kh) * W2 + (2 - kw) : kh * W2 + kw);
-            const int row = hp >> 1;
-            aaddr[t][mt] = row * 128 + (((((hp & 1) << 2) + lg) ^ (row & 7)) << 4);
+            const int dy = p.flip ? 2 - kh : kh, dx = p.flip ? 2 - kw : kw;
+            const int hr = hr0 + dy, hx = tx + dx;
+            const int key = wide ? (hx >> 2) & 1 : hr & 1;
+            aaddr[t][mt] = ((hr * W2 + hx) << 6) + ((lg ^ (key << 1)) << 4);
         }
     }
     int brow[4];                                              // byte address of the weight fragment inside a ring slot
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) {
         const int c = wn * 64 + nt * 16 + li;
-        const int row = c >> 1;
-        brow[nt] = row * 128 + (((((c & 1) << 2) + lg) ^ (row & 7)) << 4);
+        brow[nt] = (c << 6) + ((lg ^ (((c >> 2) & 1) << 1)) << 4);
     }
 
     f32x4_t acc[4][4];
@@ -600,47 +601,61 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const HaloParams p, c
 #pragma unroll
         for (int b = 0; b < 4; ++b) acc[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-    // ---- prologue: halo of slice 0 (all pieces), weights of steps 0..2, laid out as three virtual steps ----
-    // (issue order inside a step is [halo piece, weight a, weight b]; loads return in order, so "all but the
-    //  newest 6" always means: everything up to and including the weight tile of two steps ago)
+    // ---- synchronisation: loads return in order, so "at most N outstanding" = everything older has landed.
+    // Step i issues [halo piece of the next slice (taps 0..a_pieces-1, not in the last slice)] + the WN DMAs
+    // of weight tile i+3.  Before step i+1 weight tile i+1 (issued in step i-2) must be in LDS, i.e. only the
+    // DMAs of steps i-1 and i may still be in flight: N = 2*WN + pieces issued in those two steps.
+    auto wait_all_but = [&](int extra) {                      // extra (uniform) = halo pieces among them: 0, 1 or 2
+        if (WN == 2) {
+            if (extra == 0) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else if (extra == 1) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        } else {
+            if (extra == 0) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            else if (extra == 1) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        }
+    };
+    // ---- prologue: halo of slice 0, then weight tiles 0, 1, 2 (the "steps -3..-1") ----
 #pragma unroll
-    for (int j = 0; j < 7; ++j) {
+    for (int j = 0; j < 7; ++j)
         if (j < p.a_pieces) lds_dma16_asm(rs_x, ldsA + j * 4096 + wave_off, a_goff[j]);
-        else issue_dummy();
-    }
     issue_b(0, 0, 0);
-    issue_dummy(); issue_b(0, 1, 1);
-    issue_dummy(); issue_b(0, 2, 2);
-    if (WN == 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // halo of slice 0 and weight tile 0 have landed
-    else         asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    issue_b(0, 1, 1);
+    issue_b(0, 2, 2);
+    wait_all_but(0);                                          // halo of slice 0 and weight tile 0 have landed
     __builtin_amdgcn_s_barrier();
 
     for (int s = 0; s < nslices; ++s) {
         const char* la = sA + (s & 1) * a_stage;
         const uint32_t na = ldsA + ((s + 1) & 1) * a_stage + wave_off;   // next slice's halo stage
-        const bool more = s + 1 < nslices;
+        const int ap = s + 1 < nslices ? p.a_pieces : 0;      // halo pieces this slice still has to fetch
         const int nxt_c = (s + 1) * 64;                       // its channel byte offset
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
-            // exactly 3 DMAs per step: one halo piece of the next slice (taps 0..6) or a dummy, then weight tile i+3
-            if (t < 7 && more && t < p.a_pieces)
-                lds_dma16_asm(rs_x, na + t * 4096, a_goff[t < 7 ? t : 0] != EVE_OOB ? a_goff[t < 7 ? t : 0] + nxt_c : EVE_OOB);
-            else
-                issue_dummy();
-            issue_b(s + (t + 3) / 9, (t + 3) % 9, (s + t + 3) & 3);
             const char* lb = sB + ((s + t) & 3) * BSLOT;
             uint4 fx[4], fw[4];
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt) fx[mt] = *reinterpret_cast<const uint4*>(la + aaddr[t][mt]);
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) fw[nt] = *reinterpret_cast<const uint4*>(lb + brow[nt]);
+            // the DMA issues are spread between the MFMA groups so that they overlap matrix work
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt)
+            for (int nt = 0; nt < 4; ++nt) {
 #pragma unroll
-                for (int nt = 0; nt < 4; ++nt) Mma<bf16_t>::run(acc[mt][nt], fw[nt], fx[mt]);
-            // weight tile i+1 (and any halo piece issued two or more steps ago) must have landed before step i+1
-            if (WN == 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-            else         asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                for (int mt = 0; mt < 4; ++mt) Mma<bf16_t>::run(acc[mt][nt], fw[nt], fx[mt]);
+                if (nt == 0) {
+                    if (t < 7 && t < ap)
+                        lds_dma16_asm(rs_x, na + t * 4096, a_goff[t < 7 ? t : 0] != EVE_OOB ? a_goff[t < 7 ? t : 0] + nxt_c : EVE_OOB);
+                } else if (nt == 1) {
+                    issue_b(s + (t + 3) / 9, (t + 3) % 9, (s + t + 3) & 3);
+                }
+            }
+            // pieces issued in steps t-1 and t:  [t-1 < ap] + [t < ap]  (the step before tap 0 never has one)
+            int extra = ap - t + 1;
+            extra = extra < 0 ? 0 : (extra > 2 ? 2 : extra);
+            if (t == 0) extra = ap > 0 ? 1 : 0;
+            wait_all_but(extra);
             __builtin_amdgcn_s_barrier();
         }
     }
@@ -670,8 +685,8 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const HaloParams p, c
                 act_fwd4<decltype(fast)::value>(o, epi_act);
                 bf16_t* dst = out + ((size_t)(n * p.H + y) * p.W + tx) * p.Cout + co;
                 uint2 pk;
-                pk.x = f32_to_bf16_bits(o[0]) | (f32_to_bf16_bits(o[1]) << 16);
-                pk.y = f32_to_bf16_bits(o[2]) | (f32_to_bf16_bits(o[3]) << 16);
+                pk.x = pack2_bf16(o[0], o[1]);
+                pk.y = pack2_bf16(o[2], o[3]);
                 *reinterpret_cast<uint2*>(dst) = pk;
             }
         }

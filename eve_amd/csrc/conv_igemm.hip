@@ -231,8 +231,8 @@ __global__ __launch_bounds__(256) void igemm_kernel(const GatherParams p, const 
                         *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
                     } else {
                         uint2 pk;
-                        pk.x = f32_to_bf16_bits(o[0]) | (f32_to_bf16_bits(o[1]) << 16);
-                        pk.y = f32_to_bf16_bits(o[2]) | (f32_to_bf16_bits(o[3]) << 16);
+                        pk.x = pack2_bf16(o[0], o[1]);
+                        pk.y = pack2_bf16(o[2], o[3]);
                         *reinterpret_cast<uint2*>(dst) = pk;
                     }
                 } else {
@@ -539,7 +539,7 @@ static bool launch_halo(const GatherParams& p, const void* src, const void* w, c
     if (rows <= H) { h.TI = 1; h.TH = rows; h.bands = (H + rows - 1) / rows; }
     else { if (rows % H) return false; h.TI = rows / H; h.TH = H; h.bands = 1; }
     const int HP = h.TI * (h.TH + 2) * (W + 2);
-    h.a_pieces = (((HP + 1) / 2) * 8 + 255) / 256;
+    h.a_pieces = (HP * 4 + 255) / 256;
     if (h.a_pieces > 7) return false;
     const unsigned long long xb = (unsigned long long)p.N * H * W * p.Cin * 2, wb = (unsigned long long)p.Cout * p.K * 2;
     if (xb >= (1ull << 31) || wb >= (1ull << 31)) return false;
@@ -547,7 +547,7 @@ static bool launch_halo(const GatherParams& p, const void* src, const void* w, c
     h.tiles_m = h.TI == 1 ? (uint32_t)p.N * h.bands : (uint32_t)((p.N + h.TI - 1) / h.TI);
     h.tiles_n = narrow ? 1 : (p.Cout + 127) / 128;
     h.fd_w2 = make_fastdiv(W + 2); h.fd_hpi = make_fastdiv((h.TH + 2) * (W + 2)); h.fd_w = make_fastdiv(W); h.fd_th = make_fastdiv(h.TH);
-    const size_t lds = 2 * (size_t)h.a_pieces * 4096 + 4 * (narrow ? 4096 : 8192) + 4096;
+    const size_t lds = 2 * (size_t)h.a_pieces * 4096 + 4 * (narrow ? 4096 : 8192);
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)conv3x3_halo_kernel<2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

@@ -34,8 +34,8 @@ __global__ __launch_bounds__(256) void stem_pack_kernel(const float* __restrict_
         if (x >= 0 && x < IW && y >= 0 && y < IH) {
             float f[4] = {0.f, 0.f, 0.f, 0.f};
             for (int c = 0; c < C && c < 4; ++c) f[c] = src[((n * C + c) * IH + y) * IW + x];
-            q.x = f32_to_bf16_bits(f[0]) | (f32_to_bf16_bits(f[1]) << 16);
-            q.y = f32_to_bf16_bits(f[2]) | (f32_to_bf16_bits(f[3]) << 16);
+            q.x = pack2_bf16(f[0], f[1]);
+            q.y = pack2_bf16(f[2], f[3]);
         }
         dst[i] = q;
     }
@@ -105,8 +105,8 @@ __global__ __launch_bounds__(256) void stem7x7_kernel(const int N, const int IH,
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) {
                 uint2 pk;
-                pk.x = f32_to_bf16_bits(acc[mt][nt][0]) | (f32_to_bf16_bits(acc[mt][nt][1]) << 16);
-                pk.y = f32_to_bf16_bits(acc[mt][nt][2]) | (f32_to_bf16_bits(acc[mt][nt][3]) << 16);
+                pk.x = pack2_bf16(acc[mt][nt][0], acc[mt][nt][1]);
+                pk.y = pack2_bf16(acc[mt][nt][2], acc[mt][nt][3]);
                 *reinterpret_cast<uint2*>(orow + (mt * 16 + li) * 64 + nt * 16 + lg * 4) = pk;
             }
     }
