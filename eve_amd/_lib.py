@@ -28,6 +28,8 @@ SIGNATURES = {
     'eve_conv2d_wgrad': [POINTER(ConvDesc), P, P, P, I, P, P],
     'eve_stem_pack_input': [I, I, I, I, P, P, P],
     'eve_stem7x7s2_fwd': [I, I, I, P, P, P, P],
+    'eve_stem_fwd_fused': [I, I, I, P, P, F, P, P, P, P],
+    'eve_stem_bwd_dx': [I, I, I, P, P, P, P, P, P, P, P],
     'eve_bias_grad': [I, L, I, P, P, P],
     'eve_instnorm_stats': [I, I, I, I, P, F, P, P],
     'eve_instnorm_act_fwd': [I, I, I, I, P, P, P, P, P, I, P, P],

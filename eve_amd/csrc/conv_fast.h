@@ -16,41 +16,9 @@
 #pragma once
 #include <type_traits>
 #include "common.h"
+#include "lds_dma.h"
 
 namespace eve {
-
-#define EVE_LDS __attribute__((address_space(3)))
-typedef __attribute__((__vector_size__(4 * sizeof(__bf16)))) __bf16 bf16x4v_t;
-
-__device__ __forceinline__ void lds_dma16(__amdgpu_buffer_rsrc_t rsrc, const void* lds_generic_ptr, int voffset) {
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (EVE_LDS void*)(lds_generic_ptr), 16, voffset, 0, 0, 0);
-}
-#define EVE_OOB ((int)0x80000000u)   // >= num_records for every tensor we accept (< 2^31 bytes)
-
-// The same LDS-DMA as inline asm.  hipcc treats the builtin as a store to LDS and protects every later ds_read
-// with s_waitcnt vmcnt(0), which drains a multi-stage prefetch ring at every step; an asm statement is opaque to
-// that bookkeeping, so the waits are exactly the counted s_waitcnt vmcnt(N) the kernel places itself.
-// M0 (the LDS destination base) is written and restored inside the statement.
-typedef int eve_int4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ eve_int4 make_rsrc_words(const void* base, uint32_t bytes) {
-    const uint64_t a = (uint64_t)base;
-    eve_int4 r;
-    r.x = (int)(uint32_t)a;
-    r.y = (int)(uint32_t)((a >> 32) & 0xffffu);      // stride 0
-    r.z = (int)bytes;
-    r.w = 0x00020000;
-    return r;
-}
-__device__ __forceinline__ uint32_t lds_addr_of(const void* generic_ptr) {
-    return (uint32_t)(uintptr_t)((EVE_LDS void*)generic_ptr);
-}
-__device__ __forceinline__ void lds_dma16_asm(const eve_int4& rsrc, uint32_t lds_byte_addr, int voffset) {
-    uint32_t keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep)
-                 : "s"(lds_byte_addr), "v"(voffset), "s"(rsrc)
-                 : "memory");
-}
 
 // The filter taps a launch iterates over (at most 32), as source-pixel displacements and weight tap ids, plus
 // the mapping from the launch's pixel grid to output pixels.  A plain convolution uses all KH*KW taps and the

@@ -9,6 +9,7 @@
 // activations at all.  The 28 KB filter bank sits in LDS for the lifetime of the (persistent) workgroup.
 // Waves are independent after the filter load: no barriers, each wave walks its own 64-pixel row tiles and keeps
 // all 28 fragment loads of a tile in flight.  Output 64 px x 64 channels per wave tile, 112 MFMAs.
+#include <stdlib.h>
 #include "common.h"
 
 namespace eve {

@@ -1,0 +1,476 @@
+// ResNet stem, fused for gfx950:  conv 7x7/2 (3 -> 64)  ->  InstanceNorm (no affine)  ->  ReLU  ->  max-pool 3x3/2
+// in ONE kernel that never materialises the 64x64x64 convolution output.
+// Reference: torchvision ResNet._forward_impl conv1/bn1/relu/maxpool as instantiated by
+// /root/reference/src/models/eye_net.py:48-50,106 (norm_layer = InstanceNorm2d, 128x128 eye patches).
+//
+// relu(IN(.)) is monotone per channel (rstd > 0), so the window maximum is taken on the RAW convolution values
+// and only the winner is normalised.  One wavefront owns one image: it walks the 64 output rows top to bottom,
+// computes each row with 112 MFMAs (4 column tiles x 4 channel tiles x 7 filter rows, K = 8 taps x 4 channels),
+// keeps per-channel sum / sum of squares and the running 3x3 window maxima in registers, and writes only the
+// pooled 32x32x64 tensor (raw, bf16), the window arg-max and, once the plane statistics are known, normalises
+// its own pooled values in place (L2 hits).  HBM traffic per image: 146 KB in, 128 + 64 KB out, instead of
+// 146 KB in + 3 x 512 KB for the unfused conv / stats / pool sequence.
+//
+// Input rows are staged by LDS-DMA into a per-wave 12-row ring two output rows ahead (no barriers: the ring is
+// private to the wave, a counted s_waitcnt is the only synchronisation); the 28 KB filter bank is shared by the
+// block's 8 waves.
+#include <stdlib.h>
+
+#include "common.h"
+#include "lds_dma.h"
+
+namespace eve {
+
+constexpr int SF_ROWB = 1280;                    // bytes staged per input row: padded pixels 1..160
+constexpr int SF_RING = 12;                      // rows per wave: 7 live + 2 x 2 in flight (+1 spare)
+constexpr int SF_WAVES = 8;
+constexpr int SF_WBYTES = 7 * 4096;              // filter bank: 7 filter rows x 64 channels x 64 B
+constexpr int SF_XROW = 136 * 8;                 // bytes per packed input row ([IW + 8] pixels x 4 channels bf16)
+constexpr int SF_KBYTES = 64 * 3 * 4;               // backward: {rstd, B, C} per channel and wave
+constexpr uint32_t SF_NEG = 0xff61b1e0u;         // -3.0e38 with the four key bits clear
+
+__device__ __forceinline__ void sf_dma16(const eve_int4& rsrc, uint32_t lds, int voff, int soff) {
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "s"(lds), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+}
+__device__ __forceinline__ void sf_dma4(const eve_int4& rsrc, uint32_t lds, int voff, int soff) {
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dword %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "s"(lds), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+}
+typedef uint32_t sf_u32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ bf16x8_t sf_lds_read(uint32_t addr) {
+    return __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const EVE_LDS sf_u32x4_t*>((uintptr_t)addr));
+}
+template <int CTRL>
+__device__ __forceinline__ uint32_t sf_dpp(uint32_t old, uint32_t src) {
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)src, CTRL, 0xf, 0xf, false);
+}
+__device__ __forceinline__ float sf_row_sum16(float v) {          // butterfly over the 16 lanes of a DPP row
+    v += __builtin_bit_cast(float, sf_dpp<0xb1>(0u, __builtin_bit_cast(uint32_t, v)));     // quad_perm [1,0,3,2]
+    v += __builtin_bit_cast(float, sf_dpp<0x4e>(0u, __builtin_bit_cast(uint32_t, v)));     // quad_perm [2,3,0,1]
+    v += __builtin_bit_cast(float, sf_dpp<0x141>(0u, __builtin_bit_cast(uint32_t, v)));    // row_half_mirror
+    v += __builtin_bit_cast(float, sf_dpp<0x140>(0u, __builtin_bit_cast(uint32_t, v)));    // row_mirror
+    return v;
+}
+__device__ __forceinline__ float sf_fmax3(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
+
+// Filter bank fill shared by the forward and backward kernels.  LDS row c_lds = nt*16 + 4*g + r holds output
+// channel co = g*16 + nt*4 + r, so that an MFMA lane (rows 4g..4g+3 of tiles nt = 0..3) owns the 16 CONSECUTIVE
+// channels g*16 .. g*16+15 of its pixel: 32-byte stores instead of four 8-byte ones.  64-byte rows, chunk-swizzled
+// like the halo kernel (conflict-free ds_read_b128).
+__device__ __forceinline__ void sf_fill_weights(char* sW, const bf16_t* __restrict__ w8, int tid, int nthreads) {
+    for (int e = tid; e < 64 * 7 * 8; e += nthreads) {
+        const int kw = e & 7, kh = (e >> 3) % 7, co = e / 56;
+        uint2 v = make_uint2(0u, 0u);
+        if (kw < 7) v = *reinterpret_cast<const uint2*>(w8 + ((co * 7 + kh) * 7 + kw) * 8);   // channels 0..3
+        const int c_lds = ((co >> 2) & 3) * 16 + (co >> 4) * 4 + (co & 3);
+        const int chunk = (kw >> 1) ^ (((c_lds >> 2) & 1) << 1);
+        *reinterpret_cast<uint2*>(sW + kh * 4096 + c_lds * 64 + chunk * 16 + (kw & 1) * 8) = v;
+    }
+}
+
+// One output row of the convolution for the wave's image: acc[mt][nt] (mt = 2j + b holds output column
+// 2*(li + 16j) + b, so a lane owns the even/odd column pair of pooled column q = li + 16j).
+__device__ __forceinline__ void sf_conv_tap_row(f32x4_t (&acc)[4][4], uint32_t ring, int slot0, uint32_t xoff,
+                                                uint32_t wbase, int kh) {
+    int slot = slot0 + kh;
+    slot = slot >= SF_RING ? slot - SF_RING : slot;
+    const uint32_t xa = ring + slot * SF_ROWB + xoff, wa = wbase + kh * 4096;
+    bf16x8_t fx[4], fw[4];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) fx[mt] = sf_lds_read(xa + (mt & 1) * 16 + (mt >> 1) * 512);
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) fw[nt] = sf_lds_read(wa + nt * 1024);
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[nt], fx[mt], acc[mt][nt], 0, 0, 0);
+}
+// COMPACT keeps the filter-row loop rolled (one set of fragment registers) for the register-hungry backward
+template <bool COMPACT>
+__device__ __forceinline__ void sf_conv_row(f32x4_t (&acc)[4][4], uint32_t ring, int slot0, uint32_t xoff,
+                                            uint32_t wbase) {
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    if (COMPACT) {
+#pragma unroll 1
+        for (int kh = 0; kh < 7; ++kh) sf_conv_tap_row(acc, ring, slot0, xoff, wbase, kh);
+    } else {
+#pragma unroll
+        for (int kh = 0; kh < 7; ++kh) sf_conv_tap_row(acc, ring, slot0, xoff, wbase, kh);
+    }
+}
+
+// stage padded input row `row` of the image at byte offset img_off into its ring slot (rows past the image: zeros)
+__device__ __forceinline__ void sf_stage_row(const eve_int4& rs, uint32_t ring, int row, int rows, int img_off, int lane) {
+    const int slot = row % SF_RING;
+    const bool live = row < rows;
+    const int soff = live ? img_off + row * SF_XROW : 0;
+    sf_dma16(rs, ring + slot * SF_ROWB, live ? lane * 16 + 8 : EVE_OOB, soff);
+    sf_dma4(rs, ring + slot * SF_ROWB + 1024, live ? lane * 4 + 8 + 1024 : EVE_OOB, soff);
+}
+
+__global__ __launch_bounds__(64 * SF_WAVES) void stem_fwd_fused_kernel(const int N, const int IH,
+                                                                       const bf16_t* __restrict__ xp, const uint32_t xp_bytes,
+                                                                       const bf16_t* __restrict__ w8, const float eps,
+                                                                       bf16_t* yp, uint8_t* __restrict__ idx,
+                                                                       float* __restrict__ mr) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const sW = smem + SF_WAVES * SF_RING * SF_ROWB;
+    const int tid = threadIdx.x;
+    sf_fill_weights(sW, w8, tid, 64 * SF_WAVES);
+    __syncthreads();
+
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, lg = lane >> 4;
+    const int OH = IH / 2, PH = OH / 2, rows = IH + 6;
+    const uint32_t ring = lds_addr_of(smem) + wave * (SF_RING * SF_ROWB);
+    const uint32_t xoff = 16 * (2 * li + lg);
+    const uint32_t wbase = lds_addr_of(sW) + li * 64 + ((lg ^ (((li >> 2) & 1) << 1)) << 4);
+    const eve_int4 rs = make_rsrc_words(xp, xp_bytes);
+    const float inv_hw = 1.f / (float)(OH * 64);
+
+    for (int n = blockIdx.x * SF_WAVES + wave; n < N; n += gridDim.x * SF_WAVES) {
+        const int img_off = n * rows * SF_XROW;
+        for (int r = 0; r < 9; ++r) sf_stage_row(rs, ring, r, rows, img_off, lane);
+        float S[4][4], Q[4][4];
+        uint32_t M[2][4][4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) { S[a][b] = 0.f; Q[a][b] = 0.f; M[0][a][b] = SF_NEG; M[1][a][b] = SF_NEG; }
+        bf16_t* yimg = yp + (size_t)n * PH * 32 * 64;
+        uint8_t* iimg = idx + (size_t)n * PH * 32 * 64;
+        int slot0 = 0;
+        for (int oy = 0; oy < OH; ++oy) {
+            // rows 2oy .. 2oy+6 were issued two iterations ago; younger: 4 DMAs + at most 6 stores (see header)
+            if (oy < 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            sf_stage_row(rs, ring, 2 * oy + 9, rows, img_off, lane);
+            sf_stage_row(rs, ring, 2 * oy + 10, rows, img_off, lane);
+            f32x4_t acc[4][4];
+            sf_conv_row<false>(acc, ring, slot0, xoff, wbase);
+            slot0 = slot0 + 2 >= SF_RING ? slot0 + 2 - SF_RING : slot0 + 2;
+            // ---- plane statistics ----
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float s = 0.f, q = 0.f;
+#pragma unroll
+                    for (int mt = 0; mt < 4; ++mt) { const float v = acc[mt][nt][r]; s += v; q += v * v; }
+                    S[nt][r] += s; Q[nt][r] += q;
+                }
+            // ---- 3x3/2 max-pool on keys = value bits with the low 4 mantissa bits replaced by the window position ----
+            const bool odd = oy & 1;
+            const uint32_t khbits = odd ? 0u : 4u;                 // filter row 2 (odd rows) or 1 (even rows) of the window
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    uint32_t carry = 0;
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        // (copy the vector elements first: __builtin_bit_cast on an element lvalue reads element 0)
+                        const float ef = acc[2 * j][nt][r], of = acc[2 * j + 1][nt][r];
+                        const uint32_t e = __builtin_bit_cast(uint32_t, ef) & 0xfffffff0u;
+                        const uint32_t o = __builtin_bit_cast(uint32_t, of) & 0xfffffff0u;
+                        // column 2q-1 = the odd column of lane li-1 (lane 0: the last lane of the previous tile / padding)
+                        const uint32_t edge = j == 0 ? SF_NEG : sf_dpp<0x121>(0u, carry);          // row_ror:1
+                        const uint32_t l = sf_dpp<0x111>(edge, o | 2u);                              // row_shr:1
+                        carry = o | 2u;
+                        const float h = sf_fmax3(__builtin_bit_cast(float, l), __builtin_bit_cast(float, e | 1u),
+                                                 __builtin_bit_cast(float, o));
+                        const uint32_t hb = __builtin_bit_cast(uint32_t, h);
+                        const float m = fmaxf(__builtin_bit_cast(float, M[j][nt][r]), __builtin_bit_cast(float, hb | khbits));
+                        M[j][nt][r] = odd ? (hb | 8u) : __builtin_bit_cast(uint32_t, m);            // odd row: carry = filter row 0
+                        acc[2 * j][nt][r] = m;                                                      // window result (odd rows)
+                    }
+                }
+            if (odd) {
+                const int py = oy >> 1;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const size_t o = ((size_t)py * 32 + li + 16 * j) * 64 + lg * 16;
+                    uint32_t pk[8], ib[4];
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt) {
+                        uint32_t code[4];
+                        float val[4];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float kf = acc[2 * j][nt][r];
+                            const uint32_t k = __builtin_bit_cast(uint32_t, kf);
+                            val[r] = __builtin_bit_cast(float, k & 0xfffffff0u);
+                            code[r] = (uint32_t)(0x01203450678ull >> ((k & 15u) * 4)) & 15u;       // kh*3 + kw
+                        }
+                        pk[2 * nt] = pack2_bf16(val[0], val[1]);
+                        pk[2 * nt + 1] = pack2_bf16(val[2], val[3]);
+                        ib[nt] = code[0] | (code[1] << 8) | (code[2] << 16) | (code[3] << 24);
+                    }
+                    *reinterpret_cast<uint4*>(yimg + o) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+                    *reinterpret_cast<uint4*>(yimg + o + 8) = make_uint4(pk[4], pk[5], pk[6], pk[7]);
+                    *reinterpret_cast<uint4*>(iimg + o) = make_uint4(ib[0], ib[1], ib[2], ib[3]);
+                }
+            }
+        }
+        // ---- plane statistics -> mean / rstd of the lane's 16 channels ----
+        float mean[4][4], rstd[4][4];
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float s = sf_row_sum16(S[nt][r]) * inv_hw, q = sf_row_sum16(Q[nt][r]) * inv_hw;
+                const float var = fmaxf(q - s * s, 0.f);
+                mean[nt][r] = s;
+                rstd[nt][r] = rsqrtf(var + eps);
+                if (li == 0) {
+                    float* m = mr + ((size_t)n * 64 + lg * 16 + nt * 4 + r) * 2;
+                    m[0] = s; m[1] = rstd[nt][r];
+                }
+            }
+        // ---- normalise the lane's own pooled values in place: y = relu((max - mean) * rstd) ----
+        for (int py = 0; py < PH; ++py)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                bf16_t* p = yimg + ((size_t)py * 32 + li + 16 * j) * 64 + lg * 16;
+                float f[16];
+                Elem<bf16_t>::unpack(*reinterpret_cast<const uint4*>(p), f);
+                Elem<bf16_t>::unpack(*reinterpret_cast<const uint4*>(p + 8), f + 8);
+#pragma unroll
+                for (int c = 0; c < 16; ++c) f[c] = fmaxf((f[c] - mean[c >> 2][c & 3]) * rstd[c >> 2][c & 3], 0.f);
+                *reinterpret_cast<uint4*>(p) = Elem<bf16_t>::pack(f);
+                *reinterpret_cast<uint4*>(p + 8) = Elem<bf16_t>::pack(f + 8);
+            }
+    }
+}
+
+// =================================================================================================
+// Backward of the fused stem up to the convolution output:  d(conv1 out) from d(pooled output).
+// The convolution output was never stored, so the wave recomputes it row by row exactly as the forward did
+// (same MFMA sequence, bit-identical values) and applies, per pixel,
+//     g  = sum over the (at most 4) pooling windows that contain the pixel, selected it as arg-max (idx) and
+//          survived the ReLU (y > 0) of d(pooled)
+//     dx = rstd * (g - mean(g) - xhat * mean(g * xhat)),   xhat = (x - mean) * rstd
+// with mean(g) = sum d*[y>0] / HW and mean(g*xhat) = sum d*y / HW taken over the POOLED tensors first
+// (y = xhat at the arg-max wherever y > 0).  Folded: dx = rstd*g + C - x*B,  B = rstd^2 * mean(g xhat),
+// C = mean*B - rstd*mean(g).
+// =================================================================================================
+struct SfPooledRow {               // one pooled row as the lane sees it: columns q = li + 16j, its 16 channels
+    uint32_t eg[2][8];             // d(pooled) where y > 0, else 0 (packed bf16 pairs)
+    uint32_t code[2][4];           // arg-max window positions, one byte per channel
+};
+
+__device__ __forceinline__ void sf_load_pooled(SfPooledRow& P, const bf16_t* __restrict__ dyp, const bf16_t* __restrict__ yp,
+                                               const uint8_t* __restrict__ idx, size_t row_base, int li, int lg, bool live) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const size_t o = (row_base + li + 16 * j) * 64 + lg * 16;
+        uint4 d0 = make_uint4(0, 0, 0, 0), d1 = d0, y0 = d0, y1 = d0, c = d0;
+        if (live) {
+            d0 = *reinterpret_cast<const uint4*>(dyp + o); d1 = *reinterpret_cast<const uint4*>(dyp + o + 8);
+            y0 = *reinterpret_cast<const uint4*>(yp + o);  y1 = *reinterpret_cast<const uint4*>(yp + o + 8);
+            c = *reinterpret_cast<const uint4*>(idx + o);
+        }
+        const uint32_t dd[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
+        const uint32_t yy[8] = {y0.x, y0.y, y0.z, y0.w, y1.x, y1.y, y1.z, y1.w};
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const uint32_t m = ((int)(yy[k] << 16) > 0 ? 0xffffu : 0u) | ((int)(yy[k] & 0xffff0000u) > 0 ? 0xffff0000u : 0u);
+            P.eg[j][k] = dd[k] & m;
+        }
+        P.code[j][0] = c.x; P.code[j][1] = c.y; P.code[j][2] = c.z; P.code[j][3] = c.w;
+    }
+}
+// d(pooled) of channel r (0..3) of a 4-channel chunk if the window's arg-max code equals K, else 0
+__device__ __forceinline__ float sf_pick(const uint32_t (&eg)[2], uint32_t code, int r, uint32_t K) {
+    const uint32_t w = eg[r >> 1];
+    const float t = __builtin_bit_cast(float, (r & 1) ? (w & 0xffff0000u) : (w << 16));
+    const int sh = 8 * r;
+    return (code & (0xffu << sh)) == (K << sh) ? t : 0.f;
+}
+// channels 4nt..4nt+3 of pooled column q = li + 16j, and of column q + 1 (lane li+1; lane 15 takes lane 0 of
+// the next tile, or nothing past the last column)
+__device__ __forceinline__ void sf_chunk(const SfPooledRow& P, int j, int nt, uint32_t (&eg)[2], uint32_t& cd,
+                                         uint32_t (&neg)[2], uint32_t& ncd) {
+    eg[0] = P.eg[j][2 * nt]; eg[1] = P.eg[j][2 * nt + 1]; cd = P.code[j][nt];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const uint32_t edge = j == 0 ? sf_dpp<0x12f>(0u, P.eg[1][2 * nt + k]) : 0u;    // row_ror:15 = rotate left by one
+        neg[k] = sf_dpp<0x101>(edge, eg[k]);                                            // row_shl:1
+    }
+    const uint32_t edge = j == 0 ? sf_dpp<0x12f>(0u, P.code[1][nt]) : 0u;
+    ncd = sf_dpp<0x101>(edge, cd);
+}
+
+__global__ __launch_bounds__(64 * SF_WAVES) void stem_bwd_dx_kernel(const int N, const int IH,
+                                                                    const bf16_t* __restrict__ xp, const uint32_t xp_bytes,
+                                                                    const bf16_t* __restrict__ w8, const float* __restrict__ mr,
+                                                                    const bf16_t* __restrict__ dyp, const bf16_t* __restrict__ yp,
+                                                                    const uint8_t* __restrict__ idx, bf16_t* __restrict__ dx) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const sW = smem + SF_WAVES * SF_RING * SF_ROWB;
+    const int tid = threadIdx.x;
+    sf_fill_weights(sW, w8, tid, 64 * SF_WAVES);
+    __syncthreads();
+
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, lg = lane >> 4;
+    const int OH = IH / 2, PH = OH / 2, rows = IH + 6;
+    const uint32_t ring = lds_addr_of(smem) + wave * (SF_RING * SF_ROWB);
+    const uint32_t xoff = 16 * (2 * li + lg);
+    const uint32_t wbase = lds_addr_of(sW) + li * 64 + ((lg ^ (((li >> 2) & 1) << 1)) << 4);
+    const eve_int4 rs = make_rsrc_words(xp, xp_bytes);
+    const float inv_hw = 1.f / (float)(OH * 64);
+    char* const sK = sW + SF_WBYTES + wave * SF_KBYTES;         // this wave's per-channel constants
+
+    for (int n = blockIdx.x * SF_WAVES + wave; n < N; n += gridDim.x * SF_WAVES) {
+        const int img_off = n * rows * SF_XROW;
+        for (int r = 0; r < 9; ++r) sf_stage_row(rs, ring, r, rows, img_off, lane);
+        const size_t pool_base = (size_t)n * PH * 32;
+        // ---- phase A: the two plane sums, over the pooled tensors; the folded per-channel constants go to LDS ----
+        {
+            float s1[16], s2[16];
+#pragma unroll
+            for (int c = 0; c < 16; ++c) { s1[c] = 0.f; s2[c] = 0.f; }
+            for (int py = 0; py < PH; ++py)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const size_t o = (pool_base + (size_t)py * 32 + li + 16 * j) * 64 + lg * 16;
+                    float d[16], y[16];
+                    Elem<bf16_t>::unpack(*reinterpret_cast<const uint4*>(dyp + o), d);
+                    Elem<bf16_t>::unpack(*reinterpret_cast<const uint4*>(dyp + o + 8), d + 8);
+                    Elem<bf16_t>::unpack(*reinterpret_cast<const uint4*>(yp + o), y);
+                    Elem<bf16_t>::unpack(*reinterpret_cast<const uint4*>(yp + o + 8), y + 8);
+#pragma unroll
+                    for (int c = 0; c < 16; ++c) {
+                        const float g = y[c] > 0.f ? d[c] : 0.f;
+                        s1[c] += g; s2[c] += g * y[c];
+                    }
+                }
+            const float* m = mr + ((size_t)n * 64 + lg * 16) * 2;
+#pragma unroll
+            for (int c = 0; c < 16; ++c) {
+                const float a = sf_row_sum16(s1[c]) * inv_hw, b = sf_row_sum16(s2[c]) * inv_hw;
+                const float mean = m[2 * c], r = m[2 * c + 1];
+                const float B = r * r * b, C = mean * B - r * a;
+                if (li == 0) {                                   // [lg][nt][{rstd, B, C}][r]
+                    float* kc = reinterpret_cast<float*>(sK + ((lg * 4 + (c >> 2)) * 3) * 16) + (c & 3);
+                    kc[0] = r; kc[4] = B; kc[8] = C;
+                }
+            }
+        }
+        // ---- phase B: recompute the convolution row by row, emit d(conv out) ----
+        SfPooledRow P0, P1;
+        sf_load_pooled(P0, dyp, yp, idx, pool_base, li, lg, true);
+        bf16_t* dimg = dx + (size_t)n * OH * 64 * 64;
+        int slot0 = 0;
+        for (int py = 0; py < PH; ++py) {
+            sf_load_pooled(P1, dyp, yp, idx, pool_base + (size_t)(py + 1) * 32, li, lg, py + 1 < PH);
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                const int oy = 2 * py + half;
+                // rows 2oy..2oy+6 were issued two iterations ago; younger: >= 4 DMAs + 16 stores (+ pooled loads)
+                if (oy == 0)      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                else if (oy == 1) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+                else              asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
+                sf_stage_row(rs, ring, 2 * oy + 9, rows, img_off, lane);
+                sf_stage_row(rs, ring, 2 * oy + 10, rows, img_off, lane);
+                f32x4_t acc[4][4];
+                sf_conv_row<true>(acc, ring, slot0, xoff, wbase);
+                slot0 = slot0 + 2 >= SF_RING ? slot0 + 2 - SF_RING : slot0 + 2;
+                const uint32_t k0 = half ? 6u : 3u;             // window row of this conv row inside window py
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    uint32_t pe[8], po[8];                       // even / odd column of pooled column q, packed pairs
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt) {             // four channels at a time keeps the live set small
+                        const f32x4_t kr = *reinterpret_cast<const f32x4_t*>(sK + ((lg * 4 + nt) * 3) * 16);
+                        const f32x4_t kB = *reinterpret_cast<const f32x4_t*>(sK + ((lg * 4 + nt) * 3 + 1) * 16);
+                        const f32x4_t kC = *reinterpret_cast<const f32x4_t*>(sK + ((lg * 4 + nt) * 3 + 2) * 16);
+                        uint32_t eg0[2], cd0, ng0[2], nc0, eg1[2], cd1, ng1[2], nc1;
+                        sf_chunk(P0, j, nt, eg0, cd0, ng0, nc0);
+                        if (half) sf_chunk(P1, j, nt, eg1, cd1, ng1, nc1);
+                        float de[4], dd[4];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            // even column 2q: centre column (kw = 1) of window q only
+                            float ge = sf_pick(eg0, cd0, r, k0 + 1u);
+                            // odd column 2q+1: right column (kw = 2) of window q, left column (kw = 0) of window q+1
+                            float go = sf_pick(eg0, cd0, r, k0 + 2u) + sf_pick(ng0, nc0, r, k0);
+                            if (half) {                          // odd conv row: also the top row (kh = 0) of window py+1
+                                ge += sf_pick(eg1, cd1, r, 1u);
+                                go += sf_pick(eg1, cd1, r, 2u) + sf_pick(ng1, nc1, r, 0u);
+                            }
+                            const float xe = acc[2 * j][nt][r], xo = acc[2 * j + 1][nt][r];
+                            de[r] = fmaf(-xe, kB[r], fmaf(kr[r], ge, kC[r]));
+                            dd[r] = fmaf(-xo, kB[r], fmaf(kr[r], go, kC[r]));
+                        }
+                        pe[2 * nt] = pack2_bf16(de[0], de[1]); pe[2 * nt + 1] = pack2_bf16(de[2], de[3]);
+                        po[2 * nt] = pack2_bf16(dd[0], dd[1]); po[2 * nt + 1] = pack2_bf16(dd[2], dd[3]);
+                    }
+                    bf16_t* o = dimg + ((size_t)oy * 64 + 2 * (li + 16 * j)) * 64 + lg * 16;
+                    *reinterpret_cast<uint4*>(o) = make_uint4(pe[0], pe[1], pe[2], pe[3]);
+                    *reinterpret_cast<uint4*>(o + 8) = make_uint4(pe[4], pe[5], pe[6], pe[7]);
+                    *reinterpret_cast<uint4*>(o + 64) = make_uint4(po[0], po[1], po[2], po[3]);
+                    *reinterpret_cast<uint4*>(o + 72) = make_uint4(po[4], po[5], po[6], po[7]);
+                }
+            }
+            P0 = P1;
+        }
+    }
+}
+
+}  // namespace eve
+
+using namespace eve;
+
+/* conv7x7/2 + InstanceNorm + ReLU + maxpool3x3/2 of the packed patches (eve_stem_pack_input layout).
+   y_pool [N][IH/4][32][64] bf16, idx uint8 same shape (window position kh*3+kw), mean_rstd [N][64][2]. */
+extern "C" int eve_stem_fwd_fused(int N, int IH, int IW, const void* x_padded, const void* w_ohwi8, float eps,
+                                  void* y_pool, uint8_t* idx, float* mean_rstd, eve_stream_t stream) {
+    if (N <= 0 || IH <= 0 || (IH & 3) || IW != 128 || !x_padded || !w_ohwi8 || !y_pool || !idx || !mean_rstd)
+        return set_error_msg("stem_fwd_fused: needs IW == 128 and IH a multiple of 4");
+    const unsigned long long xb = (unsigned long long)N * (IH + 6) * SF_XROW;
+    if (xb >= (1ull << 31)) return set_error_msg("stem_fwd_fused: packed input must stay below 2 GiB");
+    const size_t lds = (size_t)SF_WAVES * SF_RING * SF_ROWB + SF_WBYTES;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)stem_fwd_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    unsigned blocks = (unsigned)((N + SF_WAVES - 1) / SF_WAVES);
+    if (blocks > 256) blocks = 256;
+    hipLaunchKernelGGL(stem_fwd_fused_kernel, dim3(blocks), dim3(64 * SF_WAVES), lds, (hipStream_t)stream, N, IH,
+                       (const bf16_t*)x_padded, (uint32_t)xb, (const bf16_t*)w_ohwi8, eps, (bf16_t*)y_pool, idx, mean_rstd);
+    EVE_CHECK_LAUNCH();
+    return 0;
+}
+
+/* d(conv1 output) [N][IH/2][64][64] bf16 from d(y_pool): the backward of eve_stem_fwd_fused up to the convolution
+   output (the weight gradient then runs on it).  Recomputes the convolution from x_padded instead of reading it. */
+extern "C" int eve_stem_bwd_dx(int N, int IH, int IW, const void* x_padded, const void* w_ohwi8, const float* mean_rstd,
+                               const void* dy_pool, const void* y_pool, const uint8_t* idx, void* dx, eve_stream_t stream) {
+    if (N <= 0 || IH <= 0 || (IH & 3) || IW != 128 || !x_padded || !w_ohwi8 || !mean_rstd || !dy_pool || !y_pool || !idx || !dx)
+        return set_error_msg("stem_bwd_dx: needs IW == 128 and IH a multiple of 4");
+    const unsigned long long xb = (unsigned long long)N * (IH + 6) * SF_XROW;
+    if (xb >= (1ull << 31)) return set_error_msg("stem_bwd_dx: packed input must stay below 2 GiB");
+    const size_t lds = (size_t)SF_WAVES * SF_RING * SF_ROWB + SF_WBYTES + SF_WAVES * SF_KBYTES;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)stem_bwd_dx_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    unsigned blocks = (unsigned)((N + SF_WAVES - 1) / SF_WAVES);
+    if (blocks > 256) blocks = 256;
+    hipLaunchKernelGGL(stem_bwd_dx_kernel, dim3(blocks), dim3(64 * SF_WAVES), lds, (hipStream_t)stream, N, IH,
+                       (const bf16_t*)x_padded, (uint32_t)xb, (const bf16_t*)w_ohwi8, mean_rstd, (const bf16_t*)dy_pool,
+                       (const bf16_t*)y_pool, idx, (bf16_t*)dx);
+    EVE_CHECK_LAUNCH();
+    return 0;
+}

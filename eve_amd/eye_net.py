@@ -156,11 +156,15 @@ class EyeNet(nn.Module):
         """x: [N, H, W, Cpad] NHWC compute dtype -> [N, 512] float32 (torchvision ResNet._forward_impl).
         x_padded: optional [N, H+6, W+8, 4] bf16 repack for the dedicated stem kernel."""
         cnn = self.cnn_layers
-        if x_padded is not None:
-            y = ops.StemConvFn.apply(x, x_padded, cnn.conv1.weight, P['conv1'])
+        if x_padded is not None and x_padded.shape[2] == 136 and x_padded.shape[1] % 4 == 2:
+            # 128-wide patches: conv1 -> bn1 -> relu -> maxpool in one launch
+            y = ops.StemFusedFn.apply(x, x_padded, cnn.conv1.weight, P['conv1'], 1e-5)
         else:
-            y = ops.conv2d(x, cnn.conv1.weight, None, P['conv1'], stride=2, pad=3)
-        y = ops.InReluMaxPoolFn.apply(y, 1e-5)          # bn1 -> relu -> maxpool, fused
+            if x_padded is not None:
+                y = ops.StemConvFn.apply(x, x_padded, cnn.conv1.weight, P['conv1'])
+            else:
+                y = ops.conv2d(x, cnn.conv1.weight, None, P['conv1'], stride=2, pad=3)
+            y = ops.InReluMaxPoolFn.apply(y, 1e-5)      # bn1 -> relu -> maxpool, fused
         for name, blk in cnn.blocks():
             out = ops.conv2d(y, blk.conv1.weight, None, P[name + '.conv1'], stride=blk.stride, pad=1)
             out = ops.instnorm_act(out, act=ACT_RELU)

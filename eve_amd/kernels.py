@@ -176,6 +176,30 @@ class HipKernels(object):
             N, IH, IW, self._p(x_padded), self._p(w_ohwi8), self._p(y), self._stream())))
         return y
 
+    def stem_fwd_fused(self, x_padded, w_ohwi8, eps=1e-5):
+        N, Hp, Wp, four = x_padded.shape
+        IH, IW = Hp - 6, Wp - 8
+        assert four == 4 and tuple(w_ohwi8.shape) == (64, 7, 7, 8) and w_ohwi8.dtype == torch.bfloat16
+        y = torch.empty((N, IH // 4, IW // 4, 64), dtype=torch.bfloat16, device=x_padded.device)
+        idx = torch.empty((N, IH // 4, IW // 4, 64), dtype=torch.uint8, device=x_padded.device)
+        mr = torch.empty((N, 64, 2), dtype=torch.float32, device=x_padded.device)
+        flops = 2.0 * N * (IH // 2) * (IW // 2) * 64 * 147
+        self._timed('conv_fwd', flops, lambda: self._ck(self.lib.eve_stem_fwd_fused(
+            N, IH, IW, self._p(x_padded), self._p(w_ohwi8), eps, self._p(y), self._p(idx), self._p(mr),
+            self._stream())))
+        return y, idx, mr
+
+    def stem_bwd_dx(self, x_padded, w_ohwi8, mr, dy_pool, y_pool, idx):
+        N, Hp, Wp, _ = x_padded.shape
+        IH, IW = Hp - 6, Wp - 8
+        dx = torch.empty((N, IH // 2, IW // 2, 64), dtype=torch.bfloat16, device=x_padded.device)
+        assert dy_pool.dtype == torch.bfloat16 and dy_pool.is_contiguous() and dy_pool.shape == y_pool.shape == idx.shape
+        flops = 2.0 * N * (IH // 2) * (IW // 2) * 64 * 147
+        self._timed('conv_fwd', flops, lambda: self._ck(self.lib.eve_stem_bwd_dx(
+            N, IH, IW, self._p(x_padded), self._p(w_ohwi8), self._p(self._f32(mr, 'mean_rstd')), self._p(dy_pool),
+            self._p(y_pool), self._p(idx), self._p(dx), self._stream())))
+        return dx
+
     def bias_grad(self, dy, db):
         C = dy.shape[-1]
         M = dy.numel() // C

@@ -136,6 +136,31 @@ class StemConvFn(torch.autograd.Function):
         return None, None, dwp[:O, :, :, :I].permute(0, 3, 1, 2), None
 
 
+class StemFusedFn(torch.autograd.Function):
+    """conv1 -> bn1 (InstanceNorm2d, no affine) -> relu -> maxpool of the ResNet stem (eye_net.py:48-50,106)
+    in one launch; the 64-channel convolution output is never stored.  Backward recomputes it to form
+    d(conv out) and hands that to the weight-gradient kernel.  x8 / x_padded as in StemConvFn."""
+
+    @staticmethod
+    def forward(ctx, x8, x_padded, weight, pack, eps):
+        y, idx, mr = default_kernels().stem_fwd_fused(x_padded, pack.ohwi, eps)
+        ctx.pack = pack
+        ctx.save_for_backward(x8, x_padded, y, idx, mr)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        k = default_kernels()
+        x8, x_padded, y, idx, mr = ctx.saved_tensors
+        pack = ctx.pack
+        dconv = k.stem_bwd_dx(x_padded, pack.ohwi, mr, dy.contiguous(), y, idx)
+        cout_p, KH, KW, cin_p = pack.ohwi.shape
+        dwp = torch.zeros((cout_p, KH, KW, cin_p), dtype=torch.float32, device=x8.device)
+        k.conv2d_wgrad(x8, dconv, KH, KW, 2, 3, dwp, algo=pack.algo)
+        O, I = pack.shape_oihw[0], pack.shape_oihw[1]
+        return None, None, dwp[:O, :, :, :I].permute(0, 3, 1, 2), None, None
+
+
 def conv2d(x, weight, bias, pack, stride=1, pad=0, act=ACT_NONE):
     return Conv2dFn.apply(x, weight, bias, pack, stride, pad, act)
 

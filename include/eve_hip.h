@@ -77,6 +77,16 @@ int eve_stem_pack_input(int N, int C, int IH, int IW, const float* src_nchw, voi
                         eve_stream_t stream);
 int eve_stem7x7s2_fwd(int N, int IH, int IW, const void* x_padded, const void* w_ohwi8, void* y,
                       eve_stream_t stream);
+/* The whole stem in one launch: conv1 -> bn1 (InstanceNorm2d, no affine) -> relu -> maxpool 3x3/2 pad 1
+ * (torchvision ResNet._forward_impl as built by eye_net.py:48-50).  The 64-channel convolution output is never
+ * written: y_pool [N][IH/4][IW/4][64] bf16, idx (window position kh*3+kw of the arg-max, same shape, uint8) and
+ * mean_rstd [N][64][2] are the only outputs.  IW == 128, IH a multiple of 4.                              */
+int eve_stem_fwd_fused(int N, int IH, int IW, const void* x_padded, const void* w_ohwi8, float eps,
+                       void* y_pool, uint8_t* idx, float* mean_rstd, eve_stream_t stream);
+/* Its backward up to the convolution output: dx [N][IH/2][IW/2][64] bf16 = d(conv1 out) from dy_pool, recomputing
+ * the convolution from x_padded (autograd of bn1/relu/maxpool in eye_net.py:106); feed dx to eve_conv2d_wgrad. */
+int eve_stem_bwd_dx(int N, int IH, int IW, const void* x_padded, const void* w_ohwi8, const float* mean_rstd,
+                    const void* dy_pool, const void* y_pool, const uint8_t* idx, void* dx, eve_stream_t stream);
 /* db[C] (float, accumulated) += sum over the M = N*OH*OW rows of dy[M][C]                         */
 int eve_bias_grad(int dtype, long long M, int C, const void* dy, float* db, eve_stream_t stream);
 

@@ -79,6 +79,15 @@ class FakeKernels(object):
         w = w_ohwi8[..., :4].float().permute(0, 3, 1, 2)
         return nhwc(F.conv2d(x, w, None, 2, 3), torch.bfloat16)
 
+    def stem_fwd_fused(self, x_padded, w_ohwi8, eps=1e-5):
+        conv = self.stem7x7s2_fwd(x_padded, w_ohwi8)
+        mr = self.instnorm_stats(conv, eps)
+        y, idx = self.in_relu_maxpool_fwd(conv, mr)
+        return y, idx, mr
+
+    def stem_bwd_dx(self, x_padded, w_ohwi8, mr, dy_pool, y_pool, idx):
+        return self.in_relu_maxpool_bwd(dy_pool, y_pool, idx, self.stem7x7s2_fwd(x_padded, w_ohwi8), mr)
+
     def bias_grad(self, dy, db):
         db += dy.float().reshape(-1, dy.shape[-1]).sum(0)
         return db

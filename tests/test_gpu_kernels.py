@@ -142,6 +142,53 @@ def test_stem_conv_dedicated_kernel(hip, ref):
     close(hip.stem7x7s2_fwd(xp_g, dev(w)), hip.conv2d_fwd(x8, dev(w), None, 2, 3), torch.bfloat16, 'stem vs generic')
 
 
+@pytest.mark.parametrize('N', [3, 19])
+def test_stem_fused_forward_matches_unfused(hip, N):
+    """conv1 -> IN -> ReLU -> maxpool in one launch == the three-kernel path (which the oracle tests pin)."""
+    src = rnd((N, 3, 128, 128), torch.float32, 62) + 0.3
+    w = rnd((64, 7, 7, 8), torch.bfloat16, 63, scale=0.08)
+    w[..., 3:] = 0
+    xp = hip.stem_pack_input(dev(src))
+    y_f, idx_f, mr_f = hip.stem_fwd_fused(xp, dev(w))
+    conv = hip.stem7x7s2_fwd(xp, dev(w))
+    mr_u = hip.instnorm_stats(conv, 1e-5)
+    y_u, idx_u = hip.in_relu_maxpool_fwd(conv, mr_u)
+    # statistics: the fused kernel sums the fp32 accumulators, the unfused path the bf16-rounded conv output
+    assert (mr_f[..., 0] - mr_u[..., 0]).abs().max().item() < 2e-3
+    assert ((mr_f[..., 1] - mr_u[..., 1]).abs() / mr_u[..., 1]).max().item() < 2e-3
+    d = (y_f.float() - y_u.float()).abs()
+    assert d.max().item() < 0.06 and d.mean().item() < 2e-3, (d.max().item(), d.mean().item())
+    # the arg-max may differ only where two window candidates tie after bf16 rounding of the unfused conv output
+    assert (idx_f != idx_u).float().mean().item() < 0.02
+    assert int(idx_f.max()) <= 8
+    # exact semantics against an fp32 reference built from the SAME statistics and the fp32 conv
+    x32 = torch.nn.functional.conv2d(xp.float().permute(0, 3, 1, 2)[:, :, :, 1:], w.float().permute(0, 3, 1, 2)[:, :4].to('cuda'),
+                                     stride=2)                      # padded input: rows 0.., columns 1..
+    x32 = x32[:, :, :64, :64]
+    z = torch.relu((x32 - mr_f[:, :, 0, None, None]) * mr_f[:, :, 1, None, None])
+    ref_y = torch.nn.functional.max_pool2d(z, 3, 2, 1).permute(0, 2, 3, 1)
+    d = (y_f.float() - ref_y).abs()
+    assert d.max().item() < 0.05 and d.mean().item() < 4e-3, (d.max().item(), d.mean().item())
+
+
+@pytest.mark.parametrize('N', [2, 17])
+def test_stem_fused_backward_matches_unfused(hip, N):
+    """d(conv1 out) by recomputation == the dense IN+ReLU+maxpool backward on the stored conv output."""
+    src = rnd((N, 3, 128, 128), torch.float32, 64) + 0.2
+    w = rnd((64, 7, 7, 8), torch.bfloat16, 65, scale=0.08)
+    w[..., 3:] = 0
+    xp = hip.stem_pack_input(dev(src))
+    y, idx, mr = hip.stem_fwd_fused(xp, dev(w))
+    dy = dev(rnd(tuple(y.shape), torch.bfloat16, 66))
+    dx_f = hip.stem_bwd_dx(xp, dev(w), mr, dy, y, idx)
+    conv = hip.stem7x7s2_fwd(xp, dev(w))
+    dx_u = hip.in_relu_maxpool_bwd(dy, y, idx, conv, mr)
+    a, b = dx_f.float(), dx_u.float()
+    rel = ((a - b).norm() / b.norm()).item()
+    assert rel < 6e-3, rel                       # the unfused path sees the bf16-rounded conv output
+    assert (a - b).abs().max().item() < 0.05 * b.abs().max().item()
+
+
 def test_conv_rejects_bad_shapes(hip):
     x = torch.zeros((1, 8, 8, 6), device='cuda')
     w = torch.zeros((8, 3, 3, 6), device='cuda')
