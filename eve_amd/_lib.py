@@ -25,17 +25,18 @@ F = c_float
 SIGNATURES = {
     'eve_conv2d_fwd': [POINTER(ConvDesc), P, P, P, I, P, I, P, P],
     'eve_conv2d_dgrad': [POINTER(ConvDesc), P, P, P, P],
+    'eve_conv2d_dgrad_acc': [POINTER(ConvDesc), P, P, P, P],
     'eve_conv2d_wgrad': [POINTER(ConvDesc), P, P, P, I, P, P],
     'eve_stem_pack_input': [I, I, I, I, P, P, P],
     'eve_stem7x7s2_fwd': [I, I, I, P, P, P, P],
     'eve_stem_fwd_fused': [I, I, I, P, P, F, P, P, P, P],
-    'eve_stem_bwd_dx': [I, I, I, P, P, P, P, P, P, P, P],
+    'eve_stem_bwd_dx': [I, I, I, P, P, P, P, P, P, P, P, P],
     'eve_bias_grad': [I, L, I, P, P, P],
     'eve_instnorm_stats': [I, I, I, I, P, F, P, P],
     'eve_instnorm_act_fwd': [I, I, I, I, P, P, P, P, P, I, P, P],
     'eve_instnorm_act_bwd': [I, I, I, I, P, P, P, P, P, I, P, P, P, P],
     'eve_instnorm_fwd_fused': [I, I, I, I, P, P, P, P, I, F, P, P, P],
-    'eve_instnorm_bwd_fused': [I, I, I, I, P, P, P, P, P, I, P, P, P, P],
+    'eve_instnorm_bwd_fused': [I, I, I, I, P, P, P, P, P, P, I, P, P, P, P],
     'eve_act_bwd': [I, L, P, P, I, P, P],
     'eve_add': [I, L, P, P, P, P],
     'eve_maxpool3x3s2_fwd': [I, I, I, I, I, P, P, P, P],

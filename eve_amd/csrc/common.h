@@ -86,9 +86,13 @@ __device__ __forceinline__ float act_fwd(float z, int act) {
 // switch costs more scalar branches than the epilogue has vector work and bloats the kernel past the
 // instruction cache, so the kernels run the whole epilogue as one of two bodies: FAST (identity / ReLU, the
 // ResNet trunk) or the general one.
-__device__ __forceinline__ bool act_is_fast(int act) { return act == EVE_ACT_NONE || act == EVE_ACT_RELU; }
+// bit 8 of the epilogue word: out += result (the data gradient of a residual branch lands on the gradient the
+// other branch already wrote)
+#define EVE_EPI_ACC 0x100
+__device__ __forceinline__ bool act_is_fast(int act) { return (act & 0xff) == EVE_ACT_NONE || (act & 0xff) == EVE_ACT_RELU; }
 template <bool FAST>
 __device__ __forceinline__ void act_fwd4(float* o, int act) {
+    act &= 0xff;
     if (FAST) {
         if (act == EVE_ACT_RELU) {
 #pragma unroll

@@ -188,6 +188,11 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_dma_kernel(const GatherPar
                     opix = ((size_t)n * tp.OHf + oy * tp.osy + tp.oy0) * tp.OWf + ox * tp.osx + tp.ox0;
                 }
                 T* dst = out + opix * p.Cout + co;
+                if (epi_act & EVE_EPI_ACC) {
+    #pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (co + r < (uint32_t)p.Cout) o[r] += Elem<T>::ld(dst + r);
+                }
                 if (vec_ok) {
                     if (sizeof(T) == 4) {
                         *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
@@ -652,6 +657,11 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const HaloParams p, c
                 for (int r = 0; r < 4; ++r) o[r] = acc[mt][nt][r] + bv[r];
                 act_fwd4<decltype(fast)::value>(o, epi_act);
                 bf16_t* dst = out + ((size_t)(n * p.H + y) * p.W + tx) * p.Cout + co;
+                if (epi_act & EVE_EPI_ACC) {
+                    const uint2 old = *reinterpret_cast<const uint2*>(dst);
+                    o[0] += bf16_bits_to_f32(old.x & 0xffffu); o[1] += __builtin_bit_cast(float, old.x & 0xffff0000u);
+                    o[2] += bf16_bits_to_f32(old.y & 0xffffu); o[3] += __builtin_bit_cast(float, old.y & 0xffff0000u);
+                }
                 uint2 pk;
                 pk.x = pack2_bf16(o[0], o[1]);
                 pk.y = pack2_bf16(o[2], o[3]);

@@ -226,6 +226,11 @@ __global__ __launch_bounds__(256) void igemm_kernel(const GatherParams p, const 
                 for (int r = 0; r < 4; ++r) o[r] = acc[mt][nt][r] + bv[r];
                 act_fwd4<decltype(fast)::value>(o, epi_act);
                 T* dst = out + (size_t)m * p.Cout + co;
+                if (epi_act & EVE_EPI_ACC) {
+    #pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (co + r < (uint32_t)p.Cout) o[r] += Elem<T>::ld(dst + r);
+                }
                 if (vec_ok) {
                     if (sizeof(T) == 4) {
                         *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
@@ -585,7 +590,7 @@ static bool launch_igemm_dma(const GatherParams& p, const void* src, const void*
     }
     // data gradient of a stride-`div` convolution (o_mul = 1, k_mul = -1, off = pad): output pixel iy = div*y' + py
     // takes tap kh iff (py + pad - kh) % div == 0, from source row y' + (py + pad - kh) / div
-    if (p.o_mul != 1 || p.k_mul != -1 || bias || epi_act != EVE_ACT_NONE) return false;
+    if (p.o_mul != 1 || p.k_mul != -1 || bias || (epi_act & 0xff) != EVE_ACT_NONE) return false;
     const int sd = p.div;
     bool need_zero = false;
     for (int pass = 0; pass < 2; ++pass) {
@@ -613,7 +618,7 @@ static bool launch_igemm_dma(const GatherParams& p, const void* src, const void*
                 tp.osy = tp.osx = sd; tp.oy0 = py; tp.ox0 = px; tp.OHf = p.OH; tp.OWf = p.OW;
                 launch_dma_one<T>(q, tp, src, w, bias, epi_act, out, (uint32_t)src_bytes, (uint32_t)w_bytes, s);
             }
-        if (pass == 0 && need_zero)
+        if (pass == 0 && need_zero && !(epi_act & EVE_EPI_ACC))     // accumulating: untouched classes keep their value
             (void)hipMemsetAsync(out, 0, (size_t)p.N * p.OH * p.OW * p.Cout * sizeof(T), s);
     }
     return true;
@@ -729,6 +734,22 @@ extern "C" int eve_conv2d_dgrad(const eve_conv_desc* d, const void* dy, const vo
     hipStream_t s = (hipStream_t)stream;
     if (d->dtype == EVE_DT_BF16) launch_igemm<bf16_t>(p, dy, w_ihwo, nullptr, nullptr, 0, 0, dx, s);
     else                         launch_igemm<float>(p, dy, w_ihwo, nullptr, nullptr, 0, 0, dx, s);
+    EVE_CHECK_LAUNCH();
+    return 0;
+}
+
+/* dx += data gradient: the residual join of a ResNet block (autograd's add of the two branch gradients) fused
+   into the convolution's epilogue.  dx must already hold the other branch's gradient. */
+extern "C" int eve_conv2d_dgrad_acc(const eve_conv_desc* d, const void* dy, const void* w_ihwo, void* dx,
+                                    eve_stream_t stream) {
+    const int vec = (d && d->dtype == EVE_DT_BF16) ? 8 : 4;
+    if (int e = check_desc(d, vec)) return e;
+    if (d->Cout % vec) return set_error_msg("conv2d_dgrad_acc: Cout must be a multiple of the 16-byte vector");
+    if (!dy || !w_ihwo || !dx) return set_error_msg("conv2d_dgrad_acc: null pointer");
+    GatherParams p = dgrad_params(d);
+    hipStream_t s = (hipStream_t)stream;
+    if (d->dtype == EVE_DT_BF16) launch_igemm<bf16_t>(p, dy, w_ihwo, nullptr, nullptr, 0, EVE_EPI_ACC, dx, s);
+    else                         launch_igemm<float>(p, dy, w_ihwo, nullptr, nullptr, 0, EVE_EPI_ACC, dx, s);
     EVE_CHECK_LAUNCH();
     return 0;
 }

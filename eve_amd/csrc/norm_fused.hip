@@ -100,7 +100,8 @@ __global__ __launch_bounds__(1024) void in_fwd_fused_kernel(const T* __restrict_
 }
 
 template <typename T, int VPT, int ACT>
-__global__ __launch_bounds__(1024) void in_bwd_fused_kernel(const T* __restrict__ dy, const T* __restrict__ y,
+__global__ __launch_bounds__(1024) void in_bwd_fused_kernel(const T* __restrict__ dy, const T* __restrict__ dy2,
+                                                            const T* __restrict__ y,
                                                             const T* __restrict__ x, const float* __restrict__ mr,
                                                             const float* __restrict__ gamma, int act_rt,
                                                             T* __restrict__ dx, T* __restrict__ dres,
@@ -130,6 +131,12 @@ __global__ __launch_bounds__(1024) void in_bwd_fused_kernel(const T* __restrict_
         if (i < nvec) {
             float g[VEC], xx[VEC];
             Elem<T>::unpack(reinterpret_cast<const uint4*>(dy)[base + i], g);
+            if (dy2) {                  // the gradient arrives as two summands (residual fork): add on load
+                float g2[VEC];
+                Elem<T>::unpack(reinterpret_cast<const uint4*>(dy2)[base + i], g2);
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) g[e] += g2[e];
+            }
             qx[j] = reinterpret_cast<const uint4*>(x)[base + i];
             Elem<T>::unpack(qx[j], xx);
             if (act != EVE_ACT_NONE) {
@@ -235,7 +242,7 @@ extern "C" int eve_instnorm_fwd_fused(int dtype, int N, int HW, int C, const voi
     return 0;
 }
 
-extern "C" int eve_instnorm_bwd_fused(int dtype, int N, int HW, int C, const void* dy, const void* y, const void* x,
+extern "C" int eve_instnorm_bwd_fused(int dtype, int N, int HW, int C, const void* dy, const void* dy2, const void* y, const void* x,
                                       const float* mean_rstd, const float* gamma, int act, void* dx, void* dres,
                                       float* sums, eve_stream_t stream) {
     const int vec = dtype == EVE_DT_BF16 ? 8 : 4;
@@ -246,10 +253,10 @@ extern "C" int eve_instnorm_bwd_fused(int dtype, int N, int HW, int C, const voi
     if (!fused_plan(HW * (C / vec), C / vec, threads, vpt)) return -1;
     hipStream_t s = (hipStream_t)stream;
     if (dtype == EVE_DT_BF16) {
-        LAUNCH_VPT(in_bwd_fused_kernel, bf16_t, (const bf16_t*)dy, (const bf16_t*)y, (const bf16_t*)x, mean_rstd, gamma,
+        LAUNCH_VPT(in_bwd_fused_kernel, bf16_t, (const bf16_t*)dy, (const bf16_t*)dy2, (const bf16_t*)y, (const bf16_t*)x, mean_rstd, gamma,
                    act, (bf16_t*)dx, (bf16_t*)dres, sums, HW, C)
     } else {
-        LAUNCH_VPT(in_bwd_fused_kernel, float, (const float*)dy, (const float*)y, (const float*)x, mean_rstd, gamma,
+        LAUNCH_VPT(in_bwd_fused_kernel, float, (const float*)dy, (const float*)dy2, (const float*)y, (const float*)x, mean_rstd, gamma,
                    act, (float*)dx, (float*)dres, sums, HW, C)
     }
     EVE_CHECK_LAUNCH();

@@ -266,7 +266,12 @@ struct SfPooledRow {               // one pooled row as the lane sees it: column
     uint32_t code[2][4];           // arg-max window positions, one byte per channel
 };
 
-__device__ __forceinline__ void sf_load_pooled(SfPooledRow& P, const bf16_t* __restrict__ dyp, const bf16_t* __restrict__ yp,
+__device__ __forceinline__ uint32_t sf_add_pairs(uint32_t a, uint32_t b) {      // two packed bf16 sums
+    return pack2_bf16(bf16_bits_to_f32(a & 0xffffu) + bf16_bits_to_f32(b & 0xffffu),
+                      __builtin_bit_cast(float, a & 0xffff0000u) + __builtin_bit_cast(float, b & 0xffff0000u));
+}
+__device__ __forceinline__ void sf_load_pooled(SfPooledRow& P, const bf16_t* __restrict__ dyp, const bf16_t* __restrict__ dyp2,
+                                               const bf16_t* __restrict__ yp,
                                                const uint8_t* __restrict__ idx, size_t row_base, int li, int lg, bool live) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -276,6 +281,11 @@ __device__ __forceinline__ void sf_load_pooled(SfPooledRow& P, const bf16_t* __r
             d0 = *reinterpret_cast<const uint4*>(dyp + o); d1 = *reinterpret_cast<const uint4*>(dyp + o + 8);
             y0 = *reinterpret_cast<const uint4*>(yp + o);  y1 = *reinterpret_cast<const uint4*>(yp + o + 8);
             c = *reinterpret_cast<const uint4*>(idx + o);
+            if (dyp2) {                                            // gradient delivered as two summands
+                const uint4 e0 = *reinterpret_cast<const uint4*>(dyp2 + o), e1 = *reinterpret_cast<const uint4*>(dyp2 + o + 8);
+                d0 = make_uint4(sf_add_pairs(d0.x, e0.x), sf_add_pairs(d0.y, e0.y), sf_add_pairs(d0.z, e0.z), sf_add_pairs(d0.w, e0.w));
+                d1 = make_uint4(sf_add_pairs(d1.x, e1.x), sf_add_pairs(d1.y, e1.y), sf_add_pairs(d1.z, e1.z), sf_add_pairs(d1.w, e1.w));
+            }
         }
         const uint32_t dd[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
         const uint32_t yy[8] = {y0.x, y0.y, y0.z, y0.w, y1.x, y1.y, y1.z, y1.w};
@@ -311,7 +321,8 @@ __device__ __forceinline__ void sf_chunk(const SfPooledRow& P, int j, int nt, ui
 __global__ __launch_bounds__(64 * SF_WAVES) void stem_bwd_dx_kernel(const int N, const int IH,
                                                                     const bf16_t* __restrict__ xp, const uint32_t xp_bytes,
                                                                     const bf16_t* __restrict__ w8, const float* __restrict__ mr,
-                                                                    const bf16_t* __restrict__ dyp, const bf16_t* __restrict__ yp,
+                                                                    const bf16_t* __restrict__ dyp, const bf16_t* __restrict__ dyp2,
+                                                                    const bf16_t* __restrict__ yp,
                                                                     const uint8_t* __restrict__ idx, bf16_t* __restrict__ dx) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const sW = smem + SF_WAVES * SF_RING * SF_ROWB;
@@ -345,6 +356,13 @@ __global__ __launch_bounds__(64 * SF_WAVES) void stem_bwd_dx_kernel(const int N,
                     float d[16], y[16];
                     Elem<bf16_t>::unpack(*reinterpret_cast<const uint4*>(dyp + o), d);
                     Elem<bf16_t>::unpack(*reinterpret_cast<const uint4*>(dyp + o + 8), d + 8);
+                    if (dyp2) {                                   // same rounding of the sum as sf_load_pooled
+                        float d2[16];
+                        Elem<bf16_t>::unpack(*reinterpret_cast<const uint4*>(dyp2 + o), d2);
+                        Elem<bf16_t>::unpack(*reinterpret_cast<const uint4*>(dyp2 + o + 8), d2 + 8);
+#pragma unroll
+                        for (int c = 0; c < 16; ++c) d[c] = bf16_bits_to_f32(f32_to_bf16_bits(d[c] + d2[c]));
+                    }
                     Elem<bf16_t>::unpack(*reinterpret_cast<const uint4*>(yp + o), y);
                     Elem<bf16_t>::unpack(*reinterpret_cast<const uint4*>(yp + o + 8), y + 8);
 #pragma unroll
@@ -367,11 +385,11 @@ __global__ __launch_bounds__(64 * SF_WAVES) void stem_bwd_dx_kernel(const int N,
         }
         // ---- phase B: recompute the convolution row by row, emit d(conv out) ----
         SfPooledRow P0, P1;
-        sf_load_pooled(P0, dyp, yp, idx, pool_base, li, lg, true);
+        sf_load_pooled(P0, dyp, dyp2, yp, idx, pool_base, li, lg, true);
         bf16_t* dimg = dx + (size_t)n * OH * 64 * 64;
         int slot0 = 0;
         for (int py = 0; py < PH; ++py) {
-            sf_load_pooled(P1, dyp, yp, idx, pool_base + (size_t)(py + 1) * 32, li, lg, py + 1 < PH);
+            sf_load_pooled(P1, dyp, dyp2, yp, idx, pool_base + (size_t)(py + 1) * 32, li, lg, py + 1 < PH);
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
                 const int oy = 2 * py + half;
@@ -455,7 +473,7 @@ extern "C" int eve_stem_fwd_fused(int N, int IH, int IW, const void* x_padded, c
 /* d(conv1 output) [N][IH/2][64][64] bf16 from d(y_pool): the backward of eve_stem_fwd_fused up to the convolution
    output (the weight gradient then runs on it).  Recomputes the convolution from x_padded instead of reading it. */
 extern "C" int eve_stem_bwd_dx(int N, int IH, int IW, const void* x_padded, const void* w_ohwi8, const float* mean_rstd,
-                               const void* dy_pool, const void* y_pool, const uint8_t* idx, void* dx, eve_stream_t stream) {
+                               const void* dy_pool, const void* dy_pool2, const void* y_pool, const uint8_t* idx, void* dx, eve_stream_t stream) {
     if (N <= 0 || IH <= 0 || (IH & 3) || IW != 128 || !x_padded || !w_ohwi8 || !mean_rstd || !dy_pool || !y_pool || !idx || !dx)
         return set_error_msg("stem_bwd_dx: needs IW == 128 and IH a multiple of 4");
     const unsigned long long xb = (unsigned long long)N * (IH + 6) * SF_XROW;
@@ -470,7 +488,7 @@ extern "C" int eve_stem_bwd_dx(int N, int IH, int IW, const void* x_padded, cons
     if (blocks > 256) blocks = 256;
     hipLaunchKernelGGL(stem_bwd_dx_kernel, dim3(blocks), dim3(64 * SF_WAVES), lds, (hipStream_t)stream, N, IH,
                        (const bf16_t*)x_padded, (uint32_t)xb, (const bf16_t*)w_ohwi8, mean_rstd, (const bf16_t*)dy_pool,
-                       (const bf16_t*)y_pool, idx, (bf16_t*)dx);
+                       (const bf16_t*)dy_pool2, (const bf16_t*)y_pool, idx, (bf16_t*)dx);
     EVE_CHECK_LAUNCH();
     return 0;
 }

@@ -156,25 +156,22 @@ class EyeNet(nn.Module):
         """x: [N, H, W, Cpad] NHWC compute dtype -> [N, 512] float32 (torchvision ResNet._forward_impl).
         x_padded: optional [N, H+6, W+8, 4] bf16 repack for the dedicated stem kernel."""
         cnn = self.cnn_layers
+        blocks, weights = [], []
+        for name, blk in cnn.blocks():
+            ds = blk.downsample
+            blocks.append(((P[name + '.conv1'], P[name + '.conv2'], P[name + '.downsample.0'] if ds is not None else None),
+                           blk.stride))
+            weights += [blk.conv1.weight, blk.conv2.weight] + ([ds[0].weight] if ds is not None else [])
         if x_padded is not None and x_padded.shape[2] == 136 and x_padded.shape[1] % 4 == 2:
-            # 128-wide patches: conv1 -> bn1 -> relu -> maxpool in one launch
-            y = ops.StemFusedFn.apply(x, x_padded, cnn.conv1.weight, P['conv1'], 1e-5)
+            # 128-wide patches: conv1 -> bn1 -> relu -> maxpool in one launch, inside the trunk node
+            y = ops.ResNetTrunkFn.apply(None, x, x_padded, (P['conv1'], tuple(blocks)), 1e-5, cnn.conv1.weight, *weights)
         else:
             if x_padded is not None:
                 y = ops.StemConvFn.apply(x, x_padded, cnn.conv1.weight, P['conv1'])
             else:
                 y = ops.conv2d(x, cnn.conv1.weight, None, P['conv1'], stride=2, pad=3)
             y = ops.InReluMaxPoolFn.apply(y, 1e-5)      # bn1 -> relu -> maxpool, fused
-        for name, blk in cnn.blocks():
-            out = ops.conv2d(y, blk.conv1.weight, None, P[name + '.conv1'], stride=blk.stride, pad=1)
-            out = ops.instnorm_act(out, act=ACT_RELU)
-            out = ops.conv2d(out, blk.conv2.weight, None, P[name + '.conv2'], stride=1, pad=1)
-            identity = y
-            if blk.downsample is not None:
-                identity = ops.conv2d(y, blk.downsample[0].weight, None, P[name + '.downsample.0'],
-                                      stride=blk.stride, pad=0)
-                identity = ops.instnorm_act(identity, act=ACT_NONE)
-            y = ops.instnorm_act(out, res=identity, act=ACT_RELU)
+            y = ops.ResNetTrunkFn.apply(y, None, None, (None, tuple(blocks)), 1e-5, *weights)
         feats = ops.AvgPoolFn.apply(y)
         return ops.cast(feats, torch.float32)
 

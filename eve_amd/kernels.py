@@ -132,16 +132,24 @@ class HipKernels(object):
             self._p(self._f32(ss, 'scale/shift')), pro_act, self._p(y), self._stream())))
         return y
 
-    def conv2d_dgrad(self, dy, w_ihwo, in_hw, stride, pad, algo=None):
+    def conv2d_dgrad(self, dy, w_ihwo, in_hw, stride, pad, algo=None, accumulate_into=None):
+        """Data gradient; with accumulate_into (a contiguous [N, IH, IW, Cin] tensor) it is ADDED to that tensor in
+        the kernel epilogue and the same tensor is returned."""
         N, OH, OW, Cout = dy.shape
         Cin, KH, KW, Cout2 = w_ihwo.shape
         assert Cout2 == Cout and w_ihwo.dtype == dy.dtype
         IH, IW = in_hw
         d = self._desc(dy.dtype, N, IH, IW, Cin, Cout, KH, KW, stride, pad)
         assert (d.OH, d.OW) == (OH, OW)
-        dx = torch.empty((N, IH, IW, Cin), dtype=dy.dtype, device=dy.device)
         co, kk = algo or (Cout, KH * KW * Cin)
-        self._timed('conv_dgrad', 2.0 * N * OH * OW * co * kk, lambda: self._ck(self.lib.eve_conv2d_dgrad(
+        if accumulate_into is not None:
+            dx = accumulate_into
+            assert tuple(dx.shape) == (N, IH, IW, Cin) and dx.dtype == dy.dtype and dx.is_contiguous()
+            fn = self.lib.eve_conv2d_dgrad_acc
+        else:
+            dx = torch.empty((N, IH, IW, Cin), dtype=dy.dtype, device=dy.device)
+            fn = self.lib.eve_conv2d_dgrad
+        self._timed('conv_dgrad', 2.0 * N * OH * OW * co * kk, lambda: self._ck(fn(
             ctypes.byref(d), self._p(dy), self._p(w_ihwo), self._p(dx), self._stream())))
         return dx
 
@@ -189,7 +197,7 @@ class HipKernels(object):
             self._stream())))
         return y, idx, mr
 
-    def stem_bwd_dx(self, x_padded, w_ohwi8, mr, dy_pool, y_pool, idx):
+    def stem_bwd_dx(self, x_padded, w_ohwi8, mr, dy_pool, y_pool, idx, dy_pool2=None):
         N, Hp, Wp, _ = x_padded.shape
         IH, IW = Hp - 6, Wp - 8
         dx = torch.empty((N, IH // 2, IW // 2, 64), dtype=torch.bfloat16, device=x_padded.device)
@@ -197,7 +205,7 @@ class HipKernels(object):
         flops = 2.0 * N * (IH // 2) * (IW // 2) * 64 * 147
         self._timed('conv_fwd', flops, lambda: self._ck(self.lib.eve_stem_bwd_dx(
             N, IH, IW, self._p(x_padded), self._p(w_ohwi8), self._p(self._f32(mr, 'mean_rstd')), self._p(dy_pool),
-            self._p(y_pool), self._p(idx), self._p(dx), self._stream())))
+            self._p(dy_pool2), self._p(y_pool), self._p(idx), self._p(dx), self._stream())))
         return dx
 
     def bias_grad(self, dy, db):
@@ -248,13 +256,14 @@ class HipKernels(object):
         self._ck(st)
         return y, mr
 
-    def instnorm_bwd_fused(self, dy, y, x, mr, gamma, act, want_dres):
-        """Single-launch backward; returns (dx, dres, sums) or None when the plane is too large."""
+    def instnorm_bwd_fused(self, dy, y, x, mr, gamma, act, want_dres, dy2=None):
+        """Single-launch backward; returns (dx, dres, sums) or None when the plane is too large.
+        dy2: optional second summand of the incoming gradient (added on load)."""
         N, H, W, C = x.shape
         dx = torch.empty_like(x)
         dres = torch.empty_like(x) if want_dres else None
         sums = torch.empty((N, C, 2), dtype=torch.float32, device=x.device)
-        st = self.lib.eve_instnorm_bwd_fused(dt_code(x.dtype), N, H * W, C, self._p(dy), self._p(y), self._p(x),
+        st = self.lib.eve_instnorm_bwd_fused(dt_code(x.dtype), N, H * W, C, self._p(dy), self._p(dy2), self._p(y), self._p(x),
                                              self._p(mr), self._p(self._f32(gamma, 'gamma')), act, self._p(dx),
                                              self._p(dres), self._p(sums), self._stream())
         if st == -1:

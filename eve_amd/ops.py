@@ -172,6 +172,142 @@ def linear(x2d, weight, bias, pack, act=ACT_NONE):
     return y.view(M, y.shape[-1])
 
 
+def _wgrad_into(k, x, dy, weight, pack, stride, pad):
+    """Weight gradient of a bias-free conv: straight into the flat gradient buffer when the parameter lives there
+    (returns None), else a fresh OIHW-shaped tensor for autograd."""
+    cout_p, KH, KW, cin_p = pack.ohwi.shape
+    O, I = pack.shape_oihw[0], pack.shape_oihw[1]
+    if _direct_grad_ok(weight) and (cout_p, cin_p) == (O, I):
+        k.conv2d_wgrad(x, dy, KH, KW, stride, pad, weight.grad.permute(0, 2, 3, 1), algo=pack.algo)
+        _notify_grad_ready(weight)
+        return None
+    dwp = torch.zeros((cout_p, KH, KW, cin_p), dtype=torch.float32, device=x.device)
+    k.conv2d_wgrad(x, dy, KH, KW, stride, pad, dwp, algo=pack.algo)
+    return dwp[:O, :, :, :I].permute(0, 3, 1, 2)
+
+
+def _in_fwd(k, x, res, act, eps):
+    fused = k.instnorm_fwd_fused(x, None, None, res, act, eps)
+    if fused is not None:
+        return fused
+    mr = k.instnorm_stats(x, eps)
+    return k.instnorm_act_fwd(x, mr, None, None, res, act), mr
+
+
+def _in_bwd(k, dy, y, x, mr, act, want_dres, dy2=None):
+    out = k.instnorm_bwd_fused(dy, y, x, mr, None, act, want_dres, dy2=dy2)
+    if out is None:
+        if dy2 is not None:
+            dy = k.add(dy, dy2)
+        out = k.instnorm_act_bwd(dy, y, x, mr, None, act, want_dres)
+    return out[0], out[1]
+
+
+def _block_forward(k, x, packs, stride, eps):
+    """torchvision BasicBlock with norm_layer = InstanceNorm2d (no affine), as eye_net.py:48-50 builds it:
+        out = relu(IN(conv1(x)));  out = IN(conv2(out));  y = relu(out + identity),
+        identity = x  or  IN(conv1x1/s(x)).   Returns y and the tensors the backward needs."""
+    p1, p2, pd = packs
+    a = k.conv2d_fwd(x, p1.ohwi, None, stride, 1, ACT_NONE, algo=p1.algo)
+    an, mr1 = _in_fwd(k, a, None, ACT_RELU, eps)
+    b = k.conv2d_fwd(an, p2.ohwi, None, 1, 1, ACT_NONE, algo=p2.algo)
+    if pd is not None:
+        d = k.conv2d_fwd(x, pd.ohwi, None, stride, 0, ACT_NONE, algo=pd.algo)
+        idn, mrd = _in_fwd(k, d, None, ACT_NONE, eps)
+    else:
+        d = mrd = None
+        idn = x
+    y, mr2 = _in_fwd(k, b, idn, ACT_RELU, eps)
+    return y, (x, a, mr1, an, b, mr2, y, d, mrd)
+
+
+def _block_backward(k, dy, dy2, saved, weights, packs, stride, need_w):
+    """Backward of _block_forward in dependency order.  The incoming gradient may arrive as two summands
+    (dy + dy2: the previous fork) and the gradient of the block input is RETURNED as two summands (g, dx1) --
+    residual branch and conv1 branch -- so the sum is folded into whichever kernel reads it next.
+    Returns (g, dx1, dw1, dw2, dwd); weight gradients are None when they went straight into the flat buffer."""
+    x, a, mr1, an, b, mr2, y, d, mrd = saved
+    p1, p2, pd = packs
+    w1, w2, wd = weights
+    hw = (x.shape[1], x.shape[2])
+    # y = relu(IN(b) + identity): db and the residual-branch gradient g = dy * relu'(y)
+    db, g = _in_bwd(k, dy, y, b, mr2, ACT_RELU, True, dy2=dy2)
+    dw2 = _wgrad_into(k, an, db, w2, p2, 1, 1) if need_w[1] else None
+    dan = k.conv2d_dgrad(db, p2.ihwo, (an.shape[1], an.shape[2]), 1, 1, algo=p2.algo)
+    da, _ = _in_bwd(k, dan, None, a, mr1, ACT_RELU, False)              # act' recomputed from a (no affine / residual)
+    dw1 = _wgrad_into(k, x, da, w1, p1, stride, 1) if need_w[0] else None
+    dwd = None
+    if pd is not None:
+        dd, _ = _in_bwd(k, g, None, d, mrd, ACT_NONE, False)
+        dwd = _wgrad_into(k, x, dd, wd, pd, stride, 0) if need_w[2] else None
+        g = k.conv2d_dgrad(dd, pd.ihwo, hw, stride, 0, algo=pd.algo)
+    dx1 = k.conv2d_dgrad(da, p1.ihwo, hw, stride, 1, algo=p1.algo)
+    return g, dx1, dw1, dw2, dwd
+
+
+class ResNetTrunkFn(torch.autograd.Function):
+    """conv1/bn1/relu/maxpool (optional, fused stem) and the BasicBlock chain of torchvision's ResNet as ONE
+    autograd node, so that the backward runs in dependency order with explicit buffers: every residual fork
+    hands its two gradient summands to the kernel that reads them next (the add is never a launch), and the
+    weight gradients go straight into the flat gradient buffer.
+
+    apply(x, x8, x_padded, spec, eps, *weights):
+      spec = (stem_pack or None, ((p1, p2, pd), stride) per block); weights = [conv1 if stem] + per block (w1, w2[, wd]).
+      With a stem, x is ignored and the input is (x8, x_padded) (no data gradient); without, x is the block input."""
+
+    @staticmethod
+    def forward(ctx, x, x8, x_padded, spec, eps, *weights):
+        k = default_kernels()
+        stem_pack, blocks = spec
+        saved = []
+        if stem_pack is not None:
+            y, idx, mr = k.stem_fwd_fused(x_padded, stem_pack.ohwi, eps)
+            saved += [x8, x_padded, y, idx, mr]
+        else:
+            y = x
+        for packs, stride in blocks:
+            y, sv = _block_forward(k, y, packs, stride, eps)
+            saved += list(sv)
+        ctx.spec, ctx.weights = spec, weights
+        ctx.save_for_backward(*saved)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        k = default_kernels()
+        stem_pack, blocks = ctx.spec
+        saved = list(ctx.saved_tensors)
+        weights = list(ctx.weights)
+        need_w = list(ctx.needs_input_grad[5:])
+        grads = [None] * len(weights)
+        wpos = len(weights)
+        spos = len(saved)
+        d_a, d_b = dy.contiguous(), None
+        for packs, stride in reversed(blocks):
+            nw = 3 if packs[2] is not None else 2
+            wpos -= nw
+            spos -= 9
+            ws = tuple(weights[wpos:wpos + nw]) + ((None,) if nw == 2 else ())
+            nd = tuple(need_w[wpos:wpos + nw]) + ((False,) if nw == 2 else ())
+            d_a, d_b, dw1, dw2, dwd = _block_backward(k, d_a, d_b, tuple(saved[spos:spos + 9]), ws, packs, stride, nd)
+            grads[wpos], grads[wpos + 1] = dw1, dw2
+            if nw == 3:
+                grads[wpos + 2] = dwd
+        dx = None
+        if stem_pack is not None:
+            x8, x_padded, y, idx, mr = saved[:5]
+            dconv = k.stem_bwd_dx(x_padded, stem_pack.ohwi, mr, d_a, y, idx, dy_pool2=d_b)
+            if need_w[0]:
+                cout_p, KH, KW, cin_p = stem_pack.ohwi.shape
+                dwp = torch.zeros((cout_p, KH, KW, cin_p), dtype=torch.float32, device=x8.device)
+                k.conv2d_wgrad(x8, dconv, KH, KW, 2, 3, dwp, algo=stem_pack.algo)
+                O, I = stem_pack.shape_oihw[0], stem_pack.shape_oihw[1]
+                grads[0] = dwp[:O, :, :, :I].permute(0, 3, 1, 2)
+        elif ctx.needs_input_grad[0]:
+            dx = k.add(d_a, d_b) if d_b is not None else d_a
+        return (dx, None, None, None, None) + tuple(grads)
+
+
 class InstNormActFn(torch.autograd.Function):
     """y = act(gamma * IN(x) + beta + res);  gamma/beta/res optional.  eps 1e-5, biased variance."""
 

@@ -66,6 +66,10 @@ int eve_conv2d_fwd(const eve_conv_desc* d, const void* x, const void* w_ohwi, co
 /* dx = conv_transpose(dy, w): gradient w.r.t. the conv INPUT.  w_ihwo is [Cin][KH][KW][Cout].    */
 int eve_conv2d_dgrad(const eve_conv_desc* d, const void* dy, const void* w_ihwo, void* dx,
                      eve_stream_t stream);
+/* dx += the same data gradient (dx already holds the gradient of the block's other branch: autograd's add at
+ * the residual fork of torchvision BasicBlock, fused into the epilogue).                              */
+int eve_conv2d_dgrad_acc(const eve_conv_desc* d, const void* dy, const void* w_ihwo, void* dx,
+                     eve_stream_t stream);
 /* dw[Cout][KH][KW][Cin] (float, accumulated) += sum_m dy[m][co] * x'[m][(kh,kw,ci)]              */
 int eve_conv2d_wgrad(const eve_conv_desc* d, const void* x, const void* dy,
                      const float* in_scale_shift, int pro_act, float* dw_ohwi, eve_stream_t stream);
@@ -86,7 +90,7 @@ int eve_stem_fwd_fused(int N, int IH, int IW, const void* x_padded, const void* 
 /* Its backward up to the convolution output: dx [N][IH/2][IW/2][64] bf16 = d(conv1 out) from dy_pool, recomputing
  * the convolution from x_padded (autograd of bn1/relu/maxpool in eye_net.py:106); feed dx to eve_conv2d_wgrad. */
 int eve_stem_bwd_dx(int N, int IH, int IW, const void* x_padded, const void* w_ohwi8, const float* mean_rstd,
-                    const void* dy_pool, const void* y_pool, const uint8_t* idx, void* dx, eve_stream_t stream);
+                    const void* dy_pool, const void* dy_pool2 /* nullable second summand */, const void* y_pool, const uint8_t* idx, void* dx, eve_stream_t stream);
 /* db[C] (float, accumulated) += sum over the M = N*OH*OW rows of dy[M][C]                         */
 int eve_bias_grad(int dtype, long long M, int C, const void* dy, float* db, eve_stream_t stream);
 
@@ -117,7 +121,9 @@ int eve_instnorm_act_bwd(int dtype, int N, int HW, int C, const void* dy, const 
 int eve_instnorm_fwd_fused(int dtype, int N, int HW, int C, const void* x, const float* gamma,
                            const float* beta, const void* res, int act, float eps, void* y,
                            float* mean_rstd, eve_stream_t stream);
-int eve_instnorm_bwd_fused(int dtype, int N, int HW, int C, const void* dy, const void* y,
+/* dy2 (nullable): a second summand of the incoming gradient, added on load -- the residual fork of a ResNet
+ * block delivers d(block input) as two tensors and the sum is never materialised.                      */
+int eve_instnorm_bwd_fused(int dtype, int N, int HW, int C, const void* dy, const void* dy2, const void* y,
                            const void* x, const float* mean_rstd, const float* gamma, int act,
                            void* dx, void* dres, float* sums, eve_stream_t stream);
 

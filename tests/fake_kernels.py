@@ -54,10 +54,13 @@ class FakeKernels(object):
         y = F.conv2d(nchw(xin), w_ohwi.permute(0, 3, 1, 2).float(), bias, stride, pad)
         return nhwc(act_fwd(y, epi_act), x.dtype)
 
-    def conv2d_dgrad(self, dy, w_ihwo, in_hw, stride, pad, algo=None):
+    def conv2d_dgrad(self, dy, w_ihwo, in_hw, stride, pad, algo=None, accumulate_into=None):
         w = w_ihwo.permute(3, 0, 1, 2).float()          # [Cout, Cin, KH, KW]
         N = dy.shape[0]
         dx = torch.nn.grad.conv2d_input((N, w.shape[1], in_hw[0], in_hw[1]), w, nchw(dy), stride, pad)
+        if accumulate_into is not None:
+            accumulate_into.copy_((accumulate_into.float() + nhwc(dx, torch.float32)).to(dy.dtype))
+            return accumulate_into
         return nhwc(dx, dy.dtype)
 
     def conv2d_wgrad(self, x, dy, KH, KW, stride, pad, dw_ohwi, ss=None, pro_act=ACT_NONE, algo=None):
@@ -85,7 +88,9 @@ class FakeKernels(object):
         y, idx = self.in_relu_maxpool_fwd(conv, mr)
         return y, idx, mr
 
-    def stem_bwd_dx(self, x_padded, w_ohwi8, mr, dy_pool, y_pool, idx):
+    def stem_bwd_dx(self, x_padded, w_ohwi8, mr, dy_pool, y_pool, idx, dy_pool2=None):
+        if dy_pool2 is not None:
+            dy_pool = (dy_pool.float() + dy_pool2.float()).to(dy_pool.dtype)
         return self.in_relu_maxpool_bwd(dy_pool, y_pool, idx, self.stem7x7s2_fwd(x_padded, w_ohwi8), mr)
 
     def bias_grad(self, dy, db):
@@ -127,9 +132,11 @@ class FakeKernels(object):
         mr = self.instnorm_stats(x, eps)
         return self.instnorm_act_fwd(x, mr, gamma, beta, res, act), mr
 
-    def instnorm_bwd_fused(self, dy, y, x, mr, gamma, act, want_dres):
+    def instnorm_bwd_fused(self, dy, y, x, mr, gamma, act, want_dres, dy2=None):
         if x.shape[1] * x.shape[2] * x.shape[3] > 65536:
             return None
+        if dy2 is not None:
+            dy = (dy.float() + dy2.float()).to(dy.dtype)
         return self.instnorm_act_bwd(dy, y, x, mr, gamma, act, want_dres)
 
     def act_bwd(self, dy, y, act):

@@ -91,6 +91,10 @@ def test_conv_fwd_dgrad_wgrad(hip, ref, dtype, case):
     want_dx = ref.conv2d_dgrad(dy, w_ihwo, (IH, IW), stride, pad)
     got_dx = hip.conv2d_dgrad(dev(dy), dev(w_ihwo), (IH, IW), stride, pad)
     close(got_dx, want_dx, dtype, 'conv dgrad')
+    # the same gradient accumulated onto an existing tensor (residual join fused into the epilogue)
+    base = rnd((N, IH, IW, Cin), dtype, 5)
+    got_acc = hip.conv2d_dgrad(dev(dy), dev(w_ihwo), (IH, IW), stride, pad, accumulate_into=dev(base).clone())
+    close(got_acc, (want_dx.float() + base.float()).to(dtype), dtype, 'conv dgrad accumulate')
     want_dw = ref.conv2d_wgrad(x, dy, K, K, stride, pad, torch.zeros((Cout, K, K, Cin)))
     got_dw = hip.conv2d_wgrad(dev(x), dev(dy), K, K, stride, pad,
                               torch.zeros((Cout, K, K, Cin), device='cuda'))
