@@ -331,10 +331,42 @@ __global__ __launch_bounds__(256) void wgrad_tr_kernel(const GatherParams p, con
     }
 
     // Source offsets of one stage.  Pixels past the end of the split get the out-of-range offset (zero fill).
-    // Power-of-two output sizes (every EyeNet stage) decode a pixel with shifts; others use the mul-hi division.
+    // Power-of-two output sizes (every EyeNet stage): a stage starts at a multiple of 32 pixels and a slot's row is
+    // < 32, so pixel = mbase | row and every decoded field (n, oy, ox) is the SUM of a wave-uniform part (from
+    // mbase: scalar ALU, once per stage) and a lane constant (from row: computed once).  A slot then costs one add
+    // for the address and an add + unsigned compare per bounds test, instead of a full decode (the kernel was
+    // issuing 4-6 VALU instructions per MFMA).  Other sizes use the mul-hi division per slot.
     const int sh_w = __builtin_ctz((unsigned)p.OW), sh_hw = __builtin_ctz((unsigned)(p.OH * p.OW));
     const int cin2 = p.Cin * 2, cout2 = p.Cout * 2;
+    int p_const[P_DMA], q_const[Q_DMA], q_ty[Q_DMA], q_tx[Q_DMA];
+#pragma unroll
+    for (int j = 0; j < P_DMA; ++j) p_const[j] = p_col[j] == EVE_OOB ? EVE_OOB : p_row[j] * cout2 + p_col[j];
+#pragma unroll
+    for (int j = 0; j < Q_DMA; ++j) {
+        const uint32_t r = (uint32_t)q_row[j];
+        const int n_t = (int)(r >> sh_hw), oy_t = (int)((r >> sh_w) & (uint32_t)(p.OH - 1)), ox_t = (int)(r & (uint32_t)(p.OW - 1));
+        q_ty[j] = oy_t * p.o_mul + q_dy[j];
+        q_tx[j] = ox_t * p.o_mul + q_dx[j];
+        q_const[j] = q_col[j] == EVE_OOB ? EVE_OOB : ((n_t * p.IH + q_ty[j]) * p.IW + q_tx[j]) * cin2 + q_col[j];
+    }
     auto offsets = [&](uint32_t mbase, int* vp, int* vq) {   // branch-free: selects only
+        if (POW2) {
+            const uint32_t left = m_end > mbase ? m_end - mbase : 0u;          // rows of this stage still in range
+            const int pbase = (int)mbase * cout2;
+            const uint32_t n_s = mbase >> sh_hw, oy_s = (mbase >> sh_w) & (uint32_t)(p.OH - 1), ox_s = mbase & (uint32_t)(p.OW - 1);
+            const int sy0 = (int)oy_s * p.o_mul, sx0 = (int)ox_s * p.o_mul;
+            const int qbase = (((int)n_s * p.IH + sy0) * p.IW + sx0) * cin2;
+#pragma unroll
+            for (int j = 0; j < P_DMA; ++j)
+                vp[j] = ((uint32_t)p_row[j] < left) & (p_const[j] != EVE_OOB) ? pbase + p_const[j] : EVE_OOB;
+#pragma unroll
+            for (int j = 0; j < Q_DMA; ++j) {
+                const bool ok = ((uint32_t)q_row[j] < left) & (q_const[j] != EVE_OOB) &
+                                ((uint32_t)(sy0 + q_ty[j]) < (uint32_t)p.IH) & ((uint32_t)(sx0 + q_tx[j]) < (uint32_t)p.IW);
+                vq[j] = ok ? qbase + q_const[j] : EVE_OOB;
+            }
+            return;
+        }
 #pragma unroll
         for (int j = 0; j < P_DMA; ++j) {
             const uint32_t m = mbase + p_row[j];
@@ -344,14 +376,9 @@ __global__ __launch_bounds__(256) void wgrad_tr_kernel(const GatherParams p, con
 #pragma unroll
         for (int j = 0; j < Q_DMA; ++j) {
             const uint32_t m = mbase + q_row[j];
-            uint32_t n, oy, ox;
-            if (POW2) {
-                n = m >> sh_hw; oy = (m >> sh_w) & (uint32_t)(p.OH - 1); ox = m & (uint32_t)(p.OW - 1);
-            } else {
-                n = fd_div(m, p.fd_ohw);
-                const uint32_t rem = m - n * ohw;
-                oy = fd_div(rem, p.fd_ow); ox = rem - oy * (uint32_t)p.OW;
-            }
+            const uint32_t n = fd_div(m, p.fd_ohw);
+            const uint32_t rem = m - n * ohw;
+            const uint32_t oy = fd_div(rem, p.fd_ow), ox = rem - oy * (uint32_t)p.OW;
             const int sy = (int)oy * p.o_mul + q_dy[j], sx = (int)ox * p.o_mul + q_dx[j];
             const bool ok = (m < m_end) & (q_col[j] != EVE_OOB) & (sy >= 0) & (sy < p.IH) & (sx >= 0) & (sx < p.IW);
             const int v = (((int)n * p.IH + sy) * p.IW + sx) * cin2 + q_col[j];
