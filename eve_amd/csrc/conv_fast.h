@@ -261,8 +261,11 @@ __device__ __forceinline__ int tr_key(int row) {
 }
 
 // takes a 32-bit LDS byte address: an integer -> LDS pointer cast is free, a generic -> LDS cast is ~6 VALU per read
+// (the compile-time displacement goes through pointer arithmetic so that it folds into the instruction's offset field)
+template <int IMM = 0>
 __device__ __forceinline__ uint2 lds_tr_read(uint32_t lds_byte_addr) {
-    bf16x4v_t r = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((EVE_LDS bf16x4v_t*)(size_t)lds_byte_addr);
+    EVE_LDS char* base = (EVE_LDS char*)(size_t)lds_byte_addr;
+    bf16x4v_t r = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((EVE_LDS bf16x4v_t*)(base + IMM));
     return __builtin_bit_cast(uint2, r);
 }
 
@@ -435,10 +438,10 @@ __global__ __launch_bounds__(256) void wgrad_tr_kernel(const GatherParams p, con
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const uint2 a0 = lds_tr_read(sb + poff[i]);
-                const uint2 a1 = lds_tr_read(sb + poff[i] + 4 * PROW);
+                const uint2 a1 = lds_tr_read<4 * PROW>(sb + poff[i]);
                 fp[i] = make_uint4(a0.x, a0.y, a1.x, a1.y);
                 const uint2 b0 = lds_tr_read(sb + qoff[i]);
-                const uint2 b1 = lds_tr_read(sb + qoff[i] + 4 * QROW);
+                const uint2 b1 = lds_tr_read<4 * QROW>(sb + qoff[i]);
                 fq[i] = make_uint4(b0.x, b0.y, b1.x, b1.y);
             }
             mma16_bf16_inplace(acc, fp, fq);                  // acc[mt][kt] += P[mt] x Q[kt]

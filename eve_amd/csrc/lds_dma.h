@@ -17,7 +17,7 @@ __device__ __forceinline__ void lds_dma16(__amdgpu_buffer_rsrc_t rsrc, const voi
 // The same LDS-DMA as inline asm.  hipcc treats the builtin as a store to LDS and protects every later ds_read
 // with s_waitcnt vmcnt(0), which drains a multi-stage prefetch ring at every step; an asm statement is opaque to
 // that bookkeeping, so the waits are exactly the counted s_waitcnt vmcnt(N) the kernel places itself.
-// M0 (the LDS destination base) is written and restored inside the statement.
+// M0 (the LDS destination base) is written inside the statement and declared clobbered.
 typedef int eve_int4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ eve_int4 make_rsrc_words(const void* base, uint32_t bytes) {
     const uint64_t a = (uint64_t)base;
@@ -32,11 +32,9 @@ __device__ __forceinline__ uint32_t lds_addr_of(const void* generic_ptr) {
     return (uint32_t)(uintptr_t)((EVE_LDS void*)generic_ptr);
 }
 __device__ __forceinline__ void lds_dma16_asm(const eve_int4& rsrc, uint32_t lds_byte_addr, int voffset) {
-    uint32_t keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep)
-                 : "s"(lds_byte_addr), "v"(voffset), "s"(rsrc)
-                 : "memory");
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"
+                 :: "s"(lds_byte_addr), "v"(voffset), "s"(rsrc)
+                 : "memory", "m0");
 }
 
 }  // namespace eve

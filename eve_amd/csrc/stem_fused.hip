@@ -30,14 +30,12 @@ constexpr int SF_KBYTES = 64 * 3 * 4;               // backward: {rstd, B, C} pe
 constexpr uint32_t SF_NEG = 0xff61b1e0u;         // -3.0e38 with the four key bits clear
 
 __device__ __forceinline__ void sf_dma16(const eve_int4& rsrc, uint32_t lds, int voff, int soff) {
-    uint32_t keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "s"(lds), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+                 :: "s"(lds), "v"(voff), "s"(rsrc), "s"(soff) : "memory", "m0");
 }
 __device__ __forceinline__ void sf_dma4(const eve_int4& rsrc, uint32_t lds, int voff, int soff) {
-    uint32_t keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dword %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "s"(lds), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, %3 offen lds"
+                 :: "s"(lds), "v"(voff), "s"(rsrc), "s"(soff) : "memory", "m0");
 }
 typedef uint32_t sf_u32x4_t __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ bf16x8_t sf_lds_read(uint32_t addr) {
