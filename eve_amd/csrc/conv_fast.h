@@ -249,6 +249,22 @@ __device__ __forceinline__ void mma16_bf16_inplace(f32x4_t (&acc)[4][4], const u
 }
 // wait states between the last asm MFMA and compiler-generated reads of the accumulators
 __device__ __forceinline__ void mma_drain() { asm volatile("s_nop 15\n\ts_nop 15" ::: "memory"); }
+// four in-place MFMAs sharing the A operand: c[i] += a x b[i]
+__device__ __forceinline__ void mma4_bf16_inplace(f32x4_t& c0, f32x4_t& c1, f32x4_t& c2, f32x4_t& c3, const uint4& a4,
+                                                  const uint4 (&b4)[4]) {
+    u32x4_t b[4];
+    const u32x4_t a = __builtin_bit_cast(u32x4_t, a4);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) b[i] = __builtin_bit_cast(u32x4_t, b4[i]);
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_mfma_f32_16x16x32_bf16 %0, %4, %5, %0\n\t"
+        "v_mfma_f32_16x16x32_bf16 %1, %4, %6, %1\n\t"
+        "v_mfma_f32_16x16x32_bf16 %2, %4, %7, %2\n\t"
+        "v_mfma_f32_16x16x32_bf16 %3, %4, %8, %3"
+        : "+a"(c0), "+a"(c1), "+a"(c2), "+a"(c3)
+        : "v"(a), "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]));
+}
 
 // =================================================================================================
 // bf16 weight gradient.  Block tile = (64*WCO output channels) x (64*WK filter-K values); every wave owns
@@ -556,7 +572,10 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const HaloParams p, c
     for (int j = 0; j < WN; ++j) {
         const int L = tid + 256 * j;
         const int cl = L >> 2, pc = L & 3;
-        const uint32_t co = co0 + cl;
+        // LDS row cl = (MFMA tile q, row i) holds channel (cl & ~63) + (i >> 2) * 16 + q * 4 + (i & 3), so that a lane
+        // (rows 4g..4g+3 of the four tiles) owns 16 consecutive channels: 2 x 16-byte stores per pixel
+        const int i16 = cl & 15, q = (cl >> 4) & 3;
+        const uint32_t co = co0 + (cl & ~63) + (i16 >> 2) * 16 + q * 4 + (i16 & 3);
         b_goff[j] = co < (uint32_t)p.Cout ? (int)(co * (uint32_t)p.K) * 2 + ((pc ^ (((cl >> 2) & 1) << 1)) << 4) : EVE_OOB;
     }
 
@@ -663,44 +682,272 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const HaloParams p, c
         }
     }
 
-    // ---- epilogue (two bodies, see act_fwd4) ----
+    // ---- epilogue (two bodies, see act_fwd4): the lane owns channels co .. co+15 of four pixels ----
     auto epilogue = [&](auto fast) {
-    #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) {
-            const uint32_t co = co0 + wn * 64 + nt * 16 + lg * 4;
-            float bv[4] = {0.f, 0.f, 0.f, 0.f};
-            if (bias) {
-    #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (co + r < (uint32_t)p.Cout) bv[r] = bias[co + r];
-            }
-    #pragma unroll
-            for (int mt = 0; mt < 4; ++mt) {
-                const int m = wm * 64 + mt * 16 + li;
-                const int rowi = (int)fd_div((uint32_t)m, p.fd_w), tx = m - rowi * p.W;
-                const int ti = (int)fd_div((uint32_t)rowi, p.fd_th), ty = rowi - ti * p.TH;
-                const uint32_t n = n0 + ti;
-                const int y = y0 + ty;
-                if (n >= (uint32_t)p.N || y >= p.H || co >= (uint32_t)p.Cout) continue;
-                float o[4];
-    #pragma unroll
-                for (int r = 0; r < 4; ++r) o[r] = acc[mt][nt][r] + bv[r];
+        const uint32_t co = co0 + wn * 64 + lg * 16;
+        float bv[16];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) bv[c] = (bias && co + c < (uint32_t)p.Cout) ? bias[co + c] : 0.f;
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            const int m = wm * 64 + mt * 16 + li;
+            const int rowi = (int)fd_div((uint32_t)m, p.fd_w), tx = m - rowi * p.W;
+            const int ti = (int)fd_div((uint32_t)rowi, p.fd_th), ty = rowi - ti * p.TH;
+            const uint32_t n = n0 + ti;
+            const int y = y0 + ty;
+            if (n >= (uint32_t)p.N || y >= p.H) continue;
+            bf16_t* dst = out + ((size_t)(n * p.H + y) * p.W + tx) * p.Cout + co;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {                     // two 16-byte halves of 8 channels
+                if (co + 8 * h + 8 > (uint32_t)p.Cout) continue;       // Cout is a multiple of 8
+                float o[8];
+#pragma unroll
+                for (int c = 0; c < 8; ++c) o[c] = acc[mt][2 * h + (c >> 2)][c & 3] + bv[8 * h + c];
                 act_fwd4<decltype(fast)::value>(o, epi_act);
-                bf16_t* dst = out + ((size_t)(n * p.H + y) * p.W + tx) * p.Cout + co;
+                act_fwd4<decltype(fast)::value>(o + 4, epi_act);
                 if (epi_act & EVE_EPI_ACC) {
-                    const uint2 old = *reinterpret_cast<const uint2*>(dst);
-                    o[0] += bf16_bits_to_f32(old.x & 0xffffu); o[1] += __builtin_bit_cast(float, old.x & 0xffff0000u);
-                    o[2] += bf16_bits_to_f32(old.y & 0xffffu); o[3] += __builtin_bit_cast(float, old.y & 0xffff0000u);
+                    float old[8];
+                    Elem<bf16_t>::unpack(*reinterpret_cast<const uint4*>(dst + 8 * h), old);
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) o[c] += old[c];
                 }
-                uint2 pk;
-                pk.x = pack2_bf16(o[0], o[1]);
-                pk.y = pack2_bf16(o[2], o[3]);
-                *reinterpret_cast<uint2*>(dst) = pk;
+                *reinterpret_cast<uint4*>(dst + 8 * h) = Elem<bf16_t>::pack(o);
             }
         }
     };
     if (act_is_fast(epi_act)) epilogue(std::true_type{});
     else epilogue(std::false_type{});
+}
+
+
+// -------------------------------------------------------------------------------------------------
+// Persistent variant of the kernel above.  A workgroup walks tiles t = lid, lid + G, ... and treats their
+// (tile, slice, tap) steps as ONE stream: the halo stages keep ping-ponging across the tile boundary (the last
+// slice of a tile prefetches the first slice of the next one), the weight ring keeps running 3 steps ahead, and
+// the only per-tile work is the epilogue.  With one tile per workgroup the two workgroups of a CU start, fetch
+// their first halo (a full HBM round trip with no MFMA work to hide it) and finish in lockstep; for the 64-channel
+// layers (18 steps per tile) that prologue was as long as the tile itself.  Tap / fragment addresses and the
+// halo-slot geometry are computed once per workgroup instead of once per tile.
+// -------------------------------------------------------------------------------------------------
+template <int WM, int WN>
+__global__ __launch_bounds__(256, 2) void conv3x3_halo_pkernel(const HaloParams p, const bf16_t* __restrict__ x,
+                                                            const bf16_t* __restrict__ w,
+                                                            const float* __restrict__ bias, const int epi_act,
+                                                            bf16_t* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int W2 = p.W + 2, HPI = (p.TH + 2) * W2, HP = p.TI * HPI;
+    const int a_stage = p.a_pieces * 4096;
+    char* const sA = smem;
+    constexpr int BSLOT = 4096 * WN;
+    char* const sB = smem + 2 * a_stage;
+
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t G = gridDim.x, T = p.tiles_m * p.tiles_n;
+    const uint32_t lid = xcd_remap(blockIdx.x, G);
+
+    const eve_int4 rs_x = make_rsrc_words(x, p.x_bytes);
+    const eve_int4 rs_w = make_rsrc_words(w, p.w_bytes);
+    const uint32_t ldsA = lds_addr_of(sA), ldsB = lds_addr_of(sB);
+    const bool wide = p.W >= 16;
+
+    // ---- halo DMA slots (lane constants): offset relative to pixel (n0, y0, 0), halo row / image of the slot ----
+    int a_rel[7], a_meta[7];                                  // meta = (ti << 8) | hy, or -1 for a slot that is never live
+#pragma unroll
+    for (int j = 0; j < 7; ++j) {
+        const int L = tid + 256 * j;
+        const int hp = L >> 2, pc = L & 3;
+        a_rel[j] = 0; a_meta[j] = -1;
+        if (j < p.a_pieces && hp < HP) {
+            const int ti = (int)fd_div((uint32_t)hp, p.fd_hpi);
+            const int r = hp - ti * HPI;
+            const int hy = (int)fd_div((uint32_t)r, p.fd_w2), hx = r - hy * W2;
+            const int key = wide ? (hx >> 2) & 1 : (ti * (p.TH + 2) + hy) & 1;
+            if (hx >= 1 && hx <= p.W) {
+                a_rel[j] = (((ti * p.H + hy - 1) * p.W + hx - 1) * p.Cin) * 2 + ((pc ^ (key << 1)) << 4);
+                a_meta[j] = (ti << 8) | hy;
+            }
+        }
+    }
+    // weight slots.  LDS row cl = (16-row MFMA tile q, row i) holds output channel (cl & ~63) + (i >> 2) * 16 + q * 4 +
+    // (i & 3): a lane (rows 4g..4g+3 of the four tiles) then owns 16 CONSECUTIVE channels of its pixel and the
+    // epilogue writes 2 x 16 bytes per pixel instead of 4 x 8.
+    int b_rel[WN], b_ch[WN];
+#pragma unroll
+    for (int j = 0; j < WN; ++j) {
+        const int L = tid + 256 * j;
+        const int cl = L >> 2, pc = L & 3;
+        const int i16 = cl & 15, q = (cl >> 4) & 3;
+        b_ch[j] = (cl & ~63) + (i16 >> 2) * 16 + q * 4 + (i16 & 3);
+        b_rel[j] = (b_ch[j] * p.K) * 2 + ((pc ^ (((cl >> 2) & 1) << 1)) << 4);
+    }
+
+    const int nslices = p.Cin / 32;
+    const int wave_off = wave * 1024;
+    const int lane = tid & 63, wm = wave / WN, wn = wave % WN;
+    const int li = lane & 15, lg = lane >> 4;
+    int aaddr[9][4];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+        const int m = wm * 64 + mt * 16 + li;
+        const int rowi = (int)fd_div((uint32_t)m, p.fd_w), tx = m - rowi * p.W;
+        const int ti = (int)fd_div((uint32_t)rowi, p.fd_th), ty = rowi - ti * p.TH;
+        const int hr0 = ti * (p.TH + 2) + ty;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int kh = t / 3, kw = t % 3;
+            const int dy = p.flip ? 2 - kh : kh, dx = p.flip ? 2 - kw : kw;
+            const int hr = hr0 + dy, hx = tx + dx;
+            const int key = wide ? (hx >> 2) & 1 : hr & 1;
+            aaddr[t][mt] = ((hr * W2 + hx) << 6) + ((lg ^ (key << 1)) << 4);
+        }
+    }
+    int brow[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+        const int c = wn * 64 + nt * 16 + li;
+        brow[nt] = (c << 6) + ((lg ^ (((c >> 2) & 1) << 1)) << 4);
+    }
+
+    // tile id -> (first image, first row, first output channel)
+    auto tile_coords = [&](uint32_t t, uint32_t& n0, int& y0, uint32_t& co0) {
+        const uint32_t tm = t / p.tiles_n, tn = t - tm * p.tiles_n;
+        if (p.TI == 1) { n0 = tm / p.bands; y0 = (int)(tm - n0 * p.bands) * p.TH; }
+        else { n0 = tm * p.TI; y0 = 0; }
+        co0 = tn * (64 * WN);
+    };
+    // halo piece j of the tile at (n0, y0), channel slice sl, into stage `st`
+    auto issue_a = [&](int j, uint32_t n0, int y0, int sl, int st, bool live) {
+        const int meta = a_meta[j];
+        const int hy = meta & 0xff, ti = meta >> 8;
+        const bool ok = live & (meta >= 0) & ((uint32_t)(y0 + hy - 1) < (uint32_t)p.H) & (n0 + (uint32_t)ti < (uint32_t)p.N);
+        const int base = (int)(((n0 * p.H + y0) * p.W) * p.Cin) * 2 + sl * 64;
+        lds_dma16_asm(rs_x, ldsA + st * a_stage + j * 4096 + wave_off, ok ? base + a_rel[j] : EVE_OOB);
+    };
+    // weight tile (slice sl, tap tb) of the channel block at co0 into ring slot `slot`
+    auto issue_b = [&](uint32_t co0, int sl, int tb, int slot, bool live) {
+        const int koff = (int)(co0 * (uint32_t)p.K) * 2 + (tb * p.Cin + sl * 32) * 2;
+        const uint32_t dst = ldsB + slot * BSLOT + wave_off;
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+            lds_dma16_asm(rs_w, dst + j * 4096,
+                          (live && co0 + (uint32_t)b_ch[j] < (uint32_t)p.Cout) ? b_rel[j] + koff : EVE_OOB);
+    };
+    auto wait_all_but = [&](int extra) {
+        if (WN == 2) {
+            if (extra == 0) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else if (extra == 1) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        } else {
+            if (extra == 0) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            else if (extra == 1) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        }
+    };
+
+    f32x4_t acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    if (lid >= T) return;
+    uint32_t n0, co0;
+    int y0;
+    tile_coords(lid, n0, y0, co0);
+    // ---- prologue: halo slice 0 of the first tile, weight tiles of steps 0..2 ----
+#pragma unroll
+    for (int j = 0; j < 7; ++j)
+        if (j < p.a_pieces) issue_a(j, n0, y0, 0, 0, true);
+    issue_b(co0, 0, 0, 0, true);
+    issue_b(co0, 0, 1, 1, true);
+    issue_b(co0, 0, 2, 2, true);
+    wait_all_but(0);
+    __builtin_amdgcn_s_barrier();
+
+    uint32_t gs = 0;                                          // slices consumed so far (stage parity, ring phase)
+    for (uint32_t tile = lid; tile < T; tile += G) {
+        const uint32_t nxt = tile + G;
+        const bool has_next = nxt < T;
+        uint32_t n1 = 0, co1 = 0;
+        int y1 = 0;
+        if (has_next) tile_coords(nxt, n1, y1, co1);
+        for (int s = 0; s < nslices; ++s, ++gs) {
+            const char* la = sA + (gs & 1) * a_stage;
+            const int nst = (int)((gs + 1) & 1);
+            const bool last = s + 1 == nslices;
+            // the slice after this one in the stream: same tile, or slice 0 of the next tile
+            const bool more = !last || has_next;
+            const uint32_t an = last ? n1 : n0;
+            const int ay = last ? y1 : y0, asl = last ? 0 : s + 1;
+            const int ap = more ? p.a_pieces : 0;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const char* lb = sB + ((gs + t) & 3) * BSLOT;
+                uint4 fx[4], fw[4];
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) fx[mt] = *reinterpret_cast<const uint4*>(la + aaddr[t][mt]);
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) fw[nt] = *reinterpret_cast<const uint4*>(lb + brow[nt]);
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) {
+                    mma4_bf16_inplace(acc[0][nt], acc[1][nt], acc[2][nt], acc[3][nt], fw[nt], fx);
+                    if (nt == 0) {
+                        if (t < 7 && t < ap) issue_a(t < 7 ? t : 0, an, ay, asl, nst, true);
+                    } else if (nt == 1) {
+                        // weight tile of step +3: this slice, the next slice of the tile, or the next tile's first slice
+                        const bool wrap = t + 3 >= 9;
+                        const bool to_next = wrap && last;
+                        issue_b(to_next ? co1 : co0, wrap ? (last ? 0 : s + 1) : s, (t + 3) % 9, (int)((gs + t + 3) & 3),
+                                !to_next || has_next);
+                    }
+                }
+                int extra = ap - t + 1;
+                extra = extra < 0 ? 0 : (extra > 2 ? 2 : extra);
+                if (t == 0) extra = ap > 0 ? 1 : 0;
+                // The epilogue's global stores sit between the DMAs of two tiles and count in vmcnt as well (their
+                // number is not a constant: fully masked stores are skipped).  So the last step of a tile waits one
+                // step deeper -- only its own weight DMAs stay in flight, which covers everything the next tile's first
+                // step needs -- and that first step does not wait at all; from the second step on the usual count is
+                // conservative again (the stores are older than both steps' DMAs).
+                if (last && t == 8) {
+                    if (WN == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                    else         asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+                } else if (!(t == 0 && s == 0 && tile != lid)) {
+                    wait_all_but(extra);
+                }
+                __builtin_amdgcn_s_barrier();
+            }
+        }
+        // ---- epilogue of this tile (identity / ReLU, no bias: the launcher sends everything else to the one-tile
+        //      kernel); the DMAs of the next tile's first steps are already in flight ----
+        mma_drain();
+        const uint32_t co = co0 + wn * 64 + lg * 16;          // the lane's 16 consecutive channels: co + nt*4 + r
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            const int m = wm * 64 + mt * 16 + li;
+            const int rowi = (int)fd_div((uint32_t)m, p.fd_w), tx = m - rowi * p.W;
+            const int ti = (int)fd_div((uint32_t)rowi, p.fd_th), ty = rowi - ti * p.TH;
+            const uint32_t n = n0 + ti;
+            const int y = y0 + ty;
+            uint32_t pk[8];
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                float o[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] = acc[mt][nt][r];
+                acc[mt][nt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+                act_fwd4<true>(o, epi_act);
+                pk[2 * nt] = pack2_bf16(o[0], o[1]);
+                pk[2 * nt + 1] = pack2_bf16(o[2], o[3]);
+            }
+            if (n >= (uint32_t)p.N || y >= p.H) continue;
+            bf16_t* dst = out + ((size_t)(n * p.H + y) * p.W + tx) * p.Cout + co;
+            if (co + 8 <= (uint32_t)p.Cout) *reinterpret_cast<uint4*>(dst) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+            if (co + 16 <= (uint32_t)p.Cout) *reinterpret_cast<uint4*>(dst + 8) = make_uint4(pk[4], pk[5], pk[6], pk[7]);
+        }
+        n0 = n1; y0 = y1; co0 = co1;
+    }
 }
 
 }  // namespace eve

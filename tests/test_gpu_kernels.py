@@ -67,6 +67,7 @@ CONV_CASES = [
     (2, 18, 32, 64, 64, 3, 1, 1),       # RefineNet 18x32 level: ragged last band (18 rows, 8 per tile)
     (5, 8, 8, 64, 48, 3, 1, 1),         # several whole images per tile, Cout not a multiple of 16
     (300, 32, 32, 64, 64, 3, 1, 1),     # more tiles than persistent workgroups
+    (530, 16, 16, 32, 128, 3, 1, 1),    # persistent 2x2-wave kernel (1060 tiles), one slice, two channel blocks... of one
 ]
 
 
