@@ -32,6 +32,9 @@ SIGNATURES = {
     'eve_stem_fwd_fused': [I, I, I, P, P, F, P, P, P, P],
     'eve_stem_bwd_dx': [I, I, I, P, P, P, P, P, P, P, P, P],
     'eve_bias_grad': [I, L, I, P, P, P],
+    'eve_linear_fwd': [I, I, I, P, P, P, I, P, P],
+    'eve_linear_dgrad': [I, I, I, P, P, I, P, P, P],
+    'eve_linear_wgrad': [I, I, I, P, P, I, P, P, P, P],
     'eve_instnorm_stats': [I, I, I, I, P, F, P, P],
     'eve_instnorm_act_fwd': [I, I, I, I, P, P, P, P, P, I, P, P],
     'eve_instnorm_act_bwd': [I, I, I, I, P, P, P, P, P, I, P, P, P, P],

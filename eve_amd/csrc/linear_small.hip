@@ -1,0 +1,170 @@
+// Small float32 linear layers: the EyeNet tail (fc, fc_common, GRU input projection, gaze / pupil heads --
+// /root/reference/src/models/eye_net.py:52-90) works on M = 2*B*T feature rows with K, N <= 512.  Through the
+// 128x128-tile implicit-GEMM kernels such a problem is 15 workgroups of f32 MFMAs (1/16 of the bf16 rate) on a
+// 256-CU part: ~25 us per launch, 32 launches per step.  Here the tile is 16 rows x 128 columns of plain fp32
+// FMAs (exact, same summation order as a dot product over k), 120+ workgroups, and the activation derivative of
+// the backward is applied while loading dy instead of in a separate pass.
+//
+//   eve_linear_fwd     y[M][N]  = act(x[M][K] . wt[K][N] + b)                       wt = IHWO pack ([in][out])
+//   eve_linear_dgrad   dx[M][K] = (dy . act'(y))[M][N] . w[N][K]                    w  = OHWI pack ([out][in])
+//   eve_linear_wgrad   dw[N][K] += (dy . act'(y))^T . x ;  db[N] += column sums     (float atomics over row splits)
+#include "common.h"
+
+namespace eve {
+
+constexpr int LS_TM = 16, LS_TN = 128, LS_KC = 64;
+
+// C[M][Nc] = epi( A'[M][R] . B[R][Nc] ),  A' = A * act'(Y) if Y (same shape as A), epi = act(. + bias)
+__global__ __launch_bounds__(256) void linear_mm_kernel(const float* __restrict__ A, const float* __restrict__ Y, const int pro_act,
+                                                        const float* __restrict__ B, const float* __restrict__ bias,
+                                                        const int epi_act, float* __restrict__ C, const int M, const int R,
+                                                        const int Nc) {
+    __shared__ float sA[LS_TM][LS_KC + 4];
+    const int tid = threadIdx.x;
+    const int col = blockIdx.y * LS_TN + (tid & (LS_TN - 1)), rg = tid >> 7;       // 2 row groups of 8 rows
+    const int m0 = blockIdx.x * LS_TM;
+    float acc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+    for (int k0 = 0; k0 < R; k0 += LS_KC) {
+        // stage A'[m0 .. m0+15][k0 .. k0+63]: 1024 values, 4 per thread
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int e = tid + 256 * i;
+            const int r = e >> 6, kk = e & 63;
+            const int m = m0 + r, k = k0 + kk;
+            float v = 0.f;
+            if (m < M && k < R) {
+                v = A[(size_t)m * R + k];
+                if (Y) v *= act_grad_from_out(Y[(size_t)m * R + k], pro_act);
+            }
+            sA[r][kk] = v;
+        }
+        __syncthreads();
+        const int kmax = min(LS_KC, R - k0);
+        if (col < Nc) {
+            const float* bp = B + (size_t)k0 * Nc + col;
+            for (int kk = 0; kk < kmax; kk += 4) {
+                float b[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) b[j] = kk + j < kmax ? bp[(size_t)(kk + j) * Nc] : 0.f;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const float4 a = *reinterpret_cast<const float4*>(&sA[rg * 8 + i][kk]);
+                    acc[i] = fmaf(a.x, b[0], acc[i]);
+                    acc[i] = fmaf(a.y, b[1], acc[i]);
+                    acc[i] = fmaf(a.z, b[2], acc[i]);
+                    acc[i] = fmaf(a.w, b[3], acc[i]);
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (col >= Nc) return;
+    const float bv = bias ? bias[col] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int m = m0 + rg * 8 + i;
+        if (m < M) C[(size_t)m * Nc + col] = act_fwd(acc[i] + bv, epi_act);
+    }
+}
+
+// dW[N][K] += G^T . X,  db[N] += colsum(G),  G = dY * act'(Y);  block = 32 n x 64 k x one row split
+__global__ __launch_bounds__(256) void linear_wgrad_kernel(const float* __restrict__ dY, const float* __restrict__ Y, const int act,
+                                                           const float* __restrict__ X, float* __restrict__ dW,
+                                                           float* __restrict__ db, const int M, const int N, const int K,
+                                                           const int rows_per_split) {
+    __shared__ float sG[32][32 + 4];                     // [row in chunk][n]
+    const int tid = threadIdx.x;
+    const int k = blockIdx.x * 64 + (tid & 63), ng = tid >> 6;      // 4 groups of 8 output rows
+    const int n0 = blockIdx.y * 32;
+    const int m_begin = blockIdx.z * rows_per_split, m_end = min(M, m_begin + rows_per_split);
+    float acc[8], bsum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+    for (int mc = m_begin; mc < m_end; mc += 32) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int e = tid + 256 * i;
+            const int r = e >> 5, nn = e & 31;
+            const int m = mc + r, n = n0 + nn;
+            float v = 0.f;
+            if (m < m_end && n < N) {
+                v = dY[(size_t)m * N + n];
+                if (Y) v *= act_grad_from_out(Y[(size_t)m * N + n], act);
+            }
+            sG[r][nn] = v;
+        }
+        __syncthreads();
+        const int rmax = min(32, m_end - mc);
+        if (k < K) {
+            for (int r = 0; r < rmax; ++r) {
+                const float xv = X[(size_t)(mc + r) * K + k];
+                const float4 g0 = *reinterpret_cast<const float4*>(&sG[r][ng * 8]);
+                const float4 g1 = *reinterpret_cast<const float4*>(&sG[r][ng * 8 + 4]);
+                acc[0] = fmaf(g0.x, xv, acc[0]); acc[1] = fmaf(g0.y, xv, acc[1]);
+                acc[2] = fmaf(g0.z, xv, acc[2]); acc[3] = fmaf(g0.w, xv, acc[3]);
+                acc[4] = fmaf(g1.x, xv, acc[4]); acc[5] = fmaf(g1.y, xv, acc[5]);
+                acc[6] = fmaf(g1.z, xv, acc[6]); acc[7] = fmaf(g1.w, xv, acc[7]);
+            }
+        }
+        if (db && blockIdx.x == 0 && tid < 32)
+            for (int r = 0; r < rmax; ++r) bsum += sG[r][tid];
+        __syncthreads();
+    }
+    if (k < K) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int n = n0 + ng * 8 + i;
+            if (n < N) atomicAdd(dW + (size_t)n * K + k, acc[i]);
+        }
+    }
+    if (db && blockIdx.x == 0 && tid < 32 && n0 + tid < N) atomicAdd(db + n0 + tid, bsum);
+}
+
+}  // namespace eve
+
+using namespace eve;
+
+static int ls_check(int M, int K, int N, const char* what) {
+    if (M <= 0 || K <= 0 || N <= 0 || K > 4096 || N > 4096) return set_error_msg(what);
+    return 0;
+}
+
+extern "C" int eve_linear_fwd(int M, int K, int N, const float* x, const float* w_in_out, const float* bias, int act,
+                              float* y, eve_stream_t stream) {
+    if (int e = ls_check(M, K, N, "linear_fwd: bad shape")) return e;
+    if (!x || !w_in_out || !y) return set_error_msg("linear_fwd: null pointer");
+    hipLaunchKernelGGL(linear_mm_kernel, dim3((M + LS_TM - 1) / LS_TM, (N + LS_TN - 1) / LS_TN), dim3(256), 0, (hipStream_t)stream,
+                       x, (const float*)nullptr, 0, w_in_out, bias, act, y, M, K, N);
+    EVE_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int eve_linear_dgrad(int M, int K, int N, const float* dy, const float* y, int act, const float* w_out_in,
+                                float* dx, eve_stream_t stream) {
+    if (int e = ls_check(M, K, N, "linear_dgrad: bad shape")) return e;
+    if (!dy || !w_out_in || !dx || (act != EVE_ACT_NONE && !y)) return set_error_msg("linear_dgrad: null pointer");
+    hipLaunchKernelGGL(linear_mm_kernel, dim3((M + LS_TM - 1) / LS_TM, (K + LS_TN - 1) / LS_TN), dim3(256), 0, (hipStream_t)stream,
+                       dy, act != EVE_ACT_NONE ? y : (const float*)nullptr, act, w_out_in, (const float*)nullptr, 0, dx, M, N, K);
+    EVE_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int eve_linear_wgrad(int M, int K, int N, const float* dy, const float* y, int act, const float* x, float* dw_out_in,
+                                float* db, eve_stream_t stream) {
+    if (int e = ls_check(M, K, N, "linear_wgrad: bad shape")) return e;
+    if (!dy || !x || !dw_out_in || (act != EVE_ACT_NONE && !y)) return set_error_msg("linear_wgrad: null pointer");
+    const int tiles = ((K + 63) / 64) * ((N + 31) / 32);
+    int splits = (512 + tiles - 1) / tiles;                  // ~2 workgroups per CU
+    const int max_splits = (M + 63) / 64;
+    if (splits > max_splits) splits = max_splits;
+    if (splits < 1) splits = 1;
+    int rows = (M + splits - 1) / splits;
+    rows = (rows + 31) / 32 * 32;
+    splits = (M + rows - 1) / rows;
+    hipLaunchKernelGGL(linear_wgrad_kernel, dim3((K + 63) / 64, (N + 31) / 32, splits), dim3(256), 0, (hipStream_t)stream, dy,
+                       act != EVE_ACT_NONE ? y : (const float*)nullptr, act, x, dw_out_in, db, M, N, K, rows);
+    EVE_CHECK_LAUNCH();
+    return 0;
+}

@@ -208,6 +208,35 @@ class HipKernels(object):
             self._p(dy_pool2), self._p(y_pool), self._p(idx), self._p(dx), self._stream())))
         return dx
 
+    # ------------------------------------------------------------------ small float32 linear layers
+    def linear_fwd(self, x, w_in_out, bias, act):
+        M, K = x.shape
+        N = w_in_out.shape[1]
+        assert x.dtype == torch.float32 and w_in_out.dtype == torch.float32 and w_in_out.shape[0] == K
+        assert x.is_contiguous() and w_in_out.is_contiguous()
+        y = torch.empty((M, N), dtype=torch.float32, device=x.device)
+        self._ck(self.lib.eve_linear_fwd(M, K, N, self._p(x), self._p(w_in_out), self._p(self._f32(bias, 'bias')), act,
+                                         self._p(y), self._stream()))
+        return y
+
+    def linear_dgrad(self, dy, y, act, w_out_in):
+        M, N = dy.shape
+        K = w_out_in.shape[1]
+        assert dy.dtype == torch.float32 and dy.is_contiguous() and tuple(w_out_in.shape) == (N, K)
+        dx = torch.empty((M, K), dtype=torch.float32, device=dy.device)
+        self._ck(self.lib.eve_linear_dgrad(M, K, N, self._p(dy), self._p(y), act, self._p(w_out_in), self._p(dx),
+                                           self._stream()))
+        return dx
+
+    def linear_wgrad(self, dy, y, act, x, dw_out_in, db):
+        """Accumulates into dw_out_in [N, K] (and db [N] when given)."""
+        M, N = dy.shape
+        K = x.shape[1]
+        assert tuple(dw_out_in.shape) == (N, K) and dw_out_in.dtype == torch.float32 and dw_out_in.is_contiguous()
+        assert x.is_contiguous() and dy.is_contiguous() and (db is None or (db.numel() == N and db.is_contiguous()))
+        self._ck(self.lib.eve_linear_wgrad(M, K, N, self._p(dy), self._p(y), act, self._p(x), self._p(dw_out_in),
+                                           self._p(db), self._stream()))
+
     def bias_grad(self, dy, db):
         C = dy.shape[-1]
         M = dy.numel() // C

@@ -167,9 +167,67 @@ def conv2d(x, weight, bias, pack, stride=1, pad=0, act=ACT_NONE):
     return Conv2dFn.apply(x, weight, bias, pack, stride, pad, act)
 
 
+class LinearFn(torch.autograd.Function):
+    """y = act(x W^T + b) for the float32 tail (nn.Linear): small-tile FMA kernels, the activation derivative is
+    applied while the backward kernels load dy.  x: [M, Cin_padded]; pack as for Conv2dFn (1x1)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, pack, act):
+        k = default_kernels()
+        cout_p, _, _, cin_p = pack.ohwi.shape
+        b = None
+        if bias is not None:
+            b = bias.detach().float()
+            if b.numel() != cout_p:
+                b = torch.nn.functional.pad(b, (0, cout_p - b.numel()))
+            b = b.contiguous()
+        y = k.linear_fwd(x.contiguous(), pack.ihwo.view(cin_p, cout_p), b, act)
+        ctx.pack, ctx.act, ctx.has_bias = pack, act, bias is not None
+        ctx.wshape = tuple(weight.shape)
+        ctx.w_direct = weight if _direct_grad_ok(weight) else None
+        ctx.b_direct = bias if (bias is not None and _direct_grad_ok(bias)) else None
+        ctx.save_for_backward(x, y if act != ACT_NONE else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        k = default_kernels()
+        x, y = ctx.saved_tensors
+        pack, act = ctx.pack, ctx.act
+        cout_p, _, _, cin_p = pack.ohwi.shape
+        O, I = pack.shape_oihw[0], pack.shape_oihw[1]
+        dy = dy.contiguous()
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = k.linear_dgrad(dy, y, act, pack.ohwi.view(cout_p, cin_p))
+        want_w, want_b = ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]
+        if want_w or want_b:
+            wp, bp = ctx.w_direct, ctx.b_direct
+            w_dir = wp is not None and (cout_p, cin_p) == (O, I)
+            b_dir = want_b and bp is not None and cout_p == O
+            dwbuf = wp.grad.view(O, I) if w_dir else torch.zeros((cout_p, cin_p), dtype=torch.float32, device=x.device)
+            dbbuf = None
+            if want_b:
+                dbbuf = bp.grad if b_dir else torch.zeros((cout_p,), dtype=torch.float32, device=x.device)
+            k.linear_wgrad(dy, y, act, x.contiguous(), dwbuf, dbbuf)
+            if w_dir:
+                _notify_grad_ready(wp)
+            elif want_w:
+                dw = dwbuf[:O, :I].reshape(ctx.wshape)
+            if b_dir:
+                _notify_grad_ready(bp)
+            elif want_b:
+                db = dbbuf[:O]
+        return dx, dw, db, None, None
+
+
 def linear(x2d, weight, bias, pack, act=ACT_NONE):
-    """x2d: [M, Cin_padded] -> [M, Cout_padded] through the same implicit-GEMM kernel (1x1 conv)."""
+    """x2d: [M, Cin_padded] -> [M, Cout_padded].  float32 (the EyeNet tail) goes through the small-tile FMA kernels,
+    anything else through the implicit-GEMM kernel as a 1x1 conv."""
     M, C = x2d.shape
+    if x2d.dtype == torch.float32 and pack.ohwi.dtype == torch.float32 and pack.ihwo is not None \
+            and os.environ.get('EVE_AMD_SMALL_LINEAR', '1') != '0':
+        return LinearFn.apply(x2d, weight, bias, pack, act)
     y = Conv2dFn.apply(x2d.view(M, 1, 1, C), weight, bias, pack, 1, 0, act)
     return y.view(M, y.shape[-1])
 

@@ -91,6 +91,17 @@ int eve_stem_fwd_fused(int N, int IH, int IW, const void* x_padded, const void* 
  * the convolution from x_padded (autograd of bn1/relu/maxpool in eye_net.py:106); feed dx to eve_conv2d_wgrad. */
 int eve_stem_bwd_dx(int N, int IH, int IW, const void* x_padded, const void* w_ohwi8, const float* mean_rstd,
                     const void* dy_pool, const void* dy_pool2 /* nullable second summand */, const void* y_pool, const uint8_t* idx, void* dx, eve_stream_t stream);
+/* Small float32 linear layers (nn.Linear of the EyeNet tail, eye_net.py:52-90: fc, fc_common, GRU input
+ * projection, gaze / pupil heads) with M rows and K, N <= 4096:
+ *   fwd:   y[M][N]   = act(x[M][K] . w_in_out[K][N] + bias)
+ *   dgrad: dx[M][K]  = (dy * act'(y))[M][N] . w_out_in[N][K]          (y may be NULL when act is NONE)
+ *   wgrad: dw[N][K] += (dy * act'(y))^T . x ;  db[N] += column sums    (db nullable; float atomics)          */
+int eve_linear_fwd(int M, int K, int N, const float* x, const float* w_in_out, const float* bias, int act,
+                   float* y, eve_stream_t stream);
+int eve_linear_dgrad(int M, int K, int N, const float* dy, const float* y, int act, const float* w_out_in,
+                     float* dx, eve_stream_t stream);
+int eve_linear_wgrad(int M, int K, int N, const float* dy, const float* y, int act, const float* x,
+                     float* dw_out_in, float* db, eve_stream_t stream);
 /* db[C] (float, accumulated) += sum over the M = N*OH*OW rows of dy[M][C]                         */
 int eve_bias_grad(int dtype, long long M, int C, const void* dy, float* db, eve_stream_t stream);
 

@@ -93,6 +93,22 @@ class FakeKernels(object):
             dy_pool = (dy_pool.float() + dy_pool2.float()).to(dy_pool.dtype)
         return self.in_relu_maxpool_bwd(dy_pool, y_pool, idx, self.stem7x7s2_fwd(x_padded, w_ohwi8), mr)
 
+    def linear_fwd(self, x, w_in_out, bias, act):
+        z = x @ w_in_out
+        if bias is not None:
+            z = z + bias
+        return act_fwd(z, act)
+
+    def linear_dgrad(self, dy, y, act, w_out_in):
+        g = dy * act_grad_from_out(y, act) if act != ACT_NONE else dy
+        return g @ w_out_in
+
+    def linear_wgrad(self, dy, y, act, x, dw_out_in, db):
+        g = dy * act_grad_from_out(y, act) if act != ACT_NONE else dy
+        dw_out_in += g.t() @ x
+        if db is not None:
+            db += g.sum(0)
+
     def bias_grad(self, dy, db):
         db += dy.float().reshape(-1, dy.shape[-1]).sum(0)
         return db

@@ -194,6 +194,31 @@ def test_stem_fused_backward_matches_unfused(hip, N):
     assert (a - b).abs().max().item() < 0.05 * b.abs().max().item()
 
 
+@pytest.mark.parametrize('shape', [(1920, 512, 128), (37, 130, 128), (60, 128, 384), (1920, 128, 4), (5, 7, 3)],
+                         ids=lambda s: 'x'.join(map(str, s)))
+@pytest.mark.parametrize('act', [0, 1, 3, 4], ids=['none', 'relu', 'selu', 'tanh'])
+def test_small_linear_kernels(hip, ref, shape, act):
+    """float32 nn.Linear of the EyeNet tail: forward, data gradient and weight/bias gradient."""
+    M, K, N = shape
+    x = rnd((M, K), torch.float32, 70)
+    w = rnd((N, K), torch.float32, 71, scale=(1.0 / K) ** 0.5)          # [out, in]
+    b = rnd((N,), torch.float32, 72)
+    wt = w.t().contiguous()
+    y_ref = ref.linear_fwd(x, wt, b, act)
+    y = hip.linear_fwd(dev(x), dev(wt), dev(b), act)
+    assert torch.allclose(y.cpu(), y_ref, rtol=2e-5, atol=2e-5)
+    dy = rnd((M, N), torch.float32, 73)
+    dx_ref = ref.linear_dgrad(dy, y_ref, act, w)
+    dx = hip.linear_dgrad(dev(dy), y, act, dev(w))
+    assert torch.allclose(dx.cpu(), dx_ref, rtol=1e-4, atol=2e-5)
+    dw_ref, db_ref = torch.ones((N, K)), torch.ones((N,))
+    ref.linear_wgrad(dy, y_ref, act, x, dw_ref, db_ref)
+    dw, db = torch.ones((N, K), device='cuda'), torch.ones((N,), device='cuda')
+    hip.linear_wgrad(dev(dy), y, act, dev(x), dw, db)
+    assert torch.allclose(dw.cpu(), dw_ref, rtol=2e-4, atol=2e-4 * (M ** 0.5))
+    assert torch.allclose(db.cpu(), db_ref, rtol=2e-4, atol=2e-4 * (M ** 0.5))
+
+
 def test_conv_rejects_bad_shapes(hip):
     x = torch.zeros((1, 8, 8, 6), device='cuda')
     w = torch.zeros((8, 3, 3, 6), device='cuda')
