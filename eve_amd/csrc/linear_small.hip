@@ -12,53 +12,65 @@
 
 namespace eve {
 
-constexpr int LS_TM = 16, LS_TN = 128, LS_KC = 64;
+constexpr int LS_TM = 16, LS_TN = 128, LS_KC = 32;
 
-// C[M][Nc] = epi( A'[M][R] . B[R][Nc] ),  A' = A * act'(Y) if Y (same shape as A), epi = act(. + bias)
+// C[M][Nc] = epi( A'[M][R] . B[R][Nc] ),  A' = A * act'(Y) if Y (same shape as A), epi = act(. + bias).
+// Both operand chunks go through LDS; the next chunk is fetched into registers while the current one is consumed
+// (each workgroup is alone on its SIMDs, so nothing else hides the L2 latency).
 __global__ __launch_bounds__(256) void linear_mm_kernel(const float* __restrict__ A, const float* __restrict__ Y, const int pro_act,
                                                         const float* __restrict__ B, const float* __restrict__ bias,
                                                         const int epi_act, float* __restrict__ C, const int M, const int R,
                                                         const int Nc) {
     __shared__ float sA[LS_TM][LS_KC + 4];
+    __shared__ float sB[LS_KC][LS_TN];
     const int tid = threadIdx.x;
-    const int col = blockIdx.y * LS_TN + (tid & (LS_TN - 1)), rg = tid >> 7;       // 2 row groups of 8 rows
+    const int c0 = blockIdx.y * LS_TN;
+    const int col = c0 + (tid & (LS_TN - 1)), rg = tid >> 7;                  // 2 row groups of 8 rows
     const int m0 = blockIdx.x * LS_TM;
-    float acc[8];
+    // staging slots: A' 16 x 32 = 512 values (2 per thread), B 32 x 128 = 4096 values (16 per thread)
+    const int ar = tid >> 5, ak = tid & 31;                                     // rows ar and ar + 8
+    const int bc = tid & 127, bk = tid >> 7;                                    // k rows bk, bk + 2, ...
+    float pa[2], pb[16];
+    auto fetch = [&](int k0) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) acc[i] = 0.f;
-    for (int k0 = 0; k0 < R; k0 += LS_KC) {
-        // stage A'[m0 .. m0+15][k0 .. k0+63]: 1024 values, 4 per thread
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int e = tid + 256 * i;
-            const int r = e >> 6, kk = e & 63;
-            const int m = m0 + r, k = k0 + kk;
+        for (int i = 0; i < 2; ++i) {
+            const int m = m0 + ar + 8 * i, k = k0 + ak;
             float v = 0.f;
             if (m < M && k < R) {
                 v = A[(size_t)m * R + k];
                 if (Y) v *= act_grad_from_out(Y[(size_t)m * R + k], pro_act);
             }
-            sA[r][kk] = v;
+            pa[i] = v;
         }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int k = k0 + bk + 2 * i;
+            pb[i] = (k < R && c0 + bc < Nc) ? B[(size_t)k * Nc + c0 + bc] : 0.f;
+        }
+    };
+    float acc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+    fetch(0);
+    for (int k0 = 0; k0 < R; k0 += LS_KC) {
+        __syncthreads();                                   // previous chunk fully consumed
+        sA[ar][ak] = pa[0]; sA[ar + 8][ak] = pa[1];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) sB[bk + 2 * i][bc] = pb[i];
         __syncthreads();
-        const int kmax = min(LS_KC, R - k0);
-        if (col < Nc) {
-            const float* bp = B + (size_t)k0 * Nc + col;
-            for (int kk = 0; kk < kmax; kk += 4) {
-                float b[4];
+        if (k0 + LS_KC < R) fetch(k0 + LS_KC);             // in flight during the FMAs below
 #pragma unroll
-                for (int j = 0; j < 4; ++j) b[j] = kk + j < kmax ? bp[(size_t)(kk + j) * Nc] : 0.f;
+        for (int kk = 0; kk < LS_KC; kk += 4) {
+            const float b0 = sB[kk][tid & 127], b1 = sB[kk + 1][tid & 127], b2 = sB[kk + 2][tid & 127], b3 = sB[kk + 3][tid & 127];
 #pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const float4 a = *reinterpret_cast<const float4*>(&sA[rg * 8 + i][kk]);
-                    acc[i] = fmaf(a.x, b[0], acc[i]);
-                    acc[i] = fmaf(a.y, b[1], acc[i]);
-                    acc[i] = fmaf(a.z, b[2], acc[i]);
-                    acc[i] = fmaf(a.w, b[3], acc[i]);
-                }
+            for (int i = 0; i < 8; ++i) {
+                const float4 a = *reinterpret_cast<const float4*>(&sA[rg * 8 + i][kk]);
+                acc[i] = fmaf(a.x, b0, acc[i]);
+                acc[i] = fmaf(a.y, b1, acc[i]);
+                acc[i] = fmaf(a.z, b2, acc[i]);
+                acc[i] = fmaf(a.w, b3, acc[i]);
             }
         }
-        __syncthreads();
     }
     if (col >= Nc) return;
     const float bv = bias ? bias[col] : 0.f;
@@ -83,6 +95,7 @@ __global__ __launch_bounds__(256) void linear_wgrad_kernel(const float* __restri
 #pragma unroll
     for (int i = 0; i < 8; ++i) acc[i] = 0.f;
     for (int mc = m_begin; mc < m_end; mc += 32) {
+        float g4[4], xr[8];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int e = tid + 256 * i;
@@ -93,15 +106,22 @@ __global__ __launch_bounds__(256) void linear_wgrad_kernel(const float* __restri
                 v = dY[(size_t)m * N + n];
                 if (Y) v *= act_grad_from_out(Y[(size_t)m * N + n], act);
             }
-            sG[r][nn] = v;
+            g4[i] = v;
         }
+        __syncthreads();                                   // previous chunk consumed
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { const int e = tid + 256 * i; sG[e >> 5][e & 31] = g4[i]; }
         __syncthreads();
         const int rmax = min(32, m_end - mc);
-        if (k < K) {
-            for (int r = 0; r < rmax; ++r) {
-                const float xv = X[(size_t)(mc + r) * K + k];
-                const float4 g0 = *reinterpret_cast<const float4*>(&sG[r][ng * 8]);
-                const float4 g1 = *reinterpret_cast<const float4*>(&sG[r][ng * 8 + 4]);
+#pragma unroll
+        for (int r0 = 0; r0 < 32; r0 += 8) {               // 8 row loads in flight at a time
+#pragma unroll
+            for (int j = 0; j < 8; ++j) xr[j] = (k < K && r0 + j < rmax) ? X[(size_t)(mc + r0 + j) * K + k] : 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float xv = xr[j];
+                const float4 g0 = *reinterpret_cast<const float4*>(&sG[r0 + j][ng * 8]);
+                const float4 g1 = *reinterpret_cast<const float4*>(&sG[r0 + j][ng * 8 + 4]);
                 acc[0] = fmaf(g0.x, xv, acc[0]); acc[1] = fmaf(g0.y, xv, acc[1]);
                 acc[2] = fmaf(g0.z, xv, acc[2]); acc[3] = fmaf(g0.w, xv, acc[3]);
                 acc[4] = fmaf(g1.x, xv, acc[4]); acc[5] = fmaf(g1.y, xv, acc[5]);
@@ -110,7 +130,6 @@ __global__ __launch_bounds__(256) void linear_wgrad_kernel(const float* __restri
         }
         if (db && blockIdx.x == 0 && tid < 32)
             for (int r = 0; r < rmax; ++r) bsum += sG[r][tid];
-        __syncthreads();
     }
     if (k < K) {
 #pragma unroll
