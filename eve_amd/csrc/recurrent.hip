@@ -87,6 +87,120 @@ __global__ void gru_scan_bwd_kernel(int T, int H, const float* __restrict__ dhs,
 }
 
 // ---------------------------------------------------------------------------------------------------
+// H = 128 (the configured eye_net_rnn_num_features): the recurrent weights live in REGISTERS -- thread j keeps
+// column j of W_hh^T (128 floats) for all T steps instead of re-reading 192 KB from L1/L2 every step -- and the
+// per-step operands of the NEXT step are fetched while the current dot products run.  One workgroup per sequence.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(384) void gru_scan_fwd128_kernel(int T, const float* __restrict__ gi, const float* __restrict__ whh_t,
+                                                              const float* __restrict__ bhh, const float* __restrict__ h0,
+                                                              float* __restrict__ hs, float* __restrict__ gates,
+                                                              float* __restrict__ hn_pre) {
+    constexpr int H = 128, H3 = 384;
+    __shared__ __attribute__((aligned(16))) float h[H];
+    __shared__ float gh[H3];
+    const int s = blockIdx.x, j = threadIdx.x;
+    float w[H];
+#pragma unroll
+    for (int k = 0; k < H; ++k) w[k] = whh_t[(size_t)k * H3 + j];
+    const float b = bhh[j];
+    if (j < H) h[j] = h0 ? h0[(size_t)s * H + j] : 0.f;
+    const float* g = gi + (size_t)s * T * H3;
+    float g0 = 0.f, g1 = 0.f, g2 = 0.f;
+    if (j < H) { g0 = g[j]; g1 = g[H + j]; g2 = g[2 * H + j]; }
+    __syncthreads();
+    for (int t = 0; t < T; ++t) {
+        float n0 = 0.f, n1 = 0.f, n2 = 0.f;                  // the next step's input projections, in flight during the dot
+        if (j < H && t + 1 < T) {
+            const float* gn = g + (size_t)(t + 1) * H3;
+            n0 = gn[j]; n1 = gn[H + j]; n2 = gn[2 * H + j];
+        }
+        float a = b;
+#pragma unroll
+        for (int k = 0; k < H; k += 4) {
+            const float4 hv = *reinterpret_cast<const float4*>(&h[k]);
+            a = fmaf(w[k], hv.x, a); a = fmaf(w[k + 1], hv.y, a); a = fmaf(w[k + 2], hv.z, a); a = fmaf(w[k + 3], hv.w, a);
+        }
+        gh[j] = a;
+        __syncthreads();
+        float hnew = 0.f;
+        if (j < H) {
+            const float r = sigmoidf_(g0 + gh[j]);
+            const float z = sigmoidf_(g1 + gh[H + j]);
+            const float n = tanhf(g2 + r * gh[2 * H + j]);
+            hnew = (1.f - z) * n + z * h[j];
+            const size_t o = (size_t)s * T + t;
+            float* go = gates + o * H3;
+            go[j] = r; go[H + j] = z; go[2 * H + j] = n;
+            hn_pre[o * H + j] = gh[2 * H + j];
+            hs[o * H + j] = hnew;
+        }
+        __syncthreads();
+        if (j < H) h[j] = hnew;
+        g0 = n0; g1 = n1; g2 = n2;
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(384) void gru_scan_bwd128_kernel(int T, const float* __restrict__ dhs, const float* __restrict__ whh,
+                                                              const float* __restrict__ h0, const float* __restrict__ hs,
+                                                              const float* __restrict__ gates, const float* __restrict__ hn_pre,
+                                                              float* __restrict__ dgi, float* __restrict__ dgh,
+                                                              float* __restrict__ dh0) {
+    constexpr int H = 128, H3 = 384;
+    __shared__ float dh[H];
+    __shared__ __attribute__((aligned(16))) float dg[H3];
+    __shared__ float part[3][H];
+    const int s = blockIdx.x, tid = threadIdx.x;
+    const int j = tid & (H - 1), pq = tid >> 7;               // this thread sums rows 128*pq .. 128*pq+127 of W_hh, column j
+    float w[H];
+#pragma unroll
+    for (int q = 0; q < H; ++q) w[q] = whh[(size_t)(pq * H + q) * H + j];
+    if (tid < H) dh[tid] = 0.f;
+    // operands of step t (threads < H): dhs, r, z, n, h_{t-1}, hn_pre
+    float c_d = 0.f, c_r = 0.f, c_z = 0.f, c_n = 0.f, c_hp = 0.f, c_hn = 0.f;
+    auto load_step = [&](int t, float& d, float& r, float& z, float& n, float& hp, float& hn) {
+        const size_t o = (size_t)s * T + t;
+        d = dhs[o * H + tid];
+        const float* gt = gates + o * H3;
+        r = gt[tid]; z = gt[H + tid]; n = gt[2 * H + tid];
+        hp = t > 0 ? hs[(o - 1) * H + tid] : (h0 ? h0[(size_t)s * H + tid] : 0.f);
+        hn = hn_pre[o * H + tid];
+    };
+    if (tid < H) load_step(T - 1, c_d, c_r, c_z, c_n, c_hp, c_hn);
+    __syncthreads();
+    for (int t = T - 1; t >= 0; --t) {
+        float n_d = 0.f, n_r = 0.f, n_z = 0.f, n_n = 0.f, n_hp = 0.f, n_hn = 0.f, direct = 0.f;
+        if (tid < H) {
+            if (t > 0) load_step(t - 1, n_d, n_r, n_z, n_n, n_hp, n_hn);        // in flight during this step
+            const size_t o = (size_t)s * T + t;
+            const float d = dh[tid] + c_d;
+            const float dn_pre = d * (1.f - c_z) * (1.f - c_n * c_n);
+            const float dz_pre = d * (c_hp - c_n) * c_z * (1.f - c_z);
+            const float dr_pre = dn_pre * c_hn * c_r * (1.f - c_r);
+            float* gi_o = dgi + o * H3;
+            float* gh_o = dgh + o * H3;
+            gi_o[tid] = dr_pre; gi_o[H + tid] = dz_pre; gi_o[2 * H + tid] = dn_pre;
+            gh_o[tid] = dr_pre; gh_o[H + tid] = dz_pre; gh_o[2 * H + tid] = dn_pre * c_r;
+            dg[tid] = dr_pre; dg[H + tid] = dz_pre; dg[2 * H + tid] = dn_pre * c_r;
+            direct = d * c_z;
+        }
+        __syncthreads();
+        float a = 0.f;
+#pragma unroll
+        for (int q = 0; q < H; q += 4) {
+            const float4 v = *reinterpret_cast<const float4*>(&dg[pq * H + q]);
+            a = fmaf(w[q], v.x, a); a = fmaf(w[q + 1], v.y, a); a = fmaf(w[q + 2], v.z, a); a = fmaf(w[q + 3], v.w, a);
+        }
+        part[pq][j] = a;
+        __syncthreads();
+        if (tid < H) dh[tid] = direct + part[0][tid] + part[1][tid] + part[2][tid];
+        c_d = n_d; c_r = n_r; c_z = n_z; c_n = n_n; c_hp = n_hp; c_hn = n_hn;
+        __syncthreads();
+    }
+    if (dh0 && tid < H) dh0[(size_t)s * H + tid] = dh[tid];
+}
+
+// ---------------------------------------------------------------------------------------------------
 // conv-GRU element-wise gate kernels; P pixels, C hidden channels, NHWC
 // ---------------------------------------------------------------------------------------------------
 template <typename T>
@@ -229,6 +343,12 @@ extern "C" int eve_gru_scan_fwd(int S, int T, int H, const float* gi, const floa
                                 const float* h0, float* hs, float* gates, float* hn_pre, eve_stream_t stream) {
     if (S <= 0 || T <= 0 || H <= 0 || H > 256 || !gi || !whh_t || !bhh || !hs || !gates || !hn_pre)
         return set_error_msg("gru_scan_fwd: bad arguments (H <= 256)");
+    if (H == 128) {
+        hipLaunchKernelGGL(gru_scan_fwd128_kernel, dim3(S), dim3(384), 0, (hipStream_t)stream, T, gi, whh_t, bhh, h0, hs, gates,
+                           hn_pre);
+        EVE_CHECK_LAUNCH();
+        return 0;
+    }
     const int threads = ((3 * H + 63) / 64) * 64;
     hipLaunchKernelGGL(gru_scan_fwd_kernel, dim3(S), dim3(threads), 4 * H * sizeof(float), (hipStream_t)stream,
                        T, H, gi, whh_t, bhh, h0, hs, gates, hn_pre);
@@ -240,6 +360,12 @@ extern "C" int eve_gru_scan_bwd(int S, int T, int H, const float* dhs, const flo
                                 float* dh0, eve_stream_t stream) {
     if (S <= 0 || T <= 0 || H <= 0 || H > 256 || !dhs || !whh || !hs || !gates || !hn_pre || !dgi || !dgh)
         return set_error_msg("gru_scan_bwd: bad arguments (H <= 256)");
+    if (H == 128) {
+        hipLaunchKernelGGL(gru_scan_bwd128_kernel, dim3(S), dim3(384), 0, (hipStream_t)stream, T, dhs, whh, h0, hs, gates, hn_pre,
+                           dgi, dgh, dh0);
+        EVE_CHECK_LAUNCH();
+        return 0;
+    }
     const int threads = ((3 * H + 63) / 64) * 64;
     hipLaunchKernelGGL(gru_scan_bwd_kernel, dim3(S), dim3(threads), 4 * H * sizeof(float), (hipStream_t)stream,
                        T, H, dhs, whh, h0, hs, gates, hn_pre, dgi, dgh, dh0);

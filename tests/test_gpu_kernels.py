@@ -340,8 +340,9 @@ def test_layout_and_pack(hip, ref, dtype):
     close(hip.cast(dev(w), dtype), w.to(dtype), dtype, 'cast')
 
 
-def test_gru_scan(hip, ref):
-    S, T, H = 5, 7, 128
+@pytest.mark.parametrize('H', [128, 96], ids=['h128_register_resident', 'h96_generic'])
+def test_gru_scan(hip, ref, H):
+    S, T = 5, 7
     gi = rnd((S, T, 3 * H), torch.float32, 31)
     whh = rnd((3 * H, H), torch.float32, 32, scale=H ** -0.5)
     bhh = rnd((3 * H,), torch.float32, 33, scale=0.1)
