@@ -32,6 +32,7 @@ SIGNATURES = {
     'eve_stem_fwd_fused': [I, I, I, P, P, F, P, P, P, P],
     'eve_stem_bwd_dx': [I, I, I, P, P, P, P, P, P, P, P, P],
     'eve_bias_grad': [I, L, I, P, P, P],
+    'eve_eye_losses': [I, I, P, P, P, P, P, P, F, F, P, P, P, P],
     'eve_linear_fwd': [I, I, I, P, P, P, I, P, P],
     'eve_linear_dgrad': [I, I, I, P, P, I, P, P, P],
     'eve_linear_wgrad': [I, I, I, P, P, I, P, P, P, P],

@@ -208,6 +208,38 @@ class HipKernels(object):
             self._p(dy_pool2), self._p(y_pool), self._p(idx), self._p(dx), self._stream())))
         return dx
 
+    # ------------------------------------------------------------------ fused train-step losses
+    def eye_losses(self, g_pred, g_tgt, g_val, p_pred, p_tgt, p_val, coeff_ang, coeff_l1):
+        """Each argument is a (left, right) pair.  Returns terms[5], (dg_l, dg_r), (dp_l, dp_r)."""
+        B, T = p_pred[0].shape
+        dev = p_pred[0].device
+
+        def pair(ts, dtype, shape):
+            out = []
+            for t in ts:
+                t = t.contiguous()
+                if dtype == torch.uint8:
+                    t = t.view(torch.uint8) if t.dtype == torch.bool else t.to(torch.uint8)
+                assert t.dtype == dtype and tuple(t.shape) == shape and t.is_cuda, (t.dtype, t.shape)
+                out.append(t)
+            return out, (ctypes.c_void_p * 2)(*[t.data_ptr() for t in out])
+
+        keep = []
+        ptrs = []
+        for ts, dt, shp in ((g_pred, torch.float32, (B, T, 2)), (g_tgt, torch.float32, (B, T, 2)), (g_val, torch.uint8, (B, T)),
+                            (p_pred, torch.float32, (B, T)), (p_tgt, torch.float32, (B, T)), (p_val, torch.uint8, (B, T))):
+            k_, a = pair(ts, dt, shp)
+            keep.append(k_)
+            ptrs.append(a)
+        terms = torch.zeros((5,), dtype=torch.float32, device=dev)
+        dg = [torch.empty((B, T, 2), dtype=torch.float32, device=dev) for _ in range(2)]
+        dp = [torch.empty((B, T), dtype=torch.float32, device=dev) for _ in range(2)]
+        dg_a = (ctypes.c_void_p * 2)(*[t.data_ptr() for t in dg])
+        dp_a = (ctypes.c_void_p * 2)(*[t.data_ptr() for t in dp])
+        self._ck(self.lib.eve_eye_losses(B, T, ptrs[0], ptrs[1], ptrs[2], ptrs[3], ptrs[4], ptrs[5], float(coeff_ang),
+                                         float(coeff_l1), self._p(terms), dg_a, dp_a, self._stream()))
+        return terms, dg, dp
+
     # ------------------------------------------------------------------ small float32 linear layers
     def linear_fwd(self, x, w_in_out, bias, act):
         M, K = x.shape

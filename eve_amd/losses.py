@@ -50,8 +50,54 @@ def bce_loss(pred, target, validity):
     return _masked_clip_mean(_per_step(F.binary_cross_entropy(pred, target, reduction='none')), validity)
 
 
+class EyeLossesFn(torch.autograd.Function):
+    """All four EyeNet loss terms, their weighted sum and the gradients w.r.t. the predictions from one kernel
+    (kernels.eye_losses); returns terms[5] = ang_l, l1_l, ang_r, l1_r, full."""
+
+    @staticmethod
+    def forward(ctx, g_l, g_r, p_l, p_r, tgt, c_ang, c_l1):
+        from .kernels import default_kernels
+        tg_l, tg_r, vg_l, vg_r, tp_l, tp_r, vp_l, vp_r = tgt
+        terms, dg, dp = default_kernels().eye_losses((g_l, g_r), (tg_l, tg_r), (vg_l, vg_r), (p_l, p_r), (tp_l, tp_r),
+                                                     (vp_l, vp_r), c_ang, c_l1)
+        ctx.coeffs = (c_ang, c_l1)
+        ctx.set_materialize_grads(False)
+        ctx.save_for_backward(dg[0], dg[1], dp[0], dp[1])
+        return tuple(terms.unbind(0))
+
+    @staticmethod
+    def backward(ctx, g_ang_l, g_l1_l, g_ang_r, g_l1_r, g_full):
+        dg_l, dg_r, dp_l, dp_r = ctx.saved_tensors
+        c_ang, c_l1 = ctx.coeffs
+
+        def scaled(unit, g_term, coeff):                      # unit * (g_term + coeff * g_full); usually only g_full is set
+            w = None
+            if g_full is not None:
+                w = g_full * coeff
+            if g_term is not None:
+                w = g_term if w is None else w + g_term
+            return unit * w if w is not None else None
+
+        return (scaled(dg_l, g_ang_l, c_ang), scaled(dg_r, g_ang_r, c_ang), scaled(dp_l, g_l1_l, c_l1),
+                scaled(dp_r, g_l1_r, c_l1), None, None, None)
+
+
+def _fused_losses_ok(out, batch):
+    from .kernels import default_kernels
+    t = out['left_g_initial']
+    return (t.is_cuda and t.dtype == torch.float32 and hasattr(default_kernels(), 'eye_losses') and
+            t.dim() == 3 and t.shape[1] <= 256 and batch['left_g_tobii'].dtype == torch.float32)
+
+
 def eyenet_loss_terms(out, batch, config):
     """The terms of eve.py:286-325 that carry weight in eye_net.json, and their weighted sum (:234-265)."""
+    if _fused_losses_ok(out, batch):
+        tgt = tuple(batch[k] for k in ('left_g_tobii', 'right_g_tobii', 'left_g_tobii_validity', 'right_g_tobii_validity',
+                                       'left_p', 'right_p', 'left_p_validity', 'right_p_validity'))
+        t = EyeLossesFn.apply(out['left_g_initial'], out['right_g_initial'], out['left_pupil_size'], out['right_pupil_size'],
+                              tgt, float(config.loss_coeff_g_ang_initial), float(config.loss_coeff_pupil_size))
+        return {'loss_ang_left_g_initial': t[0], 'loss_l1_left_pupil_size': t[1], 'loss_ang_right_g_initial': t[2],
+                'loss_l1_right_pupil_size': t[3], 'full_loss': t[4]}
     terms = {}
     for side in ('left', 'right'):
         terms['loss_ang_%s_g_initial' % side] = angular_loss(

@@ -102,6 +102,15 @@ int eve_linear_dgrad(int M, int K, int N, const float* dy, const float* y, int a
                      float* dx, eve_stream_t stream);
 int eve_linear_wgrad(int M, int K, int N, const float* dy, const float* y, int act, const float* x,
                      float* dw_out_in, float* db, eve_stream_t stream);
+/* The EyeNet train-step losses and their gradients in one launch (losses/angular.py:33-38, losses/l1.py,
+ * losses/base_loss_with_validity.py:64-73; weighted sum of eve.py:234-265).  Every pointer argument is an array of
+ * two device pointers {left, right}: g_pred/g_tgt [B][T][2] (pitch, yaw), p_pred/p_tgt [B][T], validity bytes [B][T].
+ * terms[5] (zeroed by the caller) += {ang_l, l1_l, ang_r, l1_r, coeff_ang*(ang_l+ang_r) + coeff_l1*(l1_l+l1_r)};
+ * dg/dp receive d(term of that side)/d(prediction).                                                     */
+int eve_eye_losses(int B, int T, const float* const* g_pred, const float* const* g_tgt, const uint8_t* const* g_val,
+                   const float* const* p_pred, const float* const* p_tgt, const uint8_t* const* p_val,
+                   float coeff_ang, float coeff_l1, float* terms, float* const* dg, float* const* dp,
+                   eve_stream_t stream);
 /* db[C] (float, accumulated) += sum over the M = N*OH*OW rows of dy[M][C]                         */
 int eve_bias_grad(int dtype, long long M, int C, const void* dy, float* db, eve_stream_t stream);
 

@@ -139,6 +139,33 @@ def test_sequence_matches_cpu_oracle_other_shape_and_grads():
         assert err <= 2e-2 or float((a - b).abs().max()) < 1e-5, '%s: rel L2 %.3e' % (n, err)
 
 
+@pytest.mark.parametrize('B,T', [(3, 5), (4, 30), (2, 70)])
+def test_fused_losses_match_oracle_values_and_gradients(B, T):
+    """eve_eye_losses (one launch: four masked terms, weighted sum, gradients) == the oracle's torch losses."""
+    from eve_amd import losses as hip_losses
+    cfg = eye_cfg()
+    batch = detweights.eyenet_batch(B, T, seed=7, invalid_fraction=0.4)
+    batch['left_g_tobii_validity'][0, 1:] = False          # a clip with a single valid step (denominator rule)
+    batch['right_p_validity'][1] = False                   # and one with none
+    g = torch.Generator().manual_seed(3)
+    out = {'left_g_initial': torch.randn((B, T, 2), generator=g) * 0.4, 'right_g_initial': torch.randn((B, T, 2), generator=g) * 0.4,
+           'left_pupil_size': torch.rand((B, T), generator=g) * 4, 'right_pupil_size': torch.rand((B, T), generator=g) * 4}
+    out['left_g_initial'][0, 0] = batch['left_g_tobii'][0, 0]          # identical vectors: clamp boundary, zero gradient
+    ref_in = {k: v.clone().requires_grad_(True) for k, v in out.items()}
+    ref_terms = sequence.eyenet_losses(ref_in, batch, cfg)
+    ref_terms['full_loss'].backward()
+    dev_in = {k: v.clone().cuda().requires_grad_(True) for k, v in out.items()}
+    terms = hip_losses.eyenet_loss_terms(dev_in, to_dev(batch), cfg)
+    assert 'EyeLossesFn' in type(terms['full_loss'].grad_fn).__name__          # the fused node, not torch ops
+    for k in ref_terms:
+        np.testing.assert_allclose(float(terms[k]), float(ref_terms[k]), rtol=2e-5, atol=1e-6, err_msg=k)
+    terms['full_loss'].backward()
+    for k in out:
+        a, b = dev_in[k].grad.cpu(), ref_in[k].grad
+        assert torch.isfinite(a).all()
+        assert float((a - b).abs().max()) <= 2e-4 * float(b.abs().max()) + 1e-7, k
+
+
 def test_bf16_deviation_is_bounded_and_reported():
     fx = np.load(os.path.join(GOLDEN, 'eyenet.npz'))
     B, T = int(fx['B']), int(fx['T'])
