@@ -67,7 +67,7 @@ SIGNATURES = {
     'eve_sumsq': [L, P, P, P],
     'eve_adam_step': [L, P, P, P, P, P, F, F, F, F, F, F, F, I, P, P],
 }
-EXPORTS = sorted(list(SIGNATURES) + ['eve_abi_version', 'eve_last_error'])
+EXPORTS = sorted(list(SIGNATURES) + ['eve_abi_version', 'eve_last_error', 'eve_last_kernel'])
 
 _lib = None
 
@@ -87,6 +87,8 @@ def load(path=None):
         fn = getattr(lib, name)
         fn.argtypes = argtypes
         fn.restype = c_int
+    lib.eve_last_kernel.argtypes = []
+    lib.eve_last_kernel.restype = ctypes.c_char_p
     lib.eve_abi_version.argtypes = []
     lib.eve_abi_version.restype = c_int
     lib.eve_last_error.argtypes = []

@@ -6,6 +6,7 @@
 
 namespace eve {
 static thread_local char g_err[512] = "";
+thread_local const char* g_last_kernel = "";
 int set_error(hipError_t e, const char* where) {
     snprintf(g_err, sizeof(g_err), "%s: HIP error %d (%s)", where, (int)e, hipGetErrorString(e));
     return 100 + (int)e;
@@ -18,3 +19,4 @@ int set_error_msg(const char* msg) {
 
 extern "C" int eve_abi_version(void) { return EVE_ABI_VERSION; }
 extern "C" const char* eve_last_error(void) { return eve::g_err; }
+extern "C" const char* eve_last_kernel(void) { return eve::g_last_kernel; }

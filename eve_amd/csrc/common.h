@@ -163,4 +163,8 @@ __device__ __forceinline__ uint32_t xcd_remap(uint32_t bid, uint32_t nblk) {
 namespace eve {
 int set_error(hipError_t e, const char* where);
 int set_error_msg(const char* msg);
+// symbol of the kernel the calling thread launched last (benchmark attribution, see eve_last_kernel)
+extern thread_local const char* g_last_kernel;
 }  // namespace eve
+#define EVE_MARK_KERNEL(name) (eve::g_last_kernel = (name))
+#define EVE_LAUNCH(name, ...) do { EVE_MARK_KERNEL(name); hipLaunchKernelGGL(__VA_ARGS__); } while (0)

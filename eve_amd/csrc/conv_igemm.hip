@@ -510,15 +510,15 @@ static void launch_dma_one(const GatherParams& p, const TapPlan& tp, const void*
     if (big < 0) { const char* e = getenv("EVE_CONV_TILE"); big = (e && e[0] == '2') ? 1 : 0; }
     if (p.Cout > 64 && big && p.M >= 256 * 256) {
         const uint32_t tiles = ((p.M + 255) / 256) * ((p.Cout + 127) / 128);
-        hipLaunchKernelGGL((igemm_dma_kernel<T, 4, 2>), dim3(tiles), dim3(512), 0, s, p, a, b, bias, epi_act, o,
+        EVE_LAUNCH("igemm_dma_kernel<T, 4, 2>", (igemm_dma_kernel<T, 4, 2>), dim3(tiles), dim3(512), 0, s, p, a, b, bias, epi_act, o,
                            src_bytes, w_bytes, tp);
     } else if (p.Cout > 64) {
         const uint32_t tiles = ((p.M + 127) / 128) * ((p.Cout + 127) / 128);
-        hipLaunchKernelGGL((igemm_dma_kernel<T, 2, 2>), dim3(tiles), dim3(256), 0, s, p, a, b, bias, epi_act, o,
+        EVE_LAUNCH("igemm_dma_kernel<T, 2, 2>", (igemm_dma_kernel<T, 2, 2>), dim3(tiles), dim3(256), 0, s, p, a, b, bias, epi_act, o,
                            src_bytes, w_bytes, tp);
     } else {
         const uint32_t tiles = (p.M + 255) / 256;
-        hipLaunchKernelGGL((igemm_dma_kernel<T, 4, 1>), dim3(tiles), dim3(256), 0, s, p, a, b, bias, epi_act, o,
+        EVE_LAUNCH("igemm_dma_kernel<T, 4, 1>", (igemm_dma_kernel<T, 4, 1>), dim3(tiles), dim3(256), 0, s, p, a, b, bias, epi_act, o,
                            src_bytes, w_bytes, tp);
     }
 }
@@ -571,18 +571,18 @@ static bool launch_halo(const GatherParams& p, const void* src, const void* w, c
             pattr = true;
         }
         if (narrow)
-            hipLaunchKernelGGL((conv3x3_halo_pkernel<4, 1>), dim3(512), dim3(256), lds, s, h, (const bf16_t*)src,
+            EVE_LAUNCH("conv3x3_halo_pkernel<4, 1>", (conv3x3_halo_pkernel<4, 1>), dim3(512), dim3(256), lds, s, h, (const bf16_t*)src,
                                (const bf16_t*)w, bias, epi_act, (bf16_t*)out);
         else
-            hipLaunchKernelGGL((conv3x3_halo_pkernel<2, 2>), dim3(512), dim3(256), lds, s, h, (const bf16_t*)src,
+            EVE_LAUNCH("conv3x3_halo_pkernel<2, 2>", (conv3x3_halo_pkernel<2, 2>), dim3(512), dim3(256), lds, s, h, (const bf16_t*)src,
                                (const bf16_t*)w, bias, epi_act, (bf16_t*)out);
         return true;
     }
     if (narrow)
-        hipLaunchKernelGGL((conv3x3_halo_kernel<4, 1>), dim3(tiles), dim3(256), lds, s, h, (const bf16_t*)src,
+        EVE_LAUNCH("conv3x3_halo_kernel<4, 1>", (conv3x3_halo_kernel<4, 1>), dim3(tiles), dim3(256), lds, s, h, (const bf16_t*)src,
                            (const bf16_t*)w, bias, epi_act, (bf16_t*)out);
     else
-        hipLaunchKernelGGL((conv3x3_halo_kernel<2, 2>), dim3(tiles), dim3(256), lds, s, h, (const bf16_t*)src,
+        EVE_LAUNCH("conv3x3_halo_kernel<2, 2>", (conv3x3_halo_kernel<2, 2>), dim3(tiles), dim3(256), lds, s, h, (const bf16_t*)src,
                            (const bf16_t*)w, bias, epi_act, (bf16_t*)out);
     return true;
 }
@@ -653,11 +653,11 @@ static int launch_igemm(const GatherParams& p, const void* src, const void* w, c
     dim3 grid(tiles), block(256);
     const T* a = (const T*)src; const T* b = (const T*)w; T* o = (T*)out;
     if (wide) {
-        if (ss) hipLaunchKernelGGL((igemm_kernel<T, 4, true>), grid, block, 0, s, p, a, b, bias, ss, pro_act, epi_act, o);
-        else    hipLaunchKernelGGL((igemm_kernel<T, 4, false>), grid, block, 0, s, p, a, b, bias, ss, pro_act, epi_act, o);
+        if (ss) EVE_LAUNCH("igemm_kernel<T, 4, true>", (igemm_kernel<T, 4, true>), grid, block, 0, s, p, a, b, bias, ss, pro_act, epi_act, o);
+        else    EVE_LAUNCH("igemm_kernel<T, 4, false>", (igemm_kernel<T, 4, false>), grid, block, 0, s, p, a, b, bias, ss, pro_act, epi_act, o);
     } else {
-        if (ss) hipLaunchKernelGGL((igemm_kernel<T, 2, true>), grid, block, 0, s, p, a, b, bias, ss, pro_act, epi_act, o);
-        else    hipLaunchKernelGGL((igemm_kernel<T, 2, false>), grid, block, 0, s, p, a, b, bias, ss, pro_act, epi_act, o);
+        if (ss) EVE_LAUNCH("igemm_kernel<T, 2, true>", (igemm_kernel<T, 2, true>), grid, block, 0, s, p, a, b, bias, ss, pro_act, epi_act, o);
+        else    EVE_LAUNCH("igemm_kernel<T, 2, false>", (igemm_kernel<T, 2, false>), grid, block, 0, s, p, a, b, bias, ss, pro_act, epi_act, o);
     }
     return 0;
 }
@@ -686,16 +686,16 @@ static int launch_wgrad(const GatherParams& p, const void* x, const void* dy, co
             if (p.Cout > 64) {
                 const uint32_t tk = (p.K + 127) / 128, tc = (p.Cout + 127) / 128;
                 wgrad_split(p, tk, tc, splits, rows);
-                if (pow2) hipLaunchKernelGGL((wgrad_tr_kernel<2, 2, true>), dim3(tk * tc * splits), dim3(256), 0, s, p, (const bf16_t*)x,
+                if (pow2) EVE_LAUNCH("wgrad_tr_kernel<2, 2, true>", (wgrad_tr_kernel<2, 2, true>), dim3(tk * tc * splits), dim3(256), 0, s, p, (const bf16_t*)x,
                                              (const bf16_t*)dy, dw, rows, (uint32_t)x_bytes, (uint32_t)dy_bytes);
-                else      hipLaunchKernelGGL((wgrad_tr_kernel<2, 2, false>), dim3(tk * tc * splits), dim3(256), 0, s, p, (const bf16_t*)x,
+                else      EVE_LAUNCH("wgrad_tr_kernel<2, 2, false>", (wgrad_tr_kernel<2, 2, false>), dim3(tk * tc * splits), dim3(256), 0, s, p, (const bf16_t*)x,
                                              (const bf16_t*)dy, dw, rows, (uint32_t)x_bytes, (uint32_t)dy_bytes);
             } else {
                 const uint32_t tk = (p.K + 255) / 256, tc = 1;
                 wgrad_split(p, tk, tc, splits, rows);
-                if (pow2) hipLaunchKernelGGL((wgrad_tr_kernel<1, 4, true>), dim3(tk * tc * splits), dim3(256), 0, s, p, (const bf16_t*)x,
+                if (pow2) EVE_LAUNCH("wgrad_tr_kernel<1, 4, true>", (wgrad_tr_kernel<1, 4, true>), dim3(tk * tc * splits), dim3(256), 0, s, p, (const bf16_t*)x,
                                              (const bf16_t*)dy, dw, rows, (uint32_t)x_bytes, (uint32_t)dy_bytes);
-                else      hipLaunchKernelGGL((wgrad_tr_kernel<1, 4, false>), dim3(tk * tc * splits), dim3(256), 0, s, p, (const bf16_t*)x,
+                else      EVE_LAUNCH("wgrad_tr_kernel<1, 4, false>", (wgrad_tr_kernel<1, 4, false>), dim3(tk * tc * splits), dim3(256), 0, s, p, (const bf16_t*)x,
                                              (const bf16_t*)dy, dw, rows, (uint32_t)x_bytes, (uint32_t)dy_bytes);
             }
             return 0;
@@ -716,11 +716,11 @@ static int launch_wgrad(const GatherParams& p, const void* x, const void* dy, co
     dim3 grid(tk, tc, splits), block(256);
     const T* a = (const T*)x; const T* b = (const T*)dy;
     if (wide) {
-        if (ss) hipLaunchKernelGGL((wgrad_kernel<T, 4, true>), grid, block, 0, s, p, a, b, ss, pro_act, dw, rows);
-        else    hipLaunchKernelGGL((wgrad_kernel<T, 4, false>), grid, block, 0, s, p, a, b, ss, pro_act, dw, rows);
+        if (ss) EVE_LAUNCH("wgrad_kernel<T, 4, true>", (wgrad_kernel<T, 4, true>), grid, block, 0, s, p, a, b, ss, pro_act, dw, rows);
+        else    EVE_LAUNCH("wgrad_kernel<T, 4, false>", (wgrad_kernel<T, 4, false>), grid, block, 0, s, p, a, b, ss, pro_act, dw, rows);
     } else {
-        if (ss) hipLaunchKernelGGL((wgrad_kernel<T, 2, true>), grid, block, 0, s, p, a, b, ss, pro_act, dw, rows);
-        else    hipLaunchKernelGGL((wgrad_kernel<T, 2, false>), grid, block, 0, s, p, a, b, ss, pro_act, dw, rows);
+        if (ss) EVE_LAUNCH("wgrad_kernel<T, 2, true>", (wgrad_kernel<T, 2, true>), grid, block, 0, s, p, a, b, ss, pro_act, dw, rows);
+        else    EVE_LAUNCH("wgrad_kernel<T, 2, false>", (wgrad_kernel<T, 2, false>), grid, block, 0, s, p, a, b, ss, pro_act, dw, rows);
     }
     return 0;
 }

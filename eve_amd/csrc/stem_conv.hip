@@ -135,6 +135,7 @@ extern "C" int eve_stem7x7s2_fwd(int N, int IH, int IW, const void* x_padded, co
     if (tiles >= (1ull << 32)) return set_error_msg("stem7x7s2_fwd: too many tiles");
     unsigned blocks = 512;
     if ((tiles + 3) / 4 < blocks) blocks = (unsigned)((tiles + 3) / 4);
+    EVE_MARK_KERNEL("stem7x7_kernel");
     hipLaunchKernelGGL(stem7x7_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, N, IH, IW, (const uint2*)x_padded,
                        (const bf16_t*)w_ohwi8, (bf16_t*)y, (uint32_t)tiles);
     EVE_CHECK_LAUNCH();

@@ -462,6 +462,7 @@ extern "C" int eve_stem_fwd_fused(int N, int IH, int IW, const void* x_padded, c
     }
     unsigned blocks = (unsigned)((N + SF_WAVES - 1) / SF_WAVES);
     if (blocks > 256) blocks = 256;
+    EVE_MARK_KERNEL("stem_fwd_fused_kernel");
     hipLaunchKernelGGL(stem_fwd_fused_kernel, dim3(blocks), dim3(64 * SF_WAVES), lds, (hipStream_t)stream, N, IH,
                        (const bf16_t*)x_padded, (uint32_t)xb, (const bf16_t*)w_ohwi8, eps, (bf16_t*)y_pool, idx, mean_rstd);
     EVE_CHECK_LAUNCH();
@@ -484,6 +485,7 @@ extern "C" int eve_stem_bwd_dx(int N, int IH, int IW, const void* x_padded, cons
     }
     unsigned blocks = (unsigned)((N + SF_WAVES - 1) / SF_WAVES);
     if (blocks > 256) blocks = 256;
+    EVE_MARK_KERNEL("stem_bwd_dx_kernel");
     hipLaunchKernelGGL(stem_bwd_dx_kernel, dim3(blocks), dim3(64 * SF_WAVES), lds, (hipStream_t)stream, N, IH,
                        (const bf16_t*)x_padded, (uint32_t)xb, (const bf16_t*)w_ohwi8, mean_rstd, (const bf16_t*)dy_pool,
                        (const bf16_t*)dy_pool2, (const bf16_t*)y_pool, idx, (bf16_t*)dx);

@@ -65,13 +65,16 @@ class HipKernels(object):
             null.append((e0, e1))
         torch.cuda.synchronize()
         overhead = sorted(a.elapsed_time(b) for a, b in null)[len(null) // 2]
-        out = {}
-        for tag, flops, e0, e1 in rec:
-            d = out.setdefault(tag, {'launches': 0, 'ms': 0.0, 'flops': 0.0})
-            d['launches'] += 1
-            d['ms'] += max(e0.elapsed_time(e1) - overhead, 1e-4)
-            d['flops'] += flops
+        out, by_kernel = {}, {}
+        for tag, flops, e0, e1, sym in rec:
+            ms = max(e0.elapsed_time(e1) - overhead, 1e-4)
+            for table, key in ((out, tag), (by_kernel, sym)):
+                d = table.setdefault(key, {'launches': 0, 'ms': 0.0, 'flops': 0.0})
+                d['launches'] += 1
+                d['ms'] += ms
+                d['flops'] += flops
         out['_event_overhead_ms'] = overhead
+        out['_by_kernel'] = by_kernel          # keyed by the kernel symbol the library reports (eve_last_kernel)
         return out
 
     def _timed(self, tag, flops, fn):
@@ -81,7 +84,8 @@ class HipKernels(object):
         e0.record()
         r = fn()
         e1.record()
-        self.prof.append((tag, flops, e0, e1))
+        sym = self.lib.eve_last_kernel()
+        self.prof.append((tag, flops, e0, e1, sym.decode() if sym else ''))
         return r
 
     # ------------------------------------------------------------------ helpers
@@ -202,8 +206,8 @@ class HipKernels(object):
         IH, IW = Hp - 6, Wp - 8
         dx = torch.empty((N, IH // 2, IW // 2, 64), dtype=torch.bfloat16, device=x_padded.device)
         assert dy_pool.dtype == torch.bfloat16 and dy_pool.is_contiguous() and dy_pool.shape == y_pool.shape == idx.shape
-        flops = 2.0 * N * (IH // 2) * (IW // 2) * 64 * 147
-        self._timed('conv_fwd', flops, lambda: self._ck(self.lib.eve_stem_bwd_dx(
+        # (the convolution is RE-computed here: no algorithmic FLOPs are credited)
+        self._timed('stem_bwd', 0.0, lambda: self._ck(self.lib.eve_stem_bwd_dx(
             N, IH, IW, self._p(x_padded), self._p(w_ohwi8), self._p(self._f32(mr, 'mean_rstd')), self._p(dy_pool),
             self._p(dy_pool2), self._p(y_pool), self._p(idx), self._p(dx), self._stream())))
         return dx

@@ -43,6 +43,9 @@ enum {
 };
 
 int eve_abi_version(void);
+/* Symbol (without namespace / signature) of the kernel the last conv / stem call of this thread launched; lets a
+ * profiler attribute a timed launch to the row of the same name in a rocprofv3 kernel summary.            */
+const char* eve_last_kernel(void);
 const char* eve_last_error(void);
 
 /* ------------------------------------------------------------------------------------------------
