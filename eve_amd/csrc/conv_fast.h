@@ -270,10 +270,12 @@ __device__ __forceinline__ void mma4_bf16_inplace(f32x4_t& c0, f32x4_t& c1, f32x
 // bf16 weight gradient.  Block tile = (64*WCO output channels) x (64*WK filter-K values); every wave owns
 // a 64 x 64 piece; each step consumes 64 pixels (two MFMA K=32 chunks).
 // =================================================================================================
+// rows of 128 B (mod 256) alternate between the two halves of the 64 banks, so two row bits separate the four rows
+// a 32-lane read group touches in one half; rows that are a multiple of 256 B all start on bank 0 and need three
 template <int ROWB>
 __device__ __forceinline__ int tr_key(int row) {
     const int b0 = row & 1, b1 = (row >> 1) & 1, b2 = (row >> 3) & 1;
-    return ROWB == 128 ? (b1 | (b2 << 1)) : (b0 | (b1 << 1) | (b2 << 2));
+    return ROWB % 256 == 128 ? (b1 | (b2 << 1)) : (b0 | (b1 << 1) | (b2 << 2));
 }
 
 // takes a 32-bit LDS byte address: an integer -> LDS pointer cast is free, a generic -> LDS cast is ~6 VALU per read
@@ -286,7 +288,7 @@ __device__ __forceinline__ uint2 lds_tr_read(uint32_t lds_byte_addr) {
 }
 
 template <int WCO, int WK, bool POW2>
-__global__ __launch_bounds__(256) void wgrad_tr_kernel(const GatherParams p, const bf16_t* __restrict__ x,
+__global__ __launch_bounds__(64 * WCO * WK) void wgrad_tr_kernel(const GatherParams p, const bf16_t* __restrict__ x,
                                                        const bf16_t* __restrict__ dy, float* __restrict__ dw,
                                                        const uint32_t rows_per_split, const uint32_t x_bytes,
                                                        const uint32_t dy_bytes) {
@@ -294,13 +296,17 @@ __global__ __launch_bounds__(256) void wgrad_tr_kernel(const GatherParams p, con
     constexpr int PROW = BCO * 2, QROW = BKK * 2;            // bytes per pixel row
     constexpr int PSL = PROW / 16, QSL = QROW / 16;          // 16-byte slots per row
     constexpr int STEP = 32;                                 // pixels per stage = one MFMA K=32 chunk
-    constexpr int P_DMA = STEP * PSL / 256, Q_DMA = STEP * QSL / 256;
+    constexpr int NT = 64 * WCO * WK;                        // 256 threads, or 448 / 576 for the one-K-tile variants
+    constexpr int P_SLOTS = STEP * PSL, Q_SLOTS = STEP * QSL;
+    // (a tile with fewer slots than threads is fetched again by the surplus waves: same data to the same place)
+    constexpr int P_DMA = (P_SLOTS + NT - 1) / NT, Q_DMA = (Q_SLOTS + NT - 1) / NT;
     constexpr int NDMA = P_DMA + Q_DMA;                      // LDS-DMA instructions per thread and stage
     constexpr int BUF = STEP * (PROW + QROW);                // bytes per stage (16 KB / 20 KB)
     constexpr int RING = 4;                                  // 64 / 80 KB of LDS, two workgroups per CU (a 3-deep ring with
                                                              // three workgroups per CU measured 7 % slower)
-    static_assert(STEP * PSL % 256 == 0 && STEP * QSL % 256 == 0, "stage slots must tile the workgroup");
-    __shared__ __attribute__((aligned(16))) char lds[RING * BUF];
+    static_assert((P_SLOTS % NT == 0 || (P_DMA == 1 && P_SLOTS % 64 == 0)) && (Q_SLOTS % NT == 0 || (Q_DMA == 1 && Q_SLOTS % 64 == 0)),
+                  "stage slots must tile the workgroup");
+    extern __shared__ __attribute__((aligned(16))) char lds[];   // RING * BUF bytes
 
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -323,7 +329,7 @@ __global__ __launch_bounds__(256) void wgrad_tr_kernel(const GatherParams p, con
     int p_row[P_DMA], p_col[P_DMA];                 // row in the stage, byte offset of the channel in dy's row
 #pragma unroll
     for (int j = 0; j < P_DMA; ++j) {
-        const int q = tid + 256 * j;
+        const int q = (tid + NT * j) % P_SLOTS;
         const int row = q / PSL, sl = q % PSL;
         const int sg = sl ^ (tr_key<PROW>(row) << 1);
         const uint32_t co = co0 + sg * 8;
@@ -333,7 +339,7 @@ __global__ __launch_bounds__(256) void wgrad_tr_kernel(const GatherParams p, con
     int q_row[Q_DMA], q_col[Q_DMA], q_dy[Q_DMA], q_dx[Q_DMA];
 #pragma unroll
     for (int j = 0; j < Q_DMA; ++j) {
-        const int q = tid + 256 * j;
+        const int q = (tid + NT * j) % Q_SLOTS;
         const int row = q / QSL, sl = q % QSL;
         const int sg = sl ^ (tr_key<QROW>(row) << 1);
         const uint32_t k = k0 + sg * 8;
@@ -405,12 +411,12 @@ __global__ __launch_bounds__(256) void wgrad_tr_kernel(const GatherParams p, con
         }
     };
     auto issue = [&](int slot, const int* vp, const int* vq) {      // always NDMA instructions
-        const uint32_t pb = lds0 + slot * BUF + wave * 1024;
+        const uint32_t pb = lds0 + slot * BUF;
         const uint32_t qb = pb + STEP * PROW;
 #pragma unroll
-        for (int j = 0; j < P_DMA; ++j) lds_dma16_asm(rs_dy, pb + j * 4096, vp[j]);
+        for (int j = 0; j < P_DMA; ++j) lds_dma16_asm(rs_dy, pb + ((wave * 64 + NT * j) % P_SLOTS) * 16, vp[j]);
 #pragma unroll
-        for (int j = 0; j < Q_DMA; ++j) lds_dma16_asm(rs_x, qb + j * 4096, vq[j]);
+        for (int j = 0; j < Q_DMA; ++j) lds_dma16_asm(rs_x, qb + ((wave * 64 + NT * j) % Q_SLOTS) * 16, vq[j]);
     };
 
     const int lane = tid & 63;

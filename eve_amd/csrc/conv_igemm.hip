@@ -683,21 +683,34 @@ static int launch_wgrad(const GatherParams& p, const void* x, const void* dy, co
         if (x_bytes < (1ull << 31) && dy_bytes < (1ull << 31)) {
             uint32_t splits, rows;
             const bool pow2 = ((p.OW & (p.OW - 1)) == 0) && ((p.OH & (p.OH - 1)) == 0);
+            // dynamic LDS = RING (4) stages of 32 pixels x (BCO + BKK) bf16
+            auto lds_bytes = [](int bco, int bkk) { return (size_t)4 * 32 * (bco + bkk) * 2; };
+#define EVE_WGRAD_LAUNCH(WCO_, WK_, P2_, TK, TC)                                                                        \
+    do {                                                                                                                \
+        static bool attr_done = false;                                                                                  \
+        if (!attr_done) {                                                                                               \
+            (void)hipFuncSetAttribute((const void*)wgrad_tr_kernel<WCO_, WK_, P2_>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                      160 * 1024);                                                                      \
+            attr_done = true;                                                                                           \
+        }                                                                                                               \
+        EVE_LAUNCH("wgrad_tr_kernel<" #WCO_ ", " #WK_ ", " #P2_ ">", (wgrad_tr_kernel<WCO_, WK_, P2_>),                    \
+                   dim3((TK) * (TC) * splits), dim3(64 * WCO_ * WK_), lds_bytes(64 * WCO_, 64 * WK_), s, p, (const bf16_t*)x, \
+                   (const bf16_t*)dy, dw, rows, (uint32_t)x_bytes, (uint32_t)dy_bytes);                                   \
+    } while (0)
             if (p.Cout > 64) {
                 const uint32_t tk = (p.K + 127) / 128, tc = (p.Cout + 127) / 128;
                 wgrad_split(p, tk, tc, splits, rows);
-                if (pow2) EVE_LAUNCH("wgrad_tr_kernel<2, 2, true>", (wgrad_tr_kernel<2, 2, true>), dim3(tk * tc * splits), dim3(256), 0, s, p, (const bf16_t*)x,
-                                             (const bf16_t*)dy, dw, rows, (uint32_t)x_bytes, (uint32_t)dy_bytes);
-                else      EVE_LAUNCH("wgrad_tr_kernel<2, 2, false>", (wgrad_tr_kernel<2, 2, false>), dim3(tk * tc * splits), dim3(256), 0, s, p, (const bf16_t*)x,
-                                             (const bf16_t*)dy, dw, rows, (uint32_t)x_bytes, (uint32_t)dy_bytes);
+                if (pow2) EVE_WGRAD_LAUNCH(2, 2, true, tk, tc);
+                else      EVE_WGRAD_LAUNCH(2, 2, false, tk, tc);
+            // (one 9-wave workgroup covering the whole 576-wide filter of the 64-channel layers -- operands fetched once
+            //  instead of once per K tile -- measured SLOWER: 0.292 vs 0.237 ms; the surplus fetches hit the Infinity Cache)
             } else {
                 const uint32_t tk = (p.K + 255) / 256, tc = 1;
                 wgrad_split(p, tk, tc, splits, rows);
-                if (pow2) EVE_LAUNCH("wgrad_tr_kernel<1, 4, true>", (wgrad_tr_kernel<1, 4, true>), dim3(tk * tc * splits), dim3(256), 0, s, p, (const bf16_t*)x,
-                                             (const bf16_t*)dy, dw, rows, (uint32_t)x_bytes, (uint32_t)dy_bytes);
-                else      EVE_LAUNCH("wgrad_tr_kernel<1, 4, false>", (wgrad_tr_kernel<1, 4, false>), dim3(tk * tc * splits), dim3(256), 0, s, p, (const bf16_t*)x,
-                                             (const bf16_t*)dy, dw, rows, (uint32_t)x_bytes, (uint32_t)dy_bytes);
+                if (pow2) EVE_WGRAD_LAUNCH(1, 4, true, tk, tc);
+                else      EVE_WGRAD_LAUNCH(1, 4, false, tk, tc);
             }
+#undef EVE_WGRAD_LAUNCH
             return 0;
         }
     }
