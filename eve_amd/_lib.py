@@ -22,6 +22,13 @@ L = c_longlong
 F = c_float
 
 # name -> argtypes; every function returns int (0 = ok) except the two noted below
+class PackItem(Structure):
+    _fields_ = [('w_ohwi', c_void_p), ('dst_ohwi', c_void_p), ('dst_ihwo', c_void_p),
+                ('Cout', c_int), ('taps', c_int), ('Cin', c_int)]
+
+
+PACK_BATCH_MAX = 48
+
 SIGNATURES = {
     'eve_conv2d_fwd': [POINTER(ConvDesc), P, P, P, I, P, I, P, P],
     'eve_conv2d_dgrad': [POINTER(ConvDesc), P, P, P, P],
@@ -32,6 +39,7 @@ SIGNATURES = {
     'eve_stem_fwd_fused': [I, I, I, P, P, F, P, P, P, P],
     'eve_stem_bwd_dx': [I, I, I, P, P, P, P, P, P, P, P, P],
     'eve_bias_grad': [I, L, I, P, P, P],
+    'eve_pack_weights_batch': [I, I, P, P],
     'eve_eye_losses': [I, I, P, P, P, P, P, P, F, F, P, P, P, P],
     'eve_linear_fwd': [I, I, I, P, P, P, I, P, P],
     'eve_linear_dgrad': [I, I, I, P, P, I, P, P, P],

@@ -324,6 +324,30 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const float* __restri
     }
 }
 
+// all conv weights of a model in one launch (the packs are rebuilt after every optimiser step: 20 launches of a few
+// microseconds each were 0.14 ms of a 15 ms step)
+struct PackItem { const float* w; void* ohwi; void* ihwo; int Cout, taps, Cin; long long start; };
+struct PackTable { PackItem it[EVE_PACK_BATCH_MAX]; int count; long long total; };
+
+template <typename T>
+__global__ __launch_bounds__(256) void pack_weights_batch_kernel(const PackTable tb) {
+    for (long long g = (long long)blockIdx.x * 256 + threadIdx.x; g < tb.total; g += (long long)gridDim.x * 256) {
+        int k = 0;
+        while (k + 1 < tb.count && g >= tb.it[k + 1].start) ++k;
+        const PackItem& q = tb.it[k];
+        const long long i = g - q.start;
+        const float v = q.w[i];
+        if (q.ohwi) Elem<T>::st((T*)q.ohwi + i, v);
+        if (q.ihwo) {
+            const int ci = (int)(i % q.Cin);
+            long long t = i / q.Cin;
+            const int tap = (int)(t % q.taps);
+            const long long co = t / q.taps;
+            Elem<T>::st((T*)q.ihwo + ((long long)ci * q.taps + tap) * q.Cout + co, v);
+        }
+    }
+}
+
 }  // namespace eve
 
 using namespace eve;
@@ -465,6 +489,25 @@ extern "C" int eve_cast(int dtype_src, int dtype_dst, long long n, const void* s
     else if (dtype_src == EVE_DT_F32 && dtype_dst == EVE_DT_F32) hipLaunchKernelGGL((cast_kernel<float, float>), dim3(g), dim3(256), 0, s, (const float*)src, (float*)dst, n);
     else if (dtype_src == EVE_DT_BF16 && dtype_dst == EVE_DT_BF16) hipLaunchKernelGGL((cast_kernel<bf16_t, bf16_t>), dim3(g), dim3(256), 0, s, (const bf16_t*)src, (bf16_t*)dst, n);
     else return set_error_msg("cast: bad dtype");
+    EVE_CHECK_LAUNCH();
+    return 0;
+}
+extern "C" int eve_pack_weights_batch(int dtype_dst, int count, const eve_pack_item* items, eve_stream_t stream) {
+    if (dtype_dst != EVE_DT_F32 && dtype_dst != EVE_DT_BF16) return set_error_msg("pack_weights_batch: bad dtype");
+    if (count <= 0 || count > EVE_PACK_BATCH_MAX || !items) return set_error_msg("pack_weights_batch: 1..EVE_PACK_BATCH_MAX items");
+    PackTable tb;
+    long long total = 0;
+    for (int i = 0; i < count; ++i) {
+        const eve_pack_item& q = items[i];
+        if (q.Cout <= 0 || q.taps <= 0 || q.Cin <= 0 || !q.w_ohwi || (!q.dst_ohwi && !q.dst_ihwo))
+            return set_error_msg("pack_weights_batch: bad item");
+        tb.it[i] = PackItem{q.w_ohwi, q.dst_ohwi, q.dst_ihwo, q.Cout, q.taps, q.Cin, total};
+        total += (long long)q.Cout * q.taps * q.Cin;
+    }
+    tb.count = count; tb.total = total;
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype_dst == EVE_DT_BF16) hipLaunchKernelGGL(pack_weights_batch_kernel<bf16_t>, dim3(sgrid(total)), dim3(256), 0, s, tb);
+    else                          hipLaunchKernelGGL(pack_weights_batch_kernel<float>, dim3(sgrid(total)), dim3(256), 0, s, tb);
     EVE_CHECK_LAUNCH();
     return 0;
 }

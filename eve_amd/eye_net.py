@@ -128,26 +128,30 @@ class EyeNet(nn.Module):
         f32 = torch.float32
         P = {}
         cnn = self.cnn_layers
-        P['conv1'] = PackedWeight(cnn.conv1.weight, dt, cin_pad=pad_channels(3, dt), want_ihwo=False)
+        P['conv1'] = PackedWeight(cnn.conv1.weight, dt, cin_pad=pad_channels(3, dt), want_ihwo=False, defer=True)
         for name, blk in cnn.blocks():
-            P[name + '.conv1'] = PackedWeight(blk.conv1.weight, dt)
-            P[name + '.conv2'] = PackedWeight(blk.conv2.weight, dt)
+            P[name + '.conv1'] = PackedWeight(blk.conv1.weight, dt, defer=True)
+            P[name + '.conv2'] = PackedWeight(blk.conv2.weight, dt, defer=True)
             if blk.downsample is not None:
-                P[name + '.downsample.0'] = PackedWeight(blk.downsample[0].weight, dt)
+                P[name + '.downsample.0'] = PackedWeight(blk.downsample[0].weight, dt, defer=True)
+        PackedWeight.pack_many(list(P.values()), dt)          # all trunk weights in one launch
         # the tail (linears + GRU) always runs in float32: < 0.03 % of the FLOPs, and it carries the recurrence
-        P['fc'] = PackedWeight(cnn.fc.weight, f32)
-        P['fc_common.0'] = PackedWeight(self.fc_common[0].weight, f32,
-                                        cin_pad=pad_channels(self.fc_common[0].in_features, f32))
-        P['fc_common.2'] = PackedWeight(self.fc_common[2].weight, f32)
+        T = {}
+        T['fc'] = PackedWeight(cnn.fc.weight, f32, defer=True)
+        T['fc_common.0'] = PackedWeight(self.fc_common[0].weight, f32,
+                                        cin_pad=pad_channels(self.fc_common[0].in_features, f32), defer=True)
+        T['fc_common.2'] = PackedWeight(self.fc_common[2].weight, f32, defer=True)
         if self.config.eye_net_use_rnn:
             for i, cell in enumerate(self.rnn_cells):
-                P['rnn.%d.ih' % i] = PackedWeight(cell.weight_ih, f32)
+                T['rnn.%d.ih' % i] = PackedWeight(cell.weight_ih, f32, defer=True)
         else:
-            P['static_fc.0'] = PackedWeight(self.static_fc[0].weight, f32)
-        P['fc_to_gaze.0'] = PackedWeight(self.fc_to_gaze[0].weight, f32)
-        P['fc_to_gaze.2'] = PackedWeight(self.fc_to_gaze[2].weight, f32, cout_pad=4)
-        P['fc_to_pupil.0'] = PackedWeight(self.fc_to_pupil[0].weight, f32)
-        P['fc_to_pupil.2'] = PackedWeight(self.fc_to_pupil[2].weight, f32, cout_pad=4)
+            T['static_fc.0'] = PackedWeight(self.static_fc[0].weight, f32, defer=True)
+        T['fc_to_gaze.0'] = PackedWeight(self.fc_to_gaze[0].weight, f32, defer=True)
+        T['fc_to_gaze.2'] = PackedWeight(self.fc_to_gaze[2].weight, f32, cout_pad=4, defer=True)
+        T['fc_to_pupil.0'] = PackedWeight(self.fc_to_pupil[0].weight, f32, defer=True)
+        T['fc_to_pupil.2'] = PackedWeight(self.fc_to_pupil[2].weight, f32, cout_pad=4, defer=True)
+        PackedWeight.pack_many(list(T.values()), f32)
+        P.update(T)
         self._packs, self._packs_key = P, key
         return P
 

@@ -466,6 +466,25 @@ class HipKernels(object):
                                            self._p(ihwo), self._stream()))
         return ohwi, ihwo
 
+    def pack_weights_batch(self, ws_ohwi_f32, dtype, want_ihwo):
+        """pack_weights for a list of OHWI float32 weights (and per-weight want_ihwo flags) in ONE launch per
+        EVE_PACK_BATCH_MAX weights.  Returns [(ohwi, ihwo)]."""
+        out, items, keep = [], [], []
+        for w, wi in zip(ws_ohwi_f32, want_ihwo):
+            Cout, KH, KW, Cin = w.shape
+            w = self._f32(w, 'weights')
+            self._p(w)                                 # (raises for a tensor that is not on the GPU)
+            ohwi = torch.empty((Cout, KH, KW, Cin), dtype=dtype, device=w.device)
+            ihwo = torch.empty((Cin, KH, KW, Cout), dtype=dtype, device=w.device) if wi else None
+            keep.append(w)
+            items.append(_lib.PackItem(w.data_ptr(), ohwi.data_ptr(), ihwo.data_ptr() if wi else None, Cout, KH * KW, Cin))
+            out.append((ohwi, ihwo))
+        for i in range(0, len(items), _lib.PACK_BATCH_MAX):
+            chunk = items[i:i + _lib.PACK_BATCH_MAX]
+            arr = (_lib.PackItem * len(chunk))(*chunk)
+            self._ck(self.lib.eve_pack_weights_batch(dt_code(dtype), len(chunk), arr, self._stream()))
+        return out
+
     # ------------------------------------------------------------------ recurrent
     def gru_scan_fwd(self, gi, whh_t, bhh, h0):
         S, T, H3 = gi.shape

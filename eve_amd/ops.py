@@ -21,7 +21,7 @@ class PackedWeight(object):
 
     __slots__ = ('ohwi', 'ihwo', 'shape_oihw', 'algo')
 
-    def __init__(self, param, dtype, cin_pad=None, cout_pad=None, want_ihwo=True):
+    def __init__(self, param, dtype, cin_pad=None, cout_pad=None, want_ihwo=True, defer=False):
         k = default_kernels()
         w = param.detach()
         if w.dim() == 2:
@@ -34,7 +34,20 @@ class PackedWeight(object):
         if cout_pad is not None and cout_pad != w.shape[0]:
             w = torch.nn.functional.pad(w, (0, 0, 0, 0, 0, 0, 0, cout_pad - w.shape[0]))
         w = w.contiguous().float()
-        self.ohwi, self.ihwo = k.pack_weights(w, dtype, want_ihwo=want_ihwo)
+        if defer:                                     # packed later, together with others (pack_many)
+            self.ohwi, self.ihwo = (w, want_ihwo), None
+        else:
+            self.ohwi, self.ihwo = k.pack_weights(w, dtype, want_ihwo=want_ihwo)
+
+    @staticmethod
+    def pack_many(packs, dtype):
+        """Finish PackedWeight(..., defer=True) objects with one batched launch."""
+        todo = [p for p in packs if isinstance(p.ohwi, tuple)]
+        if not todo:
+            return
+        res = default_kernels().pack_weights_batch([p.ohwi[0] for p in todo], dtype, [p.ohwi[1] for p in todo])
+        for p, (ohwi, ihwo) in zip(todo, res):
+            p.ohwi, p.ihwo = ohwi, ihwo
 
 
 def _direct_grad_ok(p):

@@ -205,6 +205,13 @@ int eve_cast(int dtype_src, int dtype_dst, long long n, const void* src, void* d
 /* OHWI float master weights -> OHWI and IHWO copies in the compute dtype (one pass)                */
 int eve_pack_weights(int dtype_dst, int Cout, int taps, int Cin, const float* w_ohwi, void* dst_ohwi,
                      void* dst_ihwo, eve_stream_t stream);
+/* The same for up to EVE_PACK_BATCH_MAX weights in one launch (a model's conv weights after an optimiser step). */
+#define EVE_PACK_BATCH_MAX 48
+typedef struct eve_pack_item {
+    const float* w_ohwi; void* dst_ohwi; void* dst_ihwo;      /* either destination may be NULL */
+    int Cout, taps, Cin;
+} eve_pack_item;
+int eve_pack_weights_batch(int dtype_dst, int count, const eve_pack_item* items /* host array */, eve_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Recurrent cells.

@@ -218,6 +218,9 @@ class FakeKernels(object):
     def cast(self, src, dtype):
         return src.to(dtype)
 
+    def pack_weights_batch(self, ws, dtype, want_ihwo):
+        return [self.pack_weights(w, dtype, want_ihwo=wi) for w, wi in zip(ws, want_ihwo)]
+
     def pack_weights(self, w_ohwi_f32, dtype, want_ihwo=True):
         ohwi = w_ohwi_f32.to(dtype).contiguous()
         ihwo = w_ohwi_f32.permute(3, 1, 2, 0).to(dtype).contiguous() if want_ihwo else None
