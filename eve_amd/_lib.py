@@ -39,6 +39,10 @@ SIGNATURES = {
     'eve_stem_fwd_fused': [I, I, I, P, P, F, P, P, P, P],
     'eve_stem_bwd_dx': [I, I, I, P, P, P, P, P, P, P, P, P],
     'eve_bias_grad': [I, L, I, P, P, P],
+    'eve_rnn_scan_fwd': [I, I, I, P, P, P, P, P, P],
+    'eve_rnn_scan_bwd': [I, I, I, P, P, P, P, P, P],
+    'eve_lstm_scan_fwd': [I, I, I, P, P, P, P, P, P, P, P, P],
+    'eve_lstm_scan_bwd': [I, I, I, P, P, P, P, P, P, P, P, P, P, P],
     'eve_pack_weights_batch': [I, I, P, P],
     'eve_eye_losses': [I, I, P, P, P, P, P, P, F, F, P, P, P, P],
     'eve_linear_fwd': [I, I, I, P, P, P, I, P, P],

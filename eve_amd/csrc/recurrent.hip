@@ -87,6 +87,103 @@ __global__ void gru_scan_bwd_kernel(int T, int H, const float* __restrict__ dhs,
 }
 
 // ---------------------------------------------------------------------------------------------------
+// nn.RNNCell (tanh) and nn.LSTMCell over T (eye_net.py:60-67 variants of the recurrent stage).  G gate blocks of H
+// rows (1 / 4); grid = S sequences, block = G*H threads (H <= 256); whh_t is [H][G*H].
+//   RNN : h' = tanh(gi + W_hh h + b_hh)
+//   LSTM: (i, f, g, o) = gi + W_hh h + b_hh;  c' = s(f) c + s(i) tanh(g);  h' = s(o) tanh(c')
+// ---------------------------------------------------------------------------------------------------
+template <int G>
+__global__ void cell_scan_fwd_kernel(int T, int H, const float* __restrict__ gi, const float* __restrict__ whh_t,
+                                     const float* __restrict__ bhh, const float* __restrict__ h0, const float* __restrict__ c0,
+                                     float* __restrict__ hs, float* __restrict__ cs, float* __restrict__ gates) {
+    extern __shared__ float sm[];
+    float* h = sm;                  // [H]
+    float* pre = sm + H;            // [G*H]
+    const int s = blockIdx.x, j = threadIdx.x, HG = G * H;
+    float c = 0.f;
+    if (j < H) {
+        h[j] = h0 ? h0[(size_t)s * H + j] : 0.f;
+        if (G == 4) c = c0 ? c0[(size_t)s * H + j] : 0.f;
+    }
+    __syncthreads();
+    for (int t = 0; t < T; ++t) {
+        const size_t o = (size_t)s * T + t;
+        if (j < HG) {
+            float a = bhh[j] + gi[o * HG + j];
+            for (int k = 0; k < H; ++k) a = fmaf(whh_t[(size_t)k * HG + j], h[k], a);
+            pre[j] = a;
+        }
+        __syncthreads();
+        float hnew = 0.f;
+        if (j < H) {
+            if (G == 1) {
+                hnew = tanhf(pre[j]);
+            } else {
+                const float ig = sigmoidf_(pre[j]), fg = sigmoidf_(pre[H + j]), gg = tanhf(pre[2 * H + j]);
+                const float og = sigmoidf_(pre[3 * H + j]);
+                c = fg * c + ig * gg;
+                hnew = og * tanhf(c);
+                float* go = gates + o * HG;
+                go[j] = ig; go[H + j] = fg; go[2 * H + j] = gg; go[3 * H + j] = og;
+                cs[o * H + j] = c;
+            }
+            hs[o * H + j] = hnew;
+        }
+        __syncthreads();
+        if (j < H) h[j] = hnew;
+        __syncthreads();
+    }
+}
+
+// whh is the original [G*H][H].  dhs / dcs: gradients arriving at every step's h (and c, LSTM, nullable).
+template <int G>
+__global__ void cell_scan_bwd_kernel(int T, int H, const float* __restrict__ dhs, const float* __restrict__ dcs,
+                                     const float* __restrict__ whh, const float* __restrict__ c0, const float* __restrict__ hs,
+                                     const float* __restrict__ cs, const float* __restrict__ gates, float* __restrict__ dpre_out,
+                                     float* __restrict__ dh0, float* __restrict__ dc0) {
+    extern __shared__ float sm[];
+    float* dh = sm;                 // [H]   carried gradient on h_t
+    float* dp = sm + H;             // [G*H] gradient on the pre-activations of the current step
+    const int s = blockIdx.x, j = threadIdx.x, HG = G * H;
+    float dc = 0.f;
+    if (j < H) dh[j] = 0.f;
+    __syncthreads();
+    for (int t = T - 1; t >= 0; --t) {
+        const size_t o = (size_t)s * T + t;
+        if (j < H) {
+            const float d = dh[j] + dhs[o * H + j];
+            if (G == 1) {
+                const float hv = hs[o * H + j];
+                dp[j] = d * (1.f - hv * hv);
+            } else {
+                const float* g = gates + o * HG;
+                const float ig = g[j], fg = g[H + j], gg = g[2 * H + j], og = g[3 * H + j];
+                const float cv = cs[o * H + j], tc = tanhf(cv);
+                const float cp = t > 0 ? cs[(o - 1) * H + j] : (c0 ? c0[(size_t)s * H + j] : 0.f);
+                dc += (dcs ? dcs[o * H + j] : 0.f) + d * og * (1.f - tc * tc);
+                dp[j] = dc * gg * ig * (1.f - ig);
+                dp[H + j] = dc * cp * fg * (1.f - fg);
+                dp[2 * H + j] = dc * ig * (1.f - gg * gg);
+                dp[3 * H + j] = d * tc * og * (1.f - og);
+                dc *= fg;
+            }
+        }
+        __syncthreads();
+        if (j < HG) dpre_out[o * HG + j] = dp[j];
+        if (j < H) {
+            float a = 0.f;
+            for (int q = 0; q < HG; ++q) a = fmaf(whh[(size_t)q * H + j], dp[q], a);
+            dh[j] = a;
+        }
+        __syncthreads();
+    }
+    if (j < H) {
+        if (dh0) dh0[(size_t)s * H + j] = dh[j];
+        if (G == 4 && dc0) dc0[(size_t)s * H + j] = dc;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // H = 128 (the configured eye_net_rnn_num_features): the recurrent weights live in REGISTERS -- thread j keeps
 // column j of W_hh^T (128 floats) for all T steps instead of re-reading 192 KB from L1/L2 every step -- and the
 // per-step operands of the NEXT step are fetched while the current dot products run.  One workgroup per sequence.
@@ -369,6 +466,45 @@ extern "C" int eve_gru_scan_bwd(int S, int T, int H, const float* dhs, const flo
     const int threads = ((3 * H + 63) / 64) * 64;
     hipLaunchKernelGGL(gru_scan_bwd_kernel, dim3(S), dim3(threads), 4 * H * sizeof(float), (hipStream_t)stream,
                        T, H, dhs, whh, h0, hs, gates, hn_pre, dgi, dgh, dh0);
+    EVE_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int eve_rnn_scan_fwd(int S, int T, int H, const float* gi, const float* whh_t, const float* bhh, const float* h0,
+                                float* hs, eve_stream_t stream) {
+    if (S <= 0 || T <= 0 || H <= 0 || H > 256 || !gi || !whh_t || !bhh || !hs) return set_error_msg("rnn_scan_fwd: bad arguments (H <= 256)");
+    const int threads = ((H + 63) / 64) * 64;
+    hipLaunchKernelGGL(cell_scan_fwd_kernel<1>, dim3(S), dim3(threads), 2 * H * sizeof(float), (hipStream_t)stream, T, H, gi,
+                       whh_t, bhh, h0, (const float*)nullptr, hs, (float*)nullptr, (float*)nullptr);
+    EVE_CHECK_LAUNCH();
+    return 0;
+}
+extern "C" int eve_rnn_scan_bwd(int S, int T, int H, const float* dhs, const float* whh, const float* hs, float* dpre,
+                                float* dh0, eve_stream_t stream) {
+    if (S <= 0 || T <= 0 || H <= 0 || H > 256 || !dhs || !whh || !hs || !dpre) return set_error_msg("rnn_scan_bwd: bad arguments (H <= 256)");
+    const int threads = ((H + 63) / 64) * 64;
+    hipLaunchKernelGGL(cell_scan_bwd_kernel<1>, dim3(S), dim3(threads), 2 * H * sizeof(float), (hipStream_t)stream, T, H, dhs,
+                       (const float*)nullptr, whh, (const float*)nullptr, hs, (const float*)nullptr, (const float*)nullptr, dpre, dh0,
+                       (float*)nullptr);
+    EVE_CHECK_LAUNCH();
+    return 0;
+}
+extern "C" int eve_lstm_scan_fwd(int S, int T, int H, const float* gi, const float* whh_t, const float* bhh, const float* h0,
+                                 const float* c0, float* hs, float* cs, float* gates, eve_stream_t stream) {
+    if (S <= 0 || T <= 0 || H <= 0 || H > 256 || !gi || !whh_t || !bhh || !hs || !cs || !gates)
+        return set_error_msg("lstm_scan_fwd: bad arguments (H <= 256)");
+    hipLaunchKernelGGL(cell_scan_fwd_kernel<4>, dim3(S), dim3(((4 * H + 63) / 64) * 64), 5 * H * sizeof(float), (hipStream_t)stream,
+                       T, H, gi, whh_t, bhh, h0, c0, hs, cs, gates);
+    EVE_CHECK_LAUNCH();
+    return 0;
+}
+extern "C" int eve_lstm_scan_bwd(int S, int T, int H, const float* dhs, const float* dcs, const float* whh, const float* c0,
+                                 const float* hs, const float* cs, const float* gates, float* dpre, float* dh0, float* dc0,
+                                 eve_stream_t stream) {
+    if (S <= 0 || T <= 0 || H <= 0 || H > 256 || !dhs || !whh || !hs || !cs || !gates || !dpre)
+        return set_error_msg("lstm_scan_bwd: bad arguments (H <= 256)");
+    hipLaunchKernelGGL(cell_scan_bwd_kernel<4>, dim3(S), dim3(((4 * H + 63) / 64) * 64), 5 * H * sizeof(float), (hipStream_t)stream,
+                       T, H, dhs, dcs, whh, c0, hs, cs, gates, dpre, dh0, dc0);
     EVE_CHECK_LAUNCH();
     return 0;
 }

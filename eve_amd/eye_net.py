@@ -181,8 +181,9 @@ class EyeNet(nn.Module):
 
     # ------------------------------------------------------------------ tail: fc -> fc_common -> GRU -> heads
     def _tail(self, feats, head_pose, S, T, h0, P):
-        """feats [S*T, 512] float32 ordered (sequence, time); head_pose [S*T, 2] or None; h0 [S, H] or None.
-        Returns gaze [S*T, 2] (rad), pupil [S*T], states [S, T, H]."""
+        """feats [S*T, 512] float32 ordered (sequence, time); head_pose [S*T, 2] or None; h0: None or one initial
+        state per cell ([S, H] tensor, (h, c) pair for LSTM, or None).
+        Returns gaze [S*T, 2] (rad), pupil [S*T], states: None or per cell [S, T, H] / ((h) [S, T, H], (c) [S, T, H])."""
         cfg = self.config
         cnn = self.cnn_layers
         f = ops.linear(feats, cnn.fc.weight, cnn.fc.bias, P['fc'])
@@ -196,15 +197,26 @@ class EyeNet(nn.Module):
         f = ops.linear(f, self.fc_common[2].weight, self.fc_common[2].bias, P['fc_common.2'])
         states = None
         if cfg.eye_net_use_rnn:
-            if cfg.eye_net_rnn_type != 'GRU' or len(self.rnn_cells) != 1:
-                raise NotImplementedError(
-                    'eve_amd.EyeNet: only eye_net_rnn_type="GRU" with one cell has a HIP scan kernel so far '
-                    '(SURVEY 8 f3); got %s x %d' % (cfg.eye_net_rnn_type, len(self.rnn_cells)))
-            cell = self.rnn_cells[0]
-            gi = ops.linear(f, cell.weight_ih, cell.bias_ih, P['rnn.0.ih'])
-            H = cell.hidden_size
-            states = ops.GRUScanFn.apply(gi.view(S, T, 3 * H), cell.weight_hh, cell.bias_hh, h0)
-            f = states.reshape(S * T, H)
+            # the cells form a stack over depth; cell i at step t reads cell i-1 at step t and its own state at t-1, so
+            # each cell is one scan over the whole sequence of its predecessor's outputs (eye_net.py:112-135)
+            states = []
+            for i, cell in enumerate(self.rnn_cells):
+                init = h0[i] if h0 is not None else None
+                gi = ops.linear(f, cell.weight_ih, cell.bias_ih, P['rnn.%d.ih' % i])
+                H = cell.hidden_size
+                kind = cfg.eye_net_rnn_type
+                if kind == 'GRU':
+                    st = ops.GRUScanFn.apply(gi.view(S, T, 3 * H), cell.weight_hh, cell.bias_hh, init)
+                    hs = st
+                elif kind == 'RNN':
+                    st = ops.RNNScanFn.apply(gi.view(S, T, H), cell.weight_hh, cell.bias_hh, init)
+                    hs = st
+                else:                                   # LSTM: the state is the (h, c) pair, the output is h
+                    h_init, c_init = init if init is not None else (None, None)
+                    st = ops.LSTMScanFn.apply(gi.view(S, T, 4 * H), cell.weight_hh, cell.bias_hh, h_init, c_init)
+                    hs = st[0]
+                states.append(st)
+                f = hs.reshape(S * T, H)
         else:
             f = ops.linear(f, self.static_fc[0].weight, self.static_fc[0].bias, P['static_fc.0'], act=ACT_SELU)
         g = ops.linear(f, self.fc_to_gaze[0].weight, self.fc_to_gaze[0].bias, P['fc_to_gaze.0'], act=ACT_SELU)
@@ -224,13 +236,14 @@ class EyeNet(nn.Module):
         feats = self._trunk(x, P)
         head_pose = input_dict[side + '_h'] if self.config.eye_net_use_head_pose_input else None
         h0 = None
-        skey = side + '_eye_rnn_states_0'
-        if self.config.eye_net_use_rnn and previous_output_dict is not None:
-            h0 = previous_output_dict[skey]
+        ncell = len(self.rnn_cells) if self.config.eye_net_use_rnn else 0
+        if ncell and previous_output_dict is not None:
+            h0 = [previous_output_dict[side + '_eye_rnn_states_%d' % i] for i in range(ncell)]
         B = image.shape[0]
         gaze, pupil, states = self._tail(feats, head_pose, B, 1, h0, P)
-        if states is not None:
-            output_dict[skey] = states[:, 0]
+        for i in range(ncell):
+            st = states[i]
+            output_dict[side + '_eye_rnn_states_%d' % i] = tuple(s_[:, 0] for s_ in st) if isinstance(st, tuple) else st[:, 0]
         output_dict[side + '_g_initial'] = gaze
         output_dict[side + '_pupil_size'] = pupil.reshape(-1)
         if self.config.eye_net_frozen:
@@ -240,7 +253,8 @@ class EyeNet(nn.Module):
     def forward_sequence(self, batch, initial_states=None):
         """batch: {left,right}_eye_patch [B, T, 3, H, W] float, {left,right}_h [B, T, 2].
         Returns the B x T x ... tensors eve.py:174-182 would stack: <side>_g_initial [B,T,2],
-        <side>_pupil_size [B,T], <side>_eye_rnn_states_0 [B,T,H]."""
+        <side>_pupil_size [B,T], <side>_eye_rnn_states_<i> [B,T,H] per cell ((h, c) pair of them for LSTM).
+        initial_states: {side: h [B,H]} or {side: [per-cell h | (h, c) | None]}."""
         k = default_kernels()
         P = self._get_packs()
         dt = self.compute_dtype
@@ -259,9 +273,20 @@ class EyeNet(nn.Module):
         head_pose = None
         if self.config.eye_net_use_head_pose_input:
             head_pose = torch.cat([batch['left_h'].reshape(B * T, 2), batch['right_h'].reshape(B * T, 2)], dim=0)
+        ncell = len(self.rnn_cells) if self.config.eye_net_use_rnn else 0
         h0 = None
-        if initial_states is not None:
-            h0 = torch.cat([initial_states['left'], initial_states['right']], dim=0)
+        if initial_states is not None and ncell:
+            def per_cell(v):                      # a bare tensor is the first cell's hidden state
+                return list(v) if isinstance(v, (list,)) else [v] + [None] * (ncell - 1)
+            lft, rgt = per_cell(initial_states['left']), per_cell(initial_states['right'])
+            h0 = []
+            for a, b in zip(lft, rgt):
+                if a is None:
+                    h0.append(None)
+                elif isinstance(a, tuple):
+                    h0.append(tuple(torch.cat([x_, y_], dim=0) for x_, y_ in zip(a, b)))
+                else:
+                    h0.append(torch.cat([a, b], dim=0))
         gaze, pupil, states = self._tail(feats, head_pose, 2 * B, T, h0, P)
         out = {}
         for si, side in enumerate(('left', 'right')):
@@ -269,6 +294,8 @@ class EyeNet(nn.Module):
             g = gaze[sl].reshape(B, T, 2)
             out[side + '_g_initial'] = g.detach() if self.config.eye_net_frozen else g
             out[side + '_pupil_size'] = pupil[sl].reshape(B, T)
-            if states is not None:
-                out[side + '_eye_rnn_states_0'] = states[si * B:(si + 1) * B]
+            for i in range(ncell):
+                st = states[i]
+                cut = slice(si * B, (si + 1) * B)
+                out[side + '_eye_rnn_states_%d' % i] = tuple(s_[cut] for s_ in st) if isinstance(st, tuple) else st[cut]
         return out

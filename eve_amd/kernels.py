@@ -509,6 +509,43 @@ class HipKernels(object):
                                            self._p(dh0), self._stream()))
         return dgi, dgh, dh0
 
+    def rnn_scan_fwd(self, gi, whh_t, bhh, h0):
+        S, T, H = gi.shape
+        hs = torch.empty((S, T, H), dtype=torch.float32, device=gi.device)
+        self._ck(self.lib.eve_rnn_scan_fwd(S, T, H, self._p(self._f32(gi, 'gi')), self._p(whh_t), self._p(bhh), self._p(h0),
+                                           self._p(hs), self._stream()))
+        return hs
+
+    def rnn_scan_bwd(self, dhs, whh, hs, want_dh0):
+        S, T, H = dhs.shape
+        dpre = torch.empty((S, T, H), dtype=torch.float32, device=dhs.device)
+        dh0 = torch.empty((S, H), dtype=torch.float32, device=dhs.device) if want_dh0 else None
+        self._ck(self.lib.eve_rnn_scan_bwd(S, T, H, self._p(dhs), self._p(whh), self._p(hs), self._p(dpre), self._p(dh0),
+                                           self._stream()))
+        return dpre, dh0
+
+    def lstm_scan_fwd(self, gi, whh_t, bhh, h0, c0):
+        S, T, H4 = gi.shape
+        H = H4 // 4
+        dev = gi.device
+        hs = torch.empty((S, T, H), dtype=torch.float32, device=dev)
+        cs = torch.empty((S, T, H), dtype=torch.float32, device=dev)
+        gates = torch.empty((S, T, H4), dtype=torch.float32, device=dev)
+        self._ck(self.lib.eve_lstm_scan_fwd(S, T, H, self._p(self._f32(gi, 'gi')), self._p(whh_t), self._p(bhh), self._p(h0),
+                                            self._p(c0), self._p(hs), self._p(cs), self._p(gates), self._stream()))
+        return hs, cs, gates
+
+    def lstm_scan_bwd(self, dhs, dcs, whh, c0, hs, cs, gates, want_d0):
+        S, T, H = dhs.shape
+        dev = dhs.device
+        dpre = torch.empty((S, T, 4 * H), dtype=torch.float32, device=dev)
+        dh0 = torch.empty((S, H), dtype=torch.float32, device=dev) if want_d0 else None
+        dc0 = torch.empty((S, H), dtype=torch.float32, device=dev) if want_d0 else None
+        self._ck(self.lib.eve_lstm_scan_bwd(S, T, H, self._p(dhs), self._p(dcs), self._p(whh), self._p(c0), self._p(hs),
+                                            self._p(cs), self._p(gates), self._p(dpre), self._p(dh0), self._p(dc0),
+                                            self._stream()))
+        return dpre, dh0, dc0
+
     def cgru_gates1(self, g1, h):
         C = h.shape[-1]
         P = h.numel() // C

@@ -613,17 +613,81 @@ class GRUScanFn(torch.autograd.Function):
         S, T, H = hs.shape
         dgi, dgh, dh0 = k.gru_scan_bwd(dhs.contiguous().float(), whh, h0, hs, gates, hn_pre,
                                        ctx.has_h0 and ctx.needs_input_grad[3])
-        dw = db = None
-        if ctx.needs_input_grad[1]:
-            first = h0 if h0 is not None else torch.zeros((S, H), dtype=torch.float32, device=hs.device)
-            h_prev = torch.cat([first.unsqueeze(1), hs[:, :-1]], dim=1).contiguous()   # [S, T, H]
-            dwp = torch.zeros((3 * H, 1, 1, H), dtype=torch.float32, device=hs.device)
-            k.conv2d_wgrad(h_prev.view(S * T, 1, 1, H), dgh.view(S * T, 1, 1, 3 * H), 1, 1, 1, 0, dwp)
-            dw = dwp.view(3 * H, H)
-        if ctx.needs_input_grad[2]:
-            db = torch.zeros((3 * H,), dtype=torch.float32, device=hs.device)
-            k.bias_grad(dgh.view(S * T, 3 * H), db)
+        dw, db = _recurrent_param_grads(k, dgh.view(S * T, 3 * H), _shift_states(h0, hs), ctx.needs_input_grad[1],
+                                        ctx.needs_input_grad[2])
         return dgi, dw, db, dh0
+
+
+def _recurrent_param_grads(k, dpre, h_prev, need_w, need_b):
+    """dW_hh = dpre^T . h_prev and db_hh = column sums of dpre, over all (sequence, step) rows."""
+    R, GH = dpre.shape
+    H = h_prev.shape[1]
+    dw = torch.zeros((GH, H), dtype=torch.float32, device=dpre.device) if need_w or need_b else None
+    db = torch.zeros((GH,), dtype=torch.float32, device=dpre.device) if need_b else None
+    if dw is not None:
+        k.linear_wgrad(dpre, None, ACT_NONE, h_prev, dw, db)
+    return (dw if need_w else None), db
+
+
+def _shift_states(first, hs):
+    S, T, H = hs.shape
+    if first is None:
+        first = torch.zeros((S, H), dtype=torch.float32, device=hs.device)
+    return torch.cat([first.unsqueeze(1), hs[:, :-1]], dim=1).reshape(S * T, H).contiguous()
+
+
+class RNNScanFn(torch.autograd.Function):
+    """hs[s, t] = nn.RNNCell (tanh) over t, given gi = W_ih x + b_ih for all steps (eye_net.py:62-63)."""
+
+    @staticmethod
+    def forward(ctx, gi, w_hh, b_hh, h0):
+        k = default_kernels()
+        whh = w_hh.detach().float().contiguous()
+        h0c = h0.detach().float().contiguous() if h0 is not None else None
+        hs = k.rnn_scan_fwd(gi.contiguous(), whh.t().contiguous(), b_hh.detach().float().contiguous(), h0c)
+        ctx.has_h0 = h0 is not None
+        ctx.save_for_backward(whh, h0c, hs)
+        return hs
+
+    @staticmethod
+    def backward(ctx, dhs):
+        k = default_kernels()
+        whh, h0, hs = ctx.saved_tensors
+        S, T, H = hs.shape
+        dpre, dh0 = k.rnn_scan_bwd(dhs.contiguous().float(), whh, hs, ctx.has_h0 and ctx.needs_input_grad[3])
+        dw, db = _recurrent_param_grads(k, dpre.view(S * T, H), _shift_states(h0, hs), ctx.needs_input_grad[1],
+                                        ctx.needs_input_grad[2])
+        return dpre, dw, db, dh0
+
+
+class LSTMScanFn(torch.autograd.Function):
+    """(hs, cs)[s, t] = nn.LSTMCell over t (gate order i, f, g, o), given gi = W_ih x + b_ih (eye_net.py:64-66)."""
+
+    @staticmethod
+    def forward(ctx, gi, w_hh, b_hh, h0, c0):
+        k = default_kernels()
+        whh = w_hh.detach().float().contiguous()
+        h0c = h0.detach().float().contiguous() if h0 is not None else None
+        c0c = c0.detach().float().contiguous() if c0 is not None else None
+        hs, cs, gates = k.lstm_scan_fwd(gi.contiguous(), whh.t().contiguous(), b_hh.detach().float().contiguous(), h0c, c0c)
+        ctx.has_0 = h0 is not None
+        ctx.set_materialize_grads(False)
+        ctx.save_for_backward(whh, h0c, c0c, hs, cs, gates)
+        return hs, cs
+
+    @staticmethod
+    def backward(ctx, dhs, dcs):
+        k = default_kernels()
+        whh, h0, c0, hs, cs, gates = ctx.saved_tensors
+        S, T, H = hs.shape
+        if dhs is None:
+            dhs = torch.zeros_like(hs)
+        want0 = ctx.has_0 and (ctx.needs_input_grad[3] or ctx.needs_input_grad[4])
+        dpre, dh0, dc0 = k.lstm_scan_bwd(dhs.contiguous().float(), dcs.contiguous().float() if dcs is not None else None,
+                                         whh, c0, hs, cs, gates, want0)
+        dw, db = _recurrent_param_grads(k, dpre.view(S * T, 4 * H), _shift_states(h0, hs), ctx.needs_input_grad[1],
+                                        ctx.needs_input_grad[2])
+        return dpre, dw, db, dh0, dc0
 
 
 class CGRUGates1Fn(torch.autograd.Function):

@@ -228,6 +228,18 @@ int eve_gru_scan_fwd(int S, int T, int H, const float* gi, const float* whh_t, c
 int eve_gru_scan_bwd(int S, int T, int H, const float* dhs, const float* whh, const float* h0,
                      const float* hs, const float* gates, const float* hn_pre, float* dgi, float* dgh,
                      float* dh0, eve_stream_t stream);
+/* nn.RNNCell (tanh) and nn.LSTMCell over T -- the other recurrent variants of eye_net.py:60-67.  gi = W_ih x + b_ih
+ * for all steps ([S][T][G*H], G = 1 / 4 gate blocks in torch order i,f,g,o), whh_t = W_hh^T [H][G*H], whh = W_hh.
+ * The backward returns dpre = d(pre-activation) [S][T][G*H] (the gradient of gi, and the operand of dW_hh, db_hh). */
+int eve_rnn_scan_fwd(int S, int T, int H, const float* gi, const float* whh_t, const float* bhh, const float* h0,
+                     float* hs, eve_stream_t stream);
+int eve_rnn_scan_bwd(int S, int T, int H, const float* dhs, const float* whh, const float* hs, float* dpre,
+                     float* dh0, eve_stream_t stream);
+int eve_lstm_scan_fwd(int S, int T, int H, const float* gi, const float* whh_t, const float* bhh, const float* h0,
+                      const float* c0, float* hs, float* cs, float* gates, eve_stream_t stream);
+int eve_lstm_scan_bwd(int S, int T, int H, const float* dhs, const float* dcs, const float* whh, const float* c0,
+                      const float* hs, const float* cs, const float* gates, float* dpre, float* dh0, float* dc0,
+                      eve_stream_t stream);
 
 /* conv-GRU gate math of CGRUCell.forward (common.py:409-414), NHWC, C = hidden size:
  *   step 1: (r, u) = sigmoid(g1[..., 0:C], g1[..., C:2C]);  rh = r * h

@@ -226,6 +226,55 @@ class FakeKernels(object):
         ihwo = w_ohwi_f32.permute(3, 1, 2, 0).to(dtype).contiguous() if want_ihwo else None
         return ohwi, ihwo
 
+    def rnn_scan_fwd(self, gi, whh_t, bhh, h0):
+        S, T, H = gi.shape
+        h = torch.zeros((S, H)) if h0 is None else h0
+        hs = []
+        for t in range(T):
+            h = torch.tanh(gi[:, t] + h @ whh_t + bhh)
+            hs.append(h)
+        return torch.stack(hs, 1)
+
+    def rnn_scan_bwd(self, dhs, whh, hs, want_dh0):
+        S, T, H = dhs.shape
+        dh = torch.zeros((S, H))
+        dpre = torch.zeros((S, T, H))
+        for t in range(T - 1, -1, -1):
+            d = dh + dhs[:, t]
+            dpre[:, t] = d * (1 - hs[:, t] ** 2)
+            dh = dpre[:, t] @ whh
+        return dpre, (dh if want_dh0 else None)
+
+    def lstm_scan_fwd(self, gi, whh_t, bhh, h0, c0):
+        S, T, H4 = gi.shape
+        H = H4 // 4
+        h = torch.zeros((S, H)) if h0 is None else h0
+        c = torch.zeros((S, H)) if c0 is None else c0
+        hs, cs, gates = [], [], []
+        for t in range(T):
+            pre = gi[:, t] + h @ whh_t + bhh
+            i, f, g, o = torch.sigmoid(pre[:, :H]), torch.sigmoid(pre[:, H:2 * H]), torch.tanh(pre[:, 2 * H:3 * H]), \
+                torch.sigmoid(pre[:, 3 * H:])
+            c = f * c + i * g
+            h = o * torch.tanh(c)
+            hs.append(h); cs.append(c); gates.append(torch.cat([i, f, g, o], 1))
+        return torch.stack(hs, 1), torch.stack(cs, 1), torch.stack(gates, 1)
+
+    def lstm_scan_bwd(self, dhs, dcs, whh, c0, hs, cs, gates, want_d0):
+        S, T, H = dhs.shape
+        dh, dc = torch.zeros((S, H)), torch.zeros((S, H))
+        dpre = torch.zeros((S, T, 4 * H))
+        for t in range(T - 1, -1, -1):
+            d = dh + dhs[:, t]
+            i, f, g, o = gates[:, t, :H], gates[:, t, H:2 * H], gates[:, t, 2 * H:3 * H], gates[:, t, 3 * H:]
+            tc = torch.tanh(cs[:, t])
+            cp = cs[:, t - 1] if t > 0 else (c0 if c0 is not None else torch.zeros((S, H)))
+            dc = dc + (dcs[:, t] if dcs is not None else 0) + d * o * (1 - tc * tc)
+            dpre[:, t] = torch.cat([dc * g * i * (1 - i), dc * cp * f * (1 - f), dc * i * (1 - g * g), d * tc * o * (1 - o)], 1)
+            dc = dc * f
+            dh = dpre[:, t] @ whh
+        return dpre, (dh if want_d0 else None), (dc if want_d0 else None)
+
     def gru_scan_fwd(self, gi, whh_t, bhh, h0):
         S, T, H3 = gi.shape
         H = H3 // 3

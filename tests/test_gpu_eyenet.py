@@ -166,6 +166,32 @@ def test_fused_losses_match_oracle_values_and_gradients(B, T):
         assert float((a - b).abs().max()) <= 2e-4 * float(b.abs().max()) + 1e-7, k
 
 
+from test_host_logic import VARIANTS, _variant_id, check_eyenet_variant  # noqa: E402
+
+
+@pytest.mark.parametrize('over', VARIANTS, ids=_variant_id)
+def test_recurrent_variants_match_oracle(over):
+    """RNN / LSTM / stacked cells / static_fc (eye_net.py:58-78) through the HIP kernels, fp32: outputs, states handed over
+    through the dicts ((h, c) tuples for LSTM) and parameter gradients against the oracle."""
+    check_eyenet_variant(over, to_device=lambda t: t.cuda(), tol=GAZE_TOL, grad_tol=1e-2)
+
+
+@pytest.mark.parametrize('name', ['RNN1', 'LSTM1', 'GRU2', 'LSTM2', 'STATIC'])
+def test_recurrent_variants_match_reference_golden(name):
+    """The same variants against vectors produced by the reference's own EyeNet (tests/golden/eyenet_variants.npz)."""
+    import eve_amd
+    from test_oracle_golden import VARIANT_OVERRIDES, compare_with_variant_fixture, run_per_step
+    fx = np.load(os.path.join(GOLDEN, 'eyenet_variants.npz'))
+    B, T = int(fx['B']), int(fx['T'])
+    batch = detweights.eyenet_batch(B, T, seed=int(fx['seed']), invalid_fraction=float(fx['invalid_fraction']))
+    cfg = eve_amd.reset_standalone_config()
+    cfg.import_dict(VARIANT_OVERRIDES[name])
+    net = eve_amd.EyeNet()
+    net.compute_dtype = torch.float32
+    detweights.fill_module(net, seed=0)
+    compare_with_variant_fixture(fx, name, run_per_step(net.cuda(), batch, T, device='cuda'), GAZE_TOL)
+
+
 def test_bf16_deviation_is_bounded_and_reported():
     fx = np.load(os.path.join(GOLDEN, 'eyenet.npz'))
     B, T = int(fx['B']), int(fx['T'])

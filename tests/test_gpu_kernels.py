@@ -361,6 +361,38 @@ def test_gru_scan(hip, ref, H):
             close(g_[2], w_[2], torch.float32, 'gru dh0')
 
 
+@pytest.mark.parametrize('H', [128, 48])
+def test_rnn_and_lstm_scans(hip, ref, H):
+    """nn.RNNCell / nn.LSTMCell over T (the other recurrent variants of eye_net.py:60-67): forward and backward."""
+    S, T = 5, 6
+    for G, name in ((1, 'rnn'), (4, 'lstm')):
+        gi = rnd((S, T, G * H), torch.float32, 36)
+        whh = rnd((G * H, H), torch.float32, 37, scale=H ** -0.5)
+        bhh = rnd((G * H,), torch.float32, 38, scale=0.1)
+        for with0 in (False, True):
+            h0 = rnd((S, H), torch.float32, 39, scale=0.5) if with0 else None
+            c0 = rnd((S, H), torch.float32, 40, scale=0.5) if with0 else None
+            dhs = rnd((S, T, H), torch.float32, 41)
+            if G == 1:
+                hs_w = ref.rnn_scan_fwd(gi, whh.t().contiguous(), bhh, h0)
+                hs_g = hip.rnn_scan_fwd(dev(gi), dev(whh.t().contiguous()), dev(bhh), dev(h0))
+                close(hs_g, hs_w, torch.float32, 'rnn hs')
+                w_ = ref.rnn_scan_bwd(dhs, whh, hs_w, with0)
+                g_ = hip.rnn_scan_bwd(dev(dhs), dev(whh), dev(hs_w), with0)
+            else:
+                hs_w, cs_w, g_w = ref.lstm_scan_fwd(gi, whh.t().contiguous(), bhh, h0, c0)
+                hs_g, cs_g, g_g = hip.lstm_scan_fwd(dev(gi), dev(whh.t().contiguous()), dev(bhh), dev(h0), dev(c0))
+                close(hs_g, hs_w, torch.float32, 'lstm hs')
+                close(cs_g, cs_w, torch.float32, 'lstm cs')
+                close(g_g, g_w, torch.float32, 'lstm gates')
+                dcs = rnd((S, T, H), torch.float32, 42) if with0 else None
+                w_ = ref.lstm_scan_bwd(dhs, dcs, whh, c0, hs_w, cs_w, g_w, with0)
+                g_ = hip.lstm_scan_bwd(dev(dhs), dev(dcs), dev(whh), dev(c0), dev(hs_w), dev(cs_w), dev(g_w), with0)
+            for a, b in zip(g_, w_):
+                if b is not None:
+                    close(a, b, torch.float32, name + ' backward')
+
+
 @pytest.mark.parametrize('dtype', DTYPES, ids=['f32', 'bf16'])
 def test_cgru_gates(hip, ref, dtype):
     P, C = (3, 5, 8), 64

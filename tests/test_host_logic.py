@@ -111,6 +111,79 @@ def test_eyenet_host_logic_matches_oracle(fake):
         net({}, {}, side='left')
 
 
+VARIANTS = [dict(eye_net_rnn_type='RNN'), dict(eye_net_rnn_type='LSTM'), dict(eye_net_rnn_type='GRU', eye_net_rnn_num_cells=2),
+            dict(eye_net_rnn_type='LSTM', eye_net_rnn_num_cells=2), dict(eye_net_use_rnn=False)]
+
+
+def _variant_id(v):
+    return '-'.join('%s' % x for x in v.values())
+
+
+def check_eyenet_variant(over, to_device=lambda t: t, tol=1e-4, grad_tol=2e-3):
+    """Recurrent-stage variants of eye_net.py:58-78 (RNN / LSTM / stacked cells / static_fc): folded pass, per-step
+    contract (states handed over through the dicts, (h, c) tuples for LSTM) and parameter gradients vs the oracle."""
+    cfg = eve_amd.reset_standalone_config()
+    cfg.import_dict(over)
+    net = eve_amd.EyeNet()
+    ref = OracleEyeNet(OracleConfig(**over))
+    assert list(net.state_dict().keys()) == list(ref.state_dict().keys())
+    detweights.fill_module(net); detweights.fill_module(ref)
+    net = to_device(net)
+    batch = detweights.eyenet_batch(2, 3, seed=5, invalid_fraction=0.2)
+    dbatch = {k: to_device(v) for k, v in batch.items()}
+    # oracle: the reference's per-step loop, keeping every state (tensor or tuple)
+    rsteps, prev = [], None
+    for t in range(3):
+        si = {k: v[:, t] for k, v in batch.items()}
+        so = {}
+        ref(si, so, side='left', previous_output_dict=prev)
+        ref(si, so, side='right', previous_output_dict=prev)
+        rsteps.append(so)
+        prev = so
+    out = net.forward_sequence(dbatch)
+    for k in rsteps[0]:
+        if isinstance(rsteps[0][k], tuple):
+            for j in range(2):
+                want = torch.stack([s_[k][j] for s_ in rsteps], dim=1)
+                assert float((out[k][j].cpu() - want).abs().max()) < tol, (k, j)
+        else:
+            want = torch.stack([s_[k] for s_ in rsteps], dim=1)
+            assert float((out[k].cpu() - want).abs().max()) < tol, k
+    # gradients of a loss on both outputs
+    def loss(o_g, o_p):
+        return (o_g ** 2).sum() + o_p.sum()
+    loss(torch.stack([s_['left_g_initial'] for s_ in rsteps], 1), torch.stack([s_['right_pupil_size'] for s_ in rsteps], 1)).backward()
+    loss(out['left_g_initial'], out['right_pupil_size']).backward()
+    rp = dict(ref.named_parameters())
+    for n, p in net.named_parameters():
+        if not (n.startswith('rnn_cells') or n.startswith('static_fc') or n.startswith('fc_common')):
+            continue
+        a, b = p.grad.cpu().double(), rp[n].grad.double()
+        assert float((a - b).norm()) <= grad_tol * float(b.norm()) + 1e-7, n
+    # the per-step contract of the drop-in itself
+    steps, prev = [], None
+    with torch.no_grad():
+        for t in range(3):
+            si = {k: v[:, t] for k, v in dbatch.items()}
+            so = {}
+            net(si, so, side='left', previous_output_dict=prev)
+            net(si, so, side='right', previous_output_dict=prev)
+            steps.append(so)
+            prev = so
+    for k in rsteps[0]:
+        for t in range(3):
+            a, b = steps[t][k], rsteps[t][k]
+            if isinstance(b, tuple):
+                assert isinstance(a, tuple) and all(float((x.cpu() - y).abs().max()) < tol for x, y in zip(a, b)), (k, t)
+            else:
+                assert float((a.cpu() - b.detach()).abs().max()) < tol, (k, t)
+
+
+@pytest.mark.parametrize('over', VARIANTS, ids=_variant_id)
+def test_eyenet_recurrent_variants_host_logic(fake, over):
+    check_eyenet_variant(over)
+
+
 def test_eyenet_frozen_detaches(fake):
     cfg = eve_amd.reset_standalone_config()
     cfg.override('eye_net_frozen', True)

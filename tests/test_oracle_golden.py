@@ -52,6 +52,53 @@ def test_eyenet_frame_and_sequence_match_reference(golden_dir):
     assert np.abs(fx['seq_left_g_initial']).max() > 0.05
 
 
+VARIANT_OVERRIDES = {
+    'RNN1': dict(eye_net_use_rnn=True, eye_net_rnn_type='RNN', eye_net_rnn_num_cells=1),
+    'LSTM1': dict(eye_net_use_rnn=True, eye_net_rnn_type='LSTM', eye_net_rnn_num_cells=1),
+    'GRU2': dict(eye_net_use_rnn=True, eye_net_rnn_type='GRU', eye_net_rnn_num_cells=2),
+    'LSTM2': dict(eye_net_use_rnn=True, eye_net_rnn_type='LSTM', eye_net_rnn_num_cells=2),
+    'STATIC': dict(eye_net_use_rnn=False),
+}
+
+
+def run_per_step(net, batch, T, device=None):
+    """The reference's per-step contract: states handed over through previous_output_dict."""
+    steps, prev = [], None
+    with torch.no_grad():
+        for t in range(T):
+            si = {k: (v[:, t].to(device) if device else v[:, t]) for k, v in batch.items()}
+            so = {}
+            net(si, so, side='left', previous_output_dict=prev)
+            net(si, so, side='right', previous_output_dict=prev)
+            steps.append(so)
+            prev = so
+    return steps
+
+
+def compare_with_variant_fixture(fx, name, steps, tol):
+    keys = [k for k in fx.files if k.startswith(name + '/')]
+    assert keys
+    for fk in keys:
+        parts = fk.split('/')
+        want = fx[fk]
+        if len(parts) == 3:                       # LSTM: the state is an (h, c) tuple
+            got = torch.stack([s[parts[1]][int(parts[2])] for s in steps], 1)
+        else:
+            got = torch.stack([s[parts[1]] for s in steps], 1)
+        err = float(np.abs(got.cpu().numpy() - want).max())
+        assert err < tol, (fk, err)
+
+
+@pytest.mark.parametrize('name', sorted(VARIANT_OVERRIDES))
+def test_eyenet_recurrent_variants_match_reference(golden_dir, name):
+    """RNNCell / LSTMCell / stacked cells / static_fc (eye_net.py:58-78): oracle == the reference's EyeNet, per step."""
+    fx = np.load(os.path.join(golden_dir, 'eyenet_variants.npz'))
+    B, T = int(fx['B']), int(fx['T'])
+    batch = detweights.eyenet_batch(B, T, seed=int(fx['seed']), invalid_fraction=float(fx['invalid_fraction']))
+    net = detweights.fill_module(EyeNet(OracleConfig(**VARIANT_OVERRIDES[name])), seed=0)
+    compare_with_variant_fixture(fx, name, run_per_step(net, batch, T), 2e-6)
+
+
 def test_eyenet_train_step_matches_reference_eve(golden_dir):
     fx = load(golden_dir, 'eyenet.npz')
     cfg = eye_cfg()
