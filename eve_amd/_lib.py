@@ -37,6 +37,7 @@ SIGNATURES = {
     'eve_stem_pack_input': [I, I, I, I, P, P, P],
     'eve_stem7x7s2_fwd': [I, I, I, P, P, P, P],
     'eve_stem_fwd_fused': [I, I, I, P, P, F, P, P, P, P],
+    'eve_stem_wgrad': [I, I, I, P, P, P, P],
     'eve_stem_bwd_dx': [I, I, I, P, P, P, P, P, P, P, P, P],
     'eve_bias_grad': [I, L, I, P, P, P],
     'eve_rnn_scan_fwd': [I, I, I, P, P, P, P, P, P],

@@ -801,6 +801,30 @@ extern "C" int eve_conv2d_wgrad(const eve_conv_desc* d, const void* x, const voi
     return 0;
 }
 
+/* Weight gradient of the ResNet stem straight from the packed patches the stem kernels read:
+   x_padded [N][IH+6][IW+8][4] bf16 is viewed as a 4-channel NHWC image and the filter as 7 x 8 taps (the 8th column
+   does not exist; its gradient is written and ignored), so a 16-byte operand slot is two horizontally adjacent taps and
+   K = 7*8*4 = 224 fits ONE K tile -- against K = 392 (two padded tiles, 62 % of the MACs on zero channels) for the
+   8-channel NHWC copy, which is no longer needed at all.  dw [64][7][8][4] float, accumulated. */
+extern "C" int eve_stem_wgrad(int N, int IH, int IW, const void* x_padded, const void* dconv, float* dw, eve_stream_t stream) {
+    if (N <= 0 || IH <= 0 || IW <= 0 || (IH & 1) || (IW & 1) || !x_padded || !dconv || !dw)
+        return set_error_msg("stem_wgrad: bad arguments");
+    GatherParams p;
+    p.N = N; p.IH = IH + 6; p.IW = IW + 8; p.Cin = 4;
+    p.OH = IH / 2; p.OW = IW / 2; p.Cout = 64; p.KH = 7; p.KW = 8;
+    p.o_mul = 2; p.k_mul = 1; p.off = 0; p.div = 1;          // the padding is materialised in x_padded
+    p.K = 7 * 8 * 4;
+    p.M = (uint32_t)((long long)N * p.OH * p.OW);
+    p.fd_ohw = make_fastdiv(p.OH * p.OW); p.fd_ow = make_fastdiv(p.OW);
+    p.fd_cin = make_fastdiv(4); p.fd_kw = make_fastdiv(8);
+    // conv pad is 3, the packed rows carry 4 pixels of left padding: start one pixel (8 bytes) in
+    const char* x1 = (const char*)x_padded + 8;
+    if ((unsigned long long)N * p.IH * p.IW * 8 >= (1ull << 31)) return set_error_msg("stem_wgrad: packed input must stay below 2 GiB");
+    launch_wgrad<bf16_t>(p, x1, dconv, nullptr, 0, dw, (hipStream_t)stream);
+    EVE_CHECK_LAUNCH();
+    return 0;
+}
+
 extern "C" int eve_bias_grad(int dtype, long long M, int C, const void* dy, float* db, eve_stream_t stream) {
     const int vec = dtype == EVE_DT_BF16 ? 8 : 4;
     if (M <= 0 || C <= 0 || C % vec || C / vec > 256) return set_error_msg("bias_grad: bad shape");

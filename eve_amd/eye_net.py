@@ -166,7 +166,7 @@ class EyeNet(nn.Module):
             blocks.append(((P[name + '.conv1'], P[name + '.conv2'], P[name + '.downsample.0'] if ds is not None else None),
                            blk.stride))
             weights += [blk.conv1.weight, blk.conv2.weight] + ([ds[0].weight] if ds is not None else [])
-        if x_padded is not None and x_padded.shape[2] == 136 and x_padded.shape[1] % 4 == 2:
+        if x is None or (x_padded is not None and x_padded.shape[2] == 136 and x_padded.shape[1] % 4 == 2):
             # 128-wide patches: conv1 -> bn1 -> relu -> maxpool in one launch, inside the trunk node
             y = ops.ResNetTrunkFn.apply(None, x, x_padded, (P['conv1'], tuple(blocks)), 1e-5, cnn.conv1.weight, *weights)
         else:
@@ -261,14 +261,19 @@ class EyeNet(nn.Module):
         left, right = batch['left_eye_patch'], batch['right_eye_patch']
         B, T, C, Hh, Ww = left.shape
         cpad = pad_channels(C, dt)
-        x = torch.empty((2 * B * T, Hh, Ww, cpad), dtype=dt, device=left.device)
-        k.nchw_to_nhwc(left.reshape(B * T, C, Hh, Ww), dt, cpad, out=x[:B * T])
-        k.nchw_to_nhwc(right.reshape(B * T, C, Hh, Ww), dt, cpad, out=x[B * T:])
-        x_padded = None
-        if dt == torch.bfloat16 and C <= 4 and Hh % 2 == 0 and Ww % 128 == 0:      # dedicated stem kernel
+        x = x_padded = None
+        if dt == torch.bfloat16 and C <= 4 and Hh % 4 == 0 and Ww == 128:          # fused stem: packed patches only
             x_padded = torch.empty((2 * B * T, Hh + 6, Ww + 8, 4), dtype=dt, device=left.device)
             k.stem_pack_input(left.reshape(B * T, C, Hh, Ww), out=x_padded[:B * T])
             k.stem_pack_input(right.reshape(B * T, C, Hh, Ww), out=x_padded[B * T:])
+        else:
+            x = torch.empty((2 * B * T, Hh, Ww, cpad), dtype=dt, device=left.device)
+            k.nchw_to_nhwc(left.reshape(B * T, C, Hh, Ww), dt, cpad, out=x[:B * T])
+            k.nchw_to_nhwc(right.reshape(B * T, C, Hh, Ww), dt, cpad, out=x[B * T:])
+            if dt == torch.bfloat16 and C <= 4 and Hh % 2 == 0 and Ww % 128 == 0:  # dedicated stem conv kernel
+                x_padded = torch.empty((2 * B * T, Hh + 6, Ww + 8, 4), dtype=dt, device=left.device)
+                k.stem_pack_input(left.reshape(B * T, C, Hh, Ww), out=x_padded[:B * T])
+                k.stem_pack_input(right.reshape(B * T, C, Hh, Ww), out=x_padded[B * T:])
         feats = self._trunk(x, P, x_padded)
         head_pose = None
         if self.config.eye_net_use_head_pose_input:

@@ -201,6 +201,16 @@ class HipKernels(object):
             self._stream())))
         return y, idx, mr
 
+    def stem_wgrad(self, x_padded, dconv, dw):
+        """dw [64, 7, 8, 4] float32 += weight gradient of conv1 from the packed patches (filter column 7 / channel 3 unused)."""
+        N, Hp, Wp, _ = x_padded.shape
+        IH, IW = Hp - 6, Wp - 8
+        assert tuple(dw.shape) == (64, 7, 8, 4) and dw.dtype == torch.float32 and dw.is_contiguous()
+        assert tuple(dconv.shape) == (N, IH // 2, IW // 2, 64) and dconv.dtype == torch.bfloat16
+        flops = 2.0 * N * (IH // 2) * (IW // 2) * 64 * 147
+        self._timed('conv_wgrad', flops, lambda: self._ck(self.lib.eve_stem_wgrad(
+            N, IH, IW, self._p(x_padded), self._p(dconv), self._p(dw), self._stream())))
+
     def stem_bwd_dx(self, x_padded, w_ohwi8, mr, dy_pool, y_pool, idx, dy_pool2=None):
         N, Hp, Wp, _ = x_padded.shape
         IH, IW = Hp - 6, Wp - 8

@@ -369,7 +369,7 @@ class ResNetTrunkFn(torch.autograd.Function):
 
     apply(x, x8, x_padded, spec, eps, *weights):
       spec = (stem_pack or None, ((p1, p2, pd), stride) per block); weights = [conv1 if stem] + per block (w1, w2[, wd]).
-      With a stem, x is ignored and the input is (x8, x_padded) (no data gradient); without, x is the block input."""
+      With a stem, x and x8 are ignored and the input is x_padded (no data gradient); without, x is the block input."""
 
     @staticmethod
     def forward(ctx, x, x8, x_padded, spec, eps, *weights):
@@ -378,7 +378,7 @@ class ResNetTrunkFn(torch.autograd.Function):
         saved = []
         if stem_pack is not None:
             y, idx, mr = k.stem_fwd_fused(x_padded, stem_pack.ohwi, eps)
-            saved += [x8, x_padded, y, idx, mr]
+            saved += [x_padded, y, idx, mr]
         else:
             y = x
         for packs, stride in blocks:
@@ -413,14 +413,13 @@ class ResNetTrunkFn(torch.autograd.Function):
                 grads[wpos + 2] = dwd
         dx = None
         if stem_pack is not None:
-            x8, x_padded, y, idx, mr = saved[:5]
+            x_padded, y, idx, mr = saved[:4]
             dconv = k.stem_bwd_dx(x_padded, stem_pack.ohwi, mr, d_a, y, idx, dy_pool2=d_b)
             if need_w[0]:
-                cout_p, KH, KW, cin_p = stem_pack.ohwi.shape
-                dwp = torch.zeros((cout_p, KH, KW, cin_p), dtype=torch.float32, device=x8.device)
-                k.conv2d_wgrad(x8, dconv, KH, KW, 2, 3, dwp, algo=stem_pack.algo)
+                dwp = torch.zeros((64, 7, 8, 4), dtype=torch.float32, device=dconv.device)
+                k.stem_wgrad(x_padded, dconv, dwp)          # straight from the packed patches (no 8-channel copy)
                 O, I = stem_pack.shape_oihw[0], stem_pack.shape_oihw[1]
-                grads[0] = dwp[:O, :, :, :I].permute(0, 3, 1, 2)
+                grads[0] = dwp[:O, :, :7, :I].permute(0, 3, 1, 2)
         elif ctx.needs_input_grad[0]:
             dx = k.add(d_a, d_b) if d_b is not None else d_a
         lane.join()

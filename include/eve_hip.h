@@ -92,6 +92,9 @@ int eve_stem_fwd_fused(int N, int IH, int IW, const void* x_padded, const void* 
                        void* y_pool, uint8_t* idx, float* mean_rstd, eve_stream_t stream);
 /* Its backward up to the convolution output: dx [N][IH/2][IW/2][64] bf16 = d(conv1 out) from dy_pool, recomputing
  * the convolution from x_padded (autograd of bn1/relu/maxpool in eye_net.py:106); feed dx to eve_conv2d_wgrad. */
+/* ... and the stem's weight gradient from the same packed patches: dw [64][7][8][4] float (accumulated; filter
+ * column 7 and channel 3 do not exist and are ignored by the caller).  Replaces autograd of conv1 (eye_net.py:106). */
+int eve_stem_wgrad(int N, int IH, int IW, const void* x_padded, const void* dconv, float* dw, eve_stream_t stream);
 int eve_stem_bwd_dx(int N, int IH, int IW, const void* x_padded, const void* w_ohwi8, const float* mean_rstd,
                     const void* dy_pool, const void* dy_pool2 /* nullable second summand */, const void* y_pool, const uint8_t* idx, void* dx, eve_stream_t stream);
 /* Small float32 linear layers (nn.Linear of the EyeNet tail, eye_net.py:52-90: fc, fc_common, GRU input

@@ -88,6 +88,11 @@ class FakeKernels(object):
         y, idx = self.in_relu_maxpool_fwd(conv, mr)
         return y, idx, mr
 
+    def stem_wgrad(self, x_padded, dconv, dw):
+        x = x_padded[:, 3:-3, 4:-4, :].float().permute(0, 3, 1, 2)
+        g = torch.nn.grad.conv2d_weight(x, (64, 4, 7, 7), nchw(dconv), stride=2, padding=3)     # [64, 4, 7, 7]
+        dw[:, :, :7, :] += g.permute(0, 2, 3, 1)
+
     def stem_bwd_dx(self, x_padded, w_ohwi8, mr, dy_pool, y_pool, idx, dy_pool2=None):
         if dy_pool2 is not None:
             dy_pool = (dy_pool.float() + dy_pool2.float()).to(dy_pool.dtype)

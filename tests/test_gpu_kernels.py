@@ -219,6 +219,23 @@ def test_small_linear_kernels(hip, ref, shape, act):
     assert torch.allclose(db.cpu(), db_ref, rtol=2e-4, atol=2e-4 * (M ** 0.5))
 
 
+def test_stem_wgrad_from_packed_patches(hip):
+    """conv1's weight gradient read from the 4-channel packed patches (7x8-tap view) == the generic kernel on NHWC8."""
+    N = 5
+    src = rnd((N, 3, 128, 128), torch.float32, 67)
+    xp = hip.stem_pack_input(dev(src))
+    x8 = hip.nchw_to_nhwc(dev(src), torch.bfloat16, 8)
+    dconv = dev(rnd((N, 64, 64, 64), torch.bfloat16, 68))
+    dw = torch.zeros((64, 7, 8, 4), device='cuda')
+    hip.stem_wgrad(xp, dconv, dw)
+    want = hip.conv2d_wgrad(x8, dconv, 7, 7, 2, 3, torch.zeros((64, 7, 7, 8), device='cuda'))
+    got = dw[:, :, :7, :3]
+    assert ((got - want[..., :3]).norm() / want[..., :3].norm()).item() < 2e-3
+    ref = torch.nn.grad.conv2d_weight(x8.float().permute(0, 3, 1, 2)[:, :3], (64, 3, 7, 7), dconv.float().permute(0, 3, 1, 2),
+                                      stride=2, padding=3).permute(0, 2, 3, 1)
+    assert ((got - ref).norm() / ref.norm()).item() < 2e-3
+
+
 def test_conv_rejects_bad_shapes(hip):
     x = torch.zeros((1, 8, 8, 6), device='cuda')
     w = torch.zeros((8, 3, 3, 6), device='cuda')
