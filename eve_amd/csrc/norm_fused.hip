@@ -5,6 +5,7 @@
 //   forward : 1 read (+1 for the residual) + 1 write     (was: stats pass + apply pass = 2 reads + 1 write)
 //   backward: 3 reads (dy, x, y) + 1-2 writes             (was: two passes over all three = 6 reads)
 // Statistics are the exact two-pass form (mean, then centred second moment) over registers.
+#include <stdlib.h>
 #include "common.h"
 
 namespace eve {
@@ -195,8 +196,12 @@ __global__ __launch_bounds__(1024) void in_bwd_fused_kernel(const T* __restrict_
 // threads per block and vectors per thread for a plane of nvec 16-byte vectors; false if it does not fit
 static bool fused_plan(int nvec, int cvecs, int& threads, int& vpt) {
     if (nvec <= 0 || cvecs <= 0 || cvecs > 128 || (cvecs & (cvecs - 1))) return false;
+    // as many vectors per thread as leaves >= `min_threads` threads: fewer, fatter workgroups per plane let several
+    // planes share a CU, so one plane's reduction phase overlaps another's loads / stores
+    static int min_threads = -1;
+    if (min_threads < 0) { const char* e = getenv("EVE_IN_MIN_THREADS"); min_threads = e ? atoi(e) : 512; }
     vpt = 1;
-    while (vpt < 8 && (nvec + vpt - 1) / vpt > 1024) vpt *= 2;
+    while (vpt < 8 && ((nvec + vpt - 1) / vpt > 1024 || (nvec + 2 * vpt - 1) / (2 * vpt) >= min_threads)) vpt *= 2;
     if ((nvec + vpt - 1) / vpt > 1024) return false;
     const int q = cvecs > 64 ? cvecs : 64;
     threads = ((nvec + vpt - 1) / vpt + q - 1) / q * q;
