@@ -302,8 +302,9 @@ __global__ __launch_bounds__(64 * WCO * WK) void wgrad_tr_kernel(const GatherPar
     constexpr int P_DMA = (P_SLOTS + NT - 1) / NT, Q_DMA = (Q_SLOTS + NT - 1) / NT;
     constexpr int NDMA = P_DMA + Q_DMA;                      // LDS-DMA instructions per thread and stage
     constexpr int BUF = STEP * (PROW + QROW);                // bytes per stage (16 KB / 20 KB)
-    constexpr int RING = 4;                                  // 64 / 80 KB of LDS, two workgroups per CU (a 3-deep ring with
-                                                             // three workgroups per CU measured 7 % slower)
+    // 128x128 tiles: 3 stages of 16 KB -> three workgroups per CU (after the address-arithmetic diet this beats the
+    // 4-deep ring with two workgroups by 7-9 % on layers 3/4); 64x256 tiles: 4 stages of 20 KB, two workgroups
+    constexpr int RING = WCO == 2 ? 3 : 4;
     static_assert((P_SLOTS % NT == 0 || (P_DMA == 1 && P_SLOTS % 64 == 0)) && (Q_SLOTS % NT == 0 || (Q_DMA == 1 && Q_SLOTS % 64 == 0)),
                   "stage slots must tile the workgroup");
     extern __shared__ __attribute__((aligned(16))) char lds[];   // RING * BUF bytes
@@ -450,8 +451,8 @@ __global__ __launch_bounds__(64 * WCO * WK) void wgrad_tr_kernel(const GatherPar
         offsets(m_begin + (RING - 1) * STEP, vp, vq);
         auto do_step = [&](int st) {
             // stage st has landed once at most the RING-2 newer stages are outstanding (loads return in order)
-            static_assert(RING == 4, "the immediates below are (RING - 2) * NDMA");
-            if (NDMA == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            if (RING == 3) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else if (NDMA == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
             else           asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             issue((st + RING - 1) % RING, vp, vq);            // stage st+RING-1 recycles the slot read in step st-1

@@ -684,7 +684,7 @@ static int launch_wgrad(const GatherParams& p, const void* x, const void* dy, co
             uint32_t splits, rows;
             const bool pow2 = ((p.OW & (p.OW - 1)) == 0) && ((p.OH & (p.OH - 1)) == 0);
             // dynamic LDS = RING (4) stages of 32 pixels x (BCO + BKK) bf16
-            auto lds_bytes = [](int bco, int bkk) { return (size_t)4 * 32 * (bco + bkk) * 2; };
+            auto lds_bytes = [](int bco, int bkk) { return (size_t)(bco == 128 ? 3 : 4) * 32 * (bco + bkk) * 2; };
 #define EVE_WGRAD_LAUNCH(WCO_, WK_, P2_, TK, TC)                                                                        \
     do {                                                                                                                \
         static bool attr_done = false;                                                                                  \
