@@ -450,8 +450,20 @@ __global__ __launch_bounds__(256) void bias_grad_kernel(const T* __restrict__ dy
 #pragma unroll
             for (int e = 0; e < VEC; ++e) s[e] += f[e];
         }
+    }
+    // one atomic per channel and workgroup: with few channels (RefineNet: 16..64) thousands of workgroups hammering
+    // the same handful of addresses from every thread serialised into milliseconds per launch
+    __shared__ float red[256 * VEC];
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) atomicAdd(db + cv * VEC + e, s[e]);
+    for (int e = 0; e < VEC; ++e) red[tid * VEC + e] = ph < phases ? s[e] : 0.f;
+    __syncthreads();
+    if (tid < cvecs) {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            float a = 0.f;
+            for (int q = 0; q < phases; ++q) a += red[(q * cvecs + tid) * VEC + e];
+            atomicAdd(db + tid * VEC + e, a);
+        }
     }
 }
 
