@@ -326,25 +326,47 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const float* __restri
 
 // all conv weights of a model in one launch (the packs are rebuilt after every optimiser step: 20 launches of a few
 // microseconds each were 0.14 ms of a 15 ms step)
-struct PackItem { const float* w; void* ohwi; void* ihwo; int Cout, taps, Cin; long long start; };
-struct PackTable { PackItem it[EVE_PACK_BATCH_MAX]; int count; long long total; };
+struct PackItem { const float* w; void* ohwi; void* ihwo; int Cout, taps, Cin; long long start; };   // start = first tile
+struct PackTable { PackItem it[EVE_PACK_BATCH_MAX]; int count; long long total; };                   // total tiles
 
+// One workgroup = one 32 (output channels) x 32 (input channels) tile of one filter tap: rows are read and written
+// along the input channels (OHWI copy) and, transposed through LDS, along the output channels (IHWO copy), so both
+// destinations get contiguous stores (the element-wise version scattered 2-byte writes for the IHWO copy).
 template <typename T>
 __global__ __launch_bounds__(256) void pack_weights_batch_kernel(const PackTable tb) {
-    for (long long g = (long long)blockIdx.x * 256 + threadIdx.x; g < tb.total; g += (long long)gridDim.x * 256) {
+    __shared__ float tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;          // 32 x 8
+    for (long long g = blockIdx.x; g < tb.total; g += gridDim.x) {
         int k = 0;
         while (k + 1 < tb.count && g >= tb.it[k + 1].start) ++k;
         const PackItem& q = tb.it[k];
-        const long long i = g - q.start;
-        const float v = q.w[i];
-        if (q.ohwi) Elem<T>::st((T*)q.ohwi + i, v);
-        if (q.ihwo) {
-            const int ci = (int)(i % q.Cin);
-            long long t = i / q.Cin;
-            const int tap = (int)(t % q.taps);
-            const long long co = t / q.taps;
-            Elem<T>::st((T*)q.ihwo + ((long long)ci * q.taps + tap) * q.Cout + co, v);
+        const int tci = (q.Cin + 31) / 32, tco = (q.Cout + 31) / 32;
+        long long t = g - q.start;
+        const int ci0 = (int)(t % tci) * 32; t /= tci;
+        const int tap = (int)(t % q.taps);
+        const int co0 = (int)(t / q.taps) * 32;
+        (void)tco;
+#pragma unroll
+        for (int r = ty; r < 32; r += 8) {
+            const int co = co0 + r, ci = ci0 + tx;
+            float v = 0.f;
+            if (co < q.Cout && ci < q.Cin) {
+                const long long i = ((long long)co * q.taps + tap) * q.Cin + ci;
+                v = q.w[i];
+                if (q.ohwi) Elem<T>::st((T*)q.ohwi + i, v);
+            }
+            tile[r][tx] = v;
         }
+        __syncthreads();
+        if (q.ihwo) {
+#pragma unroll
+            for (int r = ty; r < 32; r += 8) {
+                const int ci = ci0 + r, co = co0 + tx;
+                if (ci < q.Cin && co < q.Cout)
+                    Elem<T>::st((T*)q.ihwo + ((long long)ci * q.taps + tap) * q.Cout + co, tile[tx][r]);
+            }
+        }
+        __syncthreads();
     }
 }
 
@@ -502,12 +524,13 @@ extern "C" int eve_pack_weights_batch(int dtype_dst, int count, const eve_pack_i
         if (q.Cout <= 0 || q.taps <= 0 || q.Cin <= 0 || !q.w_ohwi || (!q.dst_ohwi && !q.dst_ihwo))
             return set_error_msg("pack_weights_batch: bad item");
         tb.it[i] = PackItem{q.w_ohwi, q.dst_ohwi, q.dst_ihwo, q.Cout, q.taps, q.Cin, total};
-        total += (long long)q.Cout * q.taps * q.Cin;
+        total += (long long)((q.Cout + 31) / 32) * q.taps * ((q.Cin + 31) / 32);
     }
     tb.count = count; tb.total = total;
     hipStream_t s = (hipStream_t)stream;
-    if (dtype_dst == EVE_DT_BF16) hipLaunchKernelGGL(pack_weights_batch_kernel<bf16_t>, dim3(sgrid(total)), dim3(256), 0, s, tb);
-    else                          hipLaunchKernelGGL(pack_weights_batch_kernel<float>, dim3(sgrid(total)), dim3(256), 0, s, tb);
+    const unsigned blocks = (unsigned)(total < 4096 ? total : 4096);
+    if (dtype_dst == EVE_DT_BF16) hipLaunchKernelGGL(pack_weights_batch_kernel<bf16_t>, dim3(blocks), dim3(256), 0, s, tb);
+    else                          hipLaunchKernelGGL(pack_weights_batch_kernel<float>, dim3(blocks), dim3(256), 0, s, tb);
     EVE_CHECK_LAUNCH();
     return 0;
 }

@@ -355,6 +355,15 @@ def test_layout_and_pack(hip, ref, dtype):
     close(a_g, a_w, dtype, 'pack ohwi')
     close(b_g, b_w, dtype, 'pack ihwo')
     close(hip.cast(dev(w), dtype), w.to(dtype), dtype, 'cast')
+    # the batched (one launch, tile-transposing) variant on ragged shapes, with and without the IHWO copy
+    ws = [rnd(sh, torch.float32, 90 + i) for i, sh in enumerate([(16, 3, 3, 8), (40, 1, 1, 72), (64, 7, 7, 8), (4, 1, 1, 128), (130, 3, 3, 33)])]
+    want_ihwo = [True, True, False, True, True]
+    res = hip.pack_weights_batch([dev(w_) for w_ in ws], dtype, want_ihwo)
+    for w_, wi, (a, b) in zip(ws, want_ihwo, res):
+        assert torch.equal(a.cpu(), w_.to(dtype))
+        assert (b is None) == (not wi)
+        if wi:
+            assert torch.equal(b.cpu(), w_.permute(3, 1, 2, 0).contiguous().to(dtype))
 
 
 @pytest.mark.parametrize('H', [128, 96], ids=['h128_register_resident', 'h96_generic'])
