@@ -76,6 +76,24 @@ def cpu_baseline(T, size, steps=2, budget_s=45.0):
                       % (B, T, size, size, done if done else 0)}
 
 
+def pmc_traffic(symbol):
+    """HBM bytes per launch of `symbol` from the committed rocprofv3 --pmc summary (two separate passes, FETCH_SIZE and
+    WRITE_SIZE, of this same workload; FETCH doubled as MI355X_MICROARCH.md prescribes for wide reads).  Counters cannot be
+    collected from inside the timed process, so this is the most recent measured profile, or None."""
+    here = os.path.dirname(os.path.abspath(__file__))
+    cands = sorted(f for f in os.listdir(os.path.join(here, 'profiles')) if f.endswith('_pmc_hbm_per_kernel.json')) \
+        if os.path.isdir(os.path.join(here, 'profiles')) else []
+    for name in reversed(cands):
+        try:
+            table = json.load(open(os.path.join(here, 'profiles', name)))
+        except (OSError, ValueError):
+            continue
+        for k, v in table.items():
+            if k.replace('void ', '').strip() == 'eve::' + symbol and v.get('fetch_mb_avg_x2') is not None:
+                return (v['fetch_mb_avg_x2'] + (v.get('write_mb_avg') or 0.0)) * 1024 * 1024, 'profiles/' + name
+    return None, None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -177,8 +195,10 @@ def main():
             d = by_kernel[dom]
             achieved = d['flops'] / (d['ms'] * 1e-3) / 1e12
             sym = 'eve::' + dom
+            traffic, traffic_src = pmc_traffic(dom)
             out['roofline'] = {'bound': 'mfma', 'kernel': sym, 'achieved': achieved, 'peak': peak,
-                               'unit': 'TFLOP/s', 'frac': achieved / peak, 'traffic': None,
+                               'unit': 'TFLOP/s', 'frac': achieved / peak, 'traffic': traffic,
+                               'traffic_unit': 'bytes per launch (FETCH_SIZE x2 + WRITE_SIZE)', 'traffic_source': traffic_src,
                                'launches_per_step': d['launches'] / args.profile_steps,
                                'avg_launch_ms': d['ms'] / d['launches'],
                                'algorithmic_gflop_per_launch': d['flops'] / d['launches'] / 1e9,
