@@ -17,6 +17,8 @@ is per-sample) and runs only the 64x5x8 conv-RNN sequentially.
 
 nn.Conv2d / nn.InstanceNorm2d objects are PARAMETER HOLDERS; their ATen forward is never called.
 """
+import os
+
 import torch
 from torch import nn
 
@@ -296,12 +298,26 @@ class RefineNet(nn.Module):
         x, skips, prefix = self._encode(x, P)
         C = x.shape[-1]
         xs = x.view(B, T, x.shape[1], x.shape[2], C)
-        outs, states, hist = [], None, []
-        for t in range(T):
-            xt, states = self._bottleneck(xs[:, t].contiguous(), states, prefix, P)
-            outs.append(xt)
-            hist.append(states)
-        x = torch.stack(outs, dim=1).view(B * T, x.shape[1], x.shape[2], C)
+        bott = self.network
+        while isinstance(bott, WrapEncoderDecoder):
+            bott = bott.between_module
+        cells = list(bott.rnn_cells) if self.config.refine_net_use_rnn else []
+        fused = (len(cells) == 1 and isinstance(cells[0], CGRUCell) and xs.dtype == torch.bfloat16 and
+                 tuple(xs.shape[2:]) == (5, 8, 64) and os.environ.get('EVE_AMD_CGRU_SCAN', '1') != '0')
+        if fused:
+            # the whole clip through the conv-GRU in one persistent launch (hidden state resident in LDS)
+            cell, name = cells[0], '%s.rnn_cells.0' % prefix
+            hs = ops.CGRUScanFn.apply(xs.contiguous(), cell.gates_1.weight, cell.gates_1.bias, cell.gate_2.weight,
+                                      cell.gate_2.bias, None, P[name + '.gates_1'], P[name + '.gate_2'])
+            x = hs.reshape(B * T, x.shape[1], x.shape[2], C)
+            hist = [[hs[:, t].contiguous()] for t in range(T)]
+        else:
+            outs, states, hist = [], None, []
+            for t in range(T):
+                xt, states = self._bottleneck(xs[:, t].contiguous(), states, prefix, P)
+                outs.append(xt)
+                hist.append(states)
+            x = torch.stack(outs, dim=1).view(B * T, x.shape[1], x.shape[2], C)
         y = self._decode(x, skips, P)
         hf = ops.FromNHWCFn.apply(y, 1)
         stacked = []

@@ -321,6 +321,18 @@ class FakeKernels(object):
         u = ru.float()[..., C:]
         return o.to(h.dtype), ((1 - u) * o + u * h.float()).to(h.dtype)
 
+    def cgru_scan_fwd(self, xs, h0, w1_ohwi, b1, w2_ohwi, b2):
+        B, T = xs.shape[:2]
+        h = torch.zeros_like(xs[:, 0]) if h0 is None else h0
+        hs, rus, rhs, ogs = [], [], [], []
+        for t in range(T):
+            g1 = self.conv2d_fwd(torch.cat([xs[:, t], h], -1), w1_ohwi, b1, 1, 1)
+            ru, rh = self.cgru_gates1(g1, h)
+            g2 = self.conv2d_fwd(torch.cat([rh, xs[:, t]], -1), w2_ohwi, b2, 1, 1)
+            o, h = self.cgru_gates2(g2, ru, h)
+            hs.append(h); rus.append(ru); rhs.append(rh); ogs.append(o)
+        return torch.stack(hs, 1), torch.stack(rus, 1), torch.stack(rhs, 1), torch.stack(ogs, 1)
+
     def cgru_gates2_bwd(self, dhnew, ru, h, o):
         C = h.shape[-1]
         d, u, of = dhnew.float(), ru.float()[..., C:], o.float()

@@ -118,3 +118,48 @@ def test_refinenet_bf16_deviation_reported():
     dev = np.abs(hf.cpu().numpy() - fx['CGRU_heatmap_final']).max()
     print('RefineNet bf16 max heat-map deviation vs reference fp32: %.4e' % dev)
     assert dev < 0.3      # untrained deterministic weights through ~40 bf16 layers; a precision mode, not parity
+
+
+@pytest.mark.parametrize('B,T,with_h0', [(2, 3, False), (7, 5, True), (3, 1, True)])
+def test_fused_cgru_scan_kernel_matches_per_step_path(B, T, with_h0):
+    """eve_cgru_scan_fwd (the whole clip through the conv-GRU in one persistent launch) == the per-frame path
+    (two conv launches + two gate kernels per frame), bf16; outputs and the tensors the backward consumes."""
+    from eve_amd.kernels import HipKernels
+    import fake_kernels
+    hip, ref = HipKernels(), fake_kernels.FakeKernels()
+    g = torch.Generator().manual_seed(11)
+    xs = (torch.randn((B, T, 5, 8, 64), generator=g) * 0.8).bfloat16()
+    h0 = (torch.randn((B, 5, 8, 64), generator=g) * 0.5).bfloat16() if with_h0 else None
+    w1 = (torch.randn((128, 3, 3, 128), generator=g) * 0.04).bfloat16()
+    w2 = (torch.randn((64, 3, 3, 128), generator=g) * 0.04).bfloat16()
+    b1, b2 = torch.randn((128,), generator=g) * 0.2, torch.randn((64,), generator=g) * 0.2
+    want = ref.cgru_scan_fwd(xs, h0, w1, b1, w2, b2)
+    got = hip.cgru_scan_fwd(xs.cuda(), h0.cuda() if with_h0 else None, w1.cuda(), b1.cuda(), w2.cuda(), b2.cuda())
+    for name, a, b in zip(('hs', 'ru', 'rh', 'og'), got, want):
+        d = (a.float().cpu() - b.float()).abs()
+        # bf16 storage: one ulp at |v| <= 1 is 2^-8; the fused kernel rounds at fewer points than the per-frame path
+        assert float(d.max()) < 3e-2 and float(d.mean()) < 2e-3, (name, float(d.max()), float(d.mean()))
+
+
+def test_refinenet_fused_scan_trains_like_the_per_step_path(monkeypatch):
+    """RefineNet bf16 forward + backward with the fused conv-GRU scan vs EVE_AMD_CGRU_SCAN=0: heat-maps and gradients."""
+    rb = detweights.refinenet_batch(3, 4, seed=3)
+    outs = {}
+    for mode in ('1', '0'):
+        monkeypatch.setenv('EVE_AMD_CGRU_SCAN', mode)
+        net, _ = make_net('CGRU', dtype=torch.bfloat16)
+        hf, states = net.forward_sequence(rb['heatmap_initial'].cuda(), rb['screen_frame'].cuda())
+        (hf.float() * rb['heatmap_final_gt'].cuda()).sum().backward()
+        outs[mode] = (hf.detach().float().cpu(), states[0].detach().float().cpu(),
+                      {n: p.grad.detach().float().cpu() for n, p in net.named_parameters()})
+    a, b = outs['1'], outs['0']
+    assert float((a[0] - b[0]).abs().max()) < 0.05
+    assert float((a[1] - b[1]).abs().max()) < 0.06
+    for n in b[2]:
+        ga, gb = a[2][n], b[2][n]
+        if ga.dim() < 2:
+            continue          # biases feeding an InstanceNorm have an exactly-zero gradient: what is computed is rounding noise
+        # two bf16 evaluation orders of the same network: a few per cent of relative L2 is rounding noise, direction must agree
+        assert float((ga - gb).norm()) <= 0.15 * float(gb.norm()) + 1e-4, n
+        if float(gb.norm()) > 1e-3:
+            assert float((ga * gb).sum() / (ga.norm() * gb.norm())) > 0.985, n

@@ -184,6 +184,40 @@ def test_eyenet_recurrent_variants_host_logic(fake, over):
     check_eyenet_variant(over)
 
 
+def test_cgru_scan_function_matches_autograd(fake):
+    """ops.CGRUScanFn (one launch for the clip + manual BPTT with batched weight gradients) == autograd through the
+    CGRUCell formula of common.py:388-415 applied frame by frame."""
+    from eve_amd import ops
+    torch.manual_seed(0)
+    B, T, H, W, C = 2, 3, 5, 8, 64
+    xs = torch.randn(B, T, H, W, C, requires_grad=True)
+    h0 = (torch.randn(B, H, W, C) * 0.5).requires_grad_(True)
+    w1 = (torch.randn(2 * C, 2 * C, 3, 3) * 0.03).requires_grad_(True)
+    b1 = (torch.randn(2 * C) * 0.1).requires_grad_(True)
+    w2 = (torch.randn(C, 2 * C, 3, 3) * 0.03).requires_grad_(True)
+    b2 = (torch.randn(C) * 0.1).requires_grad_(True)
+    p1, p2 = ops.PackedWeight(w1, torch.float32), ops.PackedWeight(w2, torch.float32)
+    hs = ops.CGRUScanFn.apply(xs, w1, b1, w2, b2, h0, p1, p2)
+    probe = torch.randn_like(hs)
+    (hs * probe).sum().backward()
+    got = [t.grad.clone() for t in (xs, h0, w1, b1, w2, b2)]
+    for t in (xs, h0, w1, b1, w2, b2):
+        t.grad = None
+    h, outs = h0.permute(0, 3, 1, 2), []
+    for t in range(T):
+        x = xs[:, t].permute(0, 3, 1, 2)
+        g1 = torch.sigmoid(torch.nn.functional.conv2d(torch.cat([x, h], 1), w1, b1, padding=1))
+        r, u = g1.chunk(2, 1)
+        o = torch.tanh(torch.nn.functional.conv2d(torch.cat([r * h, x], 1), w2, b2, padding=1))
+        h = (1. - u) * o + u * h
+        outs.append(h.permute(0, 2, 3, 1))
+    ref = torch.stack(outs, 1)
+    assert float((hs - ref).abs().max()) < 1e-5
+    (ref * probe).sum().backward()
+    for a, t, n in zip(got, (xs, h0, w1, b1, w2, b2), ('xs', 'h0', 'w1', 'b1', 'w2', 'b2')):
+        assert float((a - t.grad).abs().max()) <= 1e-4 * float(t.grad.abs().max()) + 1e-6, n
+
+
 def test_eyenet_frozen_detaches(fake):
     cfg = eve_amd.reset_standalone_config()
     cfg.override('eye_net_frozen', True)
