@@ -305,8 +305,7 @@ __global__ __launch_bounds__(64 * WCO * WK) void wgrad_tr_kernel(const GatherPar
     // 128x128 tiles: 3 stages of 16 KB -> three workgroups per CU (after the address-arithmetic diet this beats the
     // 4-deep ring with two workgroups by 7-9 % on layers 3/4); 64x256 tiles: 4 stages of 20 KB, two workgroups
     constexpr int RING = WCO == 2 ? 3 : 4;
-    static_assert((P_SLOTS % NT == 0 || (P_DMA == 1 && P_SLOTS % 64 == 0)) && (Q_SLOTS % NT == 0 || (Q_DMA == 1 && Q_SLOTS % 64 == 0)),
-                  "stage slots must tile the workgroup");
+    static_assert(P_SLOTS % 64 == 0 && Q_SLOTS % 64 == 0 && NT % 64 == 0, "wave-granular slot wrap-around");
     extern __shared__ __attribute__((aligned(16))) char lds[];   // RING * BUF bytes
 
     const int tid = threadIdx.x;
@@ -451,9 +450,12 @@ __global__ __launch_bounds__(64 * WCO * WK) void wgrad_tr_kernel(const GatherPar
         offsets(m_begin + (RING - 1) * STEP, vp, vq);
         auto do_step = [&](int st) {
             // stage st has landed once at most the RING-2 newer stages are outstanding (loads return in order)
-            if (RING == 3) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            static_assert((RING == 3 && (NDMA == 4 || NDMA == 6)) || (RING == 4 && (NDMA == 4 || NDMA == 5 || NDMA == 6)), "immediates below");
+            if (RING == 3 && NDMA == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else if (RING == 3) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
             else if (NDMA == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-            else           asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+            else if (NDMA == 5) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+            else           asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             issue((st + RING - 1) % RING, vp, vq);            // stage st+RING-1 recycles the slot read in step st-1
             const uint32_t sb = lds0 + (st % RING) * BUF;
