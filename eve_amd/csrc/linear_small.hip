@@ -1,8 +1,8 @@
 // Small float32 linear layers: the EyeNet tail (fc, fc_common, GRU input projection, gaze / pupil heads --
 // /root/reference/src/models/eye_net.py:52-90) works on M = 2*B*T feature rows with K, N <= 512.  Through the
 // 128x128-tile implicit-GEMM kernels such a problem is 15 workgroups of f32 MFMAs (1/16 of the bf16 rate) on a
-// 256-CU part: ~25 us per launch, 32 launches per step.  Here the tile is 16 rows x 128 columns of plain fp32
-// FMAs (exact, same summation order as a dot product over k), 120+ workgroups, and the activation derivative of
+// 256-CU part: ~25 us per launch, 32 launches per step.  Here the tile is 8 rows x 128 columns of plain fp32
+// FMAs (exact, same summation order as a dot product over k), 240+ workgroups, and the activation derivative of
 // the backward is applied while loading dy instead of in a separate pass.
 //
 //   eve_linear_fwd     y[M][N]  = act(x[M][K] . wt[K][N] + b)                       wt = IHWO pack ([in][out])
@@ -12,7 +12,7 @@
 
 namespace eve {
 
-constexpr int LS_TM = 16, LS_TN = 128, LS_KC = 32;
+constexpr int LS_TM = 8, LS_TN = 128, LS_KC = 32;     // 8 rows per workgroup: 240 workgroups at M = 1920 (one per CU)
 
 // C[M][Nc] = epi( A'[M][R] . B[R][Nc] ),  A' = A * act'(Y) if Y (same shape as A), epi = act(. + bias).
 // Both operand chunks go through LDS; the next chunk is fetched into registers while the current one is consumed
@@ -25,22 +25,21 @@ __global__ __launch_bounds__(256) void linear_mm_kernel(const float* __restrict_
     __shared__ float sB[LS_KC][LS_TN];
     const int tid = threadIdx.x;
     const int c0 = blockIdx.y * LS_TN;
-    const int col = c0 + (tid & (LS_TN - 1)), rg = tid >> 7;                  // 2 row groups of 8 rows
+    const int col = c0 + (tid & (LS_TN - 1)), rg = tid >> 7;                  // 2 row groups of 4 rows
     const int m0 = blockIdx.x * LS_TM;
-    // staging slots: A' 16 x 32 = 512 values (2 per thread), B 32 x 128 = 4096 values (16 per thread)
-    const int ar = tid >> 5, ak = tid & 31;                                     // rows ar and ar + 8
+    // staging slots: A' 8 x 32 = 256 values (1 per thread), B 32 x 128 = 4096 values (16 per thread)
+    const int ar = tid >> 5, ak = tid & 31;
     const int bc = tid & 127, bk = tid >> 7;                                    // k rows bk, bk + 2, ...
-    float pa[2], pb[16];
+    float pa[1], pb[16];
     auto fetch = [&](int k0) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int m = m0 + ar + 8 * i, k = k0 + ak;
+        {
+            const int m = m0 + ar, k = k0 + ak;
             float v = 0.f;
             if (m < M && k < R) {
                 v = A[(size_t)m * R + k];
                 if (Y) v *= act_grad_from_out(Y[(size_t)m * R + k], pro_act);
             }
-            pa[i] = v;
+            pa[0] = v;
         }
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
@@ -48,13 +47,13 @@ __global__ __launch_bounds__(256) void linear_mm_kernel(const float* __restrict_
             pb[i] = (k < R && c0 + bc < Nc) ? B[(size_t)k * Nc + c0 + bc] : 0.f;
         }
     };
-    float acc[8];
+    float acc[4];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+    for (int i = 0; i < 4; ++i) acc[i] = 0.f;
     fetch(0);
     for (int k0 = 0; k0 < R; k0 += LS_KC) {
         __syncthreads();                                   // previous chunk fully consumed
-        sA[ar][ak] = pa[0]; sA[ar + 8][ak] = pa[1];
+        sA[ar][ak] = pa[0];
 #pragma unroll
         for (int i = 0; i < 16; ++i) sB[bk + 2 * i][bc] = pb[i];
         __syncthreads();
@@ -63,8 +62,8 @@ __global__ __launch_bounds__(256) void linear_mm_kernel(const float* __restrict_
         for (int kk = 0; kk < LS_KC; kk += 4) {
             const float b0 = sB[kk][tid & 127], b1 = sB[kk + 1][tid & 127], b2 = sB[kk + 2][tid & 127], b3 = sB[kk + 3][tid & 127];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const float4 a = *reinterpret_cast<const float4*>(&sA[rg * 8 + i][kk]);
+            for (int i = 0; i < 4; ++i) {
+                const float4 a = *reinterpret_cast<const float4*>(&sA[rg * 4 + i][kk]);
                 acc[i] = fmaf(a.x, b0, acc[i]);
                 acc[i] = fmaf(a.y, b1, acc[i]);
                 acc[i] = fmaf(a.z, b2, acc[i]);
@@ -75,8 +74,8 @@ __global__ __launch_bounds__(256) void linear_mm_kernel(const float* __restrict_
     if (col >= Nc) return;
     const float bv = bias ? bias[col] : 0.f;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int m = m0 + rg * 8 + i;
+    for (int i = 0; i < 4; ++i) {
+        const int m = m0 + rg * 4 + i;
         if (m < M) C[(size_t)m * Nc + col] = act_fwd(acc[i] + bv, epi_act);
     }
 }
