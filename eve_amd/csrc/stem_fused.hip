@@ -71,6 +71,7 @@ __device__ __forceinline__ void sf_fill_weights(char* sW, const bf16_t* __restri
 
 // One output row of the convolution for the wave's image: acc[mt][nt] (mt = 2j + b holds output column
 // 2*(li + 16j) + b, so a lane owns the even/odd column pair of pooled column q = li + 16j).
+template <bool FIRST>
 __device__ __forceinline__ void sf_conv_tap_row(f32x4_t (&acc)[4][4], uint32_t ring, int slot0, uint32_t xoff,
                                                 uint32_t wbase, int kh) {
     int slot = slot0 + kh;
@@ -81,26 +82,24 @@ __device__ __forceinline__ void sf_conv_tap_row(f32x4_t (&acc)[4][4], uint32_t r
     for (int mt = 0; mt < 4; ++mt) fx[mt] = sf_lds_read(xa + (mt & 1) * 16 + (mt >> 1) * 512);
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) fw[nt] = sf_lds_read(wa + nt * 1024);
+    const f32x4_t zero = {0.f, 0.f, 0.f, 0.f};             // first filter row: C = 0 is an inline MFMA operand, no zero-fill
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt)
-            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[nt], fx[mt], acc[mt][nt], 0, 0, 0);
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[nt], fx[mt], FIRST ? zero : acc[mt][nt], 0, 0, 0);
 }
 // COMPACT keeps the filter-row loop rolled (one set of fragment registers) for the register-hungry backward
 template <bool COMPACT>
 __device__ __forceinline__ void sf_conv_row(f32x4_t (&acc)[4][4], uint32_t ring, int slot0, uint32_t xoff,
                                             uint32_t wbase) {
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int b = 0; b < 4; ++b) acc[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    sf_conv_tap_row<true>(acc, ring, slot0, xoff, wbase, 0);
     if (COMPACT) {
 #pragma unroll 1
-        for (int kh = 0; kh < 7; ++kh) sf_conv_tap_row(acc, ring, slot0, xoff, wbase, kh);
+        for (int kh = 1; kh < 7; ++kh) sf_conv_tap_row<false>(acc, ring, slot0, xoff, wbase, kh);
     } else {
 #pragma unroll
-        for (int kh = 0; kh < 7; ++kh) sf_conv_tap_row(acc, ring, slot0, xoff, wbase, kh);
+        for (int kh = 1; kh < 7; ++kh) sf_conv_tap_row<false>(acc, ring, slot0, xoff, wbase, kh);
     }
 }
 
@@ -176,17 +175,20 @@ __global__ __launch_bounds__(64 * SF_WAVES) void stem_fwd_fused_kernel(const int
                     for (int j = 0; j < 2; ++j) {
                         // (copy the vector elements first: __builtin_bit_cast on an element lvalue reads element 0)
                         const float ef = acc[2 * j][nt][r], of = acc[2 * j + 1][nt][r];
-                        const uint32_t e = __builtin_bit_cast(uint32_t, ef) & 0xfffffff0u;
-                        const uint32_t o = __builtin_bit_cast(uint32_t, of) & 0xfffffff0u;
+                        // keys: (value & ~15) | window position; the window-row bits go in with the column bits
+                        const uint32_t e = (__builtin_bit_cast(uint32_t, ef) & 0xfffffff0u) | (khbits | 1u);
+                        const uint32_t o = (__builtin_bit_cast(uint32_t, of) & 0xfffffff0u) | khbits;
+                        const uint32_t ol = (__builtin_bit_cast(uint32_t, of) & 0xfffffff0u) | (khbits | 2u);
                         // column 2q-1 = the odd column of lane li-1 (lane 0: the last lane of the previous tile / padding)
                         const uint32_t edge = j == 0 ? SF_NEG : sf_dpp<0x121>(0u, carry);          // row_ror:1
-                        const uint32_t l = sf_dpp<0x111>(edge, o | 2u);                              // row_shr:1
-                        carry = o | 2u;
-                        const float h = sf_fmax3(__builtin_bit_cast(float, l), __builtin_bit_cast(float, e | 1u),
+                        const uint32_t l = sf_dpp<0x111>(edge, ol);                                  // row_shr:1
+                        carry = ol;
+                        const float h = sf_fmax3(__builtin_bit_cast(float, l), __builtin_bit_cast(float, e),
                                                  __builtin_bit_cast(float, o));
                         const uint32_t hb = __builtin_bit_cast(uint32_t, h);
-                        const float m = fmaxf(__builtin_bit_cast(float, M[j][nt][r]), __builtin_bit_cast(float, hb | khbits));
-                        M[j][nt][r] = odd ? (hb | 8u) : __builtin_bit_cast(uint32_t, m);            // odd row: carry = filter row 0
+                        const float m = fmaxf(__builtin_bit_cast(float, M[j][nt][r]), h);
+                        // odd row: it becomes filter row 0 of the next window (khbits is 0 here: just set bit 3)
+                        M[j][nt][r] = odd ? (hb | 8u) : __builtin_bit_cast(uint32_t, m);
                         acc[2 * j][nt][r] = m;                                                      // window result (odd rows)
                     }
                 }
