@@ -30,8 +30,8 @@ __global__ __launch_bounds__(256) void cgru_scan_fwd_kernel(const int B, const i
                                                             const bf16_t* __restrict__ h0, const bf16_t* __restrict__ w1,
                                                             const float* __restrict__ b1, const bf16_t* __restrict__ w2,
                                                             const float* __restrict__ b2, bf16_t* __restrict__ hs,
-                                                            bf16_t* __restrict__ ru, bf16_t* __restrict__ rh,
-                                                            bf16_t* __restrict__ og) {
+                                                            bf16_t* __restrict__ hs_tm, bf16_t* __restrict__ ru,
+                                                            bf16_t* __restrict__ rh, bf16_t* __restrict__ og) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // planes: 0,1 = x (channels 0-31, 32-63); 2,3 = h; 4,5 = r*h
     const uint32_t lds0 = lds_addr_of(smem);
@@ -49,7 +49,7 @@ __global__ __launch_bounds__(256) void cgru_scan_fwd_kernel(const int B, const i
 
     // ---- lane constants -------------------------------------------------------------------------------------
     // interior LDS byte offset (inside a plane) of the lane's pixel for each of its four 16-pixel MFMA column tiles
-    int pix_lds[4], pix_glob[4];                     // pix_glob: (sequence * T) * 40 + pixel, or -1
+    int pix_lds[4], pix_glob[4], pix_tm[4];          // pix_glob: (sequence * T) * 40 + pixel, or -1; pix_tm: sequence * 40 + pixel
     int aaddr[9][4];
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) {
@@ -60,6 +60,7 @@ __global__ __launch_bounds__(256) void cgru_scan_fwd_kernel(const int B, const i
         const int hr0 = ti * 7 + py + 1;
         pix_lds[mt] = ((hr0 * 10 + px + 1) << 6) | ((hr0 & 1) << 16);          // row parity kept in bit 16
         pix_glob[mt] = ok ? (b0 + ti) * T * CG_PIX + rem : -1;
+        pix_tm[mt] = (b0 + ti) * CG_PIX + rem;
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
             const int hr = ti * 7 + py + t / 3, hx = px + t % 3;
@@ -196,15 +197,16 @@ __global__ __launch_bounds__(256) void cgru_scan_fwd_kernel(const int B, const i
                         v[0] = bf16_bits_to_f32(p0 & 0xffffu); v[1] = __builtin_bit_cast(float, p0 & 0xffff0000u);
                         v[2] = bf16_bits_to_f32(p1 & 0xffffu); v[3] = __builtin_bit_cast(float, p1 & 0xffff0000u);
                         const int pg = pix_glob[mt];
+                        const size_t ptm = (size_t)t * B * CG_PIX + pix_tm[mt];           // time-major: what the backward walks
                         if (pg >= 0)
-                            *reinterpret_cast<uint2*>(ru + ((size_t)pg + (size_t)t * CG_PIX) * 128 + wn * 64 + c) = make_uint2(p0, p1);
+                            *reinterpret_cast<uint2*>(ru + ptm * 128 + wn * 64 + c) = make_uint2(p0, p1);
                         if (wn == 0) {
                             const cg_u32x2_t hq = *reinterpret_cast<const EVE_LDS cg_u32x2_t*>((uintptr_t)lds_c4(2, mt, c));
                             const uint32_t q0 = pack2_bf16(v[0] * bf16_bits_to_f32(hq.x & 0xffffu), v[1] * __builtin_bit_cast(float, hq.x & 0xffff0000u));
                             const uint32_t q1 = pack2_bf16(v[2] * bf16_bits_to_f32(hq.y & 0xffffu), v[3] * __builtin_bit_cast(float, hq.y & 0xffff0000u));
                             if (pg >= 0) {
                                 *reinterpret_cast<EVE_LDS cg_u32x2_t*>((uintptr_t)lds_c4(4, mt, c)) = cg_u32x2_t{q0, q1};
-                                *reinterpret_cast<uint2*>(rh + ((size_t)pg + (size_t)t * CG_PIX) * CG_C + c) = make_uint2(q0, q1);
+                                *reinterpret_cast<uint2*>(rh + ptm * CG_C + c) = make_uint2(q0, q1);
                             }
                         } else {
                             ug[mt][nt] = f32x4_t{v[0], v[1], v[2], v[3]};
@@ -239,8 +241,10 @@ __global__ __launch_bounds__(256) void cgru_scan_fwd_kernel(const int B, const i
                     const uint32_t n0 = pack2_bf16(hn[0], hn[1]), n1 = pack2_bf16(hn[2], hn[3]);
                     *reinterpret_cast<EVE_LDS cg_u32x2_t*>((uintptr_t)ha) = cg_u32x2_t{n0, n1};
                     const size_t go = ((size_t)pg + (size_t)t * CG_PIX) * CG_C + c;
-                    *reinterpret_cast<uint2*>(og + go) = make_uint2(o0, o1);
+                    const size_t gtm = ((size_t)t * B * CG_PIX + pix_tm[mt]) * CG_C + c;
+                    *reinterpret_cast<uint2*>(og + gtm) = make_uint2(o0, o1);
                     *reinterpret_cast<uint2*>(hs + go) = make_uint2(n0, n1);
+                    *reinterpret_cast<uint2*>(hs_tm + gtm) = make_uint2(n0, n1);
                 }
             }
         }
@@ -261,11 +265,12 @@ using namespace eve;
 
 /* CGRUCell over T frames in one launch (bf16): xs [B][T][5][8][64] NHWC, h0 [B][5][8][64] or NULL (zeros),
    w1 = gates_1 weight OHWI [128][3][3][128] (input channels: x then h), w2 = gate_2 weight OHWI [64][3][3][128]
-   (input channels: r*h then x), biases float.  Outputs (all bf16, [B][T][5][8][.]): hs = hidden states, ru = the two
-   sigmoid gates (128 channels), rh = r * h_{t-1}, og = tanh output gate -- the tensors the backward consumes. */
+   (input channels: r*h then x), biases float.  Outputs (bf16): hs [B][T][5][8][64] = hidden states in the caller's
+   (sequence, frame) order; and TIME-major [T][B][5][8][.] for the backward, which walks frames: hs_tm, ru = the two
+   sigmoid gates (128 channels), rh = r * h_{t-1}, og = tanh output gate. */
 extern "C" int eve_cgru_scan_fwd(int B, int T, const void* xs, const void* h0, const void* w1, const float* b1, const void* w2,
-                                 const float* b2, void* hs, void* ru, void* rh, void* og, eve_stream_t stream) {
-    if (B <= 0 || T <= 0 || !xs || !w1 || !b1 || !w2 || !b2 || !hs || !ru || !rh || !og)
+                                 const float* b2, void* hs, void* hs_tm, void* ru, void* rh, void* og, eve_stream_t stream) {
+    if (B <= 0 || T <= 0 || !xs || !w1 || !b1 || !w2 || !b2 || !hs || !hs_tm || !ru || !rh || !og)
         return set_error_msg("cgru_scan_fwd: bad arguments");
     if ((long long)B * T * CG_PIX * 128 >= (1ll << 31)) return set_error_msg("cgru_scan_fwd: clip too large for 32-bit offsets");
     static bool attr_set = false;
@@ -275,8 +280,8 @@ extern "C" int eve_cgru_scan_fwd(int B, int T, const void* xs, const void* h0, c
     }
     EVE_MARK_KERNEL("cgru_scan_fwd_kernel");
     hipLaunchKernelGGL(cgru_scan_fwd_kernel, dim3((B + CG_IMG - 1) / CG_IMG), dim3(256), CG_LDS, (hipStream_t)stream, B, T,
-                       (const bf16_t*)xs, (const bf16_t*)h0, (const bf16_t*)w1, b1, (const bf16_t*)w2, b2, (bf16_t*)hs, (bf16_t*)ru,
-                       (bf16_t*)rh, (bf16_t*)og);
+                       (const bf16_t*)xs, (const bf16_t*)h0, (const bf16_t*)w1, b1, (const bf16_t*)w2, b2, (bf16_t*)hs, (bf16_t*)hs_tm,
+                       (bf16_t*)ru, (bf16_t*)rh, (bf16_t*)og);
     EVE_CHECK_LAUNCH();
     return 0;
 }

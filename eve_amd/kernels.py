@@ -557,19 +557,21 @@ class HipKernels(object):
         return dpre, dh0, dc0
 
     def cgru_scan_fwd(self, xs, h0, w1_ohwi, b1, w2_ohwi, b2):
-        """CGRUCell over T in one launch.  xs [B, T, 5, 8, 64] bf16 -> hs, ru, rh, og (all [B, T, 5, 8, .])."""
+        """CGRUCell over T in one launch.  xs [B, T, 5, 8, 64] bf16 -> hs [B, T, 5, 8, 64] and, time-major [T, B, 5, 8, .]
+        for the backward: hs_tm, ru, rh, og."""
         B, T, H, W, C = xs.shape
         assert (H, W, C) == (5, 8, 64) and xs.dtype == torch.bfloat16 and xs.is_contiguous()
         assert tuple(w1_ohwi.shape) == (128, 3, 3, 128) and tuple(w2_ohwi.shape) == (64, 3, 3, 128)
         dev = xs.device
         hs = torch.empty((B, T, H, W, C), dtype=torch.bfloat16, device=dev)
-        ru = torch.empty((B, T, H, W, 2 * C), dtype=torch.bfloat16, device=dev)
-        rh = torch.empty((B, T, H, W, C), dtype=torch.bfloat16, device=dev)
-        og = torch.empty((B, T, H, W, C), dtype=torch.bfloat16, device=dev)
+        hs_tm = torch.empty((T, B, H, W, C), dtype=torch.bfloat16, device=dev)
+        ru = torch.empty((T, B, H, W, 2 * C), dtype=torch.bfloat16, device=dev)
+        rh = torch.empty((T, B, H, W, C), dtype=torch.bfloat16, device=dev)
+        og = torch.empty((T, B, H, W, C), dtype=torch.bfloat16, device=dev)
         self._ck(self.lib.eve_cgru_scan_fwd(B, T, self._p(xs), self._p(h0), self._p(w1_ohwi), self._p(self._f32(b1, 'b1')),
-                                            self._p(w2_ohwi), self._p(self._f32(b2, 'b2')), self._p(hs), self._p(ru),
-                                            self._p(rh), self._p(og), self._stream()))
-        return hs, ru, rh, og
+                                            self._p(w2_ohwi), self._p(self._f32(b2, 'b2')), self._p(hs), self._p(hs_tm),
+                                            self._p(ru), self._p(rh), self._p(og), self._stream()))
+        return hs, hs_tm, ru, rh, og
 
     def cgru_gates1(self, g1, h):
         C = h.shape[-1]

@@ -709,70 +709,66 @@ class CGRUScanFn(torch.autograd.Function):
     """hs[:, t] = CGRUCell(xs[:, t], hs[:, t-1]) for the whole clip in ONE launch (kernels.cgru_scan_fwd: hidden state
     resident in LDS, both gate convolutions and their sigmoid / tanh / blend epilogues fused; common.py:388-415 applied
     per frame by refine_net.py:132-176).  The backward walks the frames in reverse with the gate-gradient kernels and the
-    data-gradient convolutions (T-sequential by nature); the two weight gradients and bias gradients are ONE batched
-    launch each over all B*T frames afterwards."""
+    data-gradient convolutions (T-sequential by nature) on TIME-major tensors (every per-frame operand is a contiguous
+    slice: no copies); the two weight gradients and bias gradients are ONE batched launch each over all T*B frames."""
 
     @staticmethod
     def forward(ctx, xs, w1, b1, w2, b2, h0, p1, p2):
         k = default_kernels()
         h0c = h0.detach().contiguous() if h0 is not None else None
-        hs, ru, rh, og = k.cgru_scan_fwd(xs.contiguous(), h0c, p1.ohwi, b1.detach().float().contiguous(), p2.ohwi,
-                                         b2.detach().float().contiguous())
+        hs, hs_tm, ru, rh, og = k.cgru_scan_fwd(xs.contiguous(), h0c, p1.ohwi, b1.detach().float().contiguous(), p2.ohwi,
+                                                b2.detach().float().contiguous())
         ctx.packs = (p1, p2)
         ctx.params = (w1, b1, w2, b2)
         ctx.has_h0 = h0 is not None
-        ctx.save_for_backward(xs, h0c, hs, ru, rh, og)
+        ctx.save_for_backward(xs, h0c, hs_tm, ru, rh, og)
         return hs
 
     @staticmethod
     def backward(ctx, dhs):
         k = default_kernels()
-        xs, h0, hs, ru, rh, og = ctx.saved_tensors
+        xs, h0, hs_tm, ru, rh, og = ctx.saved_tensors
         p1, p2 = ctx.packs
         w1, b1, w2, b2 = ctx.params
         B, T, H, W, C = xs.shape
-        dhs = dhs.contiguous()
-        first = h0 if h0 is not None else torch.zeros_like(xs[:, 0])
-        dxs = torch.empty_like(xs)
-        dg1_all = torch.empty((B, T, H, W, 2 * C), dtype=xs.dtype, device=xs.device)
-        dg2_all = torch.empty((B, T, H, W, C), dtype=xs.dtype, device=xs.device)
+        dhs_tm = dhs.transpose(0, 1).contiguous()                       # [T, B, ...]
+        xs_tm = xs.transpose(0, 1).contiguous()
+        first = h0 if h0 is not None else torch.zeros_like(xs_tm[0])
+        dcat1_all = torch.empty((T, B, H, W, 2 * C), dtype=xs.dtype, device=xs.device)      # d[x | h] per frame
+        dcat2_all = torch.empty((T, B, H, W, 2 * C), dtype=xs.dtype, device=xs.device)      # d[r*h | x] per frame
+        dg1_all = torch.empty((T, B, H, W, 2 * C), dtype=xs.dtype, device=xs.device)
+        dg2_all = torch.empty((T, B, H, W, C), dtype=xs.dtype, device=xs.device)
         carry = None
         for t in range(T - 1, -1, -1):
-            dhn = dhs[:, t] if carry is None else k.add(dhs[:, t].contiguous(), carry)
-            h_prev = hs[:, t - 1] if t > 0 else first
-            h_prev = h_prev.contiguous()
-            dg2, dru, dh_a = k.cgru_gates2_bwd(dhn.contiguous(), ru[:, t].contiguous(), h_prev, og[:, t].contiguous())
-            dcat2 = k.conv2d_dgrad(dg2, p2.ihwo, (H, W), 1, 1, algo=p2.algo)            # d[r*h | x]
-            drh = dcat2[..., :C].contiguous()
-            dg1, dh_b = k.cgru_gates1_bwd(drh, dru, ru[:, t].contiguous(), h_prev)
-            dcat1 = k.conv2d_dgrad(dg1, p1.ihwo, (H, W), 1, 1, algo=p1.algo)            # d[x | h]
-            dxs[:, t] = k.add(dcat2[..., C:].contiguous(), dcat1[..., :C].contiguous())
+            dhn = dhs_tm[t] if carry is None else k.add(dhs_tm[t], carry)
+            h_prev = hs_tm[t - 1] if t > 0 else first
+            dg2, dru, dh_a = k.cgru_gates2_bwd(dhn, ru[t], h_prev, og[t])
+            dcat2 = k.conv2d_dgrad(dg2, p2.ihwo, (H, W), 1, 1, algo=p2.algo)
+            dg1, dh_b = k.cgru_gates1_bwd(dcat2[..., :C].contiguous(), dru, ru[t], h_prev)
+            dcat1 = k.conv2d_dgrad(dg1, p1.ihwo, (H, W), 1, 1, algo=p1.algo)
             carry = k.add(k.add(dh_a, dh_b), dcat1[..., C:].contiguous())
-            dg1_all[:, t] = dg1
-            dg2_all[:, t] = dg2
-        # weight / bias gradients: one launch each over all B*T frames
-        h_prev_all = torch.cat([first.unsqueeze(1), hs[:, :-1]], dim=1)
-        cat1 = torch.cat([xs, h_prev_all], dim=-1).view(B * T, H, W, 2 * C)
-        cat2 = torch.cat([rh, xs], dim=-1).view(B * T, H, W, 2 * C)
-        g1f, g2f = dg1_all.view(B * T, H, W, 2 * C), dg2_all.view(B * T, H, W, C)
-
-        def wgrad(x_in, dy, weight, pack):
-            return _wgrad_into(k, x_in, dy, weight, pack, 1, 1)
+            dcat1_all[t], dcat2_all[t], dg1_all[t], dg2_all[t] = dcat1, dcat2, dg1, dg2
+        # d(xs) = x-halves of the two concatenated-input gradients, for all frames at once
+        dxs = (dcat1_all[..., :C] + dcat2_all[..., C:]).transpose(0, 1).contiguous()
+        # weight / bias gradients: one launch each over all T*B frames
+        h_prev_all = torch.cat([first.unsqueeze(0), hs_tm[:-1]], dim=0)
+        cat1 = torch.cat([xs_tm, h_prev_all], dim=-1).view(T * B, H, W, 2 * C)
+        cat2 = torch.cat([rh, xs_tm], dim=-1).view(T * B, H, W, 2 * C)
+        g1f, g2f = dg1_all.view(T * B, H, W, 2 * C), dg2_all.view(T * B, H, W, C)
 
         def bgrad(dy, bias):
-            Cc = dy.shape[-1]
             if _direct_grad_ok(bias):
                 k.bias_grad(dy, bias.grad)
                 _notify_grad_ready(bias)
                 return None
-            db = torch.zeros((Cc,), dtype=torch.float32, device=dy.device)
+            db = torch.zeros((dy.shape[-1],), dtype=torch.float32, device=dy.device)
             k.bias_grad(dy, db)
             return db
 
         need = ctx.needs_input_grad
-        dw1 = wgrad(cat1, g1f, w1, p1) if need[1] else None
+        dw1 = _wgrad_into(k, cat1, g1f, w1, p1, 1, 1) if need[1] else None
         db1 = bgrad(g1f, b1) if need[2] else None
-        dw2 = wgrad(cat2, g2f, w2, p2) if need[3] else None
+        dw2 = _wgrad_into(k, cat2, g2f, w2, p2, 1, 1) if need[3] else None
         db2 = bgrad(g2f, b2) if need[4] else None
         dh0 = carry if (ctx.has_h0 and need[5]) else None
         return dxs, dw1, db1, dw2, db2, dh0, None, None

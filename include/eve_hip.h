@@ -250,10 +250,11 @@ int eve_lstm_scan_bwd(int S, int T, int H, const float* dhs, const float* dcs, c
 /* CGRUCell over all T frames of a clip in ONE persistent launch (bf16; the 5x8x64 bottleneck of refine_net.py:132-176):
  * hidden state resident in LDS, both gate GEMMs on MFMA with the filter banks streamed through an LDS-DMA ring,
  * sigmoid / tanh / blend as epilogues.  xs [B][T][5][8][64]; h0 [B][5][8][64] or NULL; w1 = gates_1 OHWI
- * [128][3][3][128] (inputs x|h), w2 = gate_2 OHWI [64][3][3][128] (inputs r*h|x); outputs per frame: hs (state),
- * ru (both sigmoid gates, 128 ch), rh (r*h), og (tanh gate) -- what the backward consumes.               */
+ * [128][3][3][128] (inputs x|h), w2 = gate_2 OHWI [64][3][3][128] (inputs r*h|x); outputs: hs [B][T][5][8][64]
+ * (state, caller's order) and, TIME-major [T][B][5][8][.] for the frame-reversed backward: hs_tm, ru (both sigmoid
+ * gates, 128 ch), rh (r*h), og (tanh gate).                                                               */
 int eve_cgru_scan_fwd(int B, int T, const void* xs, const void* h0, const void* w1, const float* b1, const void* w2,
-                      const float* b2, void* hs, void* ru, void* rh, void* og, eve_stream_t stream);
+                      const float* b2, void* hs, void* hs_tm, void* ru, void* rh, void* og, eve_stream_t stream);
 int eve_cgru_gates1(int dtype, long long P, int C, const void* g1, const void* h, void* ru, void* rh,
                     eve_stream_t stream);
 int eve_cgru_gates2(int dtype, long long P, int C, const void* g2, const void* ru, const void* h,

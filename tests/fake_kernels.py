@@ -331,7 +331,7 @@ class FakeKernels(object):
             g2 = self.conv2d_fwd(torch.cat([rh, xs[:, t]], -1), w2_ohwi, b2, 1, 1)
             o, h = self.cgru_gates2(g2, ru, h)
             hs.append(h); rus.append(ru); rhs.append(rh); ogs.append(o)
-        return torch.stack(hs, 1), torch.stack(rus, 1), torch.stack(rhs, 1), torch.stack(ogs, 1)
+        return torch.stack(hs, 1), torch.stack(hs, 0), torch.stack(rus, 0), torch.stack(rhs, 0), torch.stack(ogs, 0)
 
     def cgru_gates2_bwd(self, dhnew, ru, h, o):
         C = h.shape[-1]

@@ -135,7 +135,7 @@ def test_fused_cgru_scan_kernel_matches_per_step_path(B, T, with_h0):
     b1, b2 = torch.randn((128,), generator=g) * 0.2, torch.randn((64,), generator=g) * 0.2
     want = ref.cgru_scan_fwd(xs, h0, w1, b1, w2, b2)
     got = hip.cgru_scan_fwd(xs.cuda(), h0.cuda() if with_h0 else None, w1.cuda(), b1.cuda(), w2.cuda(), b2.cuda())
-    for name, a, b in zip(('hs', 'ru', 'rh', 'og'), got, want):
+    for name, a, b in zip(('hs', 'hs_tm', 'ru', 'rh', 'og'), got, want):
         d = (a.float().cpu() - b.float()).abs()
         # bf16 storage: one ulp at |v| <= 1 is 2^-8; the fused kernel rounds at fewer points than the per-frame path
         assert float(d.max()) < 3e-2 and float(d.mean()) < 2e-3, (name, float(d.max()), float(d.mean()))
