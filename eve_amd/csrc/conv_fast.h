@@ -287,7 +287,8 @@ __device__ __forceinline__ uint2 lds_tr_read(uint32_t lds_byte_addr) {
     return __builtin_bit_cast(uint2, r);
 }
 
-template <int WCO, int WK, bool POW2>
+// MODE: 0 = any output size (mul-hi divisions per slot), 1 = OH and OW powers of two, 2 = OW a power of two only
+template <int WCO, int WK, int MODE>
 __global__ __launch_bounds__(64 * WCO * WK) void wgrad_tr_kernel(const GatherParams p, const bf16_t* __restrict__ x,
                                                        const bf16_t* __restrict__ dy, float* __restrict__ dw,
                                                        const uint32_t rows_per_split, const uint32_t x_bytes,
@@ -363,19 +364,22 @@ __global__ __launch_bounds__(64 * WCO * WK) void wgrad_tr_kernel(const GatherPar
     // issuing 4-6 VALU instructions per MFMA).  Other sizes use the mul-hi division per slot.
     const int sh_w = __builtin_ctz((unsigned)p.OW), sh_hw = __builtin_ctz((unsigned)(p.OH * p.OW));
     const int cin2 = p.Cin * 2, cout2 = p.Cout * 2;
-    int p_const[P_DMA], q_const[Q_DMA], q_ty[Q_DMA], q_tx[Q_DMA];
+    int p_const[P_DMA], q_const[Q_DMA], q_ty[Q_DMA], q_tx[Q_DMA], q_ry[Q_DMA];
 #pragma unroll
     for (int j = 0; j < P_DMA; ++j) p_const[j] = p_col[j] == EVE_OOB ? EVE_OOB : p_row[j] * cout2 + p_col[j];
 #pragma unroll
     for (int j = 0; j < Q_DMA; ++j) {
         const uint32_t r = (uint32_t)q_row[j];
-        const int n_t = (int)(r >> sh_hw), oy_t = (int)((r >> sh_w) & (uint32_t)(p.OH - 1)), ox_t = (int)(r & (uint32_t)(p.OW - 1));
+        // MODE 2 keeps the row offset whole (the wrap into the next image is resolved per stage)
+        const int n_t = MODE == 2 ? 0 : (int)(r >> sh_hw);
+        const int oy_t = MODE == 2 ? (int)(r >> sh_w) : (int)((r >> sh_w) & (uint32_t)(p.OH - 1)), ox_t = (int)(r & (uint32_t)(p.OW - 1));
+        q_ry[j] = oy_t;
         q_ty[j] = oy_t * p.o_mul + q_dy[j];
         q_tx[j] = ox_t * p.o_mul + q_dx[j];
         q_const[j] = q_col[j] == EVE_OOB ? EVE_OOB : ((n_t * p.IH + q_ty[j]) * p.IW + q_tx[j]) * cin2 + q_col[j];
     }
     auto offsets = [&](uint32_t mbase, int* vp, int* vq) {   // branch-free: selects only
-        if (POW2) {
+        if (MODE == 1) {
             const uint32_t left = m_end > mbase ? m_end - mbase : 0u;          // rows of this stage still in range
             const int pbase = (int)mbase * cout2;
             const uint32_t n_s = mbase >> sh_hw, oy_s = (mbase >> sh_w) & (uint32_t)(p.OH - 1), ox_s = mbase & (uint32_t)(p.OW - 1);
@@ -389,6 +393,30 @@ __global__ __launch_bounds__(64 * WCO * WK) void wgrad_tr_kernel(const GatherPar
                 const bool ok = ((uint32_t)q_row[j] < left) & (q_const[j] != EVE_OOB) &
                                 ((uint32_t)(sy0 + q_ty[j]) < (uint32_t)p.IH) & ((uint32_t)(sx0 + q_tx[j]) < (uint32_t)p.IW);
                 vq[j] = ok ? qbase + q_const[j] : EVE_OOB;
+            }
+            return;
+        }
+        if (MODE == 2) {
+            // only the width is a power of two (RefineNet: 72x128 ... 5x8): the column still splits without carries, the
+            // (image, row) pair of the stage's first pixel costs ONE scalar division, and a lane whose row offset runs past
+            // the last image row wraps into the next image (at most once: a stage is 32 pixels <= one image)
+            const uint32_t left = m_end > mbase ? m_end - mbase : 0u;
+            const int pbase = (int)mbase * cout2;
+            const uint32_t rowq = mbase >> sh_w;
+            const uint32_t n_s = fd_div(rowq, p.fd_oh), oy_s = rowq - n_s * (uint32_t)p.OH, ox_s = mbase & (uint32_t)(p.OW - 1);
+            const int sy0 = (int)oy_s * p.o_mul, sx0 = (int)ox_s * p.o_mul;
+            const int qbase = (((int)n_s * p.IH + sy0) * p.IW + sx0) * cin2;
+            const int wrap_y = p.OH * p.o_mul, wrap_addr = (p.IH - wrap_y) * p.IW * cin2;
+#pragma unroll
+            for (int j = 0; j < P_DMA; ++j)
+                vp[j] = ((uint32_t)p_row[j] < left) & (p_const[j] != EVE_OOB) ? pbase + p_const[j] : EVE_OOB;
+#pragma unroll
+            for (int j = 0; j < Q_DMA; ++j) {
+                const bool wrap = (int)oy_s + q_ry[j] >= p.OH;
+                const int sy = sy0 + q_ty[j] - (wrap ? wrap_y : 0);
+                const bool ok = ((uint32_t)q_row[j] < left) & (q_const[j] != EVE_OOB) &
+                                ((uint32_t)sy < (uint32_t)p.IH) & ((uint32_t)(sx0 + q_tx[j]) < (uint32_t)p.IW);
+                vq[j] = ok ? qbase + q_const[j] + (wrap ? wrap_addr : 0) : EVE_OOB;
             }
             return;
         }

@@ -33,7 +33,7 @@ struct GatherParams {
     int o_mul, k_mul, off, div;
     int K;                  // KH*KW*Cin
     uint32_t M;             // N*OH*OW
-    FastDiv fd_ohw, fd_ow, fd_cin, fd_kw;
+    FastDiv fd_ohw, fd_ow, fd_cin, fd_kw, fd_oh;
 };
 
 template <typename T>
@@ -492,7 +492,7 @@ static GatherParams fwd_params(const eve_conv_desc* d) {
     p.K = d->KH * d->KW * d->Cin;
     p.M = (uint32_t)((long long)d->N * d->OH * d->OW);
     p.fd_ohw = make_fastdiv(d->OH * d->OW); p.fd_ow = make_fastdiv(d->OW);
-    p.fd_cin = make_fastdiv(d->Cin); p.fd_kw = make_fastdiv(d->KW);
+    p.fd_cin = make_fastdiv(d->Cin); p.fd_kw = make_fastdiv(d->KW); p.fd_oh = make_fastdiv(d->OH);
     return p;
 }
 static GatherParams dgrad_params(const eve_conv_desc* d) {
@@ -503,7 +503,7 @@ static GatherParams dgrad_params(const eve_conv_desc* d) {
     p.K = d->KH * d->KW * d->Cout;
     p.M = (uint32_t)((long long)d->N * d->IH * d->IW);
     p.fd_ohw = make_fastdiv(d->IH * d->IW); p.fd_ow = make_fastdiv(d->IW);
-    p.fd_cin = make_fastdiv(d->Cout); p.fd_kw = make_fastdiv(d->KW);
+    p.fd_cin = make_fastdiv(d->Cout); p.fd_kw = make_fastdiv(d->KW); p.fd_oh = make_fastdiv(d->IH);
     return p;
 }
 
@@ -709,24 +709,29 @@ static int launch_wgrad(const GatherParams& p, const void* x, const void* dy, co
                    dim3((TK) * (TC) * splits), dim3(64 * WCO_ * WK_), lds_bytes(64 * WCO_, 64 * WK_), s, p, (const bf16_t*)x, \
                    (const bf16_t*)dy, dw, rows, (uint32_t)x_bytes, (uint32_t)dy_bytes);                                   \
     } while (0)
+            // address-decode mode of the gather (see wgrad_tr_kernel): both sizes powers of two / width only / neither
+            const bool pow2w = (p.OW & (p.OW - 1)) == 0;
+            const int mode = pow2 ? 1 : ((pow2w && p.OH * p.OW >= 32) ? 2 : 0);
             if (p.Cout > 64) {
                 const uint32_t tk = (p.K + 127) / 128, tc = (p.Cout + 127) / 128;
                 wgrad_split(p, tk, tc, splits, rows);
-                if (pow2) EVE_WGRAD_LAUNCH(2, 2, true, tk, tc);
-                else      EVE_WGRAD_LAUNCH(2, 2, false, tk, tc);
+                if (mode == 1)      EVE_WGRAD_LAUNCH(2, 2, 1, tk, tc);
+                else if (mode == 2) EVE_WGRAD_LAUNCH(2, 2, 2, tk, tc);
+                else                EVE_WGRAD_LAUNCH(2, 2, 0, tk, tc);
             // (one 9-wave workgroup covering the whole 576-wide filter of the 64-channel layers -- operands fetched once
             //  instead of once per K tile -- measured SLOWER: 0.292 vs 0.237 ms; the surplus fetches hit the Infinity Cache)
-            } else if (pow2 && p.K % 192 == 0 && p.K <= 1152) {
+            } else if (mode == 1 && p.K % 192 == 0 && p.K <= 1152) {
                 // 64-channel 3x3 layers: K = 576 = 3 x 192 exactly (three waves per workgroup) instead of 3 x 256 padded
                 // (0.235 vs 0.246 ms on layer 1; a 3-stage ring for it measured 0.242)
                 const uint32_t tk = p.K / 192;
                 wgrad_split(p, tk, 1, splits, rows);
-                EVE_WGRAD_LAUNCH(1, 3, true, tk, 1);
+                EVE_WGRAD_LAUNCH(1, 3, 1, tk, 1);
             } else {
                 const uint32_t tk = (p.K + 255) / 256, tc = 1;
                 wgrad_split(p, tk, tc, splits, rows);
-                if (pow2) EVE_WGRAD_LAUNCH(1, 4, true, tk, tc);
-                else      EVE_WGRAD_LAUNCH(1, 4, false, tk, tc);
+                if (mode == 1)      EVE_WGRAD_LAUNCH(1, 4, 1, tk, tc);
+                else if (mode == 2) EVE_WGRAD_LAUNCH(1, 4, 2, tk, tc);
+                else                EVE_WGRAD_LAUNCH(1, 4, 0, tk, tc);
             }
 #undef EVE_WGRAD_LAUNCH
             return 0;
@@ -834,7 +839,7 @@ extern "C" int eve_stem_wgrad(int N, int IH, int IW, const void* x_padded, const
     p.K = 7 * 8 * 4;
     p.M = (uint32_t)((long long)N * p.OH * p.OW);
     p.fd_ohw = make_fastdiv(p.OH * p.OW); p.fd_ow = make_fastdiv(p.OW);
-    p.fd_cin = make_fastdiv(4); p.fd_kw = make_fastdiv(8);
+    p.fd_cin = make_fastdiv(4); p.fd_kw = make_fastdiv(8); p.fd_oh = make_fastdiv(p.OH);
     // conv pad is 3, the packed rows carry 4 pixels of left padding: start one pixel (8 bytes) in
     const char* x1 = (const char*)x_padded + 8;
     if ((unsigned long long)N * p.IH * p.IW * 8 >= (1ull << 31)) return set_error_msg("stem_wgrad: packed input must stay below 2 GiB");
