@@ -34,6 +34,7 @@ SIGNATURES = {
     'eve_conv2d_dgrad': [POINTER(ConvDesc), P, P, P, P],
     'eve_conv2d_dgrad_acc': [POINTER(ConvDesc), P, P, P, P],
     'eve_conv2d_wgrad': [POINTER(ConvDesc), P, P, P, I, P, P],
+    'eve_conv2d_wgrad_bias': [POINTER(ConvDesc), P, P, P, P, P],
     'eve_stem_pack_input': [I, I, I, I, P, P, P],
     'eve_stem7x7s2_fwd': [I, I, I, P, P, P, P],
     'eve_stem_fwd_fused': [I, I, I, P, P, F, P, P, P, P],

@@ -444,6 +444,7 @@ __global__ __launch_bounds__(256) void bias_grad_kernel(const T* __restrict__ dy
     const long long r_begin = (long long)blockIdx.x * rows_per_block;
     const long long r_end = min(M, r_begin + rows_per_block);
     if (ph < phases) {
+#pragma unroll 4
         for (long long r = r_begin + ph; r < r_end; r += phases) {
             float f[VEC];
             Elem<T>::unpack(*reinterpret_cast<const uint4*>(dy + r * C + cv * VEC), f);
@@ -457,13 +458,20 @@ __global__ __launch_bounds__(256) void bias_grad_kernel(const T* __restrict__ dy
 #pragma unroll
     for (int e = 0; e < VEC; ++e) red[tid * VEC + e] = ph < phases ? s[e] : 0.f;
     __syncthreads();
+    // pairwise tree over the phases (two threads walking 128 partial rows one after the other cost more than the
+    // loads of a whole workgroup on 16-channel tensors)
+    for (int n = phases; n > 1;) {
+        const int half = (n + 1) >> 1;
+        if (ph + half < n) {
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) red[tid * VEC + e] += red[(tid + half * cvecs) * VEC + e];
+        }
+        __syncthreads();
+        n = half;
+    }
     if (tid < cvecs) {
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) {
-            float a = 0.f;
-            for (int q = 0; q < phases; ++q) a += red[(q * cvecs + tid) * VEC + e];
-            atomicAdd(db + tid * VEC + e, a);
-        }
+        for (int e = 0; e < VEC; ++e) atomicAdd(db + tid * VEC + e, red[tid * VEC + e]);
     }
 }
 
@@ -688,7 +696,7 @@ static void wgrad_split(const GatherParams& p, uint32_t tk, uint32_t tc, uint32_
 
 template <typename T>
 static int launch_wgrad(const GatherParams& p, const void* x, const void* dy, const float* ss, int pro_act,
-                        float* dw, hipStream_t s) {
+                        float* dw, hipStream_t s, float* db = nullptr) {
     if (sizeof(T) == 2 && !ss && !use_v1()) {   // bf16: LDS-DMA staging + hardware-transposing fragment reads
         const unsigned long long x_bytes = (unsigned long long)p.N * p.IH * p.IW * p.Cin * 2;
         const unsigned long long dy_bytes = (unsigned long long)p.M * p.Cout * 2;
@@ -697,17 +705,22 @@ static int launch_wgrad(const GatherParams& p, const void* x, const void* dy, co
             const bool pow2 = ((p.OW & (p.OW - 1)) == 0) && ((p.OH & (p.OH - 1)) == 0);
             // dynamic LDS = RING (4) stages of 32 pixels x (BCO + BKK) bf16
             auto lds_bytes = [](int bco, int bkk) { return (size_t)(bco == 128 ? 3 : 4) * 32 * (bco + bkk) * 2; };
-#define EVE_WGRAD_LAUNCH(WCO_, WK_, P2_, TK, TC)                                                                        \
+#define EVE_WGRAD_LAUNCH1(WCO_, WK_, P2_, B_, TK, TC)                                                                   \
     do {                                                                                                                \
         static bool attr_done = false;                                                                                  \
         if (!attr_done) {                                                                                               \
-            (void)hipFuncSetAttribute((const void*)wgrad_tr_kernel<WCO_, WK_, P2_>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+            (void)hipFuncSetAttribute((const void*)wgrad_tr_kernel<WCO_, WK_, P2_, B_>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                       160 * 1024);                                                                      \
             attr_done = true;                                                                                           \
         }                                                                                                               \
-        EVE_LAUNCH("wgrad_tr_kernel<" #WCO_ ", " #WK_ ", " #P2_ ">", (wgrad_tr_kernel<WCO_, WK_, P2_>),                    \
+        EVE_LAUNCH("wgrad_tr_kernel<" #WCO_ ", " #WK_ ", " #P2_ ">", (wgrad_tr_kernel<WCO_, WK_, P2_, B_>),                \
                    dim3((TK) * (TC) * splits), dim3(64 * WCO_ * WK_), lds_bytes(64 * WCO_, 64 * WK_), s, p, (const bf16_t*)x, \
-                   (const bf16_t*)dy, dw, rows, (uint32_t)x_bytes, (uint32_t)dy_bytes);                                   \
+                   (const bf16_t*)dy, dw, rows, (uint32_t)x_bytes, (uint32_t)dy_bytes, db);                               \
+    } while (0)
+#define EVE_WGRAD_LAUNCH(WCO_, WK_, P2_, TK, TC)                                                                        \
+    do {                                                                                                                \
+        if (db) EVE_WGRAD_LAUNCH1(WCO_, WK_, P2_, true, TK, TC);                                                        \
+        else    EVE_WGRAD_LAUNCH1(WCO_, WK_, P2_, false, TK, TC);                                                       \
     } while (0)
             // address-decode mode of the gather (see wgrad_tr_kernel): both sizes powers of two / width only / neither
             const bool pow2w = (p.OW & (p.OW - 1)) == 0;
@@ -734,7 +747,8 @@ static int launch_wgrad(const GatherParams& p, const void* x, const void* dy, co
                 else                EVE_WGRAD_LAUNCH(1, 4, 0, tk, tc);
             }
 #undef EVE_WGRAD_LAUNCH
-            return 0;
+#undef EVE_WGRAD_LAUNCH1
+            return db ? 1 : 0;                              // 1: the bias gradient has been taken care of
         }
     }
     const bool wide = p.Cout > 64;
@@ -848,19 +862,41 @@ extern "C" int eve_stem_wgrad(int N, int IH, int IW, const void* x_padded, const
     return 0;
 }
 
-extern "C" int eve_bias_grad(int dtype, long long M, int C, const void* dy, float* db, eve_stream_t stream) {
-    const int vec = dtype == EVE_DT_BF16 ? 8 : 4;
-    if (M <= 0 || C <= 0 || C % vec || C / vec > 256) return set_error_msg("bias_grad: bad shape");
-    if (!dy || !db) return set_error_msg("bias_grad: null pointer");
+static void launch_bias_grad(int dtype, long long M, int C, const void* dy, float* db, hipStream_t s) {
     long long blocks = (M + 255) / 256;
     if (blocks > 2048) blocks = 2048;
     const long long rows = (M + blocks - 1) / blocks;
     blocks = (M + rows - 1) / rows;
-    hipStream_t s = (hipStream_t)stream;
     if (dtype == EVE_DT_BF16)
         hipLaunchKernelGGL(bias_grad_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, s, (const bf16_t*)dy, db, M, C, rows);
     else
         hipLaunchKernelGGL(bias_grad_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, s, (const float*)dy, db, M, C, rows);
+}
+
+extern "C" int eve_bias_grad(int dtype, long long M, int C, const void* dy, float* db, eve_stream_t stream) {
+    const int vec = dtype == EVE_DT_BF16 ? 8 : 4;
+    if (M <= 0 || C <= 0 || C % vec || C / vec > 256) return set_error_msg("bias_grad: bad shape");
+    if (!dy || !db) return set_error_msg("bias_grad: null pointer");
+    launch_bias_grad(dtype, M, C, dy, db, (hipStream_t)stream);
+    EVE_CHECK_LAUNCH();
+    return 0;
+}
+
+/* Weight and bias gradient of one convolution in a single pass over dy where the kernel allows it (bf16: the column
+   sums ride on the weight-gradient MFMAs); otherwise the weight gradient followed by the column-sum kernel.
+   dw and db are accumulated into. */
+extern "C" int eve_conv2d_wgrad_bias(const eve_conv_desc* d, const void* x, const void* dy, float* dw_ohwi, float* db,
+                                     eve_stream_t stream) {
+    const int vec = (d && d->dtype == EVE_DT_BF16) ? 8 : 4;
+    if (int e = check_desc(d, vec)) return e;
+    if (d->Cout % vec || d->Cout / vec > 256) return set_error_msg("conv2d_wgrad_bias: bad Cout");
+    if (!x || !dy || !dw_ohwi || !db) return set_error_msg("conv2d_wgrad_bias: null pointer");
+    GatherParams p = fwd_params(d);
+    hipStream_t s = (hipStream_t)stream;
+    int fused = 0;
+    if (d->dtype == EVE_DT_BF16) fused = launch_wgrad<bf16_t>(p, x, dy, nullptr, 0, dw_ohwi, s, db);
+    else                         launch_wgrad<float>(p, x, dy, nullptr, 0, dw_ohwi, s);
+    if (!fused) launch_bias_grad(d->dtype, (long long)p.M, d->Cout, dy, db, s);
     EVE_CHECK_LAUNCH();
     return 0;
 }

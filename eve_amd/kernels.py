@@ -157,14 +157,20 @@ class HipKernels(object):
             ctypes.byref(d), self._p(dy), self._p(w_ihwo), self._p(dx), self._stream())))
         return dx
 
-    def conv2d_wgrad(self, x, dy, KH, KW, stride, pad, dw_ohwi, ss=None, pro_act=ACT_NONE, algo=None):
-        """Accumulates into dw_ohwi (float32 [Cout, KH, KW, Cin])."""
+    def conv2d_wgrad(self, x, dy, KH, KW, stride, pad, dw_ohwi, ss=None, pro_act=ACT_NONE, algo=None, db=None):
+        """Accumulates into dw_ohwi (float32 [Cout, KH, KW, Cin]) and, when given, the column sums of dy into db
+        (float32 [Cout]) in the same pass."""
         N, IH, IW, Cin = x.shape
         Cout = dy.shape[3]
         assert dw_ohwi.shape == (Cout, KH, KW, Cin) and dw_ohwi.dtype == torch.float32
         d = self._desc(x.dtype, N, IH, IW, Cin, Cout, KH, KW, stride, pad)
         assert tuple(dy.shape) == (N, d.OH, d.OW, Cout) and dy.dtype == x.dtype
         co, kk = algo or (Cout, KH * KW * Cin)
+        if db is not None:
+            assert ss is None and db.shape == (Cout,) and db.dtype == torch.float32 and db.is_contiguous()
+            self._timed('conv_wgrad', 2.0 * N * d.OH * d.OW * co * kk, lambda: self._ck(self.lib.eve_conv2d_wgrad_bias(
+                ctypes.byref(d), self._p(x), self._p(dy), self._p(dw_ohwi), self._p(db), self._stream())))
+            return dw_ohwi
         self._timed('conv_wgrad', 2.0 * N * d.OH * d.OW * co * kk, lambda: self._ck(self.lib.eve_conv2d_wgrad(
             ctypes.byref(d), self._p(x), self._p(dy), self._p(self._f32(ss, 'scale/shift')), pro_act,
             self._p(dw_ohwi), self._stream())))

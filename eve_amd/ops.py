@@ -97,6 +97,17 @@ class Conv2dFn(torch.autograd.Function):
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             dx = k.conv2d_dgrad(dy, pack.ihwo, (x.shape[1], x.shape[2]), ctx.stride, ctx.pad, algo=pack.algo)
+        # bias gradient buffer first: when the weight gradient is wanted too, its kernel sums dy's columns on the way
+        dbuf, b_direct = None, False
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            cout_p = pack.ohwi.shape[0]
+            bp = ctx.b_direct
+            if bp is not None and cout_p == pack.shape_oihw[0]:
+                dbuf, b_direct = bp.grad, True
+            else:
+                dbuf = torch.zeros((cout_p,), dtype=torch.float32, device=x.device)
+                db = dbuf[:pack.shape_oihw[0]]
+        db_pending = dbuf
         if ctx.needs_input_grad[1]:
             cout_p, KH, KW, cin_p = pack.ohwi.shape
             O, I = pack.shape_oihw[0], pack.shape_oihw[1]
@@ -106,24 +117,19 @@ class Conv2dFn(torch.autograd.Function):
                 # no temporary, no zero-fill launch, no AccumulateGrad add
                 g = wp.grad
                 buf = g.permute(0, 2, 3, 1) if g.dim() == 4 else g.view(O, 1, 1, I)
-                k.conv2d_wgrad(x, dy, KH, KW, ctx.stride, ctx.pad, buf, algo=pack.algo)
+                k.conv2d_wgrad(x, dy, KH, KW, ctx.stride, ctx.pad, buf, algo=pack.algo, db=db_pending)
                 _notify_grad_ready(wp)
             else:
                 dwp = torch.zeros((cout_p, KH, KW, cin_p), dtype=torch.float32, device=x.device)
-                k.conv2d_wgrad(x, dy, KH, KW, ctx.stride, ctx.pad, dwp, algo=pack.algo)
+                k.conv2d_wgrad(x, dy, KH, KW, ctx.stride, ctx.pad, dwp, algo=pack.algo, db=db_pending)
                 dw = dwp[:O, :, :, :I].permute(0, 3, 1, 2)          # OIHW-shaped view of OHWI memory
                 if len(ctx.wshape) == 2:
                     dw = dw.reshape(ctx.wshape)
-        if ctx.has_bias and ctx.needs_input_grad[2]:
-            cout_p = pack.ohwi.shape[0]
-            bp = ctx.b_direct
-            if bp is not None and cout_p == pack.shape_oihw[0]:
-                k.bias_grad(dy, bp.grad)
-                _notify_grad_ready(bp)
-            else:
-                dbp = torch.zeros((cout_p,), dtype=torch.float32, device=x.device)
-                k.bias_grad(dy, dbp)
-                db = dbp[:pack.shape_oihw[0]]
+            db_pending = None
+        if db_pending is not None:
+            k.bias_grad(dy, db_pending)
+        if b_direct:
+            _notify_grad_ready(ctx.b_direct)
         return dx, dw, db, None, None, None, None
 
 
@@ -288,17 +294,18 @@ class _WgradLane:
         self.used = False
 
 
-def _wgrad_into(k, x, dy, weight, pack, stride, pad):
-    """Weight gradient of a bias-free conv: straight into the flat gradient buffer when the parameter lives there
-    (returns None), else a fresh OIHW-shaped tensor for autograd."""
+def _wgrad_into(k, x, dy, weight, pack, stride, pad, db=None):
+    """Weight gradient of a conv: straight into the flat gradient buffer when the parameter lives there (returns
+    None), else a fresh OIHW-shaped tensor for autograd.  `db` (float32 [Cout_padded], accumulated) also receives the
+    bias gradient from the same kernel."""
     cout_p, KH, KW, cin_p = pack.ohwi.shape
     O, I = pack.shape_oihw[0], pack.shape_oihw[1]
     if _direct_grad_ok(weight) and (cout_p, cin_p) == (O, I):
-        k.conv2d_wgrad(x, dy, KH, KW, stride, pad, weight.grad.permute(0, 2, 3, 1), algo=pack.algo)
+        k.conv2d_wgrad(x, dy, KH, KW, stride, pad, weight.grad.permute(0, 2, 3, 1), algo=pack.algo, db=db)
         _notify_grad_ready(weight)
         return None
     dwp = torch.zeros((cout_p, KH, KW, cin_p), dtype=torch.float32, device=x.device)
-    k.conv2d_wgrad(x, dy, KH, KW, stride, pad, dwp, algo=pack.algo)
+    k.conv2d_wgrad(x, dy, KH, KW, stride, pad, dwp, algo=pack.algo, db=db)
     return dwp[:O, :, :, :I].permute(0, 3, 1, 2)
 
 

@@ -76,6 +76,10 @@ int eve_conv2d_dgrad_acc(const eve_conv_desc* d, const void* dy, const void* w_i
 /* dw[Cout][KH][KW][Cin] (float, accumulated) += sum_m dy[m][co] * x'[m][(kh,kw,ci)]              */
 int eve_conv2d_wgrad(const eve_conv_desc* d, const void* x, const void* dy,
                      const float* in_scale_shift, int pro_act, float* dw_ohwi, eve_stream_t stream);
+/* ... together with db[Cout] (float, accumulated) += sum_m dy[m][co] in the same pass over dy: autograd of a biased
+ * nn.Conv2d (refine_net.py's U-Net and conv-GRU convolutions all carry one).                                   */
+int eve_conv2d_wgrad_bias(const eve_conv_desc* d, const void* x, const void* dy, float* dw_ohwi, float* db,
+                          eve_stream_t stream);
 /* ResNet stem (torchvision ResNet.conv1: 7x7 / stride 2 / pad 3, 3 -> 64, no bias; eye_net.py:48-50), bf16:
  * eve_stem_pack_input writes x_padded [N][IH+6][IW+8][4] bf16 (channels 0..C-1, zero 4th channel and borders)
  * from the float NCHW patch; eve_stem7x7s2_fwd computes y [N][IH/2][IW/2][64] from it and the OHWI weights

@@ -63,7 +63,9 @@ class FakeKernels(object):
             return accumulate_into
         return nhwc(dx, dy.dtype)
 
-    def conv2d_wgrad(self, x, dy, KH, KW, stride, pad, dw_ohwi, ss=None, pro_act=ACT_NONE, algo=None):
+    def conv2d_wgrad(self, x, dy, KH, KW, stride, pad, dw_ohwi, ss=None, pro_act=ACT_NONE, algo=None, db=None):
+        if db is not None:
+            db += dy.float().sum(dim=(0, 1, 2))
         xin = self._pro(x, ss, pro_act).to(x.dtype)
         Cout, Cin = dy.shape[3], x.shape[3]
         dw = torch.nn.grad.conv2d_weight(nchw(xin), (Cout, Cin, KH, KW), nchw(dy), stride, pad)

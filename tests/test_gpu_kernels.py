@@ -103,6 +103,12 @@ def test_conv_fwd_dgrad_wgrad(hip, ref, dtype, case):
     want_db = ref.bias_grad(dy, torch.zeros(Cout))
     got_db = hip.bias_grad(dev(dy), torch.zeros(Cout, device='cuda'))
     close(got_db, want_db, dtype, 'bias grad')
+    # weight and bias gradient from one pass over dy (accumulating onto existing values)
+    dw0, db0 = rnd((Cout, K, K, Cin), torch.float32, 6), rnd((Cout,), torch.float32, 7)
+    got_dw2, got_db2 = dev(dw0).clone(), dev(db0).clone()
+    hip.conv2d_wgrad(dev(x), dev(dy), K, K, stride, pad, got_dw2, db=got_db2)
+    close(got_dw2, want_dw + dw0, dtype, 'conv wgrad (+bias)')
+    close(got_db2, want_db + db0, dtype, 'bias grad fused into wgrad')
 
 
 @pytest.mark.parametrize('dtype', DTYPES, ids=['f32', 'bf16'])
