@@ -19,7 +19,7 @@ class PackedWeight(object):
     `param` has the reference's OIHW (or [out, in]) SHAPE; its memory may already be OHWI (the
     flat-parameter harness stores it that way), in which case no permute copy is made."""
 
-    __slots__ = ('ohwi', 'ihwo', 'shape_oihw', 'algo')
+    __slots__ = ('ohwi', 'ihwo', 'shape_oihw', 'algo', 'pair_fwd', 'pair_dgrad')
 
     def __init__(self, param, dtype, cin_pad=None, cout_pad=None, want_ihwo=True, defer=False):
         k = default_kernels()
@@ -34,10 +34,18 @@ class PackedWeight(object):
         if cout_pad is not None and cout_pad != w.shape[0]:
             w = torch.nn.functional.pad(w, (0, 0, 0, 0, 0, 0, 0, cout_pad - w.shape[0]))
         w = w.contiguous().float()
+        self.pair_fwd = self.pair_dgrad = None
         if defer:                                     # packed later, together with others (pack_many)
             self.ohwi, self.ihwo = (w, want_ihwo), None
         else:
             self.ohwi, self.ihwo = k.pack_weights(w, dtype, want_ihwo=want_ihwo)
+            if dtype == torch.bfloat16 and w.shape[1] == w.shape[2] and param.dim() == 4:
+                cout_p, cin_p = w.shape[0], w.shape[3]
+                fac = _group_factors(w.shape[1])
+                if cin_p in fac:
+                    self.pair_fwd = (fac[cin_p], pixel_group_weights(self.ohwi, fac[cin_p], False))
+                if want_ihwo and cout_p in fac:
+                    self.pair_dgrad = (fac[cout_p], pixel_group_weights(self.ohwi, fac[cout_p], True))
 
     @staticmethod
     def pack_many(packs, dtype):
@@ -48,6 +56,68 @@ class PackedWeight(object):
         res = default_kernels().pack_weights_batch([p.ohwi[0] for p in todo], dtype, [p.ohwi[1] for p in todo])
         for p, (ohwi, ihwo) in zip(todo, res):
             p.ohwi, p.ihwo = ohwi, ihwo
+
+
+# ---- 3x3 / stride 1 / pad 1 convolutions over 8- or 16-channel tensors (RefineNet's 72x128 level, refine_net.py:
+# 96-131 of the reference) -------------------------------------------------------------------------------------------
+# An NHWC row [W][C] with C = 32/F channels is, byte for byte, a row [W/F][32]: F neighbouring pixels form one
+# 32-channel "group pixel".  The same convolution over group pixels is again 3x3 / pad 1, from 32 input channels to
+# F*Cout output channels (the F output pixels of a group), with a weight tensor that holds each original tap once per
+# (output pixel, input pixel) pair of the groups it connects and zeros elsewhere.  That is exactly the shape the
+# halo-resident MFMA kernel is built for (32-channel K steps), so these layers run there instead of on the generic
+# gather kernel (551 -> ~120 us per launch at 960 x 72 x 128); the matrix units do F x the arithmetic on a
+# bandwidth-bound layer.
+# 1x1 convolutions group pixels up to 64 channels (the LDS-DMA gather kernel's K step) with a block-diagonal filter.
+# (32-channel rows 128 pixels wide are grouped as well: the halo kernel's 256-pixel x 64-channel tile would need a
+#  two-row halo of 520 pixels, more than its DMA schedule holds, and the gather kernel wants 64-channel K steps.)
+PAIR_FACTOR = {32: 2, 16: 2, 8: 4}          # 3x3: channels -> pixels per group
+PAIR_FACTOR_1X1 = {32: 2, 16: 4, 8: 8}
+_pair_index_cache = {}
+
+
+def _pixel_group_index(cout, cin, ks, F, transpose, device):
+    key = (cout, cin, ks, F, transpose, str(device))
+    idx = _pair_index_cache.get(key)
+    if idx is None:
+        ar = lambda n: torch.arange(n, device=device)
+        pad = (ks - 1) // 2                                 # of the plain and of the grouped convolution alike
+        # output channel (po, o), taps (kh, kwg), input channel (pi, i) of the grouped filter
+        no, ni = (cin, cout) if transpose else (cout, cin)
+        po, o, kh, kwg, pi, i = torch.meshgrid(ar(F), ar(no), ar(ks), ar(ks), ar(F), ar(ni), indexing='ij')
+        kw = F * (kwg - pad) + pi - po + pad                # original tap: input pixel minus output pixel, plus pad
+        valid = (kw >= 0) & (kw < ks)
+        kw = kw.clamp(0, ks - 1)
+        if transpose:      # data gradient as a convolution: Wd[ci][kh][kw][co] = W[co][ks-1-kh][ks-1-kw][ci]
+            src = ((i * ks + (ks - 1 - kh)) * ks + (ks - 1 - kw)) * cin + o
+        else:
+            src = ((o * ks + kh) * ks + kw) * cin + i
+        idx = torch.where(valid, src, torch.full_like(src, cout * ks * ks * cin)).reshape(F * no, ks, ks, F * ni)
+        _pair_index_cache[key] = idx
+    return idx
+
+
+def pixel_group_weights(ohwi, F, transpose):
+    """Filter [F*Cout][k][k][F*Cin] of the convolution over groups of F pixels (see above) from the packed OHWI filter
+    [Cout][k][k][Cin], k = 1 or 3; with `transpose`, the filter [F*Cin][k][k][F*Cout] of its data gradient."""
+    cout, ks, _, cin = ohwi.shape
+    idx = _pixel_group_index(cout, cin, ks, F, transpose, ohwi.device)
+    flat = torch.cat([ohwi.reshape(-1), ohwi.new_zeros(1)])
+    return flat[idx]
+
+
+def _group_factors(ks):
+    return PAIR_FACTOR if ks == 3 else (PAIR_FACTOR_1X1 if ks == 1 else {})
+
+
+def _group_ok(pair, x, ks, stride, pad):
+    if pair is None or stride != 1 or pad != (ks - 1) // 2 or x.dtype != torch.bfloat16:
+        return False
+    wg = x.shape[2] // pair[0]
+    if x.shape[2] % pair[0]:
+        return False
+    if ks == 3 and x.shape[3] == 32 and x.shape[2] != 128:
+        return False                                                 # handled directly by the halo kernel
+    return ks == 1 or (4 <= wg <= 128 and (wg & (wg - 1)) == 0)      # 3x3: the halo kernel's row widths
 
 
 def _direct_grad_ok(p):
@@ -76,7 +146,14 @@ class Conv2dFn(torch.autograd.Function):
             if b.numel() != cout_p:
                 b = torch.nn.functional.pad(b, (0, cout_p - b.numel()))
             b = b.contiguous()
-        y = k.conv2d_fwd(x, pack.ohwi, b, stride, pad, epi_act, algo=pack.algo)
+        ks = pack.ohwi.shape[1]
+        if _group_ok(pack.pair_fwd, x, ks, stride, pad):
+            F, wg = pack.pair_fwd
+            N, H, W, C = x.shape
+            y = k.conv2d_fwd(x.view(N, H, W // F, F * C), wg, None if b is None else b.repeat(F), 1, pad, epi_act,
+                             algo=pack.algo).view(N, H, W, cout_p)
+        else:
+            y = k.conv2d_fwd(x, pack.ohwi, b, stride, pad, epi_act, algo=pack.algo)
         ctx.pack, ctx.stride, ctx.pad, ctx.epi_act = pack, stride, pad, epi_act
         ctx.has_bias = bias is not None
         ctx.wshape = tuple(weight.shape)
@@ -96,7 +173,13 @@ class Conv2dFn(torch.autograd.Function):
             dy = k.act_bwd(dy, y, ctx.epi_act)
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            dx = k.conv2d_dgrad(dy, pack.ihwo, (x.shape[1], x.shape[2]), ctx.stride, ctx.pad, algo=pack.algo)
+            if _group_ok(pack.pair_dgrad, dy, pack.ohwi.shape[1], ctx.stride, ctx.pad):
+                F, wg = pack.pair_dgrad
+                N, H, W, C = dy.shape
+                dx = k.conv2d_fwd(dy.view(N, H, W // F, F * C), wg, None, 1, ctx.pad, ACT_NONE,
+                                  algo=pack.algo).view(N, H, W, x.shape[3])
+            else:
+                dx = k.conv2d_dgrad(dy, pack.ihwo, (x.shape[1], x.shape[2]), ctx.stride, ctx.pad, algo=pack.algo)
         # bias gradient buffer first: when the weight gradient is wanted too, its kernel sums dy's columns on the way
         dbuf, b_direct = None, False
         if ctx.has_bias and ctx.needs_input_grad[2]:

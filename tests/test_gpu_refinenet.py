@@ -163,3 +163,31 @@ def test_refinenet_fused_scan_trains_like_the_per_step_path(monkeypatch):
         assert float((ga - gb).norm()) <= 0.15 * float(gb.norm()) + 1e-4, n
         if float(gb.norm()) > 1e-3:
             assert float((ga * gb).sum() / (ga.norm() * gb.norm())) > 0.985, n
+
+
+@pytest.mark.parametrize('cin,cout,H,W,ks', [(16, 16, 72, 128, 3), (16, 32, 36, 64, 3), (8, 16, 72, 128, 3),
+                                              (32, 16, 9, 16, 3), (32, 32, 72, 128, 3), (32, 16, 72, 128, 3), (16, 32, 72, 128, 1), (64, 16, 72, 128, 1),
+                                              (16, 8, 72, 128, 1), (32, 64, 36, 64, 1)])
+def test_pixel_group_convolution_on_the_halo_kernel(monkeypatch, cin, cout, H, W, ks):
+    """8/16-channel 3x3 convolutions (RefineNet's outer level) run as 32-channel convolutions over pixel groups on the
+    halo-resident kernel (1x1: 64-channel groups on the LDS-DMA gather kernel): same forward, data, weight and bias gradients as the generic kernel on the plain layout."""
+    from eve_amd import ops
+    torch.manual_seed(cin * 100 + cout)
+    x0 = torch.randn(3, H, W, cin).bfloat16().cuda()
+    wt0 = (torch.randn(cout, cin, ks, ks) * (2.0 / (ks * ks * cin)) ** 0.5).cuda()
+    b0 = torch.randn(cout).cuda()
+    gy = torch.randn(3, H, W, cout).bfloat16().cuda()
+    outs = []
+    for grouped in (True, False):
+        if not grouped:
+            monkeypatch.setattr(ops, 'PAIR_FACTOR', {})
+            monkeypatch.setattr(ops, 'PAIR_FACTOR_1X1', {})
+        x = x0.clone().requires_grad_(True)
+        wt, b = wt0.clone().requires_grad_(True), b0.clone().requires_grad_(True)
+        pack = ops.PackedWeight(wt, torch.bfloat16)
+        y = ops.conv2d(x, wt, b, pack, stride=1, pad=ks // 2, act=1)
+        y.backward(gy)
+        outs.append((y.detach().float().cpu(), x.grad.float().cpu(), wt.grad.cpu(), b.grad.cpu()))
+    for name, a, c in zip(('y', 'dx', 'dw', 'db'), *outs):
+        # same products, different fp32 summation order, one bf16 rounding at the end
+        assert float((a - c).abs().max()) <= 1e-2 * float(c.abs().max()) + 1e-6, name

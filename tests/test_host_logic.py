@@ -276,3 +276,31 @@ def test_refinenet_host_logic_matches_oracle(fake, kind):
             a, b = p.grad.double(), rp[n].grad.double()
             assert float((a - b).norm()) <= 3e-2 * float(b.norm()) + 1e-5, n
     eve_amd.reset_standalone_config()
+
+
+@pytest.mark.parametrize('cin,cout,W,ks', [(16, 16, 16, 3), (16, 32, 8, 3), (8, 16, 32, 3), (32, 16, 128, 3),
+                                            (16, 32, 8, 1), (64, 16, 12, 1), (16, 8, 16, 1), (32, 64, 6, 1)])
+def test_pixel_group_convolution_equals_plain_convolution(fake, monkeypatch, cin, cout, W, ks):
+    """ops.Conv2dFn on 8/16-channel tensors runs the convolution over groups of 4/2 pixels (32-channel rows); the
+    grouped filter must give the same forward, data gradient, weight and bias gradient as the plain one."""
+    from eve_amd import ops
+    torch.manual_seed(cin + cout)
+    x0 = torch.randn(2, 6, W, cin).bfloat16()
+    wt0 = (torch.randn(cout, cin, ks, ks) * 0.1)
+    b0 = torch.randn(cout)
+    fac = (8, 16, 32)
+    outs = []
+    for grouped in (True, False):
+        if not grouped:
+            monkeypatch.setattr(ops, 'PAIR_FACTOR', {})
+            monkeypatch.setattr(ops, 'PAIR_FACTOR_1X1', {})
+        x = x0.clone().requires_grad_(True)
+        wt, b = wt0.clone().requires_grad_(True), b0.clone().requires_grad_(True)
+        pack = ops.PackedWeight(wt, torch.bfloat16)
+        assert (pack.pair_fwd is not None) == (grouped and cin in fac)
+        assert (pack.pair_dgrad is not None) == (grouped and cout in fac)
+        y = ops.conv2d(x, wt, b, pack, stride=1, pad=ks // 2, act=1)
+        (y.float() * torch.linspace(-1, 1, y.numel()).view_as(y)).sum().backward()
+        outs.append((y.detach().float(), x.grad.float(), wt.grad, b.grad))
+    for a, c in zip(*outs):
+        assert float((a - c).abs().max()) <= 2e-2 * float(c.abs().max()) + 1e-6
