@@ -307,7 +307,9 @@ __device__ __forceinline__ uint2 lds_tr_read(uint32_t lds_byte_addr) {
 // BIAS: the waves of the first K tile also accumulate db[co] += sum over pixels of dy -- one more MFMA per channel
 // tile against an all-ones operand, on fragments that are in registers anyway (the separate column-sum pass re-read
 // dy from HBM: 44 launches and 8.4 ms per RefineNet step)
-template <int WCO, int WK, int MODE, bool BIAS = false>
+// MT: 16-channel tiles of dy a wave multiplies (4 = all 64; 1 / 2 for layers with <= 16 / 32 output channels, whose
+// remaining tiles are zero-fill: RefineNet's outer levels spent 3/4 of their MFMAs on them)
+template <int WCO, int WK, int MODE, bool BIAS = false, int MT = 4>
 __global__ __launch_bounds__(64 * WCO * WK) void wgrad_tr_kernel(const GatherParams p, const bf16_t* __restrict__ x,
                                                        const bf16_t* __restrict__ dy, float* __restrict__ dw,
                                                        const uint32_t rows_per_split, const uint32_t x_bytes,
@@ -489,6 +491,7 @@ __global__ __launch_bounds__(64 * WCO * WK) void wgrad_tr_kernel(const GatherPar
 #pragma unroll
     for (int a = 0; a < 4; ++a) accb[a] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     const bool do_bias = BIAS && k0 == 0 && wk == 0;                   // wave-uniform
+    const bool k_live = k0 + (uint32_t)wk * 64 < (uint32_t)p.K;        // wave-uniform: some filter column is real
     const uint4 ones = make_uint4(0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u);   // eight bf16 1.0
 
     if (m_begin < m_end) {
@@ -511,18 +514,30 @@ __global__ __launch_bounds__(64 * WCO * WK) void wgrad_tr_kernel(const GatherPar
             __builtin_amdgcn_s_barrier();
             issue((st + RING - 1) % RING, vp, vq);            // stage st+RING-1 recycles the slot read in step st-1
             const uint32_t sb = lds0 + (st % RING) * BUF;
-            uint4 fp[4], fq[4];
+            if (MT == 4 || k_live) {                          // (a wave whose 64 columns all lie beyond K only fetches)
+                uint4 fp[4], fq[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const uint2 a0 = lds_tr_read(sb + poff[i]);
-                const uint2 a1 = lds_tr_read<4 * PROW>(sb + poff[i]);
-                fp[i] = make_uint4(a0.x, a0.y, a1.x, a1.y);
-                const uint2 b0 = lds_tr_read(sb + qoff[i]);
-                const uint2 b1 = lds_tr_read<4 * QROW>(sb + qoff[i]);
-                fq[i] = make_uint4(b0.x, b0.y, b1.x, b1.y);
+                for (int i = 0; i < 4; ++i) {
+                    if (i < MT) {
+                        const uint2 a0 = lds_tr_read(sb + poff[i]);
+                        const uint2 a1 = lds_tr_read<4 * PROW>(sb + poff[i]);
+                        fp[i] = make_uint4(a0.x, a0.y, a1.x, a1.y);
+                    } else {
+                        fp[i] = make_uint4(0u, 0u, 0u, 0u);
+                    }
+                    const uint2 b0 = lds_tr_read(sb + qoff[i]);
+                    const uint2 b1 = lds_tr_read<4 * QROW>(sb + qoff[i]);
+                    fq[i] = make_uint4(b0.x, b0.y, b1.x, b1.y);
+                }
+                if (MT == 4) {
+                    mma16_bf16_inplace(acc, fp, fq);              // acc[mt][kt] += P[mt] x Q[kt]
+                } else {
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt)
+                        mma4_bf16_inplace(acc[mt][0], acc[mt][1], acc[mt][2], acc[mt][3], fp[mt], fq);
+                }
+                if (BIAS && do_bias) mma4_bf16_inplace_b(accb, fp, ones);   // every column = sum over the 32 pixels
             }
-            mma16_bf16_inplace(acc, fp, fq);                  // acc[mt][kt] += P[mt] x Q[kt]
-            if (BIAS && do_bias) mma4_bf16_inplace_b(accb, fp, ones);   // every column = sum over the 32 pixels
             // address arithmetic of stage st+4: independent VALU work the scheduler can slot between the MFMAs
             offsets(m_begin + (uint32_t)(st + RING) * STEP, vp, vq);
         };
@@ -537,7 +552,7 @@ __global__ __launch_bounds__(64 * WCO * WK) void wgrad_tr_kernel(const GatherPar
         mma_drain();
     }
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt)
+    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt) {
             const uint32_t k = k0 + wk * 64 + kt * 16 + t;

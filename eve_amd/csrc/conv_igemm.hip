@@ -705,23 +705,24 @@ static int launch_wgrad(const GatherParams& p, const void* x, const void* dy, co
             const bool pow2 = ((p.OW & (p.OW - 1)) == 0) && ((p.OH & (p.OH - 1)) == 0);
             // dynamic LDS = RING (4) stages of 32 pixels x (BCO + BKK) bf16
             auto lds_bytes = [](int bco, int bkk) { return (size_t)(bco == 128 ? 3 : 4) * 32 * (bco + bkk) * 2; };
-#define EVE_WGRAD_LAUNCH1(WCO_, WK_, P2_, B_, TK, TC)                                                                   \
+#define EVE_WGRAD_LAUNCH2(WCO_, WK_, P2_, B_, MT_, TK, TC)                                                              \
     do {                                                                                                                \
         static bool attr_done = false;                                                                                  \
         if (!attr_done) {                                                                                               \
-            (void)hipFuncSetAttribute((const void*)wgrad_tr_kernel<WCO_, WK_, P2_, B_>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+            (void)hipFuncSetAttribute((const void*)wgrad_tr_kernel<WCO_, WK_, P2_, B_, MT_>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                       160 * 1024);                                                                      \
             attr_done = true;                                                                                           \
         }                                                                                                               \
-        EVE_LAUNCH("wgrad_tr_kernel<" #WCO_ ", " #WK_ ", " #P2_ ">", (wgrad_tr_kernel<WCO_, WK_, P2_, B_>),                \
+        EVE_LAUNCH("wgrad_tr_kernel<" #WCO_ ", " #WK_ ", " #P2_ ", mt" #MT_ ">", (wgrad_tr_kernel<WCO_, WK_, P2_, B_, MT_>), \
                    dim3((TK) * (TC) * splits), dim3(64 * WCO_ * WK_), lds_bytes(64 * WCO_, 64 * WK_), s, p, (const bf16_t*)x, \
                    (const bf16_t*)dy, dw, rows, (uint32_t)x_bytes, (uint32_t)dy_bytes, db);                               \
     } while (0)
-#define EVE_WGRAD_LAUNCH(WCO_, WK_, P2_, TK, TC)                                                                        \
+#define EVE_WGRAD_LAUNCH1(WCO_, WK_, P2_, MT_, TK, TC)                                                                  \
     do {                                                                                                                \
-        if (db) EVE_WGRAD_LAUNCH1(WCO_, WK_, P2_, true, TK, TC);                                                        \
-        else    EVE_WGRAD_LAUNCH1(WCO_, WK_, P2_, false, TK, TC);                                                       \
+        if (db) EVE_WGRAD_LAUNCH2(WCO_, WK_, P2_, true, MT_, TK, TC);                                                   \
+        else    EVE_WGRAD_LAUNCH2(WCO_, WK_, P2_, false, MT_, TK, TC);                                                  \
     } while (0)
+#define EVE_WGRAD_LAUNCH(WCO_, WK_, P2_, TK, TC) EVE_WGRAD_LAUNCH1(WCO_, WK_, P2_, 4, TK, TC)
             // address-decode mode of the gather (see wgrad_tr_kernel): both sizes powers of two / width only / neither
             const bool pow2w = (p.OW & (p.OW - 1)) == 0;
             const int mode = pow2 ? 1 : ((pow2w && p.OH * p.OW >= 32) ? 2 : 0);
@@ -743,11 +744,17 @@ static int launch_wgrad(const GatherParams& p, const void* x, const void* dy, co
                 const uint32_t tk = (p.K + 255) / 256, tc = 1;
                 wgrad_split(p, tk, tc, splits, rows);
                 if (mode == 1)      EVE_WGRAD_LAUNCH(1, 4, 1, tk, tc);
-                else if (mode == 2) EVE_WGRAD_LAUNCH(1, 4, 2, tk, tc);
+                else if (mode == 2) {
+                    // RefineNet's planes (72x128 .. 5x8); its outer levels have 16 / 32 output channels
+                    if (p.Cout <= 16)      EVE_WGRAD_LAUNCH1(1, 4, 2, 1, tk, tc);
+                    else if (p.Cout <= 32) EVE_WGRAD_LAUNCH1(1, 4, 2, 2, tk, tc);
+                    else                   EVE_WGRAD_LAUNCH(1, 4, 2, tk, tc);
+                }
                 else                EVE_WGRAD_LAUNCH(1, 4, 0, tk, tc);
             }
 #undef EVE_WGRAD_LAUNCH
 #undef EVE_WGRAD_LAUNCH1
+#undef EVE_WGRAD_LAUNCH2
             return db ? 1 : 0;                              // 1: the bias gradient has been taken care of
         }
     }

@@ -193,3 +193,73 @@ def test_refinenet_without_screen_content(golden_dir):
         net({}, out)
     np.testing.assert_allclose(out['heatmap_final'].numpy()[..., ::4, ::4],
                                fx['noscreen_heatmap_final'], atol=3e-6)
+
+
+# ---------------------------------------------------------------------------------------------- EVE sequence harness
+from oracle import eve as oracle_eve  # noqa: E402
+
+EVE_CASES = {
+    # tag: (training, config overrides on top of configs/refine_net.json with CGRU)
+    'c3': (True, {}),
+    'eval': (False, {}),
+    'joint': (True, dict(eye_net_frozen=False, loss_coeff_PoG_cm_initial=0.002, loss_coeff_g_ang_initial=1.0,
+                         loss_coeff_pupil_size=1.0, loss_coeff_heatmap_ce_initial=0.0, loss_coeff_heatmap_mse_final=0.5,
+                         loss_coeff_PoG_cm_final=0.01)),
+}
+
+
+def eve_cfg(**over):
+    return OracleConfig(os.path.join(REPO, 'configs', 'refine_net.json'), refine_net_rnn_type='CGRU',
+                        eye_net_load_pretrained=False, **over)
+
+
+def grad_norms(module):
+    return {n: (-1.0 if p.grad is None else float(p.grad.double().norm())) for n, p in module.named_parameters()}
+
+
+@pytest.mark.parametrize('tag', sorted(EVE_CASES))
+def test_eve_harness_matches_reference_eve(golden_dir, tag):
+    """oracle.eve.eve_forward against the reference's own models.eve.EVE run (tests/golden/make_golden_eve.py): label
+    synthesis, kappa draw order, gaze geometry, heat-maps, soft-argmax, all 29-31 loss/metric scalars, full_loss and the
+    gradients that reach both networks."""
+    fx = load(golden_dir, 'eve_harness.npz')
+    training, over = EVE_CASES[tag]
+    cfg = eve_cfg(**over)
+    B, T = int(fx['B']), int(fx['T'])
+    batch = detweights.eve_batch(B, T, seed=int(fx['seed']), invalid_fraction=float(fx['invalid_fraction']))
+    eye = detweights.fill_module(EyeNet(cfg), seed=0)
+    ref = detweights.fill_module(RefineNet(cfg), seed=1)
+    if cfg.eye_net_frozen:
+        for p in eye.parameters():
+            p.requires_grad = False
+    np.random.seed(0)                                       # the reference draws kappa from the global numpy RNG
+    out, inter, labels = oracle_eve.eve_forward(eye, ref, batch, cfg, training, create_images=(tag == 'eval'))
+    if training:
+        np.testing.assert_allclose(labels['left_kappa_fake'].numpy(), fx[tag + '_kappa_left'], atol=0, rtol=0)
+        np.testing.assert_allclose(labels['right_kappa_fake'].numpy(), fx[tag + '_kappa_right'], atol=0, rtol=0)
+    for k in ('g', 'PoG_px_tobii', 'PoG_cm_tobii', 'o'):
+        np.testing.assert_allclose(labels[k].numpy(), fx['%s_label_%s' % (tag, k)], atol=1e-4, rtol=1e-6)
+    np.testing.assert_allclose(labels['heatmap_final'].numpy()[..., ::4, ::4], fx[tag + '_label_heatmap_final'], atol=1e-6)
+    scalars = [k[len(tag) + 1:] for k in fx.files if k.startswith(tag + '_') and fx[k].ndim == 0
+               and ('loss' in k or 'metric' in k)]
+    assert len(scalars) >= 26 and set(scalars) == set(out.keys()), set(scalars) ^ set(out.keys())
+    for k in scalars:
+        np.testing.assert_allclose(float(out[k].detach()), float(fx['%s_%s' % (tag, k)]), rtol=2e-4, atol=1e-5, err_msg=k)
+    with torch.no_grad():
+        for k in ('g_initial', 'PoG_px_initial', 'PoG_cm_initial', 'g_final', 'PoG_px_final', 'PoG_cm_final',
+                  'left_g_initial', 'right_g_initial'):
+            tol = 2e-2 if 'px' in k else (2e-3 if 'cm' in k else 1e-5)        # px ~ 1e3, cm ~ 1e1, angles ~ 1
+            np.testing.assert_allclose(inter[k].numpy(), fx['%s_%s' % (tag, k)], atol=tol, rtol=0, err_msg=k)
+        np.testing.assert_allclose(inter['heatmap_initial'].numpy()[..., ::4, ::4], fx[tag + '_heatmap_initial'], atol=2e-5)
+        if tag == 'eval':
+            np.testing.assert_allclose(inter['history_initial_last'].numpy()[..., ::4, ::4], fx['eval_initial_gaze_history'], atol=2e-5)
+            np.testing.assert_allclose(inter['refined_gaze_history'].numpy()[..., ::4, ::4], fx['eval_refined_gaze_history'], atol=2e-5)
+    if training:
+        out['full_loss'].backward()
+        for net, mod in (('eye_net', eye), ('refine_net', ref)):
+            got = grad_norms(mod)
+            for n, want in zip(fx['%s_%s_grad_names' % (tag, net)], fx['%s_%s_grad_norms' % (tag, net)]):
+                if want < 0:
+                    assert got[str(n)] < 0, n
+                else:
+                    assert abs(got[str(n)] - want) <= 2e-3 * want + 1e-6, (n, got[str(n)], want)
