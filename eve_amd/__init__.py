@@ -4,11 +4,14 @@ kernels (libeve_hip.so, C ABI in include/eve_hip.h)."""
 from .config import HotPathConfig, get_config, reset_standalone_config  # noqa: F401
 from .eye_net import EyeNet  # noqa: F401
 
-__all__ = ['EyeNet', 'RefineNet', 'get_config', 'HotPathConfig', 'reset_standalone_config']
+__all__ = ['EyeNet', 'RefineNet', 'EVE', 'get_config', 'HotPathConfig', 'reset_standalone_config']
 
 
 def __getattr__(name):
     if name == 'RefineNet':
         from .refine_net import RefineNet
         return RefineNet
+    if name == 'EVE':
+        from .eve import EVE
+        return EVE
     raise AttributeError(name)

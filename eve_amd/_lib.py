@@ -48,6 +48,13 @@ SIGNATURES = {
     'eve_lstm_scan_bwd': [I, I, I, P, P, P, P, P, P, P, P, P, P, P],
     'eve_pack_weights_batch': [I, I, P, P],
     'eve_eye_losses': [I, I, P, P, P, P, P, P, F, F, P, P, P, P],
+    'eve_gaze_to_pog': [L, P, P, P, P, P, P, P, F, F, P, P, P, P, P],
+    'eve_gaze_to_pog_bwd': [L, P, P, P, P, P, P],
+    'eve_combined_gaze': [L, P, P, P, P, P, P],
+    'eve_make_heatmaps': [L, I, I, P, P, F, F, F, P, P],
+    'eve_make_heatmaps_bwd': [L, I, I, P, F, F, F, P, P, P],
+    'eve_soft_argmax_fwd': [L, I, I, P, F, F, P, P, P],
+    'eve_soft_argmax_bwd': [L, I, I, P, P, P, F, F, P, P],
     'eve_linear_fwd': [I, I, I, P, P, P, I, P, P],
     'eve_linear_dgrad': [I, I, I, P, P, I, P, P, P],
     'eve_linear_wgrad': [I, I, I, P, P, I, P, P, P, P],

@@ -228,6 +228,89 @@ class HipKernels(object):
             self._p(dy_pool2), self._p(y_pool), self._p(idx), self._p(dx), self._stream())))
         return dx
 
+    # ------------------------------------------------------------------ gaze geometry / heat-maps / soft-argmax
+    def _flat32(self, t, shape, what):
+        t = t.contiguous()
+        assert t.dtype == torch.float32 and tuple(t.shape) == tuple(shape), (what, t.dtype, tuple(t.shape), tuple(shape))
+        self._p(t)                                   # device check
+        return t
+
+    def gaze_to_pog(self, g, origin, R, inv_cam, ppm, screen, head_R=None, kappa=None):
+        """Flat N frames.  Returns (g_out [N,2], pog_mm [N,2], pog_px [N,2], jac [N,6,2])."""
+        N = g.shape[0]
+        g = self._flat32(g, (N, 2), 'g'); origin = self._flat32(origin, (N, 3), 'origin')
+        R = self._flat32(R, (N, 3, 3), 'R'); inv_cam = self._flat32(inv_cam, (N, 4, 4), 'inv_cam')
+        ppm = self._flat32(ppm, (N, 2), 'ppm')
+        if kappa is not None:
+            head_R = self._flat32(head_R, (N, 3, 3), 'head_R'); kappa = self._flat32(kappa, (N, 2), 'kappa')
+        new = lambda *s: torch.empty(s, dtype=torch.float32, device=g.device)
+        g_out, mm, px, jac = new(N, 2), new(N, 2), new(N, 2), new(N, 6, 2)
+        self._ck(self.lib.eve_gaze_to_pog(N, self._p(g), self._p(origin), self._p(R), self._p(inv_cam), self._p(ppm),
+                                          self._p(head_R if kappa is not None else None), self._p(kappa), float(screen[0]),
+                                          float(screen[1]), self._p(g_out), self._p(mm), self._p(px), self._p(jac), self._stream()))
+        return g_out, mm, px, jac
+
+    def gaze_to_pog_bwd(self, jac, dg_out, dmm, dpx):
+        N = jac.shape[0]
+        f = lambda t: None if t is None else self._flat32(t, (N, 2), 'grad')
+        dg_out, dmm, dpx = f(dg_out), f(dmm), f(dpx)
+        dg = torch.empty((N, 2), dtype=torch.float32, device=jac.device)
+        self._ck(self.lib.eve_gaze_to_pog_bwd(N, self._p(jac), self._p(dg_out), self._p(dmm), self._p(dpx), self._p(dg), self._stream()))
+        return dg
+
+    def combined_gaze(self, origin, pog_mm, R, cam):
+        N = origin.shape[0]
+        origin = self._flat32(origin, (N, 3), 'origin'); pog_mm = self._flat32(pog_mm, (N, 2), 'pog_mm')
+        R = self._flat32(R, (N, 3, 3), 'R'); cam = self._flat32(cam, (N, 4, 4), 'cam')
+        g = torch.empty((N, 2), dtype=torch.float32, device=origin.device)
+        self._ck(self.lib.eve_combined_gaze(N, self._p(origin), self._p(pog_mm), self._p(R), self._p(cam), self._p(g), self._stream()))
+        return g
+
+    def make_heatmaps(self, centres_px, sigma, hw, screen, validity=None):
+        """centres [N,2] px -> [N,1,H,W] float32 (x validity[n] when given)."""
+        N = centres_px.shape[0]
+        c = self._flat32(centres_px, (N, 2), 'centres')
+        v = None
+        if validity is not None:
+            v = validity.contiguous()
+            v = v.view(torch.uint8) if v.dtype == torch.bool else v.to(torch.uint8)
+            assert tuple(v.shape) == (N,)
+        out = torch.empty((N, 1, hw[0], hw[1]), dtype=torch.float32, device=c.device)
+        for i in range(0, N, 65535):
+            n = min(65535, N - i)
+            self._ck(self.lib.eve_make_heatmaps(n, hw[0], hw[1], self._p(c[i:i + n]), self._p(None if v is None else v[i:i + n]),
+                                                float(sigma), float(screen[0]), float(screen[1]), self._p(out[i:i + n]), self._stream()))
+        return out
+
+    def make_heatmaps_bwd(self, centres_px, sigma, screen, dout):
+        N, _, H, W = dout.shape
+        c = self._flat32(centres_px, (N, 2), 'centres')
+        dout = self._flat32(dout, (N, 1, H, W), 'dout')
+        dc = torch.empty((N, 2), dtype=torch.float32, device=c.device)
+        self._ck(self.lib.eve_make_heatmaps_bwd(N, H, W, self._p(c), float(sigma), float(screen[0]), float(screen[1]), self._p(dout),
+                                                self._p(dc), self._stream()))
+        return dc
+
+    def soft_argmax_fwd(self, heat, screen):
+        """heat [N,1,H,W] float32 -> (pog_px [N,2], stats [N,4])."""
+        N, _, H, W = heat.shape
+        heat = self._flat32(heat, (N, 1, H, W), 'heat')
+        px = torch.empty((N, 2), dtype=torch.float32, device=heat.device)
+        stats = torch.empty((N, 4), dtype=torch.float32, device=heat.device)
+        self._ck(self.lib.eve_soft_argmax_fwd(N, H, W, self._p(heat), float(screen[0]), float(screen[1]), self._p(px), self._p(stats),
+                                              self._stream()))
+        return px, stats
+
+    def soft_argmax_bwd(self, heat, stats, dpog, screen):
+        N, _, H, W = heat.shape
+        dpog = self._flat32(dpog, (N, 2), 'dpog')
+        dh = torch.empty_like(heat)
+        for i in range(0, N, 65535):
+            n = min(65535, N - i)
+            self._ck(self.lib.eve_soft_argmax_bwd(n, H, W, self._p(heat[i:i + n]), self._p(stats[i:i + n]), self._p(dpog[i:i + n]),
+                                                  float(screen[0]), float(screen[1]), self._p(dh[i:i + n]), self._stream()))
+        return dh
+
     # ------------------------------------------------------------------ fused train-step losses
     def eye_losses(self, g_pred, g_tgt, g_val, p_pred, p_tgt, p_val, coeff_ang, coeff_l1):
         """Each argument is a (left, right) pair.  Returns terms[5], (dg_l, dg_r), (dp_l, dp_r)."""

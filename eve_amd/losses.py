@@ -46,6 +46,10 @@ def mse_loss(pred, target, validity):
     return _masked_clip_mean(_per_step((pred - target) ** 2), validity)
 
 
+def euclidean_loss(pred, target, validity):                 # euclidean.py:27-33
+    return _masked_clip_mean(torch.sqrt(((pred - target) ** 2).flatten(2).sum(dim=2)), validity)
+
+
 def bce_loss(pred, target, validity):
     return _masked_clip_mean(_per_step(F.binary_cross_entropy(pred, target, reduction='none')), validity)
 

@@ -878,3 +878,58 @@ class CGRUGates2Fn(torch.autograd.Function):
         ru, h, o = ctx.saved_tensors
         dg2, dru, dh = default_kernels().cgru_gates2_bwd(dhnew.contiguous(), ru, h, o)
         return dg2, dru, dh
+
+
+# ---- gaze geometry / heat-maps / soft-argmax around the two networks (kernels in csrc/gaze_geometry.hip) -------------
+class GazeToPoGFn(torch.autograd.Function):
+    """(g_out, PoG_mm, PoG_px) of a flat batch of frames: to_screen_coordinates (models/common.py:157-187), after
+    apply_offset_augmentation (:190-229) when `kappa` is given.  Differentiable w.r.t. the gaze angles only (the other
+    inputs are data in EVE); the kernel returns the 2x2 Jacobians, so the backward is one tiny launch."""
+
+    @staticmethod
+    def forward(ctx, g, origin, R, inv_cam, ppm, screen, head_R, kappa):
+        g_out, mm, px, jac = default_kernels().gaze_to_pog(g, origin, R, inv_cam, ppm, screen, head_R, kappa)
+        ctx.save_for_backward(jac)
+        ctx.set_materialize_grads(False)
+        return g_out, mm, px
+
+    @staticmethod
+    def backward(ctx, dg_out, dmm, dpx):
+        jac, = ctx.saved_tensors
+        if dg_out is None and dmm is None and dpx is None:
+            return (None,) * 8
+        f = lambda t: None if t is None else t.contiguous()
+        return (default_kernels().gaze_to_pog_bwd(jac, f(dg_out), f(dmm), f(dpx)),) + (None,) * 7
+
+
+class MakeHeatmapsFn(torch.autograd.Function):
+    """Gaussian heat-maps [N,1,H,W] around centres [N,2] (px) -- models/common.py:236-255."""
+
+    @staticmethod
+    def forward(ctx, centres_px, sigma, hw, screen):
+        ctx.save_for_backward(centres_px)
+        ctx.args = (sigma, screen)
+        return default_kernels().make_heatmaps(centres_px, sigma, hw, screen)
+
+    @staticmethod
+    def backward(ctx, dout):
+        centres, = ctx.saved_tensors
+        sigma, screen = ctx.args
+        return default_kernels().make_heatmaps_bwd(centres, sigma, screen, dout.contiguous()), None, None, None
+
+
+class SoftArgmaxFn(torch.autograd.Function):
+    """PoG (px) [N,2] of heat-maps [N,1,H,W] -- models/common.py:304-333."""
+
+    @staticmethod
+    def forward(ctx, heat, screen):
+        heat = heat.contiguous()
+        px, stats = default_kernels().soft_argmax_fwd(heat, screen)
+        ctx.save_for_backward(heat, stats)
+        ctx.screen = screen
+        return px
+
+    @staticmethod
+    def backward(ctx, dpx):
+        heat, stats = ctx.saved_tensors
+        return default_kernels().soft_argmax_bwd(heat, stats, dpx.contiguous(), ctx.screen), None

@@ -121,6 +121,35 @@ int eve_eye_losses(int B, int T, const float* const* g_pred, const float* const*
                    const float* const* p_pred, const float* const* p_tgt, const uint8_t* const* p_val,
                    float coeff_ang, float coeff_l1, float* terms, float* const* dg, float* const* dp,
                    eve_stream_t stream);
+/* ------------------------------------------------------------------------------------------------
+ * Gaze geometry, heat-maps and soft-argmax: the per-frame glue of EVE.forward either side of the two networks
+ * (eve.py:114-166, 545-601).  Flat batches of N = B*T frames, float32, row-major small matrices.
+ * ------------------------------------------------------------------------------------------------ */
+/* to_screen_coordinates (models/common.py:157-187), optionally preceded by apply_offset_augmentation (:190-229) when
+ * kappa/head_R are given.  g [N][2] (pitch, yaw), origin [N][3] mm (camera frame), R [N][3][3], inv_cam [N][4][4],
+ * ppm [N][2] pixels per mm.  Outputs: g_out [N][2] (the augmented angles; optional without kappa), pog_mm [N][2],
+ * pog_px [N][2] clamped to [0, screen], jac [N][6][2] = d(g_out, pog_mm, pog_px) / d(pitch, yaw) for the backward. */
+int eve_gaze_to_pog(long long N, const float* g, const float* origin, const float* R, const float* inv_cam,
+                    const float* ppm, const float* head_R, const float* kappa, float screen_w, float screen_h,
+                    float* g_out, float* pog_mm, float* pog_px, float* jac, eve_stream_t stream);
+/* dg [N][2] = jac^T (dg_out, dmm, dpx); any of the three incoming gradients may be null.                       */
+int eve_gaze_to_pog_bwd(long long N, const float* jac, const float* dg_out, const float* dmm, const float* dpx,
+                        float* dg, eve_stream_t stream);
+/* calculate_combined_gaze_direction (common.py:136-154): g [N][2] from the mean eye origin to a screen point.     */
+int eve_combined_gaze(long long N, const float* origin, const float* pog_mm, const float* R, const float* cam,
+                      float* g, eve_stream_t stream);
+/* batch_make_heatmaps (common.py:236-255): out [N][H][W] = 1e-8 + exp(-|p - c|^2 / (2 sigma^2)), c = centre_px * (W/screen_w,
+ * H/screen_h); multiplied by validity[n] (bytes) when given (the label maps of eve.py:503-520).                  */
+int eve_make_heatmaps(long long N, int H, int W, const float* centres_px, const uint8_t* validity, float sigma,
+                      float screen_w, float screen_h, float* out, eve_stream_t stream);
+int eve_make_heatmaps_bwd(long long N, int H, int W, const float* centres_px, float sigma, float screen_w, float screen_h,
+                          const float* dout, float* dcentres, eve_stream_t stream);
+/* soft_argmax (common.py:304-333): pog_px [N][2] = clamp(screen * E_softmax(100 h)[(x/(W-1), y/(H-1))]); stats [N][4] =
+ * (lx, ly, max, sum exp) feed the backward.                                                                    */
+int eve_soft_argmax_fwd(long long N, int H, int W, const float* heat, float screen_w, float screen_h, float* pog_px,
+                        float* stats, eve_stream_t stream);
+int eve_soft_argmax_bwd(long long N, int H, int W, const float* heat, const float* stats, const float* dpog,
+                        float screen_w, float screen_h, float* dheat, eve_stream_t stream);
 /* db[C] (float, accumulated) += sum over the M = N*OH*OW rows of dy[M][C]                         */
 int eve_bias_grad(int dtype, long long M, int C, const void* dy, float* db, eve_stream_t stream);
 

@@ -372,3 +372,70 @@ class FakeKernels(object):
         bc1 = 1 - beta1 ** step
         bc2 = (1 - beta2 ** step) ** 0.5
         p.sub_((lr / bc1) * m / (v.sqrt() / bc2 + eps))
+
+
+# ---- gaze geometry / heat-maps / soft-argmax: CPU stand-ins built on the oracle's restatement (tests only) ----------
+def _install_geometry_fakes():
+    import types
+    from oracle import eve as oe
+    from oracle.config import OracleConfig
+
+    def cfg_for(hw, screen):
+        c = OracleConfig()
+        c.gaze_heatmap_size = [hw[1], hw[0]]
+        c.actual_screen_size = [screen[0], screen[1]]
+        return c
+
+    def gaze_to_pog(self, g, origin, R, inv_cam, ppm, screen, head_R=None, kappa=None):
+        N = g.shape[0]
+
+        def f(gi):
+            go = gi if kappa is None else oe.offset_augmentation(gi, head_R, kappa)
+            mm, px = oe.to_screen_coordinates(origin, go, R, inv_cam, ppm, screen)
+            return go, mm, px
+        jac = torch.zeros(N, 6, 2)
+        with torch.enable_grad():
+            gi = g.detach().clone().requires_grad_(True)
+            outs = f(gi)
+            for oi, o in enumerate(outs):
+                for c in range(2):
+                    if not o.requires_grad:
+                        continue
+                    gr, = torch.autograd.grad(o[:, c].sum(), gi, retain_graph=True, allow_unused=True)
+                    jac[:, 2 * oi + c] = 0 if gr is None else gr      # frames are independent: the sum separates them
+        return outs[0].detach(), outs[1].detach(), outs[2].detach(), jac
+
+    def gaze_to_pog_bwd(self, jac, dg_out, dmm, dpx):
+        dg = torch.zeros(jac.shape[0], 2)
+        for i, d in enumerate((dg_out, dmm, dpx)):
+            if d is not None:
+                dg += torch.einsum('ni,nij->nj', d, jac[:, 2 * i:2 * i + 2])
+        return dg
+
+    def combined_gaze(self, origin, pog_mm, R, cam):
+        return oe.combined_gaze_direction(origin, pog_mm, R, cam)
+
+    def make_heatmaps(self, centres_px, sigma, hw, screen, validity=None):
+        m = oe.make_heatmaps(centres_px, sigma, cfg_for(hw, screen))
+        return m if validity is None else m * validity.float().view(-1, 1, 1, 1)
+
+    def make_heatmaps_bwd(self, centres_px, sigma, screen, dout):
+        with torch.enable_grad():
+            c = centres_px.detach().clone().requires_grad_(True)
+            m = oe.make_heatmaps(c, sigma, cfg_for(dout.shape[2:], screen))
+            return torch.autograd.grad((m * dout).sum(), c)[0]
+
+    def soft_argmax_fwd(self, heat, screen):
+        return oe.soft_argmax(heat, cfg_for(heat.shape[2:], screen)), heat.new_zeros(heat.shape[0], 4)
+
+    def soft_argmax_bwd(self, heat, stats, dpog, screen):
+        with torch.enable_grad():
+            h = heat.detach().clone().requires_grad_(True)
+            px = oe.soft_argmax(h, cfg_for(heat.shape[2:], screen))
+            return torch.autograd.grad((px * dpog).sum(), h)[0]
+
+    for fn in (gaze_to_pog, gaze_to_pog_bwd, combined_gaze, make_heatmaps, make_heatmaps_bwd, soft_argmax_fwd, soft_argmax_bwd):
+        setattr(FakeKernels, fn.__name__, fn)
+
+
+_install_geometry_fakes()

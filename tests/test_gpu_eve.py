@@ -1,0 +1,192 @@
+"""GPU: the EVE sequence harness -- the gaze-geometry / heat-map / soft-argmax kernels against the
+oracle's restatement on seeded inputs, and eve_amd.EVE end to end against the golden fixture produced by the reference's
+own models.eve.EVE (tests/golden/make_golden_eve.py)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import eve_amd
+from eve_amd import kernels, ops
+from oracle import detweights
+from oracle import eve as oracle_eve
+from oracle.config import OracleConfig
+
+pytestmark = pytest.mark.gpu
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(REPO, 'tests', 'golden')
+
+
+@pytest.fixture(scope='module')
+def hip():
+    return kernels.default_kernels()
+
+
+def frames(N, seed):
+    """Flat geometry inputs of N frames from the synthetic clip generator."""
+    b = detweights.eve_batch(N, 1, seed=seed)
+    g = torch.Generator().manual_seed(seed)
+    return {'g': 0.4 * torch.randn(N, 2, generator=g), 'kappa': 0.05 * torch.randn(N, 2, generator=g),
+            'o': b['left_o'].reshape(N, 3), 'R': b['left_R'].reshape(N, 3, 3), 'head_R': b['head_R'].reshape(N, 3, 3),
+            'inv': b['inv_camera_transformation'].reshape(N, 4, 4), 'cam': b['camera_transformation'].reshape(N, 4, 4),
+            'ppm': b['pixels_per_millimeter'].reshape(N, 2)}
+
+
+@pytest.mark.parametrize('augment', [False, True], ids=['plain', 'kappa'])
+def test_gaze_to_pog_values_and_jacobians(hip, augment):
+    N, screen = 300, (1920, 1080)
+    f = frames(N, 11)
+    # a third of the rays are pushed off-screen so that the clamp (and its zero gradient) is exercised
+    f['g'][::3] *= 3.0
+    gi = f['g'].clone().requires_grad_(True)
+    go = oracle_eve.offset_augmentation(gi, f['head_R'], f['kappa']) if augment else gi
+    mm, px = oracle_eve.to_screen_coordinates(f['o'], go, f['R'], f['inv'], f['ppm'], screen)
+    c = lambda t: t.cuda()
+    got_g, got_mm, got_px, jac = hip.gaze_to_pog(c(f['g']), c(f['o']), c(f['R']), c(f['inv']), c(f['ppm']), screen,
+                                                 c(f['head_R']) if augment else None, c(f['kappa']) if augment else None)
+    assert float((got_g.cpu() - go.detach()).abs().max()) < 3e-5           # asin near +-1 (rays pushed to 1+ rad) is ill-conditioned
+    assert float((got_mm.cpu() - mm.detach()).abs().max()) < 2e-5 * float(mm.detach().abs().max())
+    assert float((got_px.cpu() - px.detach()).abs().max()) < 2e-2
+    assert 0.05 < float(((px.detach() == 0) | (px.detach()[:, :1] == 1920)).float().mean()) < 0.9
+    want = torch.zeros(N, 6, 2)
+    for oi, o in enumerate((go, mm, px)):
+        for comp in range(2):
+            if o.requires_grad and o.grad_fn is not None:
+                want[:, 2 * oi + comp] = torch.autograd.grad(o[:, comp].sum(), gi, retain_graph=True)[0]
+            else:
+                want[:, 2 * oi + comp, comp] = 1.0            # g_out is g itself
+    err = (jac.cpu() - want).abs()
+    assert float((err / (want.abs() + 1e-3 * want.abs().max())).max()) < 2e-3
+    # the backward kernel is the transposed product with those Jacobians
+    d = [torch.randn(N, 2) for _ in range(3)]
+    dg = hip.gaze_to_pog_bwd(jac, c(d[0]), c(d[1]), c(d[2])).cpu()
+    ref = sum(torch.einsum('ni,nij->nj', d[i], jac.cpu()[:, 2 * i:2 * i + 2]) for i in range(3))
+    assert float((dg - ref).abs().max()) <= 1e-5 * float(ref.abs().max())
+    only_mm = hip.gaze_to_pog_bwd(jac, None, c(d[1]), None).cpu()
+    assert float((only_mm - torch.einsum('ni,nij->nj', d[1], jac.cpu()[:, 2:4])).abs().max()) <= 1e-5 * float(ref.abs().max())
+
+
+def test_combined_gaze_direction(hip):
+    N = 257
+    f = frames(N, 12)
+    pog = torch.stack([torch.rand(N) * 553, torch.rand(N) * 311], dim=1)
+    want = oracle_eve.combined_gaze_direction(f['o'], pog, f['R'], f['cam'])
+    got = hip.combined_gaze(f['o'].cuda(), pog.cuda(), f['R'].cuda(), f['cam'].cuda()).cpu()
+    assert float((got - want).abs().max()) < 2e-6
+
+
+@pytest.mark.parametrize('sigma', [10.0, 3.0])
+def test_heatmaps_forward_validity_and_backward(hip, sigma):
+    cfg = OracleConfig()
+    N = 37
+    g = torch.Generator().manual_seed(3)
+    centres = torch.stack([torch.rand(N, generator=g) * 2200 - 100, torch.rand(N, generator=g) * 1300 - 100], dim=1)
+    valid = torch.rand(N, generator=g) > 0.3
+    ci = centres.clone().requires_grad_(True)
+    want = oracle_eve.make_heatmaps(ci, sigma, cfg)
+    got = hip.make_heatmaps(centres.cuda(), sigma, (72, 128), (1920, 1080)).cpu()
+    assert got.shape == (N, 1, 72, 128) and float((got - want.detach()).abs().max()) < 2e-6
+    masked = hip.make_heatmaps(centres.cuda(), sigma, (72, 128), (1920, 1080), validity=valid.cuda()).cpu()
+    assert float((masked - want.detach() * valid.float().view(-1, 1, 1, 1)).abs().max()) < 2e-6
+    dout = torch.randn(N, 1, 72, 128, generator=g)
+    wantd = torch.autograd.grad((want * dout).sum(), ci)[0]
+    gotd = hip.make_heatmaps_bwd(centres.cuda(), sigma, (1920, 1080), dout.cuda()).cpu()
+    assert float((gotd - wantd).abs().max()) <= 1e-4 * float(wantd.abs().max()) + 1e-7
+
+
+def test_soft_argmax_forward_and_backward(hip):
+    cfg = OracleConfig()
+    N = 29
+    g = torch.Generator().manual_seed(5)
+    centres = torch.stack([torch.rand(N, generator=g) * 1920, torch.rand(N, generator=g) * 1080], dim=1)
+    heat = oracle_eve.make_heatmaps(centres, 5.0, cfg) * 0.9 + 0.05 * torch.rand(N, 1, 72, 128, generator=g)
+    heat[0].zero_()                                               # flat map -> centre of the screen
+    heat[1, 0, 0, 0] = 5.0                                        # a spike in the corner: the clamp boundary
+    hi = heat.clone().requires_grad_(True)
+    want = oracle_eve.soft_argmax(hi, cfg)
+    got, stats = hip.soft_argmax_fwd(heat.cuda(), (1920, 1080))
+    assert float((got.cpu() - want.detach()).abs().max()) < 5e-2           # pixels on a 1920-wide screen, fp32 softmax
+    dp = torch.randn(N, 2, generator=g)
+    wantd = torch.autograd.grad((want * dp).sum(), hi)[0]
+    gotd = hip.soft_argmax_bwd(heat.cuda(), stats, dp.cuda(), (1920, 1080)).cpu()
+    assert float((gotd - wantd).abs().max()) <= 2e-4 * float(wantd.abs().max())
+
+
+# ---------------------------------------------------------------------------------------------- the module, end to end
+EVE_CASES = {
+    'c3': (True, {}),
+    'eval': (False, {}),
+    'joint': (True, dict(eye_net_frozen=False, loss_coeff_PoG_cm_initial=0.002, loss_coeff_g_ang_initial=1.0,
+                         loss_coeff_pupil_size=1.0, loss_coeff_heatmap_mse_final=0.5, loss_coeff_PoG_cm_final=0.01)),
+}
+
+
+def make_eve(over, dtype=torch.float32):
+    cfg = eve_amd.reset_standalone_config()
+    cfg.import_json(os.path.join(REPO, 'configs', 'refine_net.json'))
+    cfg.import_dict(dict(refine_net_rnn_type='CGRU', eye_net_load_pretrained=False, **over))
+    model = eve_amd.EVE(output_predictions=True)
+    model.eye_net.compute_dtype = dtype
+    model.refine_net.compute_dtype = dtype
+    detweights.fill_module(model.eye_net, 0)
+    detweights.fill_module(model.refine_net, 1)
+    return model.cuda()
+
+
+@pytest.mark.parametrize('tag', sorted(EVE_CASES))
+def test_eve_matches_reference_golden(tag):
+    """float32 instantiation of eve_amd.EVE on the GPU against the REFERENCE's EVE (fixture): every loss / metric scalar,
+    full_loss, gaze within 1e-4 rad, PoG, and per-parameter gradient norms of both networks."""
+    fx = np.load(os.path.join(GOLDEN, 'eve_harness.npz'))
+    training, over = EVE_CASES[tag]
+    model = make_eve(over)
+    model.train(training)
+    B, T = int(fx['B']), int(fx['T'])
+    batch = {k: v.cuda() for k, v in detweights.eve_batch(B, T, seed=int(fx['seed']),
+                                                          invalid_fraction=float(fx['invalid_fraction'])).items()}
+    np.random.seed(0)
+    out = model({'synthetic': batch} if training else batch, create_images=not training, current_epoch=0.0)
+    scalars = [k[len(tag) + 1:] for k in fx.files if k.startswith(tag + '_') and fx[k].ndim == 0 and ('loss' in k or 'metric' in k)]
+    assert set(scalars) == {k for k in out if k.startswith(('loss_', 'metric_', 'full_loss'))}
+    for k in scalars:
+        want = float(fx['%s_%s' % (tag, k)])
+        assert abs(float(out[k].detach()) - want) <= 5e-4 * abs(want) + 1e-4, (k, float(out[k].detach()), want)
+    for k in ('g_initial', 'g_final'):
+        assert np.abs(out[k].detach().cpu().numpy() - fx['%s_%s' % (tag, k)]).max() < 1e-4, k       # radians (north star)
+    for k, tol in (('PoG_px_initial', 0.05), ('PoG_cm_initial', 2e-3), ('PoG_px_final', 0.5), ('PoG_cm_final', 2e-2)):
+        assert np.abs(out[k].detach().cpu().numpy() - fx['%s_%s' % (tag, k)]).max() < tol, k
+    assert np.abs(batch['g'].cpu().numpy() - fx[tag + '_label_g']).max() < 1e-5
+    assert np.abs(batch['heatmap_final'].cpu().numpy()[..., ::4, ::4] - fx[tag + '_label_heatmap_final']).max() < 1e-5
+    if training:
+        assert np.array_equal(batch['left_kappa_fake'].cpu().numpy(), fx[tag + '_kappa_left'])
+        out['full_loss'].backward()
+        for net, mod in (('eye_net', model.eye_net), ('refine_net', model.refine_net)):
+            got = {n: (-1.0 if p.grad is None else float(p.grad.double().norm())) for n, p in mod.named_parameters()}
+            scale = max(float(w) for w in fx['%s_%s_grad_norms' % (tag, net)])
+            for n, want in zip(fx['%s_%s_grad_names' % (tag, net)], fx['%s_%s_grad_norms' % (tag, net)]):
+                if want < 0:
+                    assert got[str(n)] < 0, n
+                else:
+                    # (float32 MFMA summation order through ~40 layers, then softmax(100 h): a few per cent on single-tensor norms)
+                    assert abs(got[str(n)] - want) <= 3e-2 * want + 1e-5 * max(scale, 1.0), (n, got[str(n)], want)
+    else:
+        for k in ('initial_gaze_history', 'refined_gaze_history', 'initial_heatmap', 'final_heatmap', 'gt_heatmap'):
+            assert np.abs(out[k].detach().cpu().numpy()[..., ::4, ::4] - fx['eval_' + k]).max() < 2e-3, k
+    eve_amd.reset_standalone_config()
+
+
+def test_eve_bf16_train_step_tracks_float32():
+    """The bf16 instantiation (the one that is benchmarked): same harness, losses within bf16 noise of float32."""
+    res = {}
+    for dt in (torch.float32, torch.bfloat16):
+        model = make_eve(EVE_CASES['joint'][1], dtype=dt).train()
+        batch = {k: v.cuda() for k, v in detweights.eve_batch(2, 4, seed=2).items()}
+        np.random.seed(1)
+        out = model({'s': batch}, current_epoch=0.0)
+        out['full_loss'].backward()
+        res[dt] = {k: float(v.detach()) for k, v in out.items() if torch.is_tensor(v) and v.dim() == 0}
+        assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in model.refine_net.parameters())
+    for k, v in res[torch.float32].items():
+        assert abs(res[torch.bfloat16][k] - v) <= 0.08 * abs(v) + 0.05, (k, res[torch.bfloat16][k], v)
+    eve_amd.reset_standalone_config()

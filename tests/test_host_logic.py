@@ -304,3 +304,62 @@ def test_pixel_group_convolution_equals_plain_convolution(fake, monkeypatch, cin
         outs.append((y.detach().float(), x.grad.float(), wt.grad, b.grad))
     for a, c in zip(*outs):
         assert float((a - c).abs().max()) <= 2e-2 * float(c.abs().max()) + 1e-6
+
+
+EVE_CASES = {
+    'c3': (True, {}),
+    'eval': (False, {}),
+    'joint': (True, dict(eye_net_frozen=False, loss_coeff_PoG_cm_initial=0.002, loss_coeff_g_ang_initial=1.0,
+                         loss_coeff_pupil_size=1.0, loss_coeff_heatmap_mse_final=0.5, loss_coeff_PoG_cm_final=0.01)),
+}
+
+
+@pytest.mark.parametrize('tag', sorted(EVE_CASES))
+def test_eve_harness_host_logic_matches_oracle(fake, tag):
+    """eve_amd.EVE (batched schedule, kernels faked on CPU) against oracle.eve.eve_forward (the reference's per-frame
+    data flow): same label synthesis, kappa draws, every loss / metric scalar, full_loss, and the same gradients in
+    both networks -- including the path RefineNet -> heat-map -> PoG -> augmentation -> EyeNet of the joint case."""
+    from oracle import eve as oracle_eve
+    training, over = EVE_CASES[tag]
+    json_path = os.path.join(REPO, 'configs', 'refine_net.json')
+    cfg = eve_amd.reset_standalone_config()
+    cfg.import_json(json_path)
+    cfg.import_dict(dict(refine_net_rnn_type='CGRU', eye_net_load_pretrained=False, **over))
+    ocfg = OracleConfig(json_path, refine_net_rnn_type='CGRU', eye_net_load_pretrained=False, **over)
+    model = eve_amd.EVE(output_predictions=True)
+    detweights.fill_module(model.eye_net, 0); detweights.fill_module(model.refine_net, 1)
+    oeye, oref = detweights.fill_module(OracleEyeNet(ocfg), 0), detweights.fill_module(OracleRefineNet(ocfg), 1)
+    if ocfg.eye_net_frozen:
+        for p in oeye.parameters():
+            p.requires_grad = False
+    model.train(training)
+    batch = detweights.eve_batch(2, 3, seed=4, invalid_fraction=0.25)
+    np.random.seed(5)
+    want, winter, wlabels = oracle_eve.eve_forward(oeye, oref, dict(batch), ocfg, training, create_images=not training)
+    np.random.seed(5)
+    mine = dict(batch)
+    got = model({'src': mine} if training else mine, create_images=not training, current_epoch=0.0)
+    assert {k for k in got if k.startswith(('loss_', 'metric_'))} == set(want.keys()) - {'full_loss'}
+    for k, v in want.items():
+        assert abs(float(got[k].detach()) - float(v.detach())) <= 2e-4 * abs(float(v)) + 1e-5, (k, float(got[k]), float(v))
+    for k in ('g_initial', 'PoG_px_initial', 'PoG_cm_initial', 'g_final', 'PoG_px_final', 'PoG_cm_final'):
+        assert float((got[k] - winter[k]).abs().max()) < (0.1 if 'px' in k else 4e-3), k     # soft-argmax (beta 100) amplifies fp32 noise
+    for k in ('g', 'PoG_px_tobii', 'heatmap_final', 'heatmap_initial', 'o'):
+        assert float((mine[k] - wlabels[k]).abs().max()) < 1e-4, k
+    if training:
+        assert torch.equal(mine['left_kappa_fake'], wlabels['left_kappa_fake'])
+        got['full_loss'].backward(); want['full_loss'].backward()
+        for net, onet in ((model.eye_net, oeye), (model.refine_net, oref)):
+            ref = dict(onet.named_parameters())
+            for n, p in net.named_parameters():
+                if ref[n].grad is None:
+                    assert p.grad is None, n
+                else:
+                    a, b = p.grad.double(), ref[n].grad.double()
+                    # (biases in front of an InstanceNorm have a zero gradient: what both sides hold is rounding noise
+                    #  that scales with the loss)
+                    assert float((a - b).norm()) <= 3e-2 * float(b.norm()) + 1e-5 * max(1.0, float(want['full_loss'])), n
+    else:
+        assert float((got['initial_gaze_history'] - winter['history_initial_last']).abs().max()) < 1e-3
+        assert float((got['refined_gaze_history'] - winter['refined_gaze_history']).abs().max()) < 1e-3
+    eve_amd.reset_standalone_config()
