@@ -182,3 +182,15 @@ def refinenet_trainer(refine_net, config, distributed=False, use_graph=False):
         hf, _ = refine_net.forward_sequence(batch['heatmap_initial'], batch.get('screen_frame'))
         return losses.refinenet_loss_terms(hf, batch['heatmap_final_gt'], batch['validity'], config)
     return Trainer([refine_net], config, loss_fn, distributed=distributed, use_graph=use_graph)
+
+
+def eve_trainer(model, config, distributed=False, current_epoch=0.0):
+    """Train step of the whole EVE harness (eve.EVE): forward through both networks and the geometry / heat-map /
+    soft-argmax glue, every loss of eve.py:234-265, backward, clip, Adam on whichever network is trainable
+    (refine_net.json freezes EyeNet).  Eager only: the kappa draw (numpy RNG, as in the reference) happens on the host."""
+    modules = [m for m in (model.eye_net, model.refine_net)
+               if m is not None and any(p.requires_grad for p in m.parameters())]
+
+    def loss_fn(batch):
+        return model({'train': dict(batch)}, current_epoch=current_epoch)
+    return Trainer(modules, config, loss_fn, distributed=distributed)

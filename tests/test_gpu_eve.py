@@ -190,3 +190,21 @@ def test_eve_bf16_train_step_tracks_float32():
     for k, v in res[torch.float32].items():
         assert abs(res[torch.bfloat16][k] - v) <= 0.08 * abs(v) + 0.05, (k, res[torch.bfloat16][k], v)
     eve_amd.reset_standalone_config()
+
+
+def test_eve_trainer_steps_and_learns():
+    """A few optimiser steps of the C3 pipeline (EyeNet frozen) through train.eve_trainer: finite losses, RefineNet
+    weights move, EyeNet's do not, and the heat-map loss goes down on a repeated batch."""
+    from eve_amd import train
+    model = make_eve({}, dtype=torch.bfloat16).train()
+    cfg = eve_amd.get_config()
+    tr = train.eve_trainer(model, cfg)
+    batch = {k: v.cuda() for k, v in detweights.eve_batch(2, 4, seed=6).items()}
+    eye0 = model.eye_net.fc_common[0].weight.detach().clone()
+    ref0 = model.refine_net.final[0].weight.detach().clone()
+    np.random.seed(3)
+    hist = [float(tr.step(batch)['loss_ce_heatmap_final'].detach()) for _ in range(6)]
+    assert all(np.isfinite(hist)) and hist[-1] < hist[0], hist
+    assert torch.equal(eye0, model.eye_net.fc_common[0].weight.detach())
+    assert not torch.equal(ref0, model.refine_net.final[0].weight.detach())
+    eve_amd.reset_standalone_config()
