@@ -203,3 +203,33 @@ def test_bf16_deviation_is_bounded_and_reported():
               for s in ('left', 'right'))
     print('bf16 max gaze deviation vs reference fp32: %.4e rad' % dev)
     assert dev < 0.08, 'bf16 gaze deviation %.3e rad' % dev
+
+
+def test_256x256_patches_match_oracle_and_train_in_bf16():
+    """BASELINE configs[4]'s geometry: 256 x 256 eye patches (conv work x4, 128 x 128 stem output, 8 x 8 final planes).
+    float32 against the CPU oracle within the gaze tolerance, with gradients; then the bf16 instantiation (the stem goes
+    through the stand-alone 7x7 kernel + fused IN/ReLU/pool: the one-wave-per-image fused stem is 128 pixels wide)."""
+    from oracle.eye_net import EyeNet as OracleEyeNet
+    cfg = eye_cfg()
+    batch = detweights.eyenet_batch(1, 3, size=256, seed=9, invalid_fraction=0.2)
+    ref = detweights.fill_module(OracleEyeNet(cfg), seed=0)
+    rout = sequence.eyenet_sequence(ref, batch)
+    sequence.eyenet_losses(rout, batch, cfg)['full_loss'].backward()
+    net = make_net(torch.float32)
+    dbatch = to_dev(batch)
+    out = net.forward_sequence(dbatch)
+    for k in rout:
+        assert float((out[k].cpu() - rout[k]).abs().max()) < GAZE_TOL, k
+    sequence.eyenet_losses(out, dbatch, cfg)['full_loss'].backward()
+    rp = dict(ref.named_parameters())
+    for n, p in net.named_parameters():
+        a, b = p.grad.cpu().double(), rp[n].grad.double()
+        err = float((a - b).norm() / (b.norm() + 1e-12))
+        assert err <= 2e-2 or float((a - b).abs().max()) < 1e-5, '%s: rel L2 %.3e' % (n, err)
+    net16 = make_net(torch.bfloat16)
+    out16 = net16.forward_sequence(dbatch)
+    sequence.eyenet_losses(out16, dbatch, cfg)['full_loss'].backward()
+    dev = max(float((out16[s + '_g_initial'].float().cpu() - rout[s + '_g_initial']).abs().max()) for s in ('left', 'right'))
+    print('256x256 bf16 max gaze deviation vs oracle fp32: %.4e rad' % dev)
+    assert dev < 0.08
+    assert all(p.grad is not None and bool(torch.isfinite(p.grad).all()) for p in net16.parameters())
