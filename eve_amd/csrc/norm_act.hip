@@ -116,7 +116,8 @@ __global__ __launch_bounds__(256) void in_act_fwd_kernel(const T* __restrict__ x
 template <typename T, int ACT>
 __global__ __launch_bounds__(256) void in_act_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ y,
                                                          const T* __restrict__ x, const float* __restrict__ mr,
-                                                         const float* __restrict__ gamma, const int act_rt,
+                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                         const int act_rt,
                                                          T* __restrict__ dx, T* __restrict__ dres,
                                                          float* __restrict__ sums, int HW, int C) {
     constexpr int VEC = Elem<T>::VEC;
@@ -134,6 +135,14 @@ __global__ __launch_bounds__(256) void in_act_bwd_kernel(const T* __restrict__ d
 #pragma unroll
         for (int e = 0; e < VEC; ++e) { mean[e] = m[2 * e]; rstd[e] = m[2 * e + 1]; }
     }
+    // without a residual the forward output is act(x * za + zb) with exactly these za / zb (in_act_fwd_kernel), so
+    // act'(.) is recomputed from x instead of reading y: one tensor less in both passes
+    float za[VEC], zb[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+        za[e] = rstd[e]; zb[e] = -mean[e] * za[e];
+        if (gamma && beta) { const float gm = gamma[cvc * VEC + e]; za[e] *= gm; zb[e] = zb[e] * gm + beta[cvc * VEC + e]; }   // (used only when y is omitted)
+    }
     float s1[VEC], s2[VEC];
 #pragma unroll
     for (int e = 0; e < VEC; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
@@ -146,9 +155,9 @@ __global__ __launch_bounds__(256) void in_act_bwd_kernel(const T* __restrict__ d
             if (act != EVE_ACT_NONE) {
                 if (y) {
                     Elem<T>::unpack(*reinterpret_cast<const uint4*>(y + o), yy);
-                } else {            // no affine, no residual: y = act(xhat)
+                } else {
 #pragma unroll
-                    for (int e = 0; e < VEC; ++e) yy[e] = act_fwd((xx[e] - mean[e]) * rstd[e], act);
+                    for (int e = 0; e < VEC; ++e) yy[e] = act_fwd(xx[e] * za[e] + zb[e], act);
                 }
 #pragma unroll
                 for (int e = 0; e < VEC; ++e) g[e] *= act_grad_from_out(yy[e], act);
@@ -203,9 +212,9 @@ __global__ __launch_bounds__(256) void in_act_bwd_kernel(const T* __restrict__ d
             if (act != EVE_ACT_NONE) {
                 if (y) {
                     Elem<T>::unpack(*reinterpret_cast<const uint4*>(y + o), yy);
-                } else {            // no affine, no residual: y = act(xhat)
+                } else {
 #pragma unroll
-                    for (int e = 0; e < VEC; ++e) yy[e] = act_fwd((xx[e] - mean[e]) * rstd[e], act);
+                    for (int e = 0; e < VEC; ++e) yy[e] = act_fwd(xx[e] * za[e] + zb[e], act);
                 }
 #pragma unroll
                 for (int e = 0; e < VEC; ++e) g[e] *= act_grad_from_out(yy[e], act);
@@ -319,16 +328,16 @@ extern "C" int eve_instnorm_act_fwd(int dtype, int N, int HW, int C, const void*
 }
 
 extern "C" int eve_instnorm_act_bwd(int dtype, int N, int HW, int C, const void* dy, const void* y, const void* x,
-                                    const float* mean_rstd, const float* gamma, int act, void* dx, void* dres,
+                                    const float* mean_rstd, const float* gamma, const float* beta, int act, void* dx, void* dres,
                                     float* sums, eve_stream_t stream) {
     if (int e = check_plane(dtype, N, HW, C, "instnorm_act_bwd: bad shape")) return e;
-    if (!dy || !x || !mean_rstd || !dx || (act != EVE_ACT_NONE && !y && gamma))
-        return set_error_msg("instnorm_act_bwd: null pointer");
+    if (!dy || !x || !mean_rstd || !dx || (act != EVE_ACT_NONE && !y && gamma && !beta) || (dres && act != EVE_ACT_NONE && !y))
+        return set_error_msg("instnorm_act_bwd: null pointer (y is required with a residual, beta with gamma when y is omitted)");
     hipStream_t s = (hipStream_t)stream;
     if (dtype == EVE_DT_BF16)
-        EVE_IN_ACT_DISPATCH(in_act_bwd_kernel, bf16_t, dim3(N), (const bf16_t*)dy, (const bf16_t*)y, (const bf16_t*)x, mean_rstd, gamma, act, (bf16_t*)dx, (bf16_t*)dres, sums, HW, C);
+        EVE_IN_ACT_DISPATCH(in_act_bwd_kernel, bf16_t, dim3(N), (const bf16_t*)dy, (const bf16_t*)y, (const bf16_t*)x, mean_rstd, gamma, beta, act, (bf16_t*)dx, (bf16_t*)dres, sums, HW, C);
     else
-        EVE_IN_ACT_DISPATCH(in_act_bwd_kernel, float, dim3(N), (const float*)dy, (const float*)y, (const float*)x, mean_rstd, gamma, act, (float*)dx, (float*)dres, sums, HW, C);
+        EVE_IN_ACT_DISPATCH(in_act_bwd_kernel, float, dim3(N), (const float*)dy, (const float*)y, (const float*)x, mean_rstd, gamma, beta, act, (float*)dx, (float*)dres, sums, HW, C);
     EVE_CHECK_LAUNCH();
     return 0;
 }

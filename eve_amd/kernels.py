@@ -396,13 +396,15 @@ class HipKernels(object):
                                                self._p(y), self._stream()))
         return y
 
-    def instnorm_act_bwd(self, dy, y, x, mr, gamma, act, want_dres):
+    def instnorm_act_bwd(self, dy, y, x, mr, gamma, act, want_dres, beta=None):
+        """y may be None when the forward had no residual (beta is then needed next to gamma)."""
         N, H, W, C = x.shape
         dx = torch.empty_like(x)
         dres = torch.empty_like(x) if want_dres else None
         sums = torch.empty((N, C, 2), dtype=torch.float32, device=x.device)
         self._ck(self.lib.eve_instnorm_act_bwd(dt_code(x.dtype), N, H * W, C, self._p(dy), self._p(y),
                                                self._p(x), self._p(mr), self._p(self._f32(gamma, 'gamma')),
+                                               self._p(self._f32(beta, 'beta')),
                                                act, self._p(dx), self._p(dres), self._p(sums),
                                                self._stream()))
         return dx, dres, sums

@@ -531,19 +531,22 @@ class InstNormActFn(torch.autograd.Function):
             mr = k.instnorm_stats(x, eps)
             y = k.instnorm_act_fwd(x, mr, g, b, res, act)
         ctx.act, ctx.has_res, ctx.has_affine = act, res is not None, gamma is not None
-        # the backward needs y only to evaluate act'; without affine/residual it recomputes that from x
-        need_y = act != ACT_NONE and (res is not None or gamma is not None)
-        ctx.save_for_backward(x, y if need_y else None, mr, g)
+        # the backward needs y only to evaluate act'; without a residual it recomputes that from x (the register-resident
+        # kernel does so only when there is no affine either)
+        need_y = act != ACT_NONE and (res is not None or (gamma is not None and fused is not None))
+        ctx.save_for_backward(x, y if need_y else None, mr, g, b)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         k = default_kernels()
-        x, y, mr, g = ctx.saved_tensors
+        x, y, mr, g, b = ctx.saved_tensors
         want_dres = ctx.has_res and ctx.needs_input_grad[3]
-        out = k.instnorm_bwd_fused(dy.contiguous(), y, x, mr, g, ctx.act, want_dres)
+        out = None
+        if y is not None or ctx.act == ACT_NONE or g is None:
+            out = k.instnorm_bwd_fused(dy.contiguous(), y, x, mr, g, ctx.act, want_dres)
         if out is None:
-            out = k.instnorm_act_bwd(dy.contiguous(), y, x, mr, g, ctx.act, want_dres)
+            out = k.instnorm_act_bwd(dy.contiguous(), y, x, mr, g, ctx.act, want_dres, beta=b)
         dx, dres, sums = out
         dgamma = dbeta = None
         if ctx.has_affine:

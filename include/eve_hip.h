@@ -168,9 +168,10 @@ int eve_instnorm_act_fwd(int dtype, int N, int HW, int C, const void* x, const f
                          eve_stream_t stream);
 /* g = dy * act'(y);  dx = gamma*rstd*(g - mean_hw(g) - xhat*mean_hw(g*xhat));  dres = g (if != NULL);
  * sums[n][c] = (sum_hw g, sum_hw g*xhat)  (reduce over n for dbeta / dgamma).
- * y may be NULL when there was neither affine nor residual: act'(.) is then recomputed from x (one read less). */
+ * y may be NULL when there was no residual: act'(.) is then recomputed from x with the forward's own scale / shift
+ * (beta is needed for that when gamma is given) -- one tensor less to read in both passes.                    */
 int eve_instnorm_act_bwd(int dtype, int N, int HW, int C, const void* dy, const void* y,
-                         const void* x, const float* mean_rstd, const float* gamma, int act,
+                         const void* x, const float* mean_rstd, const float* gamma, const float* beta, int act,
                          void* dx, void* dres, float* sums, eve_stream_t stream);
 
 /* Single-pass variants for planes that fit one workgroup's registers (HW*C <= 64 Ki elements): statistics and

@@ -134,12 +134,15 @@ class FakeKernels(object):
             z = z + res.float()
         return act_fwd(z, act).to(x.dtype)
 
-    def instnorm_act_bwd(self, dy, y, x, mr, gamma, act, want_dres):
+    def instnorm_act_bwd(self, dy, y, x, mr, gamma, act, want_dres, beta=None):
         g = dy.float()
         if act != ACT_NONE:
             if y is None:
-                assert gamma is None
-                y = act_fwd((x.float() - mr[:, None, None, :, 0]) * mr[:, None, None, :, 1], act)
+                assert not want_dres and (gamma is None) == (beta is None)
+                z = (x.float() - mr[:, None, None, :, 0]) * mr[:, None, None, :, 1]
+                if gamma is not None:
+                    z = z * gamma + beta
+                y = act_fwd(z, act)
             g = g * act_grad_from_out(y.float(), act)
         xhat = (x.float() - mr[:, None, None, :, 0]) * mr[:, None, None, :, 1]
         s1 = g.sum(dim=(1, 2))

@@ -294,9 +294,10 @@ def test_instnorm_fwd_bwd(hip, ref, dtype, shape):
             if r is None and g is None and act != 0:       # act' recomputed from x instead of reading y
                 fb2 = hip.instnorm_bwd_fused(dev(dy), None, dev(x), dev(mr_w), None, act, False)
                 close(fb2[0], dx_w, dtype, 'fused instnorm bwd dx without y', scale=float(dx_w.abs().max()) + 0.05)
-        if r is None and g is None and act != 0:
-            dx2 = hip.instnorm_act_bwd(dev(dy), None, dev(x), dev(mr_w), None, act, False)[0]
+        if r is None and act != 0:                         # act' recomputed from x (with the affine scale / shift)
+            dx2, _, s2 = hip.instnorm_act_bwd(dev(dy), None, dev(x), dev(mr_w), dev(g), act, False, beta=dev(b))
             close(dx2, dx_w, dtype, 'instnorm_act bwd dx without y', scale=float(dx_w.abs().max()) + 0.05)
+            close(s2, s_w, torch.float32, 'instnorm_act bwd sums without y', scale=float(s_w.abs().max()) * 4)
 
 
 @pytest.mark.parametrize('dtype', DTYPES, ids=['f32', 'bf16'])
