@@ -36,6 +36,8 @@ SIGNATURES = {
     'eve_conv2d_wgrad': [POINTER(ConvDesc), P, P, P, I, P, P],
     'eve_conv2d_wgrad_bias': [POINTER(ConvDesc), P, P, P, P, P],
     'eve_stem_pack_input': [I, I, I, I, P, P, P],
+    'eve_frames_u8_to_nchw': [L, I, I, I, P, F, F, I, P, P],
+    'eve_frames_u8_to_stem': [L, I, I, I, P, F, F, P, P],
     'eve_stem7x7s2_fwd': [I, I, I, P, P, P, P],
     'eve_stem_fwd_fused': [I, I, I, P, P, F, P, P, P, P],
     'eve_stem_wgrad': [I, I, I, P, P, P, P],

@@ -141,3 +141,75 @@ extern "C" int eve_stem7x7s2_fwd(int N, int IH, int IW, const void* x_padded, co
     EVE_CHECK_LAUNCH();
     return 0;
 }
+
+// -------------------------------------------------------------------------------------------------
+// Decoded video frames on the device.  The reference normalises uint8 N x H x W x C frames on the
+// host -- astype(float32); *= 2/255; -= 1 for eye patches, *= 1/255 for screen frames, transposed to N x C x H x W
+// (/root/reference/src/datasources/eve_sequences.py:196-211) -- and ships the float tensors over PCIe
+// (src/core/training.py:257-261): 4x the bytes of the frames themselves.  Same arithmetic here (one rounded multiply,
+// one rounded add: no fused multiply-add, so the float values are bit-identical to numpy's), from the uint8 frames:
+//   frames_u8_to_nchw_kernel   the reference's float N x C x H x W tensor
+//   frames_u8_to_stem_kernel   straight to the stem kernels' packed bf16 [N][IH+6][IW+8][4] input (eye patches)
+// -------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float normalise_u8(uint8_t v, float scale, float shift, bool has_shift) {
+#pragma clang fp contract(off)          // hipcc contracts a * b + c into one fma by default: 255 * fl(2/255) - 1 would be 1 + 2^-23
+    const float f = (float)v * scale;
+    return has_shift ? f + shift : f;
+}
+
+__global__ __launch_bounds__(256) void frames_u8_to_nchw_kernel(const uint8_t* __restrict__ src, float* __restrict__ dst, int C, int H,
+                                                                int W, float scale, float shift, bool has_shift, long long items) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < items; i += (long long)gridDim.x * 256) {
+        const int x = (int)(i % W);
+        long long t = i / W;
+        const int y = (int)(t % H); t /= H;
+        const int c = (int)(t % C);
+        const long long n = t / C;
+        dst[i] = normalise_u8(src[((n * H + y) * W + x) * C + c], scale, shift, has_shift);
+    }
+}
+
+__global__ __launch_bounds__(256) void frames_u8_to_stem_kernel(const uint8_t* __restrict__ src, uint2* __restrict__ dst, int C, int IH,
+                                                                int IW, float scale, float shift, long long items) {
+    const int IHp = IH + 6, IWp = IW + 8;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < items; i += (long long)gridDim.x * 256) {
+        const int xp = (int)(i % IWp);
+        long long t = i / IWp;
+        const int yp = (int)(t % IHp);
+        const long long n = t / IHp;
+        const int x = xp - 4, y = yp - 3;
+        uint2 q = make_uint2(0u, 0u);
+        if (x >= 0 && x < IW && y >= 0 && y < IH) {
+            float f[4] = {0.f, 0.f, 0.f, 0.f};
+            const uint8_t* p = src + ((n * IH + y) * IW + x) * C;
+            for (int c = 0; c < C && c < 4; ++c) f[c] = normalise_u8(p[c], scale, shift, true);
+            q.x = pack2_bf16(f[0], f[1]);
+            q.y = pack2_bf16(f[2], f[3]);
+        }
+        dst[i] = q;
+    }
+}
+
+extern "C" int eve_frames_u8_to_nchw(long long N, int H, int W, int C, const uint8_t* src_nhwc, float scale, float shift,
+                                     int has_shift, float* dst_nchw, eve_stream_t stream) {
+    if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || !src_nhwc || !dst_nchw) return set_error_msg("frames_u8_to_nchw: bad arguments");
+    const long long items = N * C * H * W;
+    long long blocks = (items + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(frames_u8_to_nchw_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, src_nhwc, dst_nchw, C, H, W,
+                       scale, shift, has_shift != 0, items);
+    EVE_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int eve_frames_u8_to_stem(long long N, int C, int IH, int IW, const uint8_t* src_nhwc, float scale, float shift,
+                                     void* x_padded, eve_stream_t stream) {
+    if (N <= 0 || C <= 0 || C > 4 || IH <= 0 || IW <= 0 || !src_nhwc || !x_padded) return set_error_msg("frames_u8_to_stem: bad arguments");
+    const long long items = N * (IH + 6) * (IW + 8);
+    long long blocks = (items + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(frames_u8_to_stem_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, src_nhwc, (uint2*)x_padded, C,
+                       IH, IW, scale, shift, items);
+    EVE_CHECK_LAUNCH();
+    return 0;
+}

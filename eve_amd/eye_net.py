@@ -259,10 +259,24 @@ class EyeNet(nn.Module):
         P = self._get_packs()
         dt = self.compute_dtype
         left, right = batch['left_eye_patch'], batch['right_eye_patch']
-        B, T, C, Hh, Ww = left.shape
-        cpad = pad_channels(C, dt)
         x = x_padded = None
-        if dt == torch.bfloat16 and C <= 4 and Hh % 4 == 0 and Ww == 128:          # fused stem: packed patches only
+        if left.dtype == torch.uint8:
+            # decoded frames [B, T, H, W, C] (eve_sequences.py:196-203 not applied yet): normalise on the device --
+            # straight into the stem's packed layout when the fused stem takes it, else to the reference's float NCHW
+            from . import data
+            B, T, Hh, Ww, C = left.shape
+            if dt == torch.bfloat16 and C <= 4 and Hh % 4 == 0 and Ww == 128:
+                x_padded = torch.empty((2 * B * T, Hh + 6, Ww + 8, 4), dtype=dt, device=left.device)
+                k.frames_u8_to_stem(left.reshape(B * T, Hh, Ww, C), data.EYE_SCALE, data.EYE_SHIFT, out=x_padded[:B * T])
+                k.frames_u8_to_stem(right.reshape(B * T, Hh, Ww, C), data.EYE_SCALE, data.EYE_SHIFT, out=x_padded[B * T:])
+            else:
+                left, right = data.preprocess_frames(left), data.preprocess_frames(right)
+        if x_padded is None:
+            B, T, C, Hh, Ww = left.shape
+        cpad = pad_channels(C, dt)
+        if x_padded is not None:                                                   # packed from the uint8 frames above
+            pass
+        elif dt == torch.bfloat16 and C <= 4 and Hh % 4 == 0 and Ww == 128:        # fused stem: packed patches only
             x_padded = torch.empty((2 * B * T, Hh + 6, Ww + 8, 4), dtype=dt, device=left.device)
             k.stem_pack_input(left.reshape(B * T, C, Hh, Ww), out=x_padded[:B * T])
             k.stem_pack_input(right.reshape(B * T, C, Hh, Ww), out=x_padded[B * T:])

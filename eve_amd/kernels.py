@@ -228,6 +228,25 @@ class HipKernels(object):
             self._p(dy_pool2), self._p(y_pool), self._p(idx), self._p(dx), self._stream())))
         return dx
 
+    # ------------------------------------------------------------------ decoded uint8 frames (input pipeline)
+    def frames_u8_to_nchw(self, frames, scale, shift=None):
+        """uint8 [N,H,W,C] -> float32 [N,C,H,W] = frames * scale (+ shift)."""
+        N, H, W, C = frames.shape
+        assert frames.dtype == torch.uint8
+        out = torch.empty((N, C, H, W), dtype=torch.float32, device=frames.device)
+        self._ck(self.lib.eve_frames_u8_to_nchw(N, H, W, C, self._p(frames), float(scale), float(shift or 0.0),
+                                                0 if shift is None else 1, self._p(out), self._stream()))
+        return out
+
+    def frames_u8_to_stem(self, frames, scale, shift, out=None):
+        """uint8 [N,H,W,C<=4] -> the stem's packed bf16 input [N,H+6,W+8,4]."""
+        N, H, W, C = frames.shape
+        assert frames.dtype == torch.uint8
+        dst = out if out is not None else torch.empty((N, H + 6, W + 8, 4), dtype=torch.bfloat16, device=frames.device)
+        assert tuple(dst.shape) == (N, H + 6, W + 8, 4) and dst.dtype == torch.bfloat16
+        self._ck(self.lib.eve_frames_u8_to_stem(N, C, H, W, self._p(frames), float(scale), float(shift), self._p(dst), self._stream()))
+        return dst
+
     # ------------------------------------------------------------------ gaze geometry / heat-maps / soft-argmax
     def _flat32(self, t, shape, what):
         t = t.contiguous()

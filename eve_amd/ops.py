@@ -126,10 +126,24 @@ def _direct_grad_ok(p):
     return getattr(p, '_eve_flat_grad', False) and p.grad is not None and p.requires_grad
 
 
+def _note_use(p, wanted):
+    """A parameter whose gradient is written in place can be used several times per step (the per-frame contract: one
+    Conv2dFn per time step).  Count the uses whose backward will run, so that the data-parallel bookkeeping is told
+    only when the LAST of them has accumulated (an all-reduce launched after the first would ship a partial sum)."""
+    if p is not None and wanted and getattr(p, '_eve_grad_ready', None) is not None:
+        p._eve_pending_uses = getattr(p, '_eve_pending_uses', 0) + 1
+
+
 def _notify_grad_ready(p):
     cb = getattr(p, '_eve_grad_ready', None)        # data-parallel bucket bookkeeping (parallel.GradSync)
-    if cb is not None:
-        cb(p)
+    if cb is None:
+        return
+    n = getattr(p, '_eve_pending_uses', 0)
+    if n > 1:                                       # more backward passes of this parameter are still to come
+        p._eve_pending_uses = n - 1
+        return
+    p._eve_pending_uses = 0
+    cb(p)
 
 
 class Conv2dFn(torch.autograd.Function):
@@ -160,6 +174,8 @@ class Conv2dFn(torch.autograd.Function):
         # parameters re-homed by train.FlatParameters take their gradient straight into the flat buffer
         ctx.w_direct = weight if _direct_grad_ok(weight) else None
         ctx.b_direct = bias if (bias is not None and _direct_grad_ok(bias)) else None
+        _note_use(ctx.w_direct, ctx.needs_input_grad[1])
+        _note_use(ctx.b_direct, ctx.needs_input_grad[2])
         ctx.save_for_backward(x, y if epi_act != ACT_NONE else None)
         return y
 
@@ -288,6 +304,8 @@ class LinearFn(torch.autograd.Function):
         ctx.wshape = tuple(weight.shape)
         ctx.w_direct = weight if _direct_grad_ok(weight) else None
         ctx.b_direct = bias if (bias is not None and _direct_grad_ok(bias)) else None
+        _note_use(ctx.w_direct, ctx.needs_input_grad[1])
+        _note_use(ctx.b_direct, ctx.needs_input_grad[2])
         ctx.save_for_backward(x, y if act != ACT_NONE else None)
         return y
 

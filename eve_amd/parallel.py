@@ -76,6 +76,8 @@ class GradSync(object):
         for b in self.buckets:
             b['pending'] = sum(1 for p in b['params'] if p.requires_grad)
             b['launched'] = False
+            for p in b['params']:
+                p._eve_pending_uses = 0            # ops._note_use counts this step's uses from zero
         self._handles = []
         self._seen = set()
         self._armed = True

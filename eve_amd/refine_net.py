@@ -293,6 +293,9 @@ class RefineNet(nn.Module):
         list over cells of the stacked states [B,T,C,5,8] (tuple of two for CLSTM))."""
         P = self._get_packs()
         B, T = heatmap_initial.shape[:2]
+        if screen_frame is not None and screen_frame.dtype == torch.uint8:     # decoded frames [B,T,H,W,3]: normalise here
+            from . import data
+            screen_frame = data.preprocess_screen_frames(screen_frame)
         fold = lambda t: None if t is None else t.reshape((B * T,) + tuple(t.shape[2:]))
         x = self._input_nhwc(fold(heatmap_initial), fold(screen_frame) if self.config.load_screen_content else None)
         x, skips, prefix = self._encode(x, P)

@@ -88,6 +88,15 @@ int eve_stem_pack_input(int N, int C, int IH, int IW, const float* src_nchw, voi
                         eve_stream_t stream);
 int eve_stem7x7s2_fwd(int N, int IH, int IW, const void* x_padded, const void* w_ohwi8, void* y,
                       eve_stream_t stream);
+/* Decoded uint8 frames on the device (datasources/eve_sequences.py:196-211 does this on the host and ships floats):
+ * dst[n][c][y][x] (float) = src[n][y][x][c] * scale (+ shift): eye patches scale 2/255, shift -1; screen frames
+ * scale 1/255, no shift.  One rounded multiply and one rounded add, bit-identical to the numpy expressions.      */
+int eve_frames_u8_to_nchw(long long N, int H, int W, int C, const uint8_t* src_nhwc, float scale, float shift,
+                          int has_shift, float* dst_nchw, eve_stream_t stream);
+/* ... and the same values straight into the stem kernels' packed input x_padded [N][IH+6][IW+8][4] bf16 (what
+ * eve_stem_pack_input builds from the float NCHW tensor).                                                      */
+int eve_frames_u8_to_stem(long long N, int C, int IH, int IW, const uint8_t* src_nhwc, float scale, float shift,
+                          void* x_padded, eve_stream_t stream);
 /* The whole stem in one launch: conv1 -> bn1 (InstanceNorm2d, no affine) -> relu -> maxpool 3x3/2 pad 1
  * (torchvision ResNet._forward_impl as built by eye_net.py:48-50).  The 64-channel convolution output is never
  * written: y_pool [N][IH/4][IW/4][64] bf16, idx (window position kh*3+kw of the arg-max, same shape, uint8) and

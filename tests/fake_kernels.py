@@ -442,3 +442,18 @@ def _install_geometry_fakes():
 
 
 _install_geometry_fakes()
+
+
+def _install_frame_fakes():
+    def frames_u8_to_nchw(self, frames, scale, shift=None):
+        out = frames.permute(0, 3, 1, 2).float() * torch.tensor(scale, dtype=torch.float32)
+        return out if shift is None else out + torch.tensor(shift, dtype=torch.float32)
+
+    def frames_u8_to_stem(self, frames, scale, shift, out=None):
+        return self.stem_pack_input(frames_u8_to_nchw(self, frames, scale, shift), out=out)
+
+    FakeKernels.frames_u8_to_nchw = frames_u8_to_nchw
+    FakeKernels.frames_u8_to_stem = frames_u8_to_stem
+
+
+_install_frame_fakes()

@@ -233,3 +233,33 @@ def test_256x256_patches_match_oracle_and_train_in_bf16():
     print('256x256 bf16 max gaze deviation vs oracle fp32: %.4e rad' % dev)
     assert dev < 0.08
     assert all(p.grad is not None and bool(torch.isfinite(p.grad).all()) for p in net16.parameters())
+
+
+def test_uint8_clips_through_the_prefetcher_equal_the_float_path():
+    """Input pipeline: uint8 [B,T,H,W,C] clips staged through pinned memory on the copy stream
+    (data.DevicePrefetcher) and normalised on the device give bit-identical EyeNet outputs to the reference-style float
+    batches, in float32 and in bf16 (where the frames go straight into the stem's packed layout)."""
+    from eve_amd import data
+    from oracle import frames as oframes
+    g = np.random.Generator(np.random.PCG64(21))
+    host = []
+    for _ in range(3):
+        b = {s + '_eye_patch': torch.from_numpy(g.integers(0, 256, size=(2, 3, 128, 128, 3), dtype=np.uint8)) for s in ('left', 'right')}
+        b.update({s + '_h': torch.from_numpy(g.normal(0, 0.1, size=(2, 3, 2)).astype(np.float32)) for s in ('left', 'right')})
+        b['tag'] = 'clip'
+        host.append(b)
+    for dt in (torch.float32, torch.bfloat16):
+        net = make_net(dt)
+        seen = 0
+        with torch.no_grad():
+            for dev_batch, hb in zip(data.DevicePrefetcher(host), host):
+                assert dev_batch['tag'] == 'clip' and dev_batch['left_eye_patch'].is_cuda and dev_batch['left_eye_patch'].dtype == torch.uint8
+                ref = dict(dev_batch)
+                for s in ('left', 'right'):
+                    f = oframes.preprocess_frames(hb[s + '_eye_patch'].numpy().reshape(6, 128, 128, 3))
+                    ref[s + '_eye_patch'] = torch.from_numpy(f).view(2, 3, 3, 128, 128).cuda()
+                a, b = net.forward_sequence(dev_batch), net.forward_sequence(ref)
+                for k in ('left_g_initial', 'right_g_initial', 'left_pupil_size'):
+                    assert torch.equal(a[k], b[k]), (dt, k)
+                seen += 1
+        assert seen == 3

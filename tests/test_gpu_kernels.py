@@ -463,3 +463,21 @@ def test_adam_and_sumsq(hip, ref):
     close(pg, pw, torch.float32, 'adam p')
     close(mg, mw, torch.float32, 'adam m')
     close(vg, vw, torch.float32, 'adam v')
+
+
+def test_uint8_frame_normalisation_is_bit_identical_to_the_reference(hip):
+    """eve_frames_u8_to_nchw / _to_stem against the fixture produced by the reference's own preprocess_frames /
+    preprocess_screen_frames (tests/golden/make_golden_frames.py): every uint8 value, both scalings, bit for bit."""
+    import os
+    import numpy as np
+    fx = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'frames.npz'))
+    for key in ('ramp', 'frames'):
+        u8 = torch.from_numpy(fx[key]).cuda()
+        assert np.array_equal(hip.frames_u8_to_nchw(u8, 2.0 / 255.0, -1.0).cpu().numpy(), fx[key + '_eye'])
+        assert np.array_equal(hip.frames_u8_to_nchw(u8, 1.0 / 255.0, None).cpu().numpy(), fx[key + '_screen'])
+    # packed stem input from uint8 == packed stem input from the reference's float tensor
+    g = np.random.Generator(np.random.PCG64(3))
+    u8 = torch.from_numpy(g.integers(0, 256, size=(5, 32, 128, 3), dtype=np.uint8)).cuda()
+    want = hip.stem_pack_input(hip.frames_u8_to_nchw(u8, 2.0 / 255.0, -1.0))
+    got = hip.frames_u8_to_stem(u8, 2.0 / 255.0, -1.0)
+    assert torch.equal(got.view(torch.int16), want.view(torch.int16))

@@ -363,3 +363,83 @@ def test_eve_harness_host_logic_matches_oracle(fake, tag):
         assert float((got['initial_gaze_history'] - winter['history_initial_last']).abs().max()) < 1e-3
         assert float((got['refined_gaze_history'] - winter['refined_gaze_history']).abs().max()) < 1e-3
     eve_amd.reset_standalone_config()
+
+
+def test_uint8_frames_follow_the_reference_normalisation(fake, golden_dir):
+    """oracle/frames.py against the reference's own preprocess_frames / preprocess_screen_frames (fixture), and the
+    product's uint8 entry (eve_amd.data + EyeNet.forward_sequence on [B,T,H,W,C] uint8) against the float path."""
+    from eve_amd import data
+    from oracle import frames as oframes
+    fx = np.load(os.path.join(golden_dir, 'frames.npz'))
+    for key in ('ramp', 'frames'):
+        assert np.array_equal(oframes.preprocess_frames(fx[key]), fx[key + '_eye'])
+        assert np.array_equal(oframes.preprocess_screen_frames(fx[key]), fx[key + '_screen'])
+        assert np.array_equal(data.preprocess_frames(torch.from_numpy(fx[key])).numpy(), fx[key + '_eye'])
+        assert np.array_equal(data.preprocess_screen_frames(torch.from_numpy(fx[key])).numpy(), fx[key + '_screen'])
+    cfg = eve_amd.reset_standalone_config()
+    net = detweights.fill_module(eve_amd.EyeNet(), 0)
+    g = np.random.Generator(np.random.PCG64(5))
+    u8 = {s: torch.from_numpy(g.integers(0, 256, size=(1, 2, 64, 64, 3), dtype=np.uint8)) for s in ('left', 'right')}
+    head = {s + '_h': torch.zeros(1, 2, 2) for s in ('left', 'right')}
+    as_float = {s + '_eye_patch': torch.from_numpy(oframes.preprocess_frames(u8[s].numpy().reshape(2, 64, 64, 3))).view(1, 2, 3, 64, 64)
+                for s in ('left', 'right')}
+    a = net.forward_sequence(dict(head, **{s + '_eye_patch': u8[s] for s in u8}))
+    b = net.forward_sequence(dict(head, **as_float))
+    for k in ('left_g_initial', 'right_pupil_size'):
+        assert torch.equal(a[k], b[k]), k
+
+
+def test_checkpoints_interchange_with_the_reference_layout(fake, tmp_path):
+    """eve_amd.checkpoint writes what the reference's CheckpointManager writes (checkpoint_manager.py:47-74): a directory
+    checkpoints/%07d.pt/ with eye_net.pt / refine_net.pt (prefixed keys) and optimizer_0.pt in torch.optim.Adam's
+    format -- loadable, strictly, by a model with the reference's parameter names, and the other way round."""
+    from eve_amd import checkpoint, train
+    json_path = os.path.join(REPO, 'configs', 'refine_net.json')
+    cfg = eve_amd.reset_standalone_config()
+    cfg.import_json(json_path)
+    cfg.import_dict(dict(refine_net_rnn_type='CGRU', eye_net_load_pretrained=False, refine_net_do_offset_augmentation=False))
+    ocfg = OracleConfig(json_path, refine_net_rnn_type='CGRU', eye_net_load_pretrained=False)
+    model = eve_amd.EVE().train()
+    detweights.fill_module(model.eye_net, 0); detweights.fill_module(model.refine_net, 1)
+    tr = train.eve_trainer(model, cfg)
+    tr.step(detweights.eve_batch(1, 2, seed=8))
+    out = str(tmp_path)
+    path = checkpoint.save(model, out, 12, trainer=tr)
+    assert path.endswith(os.path.join('checkpoints', '0000012.pt')) and os.path.isdir(path)
+    assert sorted(os.listdir(path)) == ['eye_net.pt', 'optimizer_0.pt', 'refine_net.pt']
+    part = torch.load(os.path.join(path, 'refine_net.pt'))
+    assert all(k.startswith('refine_net.') for k in part) and all(v.is_contiguous() for v in part.values())
+
+    class ReferenceShaped(torch.nn.Module):               # the module tree of models/eve.py:49-66 with the oracle's networks
+        def __init__(self):
+            super().__init__()
+            self.eye_net, self.refine_net = OracleEyeNet(ocfg), OracleRefineNet(ocfg)
+    ref = ReferenceShaped()
+    merged = {}
+    for f in ('eye_net.pt', 'refine_net.pt'):
+        merged.update(torch.load(os.path.join(path, f)))
+    ref.load_state_dict(merged)                           # strict
+    for (n, a), (_, b) in zip(model.state_dict().items(), ref.state_dict().items()):
+        assert torch.equal(a.cpu(), b), n
+    opt = torch.optim.Adam(ref.refine_net.parameters(), lr=cfg.learning_rate, weight_decay=cfg.weight_decay)
+    opt.load_state_dict(torch.load(os.path.join(path, 'optimizer_0.pt')))
+    st = opt.state_dict()['state']
+    assert len(st) == len(list(ref.refine_net.parameters())) and float(st[0]['step']) == 1.0
+    assert float(st[3]['exp_avg'].abs().max()) > 0
+
+    # the other direction: a checkpoint written the reference's way, read by the drop-in (+ keep-N, + load_last)
+    detweights.fill_module(ref.eye_net, 5); detweights.fill_module(ref.refine_net, 6)
+    their = os.path.join(out, 'checkpoints', '0000040.pt')
+    os.makedirs(their)
+    sd = ref.state_dict()
+    for prefix in ('eye_net', 'refine_net'):
+        torch.save({k: v for k, v in sd.items() if k.startswith(prefix + '.')}, os.path.join(their, prefix + '.pt'))
+    torch.save(opt.state_dict(), os.path.join(their, 'optimizer_0.pt'))
+    assert checkpoint.load_last(model, out, trainer=tr) == 40
+    for (n, a), (_, b) in zip(model.state_dict().items(), sd.items()):
+        assert torch.equal(a.cpu(), b), n
+    assert tr.step_count == 1 and float(tr.fp.m.abs().max()) > 0
+    for s in (41, 42, 43):
+        checkpoint.save(model, out, s, trainer=tr, keep_n=3)
+    assert [s for s, _ in checkpoint.available(out)] == [41, 42, 43]
+    eve_amd.reset_standalone_config()
