@@ -70,6 +70,78 @@ __global__ __launch_bounds__(256) void in_stats_kernel(const T* __restrict__ x, 
     }
 }
 
+// ---- statistics in ONE pass (bf16 planes too large for L2 to serve a second one: RefineNet's 72x128 level is 295 KB
+// per image, 283 MB per tensor): sums of d = x - k and d^2 with the shift k = the plane's first pixel (per channel),
+// so that var = E[d^2] - E[d]^2 loses nothing to cancellation unless that pixel is many sigmas off the mean ----
+template <typename T>
+__global__ __launch_bounds__(256) void in_stats1_kernel(const T* __restrict__ x, float* __restrict__ mr, int HW, int C, float eps) {
+    constexpr int VEC = Elem<T>::VEC;
+    __shared__ float sh[2 * 256 * VEC];
+    const int cvecs = C / VEC, phases = 256 / cvecs;
+    const int tid = threadIdx.x, cv = tid % cvecs, ph = tid / cvecs;
+    const bool on = ph < phases;
+    const T* xp = x + (size_t)blockIdx.x * HW * C + (on ? cv : 0) * VEC;
+    float k[VEC], s1[VEC], s2[VEC];
+    // shift = mean of `phases` pixels spread evenly over the plane (a single pixel -- the corner, say, with two thirds of
+    // its receptive field in the zero padding -- can sit many sigmas off the mean of a nearly constant plane)
+    {
+        const int px = (int)(((long long)(on ? ph : 0) * HW) / phases);
+        Elem<T>::unpack(*reinterpret_cast<const uint4*>(xp + (size_t)px * C), k);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) sh[tid * VEC + e] = on ? k[e] : 0.f;
+        __syncthreads();
+        for (int n = phases; n > 1;) {
+            const int half = (n + 1) >> 1;
+            if (on && ph + half < n) {
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) sh[tid * VEC + e] += sh[(tid + half * cvecs) * VEC + e];
+            }
+            __syncthreads();
+            n = half;
+        }
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) k[e] = sh[(on ? cv : 0) * VEC + e] * (1.f / (float)phases);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
+    if (on) {
+#pragma unroll 4
+        for (int px = ph; px < HW; px += phases) {
+            float f[VEC];
+            Elem<T>::unpack(*reinterpret_cast<const uint4*>(xp + (size_t)px * C), f);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) { const float d = f[e] - k[e]; s1[e] += d; s2[e] = fmaf(d, d, s2[e]); }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) { sh[tid * VEC + e] = s1[e]; sh[(256 + tid) * VEC + e] = s2[e]; }
+    __syncthreads();
+    for (int n = phases; n > 1;) {                         // pairwise tree over the phases
+        const int half = (n + 1) >> 1;
+        if (on && ph + half < n) {
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                sh[tid * VEC + e] += sh[(tid + half * cvecs) * VEC + e];
+                sh[(256 + tid) * VEC + e] += sh[(256 + tid + half * cvecs) * VEC + e];
+            }
+        }
+        __syncthreads();
+        n = half;
+    }
+    if (tid < cvecs) {
+        float* o = mr + ((size_t)blockIdx.x * C + tid * VEC) * 2;
+        const float inv = 1.f / (float)HW;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            const float m = sh[tid * VEC + e] * inv;
+            const float var = fmaxf(sh[(256 + tid) * VEC + e] * inv - m * m, 0.f);
+            o[2 * e] = k[e] + m;
+            o[2 * e + 1] = rsqrtf(var + eps);
+        }
+    }
+}
+
 // ---- y = act(gamma*(x-mean)*rstd + beta + res) ----
 // grid = (chunks, planes): a thread walks ONE plane with a stride that is a multiple of the channel-vector count, so
 // its channels -- and therefore scale / shift -- are loop invariants (the first version decoded plane and channel
@@ -294,7 +366,12 @@ extern "C" int eve_instnorm_stats(int dtype, int N, int HW, int C, const void* x
     if (int e = check_plane(dtype, N, HW, C, "instnorm_stats: bad shape")) return e;
     if (!x || !mean_rstd) return set_error_msg("instnorm_stats: null pointer");
     hipStream_t s = (hipStream_t)stream;
-    if (dtype == EVE_DT_BF16) hipLaunchKernelGGL(in_stats_kernel<bf16_t>, dim3(N), dim3(256), 0, s, (const bf16_t*)x, mean_rstd, HW, C, eps);
+    // bf16 planes beyond ~64 KB per image: the second pass of the two-pass kernel would come from HBM again
+    static int one_pass = -1;
+    if (one_pass < 0) { const char* e = getenv("EVE_IN_STATS_ONE_PASS"); one_pass = (e && e[0] == '0') ? 0 : 1; }
+    if (dtype == EVE_DT_BF16 && one_pass && (long long)HW * C * 2 >= 65536)
+        hipLaunchKernelGGL(in_stats1_kernel<bf16_t>, dim3(N), dim3(256), 0, s, (const bf16_t*)x, mean_rstd, HW, C, eps);
+    else if (dtype == EVE_DT_BF16) hipLaunchKernelGGL(in_stats_kernel<bf16_t>, dim3(N), dim3(256), 0, s, (const bf16_t*)x, mean_rstd, HW, C, eps);
     else                      hipLaunchKernelGGL(in_stats_kernel<float>, dim3(N), dim3(256), 0, s, (const float*)x, mean_rstd, HW, C, eps);
     EVE_CHECK_LAUNCH();
     return 0;
