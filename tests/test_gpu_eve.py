@@ -208,3 +208,28 @@ def test_eve_trainer_steps_and_learns():
     assert torch.equal(eye0, model.eye_net.fc_common[0].weight.detach())
     assert not torch.equal(ref0, model.refine_net.final[0].weight.detach())
     eve_amd.reset_standalone_config()
+
+
+def test_full_size_round_trips(hip):
+    """Size-independent properties at BASELINE configs[2]'s frame count (N = 32 x 30 = 960): the two encode -> decode pairs
+    of the harness.  (a) gaze geometry: the combined gaze towards a screen point, cast back through to_screen_coordinates,
+    lands on that point; (b) heat-maps: soft-argmax of the Gaussian map drawn around a centre returns the centre (up to the
+    reference's own grid conventions: maps are sampled at x = 15 i px, soft-argmax spreads i over 1920 / 127 px)."""
+    N, screen = 960, (1920, 1080)
+    b = detweights.eve_batch(32, 30, seed=17, with_screen=False)
+    c = lambda k, *s: b[k].reshape(N, *s).cuda()
+    g = torch.Generator().manual_seed(1)
+    px = torch.stack([torch.rand(N, generator=g) * 1500 + 200, torch.rand(N, generator=g) * 800 + 150], dim=1)
+    mm = (px * 0.288).cuda()
+    o = 0.5 * (c('left_o', 3) + c('right_o', 3))
+    gaze = hip.combined_gaze(o, mm, c('left_R', 3, 3), c('camera_transformation', 4, 4))
+    _, back_mm, back_px, _ = hip.gaze_to_pog(gaze, o, c('left_R', 3, 3), c('inv_camera_transformation', 4, 4),
+                                             c('pixels_per_millimeter', 2), screen)
+    assert float((back_mm - mm).abs().max()) < 5e-3                      # mm, on a 553 x 311 mm screen
+    assert float((back_px.cpu() - px).abs().max()) < 2e-2
+    maps = hip.make_heatmaps(px.cuda(), 5.0, (72, 128), screen)
+    got, _ = hip.soft_argmax_fwd(maps, screen)
+    # expected position under the reference's conventions: centre at heat-map column cx = px / 15 -> pixel 1920 cx / 127
+    want = torch.stack([px[:, 0] / 15.0 * (1920.0 / 127.0), px[:, 1] / 15.0 * (1080.0 / 71.0)], dim=1)
+    assert float((got.cpu() - want).abs().max()) < 1.0
+    assert float((got.cpu() - px).abs().max()) < 16.0                     # within one heat-map cell of the centre itself

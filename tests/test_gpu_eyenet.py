@@ -263,3 +263,39 @@ def test_uint8_clips_through_the_prefetcher_equal_the_float_path():
                     assert torch.equal(a[k], b[k]), (dt, k)
                 seen += 1
         assert seen == 3
+
+
+def test_full_size_forward_is_batch_invariant_and_deterministic():
+    """BASELINE configs[1] at full size (B=32 clips x T=30, bf16), through properties that do not need the oracle:
+    clips are independent units (InstanceNorm is per image, the GRU per sequence), so every clip's outputs are
+    bit-identical whether it runs in the batch of 32 or in a batch of 8, and a repeated forward is bit-identical;
+    the data-parallel identity grad(batch) = mean of grad(halves) holds to bf16 / atomic-order noise."""
+    cfg = eye_cfg()
+    small = detweights.eyenet_batch(8, 30, seed=12, invalid_fraction=0.1)
+    g = torch.Generator().manual_seed(0)
+    full = {}
+    for k, v in small.items():                       # 32 distinct clips: 4 perturbed copies of the 8 generated ones
+        reps = [v] + [(v + 0.05 * torch.randn(v.shape, generator=g)).clamp(-1, 1) if v.dtype == torch.float32 and 'patch' in k
+                      else v for _ in range(3)]
+        full[k] = torch.cat(reps, dim=0)
+    full = to_dev(full)
+    net = make_net(torch.bfloat16)
+    with torch.no_grad():
+        a = net.forward_sequence(full)
+        b = net.forward_sequence(full)
+        for k in ('left_g_initial', 'right_g_initial', 'left_pupil_size', 'right_pupil_size'):
+            assert torch.equal(a[k], b[k]), 'not deterministic: ' + k
+        for i in range(0, 32, 8):
+            part = net.forward_sequence({k: v[i:i + 8].contiguous() for k, v in full.items()})
+            for k in ('left_g_initial', 'right_g_initial', 'left_pupil_size', 'right_pupil_size'):
+                assert torch.equal(part[k], a[k][i:i + 8]), 'clip outputs depend on the batch: %s, clips %d..' % (k, i)
+    assert float(a['left_g_initial'].abs().max()) > 0.05
+
+    def grads(batch):
+        net.zero_grad(set_to_none=True)
+        sequence.eyenet_losses(net.forward_sequence(batch), batch, cfg)['full_loss'].backward()
+        return torch.cat([p.grad.detach().float().reshape(-1) for p in net.parameters()])
+    whole = grads(full)
+    halves = 0.5 * (grads({k: v[:16].contiguous() for k, v in full.items()}) + grads({k: v[16:].contiguous() for k, v in full.items()}))
+    rel = float((whole - halves).norm() / whole.norm())
+    assert rel < 2e-2, rel
