@@ -70,6 +70,7 @@ template <> struct Mma<float> {
 
 }  // namespace eve
 #include "conv_fast.h"
+#include "wgrad_halo.h"
 namespace eve {
 
 // =================================================================================================
@@ -694,9 +695,75 @@ static void wgrad_split(const GatherParams& p, uint32_t tk, uint32_t tc, uint32_
     splits = (p.M + rows - 1) / rows;
 }
 
+// few-channel 3x3 / stride 1 / pad 1 layers on large planes: band-resident kernel (wgrad_halo.h).  False = not this shape.
+static bool launch_wgrad_halo(const GatherParams& p, const void* x, const void* dy, float* dw, float* db, hipStream_t s) {
+    static int enabled = -1;
+    if (enabled < 0) { const char* e = getenv("EVE_WGRAD_HALO"); enabled = (e && e[0] == '0') ? 0 : 1; }
+    if (!enabled) return false;
+    const int ks = p.KH;
+    if ((ks != 3 && ks != 1) || p.KW != ks || p.o_mul != 1 || p.k_mul != 1 || p.off != -(ks / 2) || p.div != 1 || p.OH != p.IH ||
+        p.OW != p.IW)
+        return false;
+    const int W = p.IW, H = p.IH;
+    long long min_m = 1ll << 20;                      // below ~1 M pixels the gather kernel's re-reads stay in L2 anyway
+    if (const char* e = getenv("EVE_WGRAD_HALO_MIN_M")) min_m = atoll(e);          // (read per call: the tests lower it)
+    if (W < 32 || W > 128 || (W & (W - 1)) || p.Cin % 16 || p.Cout % 16 || (long long)p.M < min_m) return false;
+    const int MT = p.Cout / 16, CT = p.Cin / 16;
+    if (ks == 3 && !((MT == 1 && (CT == 1 || CT == 2 || CT == 4)) || (MT == 2 && (CT == 1 || CT == 2)))) return false;
+    if (ks == 1 && !((MT == 2 && CT == 1) || (MT == 1 && CT == 4) || (MT == 1 && CT == 2) || (MT == 4 && CT == 2) || (MT == 2 && CT == 4)))
+        return false;
+    const unsigned long long xb = (unsigned long long)p.N * H * W * p.Cin * 2, db_ = (unsigned long long)p.M * p.Cout * 2;
+    if (xb >= (1ull << 31) || db_ >= (1ull << 31)) return false;
+    const size_t red = (size_t)(ks * ks * p.Cin * p.Cout + p.Cout) * 4;
+    const unsigned occ = (ks == 3 && MT * CT >= 4) ? 2 : 3;   // workgroups per CU the accumulator registers allow (36 tiles: two)
+    int TH = 0; size_t lds = 0;
+    for (size_t budget : {(size_t)(occ == 3 ? 52 : 78) * 1024, (size_t)78 * 1024}) {
+        for (int th : {4, 2, 1}) {
+            const size_t need = (size_t)(th + ks - 1) * (W + ks - 1) * p.Cin * 2 + (size_t)th * W * p.Cout * 2;
+            if (need <= budget && need >= red) { TH = th; lds = need; break; }
+        }
+        if (TH) break;
+    }
+    if (!TH) return false;
+    WgradHaloParams h;
+    h.N = p.N; h.H = H; h.W = W; h.TH = TH; h.bands = (H + TH - 1) / TH;
+    h.total_bands = (uint32_t)p.N * h.bands; h.x_bytes = (uint32_t)xb; h.dy_bytes = (uint32_t)db_;
+    h.log2_cpr = 0;
+    while ((32 << h.log2_cpr) < W) ++h.log2_cpr;
+    const unsigned per_cu = (unsigned)((160 * 1024) / lds);
+    unsigned grid = 256 * (per_cu > occ ? occ : per_cu);
+    if (grid > h.total_bands) grid = h.total_bands;
+#define EVE_WGRAD_HALO_LAUNCH(MT_, CT_, KS_)                                                                            \
+    do {                                                                                                                \
+        static bool attr_done = false;                                                                                  \
+        if (!attr_done) {                                                                                               \
+            (void)hipFuncSetAttribute((const void*)wgrad_halo_kernel<MT_, CT_, KS_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+            attr_done = true;                                                                                           \
+        }                                                                                                               \
+        EVE_LAUNCH("wgrad_halo_kernel<" #MT_ ", " #CT_ ", " #KS_ ">", (wgrad_halo_kernel<MT_, CT_, KS_>), dim3(grid), dim3(256), lds, s, h, \
+                   (const bf16_t*)x, (const bf16_t*)dy, dw, db);                                                          \
+    } while (0)
+    if (ks == 3) {
+        if (MT == 1 && CT == 1) EVE_WGRAD_HALO_LAUNCH(1, 1, 3);
+        else if (MT == 1 && CT == 2) EVE_WGRAD_HALO_LAUNCH(1, 2, 3);
+        else if (MT == 1 && CT == 4) EVE_WGRAD_HALO_LAUNCH(1, 4, 3);
+        else if (MT == 2 && CT == 1) EVE_WGRAD_HALO_LAUNCH(2, 1, 3);
+        else EVE_WGRAD_HALO_LAUNCH(2, 2, 3);
+    } else {
+        if (MT == 2 && CT == 1) EVE_WGRAD_HALO_LAUNCH(2, 1, 1);
+        else if (MT == 1 && CT == 4) EVE_WGRAD_HALO_LAUNCH(1, 4, 1);
+        else if (MT == 1 && CT == 2) EVE_WGRAD_HALO_LAUNCH(1, 2, 1);
+        else if (MT == 4 && CT == 2) EVE_WGRAD_HALO_LAUNCH(4, 2, 1);
+        else EVE_WGRAD_HALO_LAUNCH(2, 4, 1);
+    }
+#undef EVE_WGRAD_HALO_LAUNCH
+    return true;
+}
+
 template <typename T>
 static int launch_wgrad(const GatherParams& p, const void* x, const void* dy, const float* ss, int pro_act,
                         float* dw, hipStream_t s, float* db = nullptr) {
+    if (sizeof(T) == 2 && !ss && !use_v1() && launch_wgrad_halo(p, x, dy, dw, db, s)) return db ? 1 : 0;
     if (sizeof(T) == 2 && !ss && !use_v1()) {   // bf16: LDS-DMA staging + hardware-transposing fragment reads
         const unsigned long long x_bytes = (unsigned long long)p.N * p.IH * p.IW * p.Cin * 2;
         const unsigned long long dy_bytes = (unsigned long long)p.M * p.Cout * 2;

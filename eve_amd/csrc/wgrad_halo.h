@@ -1,0 +1,180 @@
+// bf16 weight gradient of 3x3 / stride 1 / pad 1 convolutions with FEW channels (16..64 in, 16..32 out) on large planes:
+// RefineNet's 72x128 level (/root/reference/src/models/refine_net.py:96-131), 8.8 M pixels per step at B=32 x T=30.
+//
+// wgrad_tr_kernel gathers its filter-column operand tap by tap: every x pixel travels L2 -> LDS nine times, and with 16
+// channels (32 bytes per pixel) that gather, not the MFMAs, sets the time (320-920 us per layer, ~6 TB/s of L2 reads for
+// 70 us worth of HBM traffic).  Here a band of TH image rows is made resident once -- x with its one-pixel halo, dy
+// without -- and all nine taps read the same LDS tile at shifted addresses:
+//     dw[co][kh][kw][ci] += sum over the band's pixels of dy[y][x][co] * x[y + kh - 1][x + kw - 1][ci]
+// One MFMA 16x16x32 = 16 output channels x 16 input channels x 32 pixels of one image row; both operands come out of
+// the natural [pixel][channel] tiles through the transposing LDS read.  A wave owns whole 32-pixel chunks and carries
+// the full 9 x MT x CT accumulator set; workgroups stream bands persistently, and reduce through LDS float atomics before
+// touching the global gradient.  The bias gradient rides along as one more MFMA against an all-ones operand.
+#pragma once
+
+namespace eve {
+
+struct WgradHaloParams {
+    int N, H, W, TH, bands;            // bands per image = ceil(H / TH)
+    uint32_t total_bands, x_bytes, dy_bytes;
+    int log2_cpr;                      // log2(W / 32): 32-pixel chunks per row
+};
+
+// three in-place MFMAs sharing the A operand (one filter row): c[i] += a x b[i]
+__device__ __forceinline__ void mma3_bf16_inplace(f32x4_t& c0, f32x4_t& c1, f32x4_t& c2, const uint4& a4, const uint4 (&b4)[3]) {
+    const u32x4_t a = __builtin_bit_cast(u32x4_t, a4);
+    const u32x4_t b0 = __builtin_bit_cast(u32x4_t, b4[0]), b1 = __builtin_bit_cast(u32x4_t, b4[1]), b2 = __builtin_bit_cast(u32x4_t, b4[2]);
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_mfma_f32_16x16x32_bf16 %0, %3, %4, %0\n\t"
+        "v_mfma_f32_16x16x32_bf16 %1, %3, %5, %1\n\t"
+        "v_mfma_f32_16x16x32_bf16 %2, %3, %6, %2"
+        : "+v"(c0), "+v"(c1), "+v"(c2)                       // accumulators in architectural VGPRs (unified file on gfx950):
+        : "v"(a), "v"(b0), "v"(b1), "v"(b2));                 // the epilogue reads them without a copy out of the AGPRs
+}
+__device__ __forceinline__ void mma1_bf16_inplace(f32x4_t& c, const uint4& a4, const uint4& b4) {
+    const u32x4_t a = __builtin_bit_cast(u32x4_t, a4), b = __builtin_bit_cast(u32x4_t, b4);
+    asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+}
+
+// KS = 3: the 3x3 / pad 1 case above.  KS = 1: 1x1 convolutions of the same planes (skip layers): no halo, one tap --
+// a plain [Cout][Cin] += dy^T x over the band, where the gather kernel's 256-wide K tile is 6-25 % occupied.
+template <int MT, int CT, int KS = 3>
+__global__ __launch_bounds__(256) void wgrad_halo_kernel(const WgradHaloParams p, const bf16_t* __restrict__ x,
+                                                         const bf16_t* __restrict__ dy, float* __restrict__ dw,
+                                                         float* __restrict__ db) {
+    constexpr int CIN = 16 * CT, COUT = 16 * MT;
+    constexpr int XROW = CIN * 2, DROW = COUT * 2;           // bytes per pixel
+    constexpr int XS = XROW / 16, DSL = DROW / 16;           // 16-byte slots per pixel
+    constexpr int TAPS = KS * KS, PAD = KS / 2;
+    constexpr int NRED = TAPS * CIN * COUT;
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int W = p.W, W2 = W + 2 * PAD, TH = p.TH;
+    const int xs_bytes = (TH + 2 * PAD) * W2 * XROW;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int t = lane & 15, g = lane >> 4;
+    const uint32_t lds0 = lds_addr_of(lds), ldsD = lds0 + (uint32_t)xs_bytes;
+
+    // the two halo columns never receive data: zero them once
+    for (int i = tid; i < (KS == 3 ? (TH + 2) * 2 * XS : 0); i += 256) {
+        const int row = i / (2 * XS), rem = i - row * 2 * XS;
+        const int col = rem / XS ? W + 1 : 0, ch = rem % XS;
+        *reinterpret_cast<uint4*>(lds + (size_t)((row * W2 + col) * XROW + ch * 16)) = make_uint4(0u, 0u, 0u, 0u);
+    }
+    const eve_int4 rs_x = make_rsrc_words(x, p.x_bytes);
+    const eve_int4 rs_dy = make_rsrc_words(dy, p.dy_bytes);
+
+    f32x4_t acc[MT][CT][TAPS], accb[MT];
+#pragma unroll
+    for (int a = 0; a < MT; ++a) {
+        accb[a] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int b = 0; b < CT; ++b)
+#pragma unroll
+            for (int c = 0; c < TAPS; ++c) acc[a][b][c] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    }
+    const uint4 ones = make_uint4(0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u);
+    // lane-constant part of the transposing reads: pixel 8g + t/4 (+4 for the second read), channels 4 (t%4) .. +3
+    const int lrow = 8 * g + (t >> 2), sub = (t & 3) * 8;
+    const int nchunks = TH << p.log2_cpr;
+    const int xslots = W * XS, dslots = W * DSL;             // 16-byte slots per image row
+
+    for (uint32_t band = blockIdx.x; band < p.total_bands; band += gridDim.x) {
+        const int n = (int)(band / (uint32_t)p.bands), y0 = (int)(band % (uint32_t)p.bands) * TH;
+        __syncthreads();                                      // the previous band has been consumed
+        for (int hy = 0; hy < TH + 2 * PAD; ++hy) {
+            const int gy = y0 - PAD + hy;
+            const bool ok = gy >= 0 && gy < p.H;
+            const int gbase = ((n * p.H + gy) * W) * XROW;
+            const uint32_t lrow0 = lds0 + (uint32_t)((hy * W2 + PAD) * XROW);
+            for (int s0 = wave * 64; s0 < xslots; s0 += 256)
+                lds_dma16_asm(rs_x, lrow0 + s0 * 16, ok ? gbase + (s0 + lane) * 16 : EVE_OOB);
+        }
+        for (int ty = 0; ty < TH; ++ty) {
+            const int gy = y0 + ty;
+            const bool ok = gy < p.H;
+            const int gbase = ((n * p.H + gy) * W) * DROW;
+            const uint32_t lrow0 = ldsD + (uint32_t)(ty * W * DROW);
+            for (int s0 = wave * 64; s0 < dslots; s0 += 256)
+                lds_dma16_asm(rs_dy, lrow0 + s0 * 16, ok ? gbase + (s0 + lane) * 16 : EVE_OOB);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+
+        for (int c = wave; c < nchunks; c += 4) {
+            const int ty = c >> p.log2_cpr, x0 = (c - (ty << p.log2_cpr)) * 32;
+            uint4 fp[MT];
+            const uint32_t pa = ldsD + (uint32_t)((ty * W + x0 + lrow) * DROW + sub);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const uint2 a0 = lds_tr_read(pa + mt * 32);
+                const uint2 a1 = lds_tr_read<4 * DROW>(pa + mt * 32);
+                fp[mt] = make_uint4(a0.x, a0.y, a1.x, a1.y);
+            }
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) {
+                if constexpr (KS == 3) {
+#pragma unroll
+                    for (int kh = 0; kh < 3; ++kh) {         // one filter row at a time keeps the operand registers few
+                        uint4 fq[3];
+#pragma unroll
+                        for (int kw = 0; kw < 3; ++kw) {
+                            const uint32_t qa = lds0 + (uint32_t)(((ty + kh) * W2 + x0 + kw + lrow) * XROW + ct * 32 + sub);
+                            const uint2 b0 = lds_tr_read(qa);
+                            const uint2 b1 = lds_tr_read<4 * XROW>(qa);
+                            fq[kw] = make_uint4(b0.x, b0.y, b1.x, b1.y);
+                        }
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt)
+                            mma3_bf16_inplace(acc[mt][ct][kh * 3], acc[mt][ct][kh * 3 + 1], acc[mt][ct][kh * 3 + 2], fp[mt], fq);
+                    }
+                } else {
+                    const uint32_t qa = lds0 + (uint32_t)((ty * W + x0 + lrow) * XROW + ct * 32 + sub);
+                    const uint2 b0 = lds_tr_read(qa);
+                    const uint2 b1 = lds_tr_read<4 * XROW>(qa);
+                    const uint4 fq = make_uint4(b0.x, b0.y, b1.x, b1.y);
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) mma1_bf16_inplace(acc[mt][ct][0], fp[mt], fq);
+                }
+            }
+            if (db) {
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) mma1_bf16_inplace(accb[mt], fp[mt], ones);
+            }
+        }
+    }
+    mma_drain();
+
+    // ---- workgroup reduction through LDS float atomics, then one global atomic per filter element ----
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(lds);
+    for (int i = tid; i < NRED + COUT; i += 256) red[i] = 0.f;
+    __syncthreads();
+    __builtin_amdgcn_sched_barrier(0);                       // accumulators leave the AGPRs tile by tile, below this line
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+            for (int tap = 0; tap < TAPS; ++tap) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int co = mt * 16 + g * 4 + r, ci = ct * 16 + t;
+                    atomicAdd(&red[(co * TAPS + tap) * CIN + ci], acc[mt][ct][tap][r]);
+                }
+                __builtin_amdgcn_sched_barrier(0);           // (else all 36 tiles are copied out of the AGPRs at once: 144 VGPRs)
+            }
+    if (db && t == 0) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) atomicAdd(&red[NRED + mt * 16 + g * 4 + r], accb[mt][r]);
+    }
+    __syncthreads();
+    for (int i = tid; i < NRED; i += 256) atomicAdd(dw + i, red[i]);
+    if (db)
+        for (int i = tid; i < COUT; i += 256) atomicAdd(db + i, red[NRED + i]);
+}
+
+}  // namespace eve

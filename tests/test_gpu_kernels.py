@@ -481,3 +481,45 @@ def test_uint8_frame_normalisation_is_bit_identical_to_the_reference(hip):
     want = hip.stem_pack_input(hip.frames_u8_to_nchw(u8, 2.0 / 255.0, -1.0))
     got = hip.frames_u8_to_stem(u8, 2.0 / 255.0, -1.0)
     assert torch.equal(got.view(torch.int16), want.view(torch.int16))
+
+
+WGRAD_HALO_CASES = [
+    # N, H, W, Cin, Cout      (3x3 / stride 1 / pad 1, bf16; EVE_WGRAD_HALO_MIN_M=0 sends them to wgrad_halo_kernel)
+    (3, 10, 32, 16, 16),       # partial last band (TH = 4), one 32-pixel chunk per row
+    (2, 72, 128, 16, 16),      # RefineNet level 0 (initial.3, final.0)
+    (2, 72, 128, 16, 32),      # its first encoder convolution
+    (2, 36, 64, 32, 32),       # 36 accumulator tiles, TH = 2
+    (2, 72, 128, 64, 16),      # first decoder convolution (K = 576)
+    (5, 7, 64, 32, 16),        # odd height
+    (2, 72, 128, 16, 32, 1),   # 1x1 skip layer of the first encoder block
+    (2, 72, 128, 64, 16, 1),   # 1x1 skip layer of the first decoder block
+    (3, 36, 64, 32, 64, 1),    # 1x1 skip layer one level down
+]
+
+
+@pytest.mark.parametrize('case', WGRAD_HALO_CASES, ids=lambda c: 'N%d_%dx%d_c%d-%d' % c[:5] + ('_k%d' % c[5] if len(c) > 5 else ''))
+def test_band_resident_weight_gradient(hip, ref, monkeypatch, case):
+    """wgrad_halo_kernel (few channels, large planes) against the ATen restatement and against wgrad_tr_kernel on the
+    same inputs, with and without the fused bias gradient, accumulating onto existing values."""
+    N, H, W, Cin, Cout = case[:5]
+    K = case[5] if len(case) > 5 else 3
+    pad = K // 2
+    x = rnd((N, H, W, Cin), torch.bfloat16, 31)
+    dy = rnd((N, H, W, Cout), torch.bfloat16, 32)
+    want_dw = ref.conv2d_wgrad(x, dy, K, K, 1, pad, torch.zeros((Cout, K, K, Cin)))
+    want_db = ref.bias_grad(dy, torch.zeros(Cout))
+    dw0, db0 = rnd((Cout, K, K, Cin), torch.float32, 33), rnd((Cout,), torch.float32, 34)
+    res = {}
+    for mode, min_m in (('halo', '0'), ('tr', str(1 << 40))):
+        monkeypatch.setenv('EVE_WGRAD_HALO_MIN_M', min_m)
+        plain = hip.conv2d_wgrad(dev(x), dev(dy), K, K, 1, pad, dev(dw0).clone())
+        assert hip.lib.eve_last_kernel().decode().startswith('wgrad_halo_kernel' if mode == 'halo' else 'wgrad_tr_kernel')
+        fused_dw, fused_db = dev(dw0).clone(), dev(db0).clone()
+        hip.conv2d_wgrad(dev(x), dev(dy), K, K, 1, pad, fused_dw, db=fused_db)
+        res[mode] = (plain.cpu(), fused_dw.cpu(), fused_db.cpu())
+        close(plain, want_dw + dw0, torch.bfloat16, 'wgrad ' + mode)
+        close(fused_dw, want_dw + dw0, torch.bfloat16, 'wgrad+bias ' + mode)
+        close(fused_db, want_db + db0, torch.bfloat16, 'bias ' + mode)
+    # same bf16 products, float32 accumulation in a different order
+    scale = float(want_dw.abs().max())
+    assert float((res['halo'][0] - res['tr'][0]).abs().max()) <= 2e-4 * scale + 1e-4
