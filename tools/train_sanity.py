@@ -1,17 +1,53 @@
 #!/usr/bin/env python
-"""Sanity check, not a test: a few dozen EyeNet training steps (hipGraph replay, bf16) on one synthetic batch -- the loss
-must fall."""
-import os, sys, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import eve_amd
-from eve_amd import train
-from oracle import detweights
+"""Sanity check, not a test: optimisation must make progress on a small synthetic data set that can be memorised.
+  (1) EyeNet (configs/eye_net.json, bf16, hipGraph replay): angular error of 8 clips x 10 frames falls from ~50 to a few degrees
+  (2) the whole EVE pipeline (refine_net.json with CGRU, EyeNet frozen, offset augmentation on): RefineNet learns to move
+      the heat-map towards the labelled point of gaze -- BCE and the final PoG error fall
+Prints one line every few steps; the log of a run is kept in profiles/r01_train_sanity.log."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+import eve_amd  # noqa: E402
+from eve_amd import train  # noqa: E402
+from oracle import detweights  # noqa: E402  (synthetic clips only)
+
+steps = int(sys.argv[1]) if len(sys.argv) > 1 else 120
+
 cfg = eve_amd.reset_standalone_config()
-cfg.import_json(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'configs', 'eye_net.json'))
-net = eve_amd.EyeNet(); net.compute_dtype = torch.bfloat16
+cfg.import_json(os.path.join(REPO, 'configs', 'eye_net.json'))
+cfg.import_dict({'base_learning_rate': 0.000125})     # lr = 16 x this = 0.002 (eye_net.json's 0.016 is sized for real data + decay)
+net = eve_amd.EyeNet()
+net.compute_dtype = torch.bfloat16
 net = net.cuda()
 tr = train.eyenet_trainer(net, cfg, use_graph=True)
 batch = {k: v.cuda() for k, v in detweights.eyenet_batch(8, 10, seed=3).items()}
-for i in range(41):
+print('EyeNet, 8 clips x 10 frames, bf16, lr %.4f' % cfg.learning_rate)
+for i in range(steps + 1):
     t = tr.step(batch)
-    if i % 8 == 0: print(i, float(t['full_loss']), float(t['loss_ang_left_g_initial']), float(t['loss_l1_left_pupil_size']))
+    if i % (steps // 8) == 0:
+        print('  step %4d  full %.4f  angular L %.3f deg  R %.3f deg  pupil L1 %.4f' % (
+            i, float(t['full_loss'].detach()), float(t['loss_ang_left_g_initial'].detach()),
+            float(t['loss_ang_right_g_initial'].detach()), float(t['loss_l1_left_pupil_size'].detach())))
+
+cfg = eve_amd.reset_standalone_config()
+cfg.import_json(os.path.join(REPO, 'configs', 'refine_net.json'))
+cfg.import_dict({'refine_net_rnn_type': 'CGRU', 'eye_net_load_pretrained': False})
+model = eve_amd.EVE()
+model.eye_net.load_state_dict(net.state_dict())          # the EyeNet trained above, now frozen (refine_net.json)
+model.eye_net.compute_dtype = model.refine_net.compute_dtype = torch.bfloat16
+model = model.cuda().train()
+tr = train.eve_trainer(model, cfg)
+batch = {k: v.cuda() for k, v in detweights.eve_batch(8, 10, seed=3).items()}
+np.random.seed(0)
+print('EVE pipeline (EyeNet frozen, RefineNet/CGRU trained), 8 clips x 10 frames, bf16, lr %.4f' % cfg.learning_rate)
+for i in range(steps + 1):
+    t = tr.step(batch)
+    if i % (steps // 8) == 0:
+        print('  step %4d  full %.4f  BCE(heat-map) %.4f  PoG error initial %.1f px -> final %.1f px  (%.2f cm)' % (
+            i, float(t['full_loss'].detach()), float(t['loss_ce_heatmap_final'].detach()), float(t['metric_euc_PoG_px_initial']),
+            float(t['metric_euc_PoG_px_final'].detach()), float(t['metric_euc_PoG_cm_final'].detach())))
