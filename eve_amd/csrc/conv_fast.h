@@ -826,6 +826,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_pkernel(const HaloParams 
     char* const sA = smem;
     constexpr int BSLOT = 4096 * WN;
     char* const sB = smem + 2 * a_stage;
+    float* const sBias = reinterpret_cast<float*>(smem + 2 * a_stage + 4 * BSLOT);   // Cout rounded up to the tile, if bias
 
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -836,6 +837,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_pkernel(const HaloParams 
     const eve_int4 rs_w = make_rsrc_words(w, p.w_bytes);
     const uint32_t ldsA = lds_addr_of(sA), ldsB = lds_addr_of(sB);
     const bool wide = p.W >= 16;
+    if (bias) {                                               // (visible to every wave after the first tile's barriers)
+        for (int i = threadIdx.x; i < (int)p.tiles_n * 64 * WN; i += 256) sBias[i] = i < p.Cout ? bias[i] : 0.f;
+    }
 
     // ---- halo DMA slots (lane constants): offset relative to pixel (n0, y0, 0), halo row / image of the slot ----
     int a_rel[7], a_meta[7];                                  // meta = (ti << 8) | hy, or -1 for a slot that is never live
@@ -1005,8 +1009,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_pkernel(const HaloParams 
                 __builtin_amdgcn_s_barrier();
             }
         }
-        // ---- epilogue of this tile (identity / ReLU, no bias: the launcher sends everything else to the one-tile
-        //      kernel); the DMAs of the next tile's first steps are already in flight ----
+        // ---- epilogue of this tile (bias from LDS, identity / ReLU: the launcher sends every other activation to the
+        //      one-tile kernel); the DMAs of the next tile's first steps are already in flight ----
         mma_drain();
         const uint32_t co = co0 + wn * 64 + lg * 16;          // the lane's 16 consecutive channels: co + nt*4 + r
 #pragma unroll
@@ -1023,6 +1027,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_pkernel(const HaloParams 
 #pragma unroll
                 for (int r = 0; r < 4; ++r) o[r] = acc[mt][nt][r];
                 acc[mt][nt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+                if (bias) {
+                    const float4 bq = *reinterpret_cast<const float4*>(sBias + co + nt * 4);
+                    o[0] += bq.x; o[1] += bq.y; o[2] += bq.z; o[3] += bq.w;
+                }
                 act_fwd4<true>(o, epi_act);
                 pk[2 * nt] = pack2_bf16(o[0], o[1]);
                 pk[2 * nt + 1] = pack2_bf16(o[2], o[3]);

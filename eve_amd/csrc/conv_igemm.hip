@@ -584,7 +584,8 @@ static bool launch_halo(const GatherParams& p, const void* src, const void* w, c
     if (persist < 0) { const char* e = getenv("EVE_HALO_PERSIST"); persist = (e && e[0] == '0') ? 0 : 1; }
     const uint32_t tiles = h.tiles_m * h.tiles_n;
     // (pays where a tile is short -- 18 steps at 64 channels; from 128 channels on the one-tile kernel is as fast)
-    if (persist && tiles > 512 && p.Cin <= 64 && p.Cout % 8 == 0 && !bias && (epi_act == EVE_ACT_NONE || epi_act == EVE_ACT_RELU)) {           // two resident workgroups per CU walk the tiles as one stream
+    if (persist && tiles > 512 && p.Cin <= 64 && p.Cout % 8 == 0 && (epi_act == EVE_ACT_NONE || epi_act == EVE_ACT_RELU)) {           // two resident workgroups per CU walk the tiles as one stream
+        const size_t plds = lds + (bias ? (size_t)h.tiles_n * (narrow ? 64 : 128) * 4 : 0);
         static bool pattr = false;
         if (!pattr) {
             (void)hipFuncSetAttribute((const void*)conv3x3_halo_pkernel<2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -592,10 +593,10 @@ static bool launch_halo(const GatherParams& p, const void* src, const void* w, c
             pattr = true;
         }
         if (narrow)
-            EVE_LAUNCH("conv3x3_halo_pkernel<4, 1>", (conv3x3_halo_pkernel<4, 1>), dim3(512), dim3(256), lds, s, h, (const bf16_t*)src,
+            EVE_LAUNCH("conv3x3_halo_pkernel<4, 1>", (conv3x3_halo_pkernel<4, 1>), dim3(512), dim3(256), plds, s, h, (const bf16_t*)src,
                                (const bf16_t*)w, bias, epi_act, (bf16_t*)out);
         else
-            EVE_LAUNCH("conv3x3_halo_pkernel<2, 2>", (conv3x3_halo_pkernel<2, 2>), dim3(512), dim3(256), lds, s, h, (const bf16_t*)src,
+            EVE_LAUNCH("conv3x3_halo_pkernel<2, 2>", (conv3x3_halo_pkernel<2, 2>), dim3(512), dim3(256), plds, s, h, (const bf16_t*)src,
                                (const bf16_t*)w, bias, epi_act, (bf16_t*)out);
         return true;
     }
