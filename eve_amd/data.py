@@ -42,50 +42,67 @@ def preprocess_screen_frames(frames):
 class DevicePrefetcher(object):
     """Iterates `iterable` (dicts of CPU tensors, e.g. a DataLoader) and yields the same dicts on `device`.
 
-    Each batch is copied into pinned staging buffers (allocated once per key/shape and reused) and from there to the
-    device on a dedicated copy stream while the previous batch is being consumed; the consumer stream waits on the
-    copy's event, never on the host.  Non-tensor entries pass through."""
+    A worker thread pulls the next batch, copies pageable tensors into pinned staging buffers (allocated once per
+    key / shape and reused; tensors that are already pinned -- DataLoader(pin_memory=True) -- are sent as they are) and
+    enqueues the host-to-device copies on a dedicated copy stream, `depth` batches ahead of the consumer; the consumer's
+    stream waits on the copy's event, never on the host.  Non-tensor entries pass through."""
 
     def __init__(self, iterable, device='cuda', depth=2):
         self.iterable = iterable
         self.device = torch.device(device)
+        if self.device.index is None:
+            self.device = torch.device('cuda', torch.cuda.current_device())
         self.depth = max(1, int(depth))
         self.stream = torch.cuda.Stream(device=self.device)
-        self._pinned = [dict() for _ in range(self.depth + 1)]
-        self._slot = 0
+        self._pinned = [dict() for _ in range(self.depth + 2)]     # a slot is reused only after its batch was consumed
 
-    def _stage(self, batch):
-        slot = self._pinned[self._slot]
-        self._slot = (self._slot + 1) % len(self._pinned)
+    def _stage(self, batch, slot):
         out = {}
         with torch.cuda.stream(self.stream):
             for k, v in batch.items():
                 if not isinstance(v, torch.Tensor):
                     out[k] = v
                     continue
-                buf = slot.get(k)
-                if buf is None or buf.shape != v.shape or buf.dtype != v.dtype:
-                    buf = slot[k] = torch.empty(v.shape, dtype=v.dtype, pin_memory=True)
-                buf.copy_(v)
-                out[k] = buf.to(self.device, non_blocking=True)
+                src = v
+                if not v.is_pinned():
+                    buf = slot.get(k)
+                    if buf is None or buf.shape != v.shape or buf.dtype != v.dtype:
+                        buf = slot[k] = torch.empty(v.shape, dtype=v.dtype, pin_memory=True)
+                    buf.copy_(v)                                   # (memcpy: releases the GIL)
+                    src = buf
+                out[k] = src.to(self.device, non_blocking=True)
             ev = torch.cuda.Event()
             ev.record(self.stream)
         return out, ev
 
     def __iter__(self):
-        queue = []
-        for batch in self.iterable:
-            queue.append(self._stage(batch))
-            if len(queue) > self.depth - 1:
-                yield self._release(queue.pop(0))
-        while queue:
-            yield self._release(queue.pop(0))
+        import queue
+        import threading
+        q = queue.Queue(maxsize=self.depth)
+        done = object()
 
-    def _release(self, item):
-        out, ev = item
-        cur = torch.cuda.current_stream(self.device)
-        cur.wait_event(ev)
-        for v in out.values():
-            if isinstance(v, torch.Tensor):
-                v.record_stream(cur)
-        return out
+        def worker():
+            try:
+                torch.cuda.set_device(self.device)
+                for i, batch in enumerate(self.iterable):
+                    q.put(self._stage(batch, self._pinned[i % len(self._pinned)]))
+                q.put(done)
+            except BaseException as e:                              # surface loader errors in the consumer
+                q.put(e)
+
+        t = threading.Thread(target=worker, daemon=True)
+        t.start()
+        while True:
+            item = q.get()
+            if item is done:
+                break
+            if isinstance(item, BaseException):
+                raise item
+            out, ev = item
+            cur = torch.cuda.current_stream(self.device)
+            cur.wait_event(ev)
+            for v in out.values():
+                if isinstance(v, torch.Tensor):
+                    v.record_stream(cur)
+            yield out
+        t.join()
