@@ -233,3 +233,51 @@ def test_full_size_round_trips(hip):
     want = torch.stack([px[:, 0] / 15.0 * (1920.0 / 127.0), px[:, 1] / 15.0 * (1080.0 / 71.0)], dim=1)
     assert float((got.cpu() - want).abs().max()) < 1.0
     assert float((got.cpu() - px).abs().max()) < 16.0                     # within one heat-map cell of the centre itself
+
+
+@pytest.mark.parametrize('over', [dict(refine_net_rnn_type='CLSTM'), dict(refine_net_rnn_type='CRNN'),
+                                  dict(refine_net_rnn_type='CGRU', refine_net_use_skip_connections=False),
+                                  dict(refine_net_rnn_type='CGRU', refine_net_do_offset_augmentation=False)],
+                         ids=lambda o: '-'.join('%s=%s' % (k.replace('refine_net_', ''), v) for k, v in o.items()))
+def test_eve_config_variants_match_oracle(over):
+    """The refine_net.json pipeline as shipped (CLSTM: the cell whose output never reaches the decoder, refine_net.py:168-174)
+    and its other switches, float32 on the GPU against the CPU oracle: every scalar, gaze within 1e-4 rad, gradients."""
+    from oracle.eye_net import EyeNet as OracleEyeNet
+    from oracle.refine_net import RefineNet as OracleRefineNet
+    json_path = os.path.join(REPO, 'configs', 'refine_net.json')
+    cfg = eve_amd.reset_standalone_config()
+    cfg.import_json(json_path)
+    cfg.import_dict(dict(eye_net_load_pretrained=False, **over))
+    ocfg = OracleConfig(json_path, eye_net_load_pretrained=False, **over)
+    model = eve_amd.EVE(output_predictions=True)
+    model.eye_net.compute_dtype = model.refine_net.compute_dtype = torch.float32
+    detweights.fill_module(model.eye_net, 0); detweights.fill_module(model.refine_net, 1)
+    model = model.cuda().train()
+    oeye, oref = detweights.fill_module(OracleEyeNet(ocfg), 0), detweights.fill_module(OracleRefineNet(ocfg), 1)
+    for p in oeye.parameters():
+        p.requires_grad = False
+    batch = detweights.eve_batch(2, 3, seed=23, invalid_fraction=0.2)
+    np.random.seed(2)
+    want, winter, _ = oracle_eve.eve_forward(oeye, oref, dict(batch), ocfg, True)
+    np.random.seed(2)
+    got = model({'s': {k: v.cuda() for k, v in batch.items()}}, current_epoch=0.0)
+    assert {k for k in got if k.startswith(('loss_', 'metric_'))} == set(want.keys()) - {'full_loss'}
+    for k, v in want.items():
+        assert abs(float(got[k].detach()) - float(v.detach())) <= 5e-4 * abs(float(v.detach())) + 1e-4, (k, float(got[k].detach()), float(v.detach()))
+    for k in ('g_initial', 'g_final'):
+        assert float((got[k].detach().cpu() - winter[k].detach()).abs().max()) < 1e-4, k
+    got['full_loss'].backward(); want['full_loss'].backward()
+    ref = dict(oref.named_parameters())
+    scale = max(float(p.grad.norm()) for p in ref.values() if p.grad is not None)
+    for n, p in model.refine_net.named_parameters():
+        if ref[n].grad is None:
+            assert p.grad is None, n
+        else:
+            a, b = p.grad.cpu().double(), ref[n].grad.double()
+            # (the first layers sit behind ~40 float32 layers and softmax(100 h): their per-tensor gradients carry a few
+            #  per cent of summation-order noise, CPU vs GPU)
+            # adaptive-max-pool / (leaky-)ReLU decisions on near-ties differ between the two float32 evaluation orders and
+            # re-route gradient: a few per cent per tensor on untrained weights (the reference-pinned cases in
+            # test_eve_matches_reference_golden hold 3 %); this test is about the configuration surface
+            assert float((a - b).norm()) <= 1e-1 * float(b.norm()) + 1e-5 * max(1.0, scale), n
+    eve_amd.reset_standalone_config()
