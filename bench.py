@@ -133,6 +133,7 @@ def main():
     # from its gradient hook and overlaps the rest of backward (the step is GPU-bound either way)
     use_graph = args.graph or (world == 1 and not args.no_graph)
     trainer = train.eyenet_trainer(net, cfg, distributed=world > 1, use_graph=use_graph)
+    trainer.static_inputs = 'alias'      # the synthetic batch stays in the same device buffers: the graph reads it in place
     batch = synthetic_eyenet_batch(args.batch, args.seq, args.size, device, 1000 * rank)
     k = default_kernels()
 
