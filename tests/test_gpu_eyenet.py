@@ -299,3 +299,27 @@ def test_full_size_forward_is_batch_invariant_and_deterministic():
     halves = 0.5 * (grads({k: v[:16].contiguous() for k, v in full.items()}) + grads({k: v[16:].contiguous() for k, v in full.items()}))
     rel = float((whole - halves).norm() / whole.norm())
     assert rel < 2e-2, rel
+
+
+def test_long_sequence_t120():
+    """BASELINE configs[4]'s sequence length: T = 120 frames through the GRU scan (one launch for the whole clip, hidden
+    state carried on-chip) -- float32 forward against the oracle's per-frame loop, and a bf16 train step with finite
+    gradients at that length."""
+    from oracle.eye_net import EyeNet as OracleEyeNet
+    cfg = eye_cfg()
+    batch = detweights.eyenet_batch(1, 120, seed=31, invalid_fraction=0.1)
+    ref = detweights.fill_module(OracleEyeNet(cfg), seed=0)
+    with torch.no_grad():
+        rout = sequence.eyenet_sequence(ref, batch)
+        out = make_net(torch.float32).forward_sequence(to_dev(batch))
+    for k in ('left_g_initial', 'right_g_initial', 'left_pupil_size', 'right_eye_rnn_states_0'):
+        assert float((out[k].cpu() - rout[k]).abs().max()) < GAZE_TOL, k
+    # the recurrence matters: the last frame's state differs from a fresh start
+    assert float((rout['left_eye_rnn_states_0'][:, -1] - rout['left_eye_rnn_states_0'][:, 0]).abs().max()) > 1e-2
+    net16 = make_net(torch.bfloat16)
+    dbatch = to_dev(batch)
+    o16 = net16.forward_sequence(dbatch)
+    sequence.eyenet_losses(o16, dbatch, cfg)['full_loss'].backward()
+    assert all(p.grad is not None and bool(torch.isfinite(p.grad).all()) for p in net16.parameters())
+    dev = max(float((o16[s + '_g_initial'].float().cpu() - rout[s + '_g_initial']).abs().max()) for s in ('left', 'right'))
+    assert dev < 0.08, dev
