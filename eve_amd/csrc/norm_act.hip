@@ -170,6 +170,7 @@ __global__ __launch_bounds__(256) void in_act_fwd_kernel(const T* __restrict__ x
         }
     }
     const size_t base = (size_t)n * per_img;
+#pragma unroll 4
     for (int i = i0; i < per_img; i += stride) {
         float f[VEC], r[VEC];
         Elem<T>::unpack(reinterpret_cast<const uint4*>(x)[base + i], f);
@@ -219,6 +220,7 @@ __global__ __launch_bounds__(256) void in_act_bwd_kernel(const T* __restrict__ d
 #pragma unroll
     for (int e = 0; e < VEC; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
     if (on)
+#pragma unroll 2
         for (int px = ph; px < HW; px += phases) {
             const size_t o = base + (size_t)px * C;
             float g[VEC], yy[VEC], xx[VEC];
@@ -276,6 +278,7 @@ __global__ __launch_bounds__(256) void in_act_bwd_kernel(const T* __restrict__ d
         k[e] = rstd[e] * (gamma ? gamma[cvc * VEC + e] : 1.f);
     }
     if (on)
+#pragma unroll 2
         for (int px = ph; px < HW; px += phases) {
             const size_t o = base + (size_t)px * C;
             float g[VEC], yy[VEC], xx[VEC];
