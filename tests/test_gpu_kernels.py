@@ -523,3 +523,40 @@ def test_band_resident_weight_gradient(hip, ref, monkeypatch, case):
     # same bf16 products, float32 accumulation in a different order
     scale = float(want_dw.abs().max())
     assert float((res['halo'][0] - res['tr'][0]).abs().max()) <= 2e-4 * scale + 1e-4
+
+
+def _random_conv_cases(n, seed):
+    import random
+    rng = random.Random(seed)
+    cases = []
+    while len(cases) < n:
+        k = rng.choice([1, 3, 3, 3])
+        stride = rng.choice([1, 1, 2])
+        H, W = rng.randint(3, 40), rng.choice([4, 5, 8, 9, 16, 24, 32, 40, 64])
+        if (H + 2 * (k // 2) - k) // stride + 1 < 1:
+            continue
+        cases.append((rng.randint(1, 9), H, W, rng.choice([8, 16, 24, 32, 64, 96, 128]), rng.choice([8, 16, 24, 32, 40, 64, 128, 136, 256]),
+                      k, stride, k // 2))
+    return cases
+
+
+@pytest.mark.parametrize('case', _random_conv_cases(24, 2026), ids=conv_case_id)
+def test_conv_random_shapes_bf16(hip, ref, case):
+    """Shapes nobody tuned for (odd heights, widths that are not powers of two, channel counts between the tile sizes):
+    whichever kernel the dispatcher picks must agree with the ATen restatement, forward, data and weight gradient."""
+    N, IH, IW, Cin, Cout, K, stride, pad = case
+    dtype = torch.bfloat16
+    x = rnd((N, IH, IW, Cin), dtype, 41)
+    w = rnd((Cout, K, K, Cin), dtype, 42, scale=(2.0 / (K * K * Cin)) ** 0.5)
+    bias = rnd((Cout,), torch.float32, 43)
+    want = ref.conv2d_fwd(x, w, bias, stride, pad, 2)
+    got = hip.conv2d_fwd(dev(x), dev(w), dev(bias), stride, pad, 2)
+    close(got, want, dtype, 'conv fwd')
+    dy = rnd(tuple(want.shape), dtype, 44)
+    w_ihwo = w.permute(3, 1, 2, 0).contiguous()
+    close(hip.conv2d_dgrad(dev(dy), dev(w_ihwo), (IH, IW), stride, pad), ref.conv2d_dgrad(dy, w_ihwo, (IH, IW), stride, pad), dtype, 'conv dgrad')
+    want_dw = ref.conv2d_wgrad(x, dy, K, K, stride, pad, torch.zeros((Cout, K, K, Cin)))
+    got_dw, got_db = torch.zeros((Cout, K, K, Cin), device='cuda'), torch.zeros(Cout, device='cuda')
+    hip.conv2d_wgrad(dev(x), dev(dy), K, K, stride, pad, got_dw, db=got_db)
+    close(got_dw, want_dw, dtype, 'conv wgrad')
+    close(got_db, ref.bias_grad(dy, torch.zeros(Cout)), dtype, 'bias grad')
