@@ -540,6 +540,25 @@ def _random_conv_cases(n, seed):
     return cases
 
 
+@pytest.mark.parametrize('case', _random_conv_cases(10, 7), ids=conv_case_id)
+def test_conv_random_shapes_f32(hip, ref, case):
+    """The float32 instantiation (parity mode: f32 MFMA / register-staged kernels) on randomly drawn shapes."""
+    N, IH, IW, Cin, Cout, K, stride, pad = case
+    x = rnd((N, IH, IW, Cin), torch.float32, 51)
+    w = rnd((Cout, K, K, Cin), torch.float32, 52, scale=(2.0 / (K * K * Cin)) ** 0.5)
+    bias = rnd((Cout,), torch.float32, 53)
+    want = ref.conv2d_fwd(x, w, bias, stride, pad, 1)
+    close(hip.conv2d_fwd(dev(x), dev(w), dev(bias), stride, pad, 1), want, torch.float32, 'conv fwd')
+    dy = rnd(tuple(want.shape), torch.float32, 54)
+    w_ihwo = w.permute(3, 1, 2, 0).contiguous()
+    close(hip.conv2d_dgrad(dev(dy), dev(w_ihwo), (IH, IW), stride, pad), ref.conv2d_dgrad(dy, w_ihwo, (IH, IW), stride, pad),
+          torch.float32, 'conv dgrad')
+    got_dw, got_db = torch.zeros((Cout, K, K, Cin), device='cuda'), torch.zeros(Cout, device='cuda')
+    hip.conv2d_wgrad(dev(x), dev(dy), K, K, stride, pad, got_dw, db=got_db)
+    close(got_dw, ref.conv2d_wgrad(x, dy, K, K, stride, pad, torch.zeros((Cout, K, K, Cin))), torch.float32, 'conv wgrad')
+    close(got_db, ref.bias_grad(dy, torch.zeros(Cout)), torch.float32, 'bias grad')
+
+
 @pytest.mark.parametrize('case', _random_conv_cases(24, 2026), ids=conv_case_id)
 def test_conv_random_shapes_bf16(hip, ref, case):
     """Shapes nobody tuned for (odd heights, widths that are not powers of two, channel counts between the tile sizes):
