@@ -15,7 +15,7 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
 import eve_amd  # noqa: E402
 from eve_amd import train  # noqa: E402
-from oracle import detweights  # noqa: E402  (synthetic clip generator only)
+from eve_amd import synthetic as detweights  # noqa: E402  (synthetic clips and weights)
 
 ap = argparse.ArgumentParser()
 ap.add_argument('--batch', type=int, default=32)

@@ -11,7 +11,7 @@ import torch
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
 import eve_amd  # noqa: E402
-from oracle import detweights  # noqa: E402  (synthetic clips only)
+from eve_amd import synthetic as detweights  # noqa: E402  (synthetic clips and weights)
 
 B, T, STEPS = 32, 30, 10
 cfg = eve_amd.reset_standalone_config()

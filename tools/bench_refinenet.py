@@ -11,7 +11,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import eve_amd  # noqa: E402
 from eve_amd import train  # noqa: E402
-from oracle import detweights  # noqa: E402
+from eve_amd import synthetic as detweights  # noqa: E402  (synthetic clips and weights)
 
 ap = argparse.ArgumentParser()
 ap.add_argument('--batch', type=int, default=8)

@@ -9,7 +9,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import eve_amd  # noqa: E402
 from eve_amd import kernels, train  # noqa: E402
-from oracle import detweights  # noqa: E402
+from eve_amd import synthetic as detweights  # noqa: E402  (synthetic clips and weights)
 
 cfg = eve_amd.reset_standalone_config()
 cfg.import_json(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'configs', 'refine_net.json'))

@@ -14,7 +14,7 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
 import eve_amd  # noqa: E402
 from eve_amd import train  # noqa: E402
-from oracle import detweights  # noqa: E402  (synthetic clips only)
+from eve_amd import synthetic as detweights  # noqa: E402  (synthetic clips and weights)
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 120
 
