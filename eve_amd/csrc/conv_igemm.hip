@@ -686,8 +686,14 @@ static int launch_igemm(const GatherParams& p, const void* src, const void* w, c
 
 static void wgrad_split(const GatherParams& p, uint32_t tk, uint32_t tc, uint32_t& splits, uint32_t& rows) {
     // enough splits of the pixel range for ~4 workgroups per CU, each a multiple of 64 pixels
-    uint32_t want = (1024 + tk * tc - 1) / (tk * tc);
-    uint32_t max_splits = (p.M + 255) / 256;
+    static int target = -1;                           // workgroups per launch the split aims for
+    if (target < 0) { const char* e = getenv("EVE_WGRAD_TARGET_WGS"); target = e ? atoi(e) : 1024; }
+    uint32_t want = ((uint32_t)target + tk * tc - 1) / (tk * tc);
+    // ... but no split shorter than ~48 K-steps: prologue, ring fill and the 64 atomics per thread of the epilogue are per
+    // workgroup (at B=8 clips the unbounded split cost 4 % of the step; B=32 is not affected)
+    static int min_rows = -1;
+    if (min_rows < 0) { const char* e = getenv("EVE_WGRAD_MIN_ROWS"); min_rows = e ? atoi(e) : 1536; }
+    uint32_t max_splits = (p.M + (uint32_t)min_rows - 1) / (uint32_t)min_rows;
     splits = want < 1 ? 1 : (want > max_splits ? max_splits : want);
     if (splits < 1) splits = 1;
     if (splits > 65535) splits = 65535;
