@@ -12,6 +12,15 @@ import torch.multiprocessing as mp
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _free_port():
+    """A port the OS just handed out on 127.0.0.1 (a fixed one can sit in TIME_WAIT from an earlier run and stall the
+    rendezvous for minutes)."""
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
 def _worker(rank, world, port, tmp):
     sys.path.insert(0, REPO)
     sys.path.insert(0, os.path.join(REPO, 'tests'))
@@ -40,7 +49,7 @@ def _worker(rank, world, port, tmp):
 
 
 def test_two_rank_step_equals_single_process_on_the_global_batch(tmp_path):
-    port = 29500 + (os.getpid() % 2000)
+    port = _free_port()
     mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     a = torch.load(os.path.join(str(tmp_path), 'rank0.pt'))
     b = torch.load(os.path.join(str(tmp_path), 'rank1.pt'))
@@ -107,7 +116,7 @@ def _eve_worker(rank, world, port, tmp):
 
 
 def test_two_rank_eve_pipeline_step_equals_single_process(tmp_path):
-    port = 31500 + (os.getpid() % 2000)
+    port = _free_port()
     mp.spawn(_eve_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     a = torch.load(os.path.join(str(tmp_path), 'eve_rank0.pt'))
     b = torch.load(os.path.join(str(tmp_path), 'eve_rank1.pt'))
