@@ -65,7 +65,7 @@ class PackedWeight(object):
 # F*Cout output channels (the F output pixels of a group), with a weight tensor that holds each original tap once per
 # (output pixel, input pixel) pair of the groups it connects and zeros elsewhere.  That is exactly the shape the
 # halo-resident MFMA kernel is built for (32-channel K steps), so these layers run there instead of on the generic
-# gather kernel (551 -> ~120 us per launch at 960 x 72 x 128); the matrix units do F x the arithmetic on a
+# gather kernel (551 -> 200-260 us per launch at 960 x 72 x 128); the matrix units do F x the arithmetic on a
 # bandwidth-bound layer.
 # 1x1 convolutions group pixels up to 64 channels (the LDS-DMA gather kernel's K step) with a block-diagonal filter.
 # (32-channel rows 128 pixels wide are grouped as well: the halo kernel's 256-pixel x 64-channel tile would need a
