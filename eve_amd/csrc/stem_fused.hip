@@ -132,7 +132,9 @@ __global__ __launch_bounds__(64 * SF_WAVES) void stem_fwd_fused_kernel(const int
     const eve_int4 rs = make_rsrc_words(xp, xp_bytes);
     const float inv_hw = 1.f / (float)(OH * 64);
 
-    for (int n = blockIdx.x * SF_WAVES + wave; n < N; n += gridDim.x * SF_WAVES) {
+    // images are dealt round-robin over the workgroups first (wave w of workgroup b takes image w * grid + b): a small batch
+    // then puts one or two waves on every CU instead of eight waves on a fraction of them
+    for (int n = wave * gridDim.x + blockIdx.x; n < N; n += gridDim.x * SF_WAVES) {
         const int img_off = n * rows * SF_XROW;
         for (int r = 0; r < 9; ++r) sf_stage_row(rs, ring, r, rows, img_off, lane);
         float S[4][4], Q[4][4];
@@ -340,7 +342,9 @@ __global__ __launch_bounds__(64 * SF_WAVES) void stem_bwd_dx_kernel(const int N,
     const float inv_hw = 1.f / (float)(OH * 64);
     char* const sK = sW + SF_WBYTES + wave * SF_KBYTES;         // this wave's per-channel constants
 
-    for (int n = blockIdx.x * SF_WAVES + wave; n < N; n += gridDim.x * SF_WAVES) {
+    // images are dealt round-robin over the workgroups first (wave w of workgroup b takes image w * grid + b): a small batch
+    // then puts one or two waves on every CU instead of eight waves on a fraction of them
+    for (int n = wave * gridDim.x + blockIdx.x; n < N; n += gridDim.x * SF_WAVES) {
         const int img_off = n * rows * SF_XROW;
         for (int r = 0; r < 9; ++r) sf_stage_row(rs, ring, r, rows, img_off, lane);
         const size_t pool_base = (size_t)n * PH * 32;
@@ -462,8 +466,7 @@ extern "C" int eve_stem_fwd_fused(int N, int IH, int IW, const void* x_padded, c
         (void)hipFuncSetAttribute((const void*)stem_fwd_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    unsigned blocks = (unsigned)((N + SF_WAVES - 1) / SF_WAVES);
-    if (blocks > 256) blocks = 256;
+    unsigned blocks = N < 256 ? (unsigned)N : 256u;
     EVE_MARK_KERNEL("stem_fwd_fused_kernel");
     hipLaunchKernelGGL(stem_fwd_fused_kernel, dim3(blocks), dim3(64 * SF_WAVES), lds, (hipStream_t)stream, N, IH,
                        (const bf16_t*)x_padded, (uint32_t)xb, (const bf16_t*)w_ohwi8, eps, (bf16_t*)y_pool, idx, mean_rstd);
@@ -485,8 +488,7 @@ extern "C" int eve_stem_bwd_dx(int N, int IH, int IW, const void* x_padded, cons
         (void)hipFuncSetAttribute((const void*)stem_bwd_dx_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    unsigned blocks = (unsigned)((N + SF_WAVES - 1) / SF_WAVES);
-    if (blocks > 256) blocks = 256;
+    unsigned blocks = N < 256 ? (unsigned)N : 256u;
     EVE_MARK_KERNEL("stem_bwd_dx_kernel");
     hipLaunchKernelGGL(stem_bwd_dx_kernel, dim3(blocks), dim3(64 * SF_WAVES), lds, (hipStream_t)stream, N, IH,
                        (const bf16_t*)x_padded, (uint32_t)xb, (const bf16_t*)w_ohwi8, mean_rstd, (const bf16_t*)dy_pool,
