@@ -263,3 +263,113 @@ def test_eve_harness_matches_reference_eve(golden_dir, tag):
                     assert got[str(n)] < 0, n
                 else:
                     assert abs(got[str(n)] - want) <= 2e-3 * want + 1e-6, (n, got[str(n)], want)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The ResNet-18(InstanceNorm) trunk against an INDEPENDENT implementation (transformers' ResNet, BatchNorm swapped for
+# InstanceNorm2d; tests/golden/make_golden_trunk.py): the only external arithmetic available for the un-vendored
+# torchvision 0.6.1 trunk of /root/reference/src/models/eye_net.py:26,48-50,106.
+def trunk_taps_and_grads(cnn, x, proj):
+    """Stage outputs, pooled features, fc output of an oracle-shaped ResNet (`conv1, bn1, relu, maxpool, layer1..4,
+    avgpool, fc`) and its parameter gradients for the scalar sum(fc * proj)."""
+    taps = {}
+    hooks = [getattr(cnn, nm).register_forward_hook(lambda m, i, o, nm=nm: taps.__setitem__(nm, o))
+             for nm in ('maxpool', 'layer1', 'layer2', 'layer3', 'layer4', 'avgpool')]
+    y = cnn(x)
+    for h in hooks:
+        h.remove()
+    (y * proj).sum().backward()
+    return taps, y
+
+
+def check_trunk_case(fx, tag, taps, pooled, fc_out, grads, atol, grad_rtol):
+    """taps: name -> N x C x H x W tensors (any subset), grads: torchvision-style name -> tensor."""
+    for nm, v in taps.items():
+        v = v.detach().double().cpu()
+        scale = float(np.sqrt(fx['%s_tap_%s_sqsum' % (tag, nm)] / v.numel()))            # RMS of the stage output
+        np.testing.assert_allclose(v.reshape(v.shape[0], -1)[:, :256].float().numpy(), fx['%s_tap_%s_head' % (tag, nm)],
+                                   atol=atol * max(scale, 1.0), rtol=0, err_msg=nm)
+        np.testing.assert_allclose(float(v.sum()), float(fx['%s_tap_%s_sum' % (tag, nm)]),
+                                   atol=atol * scale * v.numel() ** 0.5 * 4, rtol=0, err_msg=nm + ' checksum')
+        np.testing.assert_allclose(float((v * v).sum()), float(fx['%s_tap_%s_sqsum' % (tag, nm)]), rtol=20 * atol,
+                                   err_msg=nm + ' sum of squares')
+    if 'layer4' in taps:
+        np.testing.assert_allclose(taps['layer4'].detach().float().cpu().numpy(), fx[tag + '_layer4'], atol=atol * 4, rtol=0)
+    np.testing.assert_allclose(pooled.detach().float().cpu().numpy(), fx[tag + '_pooled'], atol=atol, rtol=0)
+    np.testing.assert_allclose(fc_out.detach().float().cpu().numpy(), fx[tag + '_fc'], atol=atol * 4, rtol=0)
+    for n, ref_norm, head in zip(fx[tag + '_grad_names'], fx[tag + '_grad_norms'], fx[tag + '_grad_heads']):
+        g = grads[str(n)].detach().double().cpu().reshape(-1)
+        assert abs(float(g.norm()) - ref_norm) <= grad_rtol * ref_norm, '%s: |g| %.6g vs %.6g' % (n, float(g.norm()), ref_norm)
+        k = min(64, g.numel())
+        np.testing.assert_allclose(g[:k].float().numpy(), head[:k], atol=grad_rtol * ref_norm / g.numel() ** 0.5 * 8 + 1e-7,
+                                   rtol=0, err_msg=str(n))
+
+
+@pytest.mark.parametrize('tag', ['p128', 'p256'])
+def test_trunk_restatement_matches_independent_resnet(golden_dir, tag):
+    from oracle.resnet_in import BasicBlock, ResNet
+    fx = load(golden_dir, 'trunk_independent.npz')
+    size, B, T, seed = (int(fx['%s_%s' % (tag, k)]) for k in ('size', 'B', 'T', 'seed'))
+    cnn = ResNet(block=BasicBlock, layers=[2, 2, 2, 2], num_classes=128, norm_layer=torch.nn.InstanceNorm2d)
+    with torch.no_grad():
+        for n, t in cnn.state_dict().items():
+            t.copy_(detweights.tensor_for('cnn_layers.' + n, t.shape, 0))
+    batch = detweights.eyenet_batch(B, T, size=size, seed=seed)
+    x = torch.cat([batch['left_eye_patch'].reshape(B * T, 3, size, size),
+                   batch['right_eye_patch'].reshape(B * T, 3, size, size)], dim=0)
+    taps, y = trunk_taps_and_grads(cnn, x, torch.from_numpy(fx[tag + '_proj']))
+    pooled = taps.pop('avgpool').flatten(1)
+    grads = {n: p.grad for n, p in cnn.named_parameters()}
+    check_trunk_case(fx, tag, taps, pooled, y, grads, atol=1e-5, grad_rtol=1e-4)
+    assert float(np.abs(fx[tag + '_fc']).max()) > 0.1
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The rounding-faithful mode of the oracle (oracle/bf16_faithful.py) is tied to the pinned float32 oracle: with its
+# rounding points switched off it must reproduce the oracle's outputs and gradients.
+def _grad_rel(a, b):
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def test_bf16_faithful_mode_without_rounding_is_the_float32_oracle_eyenet():
+    from oracle import bf16_faithful as bf
+    cfg = eye_cfg()
+    net = detweights.fill_module(EyeNet(cfg), seed=0)
+    batch = detweights.eyenet_batch(2, 3, seed=0, invalid_fraction=0.25)
+    ref = sequence.eyenet_sequence(net, batch)
+    sequence.eyenet_losses(ref, batch, cfg)['full_loss'].backward()
+    g_ref = {n: p.grad.clone() for n, p in net.named_parameters()}
+    net.zero_grad()
+    with bf.rounding(False):
+        out = bf.eyenet_sequence(net, batch)
+        sequence.eyenet_losses(out, batch, cfg)['full_loss'].backward()
+    for k in ref:
+        assert float((ref[k] - out[k]).abs().max()) < 1e-6, k
+    for n, p in net.named_parameters():
+        assert _grad_rel(p.grad, g_ref[n]) < 1e-4, n
+    # and with rounding on it is a different (bf16-sized) computation: the mode does something
+    with torch.no_grad():
+        out16 = bf.eyenet_sequence(net, batch)
+    dev = float((out16['left_g_initial'] - ref['left_g_initial']).abs().max())
+    assert 1e-4 < dev < 0.1, dev
+
+
+def test_bf16_faithful_mode_without_rounding_is_the_float32_oracle_refinenet():
+    from oracle import bf16_faithful as bf
+    cfg = OracleConfig(load_screen_content=True, refine_net_enabled=True, refine_net_rnn_type='CGRU')
+    net = detweights.fill_module(RefineNet(cfg), seed=1)
+    rb = detweights.refinenet_batch(2, 3, seed=0, invalid_fraction=0.25)
+    hf, st = sequence.refinenet_sequence(net, rb['heatmap_initial'], rb['screen_frame'])
+    sequence.refinenet_losses(hf, rb['heatmap_final_gt'], rb['validity'], cfg)['full_loss'].backward()
+    g_ref = {n: p.grad.clone() for n, p in net.named_parameters()}
+    net.zero_grad()
+    with bf.rounding(False):
+        hf2, st2 = bf.refinenet_sequence(net, rb['heatmap_initial'], rb['screen_frame'])
+        sequence.refinenet_losses(hf2, rb['heatmap_final_gt'], rb['validity'], cfg)['full_loss'].backward()
+    assert float((hf - hf2).abs().max()) < 1e-6
+    assert float((st[-1] - st2[-1]).abs().max()) < 1e-6
+    for n, p in net.named_parameters():
+        if float(g_ref[n].norm()) < 1e-6:        # biases in front of an InstanceNorm: exactly zero gradient, float noise
+            assert float(p.grad.norm()) < 1e-6, n
+        else:
+            assert _grad_rel(p.grad, g_ref[n]) < 1e-4, n
