@@ -88,6 +88,10 @@ SIGNATURES = {
     'eve_cgru_gates2_bwd': [I, L, I, P, P, P, P, P, P, P, P],
     'eve_cgru_gates1_bwd': [I, L, I, P, P, P, P, P, P, P],
     'eve_clstm_gates_fwd': [I, L, I, P, P, P, P, P],
+    'eve_heatmap_head_fwd': [I, L, I, P, P, P],
+    'eve_heatmap_head_bwd': [I, L, I, P, P, P, P],
+    'eve_heatmap_loss_fwd': [I, I, I, I, P, P, P, P, P, P, P],
+    'eve_heatmap_loss_bwd': [I, I, I, P, P, P, P, P, P],
     'eve_sumsq': [L, P, P, P],
     'eve_adam_step': [L, P, P, P, P, P, F, F, F, F, F, F, F, I, P, P],
 }

@@ -1,40 +1,70 @@
-"""Build libeve_hip.so (the C-ABI HIP library) in-tree with hipcc for gfx950."""
+"""Build libeve_hip.so (the C-ABI HIP library) in-tree with hipcc for gfx950.
+
+Every csrc/*.hip is compiled to its own object (in parallel, re-used while neither the source nor any header
+changed) and the objects are linked into eve_amd/lib/libeve_hip.so."""
 import glob
 import os
 import subprocess
+from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB_DIR = os.path.join(HERE, 'lib')
+OBJ_DIR = os.path.join(LIB_DIR, 'obj')
 LIB_PATH = os.path.join(LIB_DIR, 'libeve_hip.so')
+FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC']
 
 
 def sources():
     return sorted(glob.glob(os.path.join(CSRC, '*.hip')))
 
 
+def headers():
+    return glob.glob(os.path.join(CSRC, '*.h')) + [os.path.join(os.path.dirname(HERE), 'include', 'eve_hip.h')]
+
+
 def needs_build():
     if not os.path.isfile(LIB_PATH):
         return True
     t = os.path.getmtime(LIB_PATH)
-    deps = sources() + glob.glob(os.path.join(CSRC, '*.h')) + \
-        [os.path.join(os.path.dirname(HERE), 'include', 'eve_hip.h')]
-    return any(os.path.getmtime(p) > t for p in deps)
+    return any(os.path.getmtime(p) > t for p in sources() + headers())
 
 
 def build(force=False, verbose=True):
-    """hipcc --offload-arch=gfx950 -O3 -shared -fPIC csrc/*.hip -> eve_amd/lib/libeve_hip.so"""
+    """hipcc --offload-arch=gfx950 -O3 -c csrc/X.hip (each) ; hipcc -shared -> eve_amd/lib/libeve_hip.so"""
     if not force and not needs_build():
         return LIB_PATH
-    os.makedirs(LIB_DIR, exist_ok=True)
+    os.makedirs(OBJ_DIR, exist_ok=True)
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
-    cmd = [hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-shared', '-fPIC',
-           '-o', LIB_PATH] + sources()
+    hdr_time = max(os.path.getmtime(p) for p in headers())
+    jobs, objs = [], []
+    for src in sources():
+        obj = os.path.join(OBJ_DIR, os.path.basename(src)[:-4] + '.o')
+        objs.append(obj)
+        stale = force or not os.path.isfile(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), hdr_time)
+        if stale:
+            jobs.append([hipcc] + FLAGS + ['-c', src, '-o', obj])
+
+    def run(cmd):
+        if verbose:
+            print(' '.join(cmd), flush=True)
+        p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        return cmd, p.returncode, p.stdout
+
+    with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 4) or 1) as ex:
+        for cmd, rc, out in ex.map(run, jobs):
+            if rc != 0:
+                raise RuntimeError('hipcc failed: %s\n%s' % (' '.join(cmd), out))
+    stale_objs = set(glob.glob(os.path.join(OBJ_DIR, '*.o'))) - set(objs)
+    for o in stale_objs:                   # a source file was removed
+        os.remove(o)
+    link = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB_PATH] + objs
     if verbose:
-        print(' '.join(cmd), flush=True)
-    subprocess.check_call(cmd)
+        print(' '.join(link), flush=True)
+    subprocess.check_call(link)
     return LIB_PATH
 
 
 if __name__ == '__main__':
-    build(force=True)
+    import sys
+    build(force='--force' in sys.argv)

@@ -159,6 +159,11 @@ class EyeNet(nn.Module):
     def _trunk(self, x, P, x_padded=None):
         """x: [N, H, W, Cpad] NHWC compute dtype -> [N, 512] float32 (torchvision ResNet._forward_impl).
         x_padded: optional [N, H+6, W+8, 4] bf16 repack for the dedicated stem kernel."""
+        feats = ops.AvgPoolFn.apply(self._trunk_layers(x, P, x_padded))
+        return ops.cast(feats, torch.float32)
+
+    def _trunk_layers(self, x, P, x_padded=None):
+        """conv1 .. layer4 of the trunk: -> [N, H/32, W/32, 512] NHWC compute dtype."""
         cnn = self.cnn_layers
         blocks, weights = [], []
         for name, blk in cnn.blocks():
@@ -176,8 +181,7 @@ class EyeNet(nn.Module):
                 y = ops.conv2d(x, cnn.conv1.weight, None, P['conv1'], stride=2, pad=3)
             y = ops.InReluMaxPoolFn.apply(y, 1e-5)      # bn1 -> relu -> maxpool, fused
             y = ops.ResNetTrunkFn.apply(y, None, None, (None, tuple(blocks)), 1e-5, *weights)
-        feats = ops.AvgPoolFn.apply(y)
-        return ops.cast(feats, torch.float32)
+        return y
 
     # ------------------------------------------------------------------ tail: fc -> fc_common -> GRU -> heads
     def _tail(self, feats, head_pose, S, T, h0, P):

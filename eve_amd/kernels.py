@@ -330,6 +330,50 @@ class HipKernels(object):
                                                   float(screen[0]), float(screen[1]), self._p(dh[i:i + n]), self._stream()))
         return dh
 
+    # ------------------------------------------------------------------ RefineNet head + heat-map losses
+    def heatmap_head_fwd(self, logits):
+        """logits NHWC [N, H, W, Cpad] (channel 0 is the map) -> float [N, 1, H, W] = sigmoid, evaluated in float."""
+        N, H, W, Cp = logits.shape
+        out = torch.empty((N, 1, H, W), dtype=torch.float32, device=logits.device)
+        self._ck(self.lib.eve_heatmap_head_fwd(dt_code(logits.dtype), N * H * W, Cp, self._p(logits), self._p(out),
+                                               self._stream()))
+        return out
+
+    def heatmap_head_bwd(self, dy, y, dtype, cpad):
+        N, _, H, W = y.shape
+        dy = dy.contiguous().float()
+        dl = torch.empty((N, H, W, cpad), dtype=dtype, device=y.device)
+        self._ck(self.lib.eve_heatmap_head_bwd(dt_code(dtype), N * H * W, cpad, self._p(dy), self._p(y), self._p(dl),
+                                               self._stream()))
+        return dl
+
+    def heatmap_loss_fwd(self, kind, pred, gt, validity):
+        """kind 0 = BCE, 1 = MSE; pred, gt float [B, T, ...map...]; validity bool/uint8 [B, T].
+        Returns (loss 0-dim, w [B*T] = d loss / d per-frame mean)."""
+        B, T = pred.shape[:2]
+        HW = pred[0, 0].numel()
+        pred, gt = pred.contiguous(), gt.contiguous()
+        assert pred.dtype == torch.float32 and gt.dtype == torch.float32 and gt.shape == pred.shape
+        v = validity.contiguous()
+        v = v.view(torch.uint8) if v.dtype == torch.bool else v.to(torch.uint8)
+        assert tuple(v.shape) == (B, T)
+        per_map = torch.empty((B * T,), dtype=torch.float32, device=pred.device)
+        w = torch.empty((B * T,), dtype=torch.float32, device=pred.device)
+        loss = torch.empty((1,), dtype=torch.float32, device=pred.device)
+        self._ck(self.lib.eve_heatmap_loss_fwd(kind, B, T, HW, self._p(pred), self._p(gt), self._p(v), self._p(per_map),
+                                               self._p(loss), self._p(w), self._stream()))
+        return loss.view(()), w
+
+    def heatmap_loss_bwd(self, kind, pred, gt, w, upstream):
+        B, T = pred.shape[:2]
+        HW = pred[0, 0].numel()
+        pred, gt = pred.contiguous(), gt.contiguous()
+        up = upstream.detach().float().reshape(1).contiguous()
+        dp = torch.empty_like(pred)
+        self._ck(self.lib.eve_heatmap_loss_bwd(kind, B * T, HW, self._p(pred), self._p(gt), self._p(w), self._p(up),
+                                               self._p(dp), self._stream()))
+        return dp
+
     # ------------------------------------------------------------------ fused train-step losses
     def eye_losses(self, g_pred, g_tgt, g_val, p_pred, p_tgt, p_val, coeff_ang, coeff_l1):
         """Each argument is a (left, right) pair.  Returns terms[5], (dg_l, dg_r), (dp_l, dp_r)."""

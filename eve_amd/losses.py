@@ -1,5 +1,7 @@
-"""Validity-masked sequence losses of the train step, batched over clips (device-side tensor ops on
-[B, T, ...] outputs -- a few KB; not part of the kernel hot path).
+"""Validity-masked sequence losses of the train step, batched over clips.  The terms over [B, T, k] predictions
+(gaze angles, PoG, pupil size: a few KB) are small device-side tensor expressions, the four EyeNet terms one fused
+kernel (EyeLossesFn); the terms over [B, T, 1, 72, 128] heat-maps (35 MB at B=32 x T=30) run on the HIP kernels of
+csrc/heatmap_loss.hip (ops.HeatmapLossFn).
 
 Semantics of /root/reference/src/losses/: per clip, sum over valid time steps divided by the number
 of valid steps when that number exceeds one, then the mean over clips
@@ -42,7 +44,17 @@ def l1_loss(pred, target, validity):
     return _masked_clip_mean(_per_step((pred - target).abs()), validity)
 
 
+def _heatmap_kernel_ok(pred, target):
+    """[B, T, 1, H, W] float maps on the GPU go through the fused kernels (csrc/heatmap_loss.hip); the [B, T, k]
+    point-of-gaze terms below stay small tensor expressions."""
+    return pred.dim() == 5 and pred.is_cuda and pred.dtype == torch.float32 and target.dtype == torch.float32 \
+        and target.shape == pred.shape and not target.requires_grad
+
+
 def mse_loss(pred, target, validity):
+    if _heatmap_kernel_ok(pred, target):
+        from .ops import HeatmapLossFn
+        return HeatmapLossFn.apply(pred, target, validity, 1)
     return _masked_clip_mean(_per_step((pred - target) ** 2), validity)
 
 
@@ -51,6 +63,9 @@ def euclidean_loss(pred, target, validity):                 # euclidean.py:27-33
 
 
 def bce_loss(pred, target, validity):
+    if _heatmap_kernel_ok(pred, target):
+        from .ops import HeatmapLossFn
+        return HeatmapLossFn.apply(pred, target, validity, 0)
     return _masked_clip_mean(_per_step(F.binary_cross_entropy(pred, target, reduction='none')), validity)
 
 

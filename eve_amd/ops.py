@@ -954,3 +954,39 @@ class SoftArgmaxFn(torch.autograd.Function):
     def backward(ctx, dpx):
         heat, stats = ctx.saved_tensors
         return default_kernels().soft_argmax_bwd(heat, stats, dpx.contiguous(), ctx.screen), None
+
+
+# ---- RefineNet output head and the heat-map losses (kernels in csrc/heatmap_loss.hip) ---------------------------------
+class HeatmapHeadFn(torch.autograd.Function):
+    """heatmap_final [N,1,H,W] float = sigmoid(channel 0 of the last convolution's NHWC logits), evaluated in float
+    whatever the compute dtype (refine_net.py:221-223,255): the map feeds a float BCE and a softmax(100 h)."""
+
+    @staticmethod
+    def forward(ctx, logits):
+        y = default_kernels().heatmap_head_fwd(logits.contiguous())
+        ctx.meta = (logits.dtype, logits.shape[3])
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        y, = ctx.saved_tensors
+        return default_kernels().heatmap_head_bwd(dy, y, *ctx.meta)
+
+
+class HeatmapLossFn(torch.autograd.Function):
+    """Validity-masked heat-map loss over [B,T,1,H,W] float maps: kind 0 = loss_ce_heatmap_* (cross_entropy.py:27-35),
+    kind 1 = loss_mse_heatmap_final (mse.py), with base_loss_with_validity.py:64-73's reduction -- two launches
+    forward, one backward, no host sync."""
+
+    @staticmethod
+    def forward(ctx, pred, gt, validity, kind):
+        loss, w = default_kernels().heatmap_loss_fwd(kind, pred, gt, validity)
+        ctx.kind = kind
+        ctx.save_for_backward(pred, gt, w)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        pred, gt, w = ctx.saved_tensors
+        return default_kernels().heatmap_loss_bwd(ctx.kind, pred, gt, w, g), None, None, None

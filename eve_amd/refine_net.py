@@ -25,7 +25,7 @@ from torch import nn
 from . import ops
 from .config import get_config
 from .eye_net import default_compute_dtype
-from .kernels import ACT_LEAKY, ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH, default_kernels, pad_channels
+from .kernels import ACT_LEAKY, ACT_NONE, ACT_RELU, ACT_TANH, default_kernels, pad_channels
 from .ops import PackedWeight
 
 
@@ -140,6 +140,10 @@ class RefineNet(nn.Module):
         nn.init.zeros_(self.final[-2].weight)
         self._packs = None
         self._packs_key = None
+        self._probe = None          # test hook: callable(name, NHWC tensor) -> tensor at every stage boundary
+
+    def _tap(self, name, x):
+        return x if self._probe is None else self._probe(name, x)
 
     # ------------------------------------------------------------------ packed weights
     def invalidate_packs(self):
@@ -179,17 +183,18 @@ class RefineNet(nn.Module):
     def _encode(self, x, P):
         """Runs `initial` and every level's encoder on the folded frame batch.
         Returns the bottleneck input and the per-level encoder outputs (outermost first)."""
+        x = self._tap('input', x)
         x = self._conv(x, 'initial.0', self.initial[0], P)
         x = ops.instnorm_act(x, self.initial[1].weight, self.initial[1].bias, act=ACT_RELU)
-        x = self._conv(x, 'initial.3', self.initial[3], P)
-        skips, level, prefix = [], self.network, 'network'
+        x = self._tap('initial', self._conv(x, 'initial.3', self.initial[3], P))
+        skips, level, prefix, depth = [], self.network, 'network', 0
         while isinstance(level, WrapEncoderDecoder):
             for i, blk in enumerate(level.encoder_blocks):
-                x = self._block(x, blk, '%s.encoder_blocks.%d' % (prefix, i), P)
+                x = self._tap('enc%d.%d' % (depth, i), self._block(x, blk, '%s.encoder_blocks.%d' % (prefix, i), P))
             skips.append(x)
             if level.downsample is not None:
-                x = ops.AdaptiveMaxPoolFn.apply(x, tuple(level.inner_hw))
-            level, prefix = level.between_module, prefix + '.between_module'
+                x = self._tap('pool%d' % depth, ops.AdaptiveMaxPoolFn.apply(x, tuple(level.inner_hw)))
+            level, prefix, depth = level.between_module, prefix + '.between_module', depth + 1
         return x, skips, prefix
 
     def _decode(self, x, skips, P):
@@ -197,15 +202,17 @@ class RefineNet(nn.Module):
         while isinstance(level, WrapEncoderDecoder):
             levels.append((level, prefix))
             level, prefix = level.between_module, prefix + '.between_module'
-        for (level, prefix), enc in zip(reversed(levels), reversed(skips)):
+        for depth, (level, prefix), enc in zip(reversed(range(len(levels))), reversed(levels), reversed(skips)):
             if level.upsample is not None:
-                x = ops.BilinearFn.apply(x, (level.out_shape[1], level.out_shape[2]))
+                x = self._tap('up%d' % depth, ops.BilinearFn.apply(x, (level.out_shape[1], level.out_shape[2])))
             if level.add_skip_connection:
                 x = torch.cat([x, enc], dim=-1)
             for i, blk in enumerate(level.decoder_blocks):
-                x = self._block(x, blk, '%s.decoder_blocks.%d' % (prefix, i), P)
-        x = self._conv(x, 'final.0', self.final[0], P, act=ACT_LEAKY)
-        return self._conv(x, 'final.2', self.final[2], P, act=ACT_SIGMOID)     # channel 0 is the map
+                x = self._tap('dec%d.%d' % (depth, i), self._block(x, blk, '%s.decoder_blocks.%d' % (prefix, i), P))
+        x = self._tap('final0', self._conv(x, 'final.0', self.final[0], P, act=ACT_LEAKY))
+        # logits of the last 1x1 convolution (channel 0); the sigmoid is evaluated in float by the head kernel
+        logits = self._tap('logits', self._conv(x, 'final.2', self.final[2], P))
+        return ops.HeatmapHeadFn.apply(logits)                                 # [N, 1, H, W] float
 
     # ------------------------------------------------------------------ conv-RNN bottleneck, one step
     def _cell_step(self, x, state, cell, prefix, P):
@@ -285,7 +292,7 @@ class RefineNet(nn.Module):
         for i, st in enumerate(new_states):
             output_dict['refinenet_rnn_states_%d' % i] = self._state_out(st)
         y = self._decode(x, skips, P)
-        output_dict['heatmap_final'] = ops.FromNHWCFn.apply(y, 1)
+        output_dict['heatmap_final'] = y
 
     # ------------------------------------------------------------------ whole clips in one pass
     def forward_sequence(self, heatmap_initial, screen_frame=None):
@@ -312,7 +319,7 @@ class RefineNet(nn.Module):
             cell, name = cells[0], '%s.rnn_cells.0' % prefix
             hs = ops.CGRUScanFn.apply(xs.contiguous(), cell.gates_1.weight, cell.gates_1.bias, cell.gate_2.weight,
                                       cell.gate_2.bias, None, P[name + '.gates_1'], P[name + '.gate_2'])
-            x = hs.reshape(B * T, x.shape[1], x.shape[2], C)
+            x = self._tap('rnn', hs.reshape(B * T, x.shape[1], x.shape[2], C))
             hist = [[hs[:, t].contiguous()] for t in range(T)]
         else:
             outs, states, hist = [], None, []
@@ -321,8 +328,7 @@ class RefineNet(nn.Module):
                 outs.append(xt)
                 hist.append(states)
             x = torch.stack(outs, dim=1).view(B * T, x.shape[1], x.shape[2], C)
-        y = self._decode(x, skips, P)
-        hf = ops.FromNHWCFn.apply(y, 1)
+        hf = self._decode(x, skips, P)
         stacked = []
         for i in range(len(hist[0]) if hist else 0):
             per_t = [self._state_out(h[i]) for h in hist]

@@ -319,6 +319,25 @@ int eve_clstm_gates_fwd(int dtype, long long P, int C, const void* gates, const 
                         void* c, eve_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * RefineNet output head and the heat-map losses (csrc/heatmap_loss.hip).
+ * ------------------------------------------------------------------------------------------------ */
+/* nn.Sigmoid of `final` (src/models/refine_net.py:221-223) evaluated in float: logits = channel 0 of the last 1x1
+ * convolution's NHWC output [pixels][Cpad] (compute dtype) -> out float [pixels] (= heatmap_final [N][1][H][W]).   */
+int eve_heatmap_head_fwd(int dtype, long long pixels, int Cpad, const void* logits, float* out, eve_stream_t stream);
+/* dlogits[pixel][c] = c == 0 ? dy * y * (1 - y) : 0, compute dtype                                                   */
+int eve_heatmap_head_bwd(int dtype, long long pixels, int Cpad, const float* dy, const float* y, void* dlogits,
+                         eve_stream_t stream);
+/* loss_ce_heatmap_* (kind 0: F.binary_cross_entropy per frame, src/losses/cross_entropy.py:27-35) or
+ * loss_mse_heatmap_final (kind 1, src/losses/mse.py) with the validity reduction of
+ * src/losses/base_loss_with_validity.py:64-73.  pred, gt float [B][T][HW]; validity uint8 [B][T]; outputs:
+ * per_map float [B*T] (per-frame means), loss float [1], w float [B*T] = d loss / d per_map.                        */
+int eve_heatmap_loss_fwd(int kind, int B, int T, int HW, const float* pred, const float* gt, const uint8_t* validity,
+                         float* per_map, float* loss, float* w, eve_stream_t stream);
+/* dpred = upstream[0] * w[frame] / HW * d(element loss)/d pred  (upstream: device scalar, no host sync)             */
+int eve_heatmap_loss_bwd(int kind, int BT, int HW, const float* pred, const float* gt, const float* w,
+                         const float* upstream, float* dpred, eve_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Optimiser step over flat float buffers.  torch.optim.Adam with coupled L2 weight decay
  * (src/train.py:49-55) after nn.utils.clip_grad_norm_ (src/core/training.py:492-498).
  * ------------------------------------------------------------------------------------------------ */

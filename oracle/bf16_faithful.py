@@ -68,6 +68,15 @@ def Rf(x):
     return _Round.apply(x, True, False)
 
 
+def _tap(taps, name, x):
+    """Record a stage boundary (for teacher-forced, stage-local comparisons): the tensor with its gradient retained."""
+    if taps is not None:
+        if x.requires_grad:
+            x.retain_grad()
+        taps[name] = x
+    return x
+
+
 class _ActFromOutput(torch.autograd.Function):
     """y = bf16(act(z)); dz = bf16(dy * act'(.)) with act' evaluated from the STORED y, as the conv epilogues /
     eve_act_bwd do for sigmoid and tanh (eve_amd/csrc/common.h act_grad_from_out)."""
@@ -111,23 +120,39 @@ def in_act(x, norm=None, res=None, act=None, eps=1e-5):
 
 
 # ----------------------------------------------------------------------------------------------------- EyeNet
-def resnet_trunk(cnn, x):
-    """oracle.resnet_in.ResNet `cnn` up to the pooled 512 features, N x 3 x H x W float -> N x 512 (bf16-valued).
-    Stem as stem_fused.hip computes it: conv accumulators stay float32 through InstanceNorm / ReLU / max-pool (the
-    convolution output is never stored), only the pooled tensor is bf16; its backward stores d(conv) in bf16."""
+def resnet_stem(cnn, x):
+    """conv1 -> bn1 -> relu -> maxpool as stem_fused.hip computes it: the convolution output is never stored, statistics
+    come from the float32 accumulators, only the pooled tensor is bf16; its backward stores d(conv) in bf16."""
     c = F.conv2d(Rf(x), Rf(cnn.conv1.weight), None, 2, 3)
     c = Rb(c)
-    y = R(F.max_pool2d(F.relu(F.instance_norm(c, eps=1e-5)), 3, 2, 1))
-    for layer in (cnn.layer1, cnn.layer2, cnn.layer3, cnn.layer4):
-        for blk in layer:
-            a = conv(y, blk.conv1)
-            an = in_act(a, act='relu')
-            b = conv(an, blk.conv2)
-            idn = y
-            if blk.downsample is not None:
-                idn = in_act(conv(y, blk.downsample[0]))
-            y = in_act(b, res=idn, act='relu')
-    return R(y.mean(dim=(2, 3)))            # avg-pool kernel: float sum of the bf16 plane, bf16 result
+    mean = c.mean(dim=(2, 3), keepdim=True)
+    var = c.var(dim=(2, 3), unbiased=False, keepdim=True)
+    # relu(IN(.)) is monotone per channel, so the kernel pools the RAW convolution values, parks the window maxima in
+    # bf16 (stem_fused.hip: "writes only the pooled 32x32x64 tensor (raw, bf16)") and normalises them once the plane
+    # statistics are known: the pooled value is rounded before AND after the normalisation
+    p = Rf(F.max_pool2d(c, 3, 2, 1))
+    return R(F.relu((p - mean) * torch.rsqrt(var + 1e-5)))
+
+
+def resnet_block(blk, y):
+    """torchvision BasicBlock with InstanceNorm2d: out = relu(IN(conv2(relu(IN(conv1(x))))) + identity)."""
+    a = conv(y, blk.conv1)
+    an = in_act(a, act='relu')
+    b = conv(an, blk.conv2)
+    idn = y
+    if blk.downsample is not None:
+        idn = in_act(conv(y, blk.downsample[0]))
+    return in_act(b, res=idn, act='relu')
+
+
+def resnet_trunk(cnn, x, taps=None):
+    """oracle.resnet_in.ResNet `cnn` up to the pooled 512 features, N x 3 x H x W float -> N x 512 (bf16-valued).
+    taps (dict): receives 'stem', 'layer<L>.<B>' (block outputs) and 'pooled'."""
+    y = _tap(taps, 'stem', resnet_stem(cnn, x))
+    for li, layer in enumerate((cnn.layer1, cnn.layer2, cnn.layer3, cnn.layer4), start=1):
+        for bi, blk in enumerate(layer):
+            y = _tap(taps, 'layer%d.%d' % (li, bi), resnet_block(blk, y))
+    return _tap(taps, 'pooled', R(y.mean(dim=(2, 3))))     # avg-pool kernel: float sum of the bf16 plane, bf16 result
 
 
 def eyenet_tail_step(net, feats, head_pose, prev_states):
@@ -202,7 +227,7 @@ def cgru_step(cell, x, h):
     return R((1. - u) * o + u * Rb(h))
 
 
-def refinenet_sequence(net, heatmap_initial, screen_frame=None, float_sigmoid=True):
+def refinenet_sequence(net, heatmap_initial, screen_frame=None, float_sigmoid=True, taps=None):
     """oracle.sequence.refinenet_sequence's contract (heatmap_final B x T x 1 x 72 x 128, per-step CGRU states) with the
     encoder / decoder on the folded B*T frame batch, as RefineNet.forward_sequence runs it.  CGRU only (the benchmarked
     cell); the final sigmoid is evaluated in float32 from the bf16 logits when `float_sigmoid` (eve_amd does so since
@@ -216,20 +241,20 @@ def refinenet_sequence(net, heatmap_initial, screen_frame=None, float_sigmoid=Tr
     if tuple(heat.shape[-2:]) != size:
         heat = R(F.interpolate(Rf(heat), size, mode='bilinear', align_corners=False))
     x = torch.cat([fold(screen_frame), heat], dim=1) if cfg.load_screen_content else heat
-    x = Rf(x)
+    x = _tap(taps, 'input', Rf(x))
     x = conv(x, net.initial[0])
-    x = conv(in_act(x, net.initial[1], act='relu'), net.initial[3])
+    x = _tap(taps, 'initial', conv(in_act(x, net.initial[1], act='relu'), net.initial[3]))
     levels, level = [], net.network
     while isinstance(level, WrapEncoderDecoder):
         levels.append(level)
         level = level.between_module
     skips = []
-    for lv in levels:
-        for blk in lv.encoder_blocks:
-            x = _preact_block(x, blk, 'relu')
+    for d, lv in enumerate(levels):
+        for i, blk in enumerate(lv.encoder_blocks):
+            x = _tap(taps, 'enc%d.%d' % (d, i), _preact_block(x, blk, 'relu'))
         skips.append(x)
         if lv.downsample is not None:
-            x = R(lv.downsample(Rb(x)))
+            x = _tap(taps, 'pool%d' % d, R(lv.downsample(Rb(x))))
     states = []
     cells = list(level.rnn_cells) if cfg.refine_net_use_rnn else []
     if cells:
@@ -240,17 +265,17 @@ def refinenet_sequence(net, heatmap_initial, screen_frame=None, float_sigmoid=Tr
             h = cgru_step(cells[0], xs[:, t], h)
             hs.append(h)
         states = hs
-        x = torch.stack(hs, dim=1).view_as(x)
-    for lv, enc in zip(reversed(levels), reversed(skips)):
+        x = _tap(taps, 'rnn', torch.stack(hs, dim=1).view_as(x))
+    for d, lv, enc in zip(reversed(range(len(levels))), reversed(levels), reversed(skips)):
         if lv.upsample is not None:
-            x = R(lv.upsample(Rb(x)))
+            x = _tap(taps, 'up%d' % d, R(lv.upsample(Rb(x))))
         if lv.add_skip_connection:
             x = torch.cat([Rb(x), Rb(enc)], dim=1)
-        for blk in lv.decoder_blocks:
-            x = _preact_block(x, blk, 'leaky')
-    x = R(F.leaky_relu(conv(x, net.final[0], pre_act_out=True), 0.01))
+        for i, blk in enumerate(lv.decoder_blocks):
+            x = _tap(taps, 'dec%d.%d' % (d, i), _preact_block(x, blk, 'leaky'))
+    x = _tap(taps, 'final0', R(F.leaky_relu(conv(x, net.final[0], pre_act_out=True), 0.01)))
     if float_sigmoid:
-        hf = torch.sigmoid(conv(x, net.final[2]))
+        hf = torch.sigmoid(_tap(taps, 'logits', conv(x, net.final[2])))
     else:
         hf = _ActFromOutput.apply(F.conv2d(Rb(x), Rf(net.final[2].weight), net.final[2].bias), 'sigmoid')
     return hf.view(B, T, 1, hf.shape[2], hf.shape[3]), states

@@ -457,3 +457,39 @@ def _install_frame_fakes():
 
 
 _install_frame_fakes()
+
+
+def _install_heatmap_fakes():
+    """Contracts of eve_heatmap_head_* / eve_heatmap_loss_* (include/eve_hip.h) with ATen ops."""
+    def heatmap_head_fwd(self, logits):
+        return torch.sigmoid(logits[..., 0].float()).unsqueeze(1).contiguous()
+
+    def heatmap_head_bwd(self, dy, y, dtype, cpad):
+        N, _, H, W = y.shape
+        dl = torch.zeros((N, H, W, cpad), dtype=dtype)
+        dl[..., 0] = (dy.float() * y * (1 - y))[:, 0].to(dtype)
+        return dl
+
+    def _per_map(kind, pred, gt):
+        if kind == 0:
+            return F.binary_cross_entropy(pred, gt, reduction='none').flatten(2).mean(dim=2)
+        return ((pred - gt) ** 2).flatten(2).mean(dim=2)
+
+    def heatmap_loss_fwd(self, kind, pred, gt, validity):
+        v = validity.float()
+        n = v.sum(dim=1, keepdim=True)
+        den = torch.where(n > 1, n, torch.ones_like(n))
+        w = v / (den * pred.shape[0])
+        return (_per_map(kind, pred, gt) * w).sum(), w.reshape(-1)
+
+    def heatmap_loss_bwd(self, kind, pred, gt, w, upstream):
+        with torch.enable_grad():
+            p = pred.detach().clone().requires_grad_(True)
+            loss = (_per_map(kind, p, gt) * w.view(pred.shape[0], pred.shape[1])).sum()
+            return torch.autograd.grad(loss, p)[0] * upstream
+
+    for fn in (heatmap_head_fwd, heatmap_head_bwd, heatmap_loss_fwd, heatmap_loss_bwd):
+        setattr(FakeKernels, fn.__name__, fn)
+
+
+_install_heatmap_fakes()

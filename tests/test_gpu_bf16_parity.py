@@ -1,0 +1,374 @@
+"""GPU parity of the BENCHMARKED instantiation: the bf16 kernels (fused stem, halo / LDS-DMA convolutions, transposing-
+read weight gradients, register-resident InstanceNorm, fused conv-GRU scan, heat-map head, fused Adam) against the
+oracle's rounding-faithful mode (oracle/bf16_faithful.py: the float32 oracle's arithmetic with bfloat16 rounding at
+exactly the tensors the kernels store in bfloat16; tied to the pinned float32 oracle by tests/test_oracle_golden.py).
+
+Two kinds of comparison, because of what bf16 storage does to a deep network:
+
+  * STAGE-LOCAL, teacher-forced (tight): every stage of the HIP path -- stem, each residual block, pooling, each
+    pre-activation block, the conv-GRU scan, up-sampling, the head -- is fed the ORACLE's bf16-exact input (forward) and
+    the oracle's output gradient (backward) and must reproduce the oracle's output, input gradient and parameter
+    gradients: relative L2 <= 3e-3 forward, <= 1e-2 backward.  What is left inside that is float32 summation order
+    (MFMA / wave reductions vs the host) flipping the bf16 rounding of ~0.01-1 % of a stage's elements by one ulp.
+    A defect of relative size 1e-2 in any bf16-only kernel fails here.
+
+  * END-TO-END (an envelope, not a tight bound): two bf16 evaluations that differ in ONE rounding decision do not stay
+    close.  A perturbation of relative size e at a stage's input moves e / ulp of that stage's outputs across a
+    rounding boundary, each by a whole ulp, so the perturbation leaves the stage with size ~ sqrt(e * ulp): measured
+    on this network 1.1e-4 (stem) -> 1.6e-3 -> 5.5e-3 -> ... -> 3.4e-2 after the eight blocks (tools/debug_bf16_stages.py),
+    the same size as the distance between the rounding-faithful oracle and the float32 oracle.  An end-to-end
+    tolerance below bf16's own noise therefore cannot be met by ANY independent bf16 implementation; what can be
+    asserted is that the HIP result is no further from the rounding-faithful oracle than that oracle is from float32
+    (same noise scale, no systematic offset), which these tests do for gaze, heat-map, loss and gradients.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import bf16_faithful as bf
+from oracle import detweights, sequence
+from oracle.config import OracleConfig
+
+pytestmark = pytest.mark.gpu
+
+FWD_LOCAL = 3e-3      # relative L2 of one stage's output given the oracle's input
+BWD_LOCAL = 1e-2      # relative L2 of one stage's input / parameter gradients given the oracle's output gradient
+ENVELOPE = 2.0        # end to end: |HIP bf16 - faithful oracle| <= ENVELOPE * |faithful oracle - float32 oracle| (rms over
+                      # 12..480 outputs: measured ratios 0.4..1.4 on small samples, 0.75 at B=4 x T=30)
+
+
+def eye_cfg():
+    return OracleConfig(batch_size=16, weight_decay=0.005, base_learning_rate=0.001)
+
+
+def make_eyenet(dtype=torch.bfloat16):
+    import eve_amd
+    cfg = eve_amd.reset_standalone_config()
+    cfg.import_dict({'batch_size': 16, 'weight_decay': 0.005, 'base_learning_rate': 0.001})
+    net = eve_amd.EyeNet()
+    net.compute_dtype = dtype
+    detweights.fill_module(net, seed=0)
+    return net.cuda(), cfg
+
+
+def make_refinenet(dtype=torch.bfloat16):
+    import eve_amd
+    cfg = eve_amd.reset_standalone_config()
+    cfg.import_dict({'load_screen_content': True, 'refine_net_enabled': True, 'refine_net_rnn_type': 'CGRU'})
+    net = eve_amd.RefineNet()
+    net.compute_dtype = dtype
+    detweights.fill_module(net, seed=1)
+    return net.cuda(), cfg
+
+
+def to_dev(batch):
+    return {k: v.cuda() for k, v in batch.items()}
+
+
+def rel_l2(got, want):
+    got, want = got.detach().double().cpu(), want.detach().double().cpu()
+    return float((got - want).norm() / (want.norm() + 1e-30))
+
+
+def to_nhwc(t, cpad, dtype=torch.bfloat16):
+    """oracle NCHW float (bf16-valued) -> NHWC device tensor with zero-padded channels."""
+    t = t.detach().permute(0, 2, 3, 1)
+    if t.shape[-1] != cpad:
+        t = torch.nn.functional.pad(t, (0, cpad - t.shape[-1]))
+    return t.contiguous().to(dtype).cuda()
+
+
+def from_nhwc(t, c):
+    return t.detach().float().cpu()[..., :c].permute(0, 3, 1, 2)
+
+
+def check_param_grads(params, ref_params, names, what, tol=BWD_LOCAL, zero_grad=()):
+    """zero_grad: parameters whose true gradient is exactly zero (conv biases that only feed InstanceNorms: a per-channel
+    constant is removed by the normalisation); what both sides compute there is rounding residue of the same scale."""
+    worst = 0.0
+    for n in names:
+        r = ref_params[n].grad
+        g = params[n].grad
+        assert g is not None, n
+        if n in zero_grad:
+            assert float(g.norm()) <= 10 * float(r.norm()) + 1e-4, '%s: zero-gradient bias, |g| %.3e vs residue %.3e' % (n, float(g.norm()), float(r.norm()))
+            continue
+        e = rel_l2(g, r)
+        worst = max(worst, e)
+        assert e <= tol, '%s: %s gradient relative L2 %.3e' % (what, n, e)
+    return worst
+
+
+@pytest.mark.parametrize('B,T,seed', [(2, 3, 0), (4, 30, 17)], ids=['fixture-shape', 'configs1-slice'])
+def test_eyenet_bf16_stages_teacher_forced_match_rounding_faithful_oracle(B, T, seed):
+    """Stem, the eight residual blocks and the average pool of the bf16 trunk (BASELINE configs[1]'s kernels: fused stem
+    forward / backward-by-recomputation + packed-patch weight gradient, halo and LDS-DMA convolutions, parity-class
+    strided dgrad, transposing-read weight gradients, register-resident InstanceNorm forward / backward), each fed the
+    oracle's bf16-exact input and output gradient.  The second case is a B=4 slice of the benchmarked B=32 x T=30 batch."""
+    from eve_amd import ops
+    from eve_amd.kernels import default_kernels
+    from oracle.eye_net import EyeNet as OracleEyeNet
+    cfg = eye_cfg()
+    batch = detweights.eyenet_batch(B, T, seed=seed, invalid_fraction=0.2)
+    ref = detweights.fill_module(OracleEyeNet(cfg), seed=0)
+    x = torch.cat([batch['left_eye_patch'].reshape(B * T, 3, 128, 128), batch['right_eye_patch'].reshape(B * T, 3, 128, 128)])
+    taps = {}
+    feats = bf.resnet_trunk(ref.cnn_layers, x, taps)
+    g = torch.Generator().manual_seed(seed)
+    (feats * torch.randn(feats.shape, generator=g)).sum().backward()
+    net, _ = make_eyenet()
+    P = net._get_packs()
+    k = default_kernels()
+    cnn = net.cnn_layers
+    params, rparams = dict(cnn.named_parameters()), dict(ref.cnn_layers.named_parameters())
+    N = x.shape[0]
+    xp = torch.empty((N, 134, 136, 4), dtype=torch.bfloat16, device='cuda')
+    k.stem_pack_input(x.cuda(), out=xp)
+    # ---- stem: forward, then backward from the oracle's d(stem output) ----
+    y = ops.ResNetTrunkFn.apply(None, None, xp, (P['conv1'], ()), 1e-5, cnn.conv1.weight)
+    e = rel_l2(from_nhwc(y, 64), taps['stem'])
+    assert e <= FWD_LOCAL, 'stem forward: relative L2 %.3e' % e
+    y.backward(to_nhwc(taps['stem'].grad, 64))
+    report = ['stem fwd %.1e dW %.1e' % (e, check_param_grads(params, rparams, ['conv1.weight'], 'stem'))]
+    # ---- residual blocks ----
+    prev = 'stem'
+    for name, blk in cnn.blocks():
+        ds = blk.downsample
+        packs = (P[name + '.conv1'], P[name + '.conv2'], P[name + '.downsample.0'] if ds is not None else None)
+        weights = [blk.conv1.weight, blk.conv2.weight] + ([ds[0].weight] if ds is not None else [])
+        wnames = [name + '.conv1.weight', name + '.conv2.weight'] + ([name + '.downsample.0.weight'] if ds is not None else [])
+        cin = taps[prev].shape[1]
+        xin = to_nhwc(taps[prev], cin).requires_grad_(True)
+        out = ops.ResNetTrunkFn.apply(xin, None, None, (None, ((packs, blk.stride),)), 1e-5, *weights)
+        ef = rel_l2(from_nhwc(out, out.shape[-1]), taps[name])
+        assert ef <= FWD_LOCAL, '%s forward: relative L2 %.3e' % (name, ef)
+        out.backward(to_nhwc(taps[name].grad, out.shape[-1]))
+        eb = rel_l2(from_nhwc(xin.grad, cin), taps[prev].grad)
+        assert eb <= BWD_LOCAL, '%s input gradient: relative L2 %.3e' % (name, eb)
+        ew = check_param_grads(params, rparams, wnames, name)
+        report.append('%s fwd %.1e dx %.1e dW %.1e' % (name, ef, eb, ew))
+        prev = name
+    # ---- average pool ----
+    yin = to_nhwc(taps[prev], 512).requires_grad_(True)
+    pooled = ops.AvgPoolFn.apply(yin)
+    assert rel_l2(pooled.float().cpu(), taps['pooled']) <= FWD_LOCAL
+    pooled.backward(taps['pooled'].grad.to(torch.bfloat16).cuda())
+    assert rel_l2(from_nhwc(yin.grad, 512), taps[prev].grad) <= BWD_LOCAL
+    print('; '.join(report))
+
+
+def oracle_outputs(make_ref, run):
+    """-> (faithful outputs, float32 outputs) of the same oracle network."""
+    ref = make_ref()
+    faithful = run(ref)
+    with bf.rounding(False):
+        plain = run(make_ref())
+    return ref, faithful, plain
+
+
+@pytest.mark.parametrize('B,T,seed', [(2, 3, 0), (4, 30, 17)], ids=['fixture-shape', 'configs1-slice'])
+def test_eyenet_bf16_end_to_end_within_the_bf16_noise_envelope(B, T, seed):
+    """EyeNet.forward_sequence + losses + backward in bf16, end to end: the distance to the rounding-faithful oracle is
+    bounded by that oracle's own distance to float32 (see the module docstring for why nothing tighter exists)."""
+    from oracle.eye_net import EyeNet as OracleEyeNet
+    cfg = eye_cfg()
+    batch = detweights.eyenet_batch(B, T, seed=seed, invalid_fraction=0.2)
+    res = {}
+    for mode in ('faithful', 'float32'):
+        ref = detweights.fill_module(OracleEyeNet(cfg), seed=0)
+        with bf.rounding(mode == 'faithful'):
+            out = bf.eyenet_sequence(ref, batch)
+            terms = sequence.eyenet_losses(out, batch, cfg)
+            terms['full_loss'].backward()
+        res[mode] = (out, terms, {n: p.grad.detach().clone() for n, p in ref.named_parameters()})
+    net, _ = make_eyenet()
+    dbatch = to_dev(batch)
+    out = net.forward_sequence(dbatch)
+    terms = sequence.eyenet_losses(out, dbatch, cfg)
+    terms['full_loss'].backward()
+    fo, ft, fg = res['faithful']
+    po, pt, pg = res['float32']
+    for k in ('left_g_initial', 'right_g_initial', 'left_pupil_size', 'right_pupil_size'):
+        noise = float((fo[k] - po[k]).detach().pow(2).mean().sqrt())
+        dev = float((out[k].detach().float().cpu() - fo[k].detach()).pow(2).mean().sqrt())
+        print('%s: rms deviation from the faithful oracle %.3e, bf16 noise (faithful vs float32) %.3e' % (k, dev, noise))
+        assert dev <= ENVELOPE * noise, '%s: %.3e vs noise %.3e' % (k, dev, noise)
+        assert float((out[k].detach().float().cpu() - fo[k].detach()).abs().max()) <= 3 * ENVELOPE * float((fo[k] - po[k]).abs().max())
+    lnoise = abs(float(ft['full_loss']) - float(pt['full_loss']))
+    assert abs(float(terms['full_loss']) - float(ft['full_loss'])) <= max(3 * lnoise, 5e-3 * abs(float(ft['full_loss'])))
+    worst = 0.0
+    for n, p in net.named_parameters():
+        noise = rel_l2(fg[n], pg[n])
+        dev = rel_l2(p.grad, fg[n])
+        worst = max(worst, dev / max(noise, 1e-9))
+        assert dev <= ENVELOPE * noise + 1e-3, '%s: gradient deviation %.3e vs bf16 noise %.3e' % (n, dev, noise)
+    print('worst gradient deviation / bf16 noise: %.2f' % worst)
+
+
+class TeacherForce(object):
+    """RefineNet._probe: records the HIP tensor at every stage boundary and hands the next stage the oracle's."""
+
+    def __init__(self, taps):
+        self.taps, self.hip, self.leaves = taps, {}, {}
+
+    def __call__(self, name, x):
+        self.hip[name] = x
+        leaf = to_nhwc(self.taps[name], x.shape[-1], x.dtype).requires_grad_(True)
+        self.leaves[name] = leaf
+        return leaf
+
+
+@pytest.mark.parametrize('B,T,seed', [(2, 3, 0), (4, 30, 5)], ids=['fixture-shape', 'configs2-slice'])
+def test_refinenet_bf16_stages_teacher_forced_match_rounding_faithful_oracle(B, T, seed):
+    """Every stage of RefineNet.forward_sequence in bf16 (BASELINE configs[2]: pixel-group / halo / LDS-DMA convolutions
+    with bias, multi-pass and register-resident affine InstanceNorm, adaptive max-pool, bilinear up-sampling, the fused
+    conv-GRU scan and its backward, the float sigmoid head, the HIP BCE loss) fed the oracle's input and output gradient
+    through the module's own probe hook: outputs, input gradients and parameter gradients per stage."""
+    from eve_amd import losses
+    from oracle.refine_net import RefineNet as OracleRefineNet
+    ocfg = OracleConfig(load_screen_content=True, refine_net_enabled=True, refine_net_rnn_type='CGRU')
+    rb = detweights.refinenet_batch(B, T, seed=seed, invalid_fraction=0.2)
+    ref = detweights.fill_module(OracleRefineNet(ocfg), seed=1)
+    taps = {}
+    rhf, _ = bf.refinenet_sequence(ref, rb['heatmap_initial'], rb['screen_frame'], taps=taps)
+    rhf.retain_grad()
+    rterms = sequence.refinenet_losses(rhf, rb['heatmap_final_gt'], rb['validity'], ocfg)
+    rterms['full_loss'].backward()
+    # conv biases with an exactly-zero gradient, identified on the float32 oracle: |d bias| < 1e-4 |d weight| there
+    plain = detweights.fill_module(OracleRefineNet(ocfg), seed=1)
+    with bf.rounding(False):
+        phf, _ = bf.refinenet_sequence(plain, rb['heatmap_initial'], rb['screen_frame'])
+        sequence.refinenet_losses(phf, rb['heatmap_final_gt'], rb['validity'], ocfg)['full_loss'].backward()
+    pp = dict(plain.named_parameters())
+    zero_grad = {n for n in pp if n.endswith('.bias') and n[:-4] + 'weight' in pp and pp[n].dim() == 1 and pp[n[:-4] + 'weight'].dim() == 4
+                 and float(pp[n].grad.norm()) < 1e-4 * float(pp[n[:-4] + 'weight'].grad.norm())}
+    assert 20 <= len(zero_grad) <= 40, sorted(zero_grad)
+    net, cfg = make_refinenet()
+    probe = TeacherForce(taps)
+    net._probe = probe
+    drb = to_dev(rb)
+    hf, _ = net.forward_sequence(drb['heatmap_initial'], drb['screen_frame'])
+    # head + loss on the oracle's logits
+    e = float((hf.detach().cpu() - rhf.detach()).abs().max())
+    assert e < 1e-5, 'heat-map head on the oracle logits: %.3e' % e
+    terms = losses.refinenet_loss_terms(hf, drb['heatmap_final_gt'], drb['validity'], cfg)
+    for kk in ('loss_ce_heatmap_final', 'loss_mse_heatmap_final'):
+        np.testing.assert_allclose(float(terms[kk].detach()), float(rterms[kk].detach()), rtol=2e-5, err_msg=kk)
+    names = [n for n in probe.hip if probe.hip[n].requires_grad]
+    roots = [terms['full_loss']] + [probe.hip[n] for n in names]
+    grads = [None] + [to_nhwc(taps[n].grad, probe.hip[n].shape[-1]) for n in names]
+    torch.autograd.backward(roots, grads)
+    report = []
+    for n in probe.hip:
+        c = taps[n].shape[1]
+        ef = rel_l2(from_nhwc(probe.hip[n], c), taps[n])
+        if n != 'input':
+            assert ef <= FWD_LOCAL, 'stage %s forward: relative L2 %.3e' % (n, ef)
+        eb = float('nan')
+        if taps[n].grad is not None and probe.leaves[n].grad is not None:
+            eb = rel_l2(from_nhwc(probe.leaves[n].grad, c), taps[n].grad)
+            assert eb <= BWD_LOCAL, 'gradient entering stage boundary %s: relative L2 %.3e' % (n, eb)
+        report.append('%s %.1e/%.1e' % (n, ef, eb))
+    print('stage fwd / input-gradient relative L2: ' + ', '.join(report))
+    params, rparams = dict(net.named_parameters()), dict(ref.named_parameters())
+    worst = check_param_grads(params, rparams, list(params), 'RefineNet', zero_grad=zero_grad)
+    print('worst parameter gradient relative L2 %.2e' % worst)
+
+
+@pytest.mark.parametrize('B,T,seed', [(2, 3, 0), (4, 30, 5)], ids=['fixture-shape', 'configs2-slice'])
+def test_refinenet_bf16_end_to_end_within_the_bf16_noise_envelope(B, T, seed):
+    from eve_amd import losses
+    from oracle.refine_net import RefineNet as OracleRefineNet
+    ocfg = OracleConfig(load_screen_content=True, refine_net_enabled=True, refine_net_rnn_type='CGRU')
+    rb = detweights.refinenet_batch(B, T, seed=seed, invalid_fraction=0.2)
+    res = {}
+    for mode in ('faithful', 'float32'):
+        ref = detweights.fill_module(OracleRefineNet(ocfg), seed=1)
+        with bf.rounding(mode == 'faithful'):
+            hf, _ = bf.refinenet_sequence(ref, rb['heatmap_initial'], rb['screen_frame'])
+            terms = sequence.refinenet_losses(hf, rb['heatmap_final_gt'], rb['validity'], ocfg)
+            terms['full_loss'].backward()
+        res[mode] = (hf.detach(), terms, {n: p.grad.detach().clone() for n, p in ref.named_parameters()})
+    net, cfg = make_refinenet()
+    drb = to_dev(rb)
+    hf, _ = net.forward_sequence(drb['heatmap_initial'], drb['screen_frame'])
+    terms = losses.refinenet_loss_terms(hf, drb['heatmap_final_gt'], drb['validity'], cfg)
+    terms['full_loss'].backward()
+    fh, ft, fg = res['faithful']
+    ph, pt, pg = res['float32']
+    noise = float((fh - ph).pow(2).mean().sqrt())
+    dev = float((hf.detach().cpu() - fh).pow(2).mean().sqrt())
+    print('heatmap_final: rms deviation from the faithful oracle %.3e, bf16 noise %.3e; max %.3e vs %.3e' % (
+        dev, noise, float((hf.detach().cpu() - fh).abs().max()), float((fh - ph).abs().max())))
+    assert dev <= ENVELOPE * noise
+    for kk in ('loss_ce_heatmap_final', 'loss_mse_heatmap_final'):
+        ln = abs(float(ft[kk]) - float(pt[kk]))
+        assert abs(float(terms[kk]) - float(ft[kk])) <= max(3 * ln, 5e-3 * abs(float(ft[kk]))), kk
+    worst = 0.0
+    for n, p in net.named_parameters():
+        if float(fg[n].norm()) < 1e-6 * max(1.0, fg[n].numel() ** 0.5):
+            continue
+        noise = rel_l2(fg[n], pg[n])
+        dev = rel_l2(p.grad, fg[n])
+        worst = max(worst, dev / max(noise, 1e-9))
+        assert dev <= ENVELOPE * noise + 1e-3, '%s: gradient deviation %.3e vs bf16 noise %.3e' % (n, dev, noise)
+    print('worst gradient deviation / bf16 noise: %.2f' % worst)
+
+
+def test_trainer_update_equals_clip_plus_torch_adam_on_the_same_gradients():
+    """Three optimiser steps of train.eyenet_trainer in bf16: after every backward the gradients are read from the flat
+    buffer and given to clip_grad_norm_ + torch.optim.Adam on the host (/root/reference/src/train.py:49-55,
+    src/core/training.py:492-502); eve_sumsq + eve_adam_step on the flat buffers must produce the same clip norm and
+    the same parameters (moments and bias correction included) to float32 accuracy."""
+    from eve_amd import train
+    net, cfg = make_eyenet()
+    trainer = train.eyenet_trainer(net, cfg)
+    shadow = {n: torch.nn.Parameter(p.detach().cpu().clone()) for n, p in net.named_parameters()}
+    opt = torch.optim.Adam(shadow.values(), lr=cfg.learning_rate, weight_decay=cfg.weight_decay)
+    for step in range(3):
+        batch = to_dev(detweights.eyenet_batch(2, 3, seed=40 + step, invalid_fraction=0.2))
+        trainer._forward_backward(batch)
+        for n, p in net.named_parameters():
+            shadow[n].grad = p.grad.detach().cpu().clone()
+        total = float(torch.nn.utils.clip_grad_norm_(list(shadow.values()), cfg.gradient_clip_amount))
+        opt.step()
+        trainer._update(1.0)
+        np.testing.assert_allclose(float(trainer.sumsq.sqrt()), total, rtol=1e-5)
+        for n, p in net.named_parameters():
+            d = float((p.detach().cpu() - shadow[n].detach()).abs().max())
+            # the update is lr * g' / (|g'| + 1e-8) with g' = clip * g + wd * p: where the two terms cancel to |g'| ~ 1e-8
+            # the last float bit of g' (fma vs mul + add) moves the update by a fraction of lr; everywhere else float noise
+            diff = (p.detach().cpu() - shadow[n].detach()).abs().reshape(-1)
+            assert float(diff.max()) <= 2.0 * cfg.learning_rate, (step, n)
+            assert float((diff > 1e-4 * cfg.learning_rate).float().mean()) <= 1e-3, 'step %d %s: %.3e of the elements' % (
+                step, n, float((diff > 1e-4 * cfg.learning_rate).float().mean()))
+            assert float(diff.mean()) <= 1e-4 * cfg.learning_rate, (step, n, float(diff.mean()))
+    assert total > cfg.gradient_clip_amount          # the clip was active
+
+
+def test_float32_gradient_deviation_is_float_rounding_noise():
+    """The float32 instantiation's parameter gradients differ from the float32 oracle's by up to ~1e-2 relative on a few
+    trunk tensors.  This test shows what that is: against a FLOAT64 evaluation of the same oracle, the HIP float32
+    gradients are no further away than the float32 CPU oracle itself is (ReLU / max-pool decisions taken on values that
+    differ in the last float bits), i.e. the deviation is float32 noise of the problem, not of the kernels."""
+    from oracle.eye_net import EyeNet as OracleEyeNet
+    cfg = eye_cfg()
+    batch = detweights.eyenet_batch(2, 3, seed=0, invalid_fraction=0.25)
+    grads = {}
+    for name, dt in (('f64', torch.float64), ('f32', torch.float32)):
+        ref = detweights.fill_module(OracleEyeNet(cfg), seed=0).to(dt)
+        b = {k: (v.to(dt) if v.is_floating_point() else v) for k, v in batch.items()}
+        sequence.eyenet_losses(sequence.eyenet_sequence(ref, b), b, cfg)['full_loss'].backward()
+        grads[name] = {n: p.grad.detach().double() for n, p in ref.named_parameters()}
+    net, _ = make_eyenet(torch.float32)
+    dbatch = to_dev(batch)
+    sequence.eyenet_losses(net.forward_sequence(dbatch), dbatch, cfg)['full_loss'].backward()
+    worst = []
+    for n, p in net.named_parameters():
+        g64 = grads['f64'][n]
+        e_cpu = float((grads['f32'][n] - g64).norm() / g64.norm())
+        e_hip = float((p.grad.detach().double().cpu() - g64).norm() / g64.norm())
+        worst.append((e_hip, e_cpu, n))
+        assert e_hip <= max(4 * e_cpu, 5e-4), '%s: HIP f32 vs f64 %.3e, CPU f32 vs f64 %.3e' % (n, e_hip, e_cpu)
+    worst.sort(reverse=True)
+    print('float32 gradient error vs float64 (HIP, CPU oracle):', ', '.join('%s %.1e/%.1e' % (n, a, b) for a, b, n in worst[:5]))

@@ -4,6 +4,7 @@ against an independent ATen restatement of its contract (tests/fake_kernels.py r
 float32 kernels must agree to float32 round-off (the f32 MFMA is an exact fmaf chain);
 bfloat16 kernels are compared at bf16 resolution with inputs pre-rounded to bf16 on both sides.
 """
+import numpy as np
 import pytest
 import torch
 
@@ -43,6 +44,11 @@ def close(got, want, dtype, what, scale=None):
     tol = (3e-5 if dtype == torch.float32 else 1.6e-2) * max(s, 1e-6)
     err = float((got - want).abs().max())
     assert err <= tol, '%s: max|diff| %.3e > tol %.3e (scale %.3e)' % (what, err, tol, s)
+    # and in the mean: both sides round the same float32 result to bf16, so only a few elements may sit one ulp apart;
+    # a defect of relative size 1e-2 anywhere in the kernel fails this
+    rel = float((got - want).norm()) / max(float(want.norm()), 1e-30)
+    assert rel <= (2e-5 if dtype == torch.float32 else 3e-3) or err <= 1e-6 * max(s, 1e-6), \
+        '%s: relative L2 %.3e' % (what, rel)
 
 
 CONV_CASES = [
@@ -579,3 +585,44 @@ def test_conv_random_shapes_bf16(hip, ref, case):
     hip.conv2d_wgrad(dev(x), dev(dy), K, K, stride, pad, got_dw, db=got_db)
     close(got_dw, want_dw, dtype, 'conv wgrad')
     close(got_db, ref.bias_grad(dy, torch.zeros(Cout)), dtype, 'bias grad')
+
+
+def test_heatmap_head_and_losses_match_aten():
+    """eve_heatmap_head_fwd/bwd (float sigmoid of the last convolution's channel-0 logits) and eve_heatmap_loss_fwd/bwd
+    (per-frame BCE / MSE means + the validity reduction of base_loss_with_validity.py:64-73) against ATen."""
+    import torch.nn.functional as F
+    from eve_amd import losses, ops
+    g = torch.Generator().manual_seed(5)
+    for dt, tol in ((torch.bfloat16, 0.0), (torch.float32, 0.0)):
+        logits = (torch.randn((6, 72, 128, 8), generator=g) * 4).to(dt).cuda().requires_grad_(True)
+        y = ops.HeatmapHeadFn.apply(logits)
+        ref = torch.sigmoid(logits.detach()[..., 0].float()).unsqueeze(1)
+        assert y.dtype == torch.float32 and tuple(y.shape) == (6, 1, 72, 128)
+        assert float((y - ref).abs().max()) < 1e-6
+        dy = torch.randn(y.shape, generator=g).cuda()
+        y.backward(dy)
+        want = torch.zeros_like(logits.detach().float())
+        want[..., 0] = (dy * ref * (1 - ref))[:, 0]
+        assert float((logits.grad.float() - want.to(dt).float()).abs().max()) <= 1e-6 + (4e-3 * float(want.abs().max()) if dt == torch.bfloat16 else 0)
+    B, T = 3, 5
+    pred = torch.rand((B, T, 1, 72, 128), generator=g).clamp(1e-6, 1 - 1e-6)
+    pred[0, 0, 0, 0, :4] = torch.tensor([0.0, 1.0, 1e-30, 1 - 1e-7])          # the log clamp and the 1e-12 gradient floor
+    gt = torch.rand((B, T, 1, 72, 128), generator=g)
+    valid = torch.rand((B, T), generator=g) > 0.3
+    valid[1] = False
+    valid[2, 1:] = False                                                       # a clip with a single valid frame
+    for kind, fn in ((0, losses.bce_loss), (1, losses.mse_loss)):
+        p_ref = pred.clone().requires_grad_(True)
+        per = (F.binary_cross_entropy(p_ref, gt, reduction='none') if kind == 0 else (p_ref - gt) ** 2).flatten(2).mean(dim=2)
+        v = valid.float()
+        n = v.sum(dim=1)
+        want = ((per * v).sum(dim=1) / torch.where(n > 1, n, torch.ones_like(n))).mean()
+        (3.0 * want).backward()
+        p_dev = pred.clone().cuda().requires_grad_(True)
+        got = fn(p_dev, gt.cuda(), valid.cuda())
+        assert 'HeatmapLossFn' in type(got.grad_fn).__name__
+        np.testing.assert_allclose(float(got.detach()), float(want.detach()), rtol=2e-5)
+        (3.0 * got).backward()
+        a, b = p_dev.grad.cpu(), p_ref.grad
+        assert torch.isfinite(a).all()
+        assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max()) + 1e-9, kind
