@@ -28,6 +28,7 @@ class PackItem(Structure):
 
 
 PACK_BATCH_MAX = 48
+ABI_VERSION = 2          # include/eve_hip.h EVE_ABI_VERSION
 
 SIGNATURES = {
     'eve_conv2d_fwd': [POINTER(ConvDesc), P, P, P, I, P, I, P, P],
@@ -93,7 +94,7 @@ SIGNATURES = {
     'eve_heatmap_loss_fwd': [I, I, I, I, P, P, P, P, P, P, P],
     'eve_heatmap_loss_bwd': [I, I, I, P, P, P, P, P, P],
     'eve_sumsq': [L, P, P, P],
-    'eve_adam_step': [L, P, P, P, P, P, F, F, F, F, F, F, F, I, P, P],
+    'eve_adam_step': [L, P, P, P, P, P, F, F, F, F, F, F, F, I, P, P, P],
 }
 EXPORTS = sorted(list(SIGNATURES) + ['eve_abi_version', 'eve_last_error', 'eve_last_kernel'])
 
@@ -121,8 +122,9 @@ def load(path=None):
     lib.eve_abi_version.restype = c_int
     lib.eve_last_error.argtypes = []
     lib.eve_last_error.restype = c_char_p
-    if lib.eve_abi_version() != 1:
-        raise EveLibraryError('libeve_hip.so ABI version %d, expected 1' % lib.eve_abi_version())
+    if lib.eve_abi_version() != ABI_VERSION:
+        raise EveLibraryError('libeve_hip.so ABI version %d, expected %d (rebuild: python -m eve_amd.build)' % (
+            lib.eve_abi_version(), ABI_VERSION))
     _lib = lib
     return lib
 

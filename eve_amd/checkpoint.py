@@ -7,8 +7,9 @@ file and calls a strict `load_state_dict`; only the newest `keep_n` directories 
 reference's parameter names and torch OIHW float32 shapes, so these files are interchangeable with the reference's (and
 with the released `eve_eyenet_*.pt` / `eve_refinenet_*.pt` weights, which use the same keys without the prefix).
 Optimizer state: the build's trainer keeps Adam moments in flat buffers (train.FlatParameters); they are written in
-torch.optim.Adam's state_dict format (`state` / `param_groups`, parameters numbered in `model.parameters()` order of the
-trainable ones), which is what `optimizer_0.pt` holds in the reference.
+torch.optim.Adam's state_dict format, numbered by position in `model.parameters()` with the frozen parameters counted
+(train.py:49-55 hands Adam every parameter) and state entries only for the trainable ones -- what `optimizer_0.pt`
+holds in the reference.
 """
 import glob
 import os
@@ -40,7 +41,7 @@ def save(model, output_dir, step, trainer=None, keep_n=3):
     for prefix in sorted({k.split('.')[0] for k in state}):
         torch.save({k: v for k, v in state.items() if k.startswith(prefix + '.')}, os.path.join(ofdir, prefix + SUFFIX))
     if trainer is not None:
-        torch.save(adam_state_dict(trainer), os.path.join(ofdir, 'optimizer_0' + SUFFIX))
+        torch.save(adam_state_dict(trainer, model), os.path.join(ofdir, 'optimizer_0' + SUFFIX))
     for _, path in available(output_dir)[:-keep_n] if keep_n else []:
         shutil.rmtree(path)
     return ofdir
@@ -59,7 +60,7 @@ def load(model, ifdir, trainer=None, map_location='cpu'):
             m.invalidate_packs()
     opt = os.path.join(ifdir, 'optimizer_0' + SUFFIX)
     if trainer is not None and os.path.isfile(opt):
-        load_adam_state_dict(trainer, torch.load(opt, map_location=map_location))
+        load_adam_state_dict(trainer, torch.load(opt, map_location=map_location), model)
     return int(os.path.split(ifdir.rstrip('/'))[-1][:-len(SUFFIX)])
 
 
@@ -77,25 +78,58 @@ def _param_view(flat, off, n, p):
     return v.view(tuple(p.shape))
 
 
-def adam_state_dict(trainer):
+def _positions(trainer, model):
+    """Index of every trainer parameter in `list(model.parameters())` -- the numbering torch.optim.Adam(model.parameters())
+    uses in its state_dict (/root/reference/src/train.py:49-55 builds the optimizer over ALL parameters, frozen ones
+    included, so with a frozen EyeNet the RefineNet entries start at 37).  Without a model: 0..len-1 over the trainable ones."""
+    if model is None:
+        return list(range(len(trainer.fp.entries))), len(trainer.fp.entries)
+    index = {id(p): i for i, p in enumerate(model.parameters())}
+    pos = []
+    for p, _, _ in trainer.fp.entries:
+        if id(p) not in index:
+            raise ValueError('a trainer parameter is not a parameter of the model the optimizer state is numbered by')
+        pos.append(index[id(p)])
+    return pos, len(index)
+
+
+def adam_state_dict(trainer, model=None):
+    """torch.optim.Adam(model.parameters()).state_dict() of the trainer's moments: `state` holds an entry per TRAINABLE
+    parameter under its position in model.parameters(), `param_groups[0]['params']` lists every position."""
     cfg, fp = trainer.config, trainer.fp
+    pos, total = _positions(trainer, model)
     state = {}
-    for i, (p, off, n) in enumerate(fp.entries):
+    for i, (p, off, n) in zip(pos, fp.entries):
         state[i] = {'step': torch.tensor(float(trainer.step_count)),
                     'exp_avg': _param_view(fp.m, off, n, p).detach().cpu().contiguous(),
                     'exp_avg_sq': _param_view(fp.v, off, n, p).detach().cpu().contiguous()}
-    group = {'lr': float(cfg.learning_rate), 'betas': (trainer.beta1, trainer.beta2), 'eps': trainer.eps,
-             'weight_decay': float(cfg.weight_decay), 'amsgrad': False, 'params': list(range(len(fp.entries)))}
+    lr = float(trainer.lr) if getattr(trainer, 'lr', None) is not None else float(cfg.learning_rate)
+    group = {'lr': lr, 'betas': (trainer.beta1, trainer.beta2), 'eps': trainer.eps,
+             'weight_decay': float(cfg.weight_decay), 'amsgrad': False, 'params': list(range(total))}
     return {'state': state, 'param_groups': [group]}
 
 
-def load_adam_state_dict(trainer, sd):
+def load_adam_state_dict(trainer, sd, model=None):
+    """Inverse of adam_state_dict; every entry's shapes are checked BEFORE anything is copied (a state numbered by another
+    parameter list must not land in the wrong tensors)."""
     fp = trainer.fp
-    steps = 0
-    for i, (p, off, n) in enumerate(fp.entries):
+    pos, total = _positions(trainer, model)
+    listed = sd['param_groups'][0]['params'] if sd.get('param_groups') else None
+    if listed is not None and len(listed) != total:
+        raise ValueError('optimizer state lists %d parameters, the %s has %d' % (
+            len(listed), 'model' if model is not None else 'trainer', total))
+    todo = []
+    for i, (p, off, n) in zip(pos, fp.entries):
         st = sd['state'].get(i)
         if st is None:
             continue
+        for key in ('exp_avg', 'exp_avg_sq'):
+            if tuple(st[key].shape) != tuple(p.shape):
+                raise ValueError('optimizer state %d %s has shape %s, parameter has %s' % (
+                    i, key, tuple(st[key].shape), tuple(p.shape)))
+        todo.append((st, p, off, n))
+    steps = 0
+    for st, p, off, n in todo:
         _param_view(fp.m, off, n, p).copy_(st['exp_avg'].to(fp.m.device))
         _param_view(fp.v, off, n, p).copy_(st['exp_avg_sq'].to(fp.v.device))
         steps = max(steps, int(float(st['step'])))

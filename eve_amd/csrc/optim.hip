@@ -26,12 +26,14 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
                                                    float* __restrict__ m, float* __restrict__ v,
                                                    const float* __restrict__ sumsq, float max_norm, float gscale,
                                                    float lr, float b1, float b2, float eps, float wd, float bc1,
-                                                   float bc2_sqrt, const int* __restrict__ step_dev, long long n) {
+                                                   float bc2_sqrt, const int* __restrict__ step_dev,
+                                                   const float* __restrict__ lr_dev, long long n) {
     if (step_dev) {      // step counter lives on the device (hipGraph replay cannot change kernel arguments)
         const float t = (float)(*step_dev);
         bc1 = 1.f - powf(b1, t);
         bc2_sqrt = sqrtf(1.f - powf(b2, t));
     }
+    if (lr_dev) lr = *lr_dev;      // the schedule's value for this step, written by the host before the (replayed) launch
     float clip = gscale;
     if (sumsq) {
         const float total = sqrtf(*sumsq) * gscale;
@@ -66,14 +68,15 @@ extern "C" int eve_sumsq(long long n, const float* g, float* out, eve_stream_t s
 
 extern "C" int eve_adam_step(long long n, float* p, const float* g, float* m, float* v, const float* sumsq,
                              float max_norm, float gscale, float lr, float beta1, float beta2, float eps,
-                             float weight_decay, int step, const int* step_dev, eve_stream_t stream) {
+                             float weight_decay, int step, const int* step_dev, const float* lr_dev,
+                             eve_stream_t stream) {
     if (n <= 0 || !p || !g || !m || !v || (step < 1 && !step_dev)) return set_error_msg("adam_step: bad arguments");
     const float bc1 = 1.f - powf(beta1, (float)step);
     const float bc2 = sqrtf(1.f - powf(beta2, (float)step));
     long long b = (n + 255) / 256;
     if (b > 2048) b = 2048;
     hipLaunchKernelGGL(adam_kernel, dim3((unsigned)b), dim3(256), 0, (hipStream_t)stream, p, g, m, v, sumsq, max_norm,
-                       gscale, lr, beta1, beta2, eps, weight_decay, bc1, bc2, step_dev, n);
+                       gscale, lr, beta1, beta2, eps, weight_decay, bc1, bc2, step_dev, lr_dev, n);
     EVE_CHECK_LAUNCH();
     return 0;
 }

@@ -780,10 +780,10 @@ class HipKernels(object):
         return out
 
     def adam_step(self, p, g, m, v, sumsq, max_norm, gscale, lr, beta1, beta2, eps, weight_decay, step,
-                  step_dev=None):
+                  step_dev=None, lr_dev=None):
         self._ck(self.lib.eve_adam_step(p.numel(), self._p(p), self._p(g), self._p(m), self._p(v),
                                         self._p(sumsq), max_norm, gscale, lr, beta1, beta2, eps,
-                                        weight_decay, step, self._p(step_dev), self._stream()))
+                                        weight_decay, step, self._p(step_dev), self._p(lr_dev), self._stream()))
 
 
 _default = None

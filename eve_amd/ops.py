@@ -493,6 +493,11 @@ class ResNetTrunkFn(torch.autograd.Function):
             y, sv = _block_forward(k, y, packs, stride, eps)
             saved += list(sv)
         ctx.spec, ctx.weights = spec, weights
+        # weight gradients written in place into the flat buffer: count this use, so that a trunk applied several times
+        # per step (the per-frame contract) reports each parameter to the data-parallel bookkeeping after its LAST backward
+        for i, w in enumerate(weights):
+            if _direct_grad_ok(w):
+                _note_use(w, ctx.needs_input_grad[5 + i])
         ctx.save_for_backward(*saved)
         return y
 

@@ -66,6 +66,7 @@ class GradSync(object):
         self._handles = []
         self._hooks = []
         self._armed = False
+        self.launch_counts = []
         if self.world > 1:
             for p, _, _ in entries:
                 if p.requires_grad:
@@ -81,11 +82,13 @@ class GradSync(object):
         self._handles = []
         self._seen = set()
         self._armed = True
+        self.launch_counts = [0] * len(self.buckets)     # all-reduces issued per bucket this step (tests assert 1 each)
 
     def _launch(self, b):
         if b['launched'] or b['hi'] <= b['lo']:
             return
         b['launched'] = True
+        self.launch_counts[self.buckets.index(b)] += 1
         self._handles.append(dist.all_reduce(self.flat_grad[b['lo']:b['hi']], op=dist.ReduceOp.SUM,
                                              group=self.group, async_op=True))
 

@@ -77,7 +77,11 @@ class Trainer(object):
     With data parallelism the graph holds forward+backward only; the gradient all-reduce, clip and Adam run
     eagerly behind it (collectives are not captured)."""
 
-    def __init__(self, modules, config, loss_fn, distributed=False, device=None, use_graph=False):
+    def __init__(self, modules, config, loss_fn, distributed=False, device=None, use_graph=False, lr_schedule=None):
+        """lr_schedule: None (constant config.learning_rate) or a callable step -> learning rate, e.g.
+        `lambda s: schedule.effective_learning_rate(config, steps_per_epoch, s)` for the reference's behaviour
+        (src/core/training.py:382-418,436-442).  The value lives in a device scalar the Adam kernel reads, so it also
+        changes under hipGraph replay."""
         self.modules = list(modules)
         self.config = config
         self.loss_fn = loss_fn
@@ -85,6 +89,9 @@ class Trainer(object):
         dev = self.fp.flat.device
         self.sumsq = torch.zeros(1, dtype=torch.float32, device=dev)
         self.step_dev = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.lr_schedule = lr_schedule
+        self.lr = float(config.learning_rate)
+        self.lr_dev = torch.full((1,), self.lr, dtype=torch.float32, device=dev)
         self.sync = GradSync(self.fp.grad, self.fp.entries) if distributed else None
         self.step_count = 0
         self.beta1, self.beta2, self.eps = 0.9, 0.999, 1e-8      # torch.optim.Adam defaults (train.py:49-55)
@@ -118,9 +125,20 @@ class Trainer(object):
             self.sumsq.zero_()
             k.sumsq(self.fp.grad, self.sumsq)
         k.adam_step(self.fp.flat, self.fp.grad, self.fp.m, self.fp.v, self.sumsq if clip else None,
-                    float(cfg.gradient_clip_amount), gscale, float(cfg.learning_rate), self.beta1, self.beta2,
-                    self.eps, float(cfg.weight_decay), 0, step_dev=self.step_dev)
+                    float(cfg.gradient_clip_amount), gscale, self.lr, self.beta1, self.beta2,
+                    self.eps, float(cfg.weight_decay), 0, step_dev=self.step_dev, lr_dev=self.lr_dev)
         self._invalidate()
+
+    def set_lr(self, lr):
+        """Learning rate of the next step(s): written to the device scalar the (possibly graph-captured) Adam kernel reads."""
+        lr = float(lr)
+        if lr != self.lr:
+            self.lr = lr
+            self.lr_dev.fill_(lr)
+
+    def _apply_schedule(self):
+        if self.lr_schedule is not None:
+            self.set_lr(self.lr_schedule(self.step_count))
 
     def _eager_step(self, batch):
         if self.sync is not None:
@@ -130,6 +148,14 @@ class Trainer(object):
         self._update(gscale)
         return terms
 
+    def _snapshot(self):
+        return [t.clone() for t in (self.fp.flat, self.fp.m, self.fp.v, self.step_dev)]
+
+    def _restore(self, snap):
+        for t, s_ in zip((self.fp.flat, self.fp.m, self.fp.v, self.step_dev), snap):
+            t.copy_(s_)
+        self._invalidate()
+
     def _capture(self, batch):
         # the graph reads its inputs from fixed buffers: copies of the first batch, or (static_inputs='alias') the first
         # batch's own tensors -- for a caller that refills the same device buffers every step (a prefetcher writing in
@@ -138,14 +164,18 @@ class Trainer(object):
         self._static_batch = {k: (v if alias else v.clone()) if isinstance(v, torch.Tensor) else v for k, v in batch.items()}
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):                      # warm-up off the default stream, as capture requires
+        # two eager warm-up passes (allocator, lazy initialisation) off the default stream, as capture requires; they
+        # must not train: parameters, moments and the step counter are put back afterwards, so the first replay IS the
+        # first optimiser step (one update on the first batch, exactly like the eager path and the reference)
+        snap = self._snapshot()
+        with torch.cuda.stream(side):
             for _ in range(2):
                 if self.sync is not None:
                     self._forward_backward(self._static_batch)
                     self._collective_and_update()
                 else:
                     self._eager_step(self._static_batch)
-                self.step_count += 1
+            self._restore(snap)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self._graph = torch.cuda.CUDAGraph()
@@ -159,6 +189,9 @@ class Trainer(object):
         self._update(self.sync.finish_step())
 
     def step(self, batch):
+        """One optimiser step.  Returns the loss terms; under use_graph these are the graph's static output tensors
+        (overwritten by the next step: clone what must be kept)."""
+        self._apply_schedule()
         if not self.use_graph:
             self.step_count += 1
             return self._eager_step(batch)

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define EVE_ABI_VERSION 1
+#define EVE_ABI_VERSION 2
 
 typedef void* eve_stream_t; /* hipStream_t */
 
@@ -345,11 +345,12 @@ int eve_heatmap_loss_bwd(int kind, int BT, int HW, const float* pred, const floa
 int eve_sumsq(long long n, const float* g, float* out, eve_stream_t stream);
 /* clip factor c = min(1, max_norm / (sqrt(*sumsq) * gscale + 1e-6)) if sumsq != NULL else 1;
  * g' = c * gscale * g + wd * p;  m,v Adam moments;  p -= lr * mhat / (sqrt(vhat) + eps).
- * The bias-correction step t is `step`, or *step_dev (device int) when step_dev != NULL -- the form a
- * captured hipGraph needs, since a replay cannot change kernel arguments.                            */
+ * The bias-correction step t is `step`, or *step_dev (device int) when step_dev != NULL, and the learning rate is
+ * `lr`, or *lr_dev (device float) when lr_dev != NULL -- the forms a captured hipGraph needs, since a replay cannot
+ * change kernel arguments: the LR schedule of src/core/training.py:382-418,436-442 writes *lr_dev before each step.  */
 int eve_adam_step(long long n, float* p, const float* g, float* m, float* v, const float* sumsq,
                   float max_norm, float gscale, float lr, float beta1, float beta2, float eps,
-                  float weight_decay, int step, const int* step_dev, eve_stream_t stream);
+                  float weight_decay, int step, const int* step_dev, const float* lr_dev, eve_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -19,6 +19,10 @@ class OracleConfig(object):
     batch_size = 16
     weight_decay = 0.001
     base_learning_rate = 0.0005
+    num_warmup_epochs = 0.0           # config_default.py:87-90: LR warm-up / decay (core/training.py:382-418)
+    lr_decay_strategy = 'none'
+    lr_decay_factor = 0.5
+    lr_decay_epoch_interval = 0.5
     do_gradient_clipping = True
     gradient_clip_by = 'norm'
     gradient_clip_amount = 5.0

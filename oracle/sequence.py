@@ -93,3 +93,30 @@ def eyenet_train_step(eye_net, optimizer, batch, config):
     terms['full_loss'].backward()
     apply_update(eye_net.parameters(), optimizer, config)
     return out, terms
+
+
+def lr_schedule(config, epoch_len, step):
+    """/root/reference/src/core/training.py:382-418 for one optimizer with target_lr = config.learning_rate and
+    base_lr = target_lr / batch_size (:216-217)."""
+    target = config.learning_rate
+    base = target / config.batch_size
+    n_warm = int(epoch_len * config.num_warmup_epochs)
+    if step < n_warm:
+        return (target - base) / float(n_warm) * step + base
+    epoch = (step - n_warm) / float(epoch_len)
+    interval = int(epoch / config.lr_decay_epoch_interval)
+    if config.lr_decay_strategy == 'exponential':
+        return target * config.lr_decay_factor ** interval
+    if config.lr_decay_strategy == 'cyclic':
+        peak_a = target * config.lr_decay_factor ** interval
+        peak_b = peak_a * config.lr_decay_factor
+        half = 0.5 * config.lr_decay_epoch_interval
+        mid = interval * config.lr_decay_epoch_interval + half
+        slope = -(peak_a - base) / half if epoch < mid else (peak_b - base) / half
+        return slope * (epoch - mid) + base
+    return target
+
+
+def lr_used_by_step(config, epoch_len, step):
+    """LambdaLR(optimizer, lr_schedule) as driven by training.py:436-442,576-577: initial LR times the function value."""
+    return config.learning_rate * lr_schedule(config, epoch_len, step)

@@ -1,0 +1,148 @@
+"""Workers of the data-parallel tests (TEST INFRASTRUCTURE): one optimiser step on `world` ranks, each on its share of a
+global clip batch, written to disk for the parent to compare with a single process on the whole batch.
+
+  device 'cpu' : gloo + tests/fake_kernels.py -- the host logic (bucketing, hooks, use counting) in the build container;
+  device 'cuda': gloo + the REAL HIP kernels, every rank on GPU 0 (EVE_AMD_FORCE_DEVICE=0) -- the paths that only exist
+                 with the kernels: weight gradients written in place into the flat buffer -> _eve_grad_ready -> bucket
+                 launch, hipGraph replay with eager collectives.
+"""
+import os
+import sys
+
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def free_port():
+    """A port the OS just handed out on 127.0.0.1 (a fixed one can sit in TIME_WAIT from an earlier run)."""
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def _paths():
+    for p in (REPO, os.path.join(REPO, 'tests')):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+
+
+def install_kernels(device):
+    _paths()
+    from eve_amd import kernels
+    if device == 'cpu':
+        from fake_kernels import FakeKernels
+        kernels.set_default_kernels(FakeKernels())
+    else:
+        kernels.set_default_kernels(None)           # the real library, loaded lazily; raises if it is not built
+
+
+def build(case, device, dtype):
+    """-> (config, trainer factory(distributed, use_graph), global batch).  case: 'eyenet' | 'eyenet_per_frame' | 'eve'."""
+    _paths()
+    import eve_amd
+    from eve_amd import losses, train
+    from oracle import detweights
+    dt = {'fp32': torch.float32, 'bf16': torch.bfloat16}[dtype]
+    cfg = eve_amd.reset_standalone_config()
+    if case.startswith('eyenet'):
+        cfg.import_json(os.path.join(REPO, 'configs', 'eye_net.json'))
+        net = detweights.fill_module(eve_amd.EyeNet())
+        net.compute_dtype = dt
+        net.to(device)
+        size = 64 if device == 'cpu' else 128
+        full = detweights.eyenet_batch(2, 2, seed=11, size=size)
+        if case == 'eyenet':
+            make = lambda distributed, use_graph=False: train.eyenet_trainer(net, cfg, distributed=distributed, use_graph=use_graph)
+        else:
+            # the reference's per-frame contract (src/models/eve.py:91-111): EyeNet.forward once per time step and eye
+            # side, so every trunk weight is used 2 T times per optimiser step
+            def loss_fn(batch):
+                T = batch['left_eye_patch'].shape[1]
+                steps, prev = [], None
+                for t in range(T):
+                    si = {k: v[:, t] for k, v in batch.items()}
+                    so = {}
+                    net(si, so, side='left', previous_output_dict=prev)
+                    net(si, so, side='right', previous_output_dict=prev)
+                    steps.append(so)
+                    prev = so
+                out = {k: torch.stack([s[k] for s in steps], dim=1) for k in steps[0]}
+                return losses.eyenet_loss_terms(out, batch, cfg)
+            make = lambda distributed, use_graph=False: train.Trainer([net], cfg, loss_fn, distributed=distributed)
+        return cfg, make, full
+    cfg.import_json(os.path.join(REPO, 'configs', 'refine_net.json'))
+    # (the kappa draw is per process: switch the augmentation off so that 2 x 1 clip and 1 x 2 clips see the same data)
+    cfg.import_dict({'refine_net_rnn_type': 'CGRU', 'eye_net_load_pretrained': False, 'refine_net_do_offset_augmentation': False})
+    model = eve_amd.EVE()
+    detweights.fill_module(model.eye_net, 0)
+    detweights.fill_module(model.refine_net, 1)
+    model.eye_net.compute_dtype = model.refine_net.compute_dtype = dt
+    model.to(device).train()
+    make = lambda distributed, use_graph=False: train.eve_trainer(model, cfg, distributed=distributed)
+    return cfg, make, detweights.eve_batch(2, 2, seed=13)
+
+
+def worker(rank, world, port, tmp, case, device, dtype, use_graph):
+    _paths()
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank), EVE_AMD_BUCKET_ELEMS='1000000', EVE_AMD_FORCE_DEVICE='0', EVE_AMD_DIST_BACKEND='gloo')
+    torch.set_num_threads(2)
+    import torch.distributed as dist
+    from eve_amd import parallel
+    install_kernels(device)
+    r, _, w = parallel.init_distributed(backend='gloo')
+    assert (r, w) == (rank, world)
+    cfg, make, full = build(case, device, dtype)
+    tr = make(True, use_graph)
+    assert len(tr.sync.buckets) >= 2
+    assert tr.sync.buckets[0]['hi'] == tr.fp.flat.numel() and tr.sync.buckets[-1]['lo'] == 0
+    mine = {k: v[rank:rank + 1].to(device) for k, v in full.items()}
+    steps = 3 if use_graph else 1            # graph mode: capture (with its restored warm-ups) + replays
+    for _ in range(steps):
+        terms = tr.step(mine)
+    if device != 'cpu':
+        torch.cuda.synchronize()
+    assert all(c == 1 for c in tr.sync.launch_counts), tr.sync.launch_counts        # every bucket exactly once per step
+    torch.save({'flat': tr.fp.flat.cpu().clone(), 'grad': tr.fp.grad.cpu().clone(), 'loss': float(terms['full_loss'].detach()),
+                'buckets': len(tr.sync.buckets)}, os.path.join(tmp, 'rank%d.pt' % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def single_process(case, device, dtype, steps=1):
+    install_kernels(device)
+    cfg, make, full = build(case, device, dtype)
+    tr = make(False)
+    batch = {k: v.to(device) for k, v in full.items()}
+    for _ in range(steps):
+        terms = tr.step(batch)
+    return tr.fp.flat.cpu().clone(), tr.fp.grad.cpu().clone(), float(terms['full_loss'].detach())
+
+
+def run_and_compare(tmp, case, device, dtype, use_graph=False, grad_tol=1e-3):
+    import torch.multiprocessing as mp
+    mp.spawn(worker, args=(2, free_port(), tmp, case, device, dtype, use_graph), nprocs=2, join=True)
+    a = torch.load(os.path.join(tmp, 'rank0.pt'))
+    b = torch.load(os.path.join(tmp, 'rank1.pt'))
+    assert torch.equal(a['flat'], b['flat']), 'ranks diverged (parameters)'
+    assert torch.equal(a['grad'], b['grad']), 'ranks diverged (gradients)'
+    try:
+        flat, grad, loss = single_process(case, device, dtype, steps=3 if use_graph else 1)
+        if not use_graph:
+            # summed rank gradients / world == gradient of the mean-over-clips loss on the global batch
+            rel = float((a['grad'] / 2 - grad).norm() / grad.norm())
+            assert rel < grad_tol, rel
+            assert abs(0.5 * (a['loss'] + b['loss']) - loss) < 1e-3 * max(1.0, abs(loss))      # mean of per-clip means
+        # Adam's first steps are ~ lr * sign(g): elements whose gradient is round-off noise may flip, so the update is
+        # compared in bulk rather than element by element
+        d = (a['flat'] - flat).abs()
+        frac = float((d > 1e-4).float().mean())
+        assert frac < (2e-3 if not use_graph else 2e-2), frac
+    finally:
+        from eve_amd import kernels
+        import eve_amd
+        kernels.set_default_kernels(None)
+        eve_amd.reset_standalone_config()
+    return a

@@ -362,9 +362,11 @@ class FakeKernels(object):
         return out
 
     def adam_step(self, p, g, m, v, sumsq, max_norm, gscale, lr, beta1, beta2, eps, weight_decay, step,
-                  step_dev=None):
+                  step_dev=None, lr_dev=None):
         if step_dev is not None:
             step = int(step_dev)
+        if lr_dev is not None:
+            lr = float(lr_dev)
         clip = gscale
         if sumsq is not None:
             total = float(sumsq.sqrt()) * gscale

@@ -39,7 +39,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), name
     lib.eve_abi_version.restype = ctypes.c_int
-    assert lib.eve_abi_version() == 1
+    assert lib.eve_abi_version() == 2
 
 
 def test_missing_library_fails_loudly(tmp_path, monkeypatch):
@@ -421,11 +421,22 @@ def test_checkpoints_interchange_with_the_reference_layout(fake, tmp_path):
     ref.load_state_dict(merged)                           # strict
     for (n, a), (_, b) in zip(model.state_dict().items(), ref.state_dict().items()):
         assert torch.equal(a.cpu(), b), n
-    opt = torch.optim.Adam(ref.refine_net.parameters(), lr=cfg.learning_rate, weight_decay=cfg.weight_decay)
+    # the reference builds Adam over ALL parameters, the frozen EyeNet included (src/train.py:49-55): the saved state must
+    # load into exactly that optimizer, with the RefineNet entries numbered after the 37 EyeNet parameters
+    for p_ in ref.eye_net.parameters():
+        p_.requires_grad = False
+    opt = torch.optim.Adam(ref.parameters(), lr=cfg.learning_rate, weight_decay=cfg.weight_decay)
     opt.load_state_dict(torch.load(os.path.join(path, 'optimizer_0.pt')))
     st = opt.state_dict()['state']
-    assert len(st) == len(list(ref.refine_net.parameters())) and float(st[0]['step']) == 1.0
-    assert float(st[3]['exp_avg'].abs().max()) > 0
+    n_eye = len(list(ref.eye_net.parameters()))
+    assert n_eye == 37 and min(st) == n_eye and len(st) == len(list(ref.refine_net.parameters()))
+    assert float(st[n_eye]['step']) == 1.0 and float(st[n_eye + 3]['exp_avg'].abs().max()) > 0
+    rparams = list(ref.parameters())
+    assert all(tuple(v['exp_avg'].shape) == tuple(rparams[i].shape) for i, v in st.items())
+    # a state numbered by another parameter list is refused, not copied into the wrong tensors
+    wrong = torch.optim.Adam(ref.refine_net.parameters()).state_dict()
+    with pytest.raises(ValueError):
+        checkpoint.load_adam_state_dict(tr, wrong, model)
 
     # the other direction: a checkpoint written the reference's way, read by the drop-in (+ keep-N, + load_last)
     detweights.fill_module(ref.eye_net, 5); detweights.fill_module(ref.refine_net, 6)

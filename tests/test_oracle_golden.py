@@ -373,3 +373,44 @@ def test_bf16_faithful_mode_without_rounding_is_the_float32_oracle_refinenet():
             assert float(p.grad.norm()) < 1e-6, n
         else:
             assert _grad_rel(p.grad, g_ref[n]) < 1e-4, n
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# LR schedule: the oracle's restatement and the product's eve_amd.schedule against values produced by the
+# reference's own learning_rate_schedule driving torch's LambdaLR (tests/golden/make_golden_schedule.py).
+SCHEDULE_CASES = ['none', 'eye_net_json', 'warmup_exponential', 'warmup_cyclic']
+
+
+def _schedule_cfg(fx, name, cfg):
+    for k in ('batch_size', 'base_learning_rate', 'num_warmup_epochs', 'lr_decay_strategy', 'lr_decay_factor', 'lr_decay_epoch_interval'):
+        key = '%s_cfg_%s' % (name, k)
+        if key in fx.files:
+            v = fx[key].item()
+            setattr(cfg, k, v) if not hasattr(cfg, 'override') else cfg.override(k, v)
+    return cfg, int(fx[name + '_epoch_len'])
+
+
+@pytest.mark.parametrize('name', SCHEDULE_CASES)
+def test_lr_schedule_matches_reference(golden_dir, name):
+    fx = load(golden_dir, 'lr_schedule.npz')
+    cfg, epoch_len = _schedule_cfg(fx, name, OracleConfig())
+    want_s, want_e = fx[name + '_schedule'], fx[name + '_effective']
+    got_s = np.array([sequence.lr_schedule(cfg, epoch_len, s) for s in range(len(want_s))])
+    got_e = np.array([sequence.lr_used_by_step(cfg, epoch_len, s) for s in range(len(want_e))])
+    np.testing.assert_allclose(got_s, want_s, rtol=1e-12)
+    np.testing.assert_allclose(got_e, want_e, rtol=1e-12)
+    assert want_e[0] == pytest.approx(cfg.learning_rate * want_s[0])          # the LambdaLR quirk is in the fixture
+
+
+@pytest.mark.parametrize('name', SCHEDULE_CASES)
+def test_product_lr_schedule_matches_reference(golden_dir, name):
+    import eve_amd
+    from eve_amd import schedule
+    fx = load(golden_dir, 'lr_schedule.npz')
+    cfg, epoch_len = _schedule_cfg(fx, name, eve_amd.reset_standalone_config())
+    want_s, want_e = fx[name + '_schedule'], fx[name + '_effective']
+    np.testing.assert_allclose([schedule.learning_rate_schedule(cfg, epoch_len, s) for s in range(len(want_s))], want_s, rtol=1e-12)
+    np.testing.assert_allclose([schedule.effective_learning_rate(cfg, epoch_len, s) for s in range(len(want_e))], want_e, rtol=1e-12)
+    np.testing.assert_allclose([schedule.effective_learning_rate(cfg, epoch_len, s, reference_quirk=False) for s in range(len(want_s))],
+                               want_s, rtol=1e-12)
+    eve_amd.reset_standalone_config()
