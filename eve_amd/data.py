@@ -54,9 +54,15 @@ class DevicePrefetcher(object):
             self.device = torch.device('cuda', torch.cuda.current_device())
         self.depth = max(1, int(depth))
         self.stream = torch.cuda.Stream(device=self.device)
-        self._pinned = [dict() for _ in range(self.depth + 2)]     # a slot is reused only after its batch was consumed
+        self._pinned = [dict() for _ in range(self.depth + 2)]     # staging slots, reused round-robin
+        self._slot_events = [None] * len(self._pinned)             # the copy event of the batch last staged from each slot
 
-    def _stage(self, batch, slot):
+    def _stage(self, batch, index):
+        slot = self._pinned[index]
+        # the host must not overwrite a pinned buffer whose host-to-device copy is still queued (the consumer only waits
+        # stream-side, so the host can run ahead of the device): wait for this slot's previous copy
+        if self._slot_events[index] is not None:
+            self._slot_events[index].synchronize()
         out = {}
         with torch.cuda.stream(self.stream):
             for k, v in batch.items():
@@ -73,6 +79,7 @@ class DevicePrefetcher(object):
                 out[k] = src.to(self.device, non_blocking=True)
             ev = torch.cuda.Event()
             ev.record(self.stream)
+        self._slot_events[index] = ev
         return out, ev
 
     def __iter__(self):
@@ -85,7 +92,7 @@ class DevicePrefetcher(object):
             try:
                 torch.cuda.set_device(self.device)
                 for i, batch in enumerate(self.iterable):
-                    q.put(self._stage(batch, self._pinned[i % len(self._pinned)]))
+                    q.put(self._stage(batch, i % len(self._pinned)))
                 q.put(done)
             except BaseException as e:                              # surface loader errors in the consumer
                 q.put(e)

@@ -454,3 +454,39 @@ def test_checkpoints_interchange_with_the_reference_layout(fake, tmp_path):
         checkpoint.save(model, out, s, trainer=tr, keep_n=3)
     assert [s for s, _ in checkpoint.available(out)] == [41, 42, 43]
     eve_amd.reset_standalone_config()
+
+
+def test_trainer_follows_the_reference_lr_schedule(fake):
+    """Trainer(lr_schedule=...) with eve_amd.schedule.effective_learning_rate == torch.optim.Adam stepped with the LR the
+    reference's LambdaLR arrangement produces (src/core/training.py:382-418,436-442,576-577; pinned by
+    tests/golden/lr_schedule.npz): six steps across the warm-up -> decay boundary, on the same gradients."""
+    from eve_amd import schedule
+    from oracle import sequence
+    cfg = eve_amd.reset_standalone_config()
+    cfg.import_dict(dict(batch_size=8, base_learning_rate=0.0005, num_warmup_epochs=0.5, lr_decay_strategy='exponential',
+                         lr_decay_factor=0.5, lr_decay_epoch_interval=0.5, weight_decay=0.005))
+    epoch_len = 4                                       # warm-up = 2 steps, then a decay every 2 steps
+    torch.manual_seed(0)
+    lin = torch.nn.Linear(6, 5)
+    shadow = [torch.nn.Parameter(p.detach().clone()) for p in lin.parameters()]
+    opt = torch.optim.Adam(shadow, lr=cfg.learning_rate, weight_decay=cfg.weight_decay)
+    data = torch.randn(6, 7, 6)
+    tr = train.Trainer([lin], cfg, lambda b: {'full_loss': (lin(b['x']) ** 2).mean()},
+                       lr_schedule=lambda s: schedule.effective_learning_rate(cfg, epoch_len, s))
+    ocfg = OracleConfig(batch_size=8, base_learning_rate=0.0005, num_warmup_epochs=0.5, lr_decay_strategy='exponential',
+                        lr_decay_factor=0.5, lr_decay_epoch_interval=0.5)
+    seen = []
+    for s in range(6):
+        tr.step({'x': data[s]})
+        seen.append(tr.lr)
+        for g in opt.param_groups:
+            g['lr'] = sequence.lr_used_by_step(ocfg, epoch_len, s)
+        for p, q in zip(shadow, lin.parameters()):
+            p.grad = q.grad.detach().clone()
+        torch.nn.utils.clip_grad_norm_(shadow, cfg.gradient_clip_amount)
+        opt.step()
+        for p, q in zip(shadow, lin.parameters()):
+            assert float((p - q).abs().max()) < 1e-6, s
+    assert seen[0] < seen[1] < seen[2] == seen[3] and seen[4] == 0.5 * seen[3]     # warm-up rises, the decay halves
+    assert float(tr.lr_dev) == pytest.approx(seen[-1])
+    eve_amd.reset_standalone_config()
