@@ -76,22 +76,92 @@ def cpu_baseline(T, size, steps=2, budget_s=45.0):
                       % (B, T, size, size, done if done else 0)}
 
 
-def pmc_traffic(symbol):
-    """HBM bytes per launch of `symbol` from the committed rocprofv3 --pmc summary (two separate passes, FETCH_SIZE and
+def pmc_traffic(symbol, suffix='_pmc_hbm_per_kernel.json'):
+    """HBM bytes per launch of `symbol` from a committed rocprofv3 --pmc summary (two separate passes, FETCH_SIZE and
     WRITE_SIZE, of this same workload; FETCH doubled as MI355X_MICROARCH.md prescribes for wide reads).  Counters cannot be
-    collected from inside the timed process, so this is the most recent measured profile, or None."""
+    collected from inside the timed process, so this is a measured profile from profiles/ -- but ONLY one taken on exactly
+    these kernel sources (tools/pmc_hbm_summary.py stamps eve_amd.build.kernel_tree_sha() into the file); anything else
+    is stale evidence and gives None."""
+    from eve_amd.build import kernel_tree_sha
     here = os.path.dirname(os.path.abspath(__file__))
-    cands = sorted(f for f in os.listdir(os.path.join(here, 'profiles')) if f.endswith('_pmc_hbm_per_kernel.json')) \
+    sha = kernel_tree_sha()
+    cands = sorted(f for f in os.listdir(os.path.join(here, 'profiles')) if f.endswith(suffix) and ('_c3_' in f) == ('_c3_' in suffix)) \
         if os.path.isdir(os.path.join(here, 'profiles')) else []
     for name in reversed(cands):
         try:
             table = json.load(open(os.path.join(here, 'profiles', name)))
         except (OSError, ValueError):
             continue
+        if (table.get('_meta') or {}).get('kernel_tree_sha') != sha:
+            continue
         for k, v in table.items():
             if k.replace('void ', '').strip() == 'eve::' + symbol and v.get('fetch_mb_avg_x2') is not None:
                 return (v['fetch_mb_avg_x2'] + (v.get('write_mb_avg') or 0.0)) * 1024 * 1024, 'profiles/' + name
     return None, None
+
+
+def bench_c3(args, device, k):
+    """BASELINE configs[2]: configs/refine_net.json with refine_net_rnn_type=CGRU through eve_amd.EVE --
+    EyeNet frozen and forward-only, offset augmentation, gaze geometry, heat-maps, RefineNet trained (fused conv-GRU
+    scan), soft-argmax, the 31 losses / metrics, clip, Adam -- B clips x T frames per step on this GPU.  Returns the
+    `c3` object of the JSON line: ms/step, frames/s, and the HBM roofline of its dominant kernel."""
+    import numpy as np
+    import eve_amd
+    from eve_amd import synthetic, train
+    cfg = eve_amd.reset_standalone_config()
+    cfg.import_json(os.path.join(HERE, 'configs', 'refine_net.json'))
+    cfg.import_dict({'refine_net_rnn_type': 'CGRU', 'eye_net_load_pretrained': False})
+    model = eve_amd.EVE()
+    dt = torch.bfloat16 if args.dtype == 'bf16' else torch.float32
+    model.eye_net.compute_dtype = model.refine_net.compute_dtype = dt
+    synthetic.fill_module(model.eye_net, seed=0)
+    synthetic.fill_module(model.refine_net, seed=1)
+    model = model.to(device).train()
+    tr = train.eve_trainer(model, cfg)
+    small = synthetic.eve_batch(4, args.seq, seed=1)
+    reps = (args.batch + 3) // 4
+    batch = {kk: torch.cat([v] * reps, dim=0)[:args.batch].contiguous().to(device) for kk, v in small.items()}
+    np.random.seed(0)
+    for _ in range(max(2, args.warmup)):
+        terms = tr.step(batch)
+    torch.cuda.synchronize()
+    steps = max(3, args.steps // 2)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        terms = tr.step(batch)
+    torch.cuda.synchronize()
+    ms = 1e3 * (time.perf_counter() - t0) / steps
+    out = {'workload': 'BASELINE configs[2]: configs/refine_net.json + CGRU through eve_amd.EVE (EyeNet frozen fwd, RefineNet '
+                       'trained, geometry / heat-maps / soft-argmax / 31 losses, clip, Adam), B=%d x T=%d, %s'
+                       % (args.batch, args.seq, args.dtype),
+           'ms_per_step': ms, 'value': args.batch * args.seq / (ms * 1e-3), 'unit': 'frames/s', 'steps': steps,
+           'final_loss': float(terms['full_loss'].detach()),
+           # SURVEY 8(d): 2.370 (EyeNet fwd) + 9.619 (RefineNet train) GFLOP per frame
+           'step_algorithmic_tflops': 11.989 * args.batch * args.seq / (ms * 1e-3) / 1e3}
+    out['step_mfma_frac'] = out['step_algorithmic_tflops'] / MFMA_PEAK_TFLOPS[args.dtype]
+    if not args.no_roofline:
+        k.start_profile()
+        for _ in range(args.profile_steps):
+            tr.step(batch)
+        prof = k.stop_profile()
+        by_kernel = prof.pop('_by_kernel', {})
+        overhead = prof.pop('_event_overhead_ms', None)
+        hbm = {s_: d for s_, d in by_kernel.items() if d['bytes'] > 0 and s_}
+        if hbm:
+            dom = max(hbm, key=lambda s_: hbm[s_]['ms'])
+            d = hbm[dom]
+            achieved = d['bytes'] / (d['ms'] * 1e-3) / 1e9
+            traffic, src = pmc_traffic(dom, suffix='_c3_pmc_hbm_per_kernel.json')
+            out['roofline'] = {'bound': 'hbm', 'kernel': 'eve::' + dom, 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                               'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
+                               'traffic_unit': 'bytes per launch (FETCH_SIZE x2 + WRITE_SIZE)', 'traffic_source': src,
+                               'launches_per_step': d['launches'] / args.profile_steps, 'avg_launch_ms': d['ms'] / d['launches'],
+                               'algorithmic_mb_per_launch': d['bytes'] / d['launches'] / 1e6,
+                               'event_pair_overhead_ms_subtracted': overhead}
+        out['kernels_ms_per_step'] = {s_: round(by_kernel[s_]['ms'] / args.profile_steps, 4) for s_ in by_kernel if s_}
+        out['kernel_groups_ms_per_step'] = {t: round(prof[t]['ms'] / args.profile_steps, 4) for t in prof}
+    eve_amd.reset_standalone_config()
+    return out
 
 
 def main():
@@ -108,6 +178,7 @@ def main():
     ap.add_argument('--no-graph', action='store_true', help='launch every kernel eagerly instead of replaying a hipGraph')
     ap.add_argument('--graph', action='store_true', help='force hipGraph replay also with several ranks')
     ap.add_argument('--profile-steps', type=int, default=2)
+    ap.add_argument('--no-c3', action='store_true', help='skip the configs[2] (EyeNet + RefineNet pipeline) measurement')
     args = ap.parse_args()
 
     import eve_amd
@@ -185,6 +256,7 @@ def main():
                        'global_batch': world * args.batch, 'batch_per_gpu': args.batch, 'seq_len': args.seq,
                        'parallelism': 'dp%d' % world},
             'final_loss': loss, 'hip_graph': use_graph,
+            'kernel_tree_sha': __import__('eve_amd.build', fromlist=['kernel_tree_sha']).kernel_tree_sha(),
         }
         peak = MFMA_PEAK_TFLOPS[args.dtype]
         if args.size == 128:
@@ -207,6 +279,10 @@ def main():
             out['kernels_ms_per_step'] = {t: round(by_kernel[t]['ms'] / args.profile_steps, 4) for t in by_kernel}
             out['kernel_groups_ms_per_step'] = {t: prof[t]['ms'] / args.profile_steps for t in prof}
             out['kernel_groups_tflops'] = {t: prof[t]['flops'] / (prof[t]['ms'] * 1e-3) / 1e12 for t in prof}
+        if world == 1 and not args.no_c3 and args.size == 128:
+            del trainer, net                      # release the EyeNet trainer's graph pool before the second workload
+            torch.cuda.empty_cache()
+            out['c3'] = bench_c3(args, device, k)
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(args.seq, args.size)
         print(json.dumps(out), flush=True)

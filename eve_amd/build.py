@@ -23,6 +23,18 @@ def headers():
     return glob.glob(os.path.join(CSRC, '*.h')) + [os.path.join(os.path.dirname(HERE), 'include', 'eve_hip.h')]
 
 
+def kernel_tree_sha():
+    """sha256 over the kernel sources (csrc/*, include/eve_hip.h): what a profile was taken on.  bench.py only quotes PMC
+    traffic from a profiles/ summary that carries the same value (.git does not travel to the GPU box)."""
+    import hashlib
+    h = hashlib.sha256()
+    for p in sorted(sources() + headers()):
+        h.update(os.path.basename(p).encode())
+        with open(p, 'rb') as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
 def needs_build():
     if not os.path.isfile(LIB_PATH):
         return True

@@ -338,12 +338,12 @@ __global__ __launch_bounds__(256) void add_kernel(const T* __restrict__ a, const
 }
 
 // the activations the two networks use get their own instantiation (no per-element switch), the rest the run-time one
-#define EVE_IN_ACT_DISPATCH(KERNEL, T, GRID, ...)                                                                   \
-    do { switch (act) {                                                                                             \
-        case EVE_ACT_NONE:  hipLaunchKernelGGL((KERNEL<T, EVE_ACT_NONE>), GRID, dim3(256), 0, s, __VA_ARGS__); break;  \
-        case EVE_ACT_RELU:  hipLaunchKernelGGL((KERNEL<T, EVE_ACT_RELU>), GRID, dim3(256), 0, s, __VA_ARGS__); break;  \
-        case EVE_ACT_LEAKY: hipLaunchKernelGGL((KERNEL<T, EVE_ACT_LEAKY>), GRID, dim3(256), 0, s, __VA_ARGS__); break; \
-        default:            hipLaunchKernelGGL((KERNEL<T, -1>), GRID, dim3(256), 0, s, __VA_ARGS__); break;           \
+#define EVE_IN_ACT_DISPATCH(KERNEL, T, TS, GRID, ...)                                                                                   \
+    do { switch (act) {                                                                                                                 \
+        case EVE_ACT_NONE:  EVE_LAUNCH(#KERNEL "<" TS ", 0>", (KERNEL<T, EVE_ACT_NONE>), GRID, dim3(256), 0, s, __VA_ARGS__); break;      \
+        case EVE_ACT_RELU:  EVE_LAUNCH(#KERNEL "<" TS ", 1>", (KERNEL<T, EVE_ACT_RELU>), GRID, dim3(256), 0, s, __VA_ARGS__); break;      \
+        case EVE_ACT_LEAKY: EVE_LAUNCH(#KERNEL "<" TS ", 2>", (KERNEL<T, EVE_ACT_LEAKY>), GRID, dim3(256), 0, s, __VA_ARGS__); break;     \
+        default:            EVE_LAUNCH(#KERNEL "<" TS ", -1>", (KERNEL<T, -1>), GRID, dim3(256), 0, s, __VA_ARGS__); break;               \
     } } while (0)
 
 static inline unsigned stream_grid(long long nvec) {
@@ -373,9 +373,9 @@ extern "C" int eve_instnorm_stats(int dtype, int N, int HW, int C, const void* x
     static int one_pass = -1;
     if (one_pass < 0) { const char* e = getenv("EVE_IN_STATS_ONE_PASS"); one_pass = (e && e[0] == '0') ? 0 : 1; }
     if (dtype == EVE_DT_BF16 && one_pass && (long long)HW * C * 2 >= 65536)
-        hipLaunchKernelGGL(in_stats1_kernel<bf16_t>, dim3(N), dim3(256), 0, s, (const bf16_t*)x, mean_rstd, HW, C, eps);
-    else if (dtype == EVE_DT_BF16) hipLaunchKernelGGL(in_stats_kernel<bf16_t>, dim3(N), dim3(256), 0, s, (const bf16_t*)x, mean_rstd, HW, C, eps);
-    else                      hipLaunchKernelGGL(in_stats_kernel<float>, dim3(N), dim3(256), 0, s, (const float*)x, mean_rstd, HW, C, eps);
+        EVE_LAUNCH("in_stats1_kernel<eve::bf16_t>", in_stats1_kernel<bf16_t>, dim3(N), dim3(256), 0, s, (const bf16_t*)x, mean_rstd, HW, C, eps);
+    else if (dtype == EVE_DT_BF16) EVE_LAUNCH("in_stats_kernel<eve::bf16_t>", in_stats_kernel<bf16_t>, dim3(N), dim3(256), 0, s, (const bf16_t*)x, mean_rstd, HW, C, eps);
+    else                      EVE_LAUNCH("in_stats_kernel<float>", in_stats_kernel<float>, dim3(N), dim3(256), 0, s, (const float*)x, mean_rstd, HW, C, eps);
     EVE_CHECK_LAUNCH();
     return 0;
 }
@@ -400,9 +400,9 @@ extern "C" int eve_instnorm_act_fwd(int dtype, int N, int HW, int C, const void*
     const dim3 fgrid((unsigned)chunks, (unsigned)N);
     hipStream_t s = (hipStream_t)stream;
     if (dtype == EVE_DT_BF16)
-        EVE_IN_ACT_DISPATCH(in_act_fwd_kernel, bf16_t, fgrid, (const bf16_t*)x, mean_rstd, gamma, beta, (const bf16_t*)res, act, (bf16_t*)y, HW, C);
+        EVE_IN_ACT_DISPATCH(in_act_fwd_kernel, bf16_t, "eve::bf16_t", fgrid, (const bf16_t*)x, mean_rstd, gamma, beta, (const bf16_t*)res, act, (bf16_t*)y, HW, C);
     else
-        EVE_IN_ACT_DISPATCH(in_act_fwd_kernel, float, fgrid, (const float*)x, mean_rstd, gamma, beta, (const float*)res, act, (float*)y, HW, C);
+        EVE_IN_ACT_DISPATCH(in_act_fwd_kernel, float, "float", fgrid, (const float*)x, mean_rstd, gamma, beta, (const float*)res, act, (float*)y, HW, C);
     EVE_CHECK_LAUNCH();
     return 0;
 }
@@ -415,9 +415,9 @@ extern "C" int eve_instnorm_act_bwd(int dtype, int N, int HW, int C, const void*
         return set_error_msg("instnorm_act_bwd: null pointer (y is required with a residual, beta with gamma when y is omitted)");
     hipStream_t s = (hipStream_t)stream;
     if (dtype == EVE_DT_BF16)
-        EVE_IN_ACT_DISPATCH(in_act_bwd_kernel, bf16_t, dim3(N), (const bf16_t*)dy, (const bf16_t*)y, (const bf16_t*)x, mean_rstd, gamma, beta, act, (bf16_t*)dx, (bf16_t*)dres, sums, HW, C);
+        EVE_IN_ACT_DISPATCH(in_act_bwd_kernel, bf16_t, "eve::bf16_t", dim3(N), (const bf16_t*)dy, (const bf16_t*)y, (const bf16_t*)x, mean_rstd, gamma, beta, act, (bf16_t*)dx, (bf16_t*)dres, sums, HW, C);
     else
-        EVE_IN_ACT_DISPATCH(in_act_bwd_kernel, float, dim3(N), (const float*)dy, (const float*)y, (const float*)x, mean_rstd, gamma, beta, act, (float*)dx, (float*)dres, sums, HW, C);
+        EVE_IN_ACT_DISPATCH(in_act_bwd_kernel, float, "float", dim3(N), (const float*)dy, (const float*)y, (const float*)x, mean_rstd, gamma, beta, act, (float*)dx, (float*)dres, sums, HW, C);
     EVE_CHECK_LAUNCH();
     return 0;
 }

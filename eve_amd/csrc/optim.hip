@@ -6,7 +6,10 @@
 
 namespace eve {
 
-__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, float* __restrict__ out, long long n) {
+// Two fixed-order stages (per-workgroup partials, then one workgroup summing them in index order): the result is
+// bit-reproducible for a given n, which data-parallel ranks rely on -- every rank clips identical reduced gradients by the
+// identical factor, so the replicas stay bit-identical (an atomic accumulation would differ in the last bits from run to run).
+__global__ __launch_bounds__(256) void sumsq_partial_kernel(const float* __restrict__ g, float* __restrict__ part, long long n) {
     float s = 0.f;
     const long long nvec = n / 4;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (long long)gridDim.x * 256) {
@@ -16,10 +19,19 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g,
     for (long long i = nvec * 4 + (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
         s += g[i] * g[i];
     s = wave_sum(s);
-    __shared__ float part[4];
-    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+    __shared__ float sh[4];
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
     __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(out, part[0] + part[1] + part[2] + part[3]);
+    if (threadIdx.x == 0) part[blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+__global__ __launch_bounds__(256) void sumsq_final_kernel(const float* __restrict__ part, int nparts, float* __restrict__ out) {
+    float s = 0.f;
+    for (int i = threadIdx.x; i < nparts; i += 256) s += part[i];
+    s = wave_sum(s);
+    __shared__ float sh[4];
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) out[0] += (sh[0] + sh[1]) + (sh[2] + sh[3]);
 }
 
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
@@ -56,12 +68,13 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
 
 using namespace eve;
 
-extern "C" int eve_sumsq(long long n, const float* g, float* out, eve_stream_t stream) {
-    if (n <= 0 || !g || !out) return set_error_msg("sumsq: bad arguments");
+extern "C" int eve_sumsq(long long n, const float* g, float* out, float* workspace, eve_stream_t stream) {
+    if (n <= 0 || !g || !out || !workspace) return set_error_msg("sumsq: bad arguments");
     long long b = (n / 4 + 255) / 256;
-    if (b > 1024) b = 1024;
+    if (b > EVE_SUMSQ_WORKSPACE) b = EVE_SUMSQ_WORKSPACE;
     if (b < 1) b = 1;
-    hipLaunchKernelGGL(sumsq_kernel, dim3((unsigned)b), dim3(256), 0, (hipStream_t)stream, g, out, n);
+    hipLaunchKernelGGL(sumsq_partial_kernel, dim3((unsigned)b), dim3(256), 0, (hipStream_t)stream, g, workspace, n);
+    hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, (int)b, out);
     EVE_CHECK_LAUNCH();
     return 0;
 }

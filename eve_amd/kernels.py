@@ -66,18 +66,20 @@ class HipKernels(object):
         torch.cuda.synchronize()
         overhead = sorted(a.elapsed_time(b) for a, b in null)[len(null) // 2]
         out, by_kernel = {}, {}
-        for tag, flops, e0, e1, sym in rec:
+        for tag, flops, nbytes, e0, e1, sym in rec:
             ms = max(e0.elapsed_time(e1) - overhead, 1e-4)
             for table, key in ((out, tag), (by_kernel, sym)):
-                d = table.setdefault(key, {'launches': 0, 'ms': 0.0, 'flops': 0.0})
+                d = table.setdefault(key, {'launches': 0, 'ms': 0.0, 'flops': 0.0, 'bytes': 0.0})
                 d['launches'] += 1
                 d['ms'] += ms
                 d['flops'] += flops
+                d['bytes'] += nbytes
         out['_event_overhead_ms'] = overhead
         out['_by_kernel'] = by_kernel          # keyed by the kernel symbol the library reports (eve_last_kernel)
         return out
 
-    def _timed(self, tag, flops, fn):
+    def _timed(self, tag, flops, fn, tensors=()):
+        """tensors: what the launch reads and writes once (its ALGORITHMIC bytes, for HBM-bound kernels)."""
         if self.prof is None:
             return fn()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -85,7 +87,8 @@ class HipKernels(object):
         r = fn()
         e1.record()
         sym = self.lib.eve_last_kernel()
-        self.prof.append((tag, flops, e0, e1, sym.decode() if sym else ''))
+        nbytes = float(sum(t.numel() * t.element_size() for t in tensors if t is not None))
+        self.prof.append((tag, flops, nbytes, e0, e1, sym.decode() if sym else ''))
         return r
 
     # ------------------------------------------------------------------ helpers
@@ -133,7 +136,7 @@ class HipKernels(object):
         co, kk = algo or (Cout, KH * KW * Cin)
         self._timed('conv_fwd', 2.0 * N * d.OH * d.OW * co * kk, lambda: self._ck(self.lib.eve_conv2d_fwd(
             ctypes.byref(d), self._p(x), self._p(w_ohwi), self._p(self._f32(bias, 'bias')), epi_act,
-            self._p(self._f32(ss, 'scale/shift')), pro_act, self._p(y), self._stream())))
+            self._p(self._f32(ss, 'scale/shift')), pro_act, self._p(y), self._stream())), (x, w_ohwi, y))
         return y
 
     def conv2d_dgrad(self, dy, w_ihwo, in_hw, stride, pad, algo=None, accumulate_into=None):
@@ -154,7 +157,7 @@ class HipKernels(object):
             dx = torch.empty((N, IH, IW, Cin), dtype=dy.dtype, device=dy.device)
             fn = self.lib.eve_conv2d_dgrad
         self._timed('conv_dgrad', 2.0 * N * OH * OW * co * kk, lambda: self._ck(fn(
-            ctypes.byref(d), self._p(dy), self._p(w_ihwo), self._p(dx), self._stream())))
+            ctypes.byref(d), self._p(dy), self._p(w_ihwo), self._p(dx), self._stream())), (dy, w_ihwo, dx))
         return dx
 
     def conv2d_wgrad(self, x, dy, KH, KW, stride, pad, dw_ohwi, ss=None, pro_act=ACT_NONE, algo=None, db=None):
@@ -169,7 +172,7 @@ class HipKernels(object):
         if db is not None:
             assert ss is None and db.shape == (Cout,) and db.dtype == torch.float32 and db.is_contiguous()
             self._timed('conv_wgrad', 2.0 * N * d.OH * d.OW * co * kk, lambda: self._ck(self.lib.eve_conv2d_wgrad_bias(
-                ctypes.byref(d), self._p(x), self._p(dy), self._p(dw_ohwi), self._p(db), self._stream())))
+                ctypes.byref(d), self._p(x), self._p(dy), self._p(dw_ohwi), self._p(db), self._stream())), (x, dy, dw_ohwi))
             return dw_ohwi
         self._timed('conv_wgrad', 2.0 * N * d.OH * d.OW * co * kk, lambda: self._ck(self.lib.eve_conv2d_wgrad(
             ctypes.byref(d), self._p(x), self._p(dy), self._p(self._f32(ss, 'scale/shift')), pro_act,
@@ -446,17 +449,16 @@ class HipKernels(object):
     def instnorm_stats(self, x, eps=1e-5):
         N, H, W, C = x.shape
         mr = torch.empty((N, C, 2), dtype=torch.float32, device=x.device)
-        self._ck(self.lib.eve_instnorm_stats(dt_code(x.dtype), N, H * W, C, self._p(x), eps, self._p(mr),
-                                             self._stream()))
+        self._timed('in_stats', 0.0, lambda: self._ck(self.lib.eve_instnorm_stats(
+            dt_code(x.dtype), N, H * W, C, self._p(x), eps, self._p(mr), self._stream())), (x,))
         return mr
 
     def instnorm_act_fwd(self, x, mr, gamma, beta, res, act):
         N, H, W, C = x.shape
         y = torch.empty_like(x)
-        self._ck(self.lib.eve_instnorm_act_fwd(dt_code(x.dtype), N, H * W, C, self._p(x), self._p(mr),
-                                               self._p(self._f32(gamma, 'gamma')),
-                                               self._p(self._f32(beta, 'beta')), self._p(res), act,
-                                               self._p(y), self._stream()))
+        self._timed('in_fwd', 0.0, lambda: self._ck(self.lib.eve_instnorm_act_fwd(
+            dt_code(x.dtype), N, H * W, C, self._p(x), self._p(mr), self._p(self._f32(gamma, 'gamma')),
+            self._p(self._f32(beta, 'beta')), self._p(res), act, self._p(y), self._stream())), (x, res, y))
         return y
 
     def instnorm_act_bwd(self, dy, y, x, mr, gamma, act, want_dres, beta=None):
@@ -465,11 +467,11 @@ class HipKernels(object):
         dx = torch.empty_like(x)
         dres = torch.empty_like(x) if want_dres else None
         sums = torch.empty((N, C, 2), dtype=torch.float32, device=x.device)
-        self._ck(self.lib.eve_instnorm_act_bwd(dt_code(x.dtype), N, H * W, C, self._p(dy), self._p(y),
-                                               self._p(x), self._p(mr), self._p(self._f32(gamma, 'gamma')),
-                                               self._p(self._f32(beta, 'beta')),
-                                               act, self._p(dx), self._p(dres), self._p(sums),
-                                               self._stream()))
+        # two passes over (dy, x[, y]) -- the reductions, then the gradient -- are this kernel's algorithmic traffic
+        self._timed('in_bwd', 0.0, lambda: self._ck(self.lib.eve_instnorm_act_bwd(
+            dt_code(x.dtype), N, H * W, C, self._p(dy), self._p(y), self._p(x), self._p(mr),
+            self._p(self._f32(gamma, 'gamma')), self._p(self._f32(beta, 'beta')), act, self._p(dx), self._p(dres),
+            self._p(sums), self._stream())), (dy, x, y, dy, x, y, dx, dres))
         return dx, dres, sums
 
     def instnorm_fwd_fused(self, x, gamma, beta, res, act, eps=1e-5):
@@ -477,10 +479,12 @@ class HipKernels(object):
         N, H, W, C = x.shape
         y = torch.empty_like(x)
         mr = torch.empty((N, C, 2), dtype=torch.float32, device=x.device)
-        st = self.lib.eve_instnorm_fwd_fused(dt_code(x.dtype), N, H * W, C, self._p(x),
-                                             self._p(self._f32(gamma, 'gamma')), self._p(self._f32(beta, 'beta')),
-                                             self._p(res), act, eps, self._p(y), self._p(mr), self._stream())
+        st = self._timed('in_fwd', 0.0, lambda: self.lib.eve_instnorm_fwd_fused(
+            dt_code(x.dtype), N, H * W, C, self._p(x), self._p(self._f32(gamma, 'gamma')), self._p(self._f32(beta, 'beta')),
+            self._p(res), act, eps, self._p(y), self._p(mr), self._stream()), (x, res, y))
         if st == -1:
+            if self.prof:
+                self.prof.pop()          # nothing was launched
             return None
         self._ck(st)
         return y, mr
@@ -492,10 +496,13 @@ class HipKernels(object):
         dx = torch.empty_like(x)
         dres = torch.empty_like(x) if want_dres else None
         sums = torch.empty((N, C, 2), dtype=torch.float32, device=x.device)
-        st = self.lib.eve_instnorm_bwd_fused(dt_code(x.dtype), N, H * W, C, self._p(dy), self._p(dy2), self._p(y), self._p(x),
-                                             self._p(mr), self._p(self._f32(gamma, 'gamma')), act, self._p(dx),
-                                             self._p(dres), self._p(sums), self._stream())
+        st = self._timed('in_bwd', 0.0, lambda: self.lib.eve_instnorm_bwd_fused(
+            dt_code(x.dtype), N, H * W, C, self._p(dy), self._p(dy2), self._p(y), self._p(x), self._p(mr),
+            self._p(self._f32(gamma, 'gamma')), act, self._p(dx), self._p(dres), self._p(sums), self._stream()),
+            (dy, dy2, y, x, dx, dres))
         if st == -1:
+            if self.prof:
+                self.prof.pop()
             return None
         self._ck(st)
         return dx, dres, sums
@@ -775,8 +782,14 @@ class HipKernels(object):
         return h, c
 
     # ------------------------------------------------------------------ optimiser
-    def sumsq(self, g, out):
-        self._ck(self.lib.eve_sumsq(g.numel(), self._p(self._f32(g, 'g')), self._p(out), self._stream()))
+    SUMSQ_WORKSPACE = 1024          # include/eve_hip.h EVE_SUMSQ_WORKSPACE
+
+    def sumsq(self, g, out, workspace=None):
+        """out[0] += sum g^2, in a fixed summation order (bit-reproducible).  workspace: float32 [1024] scratch."""
+        if workspace is None:
+            workspace = torch.empty((self.SUMSQ_WORKSPACE,), dtype=torch.float32, device=g.device)
+        assert workspace.numel() >= self.SUMSQ_WORKSPACE and workspace.dtype == torch.float32
+        self._ck(self.lib.eve_sumsq(g.numel(), self._p(self._f32(g, 'g')), self._p(out), self._p(workspace), self._stream()))
         return out
 
     def adam_step(self, p, g, m, v, sumsq, max_norm, gscale, lr, beta1, beta2, eps, weight_decay, step,

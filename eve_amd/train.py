@@ -88,6 +88,7 @@ class Trainer(object):
         self.fp = FlatParameters(self.modules, device)
         dev = self.fp.flat.device
         self.sumsq = torch.zeros(1, dtype=torch.float32, device=dev)
+        self.sumsq_ws = torch.zeros(1024, dtype=torch.float32, device=dev)     # scratch of the fixed-order reduction
         self.step_dev = torch.zeros(1, dtype=torch.int32, device=dev)
         self.lr_schedule = lr_schedule
         self.lr = float(config.learning_rate)
@@ -123,7 +124,7 @@ class Trainer(object):
             gscale = 1.0
         if clip:
             self.sumsq.zero_()
-            k.sumsq(self.fp.grad, self.sumsq)
+            k.sumsq(self.fp.grad, self.sumsq, self.sumsq_ws)
         k.adam_step(self.fp.flat, self.fp.grad, self.fp.m, self.fp.v, self.sumsq if clip else None,
                     float(cfg.gradient_clip_amount), gscale, self.lr, self.beta1, self.beta2,
                     self.eps, float(cfg.weight_decay), 0, step_dev=self.step_dev, lr_dev=self.lr_dev)

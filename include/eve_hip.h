@@ -341,8 +341,11 @@ int eve_heatmap_loss_bwd(int kind, int BT, int HW, const float* pred, const floa
  * Optimiser step over flat float buffers.  torch.optim.Adam with coupled L2 weight decay
  * (src/train.py:49-55) after nn.utils.clip_grad_norm_ (src/core/training.py:492-498).
  * ------------------------------------------------------------------------------------------------ */
-/* out[0] += sum g^2 (caller zeroes out[0]; take sqrt on the host or in eve_adam_step)              */
-int eve_sumsq(long long n, const float* g, float* out, eve_stream_t stream);
+/* out[0] += sum g^2 (caller zeroes out[0]; take sqrt on the host or in eve_adam_step).  Fixed summation order: the
+ * result is bit-reproducible, so data-parallel replicas clip by the identical factor.  workspace: EVE_SUMSQ_WORKSPACE
+ * floats of scratch owned by the caller.                                                            */
+#define EVE_SUMSQ_WORKSPACE 1024
+int eve_sumsq(long long n, const float* g, float* out, float* workspace, eve_stream_t stream);
 /* clip factor c = min(1, max_norm / (sqrt(*sumsq) * gscale + 1e-6)) if sumsq != NULL else 1;
  * g' = c * gscale * g + wd * p;  m,v Adam moments;  p -= lr * mhat / (sqrt(vhat) + eps).
  * The bias-correction step t is `step`, or *step_dev (device int) when step_dev != NULL, and the learning rate is

@@ -38,7 +38,7 @@ def install_kernels(device):
         kernels.set_default_kernels(None)           # the real library, loaded lazily; raises if it is not built
 
 
-def build(case, device, dtype):
+def build(case, device, dtype, base_lr=None):
     """-> (config, trainer factory(distributed, use_graph), global batch).  case: 'eyenet' | 'eyenet_per_frame' | 'eve'."""
     _paths()
     import eve_amd
@@ -48,6 +48,8 @@ def build(case, device, dtype):
     cfg = eve_amd.reset_standalone_config()
     if case.startswith('eyenet'):
         cfg.import_json(os.path.join(REPO, 'configs', 'eye_net.json'))
+        if base_lr is not None:
+            cfg.override('base_learning_rate', base_lr)
         net = detweights.fill_module(eve_amd.EyeNet())
         net.compute_dtype = dt
         net.to(device)
@@ -94,7 +96,7 @@ def worker(rank, world, port, tmp, case, device, dtype, use_graph):
     install_kernels(device)
     r, _, w = parallel.init_distributed(backend='gloo')
     assert (r, w) == (rank, world)
-    cfg, make, full = build(case, device, dtype)
+    cfg, make, full = build(case, device, dtype, 1e-7 if use_graph else None)
     tr = make(True, use_graph)
     assert len(tr.sync.buckets) >= 2
     assert tr.sync.buckets[0]['hi'] == tr.fp.flat.numel() and tr.sync.buckets[-1]['lo'] == 0
@@ -111,14 +113,14 @@ def worker(rank, world, port, tmp, case, device, dtype, use_graph):
     dist.destroy_process_group()
 
 
-def single_process(case, device, dtype, steps=1):
+def single_process(case, device, dtype, steps=1, base_lr=None):
     install_kernels(device)
-    cfg, make, full = build(case, device, dtype)
+    cfg, make, full = build(case, device, dtype, base_lr)
     tr = make(False)
     batch = {k: v.to(device) for k, v in full.items()}
     for _ in range(steps):
         terms = tr.step(batch)
-    return tr.fp.flat.cpu().clone(), tr.fp.grad.cpu().clone(), float(terms['full_loss'].detach())
+    return tr.fp.flat.cpu().clone(), tr.fp.grad.cpu().clone(), float(terms['full_loss'].detach()), float(cfg.learning_rate)
 
 
 def run_and_compare(tmp, case, device, dtype, use_graph=False, grad_tol=1e-3):
@@ -126,10 +128,18 @@ def run_and_compare(tmp, case, device, dtype, use_graph=False, grad_tol=1e-3):
     mp.spawn(worker, args=(2, free_port(), tmp, case, device, dtype, use_graph), nprocs=2, join=True)
     a = torch.load(os.path.join(tmp, 'rank0.pt'))
     b = torch.load(os.path.join(tmp, 'rank1.pt'))
-    assert torch.equal(a['flat'], b['flat']), 'ranks diverged (parameters)'
-    assert torch.equal(a['grad'], b['grad']), 'ranks diverged (gradients)'
+    def where(x, y):
+        d = (x != y).nonzero().reshape(-1)
+        return '%d of %d elements differ, first at %s, last at %s, max |d| %.3e' % (
+            d.numel(), x.numel(), d[:3].tolist(), d[-3:].tolist(), float((x - y).abs().max()))
+    assert torch.equal(a['grad'], b['grad']), 'ranks diverged (gradients): ' + where(a['grad'], b['grad'])
+    assert torch.equal(a['flat'], b['flat']), 'ranks diverged (parameters): ' + where(a['flat'], b['flat'])
     try:
-        flat, grad, loss = single_process(case, device, dtype, steps=3 if use_graph else 1)
+        # (graph case: three steps with a tiny learning rate -- Adam's first steps move every weight by ~lr * sign(g), and
+        #  with the configured lr = 0.016 a handful of sign flips on noise-level gradients would change the NEXT step's
+        #  gradients everywhere; the comparison is about launch plumbing, not about chaotic training dynamics)
+        flat, grad, loss, lr = single_process(case, device, dtype, steps=3 if use_graph else 1,
+                                              base_lr=1e-7 if use_graph else None)
         if not use_graph:
             # summed rank gradients / world == gradient of the mean-over-clips loss on the global batch
             rel = float((a['grad'] / 2 - grad).norm() / grad.norm())
@@ -138,8 +148,8 @@ def run_and_compare(tmp, case, device, dtype, use_graph=False, grad_tol=1e-3):
         # Adam's first steps are ~ lr * sign(g): elements whose gradient is round-off noise may flip, so the update is
         # compared in bulk rather than element by element
         d = (a['flat'] - flat).abs()
-        frac = float((d > 1e-4).float().mean())
-        assert frac < (2e-3 if not use_graph else 2e-2), frac
+        frac = float((d > 0.25 * lr).float().mean())
+        assert frac < (2e-3 if not use_graph else 1e-2), frac
     finally:
         from eve_amd import kernels
         import eve_amd

@@ -357,7 +357,7 @@ class FakeKernels(object):
         c = torch.sigmoid(f) * c_prev.float() + torch.sigmoid(i) * torch.tanh(g)
         return (torch.sigmoid(o) * torch.tanh(c)).to(c_prev.dtype), c.to(c_prev.dtype)
 
-    def sumsq(self, g, out):
+    def sumsq(self, g, out, workspace=None):
         out += (g.double() ** 2).sum().float()
         return out
 

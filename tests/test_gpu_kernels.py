@@ -461,6 +461,8 @@ def test_adam_and_sumsq(hip, ref):
     m, v = 0.1 * rnd((n,), torch.float32, 43), rnd((n,), torch.float32, 44).abs()
     ss_w = ref.sumsq(g, torch.zeros(1))
     ss_g = hip.sumsq(dev(g), torch.zeros(1, device='cuda'))
+    # fixed summation order: bit-reproducible (data-parallel replicas must clip by the identical factor)
+    assert all(torch.equal(hip.sumsq(dev(g), torch.zeros(1, device='cuda')), ss_g) for _ in range(5))
     close(ss_g, ss_w, torch.float32, 'sumsq', scale=float(ss_w) * 4)
     pw, mw, vw = p.clone(), m.clone(), v.clone()
     ref.adam_step(pw, g, mw, vw, ss_w, 5.0, 1.0, 0.016, 0.9, 0.999, 1e-8, 0.005, 3)

@@ -1,1 +1,1 @@
-python -m pytest tests/test_gpu_bf16_parity.py tests/test_gpu_kernels.py -m gpu -q 2>&1 | grep -v "^    \|^$" | tail -80 > gpurun_out/t1.log
+python -m pytest tests/test_gpu_data_parallel.py -m gpu -q 2>&1 | grep -E "diverged|Error|passed|failed|assert" | head -30 > gpurun_out/t_dp.log

@@ -27,4 +27,7 @@ for k in sorted(set(fetch) | set(write)):
               'fetch_kb_avg_raw': sum(f) / len(f) if f else None,
               'fetch_mb_avg_x2': 2 * sum(f) / len(f) / 1024 if f else None,
               'write_mb_avg': sum(w) / len(w) / 1024 if w else None}
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
+from eve_amd.build import kernel_tree_sha  # noqa: E402
+out['_meta'] = {'kernel_tree_sha': kernel_tree_sha(), 'command': ' '.join(sys.argv[3:]) or None}
 json.dump(out, sys.stdout, indent=1)
