@@ -70,6 +70,7 @@ template <> struct Mma<float> {
 
 }  // namespace eve
 #include "conv_fast.h"
+#include "conv_halo32.h"
 #include "wgrad_halo.h"
 namespace eve {
 
@@ -597,6 +598,27 @@ static bool launch_halo(const GatherParams& p, const void* src, const void* w, c
                                (const bf16_t*)w, bias, epi_act, (bf16_t*)out);
         else
             EVE_LAUNCH("conv3x3_halo_pkernel<2, 2>", (conv3x3_halo_pkernel<2, 2>), dim3(512), dim3(256), plds, s, h, (const bf16_t*)src,
+                               (const bf16_t*)w, bias, epi_act, (bf16_t*)out);
+        return true;
+    }
+    // EVE_HALO_MFMA32=1: the 32x32x16-MFMA, software-pipelined body (conv_halo32.h).  Measured, it is NOT faster (2.50 vs
+    // 2.39 ms per step over the 18 layer-2..4 launches) although the instruction alone sustains +35 % next to VALU work:
+    // the waves of this kernel are parked at the per-step barrier / vmcnt 35-40 % of their cycles whichever MFMA shape
+    // runs (SQ_WAIT_ANY, profiles/r02_halo_pmc.txt), so the matrix rate is not what bounds it.  Kept opt-in for that record.
+    static int mfma32 = -1;
+    if (mfma32 < 0) { const char* e = getenv("EVE_HALO_MFMA32"); mfma32 = (e && e[0] == '1') ? 1 : 0; }
+    if (mfma32 && (W >= 8 || h.TH == 4)) {
+        static bool attr32 = false;
+        if (!attr32) {
+            (void)hipFuncSetAttribute((const void*)conv3x3_halo32_kernel<2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void*)conv3x3_halo32_kernel<4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            attr32 = true;
+        }
+        if (narrow)
+            EVE_LAUNCH("conv3x3_halo32_kernel<4, 1>", (conv3x3_halo32_kernel<4, 1>), dim3(tiles), dim3(256), lds, s, h, (const bf16_t*)src,
+                               (const bf16_t*)w, bias, epi_act, (bf16_t*)out);
+        else
+            EVE_LAUNCH("conv3x3_halo32_kernel<2, 2>", (conv3x3_halo32_kernel<2, 2>), dim3(tiles), dim3(256), lds, s, h, (const bf16_t*)src,
                                (const bf16_t*)w, bias, epi_act, (bf16_t*)out);
         return true;
     }

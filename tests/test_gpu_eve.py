@@ -281,3 +281,53 @@ def test_eve_config_variants_match_oracle(over):
             # test_eve_matches_reference_golden hold 3 %); this test is about the configuration surface
             assert float((a - b).norm()) <= 1e-1 * float(b.norm()) + 1e-5 * max(1.0, scale), n
     eve_amd.reset_standalone_config()
+
+
+def test_configs4_long_sequence_large_patches_whole_pipeline():
+    """BASELINE configs[4] as one case: T = 120 frames, 256 x 256 eye patches, EyeNet + RefineNet (CGRU) together, the
+    conv-GRU / GRU hidden state carried on-chip across all 120 frames.  The reference is float32 only and the build's
+    reduced-precision mode is bf16 (it stands in for the fp16 configs[4] names: same 16-bit storage and MFMA rate, no
+    loss scaling needed): (1) float32 forward of the whole pipeline against the CPU oracle -- gaze within 1e-4 rad,
+    refined heat-map PoG within half a pixel; (2) one bf16 optimiser step of both networks at that size through
+    train.eve_trainer -- finite losses and gradients, weights move, bf16 gaze within the bf16 envelope of float32."""
+    from eve_amd import train
+    from oracle.eye_net import EyeNet as OracleEyeNet
+    from oracle.refine_net import RefineNet as OracleRefineNet
+    json_path = os.path.join(REPO, 'configs', 'refine_net.json')
+    over = dict(refine_net_rnn_type='CGRU', eye_net_load_pretrained=False, eye_net_frozen=False, loss_coeff_g_ang_initial=1.0,
+                loss_coeff_pupil_size=1.0, refine_net_do_offset_augmentation=False)
+    B, T, size = 1, 120, 256
+    batch = detweights.eve_batch(B, T, seed=41, invalid_fraction=0.1)
+    patches = detweights.eyenet_batch(B, T, size=size, seed=42)
+    for k in ('left_eye_patch', 'right_eye_patch'):
+        batch[k] = patches[k]
+    ocfg = OracleConfig(json_path, **over)
+    oeye, oref = detweights.fill_module(OracleEyeNet(ocfg), 0), detweights.fill_module(OracleRefineNet(ocfg), 1)
+    with torch.no_grad():
+        want, winter, _ = oracle_eve.eve_forward(oeye, oref, dict(batch), ocfg, False)
+    res = {}
+    for dt in (torch.float32, torch.bfloat16):
+        model = make_eve(over, dtype=dt)
+        dbatch = {k: v.cuda() for k, v in batch.items()}
+        with torch.no_grad():
+            model.eval()
+            got = model(dict(dbatch), current_epoch=0.0)
+        res[dt] = {k: got[k].detach().float().cpu() for k in ('g_initial', 'g_final', 'PoG_px_final')}
+        if dt == torch.bfloat16:
+            cfg = eve_amd.get_config()
+            tr = train.eve_trainer(model.train(), cfg)
+            assert len(tr.modules) == 2
+            before = tr.fp.flat.clone()
+            terms = tr.step(dbatch)
+            torch.cuda.synchronize()
+            assert all(bool(torch.isfinite(v).all()) for v in terms.values() if torch.is_tensor(v))
+            assert bool(torch.isfinite(tr.fp.grad).all()) and float(tr.fp.grad.abs().max()) > 0
+            assert float((tr.fp.flat - before).abs().max()) > 0
+    f32, b16 = res[torch.float32], res[torch.bfloat16]
+    for k in ('g_initial', 'g_final'):
+        assert float((f32[k] - winter[k].detach()).abs().max()) < 1e-4, k
+    assert float((f32['PoG_px_final'] - winter['PoG_px_final'].detach()).abs().max()) < 0.5
+    assert float((b16['g_initial'] - f32['g_initial']).abs().max()) < 0.08
+    # the recurrences matter at this length: the refined estimate at the last frame differs from the first frame's
+    assert float((winter['PoG_px_final'][:, -1] - winter['PoG_px_final'][:, 0]).abs().max()) > 1.0
+    eve_amd.reset_standalone_config()

@@ -628,3 +628,38 @@ def test_heatmap_head_and_losses_match_aten():
         a, b = p_dev.grad.cpu(), p_ref.grad
         assert torch.isfinite(a).all()
         assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max()) + 1e-9, kind
+
+
+def test_halo32_opt_in_kernel_matches_default(tmp_path):
+    """EVE_HALO_MFMA32=1 selects the 32x32x16-MFMA, software-pipelined halo convolution (conv_halo32.h; kept opt-in, see the
+    launcher's note).  The switch is read once per process, so the comparison runs in a child process: forward and data
+    gradient of the four halo geometries (W = 32 / 16 / 8 / 4 swizzles) against the default kernel's results."""
+    import os
+    import subprocess
+    import sys
+    code = r'''
+import sys, torch
+sys.path.insert(0, %r)
+from eve_amd.kernels import HipKernels
+k = HipKernels()
+g = torch.Generator().manual_seed(3)
+outs = []
+for N, H, C in ((20, 32, 64), (12, 16, 128), (24, 8, 256), (64, 4, 512)):
+    x = torch.randn((N, H, H, C), generator=g).bfloat16().cuda()
+    w = (torch.randn((128 if C < 512 else 256, 3, 3, C), generator=g) * (2.0 / (9 * C)) ** 0.5).bfloat16().cuda()
+    b = torch.randn((w.shape[0],), generator=g).cuda()
+    y = k.conv2d_fwd(x, w, b, 1, 1, 1)
+    dy = torch.randn(y.shape, generator=g).bfloat16().cuda()
+    dx = k.conv2d_dgrad(dy, w.permute(3, 1, 2, 0).contiguous(), (H, H), 1, 1)
+    outs += [y.float().cpu(), dx.float().cpu()]
+torch.save(outs, sys.argv[1])
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for mode in ('0', '1'):
+        path = os.path.join(str(tmp_path), 'halo%s.pt' % mode)
+        env = dict(os.environ, EVE_HALO_MFMA32=mode)
+        p = subprocess.run([sys.executable, '-c', code, path], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+        assert p.returncode == 0, p.stdout[-2000:]
+        res[mode] = torch.load(path)
+    for a, b in zip(res['1'], res['0']):
+        assert float((a - b).norm() / b.norm()) < 2e-3 and float((a - b).abs().max()) <= 1.6e-2 * float(b.abs().max())

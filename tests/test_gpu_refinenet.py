@@ -191,3 +191,36 @@ def test_pixel_group_convolution_on_the_halo_kernel(monkeypatch, cin, cout, H, W
     for name, a, c in zip(('y', 'dx', 'dw', 'db'), *outs):
         # same products, different fp32 summation order, one bf16 rounding at the end
         assert float((a - c).abs().max()) <= 1e-2 * float(c.abs().max()) + 1e-6, name
+
+
+def test_full_size_refinenet_is_batch_invariant_deterministic_and_dp_linear():
+    """BASELINE configs[2] at full size (B=32 clips x T=30, bf16, fused conv-GRU scan) through properties that need no
+    oracle: clips are independent units (InstanceNorm is per frame, the conv-GRU per clip), so every clip's heat-maps are
+    bit-identical whether it runs in the batch of 32 or in a batch of 8, a repeated forward is bit-identical, and the
+    data-parallel identity grad(batch) = mean of grad(halves) holds to atomic-order noise."""
+    from eve_amd import losses
+    small = detweights.refinenet_batch(8, 30, seed=21, invalid_fraction=0.1)
+    g = torch.Generator().manual_seed(0)
+    full = {}
+    for k, v in small.items():                       # 32 distinct clips: 4 perturbed copies of the 8 generated ones
+        reps = [v] + [(v + 0.03 * torch.rand(v.shape, generator=g)).clamp(0, 1) if k == 'screen_frame' else v for _ in range(3)]
+        full[k] = torch.cat(reps, dim=0).cuda()
+    net, cfg = make_net('CGRU', dtype=torch.bfloat16)
+    with torch.no_grad():
+        a, sa = net.forward_sequence(full['heatmap_initial'], full['screen_frame'])
+        b, sb = net.forward_sequence(full['heatmap_initial'], full['screen_frame'])
+        assert torch.equal(a, b) and torch.equal(sa[0], sb[0]), 'not deterministic'
+        for i in range(0, 32, 8):
+            part, _ = net.forward_sequence(full['heatmap_initial'][i:i + 8].contiguous(), full['screen_frame'][i:i + 8].contiguous())
+            assert torch.equal(part, a[i:i + 8]), 'clip outputs depend on the batch: clips %d..' % i
+    assert float(a.std()) > 1e-3 and tuple(a.shape) == (32, 30, 1, 72, 128)
+
+    def grads(sl):
+        net.zero_grad(set_to_none=True)
+        hf, _ = net.forward_sequence(full['heatmap_initial'][sl].contiguous(), full['screen_frame'][sl].contiguous())
+        losses.refinenet_loss_terms(hf, full['heatmap_final_gt'][sl].contiguous(), full['validity'][sl].contiguous(), cfg)['full_loss'].backward()
+        return torch.cat([p.grad.detach().float().reshape(-1) for p in net.parameters()])
+    whole = grads(slice(0, 32))
+    halves = 0.5 * (grads(slice(0, 16)) + grads(slice(16, 32)))
+    rel = float((whole - halves).norm() / whole.norm())
+    assert rel < 5e-3, rel
