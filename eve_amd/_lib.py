@@ -45,6 +45,7 @@ SIGNATURES = {
     'eve_stem_bwd_dx': [I, I, I, P, P, P, P, P, P, P, P, P],
     'eve_bias_grad': [I, L, I, P, P, P],
     'eve_cgru_scan_fwd': [I, I, P, P, P, P, P, P, P, P, P, P, P, P],
+    'eve_cgru_scan_bwd': [I, I, P, P, P, P, P, P, P, P, P, P, P, P],
     'eve_rnn_scan_fwd': [I, I, I, P, P, P, P, P, P],
     'eve_rnn_scan_bwd': [I, I, I, P, P, P, P, P, P],
     'eve_lstm_scan_fwd': [I, I, I, P, P, P, P, P, P, P, P, P],

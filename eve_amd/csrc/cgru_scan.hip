@@ -259,6 +259,255 @@ __global__ __launch_bounds__(256) void cgru_scan_fwd_kernel(const int B, const i
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // drain the zero-fill DMAs before LDS is released
 }
 
+
+// =================================================================================================
+// Backward of the scan above, also ONE persistent launch: frames are walked last to first, the gradient carried into
+// the previous hidden state stays in registers (float) for the whole clip, and per frame
+//     dhn = d hs[t] + carry
+//     dg2 = dhn (1 - u)(1 - o^2)                      d(pre-tanh)          -> LDS planes 0,1 (bf16), dg2_all[t]
+//     du  = dhn (h_prev - o);  dg1[64..] = du u (1 - u)                    -> LDS planes 4,5,        dg1_all[t][64..]
+//     dcat2 = conv3x3(dg2, W2^T)      = [d(r h) | dx_2]                    (MFMA, filter bank of gate_2 as IHWO)
+//     dg1[..64] = d(r h) h_prev r (1 - r)                                  -> LDS planes 2,3,        dg1_all[t][..64]
+//     dcat1 = conv3x3(dg1, W1^T)      = [dx_1 | dh_c]
+//     carry = dhn u + d(r h) r + dh_c;      dxs[t] = dx_1 + dx_2
+// (common.py:400-415 differentiated; the per-frame path was 2 conv launches + 2 gate kernels + 3 adds per frame = ~240
+// launches of 10-50 us per clip batch).  The data gradient of a 3x3 / pad 1 convolution is the same convolution with the
+// IHWO filter bank and the taps mirrored (tap 8 - t), so both GEMMs reuse the forward's halo tiles, ring and fragment
+// addresses.  Output-channel rows are dealt so that the wn = 1 waves own everything that feeds the carry (d(r h), dh_c)
+// and the wn = 0 waves both halves of d x: no exchange between waves.  The weight and bias gradients are batched over
+// all T*B frames afterwards from dg1_all / dg2_all (eve_conv2d_wgrad), as before.
+// =================================================================================================
+__global__ __launch_bounds__(256) void cgru_scan_bwd_kernel(const int B, const int T, const bf16_t* __restrict__ dhs_tm,
+                                                            const bf16_t* __restrict__ ru, const bf16_t* __restrict__ og,
+                                                            const bf16_t* __restrict__ hs_tm, const bf16_t* __restrict__ h0,
+                                                            const bf16_t* __restrict__ w1t, const bf16_t* __restrict__ w2t,
+                                                            bf16_t* __restrict__ dg1_all, bf16_t* __restrict__ dg2_all,
+                                                            bf16_t* __restrict__ dxs_tm, bf16_t* __restrict__ dh0) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    // planes: 0,1 = dg2 (64 channels); 2..5 = dg1 (128 channels: reset part, update part)
+    const uint32_t lds0 = lds_addr_of(smem);
+    const uint32_t ldsB = lds0 + 6 * CG_SLICE;
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63, li = lane & 15, lg = lane >> 4;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int b0 = blockIdx.x * CG_IMG;
+
+    for (int i = tid; i < 6 * CG_SLICE / 16; i += 256) reinterpret_cast<uint4*>(smem)[i] = make_uint4(0, 0, 0, 0);
+
+    constexpr int KA = 9 * 64, KB = 9 * 128;                   // row lengths of the IHWO banks (gate_2: 64 outputs, gates_1: 128)
+    const eve_int4 rs_a = make_rsrc_words(w2t, 128 * KA * 2);
+    const eve_int4 rs_b = make_rsrc_words(w1t, 128 * KB * 2);
+
+    int pix_lds[4], pix_tm[4];
+    bool pix_ok[4];
+    int aaddr[9][4];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+        const int m = wm * 64 + mt * 16 + li;
+        const bool ok = m < CG_IMG * CG_PIX && b0 + m / CG_PIX < B;
+        const int ti = ok ? m / CG_PIX : 0, rem = ok ? m % CG_PIX : 0;
+        const int py = rem >> 3, px = rem & 7;
+        const int hr0 = ti * 7 + py + 1;
+        pix_ok[mt] = ok;
+        pix_lds[mt] = ((hr0 * 10 + px + 1) << 6) | ((hr0 & 1) << 16);
+        pix_tm[mt] = (b0 + ti) * CG_PIX + rem;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int hr = ti * 7 + py + t / 3, hx = px + t % 3;
+            aaddr[t][mt] = ((hr * 10 + hx) << 6) + ((lg ^ ((hr & 1) << 1)) << 4);
+        }
+    }
+    int brow[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+        const int c1 = wn * 64 + nt * 16 + li;
+        brow[nt] = (c1 << 6) + ((lg ^ (((c1 >> 2) & 1) << 1)) << 4);
+    }
+    // weight DMA rows: LDS row cl holds input channel (= output row of the data gradient) cl of cat1 for conv B, and
+    // (cl + 64) & 127 of cat2 = [r h | x] for conv A, so that wn = 0 gets d x and wn = 1 gets d(r h)
+    int b_relA[2], b_relB[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int L = tid + 256 * j;
+        const int cl = L >> 2, sw = (((L & 3) ^ (((cl >> 2) & 1) << 1)) << 4);
+        b_relA[j] = (((cl + 64) & 127) * KA) * 2 + sw;
+        b_relB[j] = (cl * KB) * 2 + sw;
+    }
+    // stream position -> (conv, slice, tap): 18 tiles of conv A (2 slices of dg2), then 36 of conv B (4 slices of dg1)
+    auto issue_pos = [&](int pos, int slot, bool live) {
+        const bool isA = pos < 18;
+        const int q = isA ? pos : pos - 18;
+        const int sl = q / 9, tap = q - sl * 9;
+        const int koff = ((8 - tap) * (isA ? 64 : 128) + sl * 32) * 2;          // mirrored tap of the IHWO bank
+        const uint32_t dst = ldsB + slot * CG_BSLOT + wave * 1024;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            lds_dma16_asm(isA ? rs_a : rs_b, dst + j * 4096, live ? (isA ? b_relA[j] : b_relB[j]) + koff : EVE_OOB);
+    };
+    auto lds_c4 = [&](int pl, int mt, int c) -> uint32_t {
+        const int key = (pix_lds[mt] >> 16) & 1;
+        return lds0 + (pl + (c >> 5)) * CG_SLICE + (pix_lds[mt] & 0xffff) + (((((c & 31) >> 3)) ^ (key << 1)) << 4) + (c & 7) * 2;
+    };
+    auto unpack4 = [](const uint2 q, float* f) {
+        f[0] = bf16_bits_to_f32(q.x & 0xffffu); f[1] = __builtin_bit_cast(float, q.x & 0xffff0000u);
+        f[2] = bf16_bits_to_f32(q.y & 0xffffu); f[3] = __builtin_bit_cast(float, q.y & 0xffff0000u);
+    };
+
+    f32x4_t cy[4][4], dxk[4][4];                              // carry (wn = 1 waves), dx_2 (wn = 0 waves)
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) { cy[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f}; dxk[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
+
+    issue_pos(0, 0, true);
+    issue_pos(1, 1, true);
+    issue_pos(2, 2, true);
+    __syncthreads();
+
+    uint32_t gs = 0;                                          // stream position (ring phase)
+    for (int t = T - 1; t >= 0; --t) {
+        const bool more_t = t > 0;
+        const size_t frame = (size_t)t * B * CG_PIX;
+        // ---- phase A (the waves that own the carry): dg2, the update-gate half of dg1, dh_a ----
+        if (wn == 1) {
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                const int c = nt * 16 + lg * 4;
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) {
+                    if (!pix_ok[mt]) continue;
+                    const size_t pt = frame + pix_tm[mt];
+                    float d[4], u[4], o[4], hp[4] = {0.f, 0.f, 0.f, 0.f};
+                    unpack4(*reinterpret_cast<const uint2*>(dhs_tm + pt * CG_C + c), d);
+                    unpack4(*reinterpret_cast<const uint2*>(ru + pt * 128 + 64 + c), u);
+                    unpack4(*reinterpret_cast<const uint2*>(og + pt * CG_C + c), o);
+                    if (t > 0) unpack4(*reinterpret_cast<const uint2*>(hs_tm + (pt - (size_t)B * CG_PIX) * CG_C + c), hp);
+                    else if (h0) unpack4(*reinterpret_cast<const uint2*>(h0 + (size_t)pix_tm[mt] * CG_C + c), hp);
+                    float g2[4], g1u[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float dhn = d[r] + cy[mt][nt][r];
+                        g2[r] = dhn * (1.f - u[r]) * (1.f - o[r] * o[r]);
+                        g1u[r] = dhn * (hp[r] - o[r]) * u[r] * (1.f - u[r]);
+                        cy[mt][nt][r] = dhn * u[r];
+                    }
+                    const uint2 p2 = make_uint2(pack2_bf16(g2[0], g2[1]), pack2_bf16(g2[2], g2[3]));
+                    const uint2 p1 = make_uint2(pack2_bf16(g1u[0], g1u[1]), pack2_bf16(g1u[2], g1u[3]));
+                    *reinterpret_cast<EVE_LDS cg_u32x2_t*>((uintptr_t)lds_c4(0, mt, c)) = cg_u32x2_t{p2.x, p2.y};
+                    *reinterpret_cast<EVE_LDS cg_u32x2_t*>((uintptr_t)lds_c4(4, mt, c)) = cg_u32x2_t{p1.x, p1.y};
+                    *reinterpret_cast<uint2*>(dg2_all + pt * CG_C + c) = p2;
+                    *reinterpret_cast<uint2*>(dg1_all + pt * 128 + 64 + c) = p1;
+                }
+            }
+        }
+        // the weight tile of this frame's first step (issued three steps ago, or in the prologue): loads return in order,
+        // so "at most the two younger tiles outstanding" covers it for every wave, whatever it stored above
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        __syncthreads();
+        f32x4_t acc[4][4];
+#pragma unroll
+        for (int conv = 0; conv < 2; ++conv) {
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) acc[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+            const int nsl = conv == 0 ? 2 : 4, base = conv == 0 ? 0 : 18, pl0 = conv == 0 ? 0 : 2;
+            for (int sl = 0; sl < nsl; ++sl, gs += 9) {
+                const uint32_t la = lds0 + (pl0 + sl) * CG_SLICE;
+#pragma unroll
+                for (int tap = 0; tap < 9; ++tap) {
+                    int npos = base + sl * 9 + tap + 3;       // weight tile of stream position +3
+                    bool live = true;
+                    if (npos >= 54) { npos -= 54; live = more_t; }
+                    issue_pos(npos, (int)((gs + tap + 3) & 3), live);
+                    const uint32_t lb = ldsB + ((gs + tap) & 3) * CG_BSLOT;
+                    bf16x8_t fx[4], fw[4];
+#pragma unroll
+                    for (int mt = 0; mt < 4; ++mt)
+                        fx[mt] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const EVE_LDS cg_u32x4_t*>((uintptr_t)(la + aaddr[tap][mt])));
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt)
+                        fw[nt] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const EVE_LDS cg_u32x4_t*>((uintptr_t)(lb + brow[nt])));
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                        for (int mt = 0; mt < 4; ++mt)
+                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[nt], fx[mt], acc[mt][nt], 0, 0, 0);
+                    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // tile of the next step (issued 2 steps ago) landed
+                    __syncthreads();
+                }
+            }
+            if (conv == 0) {
+                if (wn == 1) {
+                    // ---- d(r h) -> reset-gate half of dg1, dh_b ----
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt) {
+                        const int c = nt * 16 + lg * 4;
+#pragma unroll
+                        for (int mt = 0; mt < 4; ++mt) {
+                            if (!pix_ok[mt]) continue;
+                            const size_t pt = frame + pix_tm[mt];
+                            float rr[4], hp[4] = {0.f, 0.f, 0.f, 0.f}, g1r[4];
+                            unpack4(*reinterpret_cast<const uint2*>(ru + pt * 128 + c), rr);
+                            if (t > 0) unpack4(*reinterpret_cast<const uint2*>(hs_tm + (pt - (size_t)B * CG_PIX) * CG_C + c), hp);
+                            else if (h0) unpack4(*reinterpret_cast<const uint2*>(h0 + (size_t)pix_tm[mt] * CG_C + c), hp);
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                const float drh = acc[mt][nt][r];
+                                g1r[r] = drh * hp[r] * rr[r] * (1.f - rr[r]);
+                                cy[mt][nt][r] += drh * rr[r];
+                            }
+                            const uint2 p1 = make_uint2(pack2_bf16(g1r[0], g1r[1]), pack2_bf16(g1r[2], g1r[3]));
+                            *reinterpret_cast<EVE_LDS cg_u32x2_t*>((uintptr_t)lds_c4(2, mt, c)) = cg_u32x2_t{p1.x, p1.y};
+                            *reinterpret_cast<uint2*>(dg1_all + pt * 128 + c) = p1;
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int a = 0; a < 4; ++a)
+#pragma unroll
+                        for (int b = 0; b < 4; ++b) dxk[a][b] = acc[a][b];
+                }
+                __syncthreads();                              // dg1 complete in LDS for conv B
+            }
+        }
+        // ---- dh_c joins the carry; d x = dx_1 + dx_2 ----
+        if (wn == 1) {
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) cy[a][b] += acc[a][b];
+        } else {
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                const int c = nt * 16 + lg * 4;
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) {
+                    if (!pix_ok[mt]) continue;
+                    const f32x4_t v = dxk[mt][nt] + acc[mt][nt];
+                    *reinterpret_cast<uint2*>(dxs_tm + (frame + pix_tm[mt]) * CG_C + c) =
+                        make_uint2(pack2_bf16(v[0], v[1]), pack2_bf16(v[2], v[3]));
+                }
+            }
+        }
+        // (the step barrier of the last tap separates this frame's reads of the planes from the next frame's phase A)
+    }
+    if (dh0 && wn == 1) {
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            const int c = nt * 16 + lg * 4;
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                if (!pix_ok[mt]) continue;
+                *reinterpret_cast<uint2*>(dh0 + (size_t)pix_tm[mt] * CG_C + c) =
+                    make_uint2(pack2_bf16(cy[mt][nt][0], cy[mt][nt][1]), pack2_bf16(cy[mt][nt][2], cy[mt][nt][3]));
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // drain the zero-fill DMAs before LDS is released
+}
+
 }  // namespace eve
 
 using namespace eve;
@@ -282,6 +531,31 @@ extern "C" int eve_cgru_scan_fwd(int B, int T, const void* xs, const void* h0, c
     hipLaunchKernelGGL(cgru_scan_fwd_kernel, dim3((B + CG_IMG - 1) / CG_IMG), dim3(256), CG_LDS, (hipStream_t)stream, B, T,
                        (const bf16_t*)xs, (const bf16_t*)h0, (const bf16_t*)w1, b1, (const bf16_t*)w2, b2, (bf16_t*)hs, (bf16_t*)hs_tm,
                        (bf16_t*)ru, (bf16_t*)rh, (bf16_t*)og);
+    EVE_CHECK_LAUNCH();
+    return 0;
+}
+
+
+/* Backward of eve_cgru_scan_fwd in one launch (bf16).  Inputs, TIME-major [T][B][5][8][.]: dhs_tm = gradient of the hidden
+   states, and the forward's ru / og / hs_tm; h0 [B][5][8][64] or NULL; w1t = gates_1 filter bank IHWO [128][3][3][128],
+   w2t = gate_2 filter bank IHWO [128][3][3][64].  Outputs (time-major): dg1_all [T][B][5][8][128] and dg2_all [..][64] = the
+   gradients of the two pre-activations (what the batched weight / bias gradients read), dxs_tm [..][64] = d xs, and dh0
+   [B][5][8][64] (NULL = not wanted).  common.py:400-415 differentiated.                                                   */
+extern "C" int eve_cgru_scan_bwd(int B, int T, const void* dhs_tm, const void* ru, const void* og, const void* hs_tm, const void* h0,
+                                 const void* w1t, const void* w2t, void* dg1_all, void* dg2_all, void* dxs_tm, void* dh0,
+                                 eve_stream_t stream) {
+    if (B <= 0 || T <= 0 || !dhs_tm || !ru || !og || !hs_tm || !w1t || !w2t || !dg1_all || !dg2_all || !dxs_tm)
+        return set_error_msg("cgru_scan_bwd: bad arguments");
+    if ((long long)B * T * CG_PIX * 128 >= (1ll << 31)) return set_error_msg("cgru_scan_bwd: clip too large for 32-bit offsets");
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)cgru_scan_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    EVE_MARK_KERNEL("cgru_scan_bwd_kernel");
+    hipLaunchKernelGGL(cgru_scan_bwd_kernel, dim3((B + CG_IMG - 1) / CG_IMG), dim3(256), CG_LDS, (hipStream_t)stream, B, T,
+                       (const bf16_t*)dhs_tm, (const bf16_t*)ru, (const bf16_t*)og, (const bf16_t*)hs_tm, (const bf16_t*)h0,
+                       (const bf16_t*)w1t, (const bf16_t*)w2t, (bf16_t*)dg1_all, (bf16_t*)dg2_all, (bf16_t*)dxs_tm, (bf16_t*)dh0);
     EVE_CHECK_LAUNCH();
     return 0;
 }

@@ -734,6 +734,23 @@ class HipKernels(object):
                                             self._p(ru), self._p(rh), self._p(og), self._stream()))
         return hs, hs_tm, ru, rh, og
 
+    def cgru_scan_bwd(self, dhs_tm, ru, og, hs_tm, h0, w1_ihwo, w2_ihwo, want_dh0=False):
+        """Backward of cgru_scan_fwd in one launch.  Time-major [T, B, 5, 8, .] bf16 inputs; returns (dg1_all [T,B,5,8,128],
+        dg2_all [T,B,5,8,64], dxs_tm [T,B,5,8,64], dh0 [B,5,8,64] or None)."""
+        T, B, H, W, C = dhs_tm.shape
+        assert (H, W, C) == (5, 8, 64) and dhs_tm.dtype == torch.bfloat16 and dhs_tm.is_contiguous()
+        assert tuple(ru.shape) == (T, B, H, W, 2 * C) and tuple(og.shape) == tuple(hs_tm.shape) == (T, B, H, W, C)
+        assert tuple(w1_ihwo.shape) == (128, 3, 3, 128) and tuple(w2_ihwo.shape) == (128, 3, 3, 64)
+        dev = dhs_tm.device
+        dg1 = torch.empty((T, B, H, W, 2 * C), dtype=torch.bfloat16, device=dev)
+        dg2 = torch.empty((T, B, H, W, C), dtype=torch.bfloat16, device=dev)
+        dxs = torch.empty((T, B, H, W, C), dtype=torch.bfloat16, device=dev)
+        dh0 = torch.empty((B, H, W, C), dtype=torch.bfloat16, device=dev) if want_dh0 else None
+        self._ck(self.lib.eve_cgru_scan_bwd(B, T, self._p(dhs_tm), self._p(ru), self._p(og), self._p(hs_tm), self._p(h0),
+                                            self._p(w1_ihwo), self._p(w2_ihwo), self._p(dg1), self._p(dg2), self._p(dxs),
+                                            self._p(dh0), self._stream()))
+        return dg1, dg2, dxs, dh0
+
     def cgru_gates1(self, g1, h):
         C = h.shape[-1]
         P = h.numel() // C

@@ -824,9 +824,10 @@ class CGRUGates1Fn(torch.autograd.Function):
 class CGRUScanFn(torch.autograd.Function):
     """hs[:, t] = CGRUCell(xs[:, t], hs[:, t-1]) for the whole clip in ONE launch (kernels.cgru_scan_fwd: hidden state
     resident in LDS, both gate convolutions and their sigmoid / tanh / blend epilogues fused; common.py:388-415 applied
-    per frame by refine_net.py:132-176).  The backward walks the frames in reverse with the gate-gradient kernels and the
-    data-gradient convolutions (T-sequential by nature) on TIME-major tensors (every per-frame operand is a contiguous
-    slice: no copies); the two weight gradients and bias gradients are ONE batched launch each over all T*B frames."""
+    per frame by refine_net.py:132-176).  The backward is one persistent launch as well (kernels.cgru_scan_bwd: frames in
+    reverse, gate gradients + both data-gradient GEMMs + the carry into the previous state fused; EVE_AMD_CGRU_SCAN_BWD=0
+    selects the per-frame kernels on time-major tensors); the two weight gradients and bias gradients are ONE batched
+    launch each over all T*B frames."""
 
     @staticmethod
     def forward(ctx, xs, w1, b1, w2, b2, h0, p1, p2):
@@ -847,25 +848,35 @@ class CGRUScanFn(torch.autograd.Function):
         p1, p2 = ctx.packs
         w1, b1, w2, b2 = ctx.params
         B, T, H, W, C = xs.shape
+        need = ctx.needs_input_grad
         dhs_tm = dhs.transpose(0, 1).contiguous()                       # [T, B, ...]
         xs_tm = xs.transpose(0, 1).contiguous()
         first = h0 if h0 is not None else torch.zeros_like(xs_tm[0])
-        dcat1_all = torch.empty((T, B, H, W, 2 * C), dtype=xs.dtype, device=xs.device)      # d[x | h] per frame
-        dcat2_all = torch.empty((T, B, H, W, 2 * C), dtype=xs.dtype, device=xs.device)      # d[r*h | x] per frame
-        dg1_all = torch.empty((T, B, H, W, 2 * C), dtype=xs.dtype, device=xs.device)
-        dg2_all = torch.empty((T, B, H, W, C), dtype=xs.dtype, device=xs.device)
-        carry = None
-        for t in range(T - 1, -1, -1):
-            dhn = dhs_tm[t] if carry is None else k.add(dhs_tm[t], carry)
-            h_prev = hs_tm[t - 1] if t > 0 else first
-            dg2, dru, dh_a = k.cgru_gates2_bwd(dhn, ru[t], h_prev, og[t])
-            dcat2 = k.conv2d_dgrad(dg2, p2.ihwo, (H, W), 1, 1, algo=p2.algo)
-            dg1, dh_b = k.cgru_gates1_bwd(dcat2[..., :C].contiguous(), dru, ru[t], h_prev)
-            dcat1 = k.conv2d_dgrad(dg1, p1.ihwo, (H, W), 1, 1, algo=p1.algo)
-            carry = k.add(k.add(dh_a, dh_b), dcat1[..., C:].contiguous())
-            dcat1_all[t], dcat2_all[t], dg1_all[t], dg2_all[t] = dcat1, dcat2, dg1, dg2
-        # d(xs) = x-halves of the two concatenated-input gradients, for all frames at once
-        dxs = (dcat1_all[..., :C] + dcat2_all[..., C:]).transpose(0, 1).contiguous()
+        want_dh0 = bool(ctx.has_h0 and need[5])
+        if hasattr(k, 'cgru_scan_bwd') and os.environ.get('EVE_AMD_CGRU_SCAN_BWD', '1') != '0':
+            # the whole frame-reversed recursion in one persistent launch (kernels.cgru_scan_bwd): gate gradients, both
+            # data-gradient GEMMs, the carry into the previous state; gradients of the two pre-activations come back for
+            # the batched weight / bias gradients below
+            dg1_all, dg2_all, dxs_tm, dh0 = k.cgru_scan_bwd(dhs_tm, ru, og, hs_tm, h0, p1.ihwo, p2.ihwo, want_dh0)
+            dxs = dxs_tm.transpose(0, 1).contiguous()
+        else:
+            dcat1_all = torch.empty((T, B, H, W, 2 * C), dtype=xs.dtype, device=xs.device)      # d[x | h] per frame
+            dcat2_all = torch.empty((T, B, H, W, 2 * C), dtype=xs.dtype, device=xs.device)      # d[r*h | x] per frame
+            dg1_all = torch.empty((T, B, H, W, 2 * C), dtype=xs.dtype, device=xs.device)
+            dg2_all = torch.empty((T, B, H, W, C), dtype=xs.dtype, device=xs.device)
+            carry = None
+            for t in range(T - 1, -1, -1):
+                dhn = dhs_tm[t] if carry is None else k.add(dhs_tm[t], carry)
+                h_prev = hs_tm[t - 1] if t > 0 else first
+                dg2, dru, dh_a = k.cgru_gates2_bwd(dhn, ru[t], h_prev, og[t])
+                dcat2 = k.conv2d_dgrad(dg2, p2.ihwo, (H, W), 1, 1, algo=p2.algo)
+                dg1, dh_b = k.cgru_gates1_bwd(dcat2[..., :C].contiguous(), dru, ru[t], h_prev)
+                dcat1 = k.conv2d_dgrad(dg1, p1.ihwo, (H, W), 1, 1, algo=p1.algo)
+                carry = k.add(k.add(dh_a, dh_b), dcat1[..., C:].contiguous())
+                dcat1_all[t], dcat2_all[t], dg1_all[t], dg2_all[t] = dcat1, dcat2, dg1, dg2
+            # d(xs) = x-halves of the two concatenated-input gradients, for all frames at once
+            dxs = (dcat1_all[..., :C] + dcat2_all[..., C:]).transpose(0, 1).contiguous()
+            dh0 = carry if want_dh0 else None
         # weight / bias gradients: one launch each over all T*B frames
         h_prev_all = torch.cat([first.unsqueeze(0), hs_tm[:-1]], dim=0)
         cat1 = torch.cat([xs_tm, h_prev_all], dim=-1).view(T * B, H, W, 2 * C)
@@ -881,12 +892,10 @@ class CGRUScanFn(torch.autograd.Function):
             k.bias_grad(dy, db)
             return db
 
-        need = ctx.needs_input_grad
         dw1 = _wgrad_into(k, cat1, g1f, w1, p1, 1, 1) if need[1] else None
         db1 = bgrad(g1f, b1) if need[2] else None
         dw2 = _wgrad_into(k, cat2, g2f, w2, p2, 1, 1) if need[3] else None
         db2 = bgrad(g2f, b2) if need[4] else None
-        dh0 = carry if (ctx.has_h0 and need[5]) else None
         return dxs, dw1, db1, dw2, db2, dh0, None, None
 
 

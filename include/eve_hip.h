@@ -298,6 +298,14 @@ int eve_lstm_scan_bwd(int S, int T, int H, const float* dhs, const float* dcs, c
  * gates, 128 ch), rh (r*h), og (tanh gate).                                                               */
 int eve_cgru_scan_fwd(int B, int T, const void* xs, const void* h0, const void* w1, const float* b1, const void* w2,
                       const float* b2, void* hs, void* hs_tm, void* ru, void* rh, void* og, eve_stream_t stream);
+/* Backward of eve_cgru_scan_fwd in ONE persistent launch (bf16; common.py:400-415 differentiated): frames last to first, the
+ * gradient into the previous hidden state carried in registers.  Time-major inputs [T][B][5][8][.]: dhs_tm (d hs), and the
+ * forward's ru / og / hs_tm; h0 or NULL; w1t = gates_1 bank IHWO [128][3][3][128], w2t = gate_2 bank IHWO [128][3][3][64].
+ * Outputs (time-major): dg1_all [..][128], dg2_all [..][64] (pre-activation gradients: the operands of the batched weight /
+ * bias gradients), dxs_tm [..][64]; dh0 [B][5][8][64] or NULL.                                                             */
+int eve_cgru_scan_bwd(int B, int T, const void* dhs_tm, const void* ru, const void* og, const void* hs_tm, const void* h0,
+                      const void* w1t, const void* w2t, void* dg1_all, void* dg2_all, void* dxs_tm, void* dh0,
+                      eve_stream_t stream);
 int eve_cgru_gates1(int dtype, long long P, int C, const void* g1, const void* h, void* ru, void* rh,
                     eve_stream_t stream);
 int eve_cgru_gates2(int dtype, long long P, int C, const void* g2, const void* ru, const void* h,

@@ -338,6 +338,27 @@ class FakeKernels(object):
             hs.append(h); rus.append(ru); rhs.append(rh); ogs.append(o)
         return torch.stack(hs, 1), torch.stack(hs, 0), torch.stack(rus, 0), torch.stack(rhs, 0), torch.stack(ogs, 0)
 
+    def cgru_scan_bwd(self, dhs_tm, ru, og, hs_tm, h0, w1_ihwo, w2_ihwo, want_dh0=False):
+        """Contract of eve_cgru_scan_bwd: frames last to first, the carry kept in float, the gradients of the two
+        pre-activations rounded to the storage dtype before they enter the data-gradient convolutions."""
+        T, B, H, W, C = dhs_tm.shape
+        dt = dhs_tm.dtype
+        carry = torch.zeros((B, H, W, C))
+        dg1_all, dg2_all, dxs = [None] * T, [None] * T, [None] * T
+        for t in range(T - 1, -1, -1):
+            hp = (hs_tm[t - 1] if t > 0 else (h0 if h0 is not None else torch.zeros_like(hs_tm[0]))).float()
+            r, u, o = ru[t].float()[..., :C], ru[t].float()[..., C:], og[t].float()
+            dhn = dhs_tm[t].float() + carry
+            dg2 = (dhn * (1 - u) * (1 - o * o)).to(dt)
+            g1u = dhn * (hp - o) * u * (1 - u)
+            dcat2 = torch.nn.grad.conv2d_input((B, 2 * C, H, W), w2_ihwo.permute(3, 0, 1, 2).float(), nchw(dg2), 1, 1).permute(0, 2, 3, 1)
+            drh, dx2 = dcat2[..., :C], dcat2[..., C:]
+            dg1 = torch.cat([drh * hp * r * (1 - r), g1u], dim=-1).to(dt)
+            dcat1 = torch.nn.grad.conv2d_input((B, 2 * C, H, W), w1_ihwo.permute(3, 0, 1, 2).float(), nchw(dg1), 1, 1).permute(0, 2, 3, 1)
+            carry = dhn * u + drh * r + dcat1[..., C:]
+            dg1_all[t], dg2_all[t], dxs[t] = dg1, dg2, (dcat1[..., :C] + dx2).to(dt)
+        return torch.stack(dg1_all, 0), torch.stack(dg2_all, 0), torch.stack(dxs, 0), (carry.to(dt) if want_dh0 else None)
+
     def cgru_gates2_bwd(self, dhnew, ru, h, o):
         C = h.shape[-1]
         d, u, of = dhnew.float(), ru.float()[..., C:], o.float()

@@ -1,3 +1,2 @@
-for cfg in "EVE_HALO_PERSIST_ALL=0" "EVE_HALO_PERSIST_ALL=1"; do
-  echo "== $cfg"; env $cfg python tools/bench_conv.py 2>&1 | grep -E "l[1234]_3x3"
-done > gpurun_out/bench_conv.txt 2>&1
+timeout 600 python -m pytest tests/test_gpu_refinenet.py tests/test_gpu_bf16_parity.py -m gpu -q -k "cgru or refinenet" 2>&1 | grep -E "passed|failed|Error|assert|rel" | head -30 > gpurun_out/t_cgru.log
+timeout 600 python tools/bench_eve.py --steps 5 > gpurun_out/c3.log 2>&1
