@@ -19,8 +19,14 @@ Pinning status (see DESIGN.md "Oracle"):
   * The ResNet-18(InstanceNorm) trunk arithmetic lives in torchvision 0.6.1,
     which is absent from /root/reference and from this image; the reference
     has no tests for it.  The trunk restatement (``oracle/resnet_in.py``)
-    follows the published torchvision algorithm and is exercised through the
+    follows the published torchvision algorithm; it is exercised through the
     reference ``EyeNet`` class with the restated trunk injected as
-    ``torchvision.models.resnet`` -- that pins the plumbing around it, while
-    the trunk arithmetic itself is "parity unpinned" by the reference.
+    ``torchvision.models.resnet`` (that pins the plumbing around it) and pinned
+    numerically by an INDEPENDENT implementation of the same architecture that
+    the image does ship -- ``transformers.models.resnet`` with InstanceNorm2d,
+    ``tests/golden/make_golden_trunk.py`` -> ``trunk_independent.npz``.  Not
+    reference-held (nothing is, for this dependency), but not oracle-vs-oracle.
+  * ``oracle/bf16_faithful.py`` is the same oracle with bfloat16 rounding at the
+    tensors the HIP bf16 instantiation stores in bfloat16; with rounding off it
+    reproduces the float32 oracle (tests/test_oracle_golden.py).
 """

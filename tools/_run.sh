@@ -1,2 +1,5 @@
-timeout 600 python -m pytest tests/test_gpu_refinenet.py tests/test_gpu_bf16_parity.py -m gpu -q -k "cgru or refinenet" 2>&1 | grep -E "passed|failed|Error|assert|rel" | head -30 > gpurun_out/t_cgru.log
-timeout 600 python tools/bench_eve.py --steps 5 > gpurun_out/c3.log 2>&1
+cd /tmp && export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_c3 -- python $R/tools/bench_eve.py --steps 5 > $R/gpurun_out/c3.log 2>&1
+cd $R
+python tools/kstats.py $(ls gpurun_out/prof_c3/*/*kernel_stats.csv | head -1) 7 0.3 > gpurun_out/c3_kstats.txt
