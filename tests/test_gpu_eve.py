@@ -125,7 +125,7 @@ EVE_CASES = {
 def make_eve(over, dtype=torch.float32):
     cfg = eve_amd.reset_standalone_config()
     cfg.import_json(os.path.join(REPO, 'configs', 'refine_net.json'))
-    cfg.import_dict(dict(refine_net_rnn_type='CGRU', eye_net_load_pretrained=False, **over))
+    cfg.import_dict(dict(dict(refine_net_rnn_type='CGRU', eye_net_load_pretrained=False), **over))
     model = eve_amd.EVE(output_predictions=True)
     model.eye_net.compute_dtype = dtype
     model.refine_net.compute_dtype = dtype
