@@ -71,6 +71,7 @@ template <> struct Mma<float> {
 }  // namespace eve
 #include "conv_fast.h"
 #include "conv_halo32.h"
+#include "conv_halo_mt.h"
 #include "wgrad_halo.h"
 namespace eve {
 
@@ -559,6 +560,48 @@ static bool launch_halo(const GatherParams& p, const void* src, const void* w, c
     if (p.Cin % 32 || W > 128 || (W & (W - 1)) || W < 4) return false;
     HaloParams h;
     h.N = p.N; h.H = H; h.W = W; h.Cin = p.Cin; h.Cout = p.Cout;
+    // ---- macro tile (conv_halo_mt.h): 256 pixels x 128 / 256 output channels, one 4-wave workgroup per CU ----
+    static int use_mt = -1;
+    if (use_mt < 0) { const char* e = getenv("EVE_HALO_MT"); use_mt = (e && e[0] == '1') ? 1 : 0; }
+    if (use_mt && p.Cout >= 128 && p.Cout % 8 == 0 && 256 % W == 0 && ((epi_act & 0xff) == EVE_ACT_NONE || (epi_act & 0xff) == EVE_ACT_RELU)) {
+        HaloParams m;
+        m.N = p.N; m.H = H; m.W = W; m.Cin = p.Cin; m.Cout = p.Cout;
+        const int rows = 256 / W;
+        bool ok = true;
+        if (rows <= H) { m.TI = 1; m.TH = rows; m.bands = (H + rows - 1) / rows; }
+        else if (rows % H == 0) { m.TI = rows / H; m.TH = H; m.bands = 1; }
+        else ok = false;
+        if (ok && W == 4 && m.TH != 4) ok = false;                     // the W = 4 swizzle table is for 4-row images
+        const int HPm = ok ? m.TI * (m.TH + 2) * (W + 2) : 0;
+        m.a_pieces = (HPm * 4 + 255) / 256;
+        const unsigned long long xb = (unsigned long long)p.N * H * W * p.Cin * 2, wb = (unsigned long long)p.Cout * p.K * 2;
+        if (ok && m.a_pieces <= MT_MAXP && xb < (1ull << 31) && wb < (1ull << 31)) {
+            const bool wide = p.Cout >= 256;
+            const int BN = wide ? 256 : 128;
+            m.flip = bwd ? 1 : 0;
+            m.K = p.K; m.x_bytes = (uint32_t)xb; m.w_bytes = (uint32_t)wb;
+            m.tiles_m = m.TI == 1 ? (uint32_t)p.N * m.bands : (uint32_t)((p.N + m.TI - 1) / m.TI);
+            m.tiles_n = (p.Cout + BN - 1) / BN;
+            m.fd_w2 = make_fastdiv(W + 2); m.fd_hpi = make_fastdiv((m.TH + 2) * (W + 2)); m.fd_w = make_fastdiv(W); m.fd_th = make_fastdiv(m.TH);
+            const size_t ldsm = 2 * (size_t)m.a_pieces * 4096 + 4 * (size_t)(64 * BN);
+            const uint32_t Tm = m.tiles_m * m.tiles_n;
+            const uint32_t rounds = (Tm + 255) / 256;
+            const uint32_t Gm = (Tm + rounds - 1) / rounds;              // balanced persistent grid (<= 256 workgroups)
+            static bool attr_mt = false;
+            if (!attr_mt) {
+                (void)hipFuncSetAttribute((const void*)conv3x3_halo_mt_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                (void)hipFuncSetAttribute((const void*)conv3x3_halo_mt_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                attr_mt = true;
+            }
+            if (wide)
+                EVE_LAUNCH("conv3x3_halo_mt_kernel<4>", (conv3x3_halo_mt_kernel<4>), dim3(Gm), dim3(256), ldsm, s, m, (const bf16_t*)src,
+                           (const bf16_t*)w, bias, epi_act, (bf16_t*)out);
+            else
+                EVE_LAUNCH("conv3x3_halo_mt_kernel<2>", (conv3x3_halo_mt_kernel<2>), dim3(Gm), dim3(256), ldsm, s, m, (const bf16_t*)src,
+                           (const bf16_t*)w, bias, epi_act, (bf16_t*)out);
+            return true;
+        }
+    }
     const bool narrow = p.Cout <= 64;               // 256 pixels x 64 channels (4x1 waves) instead of 128 x 128 (2x2)
     const int BMp = narrow ? 256 : 128;
     const int rows = BMp / W;

@@ -630,10 +630,12 @@ def test_heatmap_head_and_losses_match_aten():
         assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max()) + 1e-9, kind
 
 
-def test_halo32_opt_in_kernel_matches_default(tmp_path):
-    """EVE_HALO_MFMA32=1 selects the 32x32x16-MFMA, software-pipelined halo convolution (conv_halo32.h; kept opt-in, see the
-    launcher's note).  The switch is read once per process, so the comparison runs in a child process: forward and data
-    gradient of the four halo geometries (W = 32 / 16 / 8 / 4 swizzles) against the default kernel's results."""
+@pytest.mark.parametrize('switch', ['EVE_HALO_MFMA32', 'EVE_HALO_MT'])
+def test_opt_in_halo_kernels_match_default(tmp_path, switch):
+    """EVE_HALO_MFMA32=1 selects the 32x32x16-MFMA, software-pipelined halo convolution (conv_halo32.h) and EVE_HALO_MT=1 the
+    256-pixel macro tile with one wave per SIMD (conv_halo_mt.h); both are kept opt-in (slower than the default, see their
+    headers).  The switches are read once per process, so the comparison runs in a child process: forward and data gradient
+    of the four halo geometries (W = 32 / 16 / 8 / 4 swizzles, ragged image counts) against the default kernel's results."""
     import os
     import subprocess
     import sys
@@ -644,7 +646,7 @@ from eve_amd.kernels import HipKernels
 k = HipKernels()
 g = torch.Generator().manual_seed(3)
 outs = []
-for N, H, C in ((20, 32, 64), (12, 16, 128), (24, 8, 256), (64, 4, 512)):
+for N, H, C in ((20, 32, 64), (13, 16, 128), (25, 8, 256), (70, 4, 512)):
     x = torch.randn((N, H, H, C), generator=g).bfloat16().cuda()
     w = (torch.randn((128 if C < 512 else 256, 3, 3, C), generator=g) * (2.0 / (9 * C)) ** 0.5).bfloat16().cuda()
     b = torch.randn((w.shape[0],), generator=g).cuda()
@@ -657,7 +659,7 @@ torch.save(outs, sys.argv[1])
     res = {}
     for mode in ('0', '1'):
         path = os.path.join(str(tmp_path), 'halo%s.pt' % mode)
-        env = dict(os.environ, EVE_HALO_MFMA32=mode)
+        env = dict(os.environ, **{switch: mode})
         p = subprocess.run([sys.executable, '-c', code, path], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
         assert p.returncode == 0, p.stdout[-2000:]
         res[mode] = torch.load(path)
