@@ -781,7 +781,8 @@ static bool launch_wgrad_halo(const GatherParams& p, const void* x, const void* 
     if (const char* e = getenv("EVE_WGRAD_HALO_MIN_M")) min_m = atoll(e);          // (read per call: the tests lower it)
     if (W < 32 || W > 128 || (W & (W - 1)) || p.Cin % 16 || p.Cout % 16 || (long long)p.M < min_m) return false;
     const int MT = p.Cout / 16, CT = p.Cin / 16;
-    if (ks == 3 && !((MT == 1 && (CT == 1 || CT == 2 || CT == 4)) || (MT == 2 && (CT == 1 || CT == 2)))) return false;
+    const bool split = ks == 3 && MT == 4 && CT == 4;        // 64 -> 64 channels: wgrad_halo64_kernel (two bands resident)
+    if (ks == 3 && !split && !((MT == 1 && (CT == 1 || CT == 2 || CT == 4)) || (MT == 2 && (CT == 1 || CT == 2)))) return false;
     if (ks == 1 && !((MT == 2 && CT == 1) || (MT == 1 && CT == 4) || (MT == 1 && CT == 2) || (MT == 4 && CT == 2) || (MT == 2 && CT == 4)))
         return false;
     const unsigned long long xb = (unsigned long long)p.N * H * W * p.Cin * 2, db_ = (unsigned long long)p.M * p.Cout * 2;
@@ -789,6 +790,21 @@ static bool launch_wgrad_halo(const GatherParams& p, const void* x, const void* 
     const size_t red = (size_t)(ks * ks * p.Cin * p.Cout + p.Cout) * 4;
     const unsigned occ = (ks == 3 && MT * CT >= 4) ? 2 : 3;   // workgroups per CU the accumulator registers allow (36 tiles: two)
     int TH = 0; size_t lds = 0;
+    int nreg = 0;
+    if (split) {
+        // wgrad_halo64_kernel: one workgroup per CU with 2 or 3 resident bands (and room for the epilogue's 9 x 64 x 64 + 64 floats)
+        static int force_th = -1, force_nreg = -1;
+        if (force_th < 0) { const char* e = getenv("EVE_WG64_TH"); force_th = e ? atoi(e) : 0; const char* f = getenv("EVE_WG64_NREG"); force_nreg = f ? atoi(f) : 0; }
+        for (int th : {8, 4, 2, 1}) {
+            if (force_th && th != force_th) continue;
+            const size_t need = (size_t)(th + 2) * (W + 2) * 128 + (size_t)th * W * 128;
+            for (int nr : {3, 2}) {
+                if (force_nreg && nr != force_nreg) continue;
+                if (nr * need <= (size_t)160 * 1024) { TH = th; nreg = nr; lds = nr * need > red ? nr * need : red; break; }
+            }
+            if (TH) break;
+        }
+    } else
     for (size_t budget : {(size_t)(occ == 3 ? 52 : 78) * 1024, (size_t)78 * 1024}) {
         for (int th : {4, 2, 1}) {
             const size_t need = (size_t)(th + ks - 1) * (W + ks - 1) * p.Cin * 2 + (size_t)th * W * p.Cout * 2;
@@ -800,7 +816,7 @@ static bool launch_wgrad_halo(const GatherParams& p, const void* x, const void* 
     WgradHaloParams h;
     h.N = p.N; h.H = H; h.W = W; h.TH = TH; h.bands = (H + TH - 1) / TH;
     h.total_bands = (uint32_t)p.N * h.bands; h.x_bytes = (uint32_t)xb; h.dy_bytes = (uint32_t)db_;
-    h.log2_cpr = 0;
+    h.log2_cpr = 0; h.nreg = nreg;
     while ((32 << h.log2_cpr) < W) ++h.log2_cpr;
     const unsigned per_cu = (unsigned)((160 * 1024) / lds);
     unsigned grid = 256 * (per_cu > occ ? occ : per_cu);
@@ -815,7 +831,15 @@ static bool launch_wgrad_halo(const GatherParams& p, const void* x, const void* 
         EVE_LAUNCH("wgrad_halo_kernel<" #MT_ ", " #CT_ ", " #KS_ ">", (wgrad_halo_kernel<MT_, CT_, KS_>), dim3(grid), dim3(256), lds, s, h, \
                    (const bf16_t*)x, (const bf16_t*)dy, dw, db);                                                          \
     } while (0)
-    if (ks == 3) {
+    if (split) {
+        static bool attr_done = false;
+        if (!attr_done) {
+            (void)hipFuncSetAttribute((const void*)wgrad_halo64_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            attr_done = true;
+        }
+        const unsigned g64 = h.total_bands < 256u ? h.total_bands : 256u;
+        EVE_LAUNCH("wgrad_halo64_kernel", wgrad_halo64_kernel, dim3(g64), dim3(512), lds, s, h, (const bf16_t*)x, (const bf16_t*)dy, dw, db);
+    } else if (ks == 3) {
         if (MT == 1 && CT == 1) EVE_WGRAD_HALO_LAUNCH(1, 1, 3);
         else if (MT == 1 && CT == 2) EVE_WGRAD_HALO_LAUNCH(1, 2, 3);
         else if (MT == 1 && CT == 4) EVE_WGRAD_HALO_LAUNCH(1, 4, 3);

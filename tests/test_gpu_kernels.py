@@ -499,6 +499,9 @@ WGRAD_HALO_CASES = [
     (2, 36, 64, 32, 32),       # 36 accumulator tiles, TH = 2
     (2, 72, 128, 64, 16),      # first decoder convolution (K = 576)
     (5, 7, 64, 32, 16),        # odd height
+    (5, 32, 32, 64, 64),       # ResNet layer 1, 64 -> 64 channels: wgrad_halo64_kernel (three bands resident, TH = 4)
+    (3, 21, 64, 64, 64),       # the same with a partial last band and two chunks per row (layer 1 of 256 x 256 patches)
+    (300, 6, 32, 64, 64),      # more bands than workgroups: the persistent walk and both LDS regions
     (2, 72, 128, 16, 32, 1),   # 1x1 skip layer of the first encoder block
     (2, 72, 128, 64, 16, 1),   # 1x1 skip layer of the first decoder block
     (3, 36, 64, 32, 64, 1),    # 1x1 skip layer one level down
@@ -521,7 +524,7 @@ def test_band_resident_weight_gradient(hip, ref, monkeypatch, case):
     for mode, min_m in (('halo', '0'), ('tr', str(1 << 40))):
         monkeypatch.setenv('EVE_WGRAD_HALO_MIN_M', min_m)
         plain = hip.conv2d_wgrad(dev(x), dev(dy), K, K, 1, pad, dev(dw0).clone())
-        assert hip.lib.eve_last_kernel().decode().startswith('wgrad_halo_kernel' if mode == 'halo' else 'wgrad_tr_kernel')
+        assert hip.lib.eve_last_kernel().decode().startswith('wgrad_halo' if mode == 'halo' else 'wgrad_tr_kernel')
         fused_dw, fused_db = dev(dw0).clone(), dev(db0).clone()
         hip.conv2d_wgrad(dev(x), dev(dy), K, K, 1, pad, fused_dw, db=fused_db)
         res[mode] = (plain.cpu(), fused_dw.cpu(), fused_db.cpu())
