@@ -110,6 +110,8 @@ def test_cgru_cell_matches_reference_golden_including_grads():
 
 
 def test_refinenet_bf16_deviation_reported():
+    """Sanity bound only (bf16 storage vs the reference's float32 fixture); the bf16 parity statement is
+    tests/test_gpu_bf16_parity.py (teacher-forced stages against the rounding-faithful oracle + noise envelope)."""
     fx = np.load(os.path.join(GOLDEN, 'refinenet.npz'))
     rb = detweights.refinenet_batch(2, 3, seed=0, invalid_fraction=0.25)
     net, _ = make_net('CGRU', dtype=torch.bfloat16)
