@@ -749,11 +749,17 @@ static int launch_igemm(const GatherParams& p, const void* src, const void* w, c
     return 0;
 }
 
-static void wgrad_split(const GatherParams& p, uint32_t tk, uint32_t tc, uint32_t& splits, uint32_t& rows) {
-    // enough splits of the pixel range for ~4 workgroups per CU, each a multiple of 64 pixels
-    static int target = -1;                           // workgroups per launch the split aims for
-    if (target < 0) { const char* e = getenv("EVE_WGRAD_TARGET_WGS"); target = e ? atoi(e) : 1024; }
-    uint32_t want = ((uint32_t)target + tk * tc - 1) / (tk * tc);
+static void wgrad_split(const GatherParams& p, uint32_t tk, uint32_t tc, size_t lds_per_wg, uint32_t& splits, uint32_t& rows) {
+    // As many splits of the pixel range as fill the chip ONCE: every workgroup ends with one float atomic per element of its
+    // filter tile, and those run at one dword per L2 channel and clock (~270 G/s: 17 M atomics of a 1 024-workgroup launch =
+    // 60 us), so a second, partial round of workgroups costs its atomics and a tail.  Resident workgroups per CU: LDS-bound,
+    // at most 3 by registers.  (Layers 3 / 4: 0.184 / 0.175 -> 0.160 / 0.148 ms against the former fixed target of 1 024.)
+    static int target_env = -1;
+    if (target_env < 0) { const char* e = getenv("EVE_WGRAD_TARGET_WGS"); target_env = e ? atoi(e) : 0; }
+    uint32_t per_cu = lds_per_wg ? (uint32_t)((160 * 1024) / lds_per_wg) : 3;
+    per_cu = per_cu < 1 ? 1 : (per_cu > 3 ? 3 : per_cu);
+    const uint32_t target = target_env > 0 ? (uint32_t)target_env : 256u * per_cu;
+    uint32_t want = target / (tk * tc);
     // ... but no split shorter than ~48 K-steps: prologue, ring fill and the 64 atomics per thread of the epilogue are per
     // workgroup (at B=8 clips the unbounded split cost 4 % of the step; B=32 is not affected)
     static int min_rows = -1;
@@ -891,7 +897,7 @@ static int launch_wgrad(const GatherParams& p, const void* x, const void* dy, co
             const int mode = pow2 ? 1 : ((pow2w && p.OH * p.OW >= 32) ? 2 : 0);
             if (p.Cout > 64) {
                 const uint32_t tk = (p.K + 127) / 128, tc = (p.Cout + 127) / 128;
-                wgrad_split(p, tk, tc, splits, rows);
+                wgrad_split(p, tk, tc, lds_bytes(128, 128), splits, rows);
                 if (mode == 1)      EVE_WGRAD_LAUNCH(2, 2, 1, tk, tc);
                 else if (mode == 2) EVE_WGRAD_LAUNCH(2, 2, 2, tk, tc);
                 else                EVE_WGRAD_LAUNCH(2, 2, 0, tk, tc);
@@ -901,11 +907,11 @@ static int launch_wgrad(const GatherParams& p, const void* x, const void* dy, co
                 // 64-channel 3x3 layers: K = 576 = 3 x 192 exactly (three waves per workgroup) instead of 3 x 256 padded
                 // (0.235 vs 0.246 ms on layer 1; a 3-stage ring for it measured 0.242)
                 const uint32_t tk = p.K / 192;
-                wgrad_split(p, tk, 1, splits, rows);
+                wgrad_split(p, tk, 1, lds_bytes(64, 192), splits, rows);
                 EVE_WGRAD_LAUNCH(1, 3, 1, tk, 1);
             } else {
                 const uint32_t tk = (p.K + 255) / 256, tc = 1;
-                wgrad_split(p, tk, tc, splits, rows);
+                wgrad_split(p, tk, tc, lds_bytes(64, 256), splits, rows);
                 if (mode == 1)      EVE_WGRAD_LAUNCH(1, 4, 1, tk, tc);
                 else if (mode == 2) {
                     // RefineNet's planes (72x128 .. 5x8); its outer levels have 16 / 32 output channels
