@@ -12,7 +12,7 @@ CSRC = os.path.join(HERE, 'csrc')
 LIB_DIR = os.path.join(HERE, 'lib')
 OBJ_DIR = os.path.join(LIB_DIR, 'obj')
 LIB_PATH = os.path.join(LIB_DIR, 'libeve_hip.so')
-FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC']
+FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC'] + os.environ.get('EVE_HIPCC_FLAGS', '').split()
 
 
 def sources():

@@ -560,7 +560,11 @@ __global__ __launch_bounds__(64 * WCO * WK) void wgrad_tr_kernel(const GatherPar
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const uint32_t co = co0 + wco * 64 + mt * 16 + g * 4 + r;
+#ifdef EVE_WGRAD_ABLATE
+                if (co < (uint32_t)p.Cout && acc[mt][kt][r] == 12345.678f) atomicAdd(dw + (size_t)co * p.K + k, acc[mt][kt][r]);
+#else
                 if (co < (uint32_t)p.Cout) atomicAdd(dw + (size_t)co * p.K + k, acc[mt][kt][r]);
+#endif
             }
         }
     if (BIAS && do_bias && t == 0) {

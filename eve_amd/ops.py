@@ -461,12 +461,15 @@ def _block_backward(k, dy, dy2, saved, weights, packs, stride, need_w, lane):
     da, _ = _in_bwd(k, dan, None, a, mr1, ACT_RELU, False)              # act' recomputed from a (no affine / residual)
     dw1 = lane.run(lambda: _wgrad_into(k, x, da, w1, p1, stride, 1), x, da) if need_w[0] else None
     dwd = None
+    dx1 = k.conv2d_dgrad(da, p1.ihwo, hw, stride, 1, algo=p1.algo)
     if pd is not None:
         dd, _ = _in_bwd(k, g, None, d, mrd, ACT_NONE, False)
         dwd = lane.run(lambda: _wgrad_into(k, x, dd, wd, pd, stride, 0), x, dd) if need_w[2] else None
-        g = k.conv2d_dgrad(dd, pd.ihwo, hw, stride, 0, algo=pd.algo)
-    dx1 = k.conv2d_dgrad(da, p1.ihwo, hw, stride, 1, algo=p1.algo)
-    return g, dx1, dw1, dw2, dwd
+        # the 1x1 / stride-s branch reaches one pixel in s*s: added onto conv1's data gradient in that kernel's epilogue
+        # (no zero-filled full-size tensor, and the next InstanceNorm backward reads one summand instead of two)
+        dx1 = k.conv2d_dgrad(dd, pd.ihwo, hw, stride, 0, algo=pd.algo, accumulate_into=dx1)
+        g = None
+    return (dx1, None, dw1, dw2, dwd) if g is None else (g, dx1, dw1, dw2, dwd)
 
 
 class ResNetTrunkFn(torch.autograd.Function):
