@@ -19,7 +19,7 @@ import torch.distributed as dist
 def init_distributed(backend=None):
     """Reads RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment (torch.distributed.run)."""
     world = int(os.environ.get('WORLD_SIZE', '1'))
-    if world <= 1:
+    if world <= 1 and os.environ.get('EVE_AMD_FORCE_DIST', '0') != '1':      # (forced: a one-rank group, to exercise the transport)
         return 0, 0, 1
     rank = int(os.environ['RANK'])
     local_rank = int(os.environ.get('LOCAL_RANK', rank))
@@ -67,7 +67,9 @@ class GradSync(object):
         self._hooks = []
         self._armed = False
         self.launch_counts = []
-        if self.world > 1:
+        # a one-rank group has nothing to exchange; EVE_AMD_FORCE_DIST=1 runs the collectives anyway (transport test)
+        self.active = self.world > 1 or (dist.is_initialized() and os.environ.get('EVE_AMD_FORCE_DIST', '0') == '1')
+        if self.active:
             for p, _, _ in entries:
                 if p.requires_grad:
                     self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
@@ -108,7 +110,7 @@ class GradSync(object):
         """Launch whatever never completed (parameters without a gradient this step) and wait.
         Returns the factor the optimiser must scale the summed gradient by (1 / world)."""
         self._armed = False
-        if self.world > 1:
+        if self.active:
             for b in self.buckets:
                 self._launch(b)
             for h in self._handles:

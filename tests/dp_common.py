@@ -113,6 +113,47 @@ def worker(rank, world, port, tmp, case, device, dtype, use_graph):
     dist.destroy_process_group()
 
 
+def worker_rccl(rank, port, tmp, case, dtype, use_graph, steps):
+    """ONE rank on the GPU with backend nccl (= RCCL): the transport the multi-GPU bench uses, on the only topology a
+    one-GPU box offers.  Communicator creation, the bucket all-reduces launched from the gradient notifications onto
+    the communication stream, their ordering against clip + Adam, and (use_graph) their coexistence with hipGraph replay."""
+    _paths()
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK='0', WORLD_SIZE='1', LOCAL_RANK='0',
+                      EVE_AMD_BUCKET_ELEMS='1000000', EVE_AMD_FORCE_DIST='1', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    os.environ.pop('EVE_AMD_DIST_BACKEND', None)
+    import torch.distributed as dist
+    from eve_amd import parallel
+    install_kernels('cuda')
+    r, _, w = parallel.init_distributed(backend='nccl')
+    assert (r, w) == (0, 1) and dist.get_backend() == 'nccl'
+    cfg, make, full = build(case, 'cuda', dtype, 1e-7 if use_graph else None)
+    tr = make(True, use_graph)
+    batch = {k: v.to('cuda') for k, v in full.items()}
+    for _ in range(steps):
+        terms = tr.step(batch)
+    torch.cuda.synchronize()
+    assert all(c == 1 for c in tr.sync.launch_counts), tr.sync.launch_counts
+    torch.save({'flat': tr.fp.flat.cpu().clone(), 'grad': tr.fp.grad.cpu().clone(), 'loss': float(terms['full_loss'].detach()),
+                'buckets': len(tr.sync.buckets)}, os.path.join(tmp, 'rccl.pt'))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def run_rccl_single_rank(tmp, case, dtype, use_graph):
+    import torch.multiprocessing as mp
+    steps = 3 if use_graph else 2
+    mp.spawn(worker_rccl, args=(free_port(), tmp, case, dtype, use_graph, steps), nprocs=1, join=True)
+    a = torch.load(os.path.join(tmp, 'rccl.pt'))
+    try:
+        flat, grad, loss, lr = single_process(case, 'cuda', dtype, steps=steps, base_lr=1e-7 if use_graph else None)
+    finally:
+        from eve_amd import kernels
+        import eve_amd
+        kernels.set_default_kernels(None)
+        eve_amd.reset_standalone_config()
+    return a, flat, grad, loss, lr
+
+
 def single_process(case, device, dtype, steps=1, base_lr=None):
     install_kernels(device)
     cfg, make, full = build(case, device, dtype, base_lr)

@@ -31,3 +31,21 @@ def test_two_ranks_one_gpu_hipgraph_replay_with_eager_collectives(tmp_path):
     """use_graph with several ranks: forward + backward are captured, the bucket all-reduces, the clip and Adam run
     eagerly behind every replay; three steps (capture + two replays) equal three single-process steps."""
     dp_common.run_and_compare(str(tmp_path), 'eyenet', 'cuda', 'bf16', use_graph=True)
+
+
+@pytest.mark.parametrize('use_graph', [False, True])
+def test_rccl_transport_single_rank(tmp_path, use_graph):
+    """backend nccl (= RCCL) with the one rank a one-GPU box allows: a world of one makes every all-reduce the identity
+    and 1/world = 1, so the distributed trainer (eager launches or hipGraph replay + eager collectives, buckets launched
+    from the in-place weight-gradient notifications onto the communication stream) must reproduce the plain trainer --
+    up to the summation order of the weight-gradient atomics, which differs between any two runs -- and it only does if
+    the collectives are ordered correctly against the backward kernels before them and clip + Adam after them."""
+    import torch
+    a, flat, grad, loss, lr = dp_common.run_rccl_single_rank(str(tmp_path), 'eyenet', 'bf16', use_graph)
+    assert a['buckets'] >= 3
+    # (graph case: the THIRD step's gradient -- last-bit differences of step one pass through two bf16 forward / backward
+    #  passes, whose rounding flips amplify them to the 1e-2 level: tests/test_gpu_bf16_parity.py measures that envelope)
+    assert float((a['grad'] - grad).norm() / grad.norm()) < (1e-5 if not use_graph else 5e-2)
+    assert abs(a['loss'] - loss) < 1e-5 * max(1.0, abs(loss))
+    # Adam's first steps are ~ lr * sign(g): elements whose gradient is round-off noise may flip (see dp_common)
+    assert float(((a['flat'] - flat).abs() > 0.25 * lr).float().mean()) < (2e-3 if not use_graph else 1e-2)
