@@ -35,7 +35,7 @@ template <typename T, int VPT, int ACT>
 __global__ __launch_bounds__(1024) void in_fwd_fused_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, const T* __restrict__ res,
                                                             int act_rt, T* __restrict__ y, float* __restrict__ mr,
-                                                            int HW, int C, float eps) {
+                                                            unsigned char* __restrict__ mask, int HW, int C, float eps) {
     constexpr int VEC = Elem<T>::VEC;
     __shared__ float sh[1024 * VEC];
     const int act = ACT >= 0 ? ACT : act_rt;        // ACT >= 0: activation known at compile time
@@ -96,6 +96,12 @@ __global__ __launch_bounds__(1024) void in_fwd_fused_kernel(const T* __restrict_
                 f[e] = act_fwd(z, act);
             }
             reinterpret_cast<uint4*>(y)[base + i] = Elem<T>::pack(f);
+            if (mask) {                 // one byte per 16-byte vector: bit e = (output e > 0), all the ReLU backward needs of y
+                unsigned m = 0;
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) m |= (f[e] > 0.f ? 1u : 0u) << e;
+                mask[base + i] = (unsigned char)m;
+            }
         }
     }
 }
@@ -106,7 +112,8 @@ __global__ __launch_bounds__(1024) void in_bwd_fused_kernel(const T* __restrict_
                                                             const T* __restrict__ x, const float* __restrict__ mr,
                                                             const float* __restrict__ gamma, int act_rt,
                                                             T* __restrict__ dx, T* __restrict__ dres,
-                                                            float* __restrict__ sums, int HW, int C) {
+                                                            float* __restrict__ sums, const unsigned char* __restrict__ mask,
+                                                            int HW, int C) {
     constexpr int VEC = Elem<T>::VEC;
     __shared__ float sh[1024 * VEC];
     const int act = ACT >= 0 ? ACT : act_rt;        // ACT >= 0: activation known at compile time (no per-element switch)
@@ -140,7 +147,14 @@ __global__ __launch_bounds__(1024) void in_bwd_fused_kernel(const T* __restrict_
             }
             qx[j] = reinterpret_cast<const uint4*>(x)[base + i];
             Elem<T>::unpack(qx[j], xx);
-            if (act != EVE_ACT_NONE) {
+            if (act == EVE_ACT_RELU && mask) {           // sign bits written by the forward instead of the whole of y
+                const unsigned m = mask[base + i];
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) g[e] = (m >> e) & 1u ? g[e] : 0.f;
+                qg[j] = Elem<T>::pack(g);
+                if (dres) reinterpret_cast<uint4*>(dres)[base + i] = qg[j];
+                Elem<T>::unpack(qg[j], g);
+            } else if (act != EVE_ACT_NONE) {
                 float yy[VEC];
                 if (y) {
                     Elem<T>::unpack(reinterpret_cast<const uint4*>(y)[base + i], yy);
@@ -229,7 +243,7 @@ using namespace eve;
 /* returns 0 on launch, -1 if the plane does not fit the fused kernel (caller falls back), >0 on error */
 extern "C" int eve_instnorm_fwd_fused(int dtype, int N, int HW, int C, const void* x, const float* gamma,
                                       const float* beta, const void* res, int act, float eps, void* y,
-                                      float* mean_rstd, eve_stream_t stream) {
+                                      float* mean_rstd, unsigned char* sign_mask, eve_stream_t stream) {
     const int vec = dtype == EVE_DT_BF16 ? 8 : 4;
     if ((dtype != EVE_DT_F32 && dtype != EVE_DT_BF16) || N <= 0 || HW <= 0 || C <= 0 || C % vec || !x || !y ||
         !mean_rstd || ((gamma == nullptr) != (beta == nullptr)))
@@ -239,10 +253,10 @@ extern "C" int eve_instnorm_fwd_fused(int dtype, int N, int HW, int C, const voi
     hipStream_t s = (hipStream_t)stream;
     if (dtype == EVE_DT_BF16) {
         LAUNCH_VPT(in_fwd_fused_kernel, bf16_t, "eve::bf16_t", (const bf16_t*)x, gamma, beta, (const bf16_t*)res, act, (bf16_t*)y,
-                   mean_rstd, HW, C, eps)
+                   mean_rstd, sign_mask, HW, C, eps)
     } else {
         LAUNCH_VPT(in_fwd_fused_kernel, float, "float", (const float*)x, gamma, beta, (const float*)res, act, (float*)y,
-                   mean_rstd, HW, C, eps)
+                   mean_rstd, sign_mask, HW, C, eps)
     }
     EVE_CHECK_LAUNCH();
     return 0;
@@ -250,20 +264,20 @@ extern "C" int eve_instnorm_fwd_fused(int dtype, int N, int HW, int C, const voi
 
 extern "C" int eve_instnorm_bwd_fused(int dtype, int N, int HW, int C, const void* dy, const void* dy2, const void* y, const void* x,
                                       const float* mean_rstd, const float* gamma, int act, void* dx, void* dres,
-                                      float* sums, eve_stream_t stream) {
+                                      float* sums, const unsigned char* sign_mask, eve_stream_t stream) {
     const int vec = dtype == EVE_DT_BF16 ? 8 : 4;
     if ((dtype != EVE_DT_F32 && dtype != EVE_DT_BF16) || N <= 0 || HW <= 0 || C <= 0 || C % vec || !dy || !x ||
-        !mean_rstd || !dx || (act != EVE_ACT_NONE && !y && gamma))
+        !mean_rstd || !dx || (act != EVE_ACT_NONE && !y && gamma && !(act == EVE_ACT_RELU && sign_mask)))
         return set_error_msg("instnorm_bwd_fused: bad arguments");
     int threads, vpt;
     if (!fused_plan(HW * (C / vec), C / vec, threads, vpt)) return -1;
     hipStream_t s = (hipStream_t)stream;
     if (dtype == EVE_DT_BF16) {
         LAUNCH_VPT(in_bwd_fused_kernel, bf16_t, "eve::bf16_t", (const bf16_t*)dy, (const bf16_t*)dy2, (const bf16_t*)y, (const bf16_t*)x, mean_rstd, gamma,
-                   act, (bf16_t*)dx, (bf16_t*)dres, sums, HW, C)
+                   act, (bf16_t*)dx, (bf16_t*)dres, sums, sign_mask, HW, C)
     } else {
         LAUNCH_VPT(in_bwd_fused_kernel, float, "float", (const float*)dy, (const float*)dy2, (const float*)y, (const float*)x, mean_rstd, gamma,
-                   act, (float*)dx, (float*)dres, sums, HW, C)
+                   act, (float*)dx, (float*)dres, sums, sign_mask, HW, C)
     }
     EVE_CHECK_LAUNCH();
     return 0;

@@ -474,32 +474,35 @@ class HipKernels(object):
             self._p(sums), self._stream())), (dy, x, y, dy, x, y, dx, dres))
         return dx, dres, sums
 
-    def instnorm_fwd_fused(self, x, gamma, beta, res, act, eps=1e-5):
-        """Single-launch stats + apply; returns (y, mean_rstd) or None when the plane is too large."""
+    def instnorm_fwd_fused(self, x, gamma, beta, res, act, eps=1e-5, want_mask=False):
+        """Single-launch stats + apply; returns (y, mean_rstd) or None when the plane is too large.
+        want_mask: also the sign mask of y (one byte per 16-byte vector) -> (y, mean_rstd, mask)."""
         N, H, W, C = x.shape
         y = torch.empty_like(x)
         mr = torch.empty((N, C, 2), dtype=torch.float32, device=x.device)
+        mask = torch.empty((x.numel() * x.element_size() // 16,), dtype=torch.uint8, device=x.device) if want_mask else None
         st = self._timed('in_fwd', 0.0, lambda: self.lib.eve_instnorm_fwd_fused(
             dt_code(x.dtype), N, H * W, C, self._p(x), self._p(self._f32(gamma, 'gamma')), self._p(self._f32(beta, 'beta')),
-            self._p(res), act, eps, self._p(y), self._p(mr), self._stream()), (x, res, y))
+            self._p(res), act, eps, self._p(y), self._p(mr), self._p(mask), self._stream()), (x, res, y, mask))
         if st == -1:
             if self.prof:
                 self.prof.pop()          # nothing was launched
             return None
         self._ck(st)
-        return y, mr
+        return (y, mr, mask) if want_mask else (y, mr)
 
-    def instnorm_bwd_fused(self, dy, y, x, mr, gamma, act, want_dres, dy2=None):
+    def instnorm_bwd_fused(self, dy, y, x, mr, gamma, act, want_dres, dy2=None, mask=None):
         """Single-launch backward; returns (dx, dres, sums) or None when the plane is too large.
-        dy2: optional second summand of the incoming gradient (added on load)."""
+        dy2: optional second summand of the incoming gradient (added on load).
+        mask: the forward's sign mask (ReLU only), read instead of y."""
         N, H, W, C = x.shape
         dx = torch.empty_like(x)
         dres = torch.empty_like(x) if want_dres else None
         sums = torch.empty((N, C, 2), dtype=torch.float32, device=x.device)
         st = self._timed('in_bwd', 0.0, lambda: self.lib.eve_instnorm_bwd_fused(
-            dt_code(x.dtype), N, H * W, C, self._p(dy), self._p(dy2), self._p(y), self._p(x), self._p(mr),
-            self._p(self._f32(gamma, 'gamma')), act, self._p(dx), self._p(dres), self._p(sums), self._stream()),
-            (dy, dy2, y, x, dx, dres))
+            dt_code(x.dtype), N, H * W, C, self._p(dy), self._p(dy2), self._p(None if mask is not None else y), self._p(x), self._p(mr),
+            self._p(self._f32(gamma, 'gamma')), act, self._p(dx), self._p(dres), self._p(sums), self._p(mask),
+            self._stream()), (dy, dy2, y if mask is None else mask, x, dx, dres))
         if st == -1:
             if self.prof:
                 self.prof.pop()

@@ -410,17 +410,25 @@ def _wgrad_into(k, x, dy, weight, pack, stride, pad, db=None):
     return dwp[:O, :, :, :I].permute(0, 3, 1, 2)
 
 
-def _in_fwd(k, x, res, act, eps):
-    fused = k.instnorm_fwd_fused(x, None, None, res, act, eps)
+def _in_fwd(k, x, res, act, eps, want_mask=False):
+    """-> (y, mean_rstd[, sign mask or None]).  The mask (one byte per 16-byte vector of y) only comes out of the
+    register-resident kernel; planes too large for it take the multi-pass kernels and the backward reads y."""
+    fused = k.instnorm_fwd_fused(x, None, None, res, act, eps, want_mask=True) if want_mask else \
+        k.instnorm_fwd_fused(x, None, None, res, act, eps)
     if fused is not None:
         return fused
     mr = k.instnorm_stats(x, eps)
-    return k.instnorm_act_fwd(x, mr, None, None, res, act), mr
+    y = k.instnorm_act_fwd(x, mr, None, None, res, act)
+    return (y, mr, None) if want_mask else (y, mr)
 
 
 def _in_bwd(k, dy, y, x, mr, act, want_dres, dy2=None):
-    out = k.instnorm_bwd_fused(dy, y, x, mr, None, act, want_dres, dy2=dy2)
+    """y: the forward's output, or its sign mask (uint8) when the forward produced one."""
+    mask = y if (y is not None and y.dtype == torch.uint8) else None
+    out = k.instnorm_bwd_fused(dy, None if mask is not None else y, x, mr, None, act, want_dres, dy2=dy2, mask=mask) \
+        if mask is not None else k.instnorm_bwd_fused(dy, y, x, mr, None, act, want_dres, dy2=dy2)
     if out is None:
+        assert mask is None, 'a sign mask exists only where the fused kernel fits'
         if dy2 is not None:
             dy = k.add(dy, dy2)
         out = k.instnorm_act_bwd(dy, y, x, mr, None, act, want_dres)
@@ -441,8 +449,9 @@ def _block_forward(k, x, packs, stride, eps):
     else:
         d = mrd = None
         idn = x
-    y, mr2 = _in_fwd(k, b, idn, ACT_RELU, eps)
-    return y, (x, a, mr1, an, b, mr2, y, d, mrd)
+    y, mr2, ymask = _in_fwd(k, b, idn, ACT_RELU, eps, want_mask=True)
+    # the backward needs y only for relu'(y): the sign mask (1/16 of the bytes) when the kernel produced one
+    return y, (x, a, mr1, an, b, mr2, ymask if ymask is not None else y, d, mrd)
 
 
 def _block_backward(k, dy, dy2, saved, weights, packs, stride, need_w, lane):

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define EVE_ABI_VERSION 2
+#define EVE_ABI_VERSION 3
 
 typedef void* eve_stream_t; /* hipStream_t */
 
@@ -187,14 +187,17 @@ int eve_instnorm_act_bwd(int dtype, int N, int HW, int C, const void* dy, const 
  * apply in one launch (also writes mean_rstd), and the whole backward in one read of dy / y / x.
  * Same arithmetic as the three entry points above.  Return -1 (no error text) when the plane does not fit;
  * the caller then uses the multi-pass entry points.                                                 */
+/* sign_mask (nullable, N*HW*C/vec bytes, vec = 16 / sizeof(element)): bit e of byte v = (element e of 16-byte vector v
+ * of y is > 0) -- all a ReLU backward needs of y, at 1/16 of its bytes (the trunk's block-output InstanceNorm).   */
 int eve_instnorm_fwd_fused(int dtype, int N, int HW, int C, const void* x, const float* gamma,
                            const float* beta, const void* res, int act, float eps, void* y,
-                           float* mean_rstd, eve_stream_t stream);
+                           float* mean_rstd, unsigned char* sign_mask, eve_stream_t stream);
 /* dy2 (nullable): a second summand of the incoming gradient, added on load -- the residual fork of a ResNet
  * block delivers d(block input) as two tensors and the sum is never materialised.                      */
+/* sign_mask (nullable; act == EVE_ACT_RELU): the forward's mask, read INSTEAD of y.                          */
 int eve_instnorm_bwd_fused(int dtype, int N, int HW, int C, const void* dy, const void* dy2, const void* y,
                            const void* x, const float* mean_rstd, const float* gamma, int act,
-                           void* dx, void* dres, float* sums, eve_stream_t stream);
+                           void* dx, void* dres, float* sums, const unsigned char* sign_mask, eve_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Element-wise activation gradient: dx = dy * act'(y)  (for Linear/conv epilogue activations).

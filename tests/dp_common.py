@@ -141,7 +141,7 @@ def worker_rccl(rank, port, tmp, case, dtype, use_graph, steps):
 
 def run_rccl_single_rank(tmp, case, dtype, use_graph):
     import torch.multiprocessing as mp
-    steps = 3 if use_graph else 2
+    steps = 3 if use_graph else 1        # eager: the FIRST step's gradient (later ones inherit Adam's sign-flip chaos)
     mp.spawn(worker_rccl, args=(free_port(), tmp, case, dtype, use_graph, steps), nprocs=1, join=True)
     a = torch.load(os.path.join(tmp, 'rccl.pt'))
     try:

@@ -152,17 +152,26 @@ class FakeKernels(object):
         dx = k * (g - s1[:, None, None] / hw - xhat * s2[:, None, None] / hw)
         return dx.to(x.dtype), (g.to(x.dtype) if want_dres else None), torch.stack([s1, s2], dim=-1)
 
-    def instnorm_fwd_fused(self, x, gamma, beta, res, act, eps=1e-5):
+    def instnorm_fwd_fused(self, x, gamma, beta, res, act, eps=1e-5, want_mask=False):
         if x.shape[1] * x.shape[2] * x.shape[3] > 65536:
             return None
         mr = self.instnorm_stats(x, eps)
-        return self.instnorm_act_fwd(x, mr, gamma, beta, res, act), mr
+        y = self.instnorm_act_fwd(x, mr, gamma, beta, res, act)
+        if not want_mask:
+            return y, mr
+        vec = 16 // x.element_size()                     # bit e of byte v = (element e of 16-byte vector v of y > 0)
+        bits = (y.reshape(-1, vec) > 0).to(torch.int32) << torch.arange(vec, dtype=torch.int32)
+        return y, mr, bits.sum(dim=1).to(torch.uint8)
 
-    def instnorm_bwd_fused(self, dy, y, x, mr, gamma, act, want_dres, dy2=None):
+    def instnorm_bwd_fused(self, dy, y, x, mr, gamma, act, want_dres, dy2=None, mask=None):
         if x.shape[1] * x.shape[2] * x.shape[3] > 65536:
             return None
         if dy2 is not None:
             dy = (dy.float() + dy2.float()).to(dy.dtype)
+        if mask is not None:                             # ReLU: any y with the mask's signs gives the same derivative
+            assert act == ACT_RELU and y is None
+            vec = 16 // x.element_size()
+            y = ((mask.to(torch.int32).unsqueeze(1) >> torch.arange(vec, dtype=torch.int32)) & 1).reshape(x.shape).to(x.dtype)
         return self.instnorm_act_bwd(dy, y, x, mr, gamma, act, want_dres)
 
     def act_bwd(self, dy, y, act):

@@ -297,6 +297,17 @@ def test_instnorm_fwd_bwd(hip, ref, dtype, shape):
             close(fb[2], s_w, torch.float32, 'fused instnorm bwd sums', scale=float(s_w.abs().max()) * 4)
             if r is not None:
                 close(fb[1], dres_w, dtype, 'fused instnorm bwd dres')
+            if act == 1:       # ReLU: the forward's sign mask (one byte per 16-byte vector) replaces y in the backward
+                y_m, _, mask = hip.instnorm_fwd_fused(dev(x), dev(g), dev(b), dev(r), act, want_mask=True)
+                assert torch.equal(y_m, fused[0])
+                vec = 16 // x.element_size()
+                want_bits = ((y_m.cpu().reshape(-1, vec) > 0).to(torch.int32) << torch.arange(vec, dtype=torch.int32)).sum(1)
+                assert torch.equal(mask.cpu().to(torch.int32), want_bits)
+                fm = hip.instnorm_bwd_fused(dev(dy), None, dev(x), dev(mr_w), dev(g), act, r is not None, mask=mask)
+                fy = hip.instnorm_bwd_fused(dev(dy), y_m, dev(x), dev(mr_w), dev(g), act, r is not None)
+                assert torch.equal(fm[0], fy[0]) and torch.equal(fm[2], fy[2])          # same arithmetic, bit for bit
+                if r is not None:
+                    assert torch.equal(fm[1], fy[1])
             if r is None and g is None and act != 0:       # act' recomputed from x instead of reading y
                 fb2 = hip.instnorm_bwd_fused(dev(dy), None, dev(x), dev(mr_w), None, act, False)
                 close(fb2[0], dx_w, dtype, 'fused instnorm bwd dx without y', scale=float(dx_w.abs().max()) + 0.05)
