@@ -13,6 +13,7 @@
 namespace eve {
 
 constexpr int LS_TM = 8, LS_TN = 128, LS_KC = 32;     // 8 rows per workgroup: 240 workgroups at M = 1920 (one per CU)
+                                                       // (64-deep K chunks measured no faster: 13.4 vs 12.5 us per launch)
 
 // C[M][Nc] = epi( A'[M][R] . B[R][Nc] ),  A' = A * act'(Y) if Y (same shape as A), epi = act(. + bias).
 // Both operand chunks go through LDS; the next chunk is fetched into registers while the current one is consumed
@@ -27,22 +28,24 @@ __global__ __launch_bounds__(256) void linear_mm_kernel(const float* __restrict_
     const int c0 = blockIdx.y * LS_TN;
     const int col = c0 + (tid & (LS_TN - 1)), rg = tid >> 7;                  // 2 row groups of 4 rows
     const int m0 = blockIdx.x * LS_TM;
-    // staging slots: A' 8 x 32 = 256 values (1 per thread), B 32 x 128 = 4096 values (16 per thread)
-    const int ar = tid >> 5, ak = tid & 31;
+    // staging slots: A' 8 x KC values (KC / 32 per thread), B KC x 128 values (KC / 2 per thread)
+    constexpr int NA = LS_TM * LS_KC / 256, NB = LS_KC / 2;
     const int bc = tid & 127, bk = tid >> 7;                                    // k rows bk, bk + 2, ...
-    float pa[1], pb[16];
+    float pa[NA], pb[NB];
     auto fetch = [&](int k0) {
-        {
-            const int m = m0 + ar, k = k0 + ak;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int e = tid + 256 * i;
+            const int m = m0 + e / LS_KC, k = k0 + e % LS_KC;
             float v = 0.f;
             if (m < M && k < R) {
                 v = A[(size_t)m * R + k];
                 if (Y) v *= act_grad_from_out(Y[(size_t)m * R + k], pro_act);
             }
-            pa[0] = v;
+            pa[i] = v;
         }
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
+        for (int i = 0; i < NB; ++i) {
             const int k = k0 + bk + 2 * i;
             pb[i] = (k < R && c0 + bc < Nc) ? B[(size_t)k * Nc + c0 + bc] : 0.f;
         }
@@ -53,9 +56,10 @@ __global__ __launch_bounds__(256) void linear_mm_kernel(const float* __restrict_
     fetch(0);
     for (int k0 = 0; k0 < R; k0 += LS_KC) {
         __syncthreads();                                   // previous chunk fully consumed
-        sA[ar][ak] = pa[0];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) sB[bk + 2 * i][bc] = pb[i];
+        for (int i = 0; i < NA; ++i) { const int e = tid + 256 * i; sA[e / LS_KC][e % LS_KC] = pa[i]; }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) sB[bk + 2 * i][bc] = pb[i];
         __syncthreads();
         if (k0 + LS_KC < R) fetch(k0 + LS_KC);             // in flight during the FMAs below
 #pragma unroll
