@@ -31,18 +31,35 @@ __device__ __forceinline__ void plane_allreduce(float* s, float* sh, int tid, in
         for (int e = 0; e < VEC; ++e) s[e] += sh[(w * 64 + src_lane) * VEC + e];
 }
 
+// A plane may be dealt to 2^sl workgroups, each owning C >> sl channels of every pixel (the statistics are per channel, so
+// the parts never talk): a 64 Ki-element plane (ResNet layer 1) then runs as two 512-thread workgroups instead of one
+// 1 024-thread one, and a CU holds two independent workgroups whose load / reduce / store phases overlap (3.95-4.1 TB/s ->
+// the 4.4-5.0 of the 512-thread planes).  The parts of a plane are 8 blocks apart: same XCD under round-robin dispatch, so
+// the two halves of every 128-byte line meet in one L2.
+struct PlanePart { uint32_t plane, part; };
+__device__ __forceinline__ PlanePart plane_part(uint32_t b, int sl) {
+    if (sl == 0) return PlanePart{b, 0u};
+    const uint32_t per = 8u << sl, grp = b / per, r = b - grp * per;
+    return PlanePart{grp * 8u + (r & 7u), r >> 3};
+}
+
 template <typename T, int VPT, int ACT>
 __global__ __launch_bounds__(1024) void in_fwd_fused_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, const T* __restrict__ res,
                                                             int act_rt, T* __restrict__ y, float* __restrict__ mr,
-                                                            unsigned char* __restrict__ mask, int HW, int C, float eps) {
+                                                            unsigned char* __restrict__ mask, int N, int HW, int C, int sl,
+                                                            float eps) {
     constexpr int VEC = Elem<T>::VEC;
     __shared__ float sh[1024 * VEC];
     const int act = ACT >= 0 ? ACT : act_rt;        // ACT >= 0: activation known at compile time
     const int tid = threadIdx.x, nthreads = blockDim.x;
-    const int cvecs = C / VEC, nvec = HW * cvecs;
-    const int cv = tid % cvecs;
-    const size_t base = (size_t)blockIdx.x * nvec;
+    const PlanePart pp = plane_part(blockIdx.x, sl);
+    if (pp.plane >= (uint32_t)N) return;
+    const int Cl = C >> sl, cvecs = Cl / VEC, cfull = C / VEC, nvec = HW * cvecs;
+    const int cv = tid % cvecs, lc = 31 - __builtin_clz(cvecs);
+    const size_t base = (size_t)pp.plane * HW * cfull + pp.part * cvecs + cv;
+    const int c0 = pp.part * Cl;                    // first channel of this part
+    auto gi = [&](int i) { return base + (size_t)(i >> lc) * cfull; };       // global vector index of local vector i
     uint4 q[VPT];
     float s[VEC];
 #pragma unroll
@@ -50,7 +67,7 @@ __global__ __launch_bounds__(1024) void in_fwd_fused_kernel(const T* __restrict_
 #pragma unroll
     for (int j = 0; j < VPT; ++j) {
         const int i = tid + j * nthreads;
-        q[j] = i < nvec ? reinterpret_cast<const uint4*>(x)[base + i] : make_uint4(0, 0, 0, 0);
+        q[j] = i < nvec ? reinterpret_cast<const uint4*>(x)[gi(i)] : make_uint4(0, 0, 0, 0);
         float f[VEC];
         Elem<T>::unpack(q[j], f);
 #pragma unroll
@@ -74,12 +91,12 @@ __global__ __launch_bounds__(1024) void in_fwd_fused_kernel(const T* __restrict_
 #pragma unroll
     for (int e = 0; e < VEC; ++e) {
         const float rstd = rsqrtf(s[e] * inv + eps);
-        const int c = cv * VEC + e;
+        const int c = c0 + cv * VEC + e;
         a[e] = rstd; b[e] = -mean[e] * rstd;
         if (gamma) { a[e] *= gamma[c]; b[e] = b[e] * gamma[c] + beta[c]; }
         if (tid < cvecs) {
-            mr[((size_t)blockIdx.x * C + c) * 2] = mean[e];
-            mr[((size_t)blockIdx.x * C + c) * 2 + 1] = rstd;
+            mr[((size_t)pp.plane * C + c) * 2] = mean[e];
+            mr[((size_t)pp.plane * C + c) * 2 + 1] = rstd;
         }
     }
 #pragma unroll
@@ -88,19 +105,19 @@ __global__ __launch_bounds__(1024) void in_fwd_fused_kernel(const T* __restrict_
         if (i < nvec) {
             float f[VEC], r[VEC];
             Elem<T>::unpack(q[j], f);
-            if (res) Elem<T>::unpack(reinterpret_cast<const uint4*>(res)[base + i], r);
+            if (res) Elem<T>::unpack(reinterpret_cast<const uint4*>(res)[gi(i)], r);
 #pragma unroll
             for (int e = 0; e < VEC; ++e) {
                 float z = f[e] * a[e] + b[e];
                 if (res) z += r[e];
                 f[e] = act_fwd(z, act);
             }
-            reinterpret_cast<uint4*>(y)[base + i] = Elem<T>::pack(f);
+            reinterpret_cast<uint4*>(y)[gi(i)] = Elem<T>::pack(f);
             if (mask) {                 // one byte per 16-byte vector: bit e = (output e > 0), all the ReLU backward needs of y
                 unsigned m = 0;
 #pragma unroll
                 for (int e = 0; e < VEC; ++e) m |= (f[e] > 0.f ? 1u : 0u) << e;
-                mask[base + i] = (unsigned char)m;
+                mask[gi(i)] = (unsigned char)m;
             }
         }
     }
@@ -113,17 +130,21 @@ __global__ __launch_bounds__(1024) void in_bwd_fused_kernel(const T* __restrict_
                                                             const float* __restrict__ gamma, int act_rt,
                                                             T* __restrict__ dx, T* __restrict__ dres,
                                                             float* __restrict__ sums, const unsigned char* __restrict__ mask,
-                                                            int HW, int C) {
+                                                            int N, int HW, int C, int sl) {
     constexpr int VEC = Elem<T>::VEC;
     __shared__ float sh[1024 * VEC];
     const int act = ACT >= 0 ? ACT : act_rt;        // ACT >= 0: activation known at compile time (no per-element switch)
     const int tid = threadIdx.x, nthreads = blockDim.x;
-    const int cvecs = C / VEC, nvec = HW * cvecs;
-    const int cv = tid % cvecs;
-    const size_t base = (size_t)blockIdx.x * nvec;
+    const PlanePart pp = plane_part(blockIdx.x, sl);
+    if (pp.plane >= (uint32_t)N) return;
+    const int Cl = C >> sl, cvecs = Cl / VEC, cfull = C / VEC, nvec = HW * cvecs;
+    const int cv = tid % cvecs, lc = 31 - __builtin_clz(cvecs);
+    const size_t base = (size_t)pp.plane * HW * cfull + pp.part * cvecs + cv;
+    const int c0 = pp.part * Cl;
+    auto gi = [&](int i) { return base + (size_t)(i >> lc) * cfull; };
     float mean[VEC], rstd[VEC];
     {
-        const float* m = mr + ((size_t)blockIdx.x * C + cv * VEC) * 2;
+        const float* m = mr + ((size_t)pp.plane * C + c0 + cv * VEC) * 2;
 #pragma unroll
         for (int e = 0; e < VEC; ++e) { mean[e] = m[2 * e]; rstd[e] = m[2 * e + 1]; }
     }
@@ -138,26 +159,26 @@ __global__ __launch_bounds__(1024) void in_bwd_fused_kernel(const T* __restrict_
         qx[j] = make_uint4(0, 0, 0, 0);
         if (i < nvec) {
             float g[VEC], xx[VEC];
-            Elem<T>::unpack(reinterpret_cast<const uint4*>(dy)[base + i], g);
+            Elem<T>::unpack(reinterpret_cast<const uint4*>(dy)[gi(i)], g);
             if (dy2) {                  // the gradient arrives as two summands (residual fork): add on load
                 float g2[VEC];
-                Elem<T>::unpack(reinterpret_cast<const uint4*>(dy2)[base + i], g2);
+                Elem<T>::unpack(reinterpret_cast<const uint4*>(dy2)[gi(i)], g2);
 #pragma unroll
                 for (int e = 0; e < VEC; ++e) g[e] += g2[e];
             }
-            qx[j] = reinterpret_cast<const uint4*>(x)[base + i];
+            qx[j] = reinterpret_cast<const uint4*>(x)[gi(i)];
             Elem<T>::unpack(qx[j], xx);
             if (act == EVE_ACT_RELU && mask) {           // sign bits written by the forward instead of the whole of y
-                const unsigned m = mask[base + i];
+                const unsigned m = mask[gi(i)];
 #pragma unroll
                 for (int e = 0; e < VEC; ++e) g[e] = (m >> e) & 1u ? g[e] : 0.f;
                 qg[j] = Elem<T>::pack(g);
-                if (dres) reinterpret_cast<uint4*>(dres)[base + i] = qg[j];
+                if (dres) reinterpret_cast<uint4*>(dres)[gi(i)] = qg[j];
                 Elem<T>::unpack(qg[j], g);
             } else if (act != EVE_ACT_NONE) {
                 float yy[VEC];
                 if (y) {
-                    Elem<T>::unpack(reinterpret_cast<const uint4*>(y)[base + i], yy);
+                    Elem<T>::unpack(reinterpret_cast<const uint4*>(y)[gi(i)], yy);
                 } else {            // no affine, no residual: y = act(xhat), and sign(xhat) = sign(x - mean)
 #pragma unroll
                     for (int e = 0; e < VEC; ++e) yy[e] = act_fwd((xx[e] - mean[e]) * rstd[e], act);
@@ -165,12 +186,12 @@ __global__ __launch_bounds__(1024) void in_bwd_fused_kernel(const T* __restrict_
 #pragma unroll
                 for (int e = 0; e < VEC; ++e) g[e] *= act_grad_from_out(yy[e], act);
                 qg[j] = Elem<T>::pack(g);
-                if (dres) reinterpret_cast<uint4*>(dres)[base + i] = qg[j];
+                if (dres) reinterpret_cast<uint4*>(dres)[gi(i)] = qg[j];
                 // keep the arithmetic on the SAME rounded g the two-pass kernel and dres see
                 Elem<T>::unpack(qg[j], g);
             } else {
                 qg[j] = Elem<T>::pack(g);
-                if (dres) reinterpret_cast<uint4*>(dres)[base + i] = qg[j];
+                if (dres) reinterpret_cast<uint4*>(dres)[gi(i)] = qg[j];
             }
 #pragma unroll
             for (int e = 0; e < VEC; ++e) {
@@ -182,7 +203,7 @@ __global__ __launch_bounds__(1024) void in_bwd_fused_kernel(const T* __restrict_
     plane_allreduce<VEC>(s1, sh, tid, nthreads, cvecs);
     plane_allreduce<VEC>(s2, sh, tid, nthreads, cvecs);
     if (sums && tid < cvecs) {
-        float* o = sums + ((size_t)blockIdx.x * C + cv * VEC) * 2;
+        float* o = sums + ((size_t)pp.plane * C + c0 + cv * VEC) * 2;
 #pragma unroll
         for (int e = 0; e < VEC; ++e) { o[2 * e] = s1[e]; o[2 * e + 1] = s2[e]; }
     }
@@ -191,7 +212,7 @@ __global__ __launch_bounds__(1024) void in_bwd_fused_kernel(const T* __restrict_
 #pragma unroll
     for (int e = 0; e < VEC; ++e) {
         s1[e] *= inv; s2[e] *= inv;
-        k[e] = rstd[e] * (gamma ? gamma[cv * VEC + e] : 1.f);
+        k[e] = rstd[e] * (gamma ? gamma[c0 + cv * VEC + e] : 1.f);
     }
 #pragma unroll
     for (int j = 0; j < VPT; ++j) {
@@ -202,14 +223,19 @@ __global__ __launch_bounds__(1024) void in_bwd_fused_kernel(const T* __restrict_
             Elem<T>::unpack(qx[j], xx);
 #pragma unroll
             for (int e = 0; e < VEC; ++e) g[e] = k[e] * (g[e] - s1[e] - (xx[e] - mean[e]) * rstd[e] * s2[e]);
-            reinterpret_cast<uint4*>(dx)[base + i] = Elem<T>::pack(g);
+            reinterpret_cast<uint4*>(dx)[gi(i)] = Elem<T>::pack(g);
         }
     }
 }
 
 // threads per block and vectors per thread for a plane of nvec 16-byte vectors; false if it does not fit
-static bool fused_plan(int nvec, int cvecs, int& threads, int& vpt) {
+static bool fused_plan(int nvec, int cvecs, int& threads, int& vpt, int& sl) {
     if (nvec <= 0 || cvecs <= 0 || cvecs > 128 || (cvecs & (cvecs - 1))) return false;
+    // planes that would need a 1 024-thread workgroup go to two 512-thread ones, half the channels each
+    static int split_on = -1;
+    if (split_on < 0) { const char* e = getenv("EVE_IN_SPLIT"); split_on = (e && e[0] == '0') ? 0 : 1; }
+    sl = 0;
+    if (split_on && nvec > 4096 && nvec <= 8192 && cvecs >= 2) { sl = 1; nvec /= 2; cvecs /= 2; }
     // as many vectors per thread as leaves >= `min_threads` threads: fewer, fatter workgroups per plane let several
     // planes share a CU, so one plane's reduction phase overlaps another's loads / stores
     static int min_threads = -1;
@@ -229,10 +255,10 @@ using namespace eve;
 // (the kernel symbol is recorded the way rocprofv3 prints it, for the bench's per-kernel attribution)
 #define LAUNCH_VPT_A(KERNEL, T, TS, A, AS, ...)                                                                              \
     switch (vpt) {                                                                                                           \
-        case 1: EVE_LAUNCH(#KERNEL "<" TS ", 1, " AS ">", (KERNEL<T, 1, A>), dim3(N), dim3(threads), 0, s, __VA_ARGS__); break;  \
-        case 2: EVE_LAUNCH(#KERNEL "<" TS ", 2, " AS ">", (KERNEL<T, 2, A>), dim3(N), dim3(threads), 0, s, __VA_ARGS__); break;  \
-        case 4: EVE_LAUNCH(#KERNEL "<" TS ", 4, " AS ">", (KERNEL<T, 4, A>), dim3(N), dim3(threads), 0, s, __VA_ARGS__); break;  \
-        default: EVE_LAUNCH(#KERNEL "<" TS ", 8, " AS ">", (KERNEL<T, 8, A>), dim3(N), dim3(threads), 0, s, __VA_ARGS__); break; \
+        case 1: EVE_LAUNCH(#KERNEL "<" TS ", 1, " AS ">", (KERNEL<T, 1, A>), dim3(grid), dim3(threads), 0, s, __VA_ARGS__); break;  \
+        case 2: EVE_LAUNCH(#KERNEL "<" TS ", 2, " AS ">", (KERNEL<T, 2, A>), dim3(grid), dim3(threads), 0, s, __VA_ARGS__); break;  \
+        case 4: EVE_LAUNCH(#KERNEL "<" TS ", 4, " AS ">", (KERNEL<T, 4, A>), dim3(grid), dim3(threads), 0, s, __VA_ARGS__); break;  \
+        default: EVE_LAUNCH(#KERNEL "<" TS ", 8, " AS ">", (KERNEL<T, 8, A>), dim3(grid), dim3(threads), 0, s, __VA_ARGS__); break; \
     }
 // the two activations of the ResNet trunk get their own instantiation; everything else takes the run-time switch
 #define LAUNCH_VPT(KERNEL, T, TS, ...)                                                                    \
@@ -248,15 +274,16 @@ extern "C" int eve_instnorm_fwd_fused(int dtype, int N, int HW, int C, const voi
     if ((dtype != EVE_DT_F32 && dtype != EVE_DT_BF16) || N <= 0 || HW <= 0 || C <= 0 || C % vec || !x || !y ||
         !mean_rstd || ((gamma == nullptr) != (beta == nullptr)))
         return set_error_msg("instnorm_fwd_fused: bad arguments");
-    int threads, vpt;
-    if (!fused_plan(HW * (C / vec), C / vec, threads, vpt)) return -1;
+    int threads, vpt, sl;
+    if (!fused_plan(HW * (C / vec), C / vec, threads, vpt, sl)) return -1;
+    const unsigned grid = sl ? (unsigned)((N + 7) / 8) * (8u << sl) : (unsigned)N;
     hipStream_t s = (hipStream_t)stream;
     if (dtype == EVE_DT_BF16) {
         LAUNCH_VPT(in_fwd_fused_kernel, bf16_t, "eve::bf16_t", (const bf16_t*)x, gamma, beta, (const bf16_t*)res, act, (bf16_t*)y,
-                   mean_rstd, sign_mask, HW, C, eps)
+                   mean_rstd, sign_mask, N, HW, C, sl, eps)
     } else {
         LAUNCH_VPT(in_fwd_fused_kernel, float, "float", (const float*)x, gamma, beta, (const float*)res, act, (float*)y,
-                   mean_rstd, sign_mask, HW, C, eps)
+                   mean_rstd, sign_mask, N, HW, C, sl, eps)
     }
     EVE_CHECK_LAUNCH();
     return 0;
@@ -269,15 +296,16 @@ extern "C" int eve_instnorm_bwd_fused(int dtype, int N, int HW, int C, const voi
     if ((dtype != EVE_DT_F32 && dtype != EVE_DT_BF16) || N <= 0 || HW <= 0 || C <= 0 || C % vec || !dy || !x ||
         !mean_rstd || !dx || (act != EVE_ACT_NONE && !y && gamma && !(act == EVE_ACT_RELU && sign_mask)))
         return set_error_msg("instnorm_bwd_fused: bad arguments");
-    int threads, vpt;
-    if (!fused_plan(HW * (C / vec), C / vec, threads, vpt)) return -1;
+    int threads, vpt, sl;
+    if (!fused_plan(HW * (C / vec), C / vec, threads, vpt, sl)) return -1;
+    const unsigned grid = sl ? (unsigned)((N + 7) / 8) * (8u << sl) : (unsigned)N;
     hipStream_t s = (hipStream_t)stream;
     if (dtype == EVE_DT_BF16) {
         LAUNCH_VPT(in_bwd_fused_kernel, bf16_t, "eve::bf16_t", (const bf16_t*)dy, (const bf16_t*)dy2, (const bf16_t*)y, (const bf16_t*)x, mean_rstd, gamma,
-                   act, (bf16_t*)dx, (bf16_t*)dres, sums, sign_mask, HW, C)
+                   act, (bf16_t*)dx, (bf16_t*)dres, sums, sign_mask, N, HW, C, sl)
     } else {
         LAUNCH_VPT(in_bwd_fused_kernel, float, "float", (const float*)dy, (const float*)dy2, (const float*)y, (const float*)x, mean_rstd, gamma,
-                   act, (float*)dx, (float*)dres, sums, sign_mask, HW, C)
+                   act, (float*)dx, (float*)dres, sums, sign_mask, N, HW, C, sl)
     }
     EVE_CHECK_LAUNCH();
     return 0;

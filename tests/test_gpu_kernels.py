@@ -258,7 +258,8 @@ def test_conv_rejects_bad_shapes(hip):
 
 
 PLANE_CASES = [(3, 32, 32, 64), (2, 4, 4, 512), (2, 5, 8, 64), (2, 72, 128, 16), (2, 9, 16, 256), (1, 7, 5, 8),
-               (2, 16, 16, 128), (3, 8, 8, 256), (2, 18, 32, 64), (2, 36, 64, 32), (2, 64, 64, 64)]
+               (2, 16, 16, 128), (3, 8, 8, 256), (2, 18, 32, 64), (2, 36, 64, 32), (2, 64, 64, 64),
+               (11, 32, 32, 64)]         # (planes of 4 097 .. 8 192 vectors are dealt to two workgroups, 8 blocks apart)
 
 
 @pytest.mark.parametrize('dtype', DTYPES, ids=['f32', 'bf16'])
