@@ -326,7 +326,9 @@ __global__ __launch_bounds__(64 * WCO * WK) void wgrad_tr_kernel(const GatherPar
     constexpr int BUF = STEP * (PROW + QROW);                // bytes per stage (16 KB / 20 KB)
     // 128x128 tiles: 3 stages of 16 KB -> three workgroups per CU (after the address-arithmetic diet this beats the
     // 4-deep ring with two workgroups by 7-9 % on layers 3/4); 64x256 tiles: 4 stages of 20 KB, two workgroups
-    constexpr int RING = WCO == 2 ? 3 : 4;
+    // 64 x 256 tiles of RefineNet's planes (MODE 2): three 20 KB stages = two workgroups per CU instead of one (-9 %);
+    // the stem's weight gradient (MODE 1, one long pixel range per workgroup) measured better with four
+    constexpr int RING = (WCO == 2 || (WK == 4 && MODE == 2)) ? 3 : 4;
     static_assert(P_SLOTS % 64 == 0 && Q_SLOTS % 64 == 0 && NT % 64 == 0, "wave-granular slot wrap-around");
     extern __shared__ __attribute__((aligned(16))) char lds[];   // RING * BUF bytes
 
@@ -505,8 +507,9 @@ __global__ __launch_bounds__(64 * WCO * WK) void wgrad_tr_kernel(const GatherPar
         offsets(m_begin + (RING - 1) * STEP, vp, vq);
         auto do_step = [&](int st) {
             // stage st has landed once at most the RING-2 newer stages are outstanding (loads return in order)
-            static_assert((RING == 3 && (NDMA == 4 || NDMA == 6)) || (RING == 4 && (NDMA == 4 || NDMA == 5 || NDMA == 6)), "immediates below");
+            static_assert((RING == 3 && (NDMA == 4 || NDMA == 5 || NDMA == 6)) || (RING == 4 && (NDMA == 4 || NDMA == 5 || NDMA == 6)), "immediates below");
             if (RING == 3 && NDMA == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else if (RING == 3 && NDMA == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
             else if (RING == 3) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
             else if (NDMA == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
             else if (NDMA == 5) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");

@@ -872,8 +872,8 @@ static int launch_wgrad(const GatherParams& p, const void* x, const void* dy, co
         if (x_bytes < (1ull << 31) && dy_bytes < (1ull << 31)) {
             uint32_t splits, rows;
             const bool pow2 = ((p.OW & (p.OW - 1)) == 0) && ((p.OH & (p.OH - 1)) == 0);
-            // dynamic LDS = RING (4) stages of 32 pixels x (BCO + BKK) bf16
-            auto lds_bytes = [](int bco, int bkk) { return (size_t)(bco == 128 ? 3 : 4) * 32 * (bco + bkk) * 2; };
+            // dynamic LDS = RING (3 or 4, as in wgrad_tr_kernel) stages of 32 pixels x (BCO + BKK) bf16
+            auto lds_bytes = [](int bco, int bkk, int mode) { return (size_t)((bco == 128 || (bkk == 256 && mode == 2)) ? 3 : 4) * 32 * (bco + bkk) * 2; };
 #define EVE_WGRAD_LAUNCH2(WCO_, WK_, P2_, B_, MT_, TK, TC)                                                              \
     do {                                                                                                                \
         static bool attr_done = false;                                                                                  \
@@ -883,7 +883,7 @@ static int launch_wgrad(const GatherParams& p, const void* x, const void* dy, co
             attr_done = true;                                                                                           \
         }                                                                                                               \
         EVE_LAUNCH("wgrad_tr_kernel<" #WCO_ ", " #WK_ ", " #P2_ ", mt" #MT_ ">", (wgrad_tr_kernel<WCO_, WK_, P2_, B_, MT_>), \
-                   dim3((TK) * (TC) * splits), dim3(64 * WCO_ * WK_), lds_bytes(64 * WCO_, 64 * WK_), s, p, (const bf16_t*)x, \
+                   dim3((TK) * (TC) * splits), dim3(64 * WCO_ * WK_), lds_bytes(64 * WCO_, 64 * WK_, P2_), s, p, (const bf16_t*)x, \
                    (const bf16_t*)dy, dw, rows, (uint32_t)x_bytes, (uint32_t)dy_bytes, db);                               \
     } while (0)
 #define EVE_WGRAD_LAUNCH1(WCO_, WK_, P2_, MT_, TK, TC)                                                                  \
@@ -897,7 +897,7 @@ static int launch_wgrad(const GatherParams& p, const void* x, const void* dy, co
             const int mode = pow2 ? 1 : ((pow2w && p.OH * p.OW >= 32) ? 2 : 0);
             if (p.Cout > 64) {
                 const uint32_t tk = (p.K + 127) / 128, tc = (p.Cout + 127) / 128;
-                wgrad_split(p, tk, tc, lds_bytes(128, 128), splits, rows);
+                wgrad_split(p, tk, tc, lds_bytes(128, 128, mode), splits, rows);
                 if (mode == 1)      EVE_WGRAD_LAUNCH(2, 2, 1, tk, tc);
                 else if (mode == 2) EVE_WGRAD_LAUNCH(2, 2, 2, tk, tc);
                 else                EVE_WGRAD_LAUNCH(2, 2, 0, tk, tc);
@@ -907,11 +907,11 @@ static int launch_wgrad(const GatherParams& p, const void* x, const void* dy, co
                 // 64-channel 3x3 layers: K = 576 = 3 x 192 exactly (three waves per workgroup) instead of 3 x 256 padded
                 // (0.235 vs 0.246 ms on layer 1; a 3-stage ring for it measured 0.242)
                 const uint32_t tk = p.K / 192;
-                wgrad_split(p, tk, 1, lds_bytes(64, 192), splits, rows);
+                wgrad_split(p, tk, 1, lds_bytes(64, 192, mode), splits, rows);
                 EVE_WGRAD_LAUNCH(1, 3, 1, tk, 1);
             } else {
                 const uint32_t tk = (p.K + 255) / 256, tc = 1;
-                wgrad_split(p, tk, tc, lds_bytes(64, 256), splits, rows);
+                wgrad_split(p, tk, tc, lds_bytes(64, 256, mode), splits, rows);
                 if (mode == 1)      EVE_WGRAD_LAUNCH(1, 4, 1, tk, tc);
                 else if (mode == 2) {
                     // RefineNet's planes (72x128 .. 5x8); its outer levels have 16 / 32 output channels
