@@ -326,8 +326,9 @@ __global__ __launch_bounds__(64 * WCO * WK) void wgrad_tr_kernel(const GatherPar
     constexpr int BUF = STEP * (PROW + QROW);                // bytes per stage (16 KB / 20 KB)
     // 128x128 tiles: 3 stages of 16 KB -> three workgroups per CU (after the address-arithmetic diet this beats the
     // 4-deep ring with two workgroups by 7-9 % on layers 3/4); 64x256 tiles: 4 stages of 20 KB, two workgroups
-    // 64 x 256 tiles of RefineNet's planes (MODE 2): three 20 KB stages = two workgroups per CU instead of one (-9 %);
-    // the stem's weight gradient (MODE 1, one long pixel range per workgroup) measured better with four
+    // 64 x 256 tiles: three stages measured 9 % faster than four on RefineNet's planes (MODE 2: 2.19 -> 2.0 ms per configs[2]
+    // step) and 4 % slower on the stem's weight gradient (MODE 1); both depths leave two workgroups per CU
+    // (tools/probes/occupancy.hip)
     constexpr int RING = (WCO == 2 || (WK == 4 && MODE == 2)) ? 3 : 4;
     static_assert(P_SLOTS % 64 == 0 && Q_SLOTS % 64 == 0 && NT % 64 == 0, "wave-granular slot wrap-around");
     extern __shared__ __attribute__((aligned(16))) char lds[];   // RING * BUF bytes
