@@ -318,6 +318,60 @@ def test_instnorm_fwd_bwd(hip, ref, dtype, shape):
             close(s2, s_w, torch.float32, 'instnorm_act bwd sums without y', scale=float(s_w.abs().max()) * 4)
 
 
+def test_channel_split_instnorm_equals_the_single_workgroup_kernel(tmp_path):
+    """Planes of 4 097 .. 8 192 vectors run as two 512-thread workgroups, half the channels each (EVE_IN_SPLIT=0: one
+    1 024-thread workgroup).  Same arithmetic per channel, only the order of the plane reductions differs: forward with
+    residual + sign mask, backward with the two-summand gradient, the mask or y, dres and the per-plane sums -- masks and
+    dres bit-equal, everything else within one rounding of the reduction order.  (The switch is read once per process.)"""
+    import os
+    import subprocess
+    import sys
+    code = r'''
+import sys, torch
+sys.path.insert(0, %r)
+from eve_amd.kernels import HipKernels
+k = HipKernels()
+g = torch.Generator().manual_seed(5)
+outs = []
+for dt in (torch.float32, torch.bfloat16):
+    for (N, H, W, C) in ((3, 16, 16, 128), (11, 32, 32, 64), (2, 18, 32, 64)):
+        x, r, dy, dy2 = (torch.randn((N, H, W, C), generator=g).to(dt).cuda() for _ in range(4))
+        f = k.instnorm_fwd_fused(x, None, None, r, 1, want_mask=True)
+        if f is None:
+            outs.append(None)
+            continue
+        y, mr, mask = f
+        b = k.instnorm_bwd_fused(dy, None, x, mr, None, 1, True, dy2=dy2, mask=mask)
+        b2 = k.instnorm_bwd_fused(dy, y, x, mr, None, 1, True, dy2=dy2)
+        outs.append([t.float().cpu() for t in (y, mr, mask, b[0], b[1], b[2], b2[0], b2[1])])
+torch.save(outs, sys.argv[1])
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for mode in ('1', '0'):
+        path = os.path.join(str(tmp_path), 'in%s.pt' % mode)
+        p = subprocess.run([sys.executable, '-c', code, path], env=dict(os.environ, EVE_IN_SPLIT=mode), stdout=subprocess.PIPE,
+                           stderr=subprocess.STDOUT, text=True, timeout=600)
+        assert p.returncode == 0, p.stdout[-2000:]
+        res[mode] = torch.load(path)
+    compared = 0
+    for a, b in zip(res['1'], res['0']):
+        assert (a is None) == (b is None)
+        if a is None:
+            continue
+        compared += 1
+        y1, mr1, m1, dx1, dres1, s1, dxy1, dresy1 = a
+        y0, mr0, m0, dx0, dres0, s0, dxy0, dresy0 = b
+        assert float((mr1 - mr0).abs().max()) <= 1e-6 * float(mr0.abs().max())
+        ulp = 2.0 ** -7                                      # bf16 outputs may move by one rounding where a statistic did
+        assert float((y1 - y0).abs().max()) <= ulp * float(y0.abs().max())
+        assert float((m1 != m0).float().mean()) <= 1e-4      # a sign can only flip where y is within a rounding of 0
+        assert torch.equal(dres1, dres0) or float((dres1 != dres0).float().mean()) <= 1e-4
+        assert torch.equal(dx1, dxy1) and torch.equal(dres1, dresy1)          # mask or y: the same backward
+        assert float((dx1 - dx0).abs().max()) <= ulp * float(dx0.abs().max())
+        assert float((s1 - s0).abs().max()) <= 1e-5 * float(s0.abs().max())
+    assert compared >= 4
+
+
 @pytest.mark.parametrize('dtype', DTYPES, ids=['f32', 'bf16'])
 def test_elementwise(hip, ref, dtype):
     for n in (8 * 1000, 8 * 1000 + 3):
