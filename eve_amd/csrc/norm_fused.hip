@@ -229,13 +229,14 @@ __global__ __launch_bounds__(1024) void in_bwd_fused_kernel(const T* __restrict_
 }
 
 // threads per block and vectors per thread for a plane of nvec 16-byte vectors; false if it does not fit
-static bool fused_plan(int nvec, int cvecs, int& threads, int& vpt, int& sl) {
+static bool fused_plan(int nvec, int cvecs, int& threads, int& vpt, int& sl, bool allow_split) {
     if (nvec <= 0 || cvecs <= 0 || cvecs > 128 || (cvecs & (cvecs - 1))) return false;
     // planes that would need a 1 024-thread workgroup go to two 512-thread ones, half the channels each
     static int split_on = -1;
     if (split_on < 0) { const char* e = getenv("EVE_IN_SPLIT"); split_on = (e && e[0] == '0') ? 0 : 1; }
     sl = 0;
-    if (split_on && nvec > 4096 && nvec <= 8192 && cvecs >= 2) { sl = 1; nvec /= 2; cvecs /= 2; }
+    // (bf16 only: the float32 instantiation is the parity mode and keeps its summation order)
+    if (split_on && allow_split && nvec > 4096 && nvec <= 8192 && cvecs >= 2) { sl = 1; nvec /= 2; cvecs /= 2; }
     // as many vectors per thread as leaves >= `min_threads` threads: fewer, fatter workgroups per plane let several
     // planes share a CU, so one plane's reduction phase overlaps another's loads / stores
     static int min_threads = -1;
@@ -275,7 +276,7 @@ extern "C" int eve_instnorm_fwd_fused(int dtype, int N, int HW, int C, const voi
         !mean_rstd || ((gamma == nullptr) != (beta == nullptr)))
         return set_error_msg("instnorm_fwd_fused: bad arguments");
     int threads, vpt, sl;
-    if (!fused_plan(HW * (C / vec), C / vec, threads, vpt, sl)) return -1;
+    if (!fused_plan(HW * (C / vec), C / vec, threads, vpt, sl, dtype == EVE_DT_BF16)) return -1;
     const unsigned grid = sl ? (unsigned)((N + 7) / 8) * (8u << sl) : (unsigned)N;
     hipStream_t s = (hipStream_t)stream;
     if (dtype == EVE_DT_BF16) {
@@ -297,7 +298,7 @@ extern "C" int eve_instnorm_bwd_fused(int dtype, int N, int HW, int C, const voi
         !mean_rstd || !dx || (act != EVE_ACT_NONE && !y && gamma && !(act == EVE_ACT_RELU && sign_mask)))
         return set_error_msg("instnorm_bwd_fused: bad arguments");
     int threads, vpt, sl;
-    if (!fused_plan(HW * (C / vec), C / vec, threads, vpt, sl)) return -1;
+    if (!fused_plan(HW * (C / vec), C / vec, threads, vpt, sl, dtype == EVE_DT_BF16)) return -1;
     const unsigned grid = sl ? (unsigned)((N + 7) / 8) * (8u << sl) : (unsigned)N;
     hipStream_t s = (hipStream_t)stream;
     if (dtype == EVE_DT_BF16) {

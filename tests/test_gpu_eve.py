@@ -168,7 +168,11 @@ def test_eve_matches_reference_golden(tag):
                 if want < 0:
                     assert got[str(n)] < 0, n
                 else:
-                    # (float32 MFMA summation order through ~40 layers, then softmax(100 h): a few per cent on single-tensor norms)
+                    # (float32 MFMA summation order through ~40 layers, then softmax(100 h): a few per cent on single-tensor
+                    #  norms.  Measured: running three of RefineNet's InstanceNorm planes through a kernel variant that
+                    #  agrees with this one to 1e-7 relative -- a different order of the plane reductions -- moved
+                    #  |d initial.1.bias| by 3.9 %.  The float32 path therefore keeps ONE summation order (the channel-split
+                    #  InstanceNorm is bf16-only); what bounds kernel error is the per-kernel and teacher-forced tests)
                     assert abs(got[str(n)] - want) <= 3e-2 * want + 1e-5 * max(scale, 1.0), (n, got[str(n)], want)
     else:
         for k in ('initial_gaze_history', 'refined_gaze_history', 'initial_heatmap', 'final_heatmap', 'gt_heatmap'):
