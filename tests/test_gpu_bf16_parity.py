@@ -99,12 +99,17 @@ def check_param_grads(params, ref_params, names, what, tol=BWD_LOCAL, zero_grad=
     return worst
 
 
-@pytest.mark.parametrize('B,T,seed', [(2, 3, 0), (4, 30, 17)], ids=['fixture-shape', 'configs1-slice'])
-def test_eyenet_bf16_stages_teacher_forced_match_rounding_faithful_oracle(B, T, seed):
+@pytest.mark.parametrize('B,T,seed,band_wgrad', [(2, 3, 0, False), (4, 30, 17, False), (2, 3, 0, True)],
+                         ids=['fixture-shape', 'configs1-slice', 'fixture-shape-band-resident-wgrad'])
+def test_eyenet_bf16_stages_teacher_forced_match_rounding_faithful_oracle(B, T, seed, band_wgrad, monkeypatch):
     """Stem, the eight residual blocks and the average pool of the bf16 trunk (BASELINE configs[1]'s kernels: fused stem
     forward / backward-by-recomputation + packed-patch weight gradient, halo and LDS-DMA convolutions, parity-class
     strided dgrad, transposing-read weight gradients, register-resident InstanceNorm forward / backward), each fed the
-    oracle's bf16-exact input and output gradient.  The second case is a B=4 slice of the benchmarked B=32 x T=30 batch."""
+    oracle's bf16-exact input and output gradient.  The second case is a B=4 slice of the benchmarked B=32 x T=30 batch;
+    the third sends layer 1's weight gradients through wgrad_halo64_kernel, which the full-size batch uses (it is selected
+    from 1 M pixels up: EVE_WGRAD_HALO_MIN_M lowers that, read per call)."""
+    if band_wgrad:
+        monkeypatch.setenv('EVE_WGRAD_HALO_MIN_M', '0')
     from eve_amd import ops
     from eve_amd.kernels import default_kernels
     from oracle.eye_net import EyeNet as OracleEyeNet
