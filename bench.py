@@ -28,8 +28,9 @@ import torch
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE)
 
-MFMA_PEAK_TFLOPS = {'bf16': 2500.0, 'fp32': 157.3}     # /opt/skills/guides/MI355X_MICROARCH.md:41-42 (dense)
+MFMA_PEAK_TFLOPS = {'bf16': 2500.0, 'fp16': 2500.0, 'fp32': 157.3}     # /opt/skills/guides/MI355X_MICROARCH.md:41-42 (dense)
 HBM_PEAK_GBS = 8000.0
+TORCH_DTYPE = {'bf16': torch.bfloat16, 'fp16': torch.float16, 'fp32': torch.float32}
 # algorithmic FLOP per frame (one time step of one clip = 2 eye patches), SURVEY.md 8(d) / BASELINE.md 2
 EYENET_TRAIN_GFLOP_PER_FRAME_128 = 6.955
 
@@ -112,7 +113,7 @@ def bench_c3(args, device, k):
     cfg.import_json(os.path.join(HERE, 'configs', 'refine_net.json'))
     cfg.import_dict({'refine_net_rnn_type': 'CGRU', 'eye_net_load_pretrained': False})
     model = eve_amd.EVE()
-    dt = torch.bfloat16 if args.dtype == 'bf16' else torch.float32
+    dt = TORCH_DTYPE[args.dtype]
     model.eye_net.compute_dtype = model.refine_net.compute_dtype = dt
     synthetic.fill_module(model.eye_net, seed=0)
     synthetic.fill_module(model.refine_net, seed=1)
@@ -172,7 +173,7 @@ def main():
     ap.add_argument('--batch', type=int, default=32, help='clips per GPU')
     ap.add_argument('--seq', type=int, default=30)
     ap.add_argument('--size', type=int, default=128)
-    ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp32'])
+    ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp16', 'fp32'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--no-graph', action='store_true', help='launch every kernel eagerly instead of replaying a hipGraph')
@@ -198,7 +199,7 @@ def main():
     cfg.import_json(os.path.join(HERE, 'configs', 'eye_net.json'))
     torch.manual_seed(1234)
     net = eve_amd.EyeNet()
-    net.compute_dtype = torch.bfloat16 if args.dtype == 'bf16' else torch.float32
+    net.compute_dtype = TORCH_DTYPE[args.dtype]
     net.to(device)
     # one rank: replay the captured step; several ranks: eager launches so each bucket's RCCL all-reduce is issued
     # from its gradient hook and overlaps the rest of backward (the step is GPU-bound either way)

@@ -28,7 +28,7 @@ class PackItem(Structure):
 
 
 PACK_BATCH_MAX = 48
-ABI_VERSION = 3          # include/eve_hip.h EVE_ABI_VERSION
+ABI_VERSION = 4          # include/eve_hip.h EVE_ABI_VERSION
 
 SIGNATURES = {
     'eve_conv2d_fwd': [POINTER(ConvDesc), P, P, P, I, P, I, P, P],
@@ -36,16 +36,16 @@ SIGNATURES = {
     'eve_conv2d_dgrad_acc': [POINTER(ConvDesc), P, P, P, P],
     'eve_conv2d_wgrad': [POINTER(ConvDesc), P, P, P, I, P, P],
     'eve_conv2d_wgrad_bias': [POINTER(ConvDesc), P, P, P, P, P],
-    'eve_stem_pack_input': [I, I, I, I, P, P, P],
+    'eve_stem_pack_input': [I, I, I, I, I, P, P, P],
     'eve_frames_u8_to_nchw': [L, I, I, I, P, F, F, I, P, P],
-    'eve_frames_u8_to_stem': [L, I, I, I, P, F, F, P, P],
-    'eve_stem7x7s2_fwd': [I, I, I, P, P, P, P],
-    'eve_stem_fwd_fused': [I, I, I, P, P, F, P, P, P, P],
-    'eve_stem_wgrad': [I, I, I, P, P, P, P],
-    'eve_stem_bwd_dx': [I, I, I, P, P, P, P, P, P, P, P, P],
+    'eve_frames_u8_to_stem': [I, L, I, I, I, P, F, F, P, P],
+    'eve_stem7x7s2_fwd': [I, I, I, I, P, P, P, P],
+    'eve_stem_fwd_fused': [I, I, I, I, P, P, F, P, P, P, P],
+    'eve_stem_wgrad': [I, I, I, I, P, P, P, P],
+    'eve_stem_bwd_dx': [I, I, I, I, P, P, P, P, P, P, P, P, P],
     'eve_bias_grad': [I, L, I, P, P, P],
-    'eve_cgru_scan_fwd': [I, I, P, P, P, P, P, P, P, P, P, P, P, P],
-    'eve_cgru_scan_bwd': [I, I, P, P, P, P, P, P, P, P, P, P, P, P],
+    'eve_cgru_scan_fwd': [I, I, I, P, P, P, P, P, P, P, P, P, P, P, P],
+    'eve_cgru_scan_bwd': [I, I, I, P, P, P, P, P, P, P, P, P, P, P, P],
     'eve_rnn_scan_fwd': [I, I, I, P, P, P, P, P, P],
     'eve_rnn_scan_bwd': [I, I, I, P, P, P, P, P, P],
     'eve_lstm_scan_fwd': [I, I, I, P, P, P, P, P, P, P, P, P],

@@ -104,8 +104,11 @@ def adam_state_dict(trainer, model=None):
                     'exp_avg': _param_view(fp.m, off, n, p).detach().cpu().contiguous(),
                     'exp_avg_sq': _param_view(fp.v, off, n, p).detach().cpu().contiguous()}
     lr = float(trainer.lr) if getattr(trainer, 'lr', None) is not None else float(cfg.learning_rate)
-    group = {'lr': lr, 'betas': (trainer.beta1, trainer.beta2), 'eps': trainer.eps,
-             'weight_decay': float(cfg.weight_decay), 'amsgrad': False, 'params': list(range(total))}
+    # 'initial_lr' is what torch's LambdaLR (which the reference always wraps Adam in, training.py:436-442) multiplies its
+    # lambda by; without it a resumed reference run would take the decayed, quirk-scaled `lr` as its base
+    group = {'lr': lr, 'initial_lr': float(cfg.learning_rate), 'betas': (trainer.beta1, trainer.beta2), 'eps': trainer.eps,
+             'weight_decay': float(cfg.weight_decay), 'amsgrad': False, 'maximize': False, 'foreach': None,
+             'capturable': False, 'differentiable': False, 'fused': None, 'params': list(range(total))}
     return {'state': state, 'param_groups': [group]}
 
 

@@ -26,12 +26,13 @@ typedef uint32_t cg_u32x4_t __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ float cg_sigmoid(float z) { return 1.f / (1.f + __expf(-z)); }
 
-__global__ __launch_bounds__(256) void cgru_scan_fwd_kernel(const int B, const int T, const bf16_t* __restrict__ xs,
-                                                            const bf16_t* __restrict__ h0, const bf16_t* __restrict__ w1,
-                                                            const float* __restrict__ b1, const bf16_t* __restrict__ w2,
-                                                            const float* __restrict__ b2, bf16_t* __restrict__ hs,
-                                                            bf16_t* __restrict__ hs_tm, bf16_t* __restrict__ ru,
-                                                            bf16_t* __restrict__ rh, bf16_t* __restrict__ og) {
+template <typename H>
+__global__ __launch_bounds__(256) void cgru_scan_fwd_kernel(const int B, const int T, const H* __restrict__ xs,
+                                                            const H* __restrict__ h0, const H* __restrict__ w1,
+                                                            const float* __restrict__ b1, const H* __restrict__ w2,
+                                                            const float* __restrict__ b2, H* __restrict__ hs,
+                                                            H* __restrict__ hs_tm, H* __restrict__ ru,
+                                                            H* __restrict__ rh, H* __restrict__ og) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // planes: 0,1 = x (channels 0-31, 32-63); 2,3 = h; 4,5 = r*h
     const uint32_t lds0 = lds_addr_of(smem);
@@ -164,19 +165,19 @@ __global__ __launch_bounds__(256) void cgru_scan_fwd_kernel(const int B, const i
                     issue_w(nconv, nsl, (tap + 3) % 9, (int)((gs + tap + 3) & 3), live != 0);
                     if (active) {
                         const uint32_t lb = ldsB + ((gs + tap) & 3) * CG_BSLOT;
-                        bf16x8_t fx[4], fw[4];
+                        uint4 fx[4], fw[4];
 #pragma unroll
                         for (int mt = 0; mt < 4; ++mt)
-                            fx[mt] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const EVE_LDS cg_u32x4_t*>((uintptr_t)(la + aaddr[tap][mt])));
+                            fx[mt] = __builtin_bit_cast(uint4, *reinterpret_cast<const EVE_LDS cg_u32x4_t*>((uintptr_t)(la + aaddr[tap][mt])));
 #pragma unroll
                         for (int nt = 0; nt < 4; ++nt)
-                            fw[nt] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const EVE_LDS cg_u32x4_t*>(
+                            fw[nt] = __builtin_bit_cast(uint4, *reinterpret_cast<const EVE_LDS cg_u32x4_t*>(
                                 (uintptr_t)(lb + (conv == 0 ? brow1[nt] : brow2[nt]))));
 #pragma unroll
                         for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
                             for (int mt = 0; mt < 4; ++mt)
-                                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[nt], fx[mt], acc[mt][nt], 0, 0, 0);
+                                Elem<H>::mfma(acc[mt][nt], fw[nt], fx[mt]);
                     }
                     asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // tile of the next step (issued 2 steps ago) landed
                     __syncthreads();
@@ -193,17 +194,17 @@ __global__ __launch_bounds__(256) void cgru_scan_fwd_kernel(const int B, const i
                         float v[4] = {cg_sigmoid(acc[mt][nt][0] + bv.x), cg_sigmoid(acc[mt][nt][1] + bv.y),
                                       cg_sigmoid(acc[mt][nt][2] + bv.z), cg_sigmoid(acc[mt][nt][3] + bv.w)};
                         // the stored (bf16) gate is the one every later stage sees
-                        const uint32_t p0 = pack2_bf16(v[0], v[1]), p1 = pack2_bf16(v[2], v[3]);
-                        v[0] = bf16_bits_to_f32(p0 & 0xffffu); v[1] = __builtin_bit_cast(float, p0 & 0xffff0000u);
-                        v[2] = bf16_bits_to_f32(p1 & 0xffffu); v[3] = __builtin_bit_cast(float, p1 & 0xffff0000u);
+                        const uint32_t p0 = Elem<H>::pack2(v[0], v[1]), p1 = Elem<H>::pack2(v[2], v[3]);
+                        v[0] = Elem<H>::lo(p0); v[1] = Elem<H>::hi(p0);
+                        v[2] = Elem<H>::lo(p1); v[3] = Elem<H>::hi(p1);
                         const int pg = pix_glob[mt];
                         const size_t ptm = (size_t)t * B * CG_PIX + pix_tm[mt];           // time-major: what the backward walks
                         if (pg >= 0)
                             *reinterpret_cast<uint2*>(ru + ptm * 128 + wn * 64 + c) = make_uint2(p0, p1);
                         if (wn == 0) {
                             const cg_u32x2_t hq = *reinterpret_cast<const EVE_LDS cg_u32x2_t*>((uintptr_t)lds_c4(2, mt, c));
-                            const uint32_t q0 = pack2_bf16(v[0] * bf16_bits_to_f32(hq.x & 0xffffu), v[1] * __builtin_bit_cast(float, hq.x & 0xffff0000u));
-                            const uint32_t q1 = pack2_bf16(v[2] * bf16_bits_to_f32(hq.y & 0xffffu), v[3] * __builtin_bit_cast(float, hq.y & 0xffff0000u));
+                            const uint32_t q0 = Elem<H>::pack2(v[0] * Elem<H>::lo(hq.x), v[1] * Elem<H>::hi(hq.x));
+                            const uint32_t q1 = Elem<H>::pack2(v[2] * Elem<H>::lo(hq.y), v[3] * Elem<H>::hi(hq.y));
                             if (pg >= 0) {
                                 *reinterpret_cast<EVE_LDS cg_u32x2_t*>((uintptr_t)lds_c4(4, mt, c)) = cg_u32x2_t{q0, q1};
                                 *reinterpret_cast<uint2*>(rh + ptm * CG_C + c) = make_uint2(q0, q1);
@@ -228,17 +229,17 @@ __global__ __launch_bounds__(256) void cgru_scan_fwd_kernel(const int B, const i
                     if (pg < 0) continue;
                     float o[4] = {tanhf(acc[mt][nt][0] + bv.x), tanhf(acc[mt][nt][1] + bv.y), tanhf(acc[mt][nt][2] + bv.z),
                                   tanhf(acc[mt][nt][3] + bv.w)};
-                    const uint32_t o0 = pack2_bf16(o[0], o[1]), o1 = pack2_bf16(o[2], o[3]);
-                    o[0] = bf16_bits_to_f32(o0 & 0xffffu); o[1] = __builtin_bit_cast(float, o0 & 0xffff0000u);
-                    o[2] = bf16_bits_to_f32(o1 & 0xffffu); o[3] = __builtin_bit_cast(float, o1 & 0xffff0000u);
+                    const uint32_t o0 = Elem<H>::pack2(o[0], o[1]), o1 = Elem<H>::pack2(o[2], o[3]);
+                    o[0] = Elem<H>::lo(o0); o[1] = Elem<H>::hi(o0);
+                    o[2] = Elem<H>::lo(o1); o[3] = Elem<H>::hi(o1);
                     const uint32_t ha = lds_c4(2, mt, c);
                     const cg_u32x2_t hq = *reinterpret_cast<const EVE_LDS cg_u32x2_t*>((uintptr_t)ha);
-                    const float hv[4] = {bf16_bits_to_f32(hq.x & 0xffffu), __builtin_bit_cast(float, hq.x & 0xffff0000u),
-                                         bf16_bits_to_f32(hq.y & 0xffffu), __builtin_bit_cast(float, hq.y & 0xffff0000u)};
+                    const float hv[4] = {Elem<H>::lo(hq.x), Elem<H>::hi(hq.x),
+                                         Elem<H>::lo(hq.y), Elem<H>::hi(hq.y)};
                     float hn[4];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) hn[r] = (1.f - ug[mt][nt][r]) * o[r] + ug[mt][nt][r] * hv[r];
-                    const uint32_t n0 = pack2_bf16(hn[0], hn[1]), n1 = pack2_bf16(hn[2], hn[3]);
+                    const uint32_t n0 = Elem<H>::pack2(hn[0], hn[1]), n1 = Elem<H>::pack2(hn[2], hn[3]);
                     *reinterpret_cast<EVE_LDS cg_u32x2_t*>((uintptr_t)ha) = cg_u32x2_t{n0, n1};
                     const size_t go = ((size_t)pg + (size_t)t * CG_PIX) * CG_C + c;
                     const size_t gtm = ((size_t)t * B * CG_PIX + pix_tm[mt]) * CG_C + c;
@@ -277,12 +278,13 @@ __global__ __launch_bounds__(256) void cgru_scan_fwd_kernel(const int B, const i
 // and the wn = 0 waves both halves of d x: no exchange between waves.  The weight and bias gradients are batched over
 // all T*B frames afterwards from dg1_all / dg2_all (eve_conv2d_wgrad), as before.
 // =================================================================================================
-__global__ __launch_bounds__(256) void cgru_scan_bwd_kernel(const int B, const int T, const bf16_t* __restrict__ dhs_tm,
-                                                            const bf16_t* __restrict__ ru, const bf16_t* __restrict__ og,
-                                                            const bf16_t* __restrict__ hs_tm, const bf16_t* __restrict__ h0,
-                                                            const bf16_t* __restrict__ w1t, const bf16_t* __restrict__ w2t,
-                                                            bf16_t* __restrict__ dg1_all, bf16_t* __restrict__ dg2_all,
-                                                            bf16_t* __restrict__ dxs_tm, bf16_t* __restrict__ dh0) {
+template <typename H>
+__global__ __launch_bounds__(256) void cgru_scan_bwd_kernel(const int B, const int T, const H* __restrict__ dhs_tm,
+                                                            const H* __restrict__ ru, const H* __restrict__ og,
+                                                            const H* __restrict__ hs_tm, const H* __restrict__ h0,
+                                                            const H* __restrict__ w1t, const H* __restrict__ w2t,
+                                                            H* __restrict__ dg1_all, H* __restrict__ dg2_all,
+                                                            H* __restrict__ dxs_tm, H* __restrict__ dh0) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // planes: 0,1 = dg2 (64 channels); 2..5 = dg1 (128 channels: reset part, update part)
     const uint32_t lds0 = lds_addr_of(smem);
@@ -350,8 +352,8 @@ __global__ __launch_bounds__(256) void cgru_scan_bwd_kernel(const int B, const i
         return lds0 + (pl + (c >> 5)) * CG_SLICE + (pix_lds[mt] & 0xffff) + (((((c & 31) >> 3)) ^ (key << 1)) << 4) + (c & 7) * 2;
     };
     auto unpack4 = [](const uint2 q, float* f) {
-        f[0] = bf16_bits_to_f32(q.x & 0xffffu); f[1] = __builtin_bit_cast(float, q.x & 0xffff0000u);
-        f[2] = bf16_bits_to_f32(q.y & 0xffffu); f[3] = __builtin_bit_cast(float, q.y & 0xffff0000u);
+        f[0] = Elem<H>::lo(q.x); f[1] = Elem<H>::hi(q.x);
+        f[2] = Elem<H>::lo(q.y); f[3] = Elem<H>::hi(q.y);
     };
 
     f32x4_t cy[4][4], dxk[4][4];                              // carry (wn = 1 waves), dx_2 (wn = 0 waves)
@@ -392,8 +394,8 @@ __global__ __launch_bounds__(256) void cgru_scan_bwd_kernel(const int B, const i
                         g1u[r] = dhn * (hp[r] - o[r]) * u[r] * (1.f - u[r]);
                         cy[mt][nt][r] = dhn * u[r];
                     }
-                    const uint2 p2 = make_uint2(pack2_bf16(g2[0], g2[1]), pack2_bf16(g2[2], g2[3]));
-                    const uint2 p1 = make_uint2(pack2_bf16(g1u[0], g1u[1]), pack2_bf16(g1u[2], g1u[3]));
+                    const uint2 p2 = make_uint2(Elem<H>::pack2(g2[0], g2[1]), Elem<H>::pack2(g2[2], g2[3]));
+                    const uint2 p1 = make_uint2(Elem<H>::pack2(g1u[0], g1u[1]), Elem<H>::pack2(g1u[2], g1u[3]));
                     *reinterpret_cast<EVE_LDS cg_u32x2_t*>((uintptr_t)lds_c4(0, mt, c)) = cg_u32x2_t{p2.x, p2.y};
                     *reinterpret_cast<EVE_LDS cg_u32x2_t*>((uintptr_t)lds_c4(4, mt, c)) = cg_u32x2_t{p1.x, p1.y};
                     *reinterpret_cast<uint2*>(dg2_all + pt * CG_C + c) = p2;
@@ -422,18 +424,18 @@ __global__ __launch_bounds__(256) void cgru_scan_bwd_kernel(const int B, const i
                     if (npos >= 54) { npos -= 54; live = more_t; }
                     issue_pos(npos, (int)((gs + tap + 3) & 3), live);
                     const uint32_t lb = ldsB + ((gs + tap) & 3) * CG_BSLOT;
-                    bf16x8_t fx[4], fw[4];
+                    uint4 fx[4], fw[4];
 #pragma unroll
                     for (int mt = 0; mt < 4; ++mt)
-                        fx[mt] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const EVE_LDS cg_u32x4_t*>((uintptr_t)(la + aaddr[tap][mt])));
+                        fx[mt] = __builtin_bit_cast(uint4, *reinterpret_cast<const EVE_LDS cg_u32x4_t*>((uintptr_t)(la + aaddr[tap][mt])));
 #pragma unroll
                     for (int nt = 0; nt < 4; ++nt)
-                        fw[nt] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const EVE_LDS cg_u32x4_t*>((uintptr_t)(lb + brow[nt])));
+                        fw[nt] = __builtin_bit_cast(uint4, *reinterpret_cast<const EVE_LDS cg_u32x4_t*>((uintptr_t)(lb + brow[nt])));
 #pragma unroll
                     for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
                         for (int mt = 0; mt < 4; ++mt)
-                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[nt], fx[mt], acc[mt][nt], 0, 0, 0);
+                            Elem<H>::mfma(acc[mt][nt], fw[nt], fx[mt]);
                     asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // tile of the next step (issued 2 steps ago) landed
                     __syncthreads();
                 }
@@ -458,7 +460,7 @@ __global__ __launch_bounds__(256) void cgru_scan_bwd_kernel(const int B, const i
                                 g1r[r] = drh * hp[r] * rr[r] * (1.f - rr[r]);
                                 cy[mt][nt][r] += drh * rr[r];
                             }
-                            const uint2 p1 = make_uint2(pack2_bf16(g1r[0], g1r[1]), pack2_bf16(g1r[2], g1r[3]));
+                            const uint2 p1 = make_uint2(Elem<H>::pack2(g1r[0], g1r[1]), Elem<H>::pack2(g1r[2], g1r[3]));
                             *reinterpret_cast<EVE_LDS cg_u32x2_t*>((uintptr_t)lds_c4(2, mt, c)) = cg_u32x2_t{p1.x, p1.y};
                             *reinterpret_cast<uint2*>(dg1_all + pt * 128 + c) = p1;
                         }
@@ -487,7 +489,7 @@ __global__ __launch_bounds__(256) void cgru_scan_bwd_kernel(const int B, const i
                     if (!pix_ok[mt]) continue;
                     const f32x4_t v = dxk[mt][nt] + acc[mt][nt];
                     *reinterpret_cast<uint2*>(dxs_tm + (frame + pix_tm[mt]) * CG_C + c) =
-                        make_uint2(pack2_bf16(v[0], v[1]), pack2_bf16(v[2], v[3]));
+                        make_uint2(Elem<H>::pack2(v[0], v[1]), Elem<H>::pack2(v[2], v[3]));
                 }
             }
         }
@@ -501,7 +503,7 @@ __global__ __launch_bounds__(256) void cgru_scan_bwd_kernel(const int B, const i
             for (int mt = 0; mt < 4; ++mt) {
                 if (!pix_ok[mt]) continue;
                 *reinterpret_cast<uint2*>(dh0 + (size_t)pix_tm[mt] * CG_C + c) =
-                    make_uint2(pack2_bf16(cy[mt][nt][0], cy[mt][nt][1]), pack2_bf16(cy[mt][nt][2], cy[mt][nt][3]));
+                    make_uint2(Elem<H>::pack2(cy[mt][nt][0], cy[mt][nt][1]), Elem<H>::pack2(cy[mt][nt][2], cy[mt][nt][3]));
             }
         }
     }
@@ -517,20 +519,20 @@ using namespace eve;
    (input channels: r*h then x), biases float.  Outputs (bf16): hs [B][T][5][8][64] = hidden states in the caller's
    (sequence, frame) order; and TIME-major [T][B][5][8][.] for the backward, which walks frames: hs_tm, ru = the two
    sigmoid gates (128 channels), rh = r * h_{t-1}, og = tanh output gate. */
-extern "C" int eve_cgru_scan_fwd(int B, int T, const void* xs, const void* h0, const void* w1, const float* b1, const void* w2,
+extern "C" int eve_cgru_scan_fwd(int dtype, int B, int T, const void* xs, const void* h0, const void* w1, const float* b1, const void* w2,
                                  const float* b2, void* hs, void* hs_tm, void* ru, void* rh, void* og, eve_stream_t stream) {
-    if (B <= 0 || T <= 0 || !xs || !w1 || !b1 || !w2 || !b2 || !hs || !hs_tm || !ru || !rh || !og)
+    if ((dtype != EVE_DT_BF16 && dtype != EVE_DT_F16) || B <= 0 || T <= 0 || !xs || !w1 || !b1 || !w2 || !b2 || !hs || !hs_tm || !ru || !rh || !og)
         return set_error_msg("cgru_scan_fwd: bad arguments");
     if ((long long)B * T * CG_PIX * 128 >= (1ll << 31)) return set_error_msg("cgru_scan_fwd: clip too large for 32-bit offsets");
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)cgru_scan_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)cgru_scan_fwd_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)cgru_scan_fwd_kernel<f16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    EVE_MARK_KERNEL("cgru_scan_fwd_kernel");
-    hipLaunchKernelGGL(cgru_scan_fwd_kernel, dim3((B + CG_IMG - 1) / CG_IMG), dim3(256), CG_LDS, (hipStream_t)stream, B, T,
-                       (const bf16_t*)xs, (const bf16_t*)h0, (const bf16_t*)w1, b1, (const bf16_t*)w2, b2, (bf16_t*)hs, (bf16_t*)hs_tm,
-                       (bf16_t*)ru, (bf16_t*)rh, (bf16_t*)og);
+    EVE_DISPATCH_H16(dtype, EVE_LAUNCH(EVE_HNAME(H, "cgru_scan_fwd_kernel<", ">"), cgru_scan_fwd_kernel<H>, dim3((B + CG_IMG - 1) / CG_IMG), dim3(256), CG_LDS,
+                                       (hipStream_t)stream, B, T, (const H*)xs, (const H*)h0, (const H*)w1, b1, (const H*)w2, b2, (H*)hs, (H*)hs_tm,
+                                       (H*)ru, (H*)rh, (H*)og));
     EVE_CHECK_LAUNCH();
     return 0;
 }
@@ -541,21 +543,21 @@ extern "C" int eve_cgru_scan_fwd(int B, int T, const void* xs, const void* h0, c
    w2t = gate_2 filter bank IHWO [128][3][3][64].  Outputs (time-major): dg1_all [T][B][5][8][128] and dg2_all [..][64] = the
    gradients of the two pre-activations (what the batched weight / bias gradients read), dxs_tm [..][64] = d xs, and dh0
    [B][5][8][64] (NULL = not wanted).  common.py:400-415 differentiated.                                                   */
-extern "C" int eve_cgru_scan_bwd(int B, int T, const void* dhs_tm, const void* ru, const void* og, const void* hs_tm, const void* h0,
+extern "C" int eve_cgru_scan_bwd(int dtype, int B, int T, const void* dhs_tm, const void* ru, const void* og, const void* hs_tm, const void* h0,
                                  const void* w1t, const void* w2t, void* dg1_all, void* dg2_all, void* dxs_tm, void* dh0,
                                  eve_stream_t stream) {
-    if (B <= 0 || T <= 0 || !dhs_tm || !ru || !og || !hs_tm || !w1t || !w2t || !dg1_all || !dg2_all || !dxs_tm)
+    if ((dtype != EVE_DT_BF16 && dtype != EVE_DT_F16) || B <= 0 || T <= 0 || !dhs_tm || !ru || !og || !hs_tm || !w1t || !w2t || !dg1_all || !dg2_all || !dxs_tm)
         return set_error_msg("cgru_scan_bwd: bad arguments");
     if ((long long)B * T * CG_PIX * 128 >= (1ll << 31)) return set_error_msg("cgru_scan_bwd: clip too large for 32-bit offsets");
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)cgru_scan_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)cgru_scan_bwd_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)cgru_scan_bwd_kernel<f16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    EVE_MARK_KERNEL("cgru_scan_bwd_kernel");
-    hipLaunchKernelGGL(cgru_scan_bwd_kernel, dim3((B + CG_IMG - 1) / CG_IMG), dim3(256), CG_LDS, (hipStream_t)stream, B, T,
-                       (const bf16_t*)dhs_tm, (const bf16_t*)ru, (const bf16_t*)og, (const bf16_t*)hs_tm, (const bf16_t*)h0,
-                       (const bf16_t*)w1t, (const bf16_t*)w2t, (bf16_t*)dg1_all, (bf16_t*)dg2_all, (bf16_t*)dxs_tm, (bf16_t*)dh0);
+    EVE_DISPATCH_H16(dtype, EVE_LAUNCH(EVE_HNAME(H, "cgru_scan_bwd_kernel<", ">"), cgru_scan_bwd_kernel<H>, dim3((B + CG_IMG - 1) / CG_IMG), dim3(256), CG_LDS,
+                                       (hipStream_t)stream, B, T, (const H*)dhs_tm, (const H*)ru, (const H*)og, (const H*)hs_tm, (const H*)h0,
+                                       (const H*)w1t, (const H*)w2t, (H*)dg1_all, (H*)dg2_all, (H*)dxs_tm, (H*)dh0));
     EVE_CHECK_LAUNCH();
     return 0;
 }

@@ -13,15 +13,20 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 
 // ---------------------------------------------------------------------------------------------
-// element types: `float` and `bf16_t` (raw 16-bit storage, round-to-nearest-even conversions)
+// element types: `float` and the two 16-bit formats `bf16_t` / `f16_t` (raw 16-bit storage, round-to-nearest-even
+// conversions).  Every reduced-precision kernel is a template over the 16-bit format H: the data movement is identical,
+// only the conversions and the MFMA opcode (v_mfma_f32_16x16x32_bf16 / _f16) differ.
 // ---------------------------------------------------------------------------------------------
 struct bf16_t { uint16_t v; };
+struct f16_t { uint16_t v; };
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
 
 __device__ __forceinline__ float bf16_bits_to_f32(uint32_t bits16) {
     return __builtin_bit_cast(float, bits16 << 16);
 }
-// gfx950 converts in hardware (v_cvt_pk_bf16_f32, round-to-nearest-even, two values per instruction)
+// gfx950 converts in hardware (v_cvt_pk_bf16_f32 / v_cvt_pk_f16_f32, round-to-nearest-even, two values per instruction)
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_t;
 typedef __attribute__((ext_vector_type(2))) float f32x2_t;
 __device__ __forceinline__ uint32_t f32_to_bf16_bits(float f) {
     return (uint32_t)__builtin_bit_cast(uint16_t, (__bf16)f);
@@ -30,11 +35,17 @@ __device__ __forceinline__ uint32_t pack2_bf16(float lo, float hi) {       // lo
     const f32x2_t f = {lo, hi};
     return __builtin_bit_cast(uint32_t, __builtin_convertvector(f, bf16x2_t));
 }
+__device__ __forceinline__ uint32_t pack2_f16(float lo, float hi) {
+    const f32x2_t f = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f, f16x2_t));
+}
 
 template <typename T> struct Elem;
 template <> struct Elem<float> {
     static constexpr int VEC = 4;                     // elements per 16-byte vector
     static constexpr int DT = EVE_DT_F32;
+    static constexpr bool IS_BF16 = false;
+    __device__ static __forceinline__ uint32_t pack2(float, float) { return 0u; }      // (16-bit formats only; keeps dead branches compilable)
     __device__ static __forceinline__ float ld(const float* p) { return *p; }
     __device__ static __forceinline__ void st(float* p, float v) { *p = v; }
     // unpack a 16-byte vector into VEC floats / pack back
@@ -50,21 +61,57 @@ template <> struct Elem<float> {
 template <> struct Elem<bf16_t> {
     static constexpr int VEC = 8;
     static constexpr int DT = EVE_DT_BF16;
+    static constexpr bool IS_BF16 = true;
+    static constexpr uint32_t ONE2 = 0x3F803F80u;                 // two packed 1.0
+    // the two halves of a packed pair / a pair from two floats / one value rounded to the format and back
+    __device__ static __forceinline__ float lo(uint32_t w) { return bf16_bits_to_f32(w & 0xffffu); }
+    __device__ static __forceinline__ float hi(uint32_t w) { return __builtin_bit_cast(float, w & 0xffff0000u); }
+    __device__ static __forceinline__ uint32_t pack2(float a, float b) { return pack2_bf16(a, b); }
+    __device__ static __forceinline__ float round(float v) { return bf16_bits_to_f32(f32_to_bf16_bits(v)); }
     __device__ static __forceinline__ float ld(const bf16_t* p) { return bf16_bits_to_f32(p->v); }
     __device__ static __forceinline__ void st(bf16_t* p, float v) { p->v = (uint16_t)f32_to_bf16_bits(v); }
     __device__ static __forceinline__ void unpack(const uint4& q, float* f) {
-        f[0] = bf16_bits_to_f32(q.x & 0xffffu); f[1] = __builtin_bit_cast(float, q.x & 0xffff0000u);
-        f[2] = bf16_bits_to_f32(q.y & 0xffffu); f[3] = __builtin_bit_cast(float, q.y & 0xffff0000u);
-        f[4] = bf16_bits_to_f32(q.z & 0xffffu); f[5] = __builtin_bit_cast(float, q.z & 0xffff0000u);
-        f[6] = bf16_bits_to_f32(q.w & 0xffffu); f[7] = __builtin_bit_cast(float, q.w & 0xffff0000u);
+        f[0] = lo(q.x); f[1] = hi(q.x); f[2] = lo(q.y); f[3] = hi(q.y);
+        f[4] = lo(q.z); f[5] = hi(q.z); f[6] = lo(q.w); f[7] = hi(q.w);
     }
     __device__ static __forceinline__ uint4 pack(const float* f) {
-        return make_uint4(pack2_bf16(f[0], f[1]),
-                          pack2_bf16(f[2], f[3]),
-                          pack2_bf16(f[4], f[5]),
-                          pack2_bf16(f[6], f[7]));
+        return make_uint4(pack2(f[0], f[1]), pack2(f[2], f[3]), pack2(f[4], f[5]), pack2(f[6], f[7]));
+    }
+    // acc(16 x 16) += A(16 rows x 32 k) * B(32 k x 16 cols); a / b are the lane's 8 consecutive k
+    __device__ static __forceinline__ void mfma(f32x4_t& acc, const uint4& a, const uint4& b) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), acc, 0, 0, 0);
     }
 };
+template <> struct Elem<f16_t> {
+    static constexpr int VEC = 8;
+    static constexpr int DT = EVE_DT_F16;
+    static constexpr bool IS_BF16 = false;
+    static constexpr uint32_t ONE2 = 0x3C003C00u;
+    __device__ static __forceinline__ float lo(uint32_t w) { return (float)__builtin_bit_cast(f16x2_t, w).x; }
+    __device__ static __forceinline__ float hi(uint32_t w) { return (float)__builtin_bit_cast(f16x2_t, w).y; }
+    __device__ static __forceinline__ uint32_t pack2(float a, float b) { return pack2_f16(a, b); }
+    __device__ static __forceinline__ float round(float v) { return (float)(_Float16)v; }
+    __device__ static __forceinline__ float ld(const f16_t* p) { return (float)__builtin_bit_cast(_Float16, p->v); }
+    __device__ static __forceinline__ void st(f16_t* p, float v) { p->v = __builtin_bit_cast(uint16_t, (_Float16)v); }
+    __device__ static __forceinline__ void unpack(const uint4& q, float* f) {
+        f[0] = lo(q.x); f[1] = hi(q.x); f[2] = lo(q.y); f[3] = hi(q.y);
+        f[4] = lo(q.z); f[5] = hi(q.z); f[6] = lo(q.w); f[7] = hi(q.w);
+    }
+    __device__ static __forceinline__ uint4 pack(const float* f) {
+        return make_uint4(pack2(f[0], f[1]), pack2(f[2], f[3]), pack2(f[4], f[5]), pack2(f[6], f[7]));
+    }
+    __device__ static __forceinline__ void mfma(f32x4_t& acc, const uint4& a, const uint4& b) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), acc, 0, 0, 0);
+    }
+};
+// kernel symbol of a 16-bit instantiation, as rocprofv3 prints it (benchmark attribution)
+#define EVE_HNAME(H, pre, post) (Elem<H>::IS_BF16 ? pre "eve::bf16_t" post : pre "eve::f16_t" post)
+// run `body` with the 16-bit storage type of a dtype code bound to H (generic lambda taking a value of that type)
+#define EVE_DISPATCH_H16(dtype, ...)                                        \
+    do {                                                                    \
+        if ((dtype) == EVE_DT_BF16) { using H = eve::bf16_t; __VA_ARGS__; } \
+        else { using H = eve::f16_t; __VA_ARGS__; }                         \
+    } while (0)
 
 // ---------------------------------------------------------------------------------------------
 // activations (the set the reference uses: ReLU, LeakyReLU(0.01), SELU, tanh, sigmoid)

@@ -198,8 +198,8 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_dma_kernel(const GatherPar
                         *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
                     } else {
                         uint2 pk;
-                        pk.x = pack2_bf16(o[0], o[1]);
-                        pk.y = pack2_bf16(o[2], o[3]);
+                        pk.x = Elem<T>::pack2(o[0], o[1]);
+                        pk.y = Elem<T>::pack2(o[2], o[3]);
                         *reinterpret_cast<uint2*>(dst) = pk;
                     }
                 } else {
@@ -247,6 +247,33 @@ __device__ __forceinline__ void mma16_bf16_inplace(f32x4_t (&acc)[4][4], const u
           "+a"(acc[3][0]), "+a"(acc[3][1]), "+a"(acc[3][2]), "+a"(acc[3][3])
         : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]));
 }
+__device__ __forceinline__ void mma16_f16_inplace(f32x4_t (&acc)[4][4], const uint4 (&a4)[4], const uint4 (&b4)[4]) {
+    u32x4_t a[4], b[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { a[i] = __builtin_bit_cast(u32x4_t, a4[i]); b[i] = __builtin_bit_cast(u32x4_t, b4[i]); }
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_mfma_f32_16x16x32_f16 %0, %16, %20, %0\n\t"
+        "v_mfma_f32_16x16x32_f16 %1, %16, %21, %1\n\t"
+        "v_mfma_f32_16x16x32_f16 %2, %16, %22, %2\n\t"
+        "v_mfma_f32_16x16x32_f16 %3, %16, %23, %3\n\t"
+        "v_mfma_f32_16x16x32_f16 %4, %17, %20, %4\n\t"
+        "v_mfma_f32_16x16x32_f16 %5, %17, %21, %5\n\t"
+        "v_mfma_f32_16x16x32_f16 %6, %17, %22, %6\n\t"
+        "v_mfma_f32_16x16x32_f16 %7, %17, %23, %7\n\t"
+        "v_mfma_f32_16x16x32_f16 %8, %18, %20, %8\n\t"
+        "v_mfma_f32_16x16x32_f16 %9, %18, %21, %9\n\t"
+        "v_mfma_f32_16x16x32_f16 %10, %18, %22, %10\n\t"
+        "v_mfma_f32_16x16x32_f16 %11, %18, %23, %11\n\t"
+        "v_mfma_f32_16x16x32_f16 %12, %19, %20, %12\n\t"
+        "v_mfma_f32_16x16x32_f16 %13, %19, %21, %13\n\t"
+        "v_mfma_f32_16x16x32_f16 %14, %19, %22, %14\n\t"
+        "v_mfma_f32_16x16x32_f16 %15, %19, %23, %15"
+        : "+a"(acc[0][0]), "+a"(acc[0][1]), "+a"(acc[0][2]), "+a"(acc[0][3]), "+a"(acc[1][0]), "+a"(acc[1][1]),
+          "+a"(acc[1][2]), "+a"(acc[1][3]), "+a"(acc[2][0]), "+a"(acc[2][1]), "+a"(acc[2][2]), "+a"(acc[2][3]),
+          "+a"(acc[3][0]), "+a"(acc[3][1]), "+a"(acc[3][2]), "+a"(acc[3][3])
+        : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]));
+}
 // wait states between the last asm MFMA and compiler-generated reads of the accumulators
 __device__ __forceinline__ void mma_drain() { asm volatile("s_nop 15\n\ts_nop 15" ::: "memory"); }
 // four in-place MFMAs sharing the A operand: c[i] += a x b[i]
@@ -282,6 +309,53 @@ __device__ __forceinline__ void mma4_bf16_inplace_b(f32x4_t (&c)[4], const uint4
         : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(b));
 }
 
+// four in-place MFMAs sharing the A operand: c[i] += a x b[i]
+__device__ __forceinline__ void mma4_f16_inplace(f32x4_t& c0, f32x4_t& c1, f32x4_t& c2, f32x4_t& c3, const uint4& a4,
+                                                  const uint4 (&b4)[4]) {
+    u32x4_t b[4];
+    const u32x4_t a = __builtin_bit_cast(u32x4_t, a4);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) b[i] = __builtin_bit_cast(u32x4_t, b4[i]);
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_mfma_f32_16x16x32_f16 %0, %4, %5, %0\n\t"
+        "v_mfma_f32_16x16x32_f16 %1, %4, %6, %1\n\t"
+        "v_mfma_f32_16x16x32_f16 %2, %4, %7, %2\n\t"
+        "v_mfma_f32_16x16x32_f16 %3, %4, %8, %3"
+        : "+a"(c0), "+a"(c1), "+a"(c2), "+a"(c3)
+        : "v"(a), "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]));
+}
+
+// four in-place MFMAs sharing the B operand: c[i] += a[i] x b
+__device__ __forceinline__ void mma4_f16_inplace_b(f32x4_t (&c)[4], const uint4 (&a4)[4], const uint4& b4) {
+    u32x4_t a[4];
+    const u32x4_t b = __builtin_bit_cast(u32x4_t, b4);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a[i] = __builtin_bit_cast(u32x4_t, a4[i]);
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_mfma_f32_16x16x32_f16 %0, %4, %8, %0\n\t"
+        "v_mfma_f32_16x16x32_f16 %1, %5, %8, %1\n\t"
+        "v_mfma_f32_16x16x32_f16 %2, %6, %8, %2\n\t"
+        "v_mfma_f32_16x16x32_f16 %3, %7, %8, %3"
+        : "+a"(c[0]), "+a"(c[1]), "+a"(c[2]), "+a"(c[3])
+        : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(b));
+}
+
+// format-generic entry points of the in-place groups
+template <typename H>
+__device__ __forceinline__ void mma16_inplace(f32x4_t (&acc)[4][4], const uint4 (&a4)[4], const uint4 (&b4)[4]) {
+    if constexpr (Elem<H>::IS_BF16) mma16_bf16_inplace(acc, a4, b4); else mma16_f16_inplace(acc, a4, b4);
+}
+template <typename H>
+__device__ __forceinline__ void mma4_inplace(f32x4_t& c0, f32x4_t& c1, f32x4_t& c2, f32x4_t& c3, const uint4& a4, const uint4 (&b4)[4]) {
+    if constexpr (Elem<H>::IS_BF16) mma4_bf16_inplace(c0, c1, c2, c3, a4, b4); else mma4_f16_inplace(c0, c1, c2, c3, a4, b4);
+}
+template <typename H>
+__device__ __forceinline__ void mma4_inplace_b(f32x4_t (&c)[4], const uint4 (&a4)[4], const uint4& b4) {
+    if constexpr (Elem<H>::IS_BF16) mma4_bf16_inplace_b(c, a4, b4); else mma4_f16_inplace_b(c, a4, b4);
+}
+
 // =================================================================================================
 // bf16 weight gradient.  Block tile = (64*WCO output channels) x (64*WK filter-K values); every wave owns
 // a 64 x 64 piece; each step consumes 64 pixels (two MFMA K=32 chunks).
@@ -309,9 +383,9 @@ __device__ __forceinline__ uint2 lds_tr_read(uint32_t lds_byte_addr) {
 // dy from HBM: 44 launches and 8.4 ms per RefineNet step)
 // MT: 16-channel tiles of dy a wave multiplies (4 = all 64; 1 / 2 for layers with <= 16 / 32 output channels, whose
 // remaining tiles are zero-fill: RefineNet's outer levels spent 3/4 of their MFMAs on them)
-template <int WCO, int WK, int MODE, bool BIAS = false, int MT = 4>
-__global__ __launch_bounds__(64 * WCO * WK) void wgrad_tr_kernel(const GatherParams p, const bf16_t* __restrict__ x,
-                                                       const bf16_t* __restrict__ dy, float* __restrict__ dw,
+template <typename H, int WCO, int WK, int MODE, bool BIAS = false, int MT = 4>
+__global__ __launch_bounds__(64 * WCO * WK) void wgrad_tr_kernel(const GatherParams p, const H* __restrict__ x,
+                                                       const H* __restrict__ dy, float* __restrict__ dw,
                                                        const uint32_t rows_per_split, const uint32_t x_bytes,
                                                        const uint32_t dy_bytes, float* __restrict__ db) {
     constexpr int BCO = 64 * WCO, BKK = 64 * WK;
@@ -495,7 +569,7 @@ __global__ __launch_bounds__(64 * WCO * WK) void wgrad_tr_kernel(const GatherPar
     for (int a = 0; a < 4; ++a) accb[a] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     const bool do_bias = BIAS && k0 == 0 && wk == 0;                   // wave-uniform
     const bool k_live = k0 + (uint32_t)wk * 64 < (uint32_t)p.K;        // wave-uniform: some filter column is real
-    const uint4 ones = make_uint4(0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u);   // eight bf16 1.0
+    const uint4 ones = make_uint4(Elem<H>::ONE2, Elem<H>::ONE2, Elem<H>::ONE2, Elem<H>::ONE2);   // eight 1.0
 
     if (m_begin < m_end) {
         const int nsteps = (int)((m_end - m_begin + STEP - 1) / STEP);
@@ -534,13 +608,13 @@ __global__ __launch_bounds__(64 * WCO * WK) void wgrad_tr_kernel(const GatherPar
                     fq[i] = make_uint4(b0.x, b0.y, b1.x, b1.y);
                 }
                 if (MT == 4) {
-                    mma16_bf16_inplace(acc, fp, fq);              // acc[mt][kt] += P[mt] x Q[kt]
+                    mma16_inplace<H>(acc, fp, fq);              // acc[mt][kt] += P[mt] x Q[kt]
                 } else {
 #pragma unroll
                     for (int mt = 0; mt < MT; ++mt)
-                        mma4_bf16_inplace(acc[mt][0], acc[mt][1], acc[mt][2], acc[mt][3], fp[mt], fq);
+                        mma4_inplace<H>(acc[mt][0], acc[mt][1], acc[mt][2], acc[mt][3], fp[mt], fq);
                 }
-                if (BIAS && do_bias) mma4_bf16_inplace_b(accb, fp, ones);   // every column = sum over the 32 pixels
+                if (BIAS && do_bias) mma4_inplace_b<H>(accb, fp, ones);   // every column = sum over the 32 pixels
             }
             // address arithmetic of stage st+4: independent VALU work the scheduler can slot between the MFMAs
             offsets(m_begin + (uint32_t)(st + RING) * STEP, vp, vq);
@@ -564,11 +638,7 @@ __global__ __launch_bounds__(64 * WCO * WK) void wgrad_tr_kernel(const GatherPar
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const uint32_t co = co0 + wco * 64 + mt * 16 + g * 4 + r;
-#ifdef EVE_WGRAD_ABLATE
-                if (co < (uint32_t)p.Cout && acc[mt][kt][r] == 12345.678f) atomicAdd(dw + (size_t)co * p.K + k, acc[mt][kt][r]);
-#else
                 if (co < (uint32_t)p.Cout) atomicAdd(dw + (size_t)co * p.K + k, acc[mt][kt][r]);
-#endif
             }
         }
     if (BIAS && do_bias && t == 0) {
@@ -612,11 +682,11 @@ struct HaloParams {
     FastDiv fd_w2, fd_hpi, fd_w, fd_th;  // divisions by (W+2), (TH+2)*(W+2), W, TH
 };
 
-template <int WM, int WN>
-__global__ __launch_bounds__(256) void conv3x3_halo_kernel(const HaloParams p, const bf16_t* __restrict__ x,
-                                                           const bf16_t* __restrict__ w,
+template <typename H, int WM, int WN>
+__global__ __launch_bounds__(256) void conv3x3_halo_kernel(const HaloParams p, const H* __restrict__ x,
+                                                           const H* __restrict__ w,
                                                            const float* __restrict__ bias, const int epi_act,
-                                                           bf16_t* __restrict__ out) {
+                                                           H* __restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int W2 = p.W + 2, HPI = (p.TH + 2) * W2, HP = p.TI * HPI;
     const int a_stage = p.a_pieces * 4096;                    // bytes per halo stage (256 slots x 16 B per piece)
@@ -759,7 +829,7 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const HaloParams p, c
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) {
 #pragma unroll
-                for (int mt = 0; mt < 4; ++mt) Mma<bf16_t>::run(acc[mt][nt], fw[nt], fx[mt]);
+                for (int mt = 0; mt < 4; ++mt) Mma<H>::run(acc[mt][nt], fw[nt], fx[mt]);
                 if (nt == 0) {
                     if (t < 7 && t < ap)
                         lds_dma16_asm(rs_x, na + t * 4096, a_goff[t < 7 ? t : 0] != EVE_OOB ? a_goff[t < 7 ? t : 0] + nxt_c : EVE_OOB);
@@ -790,7 +860,7 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const HaloParams p, c
             const uint32_t n = n0 + ti;
             const int y = y0 + ty;
             if (n >= (uint32_t)p.N || y >= p.H) continue;
-            bf16_t* dst = out + ((size_t)(n * p.H + y) * p.W + tx) * p.Cout + co;
+            H* dst = out + ((size_t)(n * p.H + y) * p.W + tx) * p.Cout + co;
 #pragma unroll
             for (int h = 0; h < 2; ++h) {                     // two 16-byte halves of 8 channels
                 if (co + 8 * h + 8 > (uint32_t)p.Cout) continue;       // Cout is a multiple of 8
@@ -801,11 +871,11 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const HaloParams p, c
                 act_fwd4<decltype(fast)::value>(o + 4, epi_act);
                 if (epi_act & EVE_EPI_ACC) {
                     float old[8];
-                    Elem<bf16_t>::unpack(*reinterpret_cast<const uint4*>(dst + 8 * h), old);
+                    Elem<H>::unpack(*reinterpret_cast<const uint4*>(dst + 8 * h), old);
 #pragma unroll
                     for (int c = 0; c < 8; ++c) o[c] += old[c];
                 }
-                *reinterpret_cast<uint4*>(dst + 8 * h) = Elem<bf16_t>::pack(o);
+                *reinterpret_cast<uint4*>(dst + 8 * h) = Elem<H>::pack(o);
             }
         }
     };
@@ -823,11 +893,11 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const HaloParams p, c
 // layers (18 steps per tile) that prologue was as long as the tile itself.  Tap / fragment addresses and the
 // halo-slot geometry are computed once per workgroup instead of once per tile.
 // -------------------------------------------------------------------------------------------------
-template <int WM, int WN>
-__global__ __launch_bounds__(256, 2) void conv3x3_halo_pkernel(const HaloParams p, const bf16_t* __restrict__ x,
-                                                            const bf16_t* __restrict__ w,
+template <typename H, int WM, int WN>
+__global__ __launch_bounds__(256, 2) void conv3x3_halo_pkernel(const HaloParams p, const H* __restrict__ x,
+                                                            const H* __restrict__ w,
                                                             const float* __restrict__ bias, const int epi_act,
-                                                            bf16_t* __restrict__ out) {
+                                                            H* __restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int W2 = p.W + 2, HPI = (p.TH + 2) * W2, HP = p.TI * HPI;
     const int a_stage = p.a_pieces * 4096;
@@ -989,7 +1059,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_pkernel(const HaloParams 
                 for (int nt = 0; nt < 4; ++nt) fw[nt] = *reinterpret_cast<const uint4*>(lb + brow[nt]);
 #pragma unroll
                 for (int nt = 0; nt < 4; ++nt) {
-                    mma4_bf16_inplace(acc[0][nt], acc[1][nt], acc[2][nt], acc[3][nt], fw[nt], fx);
+                    mma4_inplace<H>(acc[0][nt], acc[1][nt], acc[2][nt], acc[3][nt], fw[nt], fx);
                     if (nt == 0) {
                         if (t < 7 && t < ap) issue_a(t < 7 ? t : 0, an, ay, asl, nst, true);
                     } else if (nt == 1) {
@@ -1040,11 +1110,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_pkernel(const HaloParams 
                     o[0] += bq.x; o[1] += bq.y; o[2] += bq.z; o[3] += bq.w;
                 }
                 act_fwd4<true>(o, epi_act);
-                pk[2 * nt] = pack2_bf16(o[0], o[1]);
-                pk[2 * nt + 1] = pack2_bf16(o[2], o[3]);
+                pk[2 * nt] = Elem<H>::pack2(o[0], o[1]);
+                pk[2 * nt + 1] = Elem<H>::pack2(o[2], o[3]);
             }
             if (n >= (uint32_t)p.N || y >= p.H) continue;
-            bf16_t* dst = out + ((size_t)(n * p.H + y) * p.W + tx) * p.Cout + co;
+            H* dst = out + ((size_t)(n * p.H + y) * p.W + tx) * p.Cout + co;
             if (co + 8 <= (uint32_t)p.Cout) *reinterpret_cast<uint4*>(dst) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
             if (co + 16 <= (uint32_t)p.Cout) *reinterpret_cast<uint4*>(dst + 8) = make_uint4(pk[4], pk[5], pk[6], pk[7]);
         }

@@ -51,13 +51,9 @@ __device__ __forceinline__ uint4 prologue_vec(uint4 q, const float* __restrict__
     return Elem<T>::pack(f);
 }
 
-template <typename T> struct Mma;
-template <> struct Mma<bf16_t> {
-    // acc(16 x 16) += A(16 rows x 32 k) * B(32 k x 16 cols); a/b are the lane's 8 consecutive k
-    __device__ static __forceinline__ void run(f32x4_t& acc, const uint4& a, const uint4& b) {
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a),
-                                                      __builtin_bit_cast(bf16x8_t, b), acc, 0, 0, 0);
-    }
+// 16-bit formats: one v_mfma_f32_16x16x32_{bf16,f16} per 16-byte fragment pair (Elem<T>::mfma)
+template <typename T> struct Mma {
+    __device__ static __forceinline__ void run(f32x4_t& acc, const uint4& a, const uint4& b) { Elem<T>::mfma(acc, a, b); }
 };
 template <> struct Mma<float> {
     __device__ static __forceinline__ void run(f32x4_t& acc, const uint4& a, const uint4& b) {
@@ -70,8 +66,6 @@ template <> struct Mma<float> {
 
 }  // namespace eve
 #include "conv_fast.h"
-#include "conv_halo32.h"
-#include "conv_halo_mt.h"
 #include "wgrad_halo.h"
 namespace eve {
 
@@ -239,8 +233,8 @@ __global__ __launch_bounds__(256) void igemm_kernel(const GatherParams p, const 
                         *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
                     } else {
                         uint2 pk;
-                        pk.x = pack2_bf16(o[0], o[1]);
-                        pk.y = pack2_bf16(o[2], o[3]);
+                        pk.x = Elem<T>::pack2(o[0], o[1]);
+                        pk.y = Elem<T>::pack2(o[2], o[3]);
                         *reinterpret_cast<uint2*>(dst) = pk;
                     }
                 } else {
@@ -483,7 +477,7 @@ __global__ __launch_bounds__(256) void bias_grad_kernel(const T* __restrict__ dy
 // -------------------------------------------------------------------------------------------------
 static int check_desc(const eve_conv_desc* d, int vec) {
     if (!d) return set_error_msg("conv: null descriptor");
-    if (d->dtype != EVE_DT_F32 && d->dtype != EVE_DT_BF16) return set_error_msg("conv: bad dtype");
+    if ((unsigned)d->dtype > (unsigned)EVE_DT_F16) return set_error_msg("conv: bad dtype");
     if (d->N <= 0 || d->IH <= 0 || d->IW <= 0 || d->OH <= 0 || d->OW <= 0 || d->Cin <= 0 || d->Cout <= 0 ||
         d->KH <= 0 || d->KW <= 0 || d->stride <= 0 || d->pad < 0)
         return set_error_msg("conv: non-positive dimension");
@@ -549,6 +543,7 @@ static void launch_dma_one(const GatherParams& p, const TapPlan& tp, const void*
 // LDS-DMA path: no prologue, channel count a multiple of the K step, 32-bit byte offsets.  Strided data
 // gradients are decomposed into stride*stride dense sub-problems (one per output parity class).
 // 3x3 / stride 1 / pad 1, bf16, halo-resident kernel.  Returns false when the shape does not qualify.
+template <typename HT>
 static bool launch_halo(const GatherParams& p, const void* src, const void* w, const float* bias, int epi_act,
                         void* out, hipStream_t s) {
     static int enabled = -1;
@@ -560,48 +555,6 @@ static bool launch_halo(const GatherParams& p, const void* src, const void* w, c
     if (p.Cin % 32 || W > 128 || (W & (W - 1)) || W < 4) return false;
     HaloParams h;
     h.N = p.N; h.H = H; h.W = W; h.Cin = p.Cin; h.Cout = p.Cout;
-    // ---- macro tile (conv_halo_mt.h): 256 pixels x 128 / 256 output channels, one 4-wave workgroup per CU ----
-    static int use_mt = -1;
-    if (use_mt < 0) { const char* e = getenv("EVE_HALO_MT"); use_mt = (e && e[0] == '1') ? 1 : 0; }
-    if (use_mt && p.Cout >= 128 && p.Cout % 8 == 0 && 256 % W == 0 && ((epi_act & 0xff) == EVE_ACT_NONE || (epi_act & 0xff) == EVE_ACT_RELU)) {
-        HaloParams m;
-        m.N = p.N; m.H = H; m.W = W; m.Cin = p.Cin; m.Cout = p.Cout;
-        const int rows = 256 / W;
-        bool ok = true;
-        if (rows <= H) { m.TI = 1; m.TH = rows; m.bands = (H + rows - 1) / rows; }
-        else if (rows % H == 0) { m.TI = rows / H; m.TH = H; m.bands = 1; }
-        else ok = false;
-        if (ok && W == 4 && m.TH != 4) ok = false;                     // the W = 4 swizzle table is for 4-row images
-        const int HPm = ok ? m.TI * (m.TH + 2) * (W + 2) : 0;
-        m.a_pieces = (HPm * 4 + 255) / 256;
-        const unsigned long long xb = (unsigned long long)p.N * H * W * p.Cin * 2, wb = (unsigned long long)p.Cout * p.K * 2;
-        if (ok && m.a_pieces <= MT_MAXP && xb < (1ull << 31) && wb < (1ull << 31)) {
-            const bool wide = p.Cout >= 256;
-            const int BN = wide ? 256 : 128;
-            m.flip = bwd ? 1 : 0;
-            m.K = p.K; m.x_bytes = (uint32_t)xb; m.w_bytes = (uint32_t)wb;
-            m.tiles_m = m.TI == 1 ? (uint32_t)p.N * m.bands : (uint32_t)((p.N + m.TI - 1) / m.TI);
-            m.tiles_n = (p.Cout + BN - 1) / BN;
-            m.fd_w2 = make_fastdiv(W + 2); m.fd_hpi = make_fastdiv((m.TH + 2) * (W + 2)); m.fd_w = make_fastdiv(W); m.fd_th = make_fastdiv(m.TH);
-            const size_t ldsm = 2 * (size_t)m.a_pieces * 4096 + 4 * (size_t)(64 * BN);
-            const uint32_t Tm = m.tiles_m * m.tiles_n;
-            const uint32_t rounds = (Tm + 255) / 256;
-            const uint32_t Gm = (Tm + rounds - 1) / rounds;              // balanced persistent grid (<= 256 workgroups)
-            static bool attr_mt = false;
-            if (!attr_mt) {
-                (void)hipFuncSetAttribute((const void*)conv3x3_halo_mt_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-                (void)hipFuncSetAttribute((const void*)conv3x3_halo_mt_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-                attr_mt = true;
-            }
-            if (wide)
-                EVE_LAUNCH("conv3x3_halo_mt_kernel<4>", (conv3x3_halo_mt_kernel<4>), dim3(Gm), dim3(256), ldsm, s, m, (const bf16_t*)src,
-                           (const bf16_t*)w, bias, epi_act, (bf16_t*)out);
-            else
-                EVE_LAUNCH("conv3x3_halo_mt_kernel<2>", (conv3x3_halo_mt_kernel<2>), dim3(Gm), dim3(256), ldsm, s, m, (const bf16_t*)src,
-                           (const bf16_t*)w, bias, epi_act, (bf16_t*)out);
-            return true;
-        }
-    }
     const bool narrow = p.Cout <= 64;               // 256 pixels x 64 channels (4x1 waves) instead of 128 x 128 (2x2)
     const int BMp = narrow ? 256 : 128;
     const int rows = BMp / W;
@@ -620,8 +573,8 @@ static bool launch_halo(const GatherParams& p, const void* src, const void* w, c
     const size_t lds = 2 * (size_t)h.a_pieces * 4096 + 4 * (narrow ? 4096 : 8192);
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)conv3x3_halo_kernel<2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)conv3x3_halo_kernel<4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv3x3_halo_kernel<HT, 2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv3x3_halo_kernel<HT, 4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
     static int persist = -1;
@@ -632,45 +585,24 @@ static bool launch_halo(const GatherParams& p, const void* src, const void* w, c
         const size_t plds = lds + (bias ? (size_t)h.tiles_n * (narrow ? 64 : 128) * 4 : 0);
         static bool pattr = false;
         if (!pattr) {
-            (void)hipFuncSetAttribute((const void*)conv3x3_halo_pkernel<2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            (void)hipFuncSetAttribute((const void*)conv3x3_halo_pkernel<4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void*)conv3x3_halo_pkernel<HT, 2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void*)conv3x3_halo_pkernel<HT, 4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             pattr = true;
         }
         if (narrow)
-            EVE_LAUNCH("conv3x3_halo_pkernel<4, 1>", (conv3x3_halo_pkernel<4, 1>), dim3(512), dim3(256), plds, s, h, (const bf16_t*)src,
-                               (const bf16_t*)w, bias, epi_act, (bf16_t*)out);
+            EVE_LAUNCH(EVE_HNAME(HT, "conv3x3_halo_pkernel<", ", 4, 1>"), (conv3x3_halo_pkernel<HT, 4, 1>), dim3(512), dim3(256), plds, s, h, (const HT*)src,
+                               (const HT*)w, bias, epi_act, (HT*)out);
         else
-            EVE_LAUNCH("conv3x3_halo_pkernel<2, 2>", (conv3x3_halo_pkernel<2, 2>), dim3(512), dim3(256), plds, s, h, (const bf16_t*)src,
-                               (const bf16_t*)w, bias, epi_act, (bf16_t*)out);
-        return true;
-    }
-    // EVE_HALO_MFMA32=1: the 32x32x16-MFMA, software-pipelined body (conv_halo32.h).  Measured, it is NOT faster (2.50 vs
-    // 2.39 ms per step over the 18 layer-2..4 launches) although the instruction alone sustains +35 % next to VALU work:
-    // the waves of this kernel are parked at the per-step barrier / vmcnt 35-40 % of their cycles whichever MFMA shape
-    // runs (SQ_WAIT_ANY, profiles/r02_halo_pmc.txt), so the matrix rate is not what bounds it.  Kept opt-in for that record.
-    static int mfma32 = -1;
-    if (mfma32 < 0) { const char* e = getenv("EVE_HALO_MFMA32"); mfma32 = (e && e[0] == '1') ? 1 : 0; }
-    if (mfma32 && (W >= 8 || h.TH == 4)) {
-        static bool attr32 = false;
-        if (!attr32) {
-            (void)hipFuncSetAttribute((const void*)conv3x3_halo32_kernel<2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            (void)hipFuncSetAttribute((const void*)conv3x3_halo32_kernel<4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            attr32 = true;
-        }
-        if (narrow)
-            EVE_LAUNCH("conv3x3_halo32_kernel<4, 1>", (conv3x3_halo32_kernel<4, 1>), dim3(tiles), dim3(256), lds, s, h, (const bf16_t*)src,
-                               (const bf16_t*)w, bias, epi_act, (bf16_t*)out);
-        else
-            EVE_LAUNCH("conv3x3_halo32_kernel<2, 2>", (conv3x3_halo32_kernel<2, 2>), dim3(tiles), dim3(256), lds, s, h, (const bf16_t*)src,
-                               (const bf16_t*)w, bias, epi_act, (bf16_t*)out);
+            EVE_LAUNCH(EVE_HNAME(HT, "conv3x3_halo_pkernel<", ", 2, 2>"), (conv3x3_halo_pkernel<HT, 2, 2>), dim3(512), dim3(256), plds, s, h, (const HT*)src,
+                               (const HT*)w, bias, epi_act, (HT*)out);
         return true;
     }
     if (narrow)
-        EVE_LAUNCH("conv3x3_halo_kernel<4, 1>", (conv3x3_halo_kernel<4, 1>), dim3(tiles), dim3(256), lds, s, h, (const bf16_t*)src,
-                           (const bf16_t*)w, bias, epi_act, (bf16_t*)out);
+        EVE_LAUNCH(EVE_HNAME(HT, "conv3x3_halo_kernel<", ", 4, 1>"), (conv3x3_halo_kernel<HT, 4, 1>), dim3(tiles), dim3(256), lds, s, h, (const HT*)src,
+                           (const HT*)w, bias, epi_act, (HT*)out);
     else
-        EVE_LAUNCH("conv3x3_halo_kernel<2, 2>", (conv3x3_halo_kernel<2, 2>), dim3(tiles), dim3(256), lds, s, h, (const bf16_t*)src,
-                           (const bf16_t*)w, bias, epi_act, (bf16_t*)out);
+        EVE_LAUNCH(EVE_HNAME(HT, "conv3x3_halo_kernel<", ", 2, 2>"), (conv3x3_halo_kernel<HT, 2, 2>), dim3(tiles), dim3(256), lds, s, h, (const HT*)src,
+                           (const HT*)w, bias, epi_act, (HT*)out);
     return true;
 }
 
@@ -678,7 +610,7 @@ template <typename T>
 static bool launch_igemm_dma(const GatherParams& p, const void* src, const void* w, const float* bias,
                              int epi_act, void* out, hipStream_t s) {
     constexpr int BK = 8 * Elem<T>::VEC;
-    if (sizeof(T) == 2 && launch_halo(p, src, w, bias, epi_act, out, s)) return true;
+    if constexpr (sizeof(T) == 2) { if (launch_halo<T>(p, src, w, bias, epi_act, out, s)) return true; }
     const unsigned long long src_bytes = (unsigned long long)p.N * p.IH * p.IW * p.Cin * sizeof(T);
     const unsigned long long w_bytes = (unsigned long long)p.Cout * p.K * sizeof(T);
     if (p.Cin % BK != 0 || p.KH * p.KW > 32 || src_bytes >= (1ull << 31) || w_bytes >= (1ull << 31)) return false;
@@ -774,6 +706,7 @@ static void wgrad_split(const GatherParams& p, uint32_t tk, uint32_t tc, size_t 
 }
 
 // few-channel 3x3 / stride 1 / pad 1 layers on large planes: band-resident kernel (wgrad_halo.h).  False = not this shape.
+template <typename HT>
 static bool launch_wgrad_halo(const GatherParams& p, const void* x, const void* dy, float* dw, float* db, hipStream_t s) {
     static int enabled = -1;
     if (enabled < 0) { const char* e = getenv("EVE_WGRAD_HALO"); enabled = (e && e[0] == '0') ? 0 : 1; }
@@ -831,20 +764,20 @@ static bool launch_wgrad_halo(const GatherParams& p, const void* x, const void* 
     do {                                                                                                                \
         static bool attr_done = false;                                                                                  \
         if (!attr_done) {                                                                                               \
-            (void)hipFuncSetAttribute((const void*)wgrad_halo_kernel<MT_, CT_, KS_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+            (void)hipFuncSetAttribute((const void*)wgrad_halo_kernel<HT, MT_, CT_, KS_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
             attr_done = true;                                                                                           \
         }                                                                                                               \
-        EVE_LAUNCH("wgrad_halo_kernel<" #MT_ ", " #CT_ ", " #KS_ ">", (wgrad_halo_kernel<MT_, CT_, KS_>), dim3(grid), dim3(256), lds, s, h, \
-                   (const bf16_t*)x, (const bf16_t*)dy, dw, db);                                                          \
+        EVE_LAUNCH(EVE_HNAME(HT, "wgrad_halo_kernel<", ", " #MT_ ", " #CT_ ", " #KS_ ">"), (wgrad_halo_kernel<HT, MT_, CT_, KS_>), dim3(grid), dim3(256), lds, s, h, \
+                   (const HT*)x, (const HT*)dy, dw, db);                                                                    \
     } while (0)
     if (split) {
         static bool attr_done = false;
         if (!attr_done) {
-            (void)hipFuncSetAttribute((const void*)wgrad_halo64_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void*)wgrad_halo64_kernel<HT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             attr_done = true;
         }
         const unsigned g64 = h.total_bands < 256u ? h.total_bands : 256u;
-        EVE_LAUNCH("wgrad_halo64_kernel", wgrad_halo64_kernel, dim3(g64), dim3(512), lds, s, h, (const bf16_t*)x, (const bf16_t*)dy, dw, db);
+        EVE_LAUNCH(EVE_HNAME(HT, "wgrad_halo64_kernel<", ">"), wgrad_halo64_kernel<HT>, dim3(g64), dim3(512), lds, s, h, (const HT*)x, (const HT*)dy, dw, db);
     } else if (ks == 3) {
         if (MT == 1 && CT == 1) EVE_WGRAD_HALO_LAUNCH(1, 1, 3);
         else if (MT == 1 && CT == 2) EVE_WGRAD_HALO_LAUNCH(1, 2, 3);
@@ -865,8 +798,9 @@ static bool launch_wgrad_halo(const GatherParams& p, const void* x, const void* 
 template <typename T>
 static int launch_wgrad(const GatherParams& p, const void* x, const void* dy, const float* ss, int pro_act,
                         float* dw, hipStream_t s, float* db = nullptr) {
-    if (sizeof(T) == 2 && !ss && !use_v1() && launch_wgrad_halo(p, x, dy, dw, db, s)) return db ? 1 : 0;
-    if (sizeof(T) == 2 && !ss && !use_v1()) {   // bf16: LDS-DMA staging + hardware-transposing fragment reads
+    if constexpr (sizeof(T) == 2) {
+    if (!ss && !use_v1() && launch_wgrad_halo<T>(p, x, dy, dw, db, s)) return db ? 1 : 0;
+    if (!ss && !use_v1()) {   // bf16: LDS-DMA staging + hardware-transposing fragment reads
         const unsigned long long x_bytes = (unsigned long long)p.N * p.IH * p.IW * p.Cin * 2;
         const unsigned long long dy_bytes = (unsigned long long)p.M * p.Cout * 2;
         if (x_bytes < (1ull << 31) && dy_bytes < (1ull << 31)) {
@@ -878,13 +812,13 @@ static int launch_wgrad(const GatherParams& p, const void* x, const void* dy, co
     do {                                                                                                                \
         static bool attr_done = false;                                                                                  \
         if (!attr_done) {                                                                                               \
-            (void)hipFuncSetAttribute((const void*)wgrad_tr_kernel<WCO_, WK_, P2_, B_, MT_>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+            (void)hipFuncSetAttribute((const void*)wgrad_tr_kernel<T, WCO_, WK_, P2_, B_, MT_>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                       160 * 1024);                                                                      \
             attr_done = true;                                                                                           \
         }                                                                                                               \
-        EVE_LAUNCH("wgrad_tr_kernel<" #WCO_ ", " #WK_ ", " #P2_ ", mt" #MT_ ">", (wgrad_tr_kernel<WCO_, WK_, P2_, B_, MT_>), \
-                   dim3((TK) * (TC) * splits), dim3(64 * WCO_ * WK_), lds_bytes(64 * WCO_, 64 * WK_, P2_), s, p, (const bf16_t*)x, \
-                   (const bf16_t*)dy, dw, rows, (uint32_t)x_bytes, (uint32_t)dy_bytes, db);                               \
+        EVE_LAUNCH(EVE_HNAME(T, "wgrad_tr_kernel<", ", " #WCO_ ", " #WK_ ", " #P2_ ", mt" #MT_ ">"), (wgrad_tr_kernel<T, WCO_, WK_, P2_, B_, MT_>), \
+                   dim3((TK) * (TC) * splits), dim3(64 * WCO_ * WK_), lds_bytes(64 * WCO_, 64 * WK_, P2_), s, p, (const T*)x, \
+                   (const T*)dy, dw, rows, (uint32_t)x_bytes, (uint32_t)dy_bytes, db);                               \
     } while (0)
 #define EVE_WGRAD_LAUNCH1(WCO_, WK_, P2_, MT_, TK, TC)                                                                  \
     do {                                                                                                                \
@@ -927,6 +861,7 @@ static int launch_wgrad(const GatherParams& p, const void* x, const void* dy, co
             return db ? 1 : 0;                              // 1: the bias gradient has been taken care of
         }
     }
+    }
     const bool wide = p.Cout > 64;
     const uint32_t bco = wide ? 128 : 64;
     const uint32_t tk = (p.K + 127) / 128, tc = (p.Cout + bco - 1) / bco;
@@ -958,12 +893,13 @@ using namespace eve;
 extern "C" int eve_conv2d_fwd(const eve_conv_desc* d, const void* x, const void* w_ohwi, const float* bias,
                               int epi_act, const float* in_scale_shift, int pro_act, void* y,
                               eve_stream_t stream) {
-    const int vec = (d && d->dtype == EVE_DT_BF16) ? 8 : 4;
+    const int vec = (d && d->dtype != EVE_DT_F32) ? 8 : 4;
     if (int e = check_desc(d, vec)) return e;
     if (!x || !w_ohwi || !y) return set_error_msg("conv2d_fwd: null pointer");
     GatherParams p = fwd_params(d);
     hipStream_t s = (hipStream_t)stream;
     if (d->dtype == EVE_DT_BF16) launch_igemm<bf16_t>(p, x, w_ohwi, bias, in_scale_shift, pro_act, epi_act, y, s);
+    else if (d->dtype == EVE_DT_F16) launch_igemm<f16_t>(p, x, w_ohwi, bias, in_scale_shift, pro_act, epi_act, y, s);
     else                         launch_igemm<float>(p, x, w_ohwi, bias, in_scale_shift, pro_act, epi_act, y, s);
     EVE_CHECK_LAUNCH();
     return 0;
@@ -971,13 +907,14 @@ extern "C" int eve_conv2d_fwd(const eve_conv_desc* d, const void* x, const void*
 
 extern "C" int eve_conv2d_dgrad(const eve_conv_desc* d, const void* dy, const void* w_ihwo, void* dx,
                                 eve_stream_t stream) {
-    const int vec = (d && d->dtype == EVE_DT_BF16) ? 8 : 4;
+    const int vec = (d && d->dtype != EVE_DT_F32) ? 8 : 4;
     if (int e = check_desc(d, vec)) return e;
     if (d->Cout % vec) return set_error_msg("conv2d_dgrad: Cout must be a multiple of the 16-byte vector");
     if (!dy || !w_ihwo || !dx) return set_error_msg("conv2d_dgrad: null pointer");
     GatherParams p = dgrad_params(d);
     hipStream_t s = (hipStream_t)stream;
     if (d->dtype == EVE_DT_BF16) launch_igemm<bf16_t>(p, dy, w_ihwo, nullptr, nullptr, 0, 0, dx, s);
+    else if (d->dtype == EVE_DT_F16) launch_igemm<f16_t>(p, dy, w_ihwo, nullptr, nullptr, 0, 0, dx, s);
     else                         launch_igemm<float>(p, dy, w_ihwo, nullptr, nullptr, 0, 0, dx, s);
     EVE_CHECK_LAUNCH();
     return 0;
@@ -987,13 +924,14 @@ extern "C" int eve_conv2d_dgrad(const eve_conv_desc* d, const void* dy, const vo
    into the convolution's epilogue.  dx must already hold the other branch's gradient. */
 extern "C" int eve_conv2d_dgrad_acc(const eve_conv_desc* d, const void* dy, const void* w_ihwo, void* dx,
                                     eve_stream_t stream) {
-    const int vec = (d && d->dtype == EVE_DT_BF16) ? 8 : 4;
+    const int vec = (d && d->dtype != EVE_DT_F32) ? 8 : 4;
     if (int e = check_desc(d, vec)) return e;
     if (d->Cout % vec) return set_error_msg("conv2d_dgrad_acc: Cout must be a multiple of the 16-byte vector");
     if (!dy || !w_ihwo || !dx) return set_error_msg("conv2d_dgrad_acc: null pointer");
     GatherParams p = dgrad_params(d);
     hipStream_t s = (hipStream_t)stream;
     if (d->dtype == EVE_DT_BF16) launch_igemm<bf16_t>(p, dy, w_ihwo, nullptr, nullptr, 0, EVE_EPI_ACC, dx, s);
+    else if (d->dtype == EVE_DT_F16) launch_igemm<f16_t>(p, dy, w_ihwo, nullptr, nullptr, 0, EVE_EPI_ACC, dx, s);
     else                         launch_igemm<float>(p, dy, w_ihwo, nullptr, nullptr, 0, EVE_EPI_ACC, dx, s);
     EVE_CHECK_LAUNCH();
     return 0;
@@ -1002,13 +940,14 @@ extern "C" int eve_conv2d_dgrad_acc(const eve_conv_desc* d, const void* dy, cons
 extern "C" int eve_conv2d_wgrad(const eve_conv_desc* d, const void* x, const void* dy,
                                 const float* in_scale_shift, int pro_act, float* dw_ohwi,
                                 eve_stream_t stream) {
-    const int vec = (d && d->dtype == EVE_DT_BF16) ? 8 : 4;
+    const int vec = (d && d->dtype != EVE_DT_F32) ? 8 : 4;
     if (int e = check_desc(d, vec)) return e;
     if (d->Cout % vec) return set_error_msg("conv2d_wgrad: Cout must be a multiple of the 16-byte vector");
     if (!x || !dy || !dw_ohwi) return set_error_msg("conv2d_wgrad: null pointer");
     GatherParams p = fwd_params(d);
     hipStream_t s = (hipStream_t)stream;
     if (d->dtype == EVE_DT_BF16) launch_wgrad<bf16_t>(p, x, dy, in_scale_shift, pro_act, dw_ohwi, s);
+    else if (d->dtype == EVE_DT_F16) launch_wgrad<f16_t>(p, x, dy, in_scale_shift, pro_act, dw_ohwi, s);
     else                         launch_wgrad<float>(p, x, dy, in_scale_shift, pro_act, dw_ohwi, s);
     EVE_CHECK_LAUNCH();
     return 0;
@@ -1019,8 +958,8 @@ extern "C" int eve_conv2d_wgrad(const eve_conv_desc* d, const void* x, const voi
    does not exist; its gradient is written and ignored), so a 16-byte operand slot is two horizontally adjacent taps and
    K = 7*8*4 = 224 fits ONE K tile -- against K = 392 (two padded tiles, 62 % of the MACs on zero channels) for the
    8-channel NHWC copy, which is no longer needed at all.  dw [64][7][8][4] float, accumulated. */
-extern "C" int eve_stem_wgrad(int N, int IH, int IW, const void* x_padded, const void* dconv, float* dw, eve_stream_t stream) {
-    if (N <= 0 || IH <= 0 || IW <= 0 || (IH & 1) || (IW & 1) || !x_padded || !dconv || !dw)
+extern "C" int eve_stem_wgrad(int dtype, int N, int IH, int IW, const void* x_padded, const void* dconv, float* dw, eve_stream_t stream) {
+    if ((dtype != EVE_DT_BF16 && dtype != EVE_DT_F16) || N <= 0 || IH <= 0 || IW <= 0 || (IH & 1) || (IW & 1) || !x_padded || !dconv || !dw)
         return set_error_msg("stem_wgrad: bad arguments");
     GatherParams p;
     p.N = N; p.IH = IH + 6; p.IW = IW + 8; p.Cin = 4;
@@ -1033,7 +972,7 @@ extern "C" int eve_stem_wgrad(int N, int IH, int IW, const void* x_padded, const
     // conv pad is 3, the packed rows carry 4 pixels of left padding: start one pixel (8 bytes) in
     const char* x1 = (const char*)x_padded + 8;
     if ((unsigned long long)N * p.IH * p.IW * 8 >= (1ull << 31)) return set_error_msg("stem_wgrad: packed input must stay below 2 GiB");
-    launch_wgrad<bf16_t>(p, x1, dconv, nullptr, 0, dw, (hipStream_t)stream);
+    EVE_DISPATCH_H16(dtype, launch_wgrad<H>(p, x1, dconv, nullptr, 0, dw, (hipStream_t)stream));
     EVE_CHECK_LAUNCH();
     return 0;
 }
@@ -1045,12 +984,14 @@ static void launch_bias_grad(int dtype, long long M, int C, const void* dy, floa
     blocks = (M + rows - 1) / rows;
     if (dtype == EVE_DT_BF16)
         hipLaunchKernelGGL(bias_grad_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, s, (const bf16_t*)dy, db, M, C, rows);
+    else if (dtype == EVE_DT_F16)
+        hipLaunchKernelGGL(bias_grad_kernel<f16_t>, dim3((unsigned)blocks), dim3(256), 0, s, (const f16_t*)dy, db, M, C, rows);
     else
         hipLaunchKernelGGL(bias_grad_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, s, (const float*)dy, db, M, C, rows);
 }
 
 extern "C" int eve_bias_grad(int dtype, long long M, int C, const void* dy, float* db, eve_stream_t stream) {
-    const int vec = dtype == EVE_DT_BF16 ? 8 : 4;
+    const int vec = dtype != EVE_DT_F32 ? 8 : 4;
     if (M <= 0 || C <= 0 || C % vec || C / vec > 256) return set_error_msg("bias_grad: bad shape");
     if (!dy || !db) return set_error_msg("bias_grad: null pointer");
     launch_bias_grad(dtype, M, C, dy, db, (hipStream_t)stream);
@@ -1063,7 +1004,7 @@ extern "C" int eve_bias_grad(int dtype, long long M, int C, const void* dy, floa
    dw and db are accumulated into. */
 extern "C" int eve_conv2d_wgrad_bias(const eve_conv_desc* d, const void* x, const void* dy, float* dw_ohwi, float* db,
                                      eve_stream_t stream) {
-    const int vec = (d && d->dtype == EVE_DT_BF16) ? 8 : 4;
+    const int vec = (d && d->dtype != EVE_DT_F32) ? 8 : 4;
     if (int e = check_desc(d, vec)) return e;
     if (d->Cout % vec || d->Cout / vec > 256) return set_error_msg("conv2d_wgrad_bias: bad Cout");
     if (!x || !dy || !dw_ohwi || !db) return set_error_msg("conv2d_wgrad_bias: null pointer");
@@ -1071,6 +1012,7 @@ extern "C" int eve_conv2d_wgrad_bias(const eve_conv_desc* d, const void* x, cons
     hipStream_t s = (hipStream_t)stream;
     int fused = 0;
     if (d->dtype == EVE_DT_BF16) fused = launch_wgrad<bf16_t>(p, x, dy, nullptr, 0, dw_ohwi, s, db);
+    else if (d->dtype == EVE_DT_F16) fused = launch_wgrad<f16_t>(p, x, dy, nullptr, 0, dw_ohwi, s, db);
     else                         launch_wgrad<float>(p, x, dy, nullptr, 0, dw_ohwi, s);
     if (!fused) launch_bias_grad(d->dtype, (long long)p.M, d->Cout, dy, db, s);
     EVE_CHECK_LAUNCH();

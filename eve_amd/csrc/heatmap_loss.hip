@@ -122,10 +122,11 @@ using namespace eve;
 
 extern "C" int eve_heatmap_head_fwd(int dtype, long long pixels, int Cpad, const void* logits, float* out,
                                     eve_stream_t stream) {
-    if ((dtype != EVE_DT_F32 && dtype != EVE_DT_BF16) || pixels <= 0 || Cpad <= 0 || !logits || !out)
+    if (((unsigned)dtype > (unsigned)EVE_DT_F16) || pixels <= 0 || Cpad <= 0 || !logits || !out)
         return set_error_msg("heatmap_head_fwd: bad arguments");
     hipStream_t s = (hipStream_t)stream;
     if (dtype == EVE_DT_BF16) hipLaunchKernelGGL(heatmap_head_fwd_kernel<bf16_t>, dim3(hm_grid(pixels)), dim3(256), 0, s, (const bf16_t*)logits, out, Cpad, pixels);
+    else if (dtype == EVE_DT_F16) hipLaunchKernelGGL(heatmap_head_fwd_kernel<f16_t>, dim3(hm_grid(pixels)), dim3(256), 0, s, (const f16_t*)logits, out, Cpad, pixels);
     else                      hipLaunchKernelGGL(heatmap_head_fwd_kernel<float>, dim3(hm_grid(pixels)), dim3(256), 0, s, (const float*)logits, out, Cpad, pixels);
     EVE_CHECK_LAUNCH();
     return 0;
@@ -133,13 +134,14 @@ extern "C" int eve_heatmap_head_fwd(int dtype, long long pixels, int Cpad, const
 
 extern "C" int eve_heatmap_head_bwd(int dtype, long long pixels, int Cpad, const float* dy, const float* y, void* dlogits,
                                     eve_stream_t stream) {
-    const int vec = dtype == EVE_DT_BF16 ? 8 : 4;
-    if ((dtype != EVE_DT_F32 && dtype != EVE_DT_BF16) || pixels <= 0 || Cpad <= 0 || Cpad % vec || !dy || !y || !dlogits)
+    const int vec = dtype != EVE_DT_F32 ? 8 : 4;
+    if (((unsigned)dtype > (unsigned)EVE_DT_F16) || pixels <= 0 || Cpad <= 0 || Cpad % vec || !dy || !y || !dlogits)
         return set_error_msg("heatmap_head_bwd: bad arguments");
     hipStream_t s = (hipStream_t)stream;
     const int cvecs = Cpad / vec;
     const long long nvec = pixels * cvecs;
     if (dtype == EVE_DT_BF16) hipLaunchKernelGGL(heatmap_head_bwd_kernel<bf16_t>, dim3(hm_grid(nvec)), dim3(256), 0, s, dy, y, (bf16_t*)dlogits, cvecs, nvec);
+    else if (dtype == EVE_DT_F16) hipLaunchKernelGGL(heatmap_head_bwd_kernel<f16_t>, dim3(hm_grid(nvec)), dim3(256), 0, s, dy, y, (f16_t*)dlogits, cvecs, nvec);
     else                      hipLaunchKernelGGL(heatmap_head_bwd_kernel<float>, dim3(hm_grid(nvec)), dim3(256), 0, s, dy, y, (float*)dlogits, cvecs, nvec);
     EVE_CHECK_LAUNCH();
     return 0;

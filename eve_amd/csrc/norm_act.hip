@@ -354,8 +354,8 @@ static inline unsigned stream_grid(long long nvec) {
 }
 
 static int check_plane(int dtype, int N, int HW, int C, const char* who) {
-    const int vec = dtype == EVE_DT_BF16 ? 8 : 4;
-    if (dtype != EVE_DT_F32 && dtype != EVE_DT_BF16) return set_error_msg("instnorm: bad dtype");
+    const int vec = dtype != EVE_DT_F32 ? 8 : 4;
+    if ((unsigned)dtype > (unsigned)EVE_DT_F16) return set_error_msg("instnorm: bad dtype");
     if (N <= 0 || HW <= 0 || C <= 0 || C % vec || C / vec > 256 || C > 1024) return set_error_msg(who);
     return 0;
 }
@@ -374,7 +374,10 @@ extern "C" int eve_instnorm_stats(int dtype, int N, int HW, int C, const void* x
     if (one_pass < 0) { const char* e = getenv("EVE_IN_STATS_ONE_PASS"); one_pass = (e && e[0] == '0') ? 0 : 1; }
     if (dtype == EVE_DT_BF16 && one_pass && (long long)HW * C * 2 >= 65536)
         EVE_LAUNCH("in_stats1_kernel<eve::bf16_t>", in_stats1_kernel<bf16_t>, dim3(N), dim3(256), 0, s, (const bf16_t*)x, mean_rstd, HW, C, eps);
+    else if (dtype == EVE_DT_F16 && one_pass && (long long)HW * C * 2 >= 65536)
+        EVE_LAUNCH("in_stats1_kernel<eve::f16_t>", in_stats1_kernel<f16_t>, dim3(N), dim3(256), 0, s, (const f16_t*)x, mean_rstd, HW, C, eps);
     else if (dtype == EVE_DT_BF16) EVE_LAUNCH("in_stats_kernel<eve::bf16_t>", in_stats_kernel<bf16_t>, dim3(N), dim3(256), 0, s, (const bf16_t*)x, mean_rstd, HW, C, eps);
+    else if (dtype == EVE_DT_F16) EVE_LAUNCH("in_stats_kernel<eve::f16_t>", in_stats_kernel<f16_t>, dim3(N), dim3(256), 0, s, (const f16_t*)x, mean_rstd, HW, C, eps);
     else                      EVE_LAUNCH("in_stats_kernel<float>", in_stats_kernel<float>, dim3(N), dim3(256), 0, s, (const float*)x, mean_rstd, HW, C, eps);
     EVE_CHECK_LAUNCH();
     return 0;
@@ -386,7 +389,7 @@ extern "C" int eve_instnorm_act_fwd(int dtype, int N, int HW, int C, const void*
     if (int e = check_plane(dtype, N, HW, C, "instnorm_act_fwd: bad shape")) return e;
     if (!x || !mean_rstd || !y || ((gamma == nullptr) != (beta == nullptr)))
         return set_error_msg("instnorm_act_fwd: null pointer / gamma-beta mismatch");
-    const int vec = dtype == EVE_DT_BF16 ? 8 : 4;
+    const int vec = dtype != EVE_DT_F32 ? 8 : 4;
     const int cvecs = C / vec;
     const long long per_img = (long long)HW * cvecs;
     if (per_img >= (1ll << 31) || N > 65535) return set_error_msg("instnorm_act_fwd: plane / batch too large");
@@ -401,6 +404,8 @@ extern "C" int eve_instnorm_act_fwd(int dtype, int N, int HW, int C, const void*
     hipStream_t s = (hipStream_t)stream;
     if (dtype == EVE_DT_BF16)
         EVE_IN_ACT_DISPATCH(in_act_fwd_kernel, bf16_t, "eve::bf16_t", fgrid, (const bf16_t*)x, mean_rstd, gamma, beta, (const bf16_t*)res, act, (bf16_t*)y, HW, C);
+    else if (dtype == EVE_DT_F16)
+        EVE_IN_ACT_DISPATCH(in_act_fwd_kernel, f16_t, "eve::f16_t", fgrid, (const f16_t*)x, mean_rstd, gamma, beta, (const f16_t*)res, act, (f16_t*)y, HW, C);
     else
         EVE_IN_ACT_DISPATCH(in_act_fwd_kernel, float, "float", fgrid, (const float*)x, mean_rstd, gamma, beta, (const float*)res, act, (float*)y, HW, C);
     EVE_CHECK_LAUNCH();
@@ -416,6 +421,8 @@ extern "C" int eve_instnorm_act_bwd(int dtype, int N, int HW, int C, const void*
     hipStream_t s = (hipStream_t)stream;
     if (dtype == EVE_DT_BF16)
         EVE_IN_ACT_DISPATCH(in_act_bwd_kernel, bf16_t, "eve::bf16_t", dim3(N), (const bf16_t*)dy, (const bf16_t*)y, (const bf16_t*)x, mean_rstd, gamma, beta, act, (bf16_t*)dx, (bf16_t*)dres, sums, HW, C);
+    else if (dtype == EVE_DT_F16)
+        EVE_IN_ACT_DISPATCH(in_act_bwd_kernel, f16_t, "eve::f16_t", dim3(N), (const f16_t*)dy, (const f16_t*)y, (const f16_t*)x, mean_rstd, gamma, beta, act, (f16_t*)dx, (f16_t*)dres, sums, HW, C);
     else
         EVE_IN_ACT_DISPATCH(in_act_bwd_kernel, float, "float", dim3(N), (const float*)dy, (const float*)y, (const float*)x, mean_rstd, gamma, beta, act, (float*)dx, (float*)dres, sums, HW, C);
     EVE_CHECK_LAUNCH();
@@ -427,6 +434,7 @@ extern "C" int eve_act_bwd(int dtype, long long n, const void* dy, const void* y
     if (n <= 0 || !dy || !y || !dx) return set_error_msg("act_bwd: bad arguments");
     hipStream_t s = (hipStream_t)stream;
     if (dtype == EVE_DT_BF16) hipLaunchKernelGGL(act_bwd_kernel<bf16_t>, dim3(stream_grid(n / 8 + 1)), dim3(256), 0, s, (const bf16_t*)dy, (const bf16_t*)y, act, (bf16_t*)dx, n);
+    else if (dtype == EVE_DT_F16) hipLaunchKernelGGL(act_bwd_kernel<f16_t>, dim3(stream_grid(n / 8 + 1)), dim3(256), 0, s, (const f16_t*)dy, (const f16_t*)y, act, (f16_t*)dx, n);
     else                      hipLaunchKernelGGL(act_bwd_kernel<float>, dim3(stream_grid(n / 4 + 1)), dim3(256), 0, s, (const float*)dy, (const float*)y, act, (float*)dx, n);
     EVE_CHECK_LAUNCH();
     return 0;
@@ -436,6 +444,7 @@ extern "C" int eve_add(int dtype, long long n, const void* a, const void* b, voi
     if (n <= 0 || !a || !b || !out) return set_error_msg("add: bad arguments");
     hipStream_t s = (hipStream_t)stream;
     if (dtype == EVE_DT_BF16) hipLaunchKernelGGL(add_kernel<bf16_t>, dim3(stream_grid(n / 8 + 1)), dim3(256), 0, s, (const bf16_t*)a, (const bf16_t*)b, (bf16_t*)out, n);
+    else if (dtype == EVE_DT_F16) hipLaunchKernelGGL(add_kernel<f16_t>, dim3(stream_grid(n / 8 + 1)), dim3(256), 0, s, (const f16_t*)a, (const f16_t*)b, (f16_t*)out, n);
     else                      hipLaunchKernelGGL(add_kernel<float>, dim3(stream_grid(n / 4 + 1)), dim3(256), 0, s, (const float*)a, (const float*)b, (float*)out, n);
     EVE_CHECK_LAUNCH();
     return 0;

@@ -271,16 +271,19 @@ using namespace eve;
 extern "C" int eve_instnorm_fwd_fused(int dtype, int N, int HW, int C, const void* x, const float* gamma,
                                       const float* beta, const void* res, int act, float eps, void* y,
                                       float* mean_rstd, unsigned char* sign_mask, eve_stream_t stream) {
-    const int vec = dtype == EVE_DT_BF16 ? 8 : 4;
-    if ((dtype != EVE_DT_F32 && dtype != EVE_DT_BF16) || N <= 0 || HW <= 0 || C <= 0 || C % vec || !x || !y ||
+    const int vec = dtype != EVE_DT_F32 ? 8 : 4;
+    if (((unsigned)dtype > (unsigned)EVE_DT_F16) || N <= 0 || HW <= 0 || C <= 0 || C % vec || !x || !y ||
         !mean_rstd || ((gamma == nullptr) != (beta == nullptr)))
         return set_error_msg("instnorm_fwd_fused: bad arguments");
     int threads, vpt, sl;
-    if (!fused_plan(HW * (C / vec), C / vec, threads, vpt, sl, dtype == EVE_DT_BF16)) return -1;
+    if (!fused_plan(HW * (C / vec), C / vec, threads, vpt, sl, dtype != EVE_DT_F32)) return -1;
     const unsigned grid = sl ? (unsigned)((N + 7) / 8) * (8u << sl) : (unsigned)N;
     hipStream_t s = (hipStream_t)stream;
     if (dtype == EVE_DT_BF16) {
         LAUNCH_VPT(in_fwd_fused_kernel, bf16_t, "eve::bf16_t", (const bf16_t*)x, gamma, beta, (const bf16_t*)res, act, (bf16_t*)y,
+                   mean_rstd, sign_mask, N, HW, C, sl, eps)
+    } else if (dtype == EVE_DT_F16) {
+        LAUNCH_VPT(in_fwd_fused_kernel, f16_t, "eve::f16_t", (const f16_t*)x, gamma, beta, (const f16_t*)res, act, (f16_t*)y,
                    mean_rstd, sign_mask, N, HW, C, sl, eps)
     } else {
         LAUNCH_VPT(in_fwd_fused_kernel, float, "float", (const float*)x, gamma, beta, (const float*)res, act, (float*)y,
@@ -293,17 +296,20 @@ extern "C" int eve_instnorm_fwd_fused(int dtype, int N, int HW, int C, const voi
 extern "C" int eve_instnorm_bwd_fused(int dtype, int N, int HW, int C, const void* dy, const void* dy2, const void* y, const void* x,
                                       const float* mean_rstd, const float* gamma, int act, void* dx, void* dres,
                                       float* sums, const unsigned char* sign_mask, eve_stream_t stream) {
-    const int vec = dtype == EVE_DT_BF16 ? 8 : 4;
-    if ((dtype != EVE_DT_F32 && dtype != EVE_DT_BF16) || N <= 0 || HW <= 0 || C <= 0 || C % vec || !dy || !x ||
+    const int vec = dtype != EVE_DT_F32 ? 8 : 4;
+    if (((unsigned)dtype > (unsigned)EVE_DT_F16) || N <= 0 || HW <= 0 || C <= 0 || C % vec || !dy || !x ||
         !mean_rstd || !dx || (act != EVE_ACT_NONE && !y && gamma && !(act == EVE_ACT_RELU && sign_mask)))
         return set_error_msg("instnorm_bwd_fused: bad arguments");
     int threads, vpt, sl;
-    if (!fused_plan(HW * (C / vec), C / vec, threads, vpt, sl, dtype == EVE_DT_BF16)) return -1;
+    if (!fused_plan(HW * (C / vec), C / vec, threads, vpt, sl, dtype != EVE_DT_F32)) return -1;
     const unsigned grid = sl ? (unsigned)((N + 7) / 8) * (8u << sl) : (unsigned)N;
     hipStream_t s = (hipStream_t)stream;
     if (dtype == EVE_DT_BF16) {
         LAUNCH_VPT(in_bwd_fused_kernel, bf16_t, "eve::bf16_t", (const bf16_t*)dy, (const bf16_t*)dy2, (const bf16_t*)y, (const bf16_t*)x, mean_rstd, gamma,
                    act, (bf16_t*)dx, (bf16_t*)dres, sums, sign_mask, N, HW, C, sl)
+    } else if (dtype == EVE_DT_F16) {
+        LAUNCH_VPT(in_bwd_fused_kernel, f16_t, "eve::f16_t", (const f16_t*)dy, (const f16_t*)dy2, (const f16_t*)y, (const f16_t*)x, mean_rstd, gamma,
+                   act, (f16_t*)dx, (f16_t*)dres, sums, sign_mask, N, HW, C, sl)
     } else {
         LAUNCH_VPT(in_bwd_fused_kernel, float, "float", (const float*)dy, (const float*)dy2, (const float*)y, (const float*)x, mean_rstd, gamma,
                    act, (float*)dx, (float*)dres, sums, sign_mask, N, HW, C, sl)
@@ -474,8 +480,8 @@ __global__ __launch_bounds__(1024) void in_relu_pool_bwd_kernel(const T* __restr
 
 extern "C" int eve_in_relu_maxpool_fwd(int dtype, int N, int IH, int IW, int C, const void* x, const float* mean_rstd,
                                        void* y, uint8_t* idx, eve_stream_t stream) {
-    const int vec = dtype == EVE_DT_BF16 ? 8 : 4;
-    if ((dtype != EVE_DT_F32 && dtype != EVE_DT_BF16) || N <= 0 || IH <= 0 || IW <= 0 || C <= 0 || C % vec || !x ||
+    const int vec = dtype != EVE_DT_F32 ? 8 : 4;
+    if (((unsigned)dtype > (unsigned)EVE_DT_F16) || N <= 0 || IH <= 0 || IW <= 0 || C <= 0 || C % vec || !x ||
         !mean_rstd || !y || !idx)
         return set_error_msg("in_relu_maxpool_fwd: bad arguments");
     const int OH = (IH - 1) / 2 + 1, OW = (IW - 1) / 2 + 1;
@@ -484,6 +490,7 @@ extern "C" int eve_in_relu_maxpool_fwd(int dtype, int N, int IH, int IW, int C, 
     if (blocks > 4096) blocks = 4096;
     hipStream_t s = (hipStream_t)stream;
     if (dtype == EVE_DT_BF16) hipLaunchKernelGGL(in_relu_pool_fwd_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, s, (const bf16_t*)x, mean_rstd, (bf16_t*)y, idx, IH, IW, OH, OW, C, items);
+    else if (dtype == EVE_DT_F16) hipLaunchKernelGGL(in_relu_pool_fwd_kernel<f16_t>, dim3((unsigned)blocks), dim3(256), 0, s, (const f16_t*)x, mean_rstd, (f16_t*)y, idx, IH, IW, OH, OW, C, items);
     else                      hipLaunchKernelGGL(in_relu_pool_fwd_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, s, (const float*)x, mean_rstd, (float*)y, idx, IH, IW, OH, OW, C, items);
     EVE_CHECK_LAUNCH();
     return 0;
@@ -492,13 +499,14 @@ extern "C" int eve_in_relu_maxpool_fwd(int dtype, int N, int IH, int IW, int C, 
 extern "C" int eve_in_relu_maxpool_bwd(int dtype, int N, int IH, int IW, int C, const void* dy_pool, const void* y_pool,
                                        const uint8_t* idx, const void* x, const float* mean_rstd, void* dx,
                                        eve_stream_t stream) {
-    const int vec = dtype == EVE_DT_BF16 ? 8 : 4;
-    if ((dtype != EVE_DT_F32 && dtype != EVE_DT_BF16) || N <= 0 || IH <= 0 || IW <= 0 || C <= 0 || C % vec ||
+    const int vec = dtype != EVE_DT_F32 ? 8 : 4;
+    if (((unsigned)dtype > (unsigned)EVE_DT_F16) || N <= 0 || IH <= 0 || IW <= 0 || C <= 0 || C % vec ||
         C / vec > 256 || C > 1024 || !dy_pool || !y_pool || !idx || !x || !mean_rstd || !dx)
         return set_error_msg("in_relu_maxpool_bwd: bad arguments");
     const int OH = (IH - 1) / 2 + 1, OW = (IW - 1) / 2 + 1;
     hipStream_t s = (hipStream_t)stream;
     if (dtype == EVE_DT_BF16) hipLaunchKernelGGL(in_relu_pool_bwd_kernel<bf16_t>, dim3(N), dim3(1024), 0, s, (const bf16_t*)dy_pool, (const bf16_t*)y_pool, idx, (const bf16_t*)x, mean_rstd, (bf16_t*)dx, IH, IW, OH, OW, C);
+    else if (dtype == EVE_DT_F16) hipLaunchKernelGGL(in_relu_pool_bwd_kernel<f16_t>, dim3(N), dim3(1024), 0, s, (const f16_t*)dy_pool, (const f16_t*)y_pool, idx, (const f16_t*)x, mean_rstd, (f16_t*)dx, IH, IW, OH, OW, C);
     else                      hipLaunchKernelGGL(in_relu_pool_bwd_kernel<float>, dim3(N), dim3(1024), 0, s, (const float*)dy_pool, (const float*)y_pool, idx, (const float*)x, mean_rstd, (float*)dx, IH, IW, OH, OW, C);
     EVE_CHECK_LAUNCH();
     return 0;

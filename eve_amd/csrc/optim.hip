@@ -48,6 +48,9 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
     if (lr_dev) lr = *lr_dev;      // the schedule's value for this step, written by the host before the (replayed) launch
     float clip = gscale;
     if (sumsq) {
+        // float16 training (static loss scale, train.Trainer): a gradient that overflowed the format shows up as an
+        // infinite / NaN norm -- the step is skipped, weights and moments stay as they are (wave-uniform exit)
+        if (!(*sumsq < 3.0e38f)) return;
         const float total = sqrtf(*sumsq) * gscale;
         const float c = max_norm / (total + 1e-6f);
         clip = gscale * (c < 1.f ? c : 1.f);

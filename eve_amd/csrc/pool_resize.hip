@@ -376,8 +376,8 @@ using namespace eve;
 
 
 static int chk(int dtype, int C, const char* who) {
-    const int vec = dtype == EVE_DT_BF16 ? 8 : 4;
-    if ((dtype != EVE_DT_F32 && dtype != EVE_DT_BF16) || C <= 0 || C % vec) return set_error_msg(who);
+    const int vec = dtype != EVE_DT_F32 ? 8 : 4;
+    if (((unsigned)dtype > (unsigned)EVE_DT_F16) || C <= 0 || C % vec) return set_error_msg(who);
     return 0;
 }
 
@@ -386,10 +386,11 @@ extern "C" int eve_maxpool3x3s2_fwd(int dtype, int N, int IH, int IW, int C, con
     if (int e = chk(dtype, C, "maxpool_fwd: bad dtype / C")) return e;
     if (N <= 0 || IH <= 0 || IW <= 0 || !x || !y || !idx) return set_error_msg("maxpool_fwd: bad arguments");
     const int OH = (IH - 1) / 2 + 1, OW = (IW - 1) / 2 + 1;
-    const int vec = dtype == EVE_DT_BF16 ? 8 : 4;
+    const int vec = dtype != EVE_DT_F32 ? 8 : 4;
     const long long items = (long long)N * OH * OW * (C / vec);
     hipStream_t s = (hipStream_t)stream;
     if (dtype == EVE_DT_BF16) hipLaunchKernelGGL(maxpool_fwd_kernel<bf16_t>, dim3(sgrid(items)), dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)y, idx, IH, IW, OH, OW, C, items);
+    else if (dtype == EVE_DT_F16) hipLaunchKernelGGL(maxpool_fwd_kernel<f16_t>, dim3(sgrid(items)), dim3(256), 0, s, (const f16_t*)x, (f16_t*)y, idx, IH, IW, OH, OW, C, items);
     else                      hipLaunchKernelGGL(maxpool_fwd_kernel<float>, dim3(sgrid(items)), dim3(256), 0, s, (const float*)x, (float*)y, idx, IH, IW, OH, OW, C, items);
     EVE_CHECK_LAUNCH();
     return 0;
@@ -399,10 +400,11 @@ extern "C" int eve_maxpool3x3s2_bwd(int dtype, int N, int IH, int IW, int C, con
     if (int e = chk(dtype, C, "maxpool_bwd: bad dtype / C")) return e;
     if (N <= 0 || IH <= 0 || IW <= 0 || !dy || !dx || !idx) return set_error_msg("maxpool_bwd: bad arguments");
     const int OH = (IH - 1) / 2 + 1, OW = (IW - 1) / 2 + 1;
-    const int vec = dtype == EVE_DT_BF16 ? 8 : 4;
+    const int vec = dtype != EVE_DT_F32 ? 8 : 4;
     const long long items = (long long)N * IH * IW * (C / vec);
     hipStream_t s = (hipStream_t)stream;
     if (dtype == EVE_DT_BF16) hipLaunchKernelGGL(maxpool_bwd_kernel<bf16_t>, dim3(sgrid(items)), dim3(256), 0, s, (const bf16_t*)dy, idx, (bf16_t*)dx, IH, IW, OH, OW, C, items);
+    else if (dtype == EVE_DT_F16) hipLaunchKernelGGL(maxpool_bwd_kernel<f16_t>, dim3(sgrid(items)), dim3(256), 0, s, (const f16_t*)dy, idx, (f16_t*)dx, IH, IW, OH, OW, C, items);
     else                      hipLaunchKernelGGL(maxpool_bwd_kernel<float>, dim3(sgrid(items)), dim3(256), 0, s, (const float*)dy, idx, (float*)dx, IH, IW, OH, OW, C, items);
     EVE_CHECK_LAUNCH();
     return 0;
@@ -410,10 +412,11 @@ extern "C" int eve_maxpool3x3s2_bwd(int dtype, int N, int IH, int IW, int C, con
 extern "C" int eve_avgpool_fwd(int dtype, int N, int HW, int C, const void* x, void* y, eve_stream_t stream) {
     if (int e = chk(dtype, C, "avgpool_fwd: bad dtype / C")) return e;
     if (N <= 0 || HW <= 0 || !x || !y) return set_error_msg("avgpool_fwd: bad arguments");
-    const int vec = dtype == EVE_DT_BF16 ? 8 : 4;
+    const int vec = dtype != EVE_DT_F32 ? 8 : 4;
     const long long items = (long long)N * (C / vec);
     hipStream_t s = (hipStream_t)stream;
     if (dtype == EVE_DT_BF16) hipLaunchKernelGGL(avgpool_fwd_kernel<bf16_t>, dim3(sgrid(items)), dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)y, HW, C, items);
+    else if (dtype == EVE_DT_F16) hipLaunchKernelGGL(avgpool_fwd_kernel<f16_t>, dim3(sgrid(items)), dim3(256), 0, s, (const f16_t*)x, (f16_t*)y, HW, C, items);
     else                      hipLaunchKernelGGL(avgpool_fwd_kernel<float>, dim3(sgrid(items)), dim3(256), 0, s, (const float*)x, (float*)y, HW, C, items);
     EVE_CHECK_LAUNCH();
     return 0;
@@ -421,10 +424,11 @@ extern "C" int eve_avgpool_fwd(int dtype, int N, int HW, int C, const void* x, v
 extern "C" int eve_avgpool_bwd(int dtype, int N, int HW, int C, const void* dy, void* dx, eve_stream_t stream) {
     if (int e = chk(dtype, C, "avgpool_bwd: bad dtype / C")) return e;
     if (N <= 0 || HW <= 0 || !dy || !dx) return set_error_msg("avgpool_bwd: bad arguments");
-    const int vec = dtype == EVE_DT_BF16 ? 8 : 4;
+    const int vec = dtype != EVE_DT_F32 ? 8 : 4;
     const long long items = (long long)N * HW * (C / vec);
     hipStream_t s = (hipStream_t)stream;
     if (dtype == EVE_DT_BF16) hipLaunchKernelGGL(avgpool_bwd_kernel<bf16_t>, dim3(sgrid(items)), dim3(256), 0, s, (const bf16_t*)dy, (bf16_t*)dx, HW, C, items);
+    else if (dtype == EVE_DT_F16) hipLaunchKernelGGL(avgpool_bwd_kernel<f16_t>, dim3(sgrid(items)), dim3(256), 0, s, (const f16_t*)dy, (f16_t*)dx, HW, C, items);
     else                      hipLaunchKernelGGL(avgpool_bwd_kernel<float>, dim3(sgrid(items)), dim3(256), 0, s, (const float*)dy, (float*)dx, HW, C, items);
     EVE_CHECK_LAUNCH();
     return 0;
@@ -434,10 +438,11 @@ extern "C" int eve_adaptive_maxpool_fwd(int dtype, int N, int IH, int IW, int OH
     if (int e = chk(dtype, C, "adaptive_maxpool_fwd: bad dtype / C")) return e;
     if (N <= 0 || IH <= 0 || IW <= 0 || OH <= 0 || OW <= 0 || OH > IH || OW > IW || !x || !y || !idx)
         return set_error_msg("adaptive_maxpool_fwd: bad arguments");
-    const int vec = dtype == EVE_DT_BF16 ? 8 : 4;
+    const int vec = dtype != EVE_DT_F32 ? 8 : 4;
     const long long items = (long long)N * OH * OW * (C / vec);
     hipStream_t s = (hipStream_t)stream;
     if (dtype == EVE_DT_BF16) hipLaunchKernelGGL(adapool_fwd_kernel<bf16_t>, dim3(sgrid(items)), dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)y, idx, IH, IW, OH, OW, C, items);
+    else if (dtype == EVE_DT_F16) hipLaunchKernelGGL(adapool_fwd_kernel<f16_t>, dim3(sgrid(items)), dim3(256), 0, s, (const f16_t*)x, (f16_t*)y, idx, IH, IW, OH, OW, C, items);
     else                      hipLaunchKernelGGL(adapool_fwd_kernel<float>, dim3(sgrid(items)), dim3(256), 0, s, (const float*)x, (float*)y, idx, IH, IW, OH, OW, C, items);
     EVE_CHECK_LAUNCH();
     return 0;
@@ -447,10 +452,11 @@ extern "C" int eve_adaptive_maxpool_bwd(int dtype, int N, int IH, int IW, int OH
     if (int e = chk(dtype, C, "adaptive_maxpool_bwd: bad dtype / C")) return e;
     if (N <= 0 || IH <= 0 || IW <= 0 || OH <= 0 || OW <= 0 || OH > IH || OW > IW || !dy || !dx || !idx)
         return set_error_msg("adaptive_maxpool_bwd: bad arguments");
-    const int vec = dtype == EVE_DT_BF16 ? 8 : 4;
+    const int vec = dtype != EVE_DT_F32 ? 8 : 4;
     const long long items = (long long)N * IH * IW * (C / vec);
     hipStream_t s = (hipStream_t)stream;
     if (dtype == EVE_DT_BF16) hipLaunchKernelGGL(adapool_bwd_kernel<bf16_t>, dim3(sgrid(items)), dim3(256), 0, s, (const bf16_t*)dy, idx, (bf16_t*)dx, IH, IW, OH, OW, C, items);
+    else if (dtype == EVE_DT_F16) hipLaunchKernelGGL(adapool_bwd_kernel<f16_t>, dim3(sgrid(items)), dim3(256), 0, s, (const f16_t*)dy, idx, (f16_t*)dx, IH, IW, OH, OW, C, items);
     else                      hipLaunchKernelGGL(adapool_bwd_kernel<float>, dim3(sgrid(items)), dim3(256), 0, s, (const float*)dy, idx, (float*)dx, IH, IW, OH, OW, C, items);
     EVE_CHECK_LAUNCH();
     return 0;
@@ -459,10 +465,11 @@ extern "C" int eve_bilinear_fwd(int dtype, int N, int IH, int IW, int OH, int OW
                                 eve_stream_t stream) {
     if (int e = chk(dtype, C, "bilinear_fwd: bad dtype / C")) return e;
     if (N <= 0 || IH <= 0 || IW <= 0 || OH <= 0 || OW <= 0 || !x || !y) return set_error_msg("bilinear_fwd: bad arguments");
-    const int vec = dtype == EVE_DT_BF16 ? 8 : 4;
+    const int vec = dtype != EVE_DT_F32 ? 8 : 4;
     const long long items = (long long)N * OH * OW * (C / vec);
     hipStream_t s = (hipStream_t)stream;
     if (dtype == EVE_DT_BF16) hipLaunchKernelGGL(bilinear_fwd_kernel<bf16_t>, dim3(sgrid(items)), dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)y, IH, IW, OH, OW, C, items);
+    else if (dtype == EVE_DT_F16) hipLaunchKernelGGL(bilinear_fwd_kernel<f16_t>, dim3(sgrid(items)), dim3(256), 0, s, (const f16_t*)x, (f16_t*)y, IH, IW, OH, OW, C, items);
     else                      hipLaunchKernelGGL(bilinear_fwd_kernel<float>, dim3(sgrid(items)), dim3(256), 0, s, (const float*)x, (float*)y, IH, IW, OH, OW, C, items);
     EVE_CHECK_LAUNCH();
     return 0;
@@ -471,10 +478,11 @@ extern "C" int eve_bilinear_bwd(int dtype, int N, int IH, int IW, int OH, int OW
                                 eve_stream_t stream) {
     if (int e = chk(dtype, C, "bilinear_bwd: bad dtype / C")) return e;
     if (N <= 0 || IH <= 0 || IW <= 0 || OH <= 0 || OW <= 0 || !dy || !dx) return set_error_msg("bilinear_bwd: bad arguments");
-    const int vec = dtype == EVE_DT_BF16 ? 8 : 4;
+    const int vec = dtype != EVE_DT_F32 ? 8 : 4;
     const long long items = (long long)N * IH * IW * (C / vec);
     hipStream_t s = (hipStream_t)stream;
     if (dtype == EVE_DT_BF16) hipLaunchKernelGGL(bilinear_bwd_kernel<bf16_t>, dim3(sgrid(items)), dim3(256), 0, s, (const bf16_t*)dy, (bf16_t*)dx, IH, IW, OH, OW, C, items);
+    else if (dtype == EVE_DT_F16) hipLaunchKernelGGL(bilinear_bwd_kernel<f16_t>, dim3(sgrid(items)), dim3(256), 0, s, (const f16_t*)dy, (f16_t*)dx, IH, IW, OH, OW, C, items);
     else                      hipLaunchKernelGGL(bilinear_bwd_kernel<float>, dim3(sgrid(items)), dim3(256), 0, s, (const float*)dy, (float*)dx, IH, IW, OH, OW, C, items);
     EVE_CHECK_LAUNCH();
     return 0;
@@ -483,21 +491,23 @@ extern "C" int eve_nchw_to_nhwc(int dtype_dst, int N, int C, int H, int W, int C
                                 void* dst_nhwc, eve_stream_t stream) {
     if (int e = chk(dtype_dst, Cpad, "nchw_to_nhwc: bad dtype / Cpad")) return e;
     if (N <= 0 || C <= 0 || C > Cpad || H <= 0 || W <= 0 || !src_nchw || !dst_nhwc) return set_error_msg("nchw_to_nhwc: bad arguments");
-    const int vec = dtype_dst == EVE_DT_BF16 ? 8 : 4;
+    const int vec = dtype_dst != EVE_DT_F32 ? 8 : 4;
     const long long items = (long long)N * H * W * (Cpad / vec);
     hipStream_t s = (hipStream_t)stream;
     if (dtype_dst == EVE_DT_BF16) hipLaunchKernelGGL(nchw_to_nhwc_kernel<bf16_t>, dim3(sgrid(items)), dim3(256), 0, s, src_nchw, (bf16_t*)dst_nhwc, C, H * W, Cpad, items);
+    else if (dtype_dst == EVE_DT_F16) hipLaunchKernelGGL(nchw_to_nhwc_kernel<f16_t>, dim3(sgrid(items)), dim3(256), 0, s, src_nchw, (f16_t*)dst_nhwc, C, H * W, Cpad, items);
     else                          hipLaunchKernelGGL(nchw_to_nhwc_kernel<float>, dim3(sgrid(items)), dim3(256), 0, s, src_nchw, (float*)dst_nhwc, C, H * W, Cpad, items);
     EVE_CHECK_LAUNCH();
     return 0;
 }
 extern "C" int eve_nhwc_to_nchw(int dtype_src, int N, int C, int H, int W, int Cpad, const void* src_nhwc,
                                 float* dst_nchw, eve_stream_t stream) {
-    if (dtype_src != EVE_DT_F32 && dtype_src != EVE_DT_BF16) return set_error_msg("nhwc_to_nchw: bad dtype");
+    if ((unsigned)dtype_src > (unsigned)EVE_DT_F16) return set_error_msg("nhwc_to_nchw: bad dtype");
     if (N <= 0 || C <= 0 || C > Cpad || H <= 0 || W <= 0 || !src_nhwc || !dst_nchw) return set_error_msg("nhwc_to_nchw: bad arguments");
     const long long items = (long long)N * C * H * W;
     hipStream_t s = (hipStream_t)stream;
     if (dtype_src == EVE_DT_BF16) hipLaunchKernelGGL(nhwc_to_nchw_kernel<bf16_t>, dim3(sgrid(items)), dim3(256), 0, s, (const bf16_t*)src_nhwc, dst_nchw, C, H * W, Cpad, items);
+    else if (dtype_src == EVE_DT_F16) hipLaunchKernelGGL(nhwc_to_nchw_kernel<f16_t>, dim3(sgrid(items)), dim3(256), 0, s, (const f16_t*)src_nhwc, dst_nchw, C, H * W, Cpad, items);
     else                          hipLaunchKernelGGL(nhwc_to_nchw_kernel<float>, dim3(sgrid(items)), dim3(256), 0, s, (const float*)src_nhwc, dst_nchw, C, H * W, Cpad, items);
     EVE_CHECK_LAUNCH();
     return 0;
@@ -506,16 +516,22 @@ extern "C" int eve_cast(int dtype_src, int dtype_dst, long long n, const void* s
     if (n <= 0 || !src || !dst) return set_error_msg("cast: bad arguments");
     hipStream_t s = (hipStream_t)stream;
     const unsigned g = sgrid(n);
-    if (dtype_src == EVE_DT_F32 && dtype_dst == EVE_DT_BF16) hipLaunchKernelGGL((cast_kernel<float, bf16_t>), dim3(g), dim3(256), 0, s, (const float*)src, (bf16_t*)dst, n);
-    else if (dtype_src == EVE_DT_BF16 && dtype_dst == EVE_DT_F32) hipLaunchKernelGGL((cast_kernel<bf16_t, float>), dim3(g), dim3(256), 0, s, (const bf16_t*)src, (float*)dst, n);
-    else if (dtype_src == EVE_DT_F32 && dtype_dst == EVE_DT_F32) hipLaunchKernelGGL((cast_kernel<float, float>), dim3(g), dim3(256), 0, s, (const float*)src, (float*)dst, n);
-    else if (dtype_src == EVE_DT_BF16 && dtype_dst == EVE_DT_BF16) hipLaunchKernelGGL((cast_kernel<bf16_t, bf16_t>), dim3(g), dim3(256), 0, s, (const bf16_t*)src, (bf16_t*)dst, n);
-    else return set_error_msg("cast: bad dtype");
+#define EVE_CAST_CASE(DS, TS, DD, TD) \
+    if (dtype_src == DS && dtype_dst == DD) hipLaunchKernelGGL((cast_kernel<TS, TD>), dim3(g), dim3(256), 0, s, (const TS*)src, (TD*)dst, n); else
+    EVE_CAST_CASE(EVE_DT_F32, float, EVE_DT_BF16, bf16_t)
+    EVE_CAST_CASE(EVE_DT_BF16, bf16_t, EVE_DT_F32, float)
+    EVE_CAST_CASE(EVE_DT_F32, float, EVE_DT_F16, f16_t)
+    EVE_CAST_CASE(EVE_DT_F16, f16_t, EVE_DT_F32, float)
+    EVE_CAST_CASE(EVE_DT_F32, float, EVE_DT_F32, float)
+    EVE_CAST_CASE(EVE_DT_BF16, bf16_t, EVE_DT_BF16, bf16_t)
+    EVE_CAST_CASE(EVE_DT_F16, f16_t, EVE_DT_F16, f16_t)
+#undef EVE_CAST_CASE
+    return set_error_msg("cast: bad dtype");
     EVE_CHECK_LAUNCH();
     return 0;
 }
 extern "C" int eve_pack_weights_batch(int dtype_dst, int count, const eve_pack_item* items, eve_stream_t stream) {
-    if (dtype_dst != EVE_DT_F32 && dtype_dst != EVE_DT_BF16) return set_error_msg("pack_weights_batch: bad dtype");
+    if ((unsigned)dtype_dst > (unsigned)EVE_DT_F16) return set_error_msg("pack_weights_batch: bad dtype");
     if (count <= 0 || count > EVE_PACK_BATCH_MAX || !items) return set_error_msg("pack_weights_batch: 1..EVE_PACK_BATCH_MAX items");
     PackTable tb;
     long long total = 0;
@@ -530,17 +546,19 @@ extern "C" int eve_pack_weights_batch(int dtype_dst, int count, const eve_pack_i
     hipStream_t s = (hipStream_t)stream;
     const unsigned blocks = (unsigned)(total < 4096 ? total : 4096);
     if (dtype_dst == EVE_DT_BF16) hipLaunchKernelGGL(pack_weights_batch_kernel<bf16_t>, dim3(blocks), dim3(256), 0, s, tb);
+    else if (dtype_dst == EVE_DT_F16) hipLaunchKernelGGL(pack_weights_batch_kernel<f16_t>, dim3(blocks), dim3(256), 0, s, tb);
     else                          hipLaunchKernelGGL(pack_weights_batch_kernel<float>, dim3(blocks), dim3(256), 0, s, tb);
     EVE_CHECK_LAUNCH();
     return 0;
 }
 extern "C" int eve_pack_weights(int dtype_dst, int Cout, int taps, int Cin, const float* w_ohwi, void* dst_ohwi,
                                 void* dst_ihwo, eve_stream_t stream) {
-    if (dtype_dst != EVE_DT_F32 && dtype_dst != EVE_DT_BF16) return set_error_msg("pack_weights: bad dtype");
+    if ((unsigned)dtype_dst > (unsigned)EVE_DT_F16) return set_error_msg("pack_weights: bad dtype");
     if (Cout <= 0 || taps <= 0 || Cin <= 0 || !w_ohwi || (!dst_ohwi && !dst_ihwo)) return set_error_msg("pack_weights: bad arguments");
     const long long n = (long long)Cout * taps * Cin;
     hipStream_t s = (hipStream_t)stream;
     if (dtype_dst == EVE_DT_BF16) hipLaunchKernelGGL(pack_weights_kernel<bf16_t>, dim3(sgrid(n)), dim3(256), 0, s, w_ohwi, (bf16_t*)dst_ohwi, (bf16_t*)dst_ihwo, Cout, taps, Cin, n);
+    else if (dtype_dst == EVE_DT_F16) hipLaunchKernelGGL(pack_weights_kernel<f16_t>, dim3(sgrid(n)), dim3(256), 0, s, w_ohwi, (f16_t*)dst_ohwi, (f16_t*)dst_ihwo, Cout, taps, Cin, n);
     else                          hipLaunchKernelGGL(pack_weights_kernel<float>, dim3(sgrid(n)), dim3(256), 0, s, w_ohwi, (float*)dst_ohwi, (float*)dst_ihwo, Cout, taps, Cin, n);
     EVE_CHECK_LAUNCH();
     return 0;

@@ -510,8 +510,8 @@ extern "C" int eve_lstm_scan_bwd(int S, int T, int H, const float* dhs, const fl
 }
 
 #define CG_CHECK(who)                                                                     \
-    const int vec = dtype == EVE_DT_BF16 ? 8 : 4;                                         \
-    if ((dtype != EVE_DT_F32 && dtype != EVE_DT_BF16) || P <= 0 || C <= 0 || C % vec)    \
+    const int vec = dtype != EVE_DT_F32 ? 8 : 4;                                         \
+    if (((unsigned)dtype > (unsigned)EVE_DT_F16) || P <= 0 || C <= 0 || C % vec)    \
         return set_error_msg(who ": bad arguments");                                      \
     const long long items = P * (C / vec);                                                \
     hipStream_t s = (hipStream_t)stream;
@@ -520,6 +520,7 @@ extern "C" int eve_cgru_gates1(int dtype, long long P, int C, const void* g1, co
                                eve_stream_t stream) {
     CG_CHECK("cgru_gates1")
     if (dtype == EVE_DT_BF16) hipLaunchKernelGGL(cgru_gates1_kernel<bf16_t>, dim3(rgrid(items)), dim3(256), 0, s, (const bf16_t*)g1, (const bf16_t*)h, (bf16_t*)ru, (bf16_t*)rh, C, items);
+    else if (dtype == EVE_DT_F16) hipLaunchKernelGGL(cgru_gates1_kernel<f16_t>, dim3(rgrid(items)), dim3(256), 0, s, (const f16_t*)g1, (const f16_t*)h, (f16_t*)ru, (f16_t*)rh, C, items);
     else                      hipLaunchKernelGGL(cgru_gates1_kernel<float>, dim3(rgrid(items)), dim3(256), 0, s, (const float*)g1, (const float*)h, (float*)ru, (float*)rh, C, items);
     EVE_CHECK_LAUNCH();
     return 0;
@@ -528,6 +529,7 @@ extern "C" int eve_cgru_gates2(int dtype, long long P, int C, const void* g2, co
                                void* hnew, eve_stream_t stream) {
     CG_CHECK("cgru_gates2")
     if (dtype == EVE_DT_BF16) hipLaunchKernelGGL(cgru_gates2_kernel<bf16_t>, dim3(rgrid(items)), dim3(256), 0, s, (const bf16_t*)g2, (const bf16_t*)ru, (const bf16_t*)h, (bf16_t*)o, (bf16_t*)hnew, C, items);
+    else if (dtype == EVE_DT_F16) hipLaunchKernelGGL(cgru_gates2_kernel<f16_t>, dim3(rgrid(items)), dim3(256), 0, s, (const f16_t*)g2, (const f16_t*)ru, (const f16_t*)h, (f16_t*)o, (f16_t*)hnew, C, items);
     else                      hipLaunchKernelGGL(cgru_gates2_kernel<float>, dim3(rgrid(items)), dim3(256), 0, s, (const float*)g2, (const float*)ru, (const float*)h, (float*)o, (float*)hnew, C, items);
     EVE_CHECK_LAUNCH();
     return 0;
@@ -536,6 +538,7 @@ extern "C" int eve_cgru_gates2_bwd(int dtype, long long P, int C, const void* dh
                                    const void* o, void* dg2, void* du, void* dh, eve_stream_t stream) {
     CG_CHECK("cgru_gates2_bwd")
     if (dtype == EVE_DT_BF16) hipLaunchKernelGGL(cgru_gates2_bwd_kernel<bf16_t>, dim3(rgrid(items)), dim3(256), 0, s, (const bf16_t*)dhnew, (const bf16_t*)ru, (const bf16_t*)h, (const bf16_t*)o, (bf16_t*)dg2, (bf16_t*)du, (bf16_t*)dh, C, items);
+    else if (dtype == EVE_DT_F16) hipLaunchKernelGGL(cgru_gates2_bwd_kernel<f16_t>, dim3(rgrid(items)), dim3(256), 0, s, (const f16_t*)dhnew, (const f16_t*)ru, (const f16_t*)h, (const f16_t*)o, (f16_t*)dg2, (f16_t*)du, (f16_t*)dh, C, items);
     else                      hipLaunchKernelGGL(cgru_gates2_bwd_kernel<float>, dim3(rgrid(items)), dim3(256), 0, s, (const float*)dhnew, (const float*)ru, (const float*)h, (const float*)o, (float*)dg2, (float*)du, (float*)dh, C, items);
     EVE_CHECK_LAUNCH();
     return 0;
@@ -544,6 +547,7 @@ extern "C" int eve_cgru_gates1_bwd(int dtype, long long P, int C, const void* dr
                                    const void* h, void* dg1, void* dh_accum, eve_stream_t stream) {
     CG_CHECK("cgru_gates1_bwd")
     if (dtype == EVE_DT_BF16) hipLaunchKernelGGL(cgru_gates1_bwd_kernel<bf16_t>, dim3(rgrid(items)), dim3(256), 0, s, (const bf16_t*)drh, (const bf16_t*)du, (const bf16_t*)ru, (const bf16_t*)h, (bf16_t*)dg1, (bf16_t*)dh_accum, C, items);
+    else if (dtype == EVE_DT_F16) hipLaunchKernelGGL(cgru_gates1_bwd_kernel<f16_t>, dim3(rgrid(items)), dim3(256), 0, s, (const f16_t*)drh, (const f16_t*)du, (const f16_t*)ru, (const f16_t*)h, (f16_t*)dg1, (f16_t*)dh_accum, C, items);
     else                      hipLaunchKernelGGL(cgru_gates1_bwd_kernel<float>, dim3(rgrid(items)), dim3(256), 0, s, (const float*)drh, (const float*)du, (const float*)ru, (const float*)h, (float*)dg1, (float*)dh_accum, C, items);
     EVE_CHECK_LAUNCH();
     return 0;
@@ -553,6 +557,7 @@ extern "C" int eve_clstm_gates_fwd(int dtype, long long P, int C, const void* ga
                                    void* c, eve_stream_t stream) {
     CG_CHECK("clstm_gates_fwd")
     if (dtype == EVE_DT_BF16) hipLaunchKernelGGL(clstm_gates_kernel<bf16_t>, dim3(rgrid(items)), dim3(256), 0, s, (const bf16_t*)gates, (const bf16_t*)c_prev, (bf16_t*)h, (bf16_t*)c, C, items);
+    else if (dtype == EVE_DT_F16) hipLaunchKernelGGL(clstm_gates_kernel<f16_t>, dim3(rgrid(items)), dim3(256), 0, s, (const f16_t*)gates, (const f16_t*)c_prev, (f16_t*)h, (f16_t*)c, C, items);
     else                      hipLaunchKernelGGL(clstm_gates_kernel<float>, dim3(rgrid(items)), dim3(256), 0, s, (const float*)gates, (const float*)c_prev, (float*)h, (float*)c, C, items);
     EVE_CHECK_LAUNCH();
     return 0;

@@ -14,14 +14,8 @@
 
 namespace eve {
 
-struct Mma16 {
-    __device__ static __forceinline__ void run(f32x4_t& acc, const uint4& a, const uint4& b) {
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b),
-                                                      acc, 0, 0, 0);
-    }
-};
-
 // dst[n][y+3][x+4][c] = c < C ? src[n][c][y][x] : 0, borders zero (dst is fully written)
+template <typename H>
 __global__ __launch_bounds__(256) void stem_pack_kernel(const float* __restrict__ src, uint2* __restrict__ dst, int C,
                                                         int IH, int IW, long long items) {
     const int IHp = IH + 6, IWp = IW + 8;
@@ -35,8 +29,8 @@ __global__ __launch_bounds__(256) void stem_pack_kernel(const float* __restrict_
         if (x >= 0 && x < IW && y >= 0 && y < IH) {
             float f[4] = {0.f, 0.f, 0.f, 0.f};
             for (int c = 0; c < C && c < 4; ++c) f[c] = src[((n * C + c) * IH + y) * IW + x];
-            q.x = pack2_bf16(f[0], f[1]);
-            q.y = pack2_bf16(f[2], f[3]);
+            q.x = Elem<H>::pack2(f[0], f[1]);
+            q.y = Elem<H>::pack2(f[2], f[3]);
         }
         dst[i] = q;
     }
@@ -45,6 +39,7 @@ __global__ __launch_bounds__(256) void stem_pack_kernel(const float* __restrict_
 // the same, four pixels of a row per thread (IW % 4 == 0: a group of four is inside the image or in the border as a
 // whole): 16-byte loads from each channel plane, 32 bytes stored -- the one-pixel version moved 20 bytes per thread
 // and ran at half the rate of its HBM traffic
+template <typename H>
 __global__ __launch_bounds__(256) void stem_pack4_kernel(const float* __restrict__ src, uint4* __restrict__ dst, int C,
                                                          int IH, int IW, long long groups) {
     const int IHp = IH + 6, GW = (IW + 8) / 4;
@@ -60,17 +55,18 @@ __global__ __launch_bounds__(256) void stem_pack4_kernel(const float* __restrict
 #pragma unroll
             for (int c = 0; c < 4; ++c)
                 f[c] = c < C ? *reinterpret_cast<const float4*>(src + ((n * C + c) * IH + y) * IW + x) : make_float4(0.f, 0.f, 0.f, 0.f);
-            lo = make_uint4(pack2_bf16(f[0].x, f[1].x), pack2_bf16(f[2].x, f[3].x), pack2_bf16(f[0].y, f[1].y), pack2_bf16(f[2].y, f[3].y));
-            hi = make_uint4(pack2_bf16(f[0].z, f[1].z), pack2_bf16(f[2].z, f[3].z), pack2_bf16(f[0].w, f[1].w), pack2_bf16(f[2].w, f[3].w));
+            lo = make_uint4(Elem<H>::pack2(f[0].x, f[1].x), Elem<H>::pack2(f[2].x, f[3].x), Elem<H>::pack2(f[0].y, f[1].y), Elem<H>::pack2(f[2].y, f[3].y));
+            hi = make_uint4(Elem<H>::pack2(f[0].z, f[1].z), Elem<H>::pack2(f[2].z, f[3].z), Elem<H>::pack2(f[0].w, f[1].w), Elem<H>::pack2(f[2].w, f[3].w));
         }
         dst[2 * i] = lo;
         dst[2 * i + 1] = hi;
     }
 }
 
+template <typename H>
 __global__ __launch_bounds__(256) void stem7x7_kernel(const int N, const int IH, const int IW,
-                                                      const uint2* __restrict__ xp, const bf16_t* __restrict__ w8,
-                                                      bf16_t* __restrict__ y, const uint32_t ntiles) {
+                                                      const uint2* __restrict__ xp, const H* __restrict__ w8,
+                                                      H* __restrict__ y, const uint32_t ntiles) {
     __shared__ uint4 sW[7 * 256];                              // 7 filter rows x (64 output channels x 64 B)
     const int tid = threadIdx.x;
     // ---- filter bank: w8 is [64][7][7][8] (Cin padded to 8); LDS row = 2 output channels x 64 B, slot ^= row & 7 ----
@@ -124,16 +120,16 @@ __global__ __launch_bounds__(256) void stem7x7_kernel(const int N, const int IH,
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-                for (int nt = 0; nt < 4; ++nt) Mma16::run(acc[mt][nt], fw[nt], fx[kh][mt]);
+                for (int nt = 0; nt < 4; ++nt) Elem<H>::mfma(acc[mt][nt], fw[nt], fx[kh][mt]);
         }
-        bf16_t* orow = y + (((size_t)n * OH + oy) * OW + xb * 64) * 64;
+        H* orow = y + (((size_t)n * OH + oy) * OW + xb * 64) * 64;
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) {
                 uint2 pk;
-                pk.x = pack2_bf16(acc[mt][nt][0], acc[mt][nt][1]);
-                pk.y = pack2_bf16(acc[mt][nt][2], acc[mt][nt][3]);
+                pk.x = Elem<H>::pack2(acc[mt][nt][0], acc[mt][nt][1]);
+                pk.y = Elem<H>::pack2(acc[mt][nt][2], acc[mt][nt][3]);
                 *reinterpret_cast<uint2*>(orow + (mt * 16 + li) * 64 + nt * 16 + lg * 4) = pk;
             }
     }
@@ -143,8 +139,8 @@ __global__ __launch_bounds__(256) void stem7x7_kernel(const int N, const int IH,
 
 using namespace eve;
 
-extern "C" int eve_stem_pack_input(int N, int C, int IH, int IW, const float* src_nchw, void* dst, eve_stream_t stream) {
-    if (N <= 0 || C <= 0 || C > 4 || IH <= 0 || IW <= 0 || !src_nchw || !dst) return set_error_msg("stem_pack_input: bad arguments");
+extern "C" int eve_stem_pack_input(int dtype, int N, int C, int IH, int IW, const float* src_nchw, void* dst, eve_stream_t stream) {
+    if ((dtype != EVE_DT_BF16 && dtype != EVE_DT_F16) || N <= 0 || C <= 0 || C > 4 || IH <= 0 || IW <= 0 || !src_nchw || !dst) return set_error_msg("stem_pack_input: bad arguments");
     const long long items = (long long)N * (IH + 6) * (IW + 8);
     long long blocks = (items + 255) / 256;
     if (blocks > 4096) blocks = 4096;
@@ -152,25 +148,24 @@ extern "C" int eve_stem_pack_input(int N, int C, int IH, int IW, const float* sr
         const long long groups = items / 4;
         long long gb = (groups + 255) / 256;
         if (gb > 8192) gb = 8192;
-        hipLaunchKernelGGL(stem_pack4_kernel, dim3((unsigned)gb), dim3(256), 0, (hipStream_t)stream, src_nchw, (uint4*)dst, C, IH, IW, groups);
+        EVE_DISPATCH_H16(dtype, hipLaunchKernelGGL(stem_pack4_kernel<H>, dim3((unsigned)gb), dim3(256), 0, (hipStream_t)stream, src_nchw, (uint4*)dst, C, IH, IW, groups));
     } else {
-        hipLaunchKernelGGL(stem_pack_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, src_nchw, (uint2*)dst, C, IH, IW, items);
+        EVE_DISPATCH_H16(dtype, hipLaunchKernelGGL(stem_pack_kernel<H>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, src_nchw, (uint2*)dst, C, IH, IW, items));
     }
     EVE_CHECK_LAUNCH();
     return 0;
 }
 
-extern "C" int eve_stem7x7s2_fwd(int N, int IH, int IW, const void* x_padded, const void* w_ohwi8, void* y,
+extern "C" int eve_stem7x7s2_fwd(int dtype, int N, int IH, int IW, const void* x_padded, const void* w_ohwi8, void* y,
                                  eve_stream_t stream) {
-    if (N <= 0 || IH <= 0 || IW <= 0 || (IH & 1) || (IW % 128) || !x_padded || !w_ohwi8 || !y)
+    if ((dtype != EVE_DT_BF16 && dtype != EVE_DT_F16) || N <= 0 || IH <= 0 || IW <= 0 || (IH & 1) || (IW % 128) || !x_padded || !w_ohwi8 || !y)
         return set_error_msg("stem7x7s2_fwd: needs even IH and IW a multiple of 128");
     const unsigned long long tiles = (unsigned long long)N * (IH / 2) * (IW / 128);
     if (tiles >= (1ull << 32)) return set_error_msg("stem7x7s2_fwd: too many tiles");
     unsigned blocks = 512;
     if ((tiles + 3) / 4 < blocks) blocks = (unsigned)((tiles + 3) / 4);
-    EVE_MARK_KERNEL("stem7x7_kernel");
-    hipLaunchKernelGGL(stem7x7_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, N, IH, IW, (const uint2*)x_padded,
-                       (const bf16_t*)w_ohwi8, (bf16_t*)y, (uint32_t)tiles);
+    EVE_DISPATCH_H16(dtype, EVE_LAUNCH(EVE_HNAME(H, "stem7x7_kernel<", ">"), stem7x7_kernel<H>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, N, IH, IW,
+                                       (const uint2*)x_padded, (const H*)w_ohwi8, (H*)y, (uint32_t)tiles));
     EVE_CHECK_LAUNCH();
     return 0;
 }
@@ -202,6 +197,7 @@ __global__ __launch_bounds__(256) void frames_u8_to_nchw_kernel(const uint8_t* _
     }
 }
 
+template <typename H>
 __global__ __launch_bounds__(256) void frames_u8_to_stem_kernel(const uint8_t* __restrict__ src, uint2* __restrict__ dst, int C, int IH,
                                                                 int IW, float scale, float shift, long long items) {
     const int IHp = IH + 6, IWp = IW + 8;
@@ -216,8 +212,8 @@ __global__ __launch_bounds__(256) void frames_u8_to_stem_kernel(const uint8_t* _
             float f[4] = {0.f, 0.f, 0.f, 0.f};
             const uint8_t* p = src + ((n * IH + y) * IW + x) * C;
             for (int c = 0; c < C && c < 4; ++c) f[c] = normalise_u8(p[c], scale, shift, true);
-            q.x = pack2_bf16(f[0], f[1]);
-            q.y = pack2_bf16(f[2], f[3]);
+            q.x = Elem<H>::pack2(f[0], f[1]);
+            q.y = Elem<H>::pack2(f[2], f[3]);
         }
         dst[i] = q;
     }
@@ -235,14 +231,14 @@ extern "C" int eve_frames_u8_to_nchw(long long N, int H, int W, int C, const uin
     return 0;
 }
 
-extern "C" int eve_frames_u8_to_stem(long long N, int C, int IH, int IW, const uint8_t* src_nhwc, float scale, float shift,
+extern "C" int eve_frames_u8_to_stem(int dtype, long long N, int C, int IH, int IW, const uint8_t* src_nhwc, float scale, float shift,
                                      void* x_padded, eve_stream_t stream) {
-    if (N <= 0 || C <= 0 || C > 4 || IH <= 0 || IW <= 0 || !src_nhwc || !x_padded) return set_error_msg("frames_u8_to_stem: bad arguments");
+    if ((dtype != EVE_DT_BF16 && dtype != EVE_DT_F16) || N <= 0 || C <= 0 || C > 4 || IH <= 0 || IW <= 0 || !src_nhwc || !x_padded) return set_error_msg("frames_u8_to_stem: bad arguments");
     const long long items = N * (IH + 6) * (IW + 8);
     long long blocks = (items + 255) / 256;
     if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL(frames_u8_to_stem_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, src_nhwc, (uint2*)x_padded, C,
-                       IH, IW, scale, shift, items);
+    EVE_DISPATCH_H16(dtype, hipLaunchKernelGGL(frames_u8_to_stem_kernel<H>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, src_nhwc,
+                                               (uint2*)x_padded, C, IH, IW, scale, shift, items));
     EVE_CHECK_LAUNCH();
     return 0;
 }

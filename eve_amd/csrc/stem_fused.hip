@@ -38,8 +38,8 @@ __device__ __forceinline__ void sf_dma4(const eve_int4& rsrc, uint32_t lds, int 
                  :: "s"(lds), "v"(voff), "s"(rsrc), "s"(soff) : "memory", "m0");
 }
 typedef uint32_t sf_u32x4_t __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ bf16x8_t sf_lds_read(uint32_t addr) {
-    return __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const EVE_LDS sf_u32x4_t*>((uintptr_t)addr));
+__device__ __forceinline__ uint4 sf_lds_read(uint32_t addr) {
+    return __builtin_bit_cast(uint4, *reinterpret_cast<const EVE_LDS sf_u32x4_t*>((uintptr_t)addr));
 }
 template <int CTRL>
 __device__ __forceinline__ uint32_t sf_dpp(uint32_t old, uint32_t src) {
@@ -58,7 +58,8 @@ __device__ __forceinline__ float sf_fmax3(float a, float b, float c) { return fm
 // channel co = g*16 + nt*4 + r, so that an MFMA lane (rows 4g..4g+3 of tiles nt = 0..3) owns the 16 CONSECUTIVE
 // channels g*16 .. g*16+15 of its pixel: 32-byte stores instead of four 8-byte ones.  64-byte rows, chunk-swizzled
 // like the halo kernel (conflict-free ds_read_b128).
-__device__ __forceinline__ void sf_fill_weights(char* sW, const bf16_t* __restrict__ w8, int tid, int nthreads) {
+template <typename H>
+__device__ __forceinline__ void sf_fill_weights(char* sW, const H* __restrict__ w8, int tid, int nthreads) {
     for (int e = tid; e < 64 * 7 * 8; e += nthreads) {
         const int kw = e & 7, kh = (e >> 3) % 7, co = e / 56;
         uint2 v = make_uint2(0u, 0u);
@@ -71,13 +72,13 @@ __device__ __forceinline__ void sf_fill_weights(char* sW, const bf16_t* __restri
 
 // One output row of the convolution for the wave's image: acc[mt][nt] (mt = 2j + b holds output column
 // 2*(li + 16j) + b, so a lane owns the even/odd column pair of pooled column q = li + 16j).
-template <bool FIRST>
+template <typename H, bool FIRST>
 __device__ __forceinline__ void sf_conv_tap_row(f32x4_t (&acc)[4][4], uint32_t ring, int slot0, uint32_t xoff,
                                                 uint32_t wbase, int kh) {
     int slot = slot0 + kh;
     slot = slot >= SF_RING ? slot - SF_RING : slot;
     const uint32_t xa = ring + slot * SF_ROWB + xoff, wa = wbase + kh * 4096;
-    bf16x8_t fx[4], fw[4];
+    uint4 fx[4], fw[4];
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) fx[mt] = sf_lds_read(xa + (mt & 1) * 16 + (mt >> 1) * 512);
 #pragma unroll
@@ -87,19 +88,22 @@ __device__ __forceinline__ void sf_conv_tap_row(f32x4_t (&acc)[4][4], uint32_t r
     for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt)
-            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[nt], fx[mt], FIRST ? zero : acc[mt][nt], 0, 0, 0);
+        {
+            if (FIRST) acc[mt][nt] = zero;
+            Elem<H>::mfma(acc[mt][nt], fw[nt], fx[mt]);
+        }
 }
 // COMPACT keeps the filter-row loop rolled (one set of fragment registers) for the register-hungry backward
-template <bool COMPACT>
+template <typename H, bool COMPACT>
 __device__ __forceinline__ void sf_conv_row(f32x4_t (&acc)[4][4], uint32_t ring, int slot0, uint32_t xoff,
                                             uint32_t wbase) {
-    sf_conv_tap_row<true>(acc, ring, slot0, xoff, wbase, 0);
+    sf_conv_tap_row<H, true>(acc, ring, slot0, xoff, wbase, 0);
     if (COMPACT) {
 #pragma unroll 1
-        for (int kh = 1; kh < 7; ++kh) sf_conv_tap_row<false>(acc, ring, slot0, xoff, wbase, kh);
+        for (int kh = 1; kh < 7; ++kh) sf_conv_tap_row<H, false>(acc, ring, slot0, xoff, wbase, kh);
     } else {
 #pragma unroll
-        for (int kh = 1; kh < 7; ++kh) sf_conv_tap_row<false>(acc, ring, slot0, xoff, wbase, kh);
+        for (int kh = 1; kh < 7; ++kh) sf_conv_tap_row<H, false>(acc, ring, slot0, xoff, wbase, kh);
     }
 }
 
@@ -112,15 +116,16 @@ __device__ __forceinline__ void sf_stage_row(const eve_int4& rs, uint32_t ring, 
     sf_dma4(rs, ring + slot * SF_ROWB + 1024, live ? lane * 4 + 8 + 1024 : EVE_OOB, soff);
 }
 
+template <typename H>
 __global__ __launch_bounds__(64 * SF_WAVES) void stem_fwd_fused_kernel(const int N, const int IH,
-                                                                       const bf16_t* __restrict__ xp, const uint32_t xp_bytes,
-                                                                       const bf16_t* __restrict__ w8, const float eps,
-                                                                       bf16_t* yp, uint8_t* __restrict__ idx,
+                                                                       const H* __restrict__ xp, const uint32_t xp_bytes,
+                                                                       const H* __restrict__ w8, const float eps,
+                                                                       H* yp, uint8_t* __restrict__ idx,
                                                                        float* __restrict__ mr) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const sW = smem + SF_WAVES * SF_RING * SF_ROWB;
     const int tid = threadIdx.x;
-    sf_fill_weights(sW, w8, tid, 64 * SF_WAVES);
+    sf_fill_weights<H>(sW, w8, tid, 64 * SF_WAVES);
     __syncthreads();
 
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -143,7 +148,7 @@ __global__ __launch_bounds__(64 * SF_WAVES) void stem_fwd_fused_kernel(const int
         for (int a = 0; a < 4; ++a)
 #pragma unroll
             for (int b = 0; b < 4; ++b) { S[a][b] = 0.f; Q[a][b] = 0.f; M[0][a][b] = SF_NEG; M[1][a][b] = SF_NEG; }
-        bf16_t* yimg = yp + (size_t)n * PH * 32 * 64;
+        H* yimg = yp + (size_t)n * PH * 32 * 64;
         uint8_t* iimg = idx + (size_t)n * PH * 32 * 64;
         int slot0 = 0;
         for (int oy = 0; oy < OH; ++oy) {
@@ -153,7 +158,7 @@ __global__ __launch_bounds__(64 * SF_WAVES) void stem_fwd_fused_kernel(const int
             sf_stage_row(rs, ring, 2 * oy + 9, rows, img_off, lane);
             sf_stage_row(rs, ring, 2 * oy + 10, rows, img_off, lane);
             f32x4_t acc[4][4];
-            sf_conv_row<false>(acc, ring, slot0, xoff, wbase);
+            sf_conv_row<H, false>(acc, ring, slot0, xoff, wbase);
             slot0 = slot0 + 2 >= SF_RING ? slot0 + 2 - SF_RING : slot0 + 2;
             // ---- plane statistics ----
 #pragma unroll
@@ -211,8 +216,8 @@ __global__ __launch_bounds__(64 * SF_WAVES) void stem_fwd_fused_kernel(const int
                             val[r] = __builtin_bit_cast(float, k & 0xfffffff0u);
                             code[r] = (uint32_t)(0x01203450678ull >> ((k & 15u) * 4)) & 15u;       // kh*3 + kw
                         }
-                        pk[2 * nt] = pack2_bf16(val[0], val[1]);
-                        pk[2 * nt + 1] = pack2_bf16(val[2], val[3]);
+                        pk[2 * nt] = Elem<H>::pack2(val[0], val[1]);
+                        pk[2 * nt + 1] = Elem<H>::pack2(val[2], val[3]);
                         ib[nt] = code[0] | (code[1] << 8) | (code[2] << 16) | (code[3] << 24);
                     }
                     *reinterpret_cast<uint4*>(yimg + o) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
@@ -240,14 +245,14 @@ __global__ __launch_bounds__(64 * SF_WAVES) void stem_fwd_fused_kernel(const int
         for (int py = 0; py < PH; ++py)
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                bf16_t* p = yimg + ((size_t)py * 32 + li + 16 * j) * 64 + lg * 16;
+                H* p = yimg + ((size_t)py * 32 + li + 16 * j) * 64 + lg * 16;
                 float f[16];
-                Elem<bf16_t>::unpack(*reinterpret_cast<const uint4*>(p), f);
-                Elem<bf16_t>::unpack(*reinterpret_cast<const uint4*>(p + 8), f + 8);
+                Elem<H>::unpack(*reinterpret_cast<const uint4*>(p), f);
+                Elem<H>::unpack(*reinterpret_cast<const uint4*>(p + 8), f + 8);
 #pragma unroll
                 for (int c = 0; c < 16; ++c) f[c] = fmaxf((f[c] - mean[c >> 2][c & 3]) * rstd[c >> 2][c & 3], 0.f);
-                *reinterpret_cast<uint4*>(p) = Elem<bf16_t>::pack(f);
-                *reinterpret_cast<uint4*>(p + 8) = Elem<bf16_t>::pack(f + 8);
+                *reinterpret_cast<uint4*>(p) = Elem<H>::pack(f);
+                *reinterpret_cast<uint4*>(p + 8) = Elem<H>::pack(f + 8);
             }
     }
 }
@@ -268,12 +273,13 @@ struct SfPooledRow {               // one pooled row as the lane sees it: column
     uint32_t code[2][4];           // arg-max window positions, one byte per channel
 };
 
-__device__ __forceinline__ uint32_t sf_add_pairs(uint32_t a, uint32_t b) {      // two packed bf16 sums
-    return pack2_bf16(bf16_bits_to_f32(a & 0xffffu) + bf16_bits_to_f32(b & 0xffffu),
-                      __builtin_bit_cast(float, a & 0xffff0000u) + __builtin_bit_cast(float, b & 0xffff0000u));
+template <typename H>
+__device__ __forceinline__ uint32_t sf_add_pairs(uint32_t a, uint32_t b) {      // two packed 16-bit sums
+    return Elem<H>::pack2(Elem<H>::lo(a) + Elem<H>::lo(b), Elem<H>::hi(a) + Elem<H>::hi(b));
 }
-__device__ __forceinline__ void sf_load_pooled(SfPooledRow& P, const bf16_t* __restrict__ dyp, const bf16_t* __restrict__ dyp2,
-                                               const bf16_t* __restrict__ yp,
+template <typename H>
+__device__ __forceinline__ void sf_load_pooled(SfPooledRow& P, const H* __restrict__ dyp, const H* __restrict__ dyp2,
+                                               const H* __restrict__ yp,
                                                const uint8_t* __restrict__ idx, size_t row_base, int li, int lg, bool live) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -285,8 +291,8 @@ __device__ __forceinline__ void sf_load_pooled(SfPooledRow& P, const bf16_t* __r
             c = *reinterpret_cast<const uint4*>(idx + o);
             if (dyp2) {                                            // gradient delivered as two summands
                 const uint4 e0 = *reinterpret_cast<const uint4*>(dyp2 + o), e1 = *reinterpret_cast<const uint4*>(dyp2 + o + 8);
-                d0 = make_uint4(sf_add_pairs(d0.x, e0.x), sf_add_pairs(d0.y, e0.y), sf_add_pairs(d0.z, e0.z), sf_add_pairs(d0.w, e0.w));
-                d1 = make_uint4(sf_add_pairs(d1.x, e1.x), sf_add_pairs(d1.y, e1.y), sf_add_pairs(d1.z, e1.z), sf_add_pairs(d1.w, e1.w));
+                d0 = make_uint4(sf_add_pairs<H>(d0.x, e0.x), sf_add_pairs<H>(d0.y, e0.y), sf_add_pairs<H>(d0.z, e0.z), sf_add_pairs<H>(d0.w, e0.w));
+                d1 = make_uint4(sf_add_pairs<H>(d1.x, e1.x), sf_add_pairs<H>(d1.y, e1.y), sf_add_pairs<H>(d1.z, e1.z), sf_add_pairs<H>(d1.w, e1.w));
             }
         }
         const uint32_t dd[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
@@ -300,9 +306,10 @@ __device__ __forceinline__ void sf_load_pooled(SfPooledRow& P, const bf16_t* __r
     }
 }
 // d(pooled) of channel r (0..3) of a 4-channel chunk if the window's arg-max code equals K, else 0
+template <typename H>
 __device__ __forceinline__ float sf_pick(const uint32_t (&eg)[2], uint32_t code, int r, uint32_t K) {
     const uint32_t w = eg[r >> 1];
-    const float t = __builtin_bit_cast(float, (r & 1) ? (w & 0xffff0000u) : (w << 16));
+    const float t = (r & 1) ? Elem<H>::hi(w) : Elem<H>::lo(w);
     const int sh = 8 * r;
     return (code & (0xffu << sh)) == (K << sh) ? t : 0.f;
 }
@@ -320,16 +327,17 @@ __device__ __forceinline__ void sf_chunk(const SfPooledRow& P, int j, int nt, ui
     ncd = sf_dpp<0x101>(edge, cd);
 }
 
+template <typename H>
 __global__ __launch_bounds__(64 * SF_WAVES) void stem_bwd_dx_kernel(const int N, const int IH,
-                                                                    const bf16_t* __restrict__ xp, const uint32_t xp_bytes,
-                                                                    const bf16_t* __restrict__ w8, const float* __restrict__ mr,
-                                                                    const bf16_t* __restrict__ dyp, const bf16_t* __restrict__ dyp2,
-                                                                    const bf16_t* __restrict__ yp,
-                                                                    const uint8_t* __restrict__ idx, bf16_t* __restrict__ dx) {
+                                                                    const H* __restrict__ xp, const uint32_t xp_bytes,
+                                                                    const H* __restrict__ w8, const float* __restrict__ mr,
+                                                                    const H* __restrict__ dyp, const H* __restrict__ dyp2,
+                                                                    const H* __restrict__ yp,
+                                                                    const uint8_t* __restrict__ idx, H* __restrict__ dx) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const sW = smem + SF_WAVES * SF_RING * SF_ROWB;
     const int tid = threadIdx.x;
-    sf_fill_weights(sW, w8, tid, 64 * SF_WAVES);
+    sf_fill_weights<H>(sW, w8, tid, 64 * SF_WAVES);
     __syncthreads();
 
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -358,17 +366,17 @@ __global__ __launch_bounds__(64 * SF_WAVES) void stem_bwd_dx_kernel(const int N,
                 for (int j = 0; j < 2; ++j) {
                     const size_t o = (pool_base + (size_t)py * 32 + li + 16 * j) * 64 + lg * 16;
                     float d[16], y[16];
-                    Elem<bf16_t>::unpack(*reinterpret_cast<const uint4*>(dyp + o), d);
-                    Elem<bf16_t>::unpack(*reinterpret_cast<const uint4*>(dyp + o + 8), d + 8);
+                    Elem<H>::unpack(*reinterpret_cast<const uint4*>(dyp + o), d);
+                    Elem<H>::unpack(*reinterpret_cast<const uint4*>(dyp + o + 8), d + 8);
                     if (dyp2) {                                   // same rounding of the sum as sf_load_pooled
                         float d2[16];
-                        Elem<bf16_t>::unpack(*reinterpret_cast<const uint4*>(dyp2 + o), d2);
-                        Elem<bf16_t>::unpack(*reinterpret_cast<const uint4*>(dyp2 + o + 8), d2 + 8);
+                        Elem<H>::unpack(*reinterpret_cast<const uint4*>(dyp2 + o), d2);
+                        Elem<H>::unpack(*reinterpret_cast<const uint4*>(dyp2 + o + 8), d2 + 8);
 #pragma unroll
-                        for (int c = 0; c < 16; ++c) d[c] = bf16_bits_to_f32(f32_to_bf16_bits(d[c] + d2[c]));
+                        for (int c = 0; c < 16; ++c) d[c] = Elem<H>::round(d[c] + d2[c]);
                     }
-                    Elem<bf16_t>::unpack(*reinterpret_cast<const uint4*>(yp + o), y);
-                    Elem<bf16_t>::unpack(*reinterpret_cast<const uint4*>(yp + o + 8), y + 8);
+                    Elem<H>::unpack(*reinterpret_cast<const uint4*>(yp + o), y);
+                    Elem<H>::unpack(*reinterpret_cast<const uint4*>(yp + o + 8), y + 8);
 #pragma unroll
                     for (int c = 0; c < 16; ++c) {
                         const float g = y[c] > 0.f ? d[c] : 0.f;
@@ -389,11 +397,11 @@ __global__ __launch_bounds__(64 * SF_WAVES) void stem_bwd_dx_kernel(const int N,
         }
         // ---- phase B: recompute the convolution row by row, emit d(conv out) ----
         SfPooledRow P0, P1;
-        sf_load_pooled(P0, dyp, dyp2, yp, idx, pool_base, li, lg, true);
-        bf16_t* dimg = dx + (size_t)n * OH * 64 * 64;
+        sf_load_pooled<H>(P0, dyp, dyp2, yp, idx, pool_base, li, lg, true);
+        H* dimg = dx + (size_t)n * OH * 64 * 64;
         int slot0 = 0;
         for (int py = 0; py < PH; ++py) {
-            sf_load_pooled(P1, dyp, dyp2, yp, idx, pool_base + (size_t)(py + 1) * 32, li, lg, py + 1 < PH);
+            sf_load_pooled<H>(P1, dyp, dyp2, yp, idx, pool_base + (size_t)(py + 1) * 32, li, lg, py + 1 < PH);
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
                 const int oy = 2 * py + half;
@@ -404,7 +412,7 @@ __global__ __launch_bounds__(64 * SF_WAVES) void stem_bwd_dx_kernel(const int N,
                 sf_stage_row(rs, ring, 2 * oy + 9, rows, img_off, lane);
                 sf_stage_row(rs, ring, 2 * oy + 10, rows, img_off, lane);
                 f32x4_t acc[4][4];
-                sf_conv_row<true>(acc, ring, slot0, xoff, wbase);
+                sf_conv_row<H, true>(acc, ring, slot0, xoff, wbase);
                 slot0 = slot0 + 2 >= SF_RING ? slot0 + 2 - SF_RING : slot0 + 2;
                 const uint32_t k0 = half ? 6u : 3u;             // window row of this conv row inside window py
 #pragma unroll
@@ -422,21 +430,21 @@ __global__ __launch_bounds__(64 * SF_WAVES) void stem_bwd_dx_kernel(const int N,
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             // even column 2q: centre column (kw = 1) of window q only
-                            float ge = sf_pick(eg0, cd0, r, k0 + 1u);
+                            float ge = sf_pick<H>(eg0, cd0, r, k0 + 1u);
                             // odd column 2q+1: right column (kw = 2) of window q, left column (kw = 0) of window q+1
-                            float go = sf_pick(eg0, cd0, r, k0 + 2u) + sf_pick(ng0, nc0, r, k0);
+                            float go = sf_pick<H>(eg0, cd0, r, k0 + 2u) + sf_pick<H>(ng0, nc0, r, k0);
                             if (half) {                          // odd conv row: also the top row (kh = 0) of window py+1
-                                ge += sf_pick(eg1, cd1, r, 1u);
-                                go += sf_pick(eg1, cd1, r, 2u) + sf_pick(ng1, nc1, r, 0u);
+                                ge += sf_pick<H>(eg1, cd1, r, 1u);
+                                go += sf_pick<H>(eg1, cd1, r, 2u) + sf_pick<H>(ng1, nc1, r, 0u);
                             }
                             const float xe = acc[2 * j][nt][r], xo = acc[2 * j + 1][nt][r];
                             de[r] = fmaf(-xe, kB[r], fmaf(kr[r], ge, kC[r]));
                             dd[r] = fmaf(-xo, kB[r], fmaf(kr[r], go, kC[r]));
                         }
-                        pe[2 * nt] = pack2_bf16(de[0], de[1]); pe[2 * nt + 1] = pack2_bf16(de[2], de[3]);
-                        po[2 * nt] = pack2_bf16(dd[0], dd[1]); po[2 * nt + 1] = pack2_bf16(dd[2], dd[3]);
+                        pe[2 * nt] = Elem<H>::pack2(de[0], de[1]); pe[2 * nt + 1] = Elem<H>::pack2(de[2], de[3]);
+                        po[2 * nt] = Elem<H>::pack2(dd[0], dd[1]); po[2 * nt + 1] = Elem<H>::pack2(dd[2], dd[3]);
                     }
-                    bf16_t* o = dimg + ((size_t)oy * 64 + 2 * (li + 16 * j)) * 64 + lg * 16;
+                    H* o = dimg + ((size_t)oy * 64 + 2 * (li + 16 * j)) * 64 + lg * 16;
                     *reinterpret_cast<uint4*>(o) = make_uint4(pe[0], pe[1], pe[2], pe[3]);
                     *reinterpret_cast<uint4*>(o + 8) = make_uint4(pe[4], pe[5], pe[6], pe[7]);
                     *reinterpret_cast<uint4*>(o + 64) = make_uint4(po[0], po[1], po[2], po[3]);
@@ -454,45 +462,45 @@ using namespace eve;
 
 /* conv7x7/2 + InstanceNorm + ReLU + maxpool3x3/2 of the packed patches (eve_stem_pack_input layout).
    y_pool [N][IH/4][32][64] bf16, idx uint8 same shape (window position kh*3+kw), mean_rstd [N][64][2]. */
-extern "C" int eve_stem_fwd_fused(int N, int IH, int IW, const void* x_padded, const void* w_ohwi8, float eps,
+extern "C" int eve_stem_fwd_fused(int dtype, int N, int IH, int IW, const void* x_padded, const void* w_ohwi8, float eps,
                                   void* y_pool, uint8_t* idx, float* mean_rstd, eve_stream_t stream) {
-    if (N <= 0 || IH <= 0 || (IH & 3) || IW != 128 || !x_padded || !w_ohwi8 || !y_pool || !idx || !mean_rstd)
+    if ((dtype != EVE_DT_BF16 && dtype != EVE_DT_F16) || N <= 0 || IH <= 0 || (IH & 3) || IW != 128 || !x_padded || !w_ohwi8 || !y_pool || !idx || !mean_rstd)
         return set_error_msg("stem_fwd_fused: needs IW == 128 and IH a multiple of 4");
     const unsigned long long xb = (unsigned long long)N * (IH + 6) * SF_XROW;
     if (xb >= (1ull << 31)) return set_error_msg("stem_fwd_fused: packed input must stay below 2 GiB");
     const size_t lds = (size_t)SF_WAVES * SF_RING * SF_ROWB + SF_WBYTES;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)stem_fwd_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)stem_fwd_fused_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)stem_fwd_fused_kernel<f16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
     unsigned blocks = N < 256 ? (unsigned)N : 256u;
-    EVE_MARK_KERNEL("stem_fwd_fused_kernel");
-    hipLaunchKernelGGL(stem_fwd_fused_kernel, dim3(blocks), dim3(64 * SF_WAVES), lds, (hipStream_t)stream, N, IH,
-                       (const bf16_t*)x_padded, (uint32_t)xb, (const bf16_t*)w_ohwi8, eps, (bf16_t*)y_pool, idx, mean_rstd);
+    EVE_DISPATCH_H16(dtype, EVE_LAUNCH(EVE_HNAME(H, "stem_fwd_fused_kernel<", ">"), stem_fwd_fused_kernel<H>, dim3(blocks), dim3(64 * SF_WAVES), lds,
+                                       (hipStream_t)stream, N, IH, (const H*)x_padded, (uint32_t)xb, (const H*)w_ohwi8, eps, (H*)y_pool, idx, mean_rstd));
     EVE_CHECK_LAUNCH();
     return 0;
 }
 
 /* d(conv1 output) [N][IH/2][64][64] bf16 from d(y_pool): the backward of eve_stem_fwd_fused up to the convolution
    output (the weight gradient then runs on it).  Recomputes the convolution from x_padded instead of reading it. */
-extern "C" int eve_stem_bwd_dx(int N, int IH, int IW, const void* x_padded, const void* w_ohwi8, const float* mean_rstd,
+extern "C" int eve_stem_bwd_dx(int dtype, int N, int IH, int IW, const void* x_padded, const void* w_ohwi8, const float* mean_rstd,
                                const void* dy_pool, const void* dy_pool2, const void* y_pool, const uint8_t* idx, void* dx, eve_stream_t stream) {
-    if (N <= 0 || IH <= 0 || (IH & 3) || IW != 128 || !x_padded || !w_ohwi8 || !mean_rstd || !dy_pool || !y_pool || !idx || !dx)
+    if ((dtype != EVE_DT_BF16 && dtype != EVE_DT_F16) || N <= 0 || IH <= 0 || (IH & 3) || IW != 128 || !x_padded || !w_ohwi8 || !mean_rstd || !dy_pool || !y_pool || !idx || !dx)
         return set_error_msg("stem_bwd_dx: needs IW == 128 and IH a multiple of 4");
     const unsigned long long xb = (unsigned long long)N * (IH + 6) * SF_XROW;
     if (xb >= (1ull << 31)) return set_error_msg("stem_bwd_dx: packed input must stay below 2 GiB");
     const size_t lds = (size_t)SF_WAVES * SF_RING * SF_ROWB + SF_WBYTES + SF_WAVES * SF_KBYTES;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)stem_bwd_dx_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)stem_bwd_dx_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)stem_bwd_dx_kernel<f16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
     unsigned blocks = N < 256 ? (unsigned)N : 256u;
-    EVE_MARK_KERNEL("stem_bwd_dx_kernel");
-    hipLaunchKernelGGL(stem_bwd_dx_kernel, dim3(blocks), dim3(64 * SF_WAVES), lds, (hipStream_t)stream, N, IH,
-                       (const bf16_t*)x_padded, (uint32_t)xb, (const bf16_t*)w_ohwi8, mean_rstd, (const bf16_t*)dy_pool,
-                       (const bf16_t*)dy_pool2, (const bf16_t*)y_pool, idx, (bf16_t*)dx);
+    EVE_DISPATCH_H16(dtype, EVE_LAUNCH(EVE_HNAME(H, "stem_bwd_dx_kernel<", ">"), stem_bwd_dx_kernel<H>, dim3(blocks), dim3(64 * SF_WAVES), lds,
+                                       (hipStream_t)stream, N, IH, (const H*)x_padded, (uint32_t)xb, (const H*)w_ohwi8, mean_rstd, (const H*)dy_pool,
+                                       (const H*)dy_pool2, (const H*)y_pool, idx, (H*)dx));
     EVE_CHECK_LAUNCH();
     return 0;
 }

@@ -37,12 +37,35 @@ __device__ __forceinline__ void mma1_bf16_inplace(f32x4_t& c, const uint4& a4, c
     const u32x4_t a = __builtin_bit_cast(u32x4_t, a4), b = __builtin_bit_cast(u32x4_t, b4);
     asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
 }
+__device__ __forceinline__ void mma3_f16_inplace(f32x4_t& c0, f32x4_t& c1, f32x4_t& c2, const uint4& a4, const uint4 (&b4)[3]) {
+    const u32x4_t a = __builtin_bit_cast(u32x4_t, a4);
+    const u32x4_t b0 = __builtin_bit_cast(u32x4_t, b4[0]), b1 = __builtin_bit_cast(u32x4_t, b4[1]), b2 = __builtin_bit_cast(u32x4_t, b4[2]);
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_mfma_f32_16x16x32_f16 %0, %3, %4, %0\n\t"
+        "v_mfma_f32_16x16x32_f16 %1, %3, %5, %1\n\t"
+        "v_mfma_f32_16x16x32_f16 %2, %3, %6, %2"
+        : "+v"(c0), "+v"(c1), "+v"(c2)                       // accumulators in architectural VGPRs (unified file on gfx950):
+        : "v"(a), "v"(b0), "v"(b1), "v"(b2));                 // the epilogue reads them without a copy out of the AGPRs
+}
+__device__ __forceinline__ void mma1_f16_inplace(f32x4_t& c, const uint4& a4, const uint4& b4) {
+    const u32x4_t a = __builtin_bit_cast(u32x4_t, a4), b = __builtin_bit_cast(u32x4_t, b4);
+    asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+}
+template <typename H>
+__device__ __forceinline__ void mma3_inplace(f32x4_t& c0, f32x4_t& c1, f32x4_t& c2, const uint4& a4, const uint4 (&b4)[3]) {
+    if constexpr (Elem<H>::IS_BF16) mma3_bf16_inplace(c0, c1, c2, a4, b4); else mma3_f16_inplace(c0, c1, c2, a4, b4);
+}
+template <typename H>
+__device__ __forceinline__ void mma1_inplace(f32x4_t& c, const uint4& a4, const uint4& b4) {
+    if constexpr (Elem<H>::IS_BF16) mma1_bf16_inplace(c, a4, b4); else mma1_f16_inplace(c, a4, b4);
+}
 
 // KS = 3: the 3x3 / pad 1 case above.  KS = 1: 1x1 convolutions of the same planes (skip layers): no halo, one tap --
 // a plain [Cout][Cin] += dy^T x over the band, where the gather kernel's 256-wide K tile is 6-25 % occupied.
-template <int MT, int CT, int KS = 3>
-__global__ __launch_bounds__(256) void wgrad_halo_kernel(const WgradHaloParams p, const bf16_t* __restrict__ x,
-                                                         const bf16_t* __restrict__ dy, float* __restrict__ dw,
+template <typename H, int MT, int CT, int KS = 3>
+__global__ __launch_bounds__(256) void wgrad_halo_kernel(const WgradHaloParams p, const H* __restrict__ x,
+                                                         const H* __restrict__ dy, float* __restrict__ dw,
                                                          float* __restrict__ db) {
     constexpr int CIN = 16 * CT, COUT = 16 * MT;
     constexpr int XROW = CIN * 2, DROW = COUT * 2;           // bytes per pixel
@@ -75,7 +98,7 @@ __global__ __launch_bounds__(256) void wgrad_halo_kernel(const WgradHaloParams p
 #pragma unroll
             for (int c = 0; c < TAPS; ++c) acc[a][b][c] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     }
-    const uint4 ones = make_uint4(0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u);
+    const uint4 ones = make_uint4(Elem<H>::ONE2, Elem<H>::ONE2, Elem<H>::ONE2, Elem<H>::ONE2);
     // lane-constant part of the transposing reads: pixel 8g + t/4 (+4 for the second read), channels 4 (t%4) .. +3
     const int lrow = 8 * g + (t >> 2), sub = (t & 3) * 8;
     const int nchunks = TH << p.log2_cpr;
@@ -128,7 +151,7 @@ __global__ __launch_bounds__(256) void wgrad_halo_kernel(const WgradHaloParams p
                         }
 #pragma unroll
                         for (int mt = 0; mt < MT; ++mt)
-                            mma3_bf16_inplace(acc[mt][ct][kh * 3], acc[mt][ct][kh * 3 + 1], acc[mt][ct][kh * 3 + 2], fp[mt], fq);
+                            mma3_inplace<H>(acc[mt][ct][kh * 3], acc[mt][ct][kh * 3 + 1], acc[mt][ct][kh * 3 + 2], fp[mt], fq);
                     }
                 } else {
                     const uint32_t qa = lds0 + (uint32_t)((ty * W + x0 + lrow) * XROW + ct * 32 + sub);
@@ -136,12 +159,12 @@ __global__ __launch_bounds__(256) void wgrad_halo_kernel(const WgradHaloParams p
                     const uint2 b1 = lds_tr_read<4 * XROW>(qa);
                     const uint4 fq = make_uint4(b0.x, b0.y, b1.x, b1.y);
 #pragma unroll
-                    for (int mt = 0; mt < MT; ++mt) mma1_bf16_inplace(acc[mt][ct][0], fp[mt], fq);
+                    for (int mt = 0; mt < MT; ++mt) mma1_inplace<H>(acc[mt][ct][0], fp[mt], fq);
                 }
             }
             if (db) {
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt) mma1_bf16_inplace(accb[mt], fp[mt], ones);
+                for (int mt = 0; mt < MT; ++mt) mma1_inplace<H>(accb[mt], fp[mt], ones);
             }
         }
     }
@@ -191,8 +214,9 @@ __global__ __launch_bounds__(256) void wgrad_halo_kernel(const WgradHaloParams p
 // gradient with coalesced atomics, starting at a different offset per workgroup.
 __device__ __forceinline__ int wgrad64_swz(int col) { return ((col >> 1) & 1) | (((col >> 3) & 1) << 1); }
 
-__global__ __launch_bounds__(512) void wgrad_halo64_kernel(const WgradHaloParams p, const bf16_t* __restrict__ x,
-                                                           const bf16_t* __restrict__ dy, float* __restrict__ dw,
+template <typename H>
+__global__ __launch_bounds__(512) void wgrad_halo64_kernel(const WgradHaloParams p, const H* __restrict__ x,
+                                                           const H* __restrict__ dy, float* __restrict__ dw,
                                                            float* __restrict__ db) {
     constexpr int ROW = 128;                                 // bytes per pixel, both operands
     extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -221,7 +245,7 @@ __global__ __launch_bounds__(512) void wgrad_halo64_kernel(const WgradHaloParams
 #pragma unroll
         for (int c = 0; c < 9; ++c) acc[a][c] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     }
-    const uint4 ones = make_uint4(0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u);
+    const uint4 ones = make_uint4(Elem<H>::ONE2, Elem<H>::ONE2, Elem<H>::ONE2, Elem<H>::ONE2);
     const int lrow = 8 * g + (t >> 2), sub = (t & 3) * 8;    // lane-constant part of the transposing reads (see above)
     const int nchunks = TH << p.log2_cpr;
     const bool bias_wave = db != nullptr && ct == 0;
@@ -314,11 +338,11 @@ __global__ __launch_bounds__(512) void wgrad_halo64_kernel(const WgradHaloParams
                 }
 #pragma unroll
                 for (int mt = 0; mt < 4; ++mt)
-                    mma3_bf16_inplace(acc[mt][kh * 3], acc[mt][kh * 3 + 1], acc[mt][kh * 3 + 2], fp[mt], fq);
+                    mma3_inplace<H>(acc[mt][kh * 3], acc[mt][kh * 3 + 1], acc[mt][kh * 3 + 2], fp[mt], fq);
             }
             if (bias_wave) {
 #pragma unroll
-                for (int mt = 0; mt < 4; ++mt) mma1_bf16_inplace(accb[mt], fp[mt], ones);
+                for (int mt = 0; mt < 4; ++mt) mma1_inplace<H>(accb[mt], fp[mt], ones);
             }
         }
     }

@@ -26,7 +26,7 @@ from torch import nn
 
 from . import ops
 from .config import get_config
-from .kernels import ACT_NONE, ACT_RELU, ACT_SELU, ACT_TANH, default_kernels, pad_channels
+from .kernels import ACT_NONE, ACT_RELU, ACT_SELU, ACT_TANH, HALF_DTYPES, default_kernels, pad_channels
 from .ops import PackedWeight
 
 half_pi = 0.5 * math.pi
@@ -36,9 +36,11 @@ def default_compute_dtype():
     name = os.environ.get('EVE_AMD_DTYPE', 'fp32').lower()
     if name in ('bf16', 'bfloat16'):
         return torch.bfloat16
+    if name in ('fp16', 'float16', 'half'):
+        return torch.float16
     if name in ('fp32', 'float32', 'f32'):
         return torch.float32
-    raise ValueError('EVE_AMD_DTYPE must be fp32 or bf16, got %r' % name)
+    raise ValueError('EVE_AMD_DTYPE must be fp32, bf16 or fp16, got %r' % name)
 
 
 class _Block(nn.Module):
@@ -269,7 +271,7 @@ class EyeNet(nn.Module):
             # straight into the stem's packed layout when the fused stem takes it, else to the reference's float NCHW
             from . import data
             B, T, Hh, Ww, C = left.shape
-            if dt == torch.bfloat16 and C <= 4 and Hh % 4 == 0 and Ww == 128:
+            if dt in HALF_DTYPES and C <= 4 and Hh % 4 == 0 and Ww == 128:
                 x_padded = torch.empty((2 * B * T, Hh + 6, Ww + 8, 4), dtype=dt, device=left.device)
                 k.frames_u8_to_stem(left.reshape(B * T, Hh, Ww, C), data.EYE_SCALE, data.EYE_SHIFT, out=x_padded[:B * T])
                 k.frames_u8_to_stem(right.reshape(B * T, Hh, Ww, C), data.EYE_SCALE, data.EYE_SHIFT, out=x_padded[B * T:])
@@ -280,7 +282,7 @@ class EyeNet(nn.Module):
         cpad = pad_channels(C, dt)
         if x_padded is not None:                                                   # packed from the uint8 frames above
             pass
-        elif dt == torch.bfloat16 and C <= 4 and Hh % 4 == 0 and Ww == 128:        # fused stem: packed patches only
+        elif dt in HALF_DTYPES and C <= 4 and Hh % 4 == 0 and Ww == 128:        # fused stem: packed patches only
             x_padded = torch.empty((2 * B * T, Hh + 6, Ww + 8, 4), dtype=dt, device=left.device)
             k.stem_pack_input(left.reshape(B * T, C, Hh, Ww), out=x_padded[:B * T])
             k.stem_pack_input(right.reshape(B * T, C, Hh, Ww), out=x_padded[B * T:])
@@ -288,7 +290,7 @@ class EyeNet(nn.Module):
             x = torch.empty((2 * B * T, Hh, Ww, cpad), dtype=dt, device=left.device)
             k.nchw_to_nhwc(left.reshape(B * T, C, Hh, Ww), dt, cpad, out=x[:B * T])
             k.nchw_to_nhwc(right.reshape(B * T, C, Hh, Ww), dt, cpad, out=x[B * T:])
-            if dt == torch.bfloat16 and C <= 4 and Hh % 2 == 0 and Ww % 128 == 0:  # dedicated stem conv kernel
+            if dt in HALF_DTYPES and C <= 4 and Hh % 2 == 0 and Ww % 128 == 0:  # dedicated stem conv kernel
                 x_padded = torch.empty((2 * B * T, Hh + 6, Ww + 8, 4), dtype=dt, device=left.device)
                 k.stem_pack_input(left.reshape(B * T, C, Hh, Ww), out=x_padded[:B * T])
                 k.stem_pack_input(right.reshape(B * T, C, Hh, Ww), out=x_padded[B * T:])

@@ -4,7 +4,7 @@
 and calls the `extern "C"` entry points of include/eve_hip.h with raw pointers, explicit shapes and
 torch's current HIP stream.  PyTorch is plumbing here: allocation and stream only.
 
-Activations are NHWC (`[N, H, W, C]` contiguous) in the compute dtype (float32 or bfloat16).
+Activations are NHWC (`[N, H, W, C]` contiguous) in the compute dtype (float32, bfloat16 or float16).
 """
 import ctypes
 
@@ -14,7 +14,8 @@ from . import _lib
 from ._lib import ConvDesc
 
 ACT_NONE, ACT_RELU, ACT_LEAKY, ACT_SELU, ACT_TANH, ACT_SIGMOID = range(6)
-DT_F32, DT_BF16 = 0, 1
+DT_F32, DT_BF16, DT_F16 = 0, 1, 2
+HALF_DTYPES = (torch.bfloat16, torch.float16)      # the two 16-bit instantiations of the MFMA kernels
 
 
 def dt_code(dtype):
@@ -22,7 +23,9 @@ def dt_code(dtype):
         return DT_F32
     if dtype == torch.bfloat16:
         return DT_BF16
-    raise TypeError('eve_amd kernels support float32 and bfloat16, got %s' % dtype)
+    if dtype == torch.float16:
+        return DT_F16
+    raise TypeError('eve_amd kernels support float32, bfloat16 and float16, got %s' % dtype)
 
 
 def vec_of(dtype):
@@ -179,34 +182,34 @@ class HipKernels(object):
             self._p(dw_ohwi), self._stream())))
         return dw_ohwi
 
-    def stem_pack_input(self, src_nchw, out=None):
+    def stem_pack_input(self, src_nchw, out=None, dtype=torch.bfloat16):
         N, C, H, W = src_nchw.shape
         src = self._f32(src_nchw.contiguous(), 'src')
-        dst = out if out is not None else torch.empty((N, H + 6, W + 8, 4), dtype=torch.bfloat16, device=src.device)
-        assert tuple(dst.shape) == (N, H + 6, W + 8, 4) and dst.dtype == torch.bfloat16
-        self._ck(self.lib.eve_stem_pack_input(N, C, H, W, self._p(src), self._p(dst), self._stream()))
+        dst = out if out is not None else torch.empty((N, H + 6, W + 8, 4), dtype=dtype, device=src.device)
+        assert tuple(dst.shape) == (N, H + 6, W + 8, 4) and dst.dtype in HALF_DTYPES
+        self._ck(self.lib.eve_stem_pack_input(dt_code(dst.dtype), N, C, H, W, self._p(src), self._p(dst), self._stream()))
         return dst
 
     def stem7x7s2_fwd(self, x_padded, w_ohwi8):
         N, Hp, Wp, four = x_padded.shape
         IH, IW = Hp - 6, Wp - 8
-        assert four == 4 and tuple(w_ohwi8.shape) == (64, 7, 7, 8) and w_ohwi8.dtype == torch.bfloat16
-        y = torch.empty((N, IH // 2, IW // 2, 64), dtype=torch.bfloat16, device=x_padded.device)
+        assert four == 4 and tuple(w_ohwi8.shape) == (64, 7, 7, 8) and w_ohwi8.dtype == x_padded.dtype and x_padded.dtype in HALF_DTYPES
+        y = torch.empty((N, IH // 2, IW // 2, 64), dtype=x_padded.dtype, device=x_padded.device)
         flops = 2.0 * N * (IH // 2) * (IW // 2) * 64 * 147
         self._timed('conv_fwd', flops, lambda: self._ck(self.lib.eve_stem7x7s2_fwd(
-            N, IH, IW, self._p(x_padded), self._p(w_ohwi8), self._p(y), self._stream())))
+            dt_code(x_padded.dtype), N, IH, IW, self._p(x_padded), self._p(w_ohwi8), self._p(y), self._stream())))
         return y
 
     def stem_fwd_fused(self, x_padded, w_ohwi8, eps=1e-5):
         N, Hp, Wp, four = x_padded.shape
         IH, IW = Hp - 6, Wp - 8
-        assert four == 4 and tuple(w_ohwi8.shape) == (64, 7, 7, 8) and w_ohwi8.dtype == torch.bfloat16
-        y = torch.empty((N, IH // 4, IW // 4, 64), dtype=torch.bfloat16, device=x_padded.device)
+        assert four == 4 and tuple(w_ohwi8.shape) == (64, 7, 7, 8) and w_ohwi8.dtype == x_padded.dtype and x_padded.dtype in HALF_DTYPES
+        y = torch.empty((N, IH // 4, IW // 4, 64), dtype=x_padded.dtype, device=x_padded.device)
         idx = torch.empty((N, IH // 4, IW // 4, 64), dtype=torch.uint8, device=x_padded.device)
         mr = torch.empty((N, 64, 2), dtype=torch.float32, device=x_padded.device)
         flops = 2.0 * N * (IH // 2) * (IW // 2) * 64 * 147
         self._timed('conv_fwd', flops, lambda: self._ck(self.lib.eve_stem_fwd_fused(
-            N, IH, IW, self._p(x_padded), self._p(w_ohwi8), eps, self._p(y), self._p(idx), self._p(mr),
+            dt_code(x_padded.dtype), N, IH, IW, self._p(x_padded), self._p(w_ohwi8), eps, self._p(y), self._p(idx), self._p(mr),
             self._stream())))
         return y, idx, mr
 
@@ -215,19 +218,19 @@ class HipKernels(object):
         N, Hp, Wp, _ = x_padded.shape
         IH, IW = Hp - 6, Wp - 8
         assert tuple(dw.shape) == (64, 7, 8, 4) and dw.dtype == torch.float32 and dw.is_contiguous()
-        assert tuple(dconv.shape) == (N, IH // 2, IW // 2, 64) and dconv.dtype == torch.bfloat16
+        assert tuple(dconv.shape) == (N, IH // 2, IW // 2, 64) and dconv.dtype == x_padded.dtype
         flops = 2.0 * N * (IH // 2) * (IW // 2) * 64 * 147
         self._timed('conv_wgrad', flops, lambda: self._ck(self.lib.eve_stem_wgrad(
-            N, IH, IW, self._p(x_padded), self._p(dconv), self._p(dw), self._stream())))
+            dt_code(x_padded.dtype), N, IH, IW, self._p(x_padded), self._p(dconv), self._p(dw), self._stream())))
 
     def stem_bwd_dx(self, x_padded, w_ohwi8, mr, dy_pool, y_pool, idx, dy_pool2=None):
         N, Hp, Wp, _ = x_padded.shape
         IH, IW = Hp - 6, Wp - 8
-        dx = torch.empty((N, IH // 2, IW // 2, 64), dtype=torch.bfloat16, device=x_padded.device)
-        assert dy_pool.dtype == torch.bfloat16 and dy_pool.is_contiguous() and dy_pool.shape == y_pool.shape == idx.shape
+        dx = torch.empty((N, IH // 2, IW // 2, 64), dtype=x_padded.dtype, device=x_padded.device)
+        assert dy_pool.dtype == x_padded.dtype and dy_pool.is_contiguous() and dy_pool.shape == y_pool.shape == idx.shape
         # (the convolution is RE-computed here: no algorithmic FLOPs are credited)
         self._timed('stem_bwd', 0.0, lambda: self._ck(self.lib.eve_stem_bwd_dx(
-            N, IH, IW, self._p(x_padded), self._p(w_ohwi8), self._p(self._f32(mr, 'mean_rstd')), self._p(dy_pool),
+            dt_code(x_padded.dtype), N, IH, IW, self._p(x_padded), self._p(w_ohwi8), self._p(self._f32(mr, 'mean_rstd')), self._p(dy_pool),
             self._p(dy_pool2), self._p(y_pool), self._p(idx), self._p(dx), self._stream())))
         return dx
 
@@ -241,13 +244,13 @@ class HipKernels(object):
                                                 0 if shift is None else 1, self._p(out), self._stream()))
         return out
 
-    def frames_u8_to_stem(self, frames, scale, shift, out=None):
-        """uint8 [N,H,W,C<=4] -> the stem's packed bf16 input [N,H+6,W+8,4]."""
+    def frames_u8_to_stem(self, frames, scale, shift, out=None, dtype=torch.bfloat16):
+        """uint8 [N,H,W,C<=4] -> the stem's packed 16-bit input [N,H+6,W+8,4]."""
         N, H, W, C = frames.shape
         assert frames.dtype == torch.uint8
-        dst = out if out is not None else torch.empty((N, H + 6, W + 8, 4), dtype=torch.bfloat16, device=frames.device)
-        assert tuple(dst.shape) == (N, H + 6, W + 8, 4) and dst.dtype == torch.bfloat16
-        self._ck(self.lib.eve_frames_u8_to_stem(N, C, H, W, self._p(frames), float(scale), float(shift), self._p(dst), self._stream()))
+        dst = out if out is not None else torch.empty((N, H + 6, W + 8, 4), dtype=dtype, device=frames.device)
+        assert tuple(dst.shape) == (N, H + 6, W + 8, 4) and dst.dtype in HALF_DTYPES
+        self._ck(self.lib.eve_frames_u8_to_stem(dt_code(dst.dtype), N, C, H, W, self._p(frames), float(scale), float(shift), self._p(dst), self._stream()))
         return dst
 
     # ------------------------------------------------------------------ gaze geometry / heat-maps / soft-argmax
@@ -721,35 +724,37 @@ class HipKernels(object):
         return dpre, dh0, dc0
 
     def cgru_scan_fwd(self, xs, h0, w1_ohwi, b1, w2_ohwi, b2):
-        """CGRUCell over T in one launch.  xs [B, T, 5, 8, 64] bf16 -> hs [B, T, 5, 8, 64] and, time-major [T, B, 5, 8, .]
+        """CGRUCell over T in one launch.  xs [B, T, 5, 8, 64] bf16 / fp16 -> hs [B, T, 5, 8, 64] and, time-major [T, B, 5, 8, .]
         for the backward: hs_tm, ru, rh, og."""
         B, T, H, W, C = xs.shape
-        assert (H, W, C) == (5, 8, 64) and xs.dtype == torch.bfloat16 and xs.is_contiguous()
+        assert (H, W, C) == (5, 8, 64) and xs.dtype in HALF_DTYPES and xs.is_contiguous()
         assert tuple(w1_ohwi.shape) == (128, 3, 3, 128) and tuple(w2_ohwi.shape) == (64, 3, 3, 128)
         dev = xs.device
-        hs = torch.empty((B, T, H, W, C), dtype=torch.bfloat16, device=dev)
-        hs_tm = torch.empty((T, B, H, W, C), dtype=torch.bfloat16, device=dev)
-        ru = torch.empty((T, B, H, W, 2 * C), dtype=torch.bfloat16, device=dev)
-        rh = torch.empty((T, B, H, W, C), dtype=torch.bfloat16, device=dev)
-        og = torch.empty((T, B, H, W, C), dtype=torch.bfloat16, device=dev)
-        self._ck(self.lib.eve_cgru_scan_fwd(B, T, self._p(xs), self._p(h0), self._p(w1_ohwi), self._p(self._f32(b1, 'b1')),
+        hdt = xs.dtype
+        hs = torch.empty((B, T, H, W, C), dtype=hdt, device=dev)
+        hs_tm = torch.empty((T, B, H, W, C), dtype=hdt, device=dev)
+        ru = torch.empty((T, B, H, W, 2 * C), dtype=hdt, device=dev)
+        rh = torch.empty((T, B, H, W, C), dtype=hdt, device=dev)
+        og = torch.empty((T, B, H, W, C), dtype=hdt, device=dev)
+        self._ck(self.lib.eve_cgru_scan_fwd(dt_code(hdt), B, T, self._p(xs), self._p(h0), self._p(w1_ohwi), self._p(self._f32(b1, 'b1')),
                                             self._p(w2_ohwi), self._p(self._f32(b2, 'b2')), self._p(hs), self._p(hs_tm),
                                             self._p(ru), self._p(rh), self._p(og), self._stream()))
         return hs, hs_tm, ru, rh, og
 
     def cgru_scan_bwd(self, dhs_tm, ru, og, hs_tm, h0, w1_ihwo, w2_ihwo, want_dh0=False):
-        """Backward of cgru_scan_fwd in one launch.  Time-major [T, B, 5, 8, .] bf16 inputs; returns (dg1_all [T,B,5,8,128],
+        """Backward of cgru_scan_fwd in one launch.  Time-major [T, B, 5, 8, .] 16-bit inputs; returns (dg1_all [T,B,5,8,128],
         dg2_all [T,B,5,8,64], dxs_tm [T,B,5,8,64], dh0 [B,5,8,64] or None)."""
         T, B, H, W, C = dhs_tm.shape
-        assert (H, W, C) == (5, 8, 64) and dhs_tm.dtype == torch.bfloat16 and dhs_tm.is_contiguous()
+        assert (H, W, C) == (5, 8, 64) and dhs_tm.dtype in HALF_DTYPES and dhs_tm.is_contiguous()
         assert tuple(ru.shape) == (T, B, H, W, 2 * C) and tuple(og.shape) == tuple(hs_tm.shape) == (T, B, H, W, C)
         assert tuple(w1_ihwo.shape) == (128, 3, 3, 128) and tuple(w2_ihwo.shape) == (128, 3, 3, 64)
         dev = dhs_tm.device
-        dg1 = torch.empty((T, B, H, W, 2 * C), dtype=torch.bfloat16, device=dev)
-        dg2 = torch.empty((T, B, H, W, C), dtype=torch.bfloat16, device=dev)
-        dxs = torch.empty((T, B, H, W, C), dtype=torch.bfloat16, device=dev)
-        dh0 = torch.empty((B, H, W, C), dtype=torch.bfloat16, device=dev) if want_dh0 else None
-        self._ck(self.lib.eve_cgru_scan_bwd(B, T, self._p(dhs_tm), self._p(ru), self._p(og), self._p(hs_tm), self._p(h0),
+        hdt = dhs_tm.dtype
+        dg1 = torch.empty((T, B, H, W, 2 * C), dtype=hdt, device=dev)
+        dg2 = torch.empty((T, B, H, W, C), dtype=hdt, device=dev)
+        dxs = torch.empty((T, B, H, W, C), dtype=hdt, device=dev)
+        dh0 = torch.empty((B, H, W, C), dtype=hdt, device=dev) if want_dh0 else None
+        self._ck(self.lib.eve_cgru_scan_bwd(dt_code(hdt), B, T, self._p(dhs_tm), self._p(ru), self._p(og), self._p(hs_tm), self._p(h0),
                                             self._p(w1_ihwo), self._p(w2_ihwo), self._p(dg1), self._p(dg2), self._p(dxs),
                                             self._p(dh0), self._stream()))
         return dg1, dg2, dxs, dh0

@@ -10,7 +10,7 @@ import torch
 
 from . import kernels as K
 from .kernels import (ACT_LEAKY, ACT_NONE, ACT_RELU, ACT_SELU, ACT_SIGMOID, ACT_TANH,  # noqa: F401
-                      default_kernels)
+                      HALF_DTYPES, default_kernels)
 
 
 class PackedWeight(object):
@@ -39,7 +39,7 @@ class PackedWeight(object):
             self.ohwi, self.ihwo = (w, want_ihwo), None
         else:
             self.ohwi, self.ihwo = k.pack_weights(w, dtype, want_ihwo=want_ihwo)
-            if dtype == torch.bfloat16 and w.shape[1] == w.shape[2] and param.dim() == 4:
+            if dtype in HALF_DTYPES and w.shape[1] == w.shape[2] and param.dim() == 4:
                 cout_p, cin_p = w.shape[0], w.shape[3]
                 fac = _group_factors(w.shape[1])
                 if cin_p in fac:
@@ -110,7 +110,7 @@ def _group_factors(ks):
 
 
 def _group_ok(pair, x, ks, stride, pad):
-    if pair is None or stride != 1 or pad != (ks - 1) // 2 or x.dtype != torch.bfloat16:
+    if pair is None or stride != 1 or pad != (ks - 1) // 2 or x.dtype not in HALF_DTYPES:
         return False
     wg = x.shape[2] // pair[0]
     if x.shape[2] % pair[0]:

@@ -25,7 +25,7 @@ from torch import nn
 from . import ops
 from .config import get_config
 from .eye_net import default_compute_dtype
-from .kernels import ACT_LEAKY, ACT_NONE, ACT_RELU, ACT_TANH, default_kernels, pad_channels
+from .kernels import ACT_LEAKY, ACT_NONE, ACT_RELU, ACT_TANH, HALF_DTYPES, default_kernels, pad_channels
 from .ops import PackedWeight
 
 
@@ -312,7 +312,7 @@ class RefineNet(nn.Module):
         while isinstance(bott, WrapEncoderDecoder):
             bott = bott.between_module
         cells = list(bott.rnn_cells) if self.config.refine_net_use_rnn else []
-        fused = (len(cells) == 1 and isinstance(cells[0], CGRUCell) and xs.dtype == torch.bfloat16 and
+        fused = (len(cells) == 1 and isinstance(cells[0], CGRUCell) and xs.dtype in HALF_DTYPES and
                  tuple(xs.shape[2:]) == (5, 8, 64) and os.environ.get('EVE_AMD_CGRU_SCAN', '1') != '0')
         if fused:
             # the whole clip through the conv-GRU in one persistent launch (hidden state resident in LDS)

@@ -77,14 +77,21 @@ class Trainer(object):
     With data parallelism the graph holds forward+backward only; the gradient all-reduce, clip and Adam run
     eagerly behind it (collectives are not captured)."""
 
-    def __init__(self, modules, config, loss_fn, distributed=False, device=None, use_graph=False, lr_schedule=None):
+    def __init__(self, modules, config, loss_fn, distributed=False, device=None, use_graph=False, lr_schedule=None,
+                 loss_scale=None):
         """lr_schedule: None (constant config.learning_rate) or a callable step -> learning rate, e.g.
         `lambda s: schedule.effective_learning_rate(config, steps_per_epoch, s)` for the reference's behaviour
         (src/core/training.py:382-418,436-442).  The value lives in a device scalar the Adam kernel reads, so it also
-        changes under hipGraph replay."""
+        changes under hipGraph replay.
+        loss_scale: static factor on the loss before backward, divided out again inside the Adam kernel's gradient scale
+        (clip norm included).  None = 1024 when a module computes in float16 (activation gradients of this network reach
+        1e-6..1e-8 per element, below float16's normal range; the reference is float32 and has no such step), else 1."""
         self.modules = list(modules)
         self.config = config
         self.loss_fn = loss_fn
+        if loss_scale is None:
+            loss_scale = 1024.0 if any(getattr(m, 'compute_dtype', None) == torch.float16 for m in self.modules) else 1.0
+        self.loss_scale = float(loss_scale)
         self.fp = FlatParameters(self.modules, device)
         dev = self.fp.flat.device
         self.sumsq = torch.zeros(1, dtype=torch.float32, device=dev)
@@ -111,12 +118,14 @@ class Trainer(object):
     def _forward_backward(self, batch):
         self.fp.zero_grad()
         terms = self.loss_fn(batch)
-        terms['full_loss'].backward()
+        loss = terms['full_loss']
+        (loss if self.loss_scale == 1.0 else loss * self.loss_scale).backward()
         return terms
 
     def _update(self, gscale):
         k = default_kernels()
         cfg = self.config
+        gscale = gscale / self.loss_scale           # the gradients in the flat buffer are loss_scale x the true ones
         self.step_dev.add_(1)
         clip = cfg.do_gradient_clipping and cfg.gradient_clip_by == 'norm'
         if cfg.do_gradient_clipping and not clip:
@@ -167,9 +176,10 @@ class Trainer(object):
         side.wait_stream(torch.cuda.current_stream())
         # two eager warm-up passes (allocator, lazy initialisation) off the default stream, as capture requires; they
         # must not train: parameters, moments and the step counter are put back afterwards, so the first replay IS the
-        # first optimiser step (one update on the first batch, exactly like the eager path and the reference)
-        snap = self._snapshot()
+        # first optimiser step (one update on the first batch, exactly like the eager path and the reference).
+        # The snapshot is taken ON the side stream, after its wait: clone, warm-up and restore are ordered on one stream.
         with torch.cuda.stream(side):
+            snap = self._snapshot()
             for _ in range(2):
                 if self.sync is not None:
                     self._forward_backward(self._static_batch)
@@ -209,20 +219,33 @@ class Trainer(object):
         return self._static_terms
 
 
-def eyenet_trainer(eye_net, config, distributed=False, use_graph=False):
+def _resolve_schedule(config, lr_schedule, steps_per_epoch):
+    """The factories' learning-rate argument.  `lr_schedule` (callable step -> LR) wins; else `steps_per_epoch` selects the
+    REFERENCE's behaviour -- warm-up / decay per src/core/training.py:382-418 multiplied by the optimiser's initial LR
+    as torch's LambdaLR does (:436-442), i.e. schedule.effective_learning_rate; with neither the LR is the constant
+    config.learning_rate (what bench.py and the parity tests step with: one schedule-free Adam update per call)."""
+    if lr_schedule is not None or steps_per_epoch is None:
+        return lr_schedule
+    from . import schedule
+    return lambda s: schedule.effective_learning_rate(config, steps_per_epoch, s)
+
+
+def eyenet_trainer(eye_net, config, distributed=False, use_graph=False, lr_schedule=None, steps_per_epoch=None):
     def loss_fn(batch):
         return losses.eyenet_loss_terms(eye_net.forward_sequence(batch), batch, config)
-    return Trainer([eye_net], config, loss_fn, distributed=distributed, use_graph=use_graph)
+    return Trainer([eye_net], config, loss_fn, distributed=distributed, use_graph=use_graph,
+                   lr_schedule=_resolve_schedule(config, lr_schedule, steps_per_epoch))
 
 
-def refinenet_trainer(refine_net, config, distributed=False, use_graph=False):
+def refinenet_trainer(refine_net, config, distributed=False, use_graph=False, lr_schedule=None, steps_per_epoch=None):
     def loss_fn(batch):
         hf, _ = refine_net.forward_sequence(batch['heatmap_initial'], batch.get('screen_frame'))
         return losses.refinenet_loss_terms(hf, batch['heatmap_final_gt'], batch['validity'], config)
-    return Trainer([refine_net], config, loss_fn, distributed=distributed, use_graph=use_graph)
+    return Trainer([refine_net], config, loss_fn, distributed=distributed, use_graph=use_graph,
+                   lr_schedule=_resolve_schedule(config, lr_schedule, steps_per_epoch))
 
 
-def eve_trainer(model, config, distributed=False, current_epoch=0.0):
+def eve_trainer(model, config, distributed=False, current_epoch=0.0, lr_schedule=None, steps_per_epoch=None):
     """Train step of the whole EVE harness (eve.EVE): forward through both networks and the geometry / heat-map /
     soft-argmax glue, every loss of eve.py:234-265, backward, clip, Adam on whichever network is trainable
     (refine_net.json freezes EyeNet).  Eager only: the kappa draw (numpy RNG, as in the reference) happens on the host."""
@@ -231,4 +254,4 @@ def eve_trainer(model, config, distributed=False, current_epoch=0.0):
 
     def loss_fn(batch):
         return model({'train': dict(batch)}, current_epoch=current_epoch)
-    return Trainer(modules, config, loss_fn, distributed=distributed)
+    return Trainer(modules, config, loss_fn, distributed=distributed, lr_schedule=_resolve_schedule(config, lr_schedule, steps_per_epoch))

@@ -28,11 +28,11 @@
 extern "C" {
 #endif
 
-#define EVE_ABI_VERSION 3
+#define EVE_ABI_VERSION 4
 
 typedef void* eve_stream_t; /* hipStream_t */
 
-enum { EVE_DT_F32 = 0, EVE_DT_BF16 = 1 };
+enum { EVE_DT_F32 = 0, EVE_DT_BF16 = 1, EVE_DT_F16 = 2 };   /* F16: IEEE half, the second 16-bit instantiation */
 enum {
     EVE_ACT_NONE = 0,
     EVE_ACT_RELU = 1,    /* nn.ReLU          (eye_net trunk; refine_net.py:38 encoder blocks)   */
@@ -84,9 +84,9 @@ int eve_conv2d_wgrad_bias(const eve_conv_desc* d, const void* x, const void* dy,
  * eve_stem_pack_input writes x_padded [N][IH+6][IW+8][4] bf16 (channels 0..C-1, zero 4th channel and borders)
  * from the float NCHW patch; eve_stem7x7s2_fwd computes y [N][IH/2][IW/2][64] from it and the OHWI weights
  * with Cin padded to 8 ([64][7][7][8] bf16).  IH even, IW a multiple of 128.                           */
-int eve_stem_pack_input(int N, int C, int IH, int IW, const float* src_nchw, void* x_padded,
+int eve_stem_pack_input(int dtype /* EVE_DT_BF16 | EVE_DT_F16 */, int N, int C, int IH, int IW, const float* src_nchw, void* x_padded,
                         eve_stream_t stream);
-int eve_stem7x7s2_fwd(int N, int IH, int IW, const void* x_padded, const void* w_ohwi8, void* y,
+int eve_stem7x7s2_fwd(int dtype, int N, int IH, int IW, const void* x_padded, const void* w_ohwi8, void* y,
                       eve_stream_t stream);
 /* Decoded uint8 frames on the device (datasources/eve_sequences.py:196-211 does this on the host and ships floats):
  * dst[n][c][y][x] (float) = src[n][y][x][c] * scale (+ shift): eye patches scale 2/255, shift -1; screen frames
@@ -95,20 +95,20 @@ int eve_frames_u8_to_nchw(long long N, int H, int W, int C, const uint8_t* src_n
                           int has_shift, float* dst_nchw, eve_stream_t stream);
 /* ... and the same values straight into the stem kernels' packed input x_padded [N][IH+6][IW+8][4] bf16 (what
  * eve_stem_pack_input builds from the float NCHW tensor).                                                      */
-int eve_frames_u8_to_stem(long long N, int C, int IH, int IW, const uint8_t* src_nhwc, float scale, float shift,
+int eve_frames_u8_to_stem(int dtype, long long N, int C, int IH, int IW, const uint8_t* src_nhwc, float scale, float shift,
                           void* x_padded, eve_stream_t stream);
 /* The whole stem in one launch: conv1 -> bn1 (InstanceNorm2d, no affine) -> relu -> maxpool 3x3/2 pad 1
  * (torchvision ResNet._forward_impl as built by eye_net.py:48-50).  The 64-channel convolution output is never
  * written: y_pool [N][IH/4][IW/4][64] bf16, idx (window position kh*3+kw of the arg-max, same shape, uint8) and
  * mean_rstd [N][64][2] are the only outputs.  IW == 128, IH a multiple of 4.                              */
-int eve_stem_fwd_fused(int N, int IH, int IW, const void* x_padded, const void* w_ohwi8, float eps,
+int eve_stem_fwd_fused(int dtype, int N, int IH, int IW, const void* x_padded, const void* w_ohwi8, float eps,
                        void* y_pool, uint8_t* idx, float* mean_rstd, eve_stream_t stream);
 /* Its backward up to the convolution output: dx [N][IH/2][IW/2][64] bf16 = d(conv1 out) from dy_pool, recomputing
  * the convolution from x_padded (autograd of bn1/relu/maxpool in eye_net.py:106); feed dx to eve_conv2d_wgrad. */
 /* ... and the stem's weight gradient from the same packed patches: dw [64][7][8][4] float (accumulated; filter
  * column 7 and channel 3 do not exist and are ignored by the caller).  Replaces autograd of conv1 (eye_net.py:106). */
-int eve_stem_wgrad(int N, int IH, int IW, const void* x_padded, const void* dconv, float* dw, eve_stream_t stream);
-int eve_stem_bwd_dx(int N, int IH, int IW, const void* x_padded, const void* w_ohwi8, const float* mean_rstd,
+int eve_stem_wgrad(int dtype, int N, int IH, int IW, const void* x_padded, const void* dconv, float* dw, eve_stream_t stream);
+int eve_stem_bwd_dx(int dtype, int N, int IH, int IW, const void* x_padded, const void* w_ohwi8, const float* mean_rstd,
                     const void* dy_pool, const void* dy_pool2 /* nullable second summand */, const void* y_pool, const uint8_t* idx, void* dx, eve_stream_t stream);
 /* Small float32 linear layers (nn.Linear of the EyeNet tail, eye_net.py:52-90: fc, fc_common, GRU input
  * projection, gaze / pupil heads) with M rows and K, N <= 4096:
@@ -299,14 +299,14 @@ int eve_lstm_scan_bwd(int S, int T, int H, const float* dhs, const float* dcs, c
  * [128][3][3][128] (inputs x|h), w2 = gate_2 OHWI [64][3][3][128] (inputs r*h|x); outputs: hs [B][T][5][8][64]
  * (state, caller's order) and, TIME-major [T][B][5][8][.] for the frame-reversed backward: hs_tm, ru (both sigmoid
  * gates, 128 ch), rh (r*h), og (tanh gate).                                                               */
-int eve_cgru_scan_fwd(int B, int T, const void* xs, const void* h0, const void* w1, const float* b1, const void* w2,
+int eve_cgru_scan_fwd(int dtype, int B, int T, const void* xs, const void* h0, const void* w1, const float* b1, const void* w2,
                       const float* b2, void* hs, void* hs_tm, void* ru, void* rh, void* og, eve_stream_t stream);
 /* Backward of eve_cgru_scan_fwd in ONE persistent launch (bf16; common.py:400-415 differentiated): frames last to first, the
  * gradient into the previous hidden state carried in registers.  Time-major inputs [T][B][5][8][.]: dhs_tm (d hs), and the
  * forward's ru / og / hs_tm; h0 or NULL; w1t = gates_1 bank IHWO [128][3][3][128], w2t = gate_2 bank IHWO [128][3][3][64].
  * Outputs (time-major): dg1_all [..][128], dg2_all [..][64] (pre-activation gradients: the operands of the batched weight /
  * bias gradients), dxs_tm [..][64]; dh0 [B][5][8][64] or NULL.                                                             */
-int eve_cgru_scan_bwd(int B, int T, const void* dhs_tm, const void* ru, const void* og, const void* hs_tm, const void* h0,
+int eve_cgru_scan_bwd(int dtype, int B, int T, const void* dhs_tm, const void* ru, const void* og, const void* hs_tm, const void* h0,
                       const void* w1t, const void* w2t, void* dg1_all, void* dg2_all, void* dxs_tm, void* dh0,
                       eve_stream_t stream);
 int eve_cgru_gates1(int dtype, long long P, int C, const void* g1, const void* h, void* ru, void* rh,

@@ -28,21 +28,27 @@ import torch
 from torch.nn import functional as F
 
 _ENABLED = True
+_FORMAT = torch.bfloat16          # the 16-bit storage format the rounding points model: bfloat16 or float16
 
 
 @contextlib.contextmanager
-def rounding(enabled):
-    """rounding(False): every rounding point becomes the identity (float32 oracle arithmetic)."""
-    global _ENABLED
-    old, _ENABLED = _ENABLED, bool(enabled)
+def rounding(enabled, fmt=torch.bfloat16):
+    """rounding(False): every rounding point becomes the identity (float32 oracle arithmetic).
+    rounding(True, torch.float16): the float16 instantiation of the kernels (BASELINE configs[4]) -- same rounding points,
+    IEEE half instead of bfloat16 (the kernels are templates over the format; nothing else differs)."""
+    global _ENABLED, _FORMAT
+    assert fmt in (torch.bfloat16, torch.float16)
+    old, _ENABLED = (_ENABLED, _FORMAT), bool(enabled)
+    _FORMAT = fmt
     try:
         yield
     finally:
-        _ENABLED = old
+        _ENABLED, _FORMAT = old
 
 
 def _bf16(x):
-    return x.to(torch.bfloat16).to(torch.float32) if _ENABLED else x
+    """x rounded to the active 16-bit format (named after the default one)."""
+    return x.to(_FORMAT).to(torch.float32) if _ENABLED else x
 
 
 class _Round(torch.autograd.Function):

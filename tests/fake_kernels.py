@@ -72,17 +72,17 @@ class FakeKernels(object):
         dw_ohwi += dw.permute(0, 2, 3, 1)
         return dw_ohwi
 
-    def stem_pack_input(self, src_nchw, out=None):
+    def stem_pack_input(self, src_nchw, out=None, dtype=torch.bfloat16):
         N, C, H, W = src_nchw.shape
-        dst = torch.zeros((N, H + 6, W + 8, 4), dtype=torch.bfloat16) if out is None else out
+        dst = torch.zeros((N, H + 6, W + 8, 4), dtype=dtype) if out is None else out
         dst.zero_()
-        dst[:, 3:H + 3, 4:W + 4, :C] = src_nchw.permute(0, 2, 3, 1).to(torch.bfloat16)
+        dst[:, 3:H + 3, 4:W + 4, :C] = src_nchw.permute(0, 2, 3, 1).to(dst.dtype)
         return dst
 
     def stem7x7s2_fwd(self, x_padded, w_ohwi8):
         x = x_padded[:, 3:-3, 4:-4, :].float().permute(0, 3, 1, 2)
         w = w_ohwi8[..., :4].float().permute(0, 3, 1, 2)
-        return nhwc(F.conv2d(x, w, None, 2, 3), torch.bfloat16)
+        return nhwc(F.conv2d(x, w, None, 2, 3), x_padded.dtype)
 
     def stem_fwd_fused(self, x_padded, w_ohwi8, eps=1e-5):
         conv = self.stem7x7s2_fwd(x_padded, w_ohwi8)

@@ -99,9 +99,16 @@ def check_param_grads(params, ref_params, names, what, tol=BWD_LOCAL, zero_grad=
     return worst
 
 
+FORMATS = pytest.mark.parametrize('fmt', [torch.bfloat16, torch.float16], ids=['bf16', 'fp16'])
+# float16 (BASELINE configs[4]) keeps 3 more mantissa bits than bfloat16, so the SAME tolerances hold with margin; its
+# narrower exponent is handled the way train.Trainer does it: the root gradient carries the static loss scale.
+FP16_LOSS_SCALE = 1024.0
+
+
+@FORMATS
 @pytest.mark.parametrize('B,T,seed,band_wgrad', [(2, 3, 0, False), (4, 30, 17, False), (2, 3, 0, True)],
                          ids=['fixture-shape', 'configs1-slice', 'fixture-shape-band-resident-wgrad'])
-def test_eyenet_bf16_stages_teacher_forced_match_rounding_faithful_oracle(B, T, seed, band_wgrad, monkeypatch):
+def test_eyenet_bf16_stages_teacher_forced_match_rounding_faithful_oracle(B, T, seed, band_wgrad, monkeypatch, fmt):
     """Stem, the eight residual blocks and the average pool of the bf16 trunk (BASELINE configs[1]'s kernels: fused stem
     forward / backward-by-recomputation + packed-patch weight gradient, halo and LDS-DMA convolutions, parity-class
     strided dgrad, transposing-read weight gradients, register-resident InstanceNorm forward / backward), each fed the
@@ -118,22 +125,23 @@ def test_eyenet_bf16_stages_teacher_forced_match_rounding_faithful_oracle(B, T, 
     ref = detweights.fill_module(OracleEyeNet(cfg), seed=0)
     x = torch.cat([batch['left_eye_patch'].reshape(B * T, 3, 128, 128), batch['right_eye_patch'].reshape(B * T, 3, 128, 128)])
     taps = {}
-    feats = bf.resnet_trunk(ref.cnn_layers, x, taps)
-    g = torch.Generator().manual_seed(seed)
-    (feats * torch.randn(feats.shape, generator=g)).sum().backward()
-    net, _ = make_eyenet()
+    with bf.rounding(True, fmt):
+        feats = bf.resnet_trunk(ref.cnn_layers, x, taps)
+        g = torch.Generator().manual_seed(seed)
+        (feats * torch.randn(feats.shape, generator=g)).sum().backward()
+    net, _ = make_eyenet(fmt)
     P = net._get_packs()
     k = default_kernels()
     cnn = net.cnn_layers
     params, rparams = dict(cnn.named_parameters()), dict(ref.cnn_layers.named_parameters())
     N = x.shape[0]
-    xp = torch.empty((N, 134, 136, 4), dtype=torch.bfloat16, device='cuda')
+    xp = torch.empty((N, 134, 136, 4), dtype=fmt, device='cuda')
     k.stem_pack_input(x.cuda(), out=xp)
     # ---- stem: forward, then backward from the oracle's d(stem output) ----
     y = ops.ResNetTrunkFn.apply(None, None, xp, (P['conv1'], ()), 1e-5, cnn.conv1.weight)
     e = rel_l2(from_nhwc(y, 64), taps['stem'])
     assert e <= FWD_LOCAL, 'stem forward: relative L2 %.3e' % e
-    y.backward(to_nhwc(taps['stem'].grad, 64))
+    y.backward(to_nhwc(taps['stem'].grad, 64, fmt))
     report = ['stem fwd %.1e dW %.1e' % (e, check_param_grads(params, rparams, ['conv1.weight'], 'stem'))]
     # ---- residual blocks ----
     prev = 'stem'
@@ -143,21 +151,21 @@ def test_eyenet_bf16_stages_teacher_forced_match_rounding_faithful_oracle(B, T, 
         weights = [blk.conv1.weight, blk.conv2.weight] + ([ds[0].weight] if ds is not None else [])
         wnames = [name + '.conv1.weight', name + '.conv2.weight'] + ([name + '.downsample.0.weight'] if ds is not None else [])
         cin = taps[prev].shape[1]
-        xin = to_nhwc(taps[prev], cin).requires_grad_(True)
+        xin = to_nhwc(taps[prev], cin, fmt).requires_grad_(True)
         out = ops.ResNetTrunkFn.apply(xin, None, None, (None, ((packs, blk.stride),)), 1e-5, *weights)
         ef = rel_l2(from_nhwc(out, out.shape[-1]), taps[name])
         assert ef <= FWD_LOCAL, '%s forward: relative L2 %.3e' % (name, ef)
-        out.backward(to_nhwc(taps[name].grad, out.shape[-1]))
+        out.backward(to_nhwc(taps[name].grad, out.shape[-1], fmt))
         eb = rel_l2(from_nhwc(xin.grad, cin), taps[prev].grad)
         assert eb <= BWD_LOCAL, '%s input gradient: relative L2 %.3e' % (name, eb)
         ew = check_param_grads(params, rparams, wnames, name)
         report.append('%s fwd %.1e dx %.1e dW %.1e' % (name, ef, eb, ew))
         prev = name
     # ---- average pool ----
-    yin = to_nhwc(taps[prev], 512).requires_grad_(True)
+    yin = to_nhwc(taps[prev], 512, fmt).requires_grad_(True)
     pooled = ops.AvgPoolFn.apply(yin)
     assert rel_l2(pooled.float().cpu(), taps['pooled']) <= FWD_LOCAL
-    pooled.backward(taps['pooled'].grad.to(torch.bfloat16).cuda())
+    pooled.backward(taps['pooled'].grad.to(fmt).cuda())
     assert rel_l2(from_nhwc(yin.grad, 512), taps[prev].grad) <= BWD_LOCAL
     print('; '.join(report))
 
@@ -223,8 +231,9 @@ class TeacherForce(object):
         return leaf
 
 
+@FORMATS
 @pytest.mark.parametrize('B,T,seed', [(2, 3, 0), (4, 30, 5)], ids=['fixture-shape', 'configs2-slice'])
-def test_refinenet_bf16_stages_teacher_forced_match_rounding_faithful_oracle(B, T, seed):
+def test_refinenet_bf16_stages_teacher_forced_match_rounding_faithful_oracle(B, T, seed, fmt):
     """Every stage of RefineNet.forward_sequence in bf16 (BASELINE configs[2]: pixel-group / halo / LDS-DMA convolutions
     with bias, multi-pass and register-resident affine InstanceNorm, adaptive max-pool, bilinear up-sampling, the fused
     conv-GRU scan and its backward, the float sigmoid head, the HIP BCE loss) fed the oracle's input and output gradient
@@ -235,10 +244,12 @@ def test_refinenet_bf16_stages_teacher_forced_match_rounding_faithful_oracle(B, 
     rb = detweights.refinenet_batch(B, T, seed=seed, invalid_fraction=0.2)
     ref = detweights.fill_module(OracleRefineNet(ocfg), seed=1)
     taps = {}
-    rhf, _ = bf.refinenet_sequence(ref, rb['heatmap_initial'], rb['screen_frame'], taps=taps)
-    rhf.retain_grad()
-    rterms = sequence.refinenet_losses(rhf, rb['heatmap_final_gt'], rb['validity'], ocfg)
-    rterms['full_loss'].backward()
+    S = FP16_LOSS_SCALE if fmt == torch.float16 else 1.0        # the Trainer's static loss scale: both sides back-propagate S * loss
+    with bf.rounding(True, fmt):
+        rhf, _ = bf.refinenet_sequence(ref, rb['heatmap_initial'], rb['screen_frame'], taps=taps)
+        rhf.retain_grad()
+        rterms = sequence.refinenet_losses(rhf, rb['heatmap_final_gt'], rb['validity'], ocfg)
+        (rterms['full_loss'] * S).backward()
     # conv biases with an exactly-zero gradient, identified on the float32 oracle: |d bias| < 1e-4 |d weight| there
     plain = detweights.fill_module(OracleRefineNet(ocfg), seed=1)
     with bf.rounding(False):
@@ -248,7 +259,7 @@ def test_refinenet_bf16_stages_teacher_forced_match_rounding_faithful_oracle(B, 
     zero_grad = {n for n in pp if n.endswith('.bias') and n[:-4] + 'weight' in pp and pp[n].dim() == 1 and pp[n[:-4] + 'weight'].dim() == 4
                  and float(pp[n].grad.norm()) < 1e-4 * float(pp[n[:-4] + 'weight'].grad.norm())}
     assert 20 <= len(zero_grad) <= 40, sorted(zero_grad)
-    net, cfg = make_refinenet()
+    net, cfg = make_refinenet(fmt)
     probe = TeacherForce(taps)
     net._probe = probe
     drb = to_dev(rb)
@@ -260,8 +271,8 @@ def test_refinenet_bf16_stages_teacher_forced_match_rounding_faithful_oracle(B, 
     for kk in ('loss_ce_heatmap_final', 'loss_mse_heatmap_final'):
         np.testing.assert_allclose(float(terms[kk].detach()), float(rterms[kk].detach()), rtol=2e-5, err_msg=kk)
     names = [n for n in probe.hip if probe.hip[n].requires_grad]
-    roots = [terms['full_loss']] + [probe.hip[n] for n in names]
-    grads = [None] + [to_nhwc(taps[n].grad, probe.hip[n].shape[-1]) for n in names]
+    roots = [terms['full_loss'] * S] + [probe.hip[n] for n in names]
+    grads = [None] + [to_nhwc(taps[n].grad, probe.hip[n].shape[-1], fmt) for n in names]
     torch.autograd.backward(roots, grads)
     report = []
     for n in probe.hip:

@@ -287,13 +287,18 @@ def test_eve_config_variants_match_oracle(over):
     eve_amd.reset_standalone_config()
 
 
-def test_configs4_long_sequence_large_patches_whole_pipeline():
+_CONFIGS4 = {}
+
+
+@pytest.mark.parametrize('half', [torch.bfloat16, torch.float16], ids=['bf16', 'fp16'])
+def test_configs4_long_sequence_large_patches_whole_pipeline(half):
     """BASELINE configs[4] as one case: T = 120 frames, 256 x 256 eye patches, EyeNet + RefineNet (CGRU) together, the
-    conv-GRU / GRU hidden state carried on-chip across all 120 frames.  The reference is float32 only and the build's
-    reduced-precision mode is bf16 (it stands in for the fp16 configs[4] names: same 16-bit storage and MFMA rate, no
-    loss scaling needed): (1) float32 forward of the whole pipeline against the CPU oracle -- gaze within 1e-4 rad,
-    refined heat-map PoG within half a pixel; (2) one bf16 optimiser step of both networks at that size through
-    train.eve_trainer -- finite losses and gradients, weights move, bf16 gaze within the bf16 envelope of float32."""
+    conv-GRU / GRU hidden state carried on-chip across all 120 frames, in BOTH 16-bit instantiations of the kernels:
+    float16 (what configs[4] names; static loss scale in the Trainer) and bfloat16 (the headline configs[1] format).  The
+    reference is float32 only, so: (1) float32 forward of the whole pipeline against the CPU oracle -- gaze within 1e-4
+    rad, refined heat-map PoG within half a pixel; (2) one 16-bit optimiser step of both networks at that size through
+    train.eve_trainer -- finite losses and gradients, weights move, 16-bit gaze within the format's envelope of float32
+    (float16's 11-bit significand must land closer than bfloat16's 8-bit one)."""
     from eve_amd import train
     from oracle.eye_net import EyeNet as OracleEyeNet
     from oracle.refine_net import RefineNet as OracleRefineNet
@@ -305,33 +310,44 @@ def test_configs4_long_sequence_large_patches_whole_pipeline():
     patches = detweights.eyenet_batch(B, T, size=size, seed=42)
     for k in ('left_eye_patch', 'right_eye_patch'):
         batch[k] = patches[k]
-    ocfg = OracleConfig(json_path, **over)
-    oeye, oref = detweights.fill_module(OracleEyeNet(ocfg), 0), detweights.fill_module(OracleRefineNet(ocfg), 1)
-    with torch.no_grad():
-        want, winter, _ = oracle_eve.eve_forward(oeye, oref, dict(batch), ocfg, False)
+    if 'winter' not in _CONFIGS4:                       # the CPU oracle's forward is shared by the two cases
+        ocfg = OracleConfig(json_path, **over)
+        oeye, oref = detweights.fill_module(OracleEyeNet(ocfg), 0), detweights.fill_module(OracleRefineNet(ocfg), 1)
+        with torch.no_grad():
+            _, winter, _ = oracle_eve.eve_forward(oeye, oref, dict(batch), ocfg, False)
+        _CONFIGS4['winter'] = {k: winter[k].detach() for k in ('g_initial', 'g_final', 'PoG_px_final')}
+    winter = _CONFIGS4['winter']
     res = {}
-    for dt in (torch.float32, torch.bfloat16):
+    for dt in (torch.float32, half):
+        if dt == torch.float32 and 'f32' in _CONFIGS4:
+            res[dt] = _CONFIGS4['f32']
+            continue
         model = make_eve(over, dtype=dt)
         dbatch = {k: v.cuda() for k, v in batch.items()}
         with torch.no_grad():
             model.eval()
             got = model(dict(dbatch), current_epoch=0.0)
         res[dt] = {k: got[k].detach().float().cpu() for k in ('g_initial', 'g_final', 'PoG_px_final')}
-        if dt == torch.bfloat16:
+        if dt == torch.float32:
+            _CONFIGS4['f32'] = res[dt]
+        else:
             cfg = eve_amd.get_config()
             tr = train.eve_trainer(model.train(), cfg)
             assert len(tr.modules) == 2
+            assert tr.loss_scale == (1024.0 if dt == torch.float16 else 1.0)
             before = tr.fp.flat.clone()
             terms = tr.step(dbatch)
             torch.cuda.synchronize()
             assert all(bool(torch.isfinite(v).all()) for v in terms.values() if torch.is_tensor(v))
             assert bool(torch.isfinite(tr.fp.grad).all()) and float(tr.fp.grad.abs().max()) > 0
             assert float((tr.fp.flat - before).abs().max()) > 0
-    f32, b16 = res[torch.float32], res[torch.bfloat16]
+    f32, h16 = res[torch.float32], res[half]
     for k in ('g_initial', 'g_final'):
-        assert float((f32[k] - winter[k].detach()).abs().max()) < 1e-4, k
-    assert float((f32['PoG_px_final'] - winter['PoG_px_final'].detach()).abs().max()) < 0.5
-    assert float((b16['g_initial'] - f32['g_initial']).abs().max()) < 0.08
+        assert float((f32[k] - winter[k]).abs().max()) < 1e-4, k
+    assert float((f32['PoG_px_final'] - winter['PoG_px_final']).abs().max()) < 0.5
+    dev = float((h16['g_initial'] - f32['g_initial']).abs().max())
+    print('%s gaze vs float32: %.3e rad' % (half, dev))
+    assert dev < (0.08 if half == torch.bfloat16 else 0.02)
     # the recurrences matter at this length: the refined estimate at the last frame differs from the first frame's
     assert float((winter['PoG_px_final'][:, -1] - winter['PoG_px_final'][:, 0]).abs().max()) > 1.0
     eve_amd.reset_standalone_config()

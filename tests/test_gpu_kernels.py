@@ -2,7 +2,8 @@
 against an independent ATen restatement of its contract (tests/fake_kernels.py run on the CPU).
 
 float32 kernels must agree to float32 round-off (the f32 MFMA is an exact fmaf chain);
-bfloat16 kernels are compared at bf16 resolution with inputs pre-rounded to bf16 on both sides.
+bfloat16 / float16 kernels (the same templates over the 16-bit format) are compared at that format's resolution with
+inputs pre-rounded to it on both sides.
 """
 import numpy as np
 import pytest
@@ -12,7 +13,9 @@ from fake_kernels import FakeKernels
 
 pytestmark = pytest.mark.gpu
 
-DTYPES = [torch.float32, torch.bfloat16]
+DTYPES = [torch.float32, torch.bfloat16, torch.float16]
+DT_IDS = ['f32', 'bf16', 'fp16']
+HALVES = pytest.mark.parametrize('hdt', [torch.bfloat16, torch.float16], ids=['bf16', 'fp16'])
 
 
 @pytest.fixture(scope='module')
@@ -41,13 +44,13 @@ def close(got, want, dtype, what, scale=None):
     assert got.shape == want.shape, '%s: shape %s vs %s' % (what, got.shape, want.shape)
     assert torch.isfinite(got).all(), '%s: non-finite values' % what
     s = float(want.abs().max()) if scale is None else scale
-    tol = (3e-5 if dtype == torch.float32 else 1.6e-2) * max(s, 1e-6)
+    tol = {torch.float32: 3e-5, torch.bfloat16: 1.6e-2, torch.float16: 2e-3}[dtype] * max(s, 1e-6)
     err = float((got - want).abs().max())
     assert err <= tol, '%s: max|diff| %.3e > tol %.3e (scale %.3e)' % (what, err, tol, s)
     # and in the mean: both sides round the same float32 result to bf16, so only a few elements may sit one ulp apart;
     # a defect of relative size 1e-2 anywhere in the kernel fails this
     rel = float((got - want).norm()) / max(float(want.norm()), 1e-30)
-    assert rel <= (2e-5 if dtype == torch.float32 else 3e-3) or err <= 1e-6 * max(s, 1e-6), \
+    assert rel <= {torch.float32: 2e-5, torch.bfloat16: 3e-3, torch.float16: 4e-4}[dtype] or err <= 1e-6 * max(s, 1e-6), \
         '%s: relative L2 %.3e' % (what, rel)
 
 
@@ -81,12 +84,12 @@ def conv_case_id(c):
     return 'N%d_%dx%d_c%d-%d_k%d_s%d' % c[:7]
 
 
-@pytest.mark.parametrize('dtype', DTYPES, ids=['f32', 'bf16'])
+@pytest.mark.parametrize('dtype', DTYPES, ids=DT_IDS)
 @pytest.mark.parametrize('case', CONV_CASES, ids=conv_case_id)
 def test_conv_fwd_dgrad_wgrad(hip, ref, dtype, case):
     N, IH, IW, Cin, Cout, K, stride, pad = case
-    if dtype == torch.bfloat16 and (Cin % 8 or Cout % 8):
-        pytest.skip('bf16 needs 8-channel vectors')
+    if dtype != torch.float32 and (Cin % 8 or Cout % 8):
+        pytest.skip('16-bit formats need 8-channel vectors')
     x = rnd((N, IH, IW, Cin), dtype, 1)
     w = rnd((Cout, K, K, Cin), dtype, 2, scale=(2.0 / (K * K * Cin)) ** 0.5)
     bias = rnd((Cout,), torch.float32, 3)
@@ -117,9 +120,9 @@ def test_conv_fwd_dgrad_wgrad(hip, ref, dtype, case):
     close(got_db2, want_db + db0, dtype, 'bias grad fused into wgrad')
 
 
-@pytest.mark.parametrize('dtype', DTYPES, ids=['f32', 'bf16'])
+@pytest.mark.parametrize('dtype', DTYPES, ids=DT_IDS)
 def test_conv_small_cout_and_epilogues(hip, ref, dtype):
-    if dtype == torch.bfloat16:
+    if dtype != torch.float32:
         pytest.skip('tail runs in float32')
     for Cout, act in ((2, 4), (1, 1), (4, 3), (6, 5), (12, 2)):
         x = rnd((19, 1, 1, 128), dtype, 5)
@@ -129,7 +132,7 @@ def test_conv_small_cout_and_epilogues(hip, ref, dtype):
               ref.conv2d_fwd(x, w, b, 1, 0, epi_act=act), dtype, 'conv Cout=%d act=%d' % (Cout, act))
 
 
-@pytest.mark.parametrize('dtype', DTYPES, ids=['f32', 'bf16'])
+@pytest.mark.parametrize('dtype', DTYPES, ids=DT_IDS)
 def test_conv_prologue_fused_instnorm(hip, ref, dtype):
     N, H, W, Cin, Cout = 3, 16, 16, 64, 128
     x = rnd((N, H, W, Cin), dtype, 8)
@@ -146,26 +149,28 @@ def test_conv_prologue_fused_instnorm(hip, ref, dtype):
           dtype, 'wgrad prologue')
 
 
-def test_stem_conv_dedicated_kernel(hip, ref):
+@HALVES
+def test_stem_conv_dedicated_kernel(hip, ref, hdt):
     src = rnd((3, 3, 128, 128), torch.float32, 60)
-    xp_w = ref.stem_pack_input(src)
-    xp_g = hip.stem_pack_input(dev(src))
+    xp_w = ref.stem_pack_input(src, dtype=hdt)
+    xp_g = hip.stem_pack_input(dev(src), dtype=hdt)
     assert torch.equal(xp_g.cpu().view(torch.int16), xp_w.view(torch.int16))
-    w = rnd((64, 7, 7, 8), torch.bfloat16, 61, scale=0.08)
+    w = rnd((64, 7, 7, 8), hdt, 61, scale=0.08)
     w[..., 3:] = 0
-    close(hip.stem7x7s2_fwd(xp_g, dev(w)), ref.stem7x7s2_fwd(xp_w, w), torch.bfloat16, 'stem 7x7/2')
+    close(hip.stem7x7s2_fwd(xp_g, dev(w)), ref.stem7x7s2_fwd(xp_w, w), hdt, 'stem 7x7/2')
     # and against the generic implicit-GEMM path on the 8-channel NHWC input
-    x8 = hip.nchw_to_nhwc(dev(src), torch.bfloat16, 8)
-    close(hip.stem7x7s2_fwd(xp_g, dev(w)), hip.conv2d_fwd(x8, dev(w), None, 2, 3), torch.bfloat16, 'stem vs generic')
+    x8 = hip.nchw_to_nhwc(dev(src), hdt, 8)
+    close(hip.stem7x7s2_fwd(xp_g, dev(w)), hip.conv2d_fwd(x8, dev(w), None, 2, 3), hdt, 'stem vs generic')
 
 
+@HALVES
 @pytest.mark.parametrize('N', [3, 19])
-def test_stem_fused_forward_matches_unfused(hip, N):
+def test_stem_fused_forward_matches_unfused(hip, N, hdt):
     """conv1 -> IN -> ReLU -> maxpool in one launch == the three-kernel path (which the oracle tests pin)."""
     src = rnd((N, 3, 128, 128), torch.float32, 62) + 0.3
-    w = rnd((64, 7, 7, 8), torch.bfloat16, 63, scale=0.08)
+    w = rnd((64, 7, 7, 8), hdt, 63, scale=0.08)
     w[..., 3:] = 0
-    xp = hip.stem_pack_input(dev(src))
+    xp = hip.stem_pack_input(dev(src), dtype=hdt)
     y_f, idx_f, mr_f = hip.stem_fwd_fused(xp, dev(w))
     conv = hip.stem7x7s2_fwd(xp, dev(w))
     mr_u = hip.instnorm_stats(conv, 1e-5)
@@ -188,15 +193,16 @@ def test_stem_fused_forward_matches_unfused(hip, N):
     assert d.max().item() < 0.05 and d.mean().item() < 4e-3, (d.max().item(), d.mean().item())
 
 
+@HALVES
 @pytest.mark.parametrize('N', [2, 17])
-def test_stem_fused_backward_matches_unfused(hip, N):
+def test_stem_fused_backward_matches_unfused(hip, N, hdt):
     """d(conv1 out) by recomputation == the dense IN+ReLU+maxpool backward on the stored conv output."""
     src = rnd((N, 3, 128, 128), torch.float32, 64) + 0.2
-    w = rnd((64, 7, 7, 8), torch.bfloat16, 65, scale=0.08)
+    w = rnd((64, 7, 7, 8), hdt, 65, scale=0.08)
     w[..., 3:] = 0
-    xp = hip.stem_pack_input(dev(src))
+    xp = hip.stem_pack_input(dev(src), dtype=hdt)
     y, idx, mr = hip.stem_fwd_fused(xp, dev(w))
-    dy = dev(rnd(tuple(y.shape), torch.bfloat16, 66))
+    dy = dev(rnd(tuple(y.shape), hdt, 66))
     dx_f = hip.stem_bwd_dx(xp, dev(w), mr, dy, y, idx)
     conv = hip.stem7x7s2_fwd(xp, dev(w))
     dx_u = hip.in_relu_maxpool_bwd(dy, y, idx, conv, mr)
@@ -231,13 +237,14 @@ def test_small_linear_kernels(hip, ref, shape, act):
     assert torch.allclose(db.cpu(), db_ref, rtol=2e-4, atol=2e-4 * (M ** 0.5))
 
 
-def test_stem_wgrad_from_packed_patches(hip):
+@HALVES
+def test_stem_wgrad_from_packed_patches(hip, hdt):
     """conv1's weight gradient read from the 4-channel packed patches (7x8-tap view) == the generic kernel on NHWC8."""
     N = 5
     src = rnd((N, 3, 128, 128), torch.float32, 67)
-    xp = hip.stem_pack_input(dev(src))
-    x8 = hip.nchw_to_nhwc(dev(src), torch.bfloat16, 8)
-    dconv = dev(rnd((N, 64, 64, 64), torch.bfloat16, 68))
+    xp = hip.stem_pack_input(dev(src), dtype=hdt)
+    x8 = hip.nchw_to_nhwc(dev(src), hdt, 8)
+    dconv = dev(rnd((N, 64, 64, 64), hdt, 68))
     dw = torch.zeros((64, 7, 8, 4), device='cuda')
     hip.stem_wgrad(xp, dconv, dw)
     want = hip.conv2d_wgrad(x8, dconv, 7, 7, 2, 3, torch.zeros((64, 7, 7, 8), device='cuda'))
@@ -262,7 +269,7 @@ PLANE_CASES = [(3, 32, 32, 64), (2, 4, 4, 512), (2, 5, 8, 64), (2, 72, 128, 16),
                (11, 32, 32, 64)]         # (planes of 4 097 .. 8 192 vectors are dealt to two workgroups, 8 blocks apart)
 
 
-@pytest.mark.parametrize('dtype', DTYPES, ids=['f32', 'bf16'])
+@pytest.mark.parametrize('dtype', DTYPES, ids=DT_IDS)
 @pytest.mark.parametrize('shape', PLANE_CASES, ids=lambda s: 'x'.join(map(str, s)))
 def test_instnorm_fwd_bwd(hip, ref, dtype, shape):
     N, H, W, C = shape
@@ -372,7 +379,7 @@ torch.save(outs, sys.argv[1])
     assert compared >= 4
 
 
-@pytest.mark.parametrize('dtype', DTYPES, ids=['f32', 'bf16'])
+@pytest.mark.parametrize('dtype', DTYPES, ids=DT_IDS)
 def test_elementwise(hip, ref, dtype):
     for n in (8 * 1000, 8 * 1000 + 3):
         a, b = rnd((n,), dtype, 19), rnd((n,), dtype, 20)
@@ -382,7 +389,7 @@ def test_elementwise(hip, ref, dtype):
             close(hip.act_bwd(dev(b), dev(y), act), ref.act_bwd(b, y, act), dtype, 'act_bwd %d' % act)
 
 
-@pytest.mark.parametrize('dtype', DTYPES, ids=['f32', 'bf16'])
+@pytest.mark.parametrize('dtype', DTYPES, ids=DT_IDS)
 def test_pooling_and_resize(hip, ref, dtype):
     x = torch.relu(rnd((2, 64, 64, 64), dtype, 21))          # post-ReLU: many exact ties at 0
     y_w, idx_w = ref.maxpool3x3s2_fwd(x)
@@ -421,7 +428,7 @@ def test_pooling_and_resize(hip, ref, dtype):
         close(hip.bilinear_bwd(dev(dyu), (oh, ow)), ref.bilinear_bwd(dyu, (oh, ow)), dtype, 'bilinear bwd')
 
 
-@pytest.mark.parametrize('dtype', DTYPES, ids=['f32', 'bf16'])
+@pytest.mark.parametrize('dtype', DTYPES, ids=DT_IDS)
 def test_layout_and_pack(hip, ref, dtype):
     src = rnd((3, 3, 16, 24), torch.float32, 29)
     cpad = 4 if dtype == torch.float32 else 8
@@ -498,7 +505,7 @@ def test_rnn_and_lstm_scans(hip, ref, H):
                     close(a, b, torch.float32, name + ' backward')
 
 
-@pytest.mark.parametrize('dtype', DTYPES, ids=['f32', 'bf16'])
+@pytest.mark.parametrize('dtype', DTYPES, ids=DT_IDS)
 def test_cgru_gates(hip, ref, dtype):
     P, C = (3, 5, 8), 64
     g1, g2 = rnd(P + (2 * C,), dtype, 36), rnd(P + (C,), dtype, 37)
@@ -697,40 +704,3 @@ def test_heatmap_head_and_losses_match_aten():
         a, b = p_dev.grad.cpu(), p_ref.grad
         assert torch.isfinite(a).all()
         assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max()) + 1e-9, kind
-
-
-@pytest.mark.parametrize('switch', ['EVE_HALO_MFMA32', 'EVE_HALO_MT'])
-def test_opt_in_halo_kernels_match_default(tmp_path, switch):
-    """EVE_HALO_MFMA32=1 selects the 32x32x16-MFMA, software-pipelined halo convolution (conv_halo32.h) and EVE_HALO_MT=1 the
-    256-pixel macro tile with one wave per SIMD (conv_halo_mt.h); both are kept opt-in (slower than the default, see their
-    headers).  The switches are read once per process, so the comparison runs in a child process: forward and data gradient
-    of the four halo geometries (W = 32 / 16 / 8 / 4 swizzles, ragged image counts) against the default kernel's results."""
-    import os
-    import subprocess
-    import sys
-    code = r'''
-import sys, torch
-sys.path.insert(0, %r)
-from eve_amd.kernels import HipKernels
-k = HipKernels()
-g = torch.Generator().manual_seed(3)
-outs = []
-for N, H, C in ((20, 32, 64), (13, 16, 128), (25, 8, 256), (70, 4, 512)):
-    x = torch.randn((N, H, H, C), generator=g).bfloat16().cuda()
-    w = (torch.randn((128 if C < 512 else 256, 3, 3, C), generator=g) * (2.0 / (9 * C)) ** 0.5).bfloat16().cuda()
-    b = torch.randn((w.shape[0],), generator=g).cuda()
-    y = k.conv2d_fwd(x, w, b, 1, 1, 1)
-    dy = torch.randn(y.shape, generator=g).bfloat16().cuda()
-    dx = k.conv2d_dgrad(dy, w.permute(3, 1, 2, 0).contiguous(), (H, H), 1, 1)
-    outs += [y.float().cpu(), dx.float().cpu()]
-torch.save(outs, sys.argv[1])
-''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    res = {}
-    for mode in ('0', '1'):
-        path = os.path.join(str(tmp_path), 'halo%s.pt' % mode)
-        env = dict(os.environ, **{switch: mode})
-        p = subprocess.run([sys.executable, '-c', code, path], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
-        assert p.returncode == 0, p.stdout[-2000:]
-        res[mode] = torch.load(path)
-    for a, b in zip(res['1'], res['0']):
-        assert float((a - b).norm() / b.norm()) < 2e-3 and float((a - b).abs().max()) <= 1.6e-2 * float(b.abs().max())
