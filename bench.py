@@ -48,7 +48,7 @@ def synthetic_eyenet_batch(B, T, size, device, seed):
     return {k: v.to(device) for k, v in b.items()}
 
 
-def cpu_baseline(T, size, steps=2, budget_s=45.0):
+def cpu_baseline(T, size, steps=3, budget_s=45.0):
     """The oracle's train step on the host cores (bounded sample: B=2 clips of T frames, per-time-step loop
     exactly like the reference).  Thread count is capped at 32: with N=2 images per op, more threads only add
     synchronisation overhead (a 256-thread run of this sample did not finish in 10 minutes on the GPU box)."""
@@ -75,6 +75,42 @@ def cpu_baseline(T, size, steps=2, budget_s=45.0):
             'sample': 'oracle (plain-torch fp32 restatement of the reference, per-time-step loop) EyeNet train '
                       'step, B=%d clips x T=%d, %dx%d, %d timed step(s) after 1 warm-up'
                       % (B, T, size, size, done if done else 0)}
+
+
+def cpu_baseline_c3(T, steps=3, budget_s=60.0):
+    """The oracle's configs[2] train step on the host cores: EVE pipeline (EyeNet frozen forward, RefineNet / CGRU trained,
+    geometry, heat-maps, soft-argmax, the 31 losses) + clip + Adam, B=2 clips x T frames, per-frame loop like the reference."""
+    from oracle import detweights, eve as oracle_eve
+    from oracle.config import OracleConfig
+    from oracle.eye_net import EyeNet as OracleEyeNet
+    from oracle.refine_net import RefineNet as OracleRefineNet
+    cores = min(os.cpu_count() or 1, 32)
+    torch.set_num_threads(cores)
+    cfg = OracleConfig(os.path.join(HERE, 'configs', 'refine_net.json'), refine_net_rnn_type='CGRU', eye_net_load_pretrained=False)
+    eye, ref = detweights.fill_module(OracleEyeNet(cfg), 0), detweights.fill_module(OracleRefineNet(cfg), 1)
+    for q in eye.parameters():
+        q.requires_grad_(False)
+    opt = torch.optim.Adam(ref.parameters(), lr=cfg.learning_rate, weight_decay=cfg.weight_decay)
+    B = 2
+    batch = detweights.eve_batch(B, T, seed=3)
+
+    def step():
+        opt.zero_grad()
+        out, _, _ = oracle_eve.eve_forward(eye, ref, dict(batch), cfg, True)
+        out['full_loss'].backward()
+        torch.nn.utils.clip_grad_norm_(ref.parameters(), cfg.gradient_clip_amount)
+        opt.step()
+    t0 = time.perf_counter()
+    step()
+    warm = time.perf_counter() - t0
+    done, t0 = 0, time.perf_counter()
+    while done < steps and (time.perf_counter() - t0) + warm < budget_s:
+        step()
+        done += 1
+    dt = (time.perf_counter() - t0) / done if done else warm
+    return {'value': B * T / dt, 'unit': 'frames/s', 'cores': cores, 'host_cpus': os.cpu_count(), 'kind': 'port',
+            'sample': 'oracle EVE train step of configs[2] (EyeNet frozen fwd, RefineNet/CGRU trained, per-frame loop), '
+                      'B=%d clips x T=%d, %d timed step(s) after 1 warm-up' % (B, T, done)}
 
 
 def pmc_traffic(symbol, suffix='_pmc_hbm_per_kernel.json'):
@@ -165,6 +201,58 @@ def bench_c3(args, device, k):
     return out
 
 
+def eyenet_point(args, device, dtype_name, batch, steps, warmup, k, profile=True):
+    """One more operating point of the configs[1] workload on this GPU (world == 1): `dtype_name`, `batch` clips per step.
+    -> {ms_per_step, value, step MFMA fraction, roofline of its dominant kernel}."""
+    import eve_amd
+    from eve_amd import train
+    cfg = eve_amd.reset_standalone_config()
+    cfg.import_json(os.path.join(HERE, 'configs', 'eye_net.json'))
+    torch.manual_seed(1234)
+    net = eve_amd.EyeNet()
+    net.compute_dtype = TORCH_DTYPE[dtype_name]
+    net.to(device)
+    tr = train.eyenet_trainer(net, cfg, use_graph=not args.no_graph)
+    tr.static_inputs = 'alias'
+    data = synthetic_eyenet_batch(batch, args.seq, args.size, device, 77)
+    for _ in range(warmup):
+        tr.step(data)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        terms = tr.step(data)
+    torch.cuda.synchronize()
+    ms = 1e3 * (time.perf_counter() - t0) / steps
+    peak = MFMA_PEAK_TFLOPS[dtype_name]
+    out = {'dtype': dtype_name, 'batch_per_gpu': batch, 'seq_len': args.seq, 'steps': steps, 'ms_per_step': ms,
+           'value': batch * args.seq / (ms * 1e-3), 'unit': 'frames/s', 'final_loss': float(terms['full_loss'].detach())}
+    if args.size == 128:
+        out['step_algorithmic_tflops'] = EYENET_TRAIN_GFLOP_PER_FRAME_128 * out['value'] / 1e3
+        out['step_mfma_frac'] = out['step_algorithmic_tflops'] / peak
+    if profile and not args.no_roofline:
+        tr._eager_step(data)
+        torch.cuda.synchronize()
+        k.start_profile()
+        for _ in range(args.profile_steps):
+            tr._eager_step(data)
+        prof = k.stop_profile()
+        overhead = prof.pop('_event_overhead_ms', None)
+        by_kernel = prof.pop('_by_kernel', {})
+        if by_kernel:
+            dom = max(by_kernel, key=lambda t: by_kernel[t]['ms'])
+            d = by_kernel[dom]
+            ach = d['flops'] / (d['ms'] * 1e-3) / 1e12
+            out['roofline'] = {'bound': 'mfma', 'kernel': 'eve::' + dom, 'achieved': ach, 'peak': peak, 'unit': 'TFLOP/s',
+                               'frac': ach / peak, 'traffic': None, 'launches_per_step': d['launches'] / args.profile_steps,
+                               'avg_launch_ms': d['ms'] / d['launches'],
+                               'algorithmic_gflop_per_launch': d['flops'] / d['launches'] / 1e9,
+                               'event_pair_overhead_ms_subtracted': overhead}
+    del tr, net
+    torch.cuda.empty_cache()
+    eve_amd.reset_standalone_config()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -180,6 +268,7 @@ def main():
     ap.add_argument('--graph', action='store_true', help='force hipGraph replay also with several ranks')
     ap.add_argument('--profile-steps', type=int, default=2)
     ap.add_argument('--no-c3', action='store_true', help='skip the configs[2] (EyeNet + RefineNet pipeline) measurement')
+    ap.add_argument('--no-points', action='store_true', help='skip the extra operating points (fp32 parity mode, B=8 per GPU)')
     args = ap.parse_args()
 
     import eve_amd
@@ -237,6 +326,11 @@ def main():
         by_kernel = prof.pop('_by_kernel', {})
         barrier()
     loss = float(terms['full_loss'].detach())
+    ranks_seen = 1
+    if world > 1:        # proof that the collective saw every rank (RCCL over xGMI): an all-reduce of ones
+        ones = torch.ones(1, dtype=torch.float32, device=device)
+        torch.distributed.all_reduce(ones)
+        ranks_seen = int(round(float(ones)))
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -256,7 +350,7 @@ def main():
                                    % (args.size, args.size),
                        'global_batch': world * args.batch, 'batch_per_gpu': args.batch, 'seq_len': args.seq,
                        'parallelism': 'dp%d' % world},
-            'final_loss': loss, 'hip_graph': use_graph,
+            'final_loss': loss, 'hip_graph': use_graph, 'ranks_seen': ranks_seen,
             'kernel_tree_sha': __import__('eve_amd.build', fromlist=['kernel_tree_sha']).kernel_tree_sha(),
         }
         peak = MFMA_PEAK_TFLOPS[args.dtype]
@@ -284,8 +378,21 @@ def main():
             del trainer, net                      # release the EyeNet trainer's graph pool before the second workload
             torch.cuda.empty_cache()
             out['c3'] = bench_c3(args, device, k)
+        if world == 1 and not args.no_points and args.size == 128 and args.batch == 32 and args.dtype == 'bf16':
+            # the other stated operating points, same workload: north_star's B = 8 clips per GPU, and the float32 parity
+            # mode (the instantiation that holds the 1e-4 rad tolerance; its roofline is the 157.3 TFLOP/s f32-input MFMA peak)
+            try:
+                del trainer, net
+            except NameError:
+                pass
+            torch.cuda.empty_cache()
+            out['b8'] = eyenet_point(args, device, 'bf16', 8, max(args.steps, 10), args.warmup, k)
+            out['fp32'] = eyenet_point(args, device, 'fp32', args.batch, max(3, args.steps // 2), 2, k)
+            out['fp16'] = eyenet_point(args, device, 'fp16', args.batch, args.steps, args.warmup, k, profile=False)
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(args.seq, args.size)
+            if 'c3' in out:
+                out['c3']['cpu_baseline'] = cpu_baseline_c3(args.seq)
         print(json.dumps(out), flush=True)
     if world > 1:
         torch.distributed.barrier()

@@ -66,6 +66,7 @@ template <> struct Mma<float> {
 
 }  // namespace eve
 #include "conv_fast.h"
+#include "conv_wg8.h"
 #include "wgrad_halo.h"
 namespace eve {
 
@@ -555,6 +556,35 @@ static bool launch_halo(const GatherParams& p, const void* src, const void* w, c
     if (p.Cin % 32 || W > 128 || (W & (W - 1)) || W < 4) return false;
     HaloParams h;
     h.N = p.N; h.H = H; h.W = W; h.Cin = p.Cin; h.Cout = p.Cout;
+    // ---- eight-wave workgroups, 32x32x16 MFMA, staggered wave groups (conv_wg8.h): whole square images per tile ----
+    static int wg8 = -1;
+    if (wg8 < 0) { const char* e = getenv("EVE_CONV_WG8"); wg8 = (e && e[0] == '0') ? 0 : 1; }
+    if (wg8 && H == W && p.Cin % 64 == 0 && ((epi_act & ~0xff) == 0) &&
+        ((epi_act & 0xff) == EVE_ACT_NONE || (epi_act & 0xff) == EVE_ACT_RELU)) {
+        const unsigned long long xb8 = (unsigned long long)p.N * H * W * p.Cin * 2, wb8 = (unsigned long long)p.Cout * p.K * 2;
+        Wg8Params g;
+        g.N = p.N; g.Cin = p.Cin; g.Cout = p.Cout; g.flip = bwd ? 1 : 0; g.K = p.K; g.x_bytes = (uint32_t)xb8; g.w_bytes = (uint32_t)wb8;
+#define EVE_WG8_LAUNCH(WM_, WN_, W_)                                                                                      \
+        do {                                                                                                             \
+            using G8 = Wg8Geom<WM_, WN_, W_>;                                                                              \
+            static bool attr_done = false;                                                                               \
+            if (!attr_done) {                                                                                            \
+                (void)hipFuncSetAttribute((const void*)conv3x3_wg8_kernel<HT, WM_, WN_, W_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+                attr_done = true;                                                                                        \
+            }                                                                                                            \
+            g.tiles_n = (uint32_t)(p.Cout / G8::COUT_T);                                                                   \
+            const uint32_t tiles8 = (uint32_t)((p.N + G8::TI - 1) / G8::TI) * g.tiles_n;                                     \
+            EVE_LAUNCH(EVE_HNAME(HT, "conv3x3_wg8_kernel<", ", " #WM_ ", " #WN_ ", " #W_ ">"), (conv3x3_wg8_kernel<HT, WM_, WN_, W_>), dim3(tiles8), \
+                       dim3(512), G8::LDS, s, g, (const HT*)src, (const HT*)w, bias, epi_act, (HT*)out);                   \
+            return true;                                                                                                 \
+        } while (0)
+        if (xb8 < (1ull << 31) && wb8 < (1ull << 31)) {
+            if (W == 16 && p.Cout % 128 == 0 && p.Cout % 256 != 0) EVE_WG8_LAUNCH(4, 2, 16);
+            if (W == 8 && p.Cout % 256 == 0) EVE_WG8_LAUNCH(2, 4, 8);
+            if (W == 4 && p.Cout % 256 == 0) EVE_WG8_LAUNCH(2, 4, 4);
+        }
+#undef EVE_WG8_LAUNCH
+    }
     const bool narrow = p.Cout <= 64;               // 256 pixels x 64 channels (4x1 waves) instead of 128 x 128 (2x2)
     const int BMp = narrow ? 256 : 128;
     const int rows = BMp / W;
