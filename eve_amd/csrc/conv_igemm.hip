@@ -558,7 +558,7 @@ static bool launch_halo(const GatherParams& p, const void* src, const void* w, c
     h.N = p.N; h.H = H; h.W = W; h.Cin = p.Cin; h.Cout = p.Cout;
     // ---- eight-wave workgroups, 32x32x16 MFMA, staggered wave groups (conv_wg8.h): whole square images per tile ----
     static int wg8 = -1;
-    if (wg8 < 0) { const char* e = getenv("EVE_CONV_WG8"); wg8 = (e && e[0] == '0') ? 0 : 1; }
+    if (wg8 < 0) { const char* e = getenv("EVE_CONV_WG8"); wg8 = e ? atoi(e) : 1; }
     if (wg8 && H == W && p.Cin % 64 == 0 && ((epi_act & ~0xff) == 0) &&
         ((epi_act & 0xff) == EVE_ACT_NONE || (epi_act & 0xff) == EVE_ACT_RELU)) {
         const unsigned long long xb8 = (unsigned long long)p.N * H * W * p.Cin * 2, wb8 = (unsigned long long)p.Cout * p.K * 2;
@@ -579,7 +579,10 @@ static bool launch_halo(const GatherParams& p, const void* src, const void* w, c
             return true;                                                                                                 \
         } while (0)
         if (xb8 < (1ull << 31) && wb8 < (1ull << 31)) {
-            if (W == 16 && p.Cout % 128 == 0 && p.Cout % 256 != 0) EVE_WG8_LAUNCH(4, 2, 16);
+            // 16 x 16 images x 128 channels (512-pixel tiles, 36 steps each): a one-tile workgroup per CU spends ~15 % of its
+            // time in the un-overlapped prologue / epilogue and measures 0.150-0.159 ms against 0.145 for the four-wave kernel
+            // with two workgroups per CU (profiles/r03_conv_wg8.md); EVE_CONV_WG8=2 selects it there as well
+            if (wg8 == 2 && W == 16 && p.Cout % 128 == 0 && p.Cout % 256 != 0) EVE_WG8_LAUNCH(4, 2, 16);
             if (W == 8 && p.Cout % 256 == 0) EVE_WG8_LAUNCH(2, 4, 8);
             if (W == 4 && p.Cout % 256 == 0) EVE_WG8_LAUNCH(2, 4, 4);
         }

@@ -13,8 +13,12 @@
 //     phase 2g+1   group 0: 16 MFMAs of step g                                          group 1: read fragments of step g
 //
 // so on every SIMD one wave feeds the matrix pipe while the other one does LDS / DMA / address work, by construction
-// (the 8-phase GEMM schedule of cdna_hip_programming.md, 5.5 T3-T5, carried over to the halo-resident convolution).
-// A step = one filter tap x one 32-channel slice (K = 32 = two K=16 MFMA halves).
+// (the role split of the 8-phase GEMM schedule of cdna_hip_programming.md, 5.5 T3-T5, carried over to the halo-resident
+// convolution).  A step = one filter tap x one 32-channel slice (K = 32 = two K=16 MFMA halves).  The two groups do NOT
+// need a barrier between their phases: between two workgroup barriers (ONE per step) group 0 runs [read g, multiply g]
+// and group 1, at a higher static priority, [multiply g-1, read g]; the matrix pipe itself serialises the two multiplies
+// (group 1's first), so each wave's LDS / DMA half lies under its partner's 16 MFMAs.  (The first version synchronised
+// the whole workgroup after every phase: 740 cycles per 512-cycle phase; profiles/r03_conv_wg8.md.)
 //
 // Data movement is the halo design's: per 32-channel slice the (W+2) x (W+2) halo of each of the tile's TI whole images
 // is fetched ONCE by LDS-DMA (two stages, the next slice streams in during taps 1..AP of the current one) and all nine
@@ -22,13 +26,13 @@
 // steps ahead in a 4-slot ring.  Every wave issues the same share (WN/2 weight pieces, <= 1 halo piece per step), the
 // tap / slice part of a source address is the instruction's scalar offset, so a DMA costs no vector instruction at all.
 //
-// Synchronisation (P_k = phase k; group 0 reads step g in P_2g, group 1 in P_2g+1):
-//   * weight tile g+2 -> slot (g+2)&3 = slot of tile g-2, whose last reads (group 1, P_2g-3) completed at the start of
-//     P_2g-2; it is issued in P_2g / P_2g+1, every wave waits for its pieces at the end of its read phase of step g+1
-//     (s_waitcnt vmcnt(pieces issued in that phase): loads return in order), the barriers after P_2g+2 / P_2g+3 publish
-//     them, first read in P_2g+4.
-//   * halo pieces of slice s+1 go to the stage slice s-1 used (last read P_18s-1, done at the start of P_18s); issued from
-//     tap 1 (P_18s+2) to tap AP <= 7, waited for one step later, first read in P_18s+18.
+// Synchronisation (interval g = between the barriers of steps g-1 and g; both groups read step g's operands in it):
+//   * weight tile g+2 -> slot (g+2)&3 = slot of tile g-2, last read in interval g-2 (complete at the first lgkmcnt(0) of
+//     interval g-1); issued in interval g, every wave waits for its pieces at the end of interval g+1
+//     (s_waitcnt vmcnt(pieces issued in that interval): loads return in order), that barrier publishes them, first read
+//     in interval g+2.
+//   * halo pieces of slice s+1 go to the stage slice s-1 used (last read in interval 9s-1); issued in intervals 9s+1 ..
+//     9s+AP (AP <= 7), waited for one interval later, first read in interval 9s+9.
 //
 // LDS rows are 64 bytes (one halo pixel / output channel x 32 channels) with the 16-byte chunk XOR-ed by a key of the
 // halo column (W >= 8) or halo row (W = 4) / of the weight row: every ds_read_b128 is bank-conflict free under gfx950's
@@ -202,7 +206,21 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wg8_kernel(const Wg8Params p, 
     issue_b(0, 1, 1);
     wg8_wait_vm<0>();
     __builtin_amdgcn_s_barrier();
-    if (wave >= 4) __builtin_amdgcn_s_barrier();                // group 1 runs one phase behind from here on
+
+    // One barrier per step.  Between two barriers group 0 runs [read step g, multiply step g] and group 1 runs
+    // [multiply step g-1, read step g]: on every SIMD one wave starts with LDS / DMA work while its partner (higher
+    // priority) owns the matrix pipe, then they swap -- no barrier is needed for that, the pipe itself orders them.
+    const bool lead = wave < 4;
+    u32x4_t wf[2][2], xf[4][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) wf[i][j] = u32x4_t{0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) xf[i][j] = u32x4_t{0u, 0u, 0u, 0u};
+    if (!lead) __builtin_amdgcn_s_setprio(2);
 
     for (int s2 = 0; s2 < nslices; s2 += 2) {
 #pragma unroll
@@ -211,11 +229,13 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wg8_kernel(const Wg8Params p, 
             const bool last = s + 1 == nslices;
 #pragma unroll
             for (int t = 0; t < 9; ++t) {
-                constexpr int dummy = 0; (void)dummy;
                 const int dy = t / 3, dx = t % 3;
-                // ================= read phase of step g = 9 s + t =================
+                const int t2 = (t + 2) % 9, sd = (t + 2) / 9;
+                const bool more_b = !(last && sd);                                       // a step g + 2 exists
+                const bool piece = t >= 1 && t <= AP;
+                if (!lead) wg8_mma16<H>(acc, wf, xf);                                    // step g - 1 (zeros before step 0)
+                // ---- fragments of step g = 9 s + t ----
                 const uint32_t slot_off = (uint32_t)((s + t) & 3) * BSLOT;             // (9 s + t) & 3
-                u32x4_t wf[2][2], xf[4][2];
 #pragma unroll
                 for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
@@ -228,34 +248,42 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wg8_kernel(const Wg8Params p, 
 #pragma unroll
                     for (int kh = 0; kh < 2; ++kh)
                         xf[pt][kh] = *reinterpret_cast<const EVE_LDS u32x4_t*>((uintptr_t)(xrd[pt][q][kh] + imm));
-                // DMAs of this phase: weight tile of step g + 2, halo piece t - 1 of the next slice
-                const int t2 = (t + 2) % 9, sd = (t + 2) / 9;
-                const bool more_b = !(last && sd);                                       // a step g + 2 exists
-                const bool piece = t >= 1 && t <= AP;
+                // ---- DMAs of this step (issued while the fragment reads are in flight): weight tile of step g + 2, halo
+                //      piece t - 1 of the next slice ----
                 if (more_b) issue_b(s + sd, t2, (s + t + 2) & 3);
                 if (piece && !last) wg8_dma(rs_x, ldsA + (ss ^ 1) * ASTAGE + ((t - 1) * 8 + wave) * 1024, a_goff[piece ? t - 1 : 0], (s + 1) * 64);
-                // everything this wave issued BEFORE this phase has landed once only this phase's pieces are outstanding
+                if (lead) wg8_mma16<H>(acc, wf, xf);
+                // everything this wave issued BEFORE this step has landed once only this step's pieces are outstanding
                 if (more_b) {
                     if (piece && !last) wg8_wait_vm<BP + 1>(); else wg8_wait_vm<BP>();
                 } else {
                     wg8_wait_vm<0>();
                 }
                 __builtin_amdgcn_s_barrier();
-                // ================= matrix phase =================
-                __builtin_amdgcn_s_setprio(1);
-                wg8_mma16<H>(acc, wf, xf);
-                __builtin_amdgcn_s_setprio(0);
-                if (!(last && t == 8 && wave >= 4)) __builtin_amdgcn_s_barrier();      // (group 1's last phase has no successor)
             }
         }
     }
-    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");        // MFMA results -> compiler-generated reads of the accumulators
+    if (!lead) wg8_mma16<H>(acc, wf, xf);                       // group 1's last step
+    __builtin_amdgcn_s_setprio(0);
+    // MFMA results -> compiler-generated reads of the accumulators: the wait states must sit BETWEEN the last MFMA and the
+    // first v_accvgpr_read, so the statement names the accumulators (an asm with only a memory clobber may be scheduled
+    // after register-only reads: the last tile of the last wave then came out stale every few launches)
+    asm volatile("s_nop 15\n\ts_nop 15"
+                 : "+a"(acc[0][0]), "+a"(acc[0][1]), "+a"(acc[0][2]), "+a"(acc[0][3]), "+a"(acc[1][0]), "+a"(acc[1][1]),
+                   "+a"(acc[1][2]), "+a"(acc[1][3]) :: "memory");
 
     // ---- epilogue: the lane owns 32 consecutive channels (64 bytes) of each of its four pixels ----
     const uint32_t co = co0 + wn * 64 + l5 * 32;
     const bool relu = (epi_act & 0xff) == EVE_ACT_RELU;
+    float bv[32];
+#pragma unroll
+    for (int c = 0; c < 32; c += 4) {
+        const float4 b4 = bias ? *reinterpret_cast<const float4*>(bias + co + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        bv[c] = b4.x; bv[c + 1] = b4.y; bv[c + 2] = b4.z; bv[c + 3] = b4.w;
+    }
 #pragma unroll
     for (int pt = 0; pt < 4; ++pt) {
+        __builtin_amdgcn_sched_barrier(0);                      // one pixel tile at a time: 32 accumulators live, not 128
         const int m = wm * 128 + pt * 32 + l31;
         const int ti = m / (W * W), pix = m - ti * (W * W);
         const uint32_t n = n0 + ti;
@@ -264,16 +292,16 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wg8_kernel(const Wg8Params p, 
         for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
             for (int r = 0; r < 16; r += 2) {
-                float o0 = acc[ct][pt][r], o1 = acc[ct][pt][r + 1];
-                if (bias) { o0 += bias[co + ct * 16 + r]; o1 += bias[co + ct * 16 + r + 1]; }
+                float o0 = acc[ct][pt][r] + bv[ct * 16 + r], o1 = acc[ct][pt][r + 1] + bv[ct * 16 + r + 1];
                 if (relu) { o0 = fmaxf(o0, 0.f); o1 = fmaxf(o1, 0.f); }
                 pk[ct * 8 + r / 2] = Elem<H>::pack2(o0, o1);
             }
-        if (n >= (uint32_t)p.N) continue;
-        H* dst = out + ((size_t)n * (W * W) + pix) * p.Cout + co;
+        if (n < (uint32_t)p.N) {
+            H* dst = out + ((size_t)n * (W * W) + pix) * p.Cout + co;
 #pragma unroll
-        for (int v = 0; v < 4; ++v)
-            *reinterpret_cast<uint4*>(dst + 8 * v) = make_uint4(pk[4 * v], pk[4 * v + 1], pk[4 * v + 2], pk[4 * v + 3]);
+            for (int v = 0; v < 4; ++v)
+                *reinterpret_cast<uint4*>(dst + 8 * v) = make_uint4(pk[4 * v], pk[4 * v + 1], pk[4 * v + 2], pk[4 * v + 3]);
+        }
     }
 }
 

@@ -388,3 +388,44 @@ def test_float32_gradient_deviation_is_float_rounding_noise():
         assert e_hip <= max(4 * e_cpu, 5e-4), '%s: HIP f32 vs f64 %.3e, CPU f32 vs f64 %.3e' % (n, e_hip, e_cpu)
     worst.sort(reverse=True)
     print('float32 gradient error vs float64 (HIP, CPU oracle):', ', '.join('%s %.1e/%.1e' % (n, a, b) for a, b, n in worst[:5]))
+
+
+def _no_bias(dev_per_clip, what):
+    """dev_per_clip: one mean SIGNED deviation per clip (independent samples).  A systematic offset shows as a mean that
+    is not compatible with zero; pure rounding noise gives |mean| <= 3 sigma / sqrt(n) (0.3 % false-alarm rate)."""
+    d = np.asarray(dev_per_clip, dtype=np.float64)
+    n = d.size
+    mean, sem = float(d.mean()), float(d.std(ddof=1) / np.sqrt(n))
+    print('%s: mean signed deviation %.3e, standard error %.3e (n = %d clips)' % (what, mean, sem, n))
+    assert abs(mean) <= 3.0 * sem, '%s: mean signed deviation %.3e is %.1f standard errors from zero' % (what, mean, abs(mean) / sem)
+
+
+def test_bf16_outputs_carry_no_systematic_offset_against_the_rounding_faithful_oracle():
+    """The envelope tests bound the SIZE of the end-to-end bf16 deviation; this one looks at its SIGN.  64 independent clips:
+    the per-clip mean signed deviation of the HIP bf16 gaze angles / pupil sizes (EyeNet, T = 2) and of the refined heat-map
+    (RefineNet / CGRU, T = 2) from the rounding-faithful oracle must be compatible with zero (3 standard errors).  A
+    truncating conversion or a biased epilogue in any bf16-only kernel shifts every clip the same way and fails here even
+    when it is far below the per-stage tolerances."""
+    from oracle.eye_net import EyeNet as OracleEyeNet
+    from oracle.refine_net import RefineNet as OracleRefineNet
+    B, T = 64, 2
+    cfg = eye_cfg()
+    batch = detweights.eyenet_batch(B, T, seed=123)
+    ref = detweights.fill_module(OracleEyeNet(cfg), seed=0)
+    with torch.no_grad(), bf.rounding(True):
+        fo = bf.eyenet_sequence(ref, batch)
+    net, _ = make_eyenet()
+    with torch.no_grad():
+        out = net.forward_sequence(to_dev(batch))
+    for keys, what in ((('left_g_initial', 'right_g_initial'), 'gaze (rad)'), (('left_pupil_size', 'right_pupil_size'), 'pupil size')):
+        dev = sum((out[k].detach().float().cpu() - fo[k]).reshape(B, -1).mean(dim=1) for k in keys) / len(keys)
+        _no_bias(dev.numpy(), 'EyeNet bf16 ' + what)
+    ocfg = OracleConfig(load_screen_content=True, refine_net_enabled=True, refine_net_rnn_type='CGRU')
+    rb = detweights.refinenet_batch(B, T, seed=321)
+    rref = detweights.fill_module(OracleRefineNet(ocfg), seed=1)
+    with torch.no_grad(), bf.rounding(True):
+        fh, _ = bf.refinenet_sequence(rref, rb['heatmap_initial'], rb['screen_frame'])
+    rnet, _ = make_refinenet()
+    with torch.no_grad():
+        hf, _ = rnet.forward_sequence(rb['heatmap_initial'].cuda(), rb['screen_frame'].cuda())
+    _no_bias((hf.detach().float().cpu() - fh).reshape(B, -1).mean(dim=1).numpy(), 'RefineNet bf16 heat-map')

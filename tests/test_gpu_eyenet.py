@@ -349,3 +349,33 @@ def test_trunk_matches_independent_resnet_fixture(tag):
     (fc * torch.from_numpy(fx[tag + '_proj']).cuda()).sum().backward()
     grads = {n: p.grad for n, p in net.cnn_layers.named_parameters()}
     check_trunk_case(fx, tag, {'layer4': y4.permute(0, 3, 1, 2)}, pooled, fc, grads, atol=1e-4, grad_rtol=1e-2)
+
+
+def test_float32_gradients_match_the_reference_float64_full_tensors():
+    """tests/golden/grads_f64.npz (the reference's EVE + EyeNet evaluated in float64, make_golden_grads.py): the float32 HIP
+    path's gradients -- the FULL tensors of the stem convolution, a layer-1 convolution, the GRU's hidden weights, the gaze
+    head, a 64 x 64 channel block of the last layer-4 convolution -- within 1e-4 relative L2, and every parameter's norm
+    within 1e-4.  (The reference's own float32 CPU evaluation is 5.5e-4 away from these on the first layers: the fixture
+    records that figure; a float32 fixture could not carry this tolerance.)"""
+    fx = np.load(os.path.join(GOLDEN, 'grads_f64.npz'))
+    cfg = eye_cfg()
+    batch = to_dev(detweights.eyenet_batch(2, 3, seed=0, invalid_fraction=0.25))
+    net = make_net(torch.float32)
+    terms = sequence.eyenet_losses(net.forward_sequence(batch), batch, cfg)
+    np.testing.assert_allclose(float(terms['full_loss'].detach()), float(fx['eye_full_loss_f64']), rtol=2e-6)
+    terms['full_loss'].backward()
+    params = dict(net.named_parameters())
+    for n, want in zip(fx['eye_names'], fx['eye_norms']):
+        got = float(params[str(n)].grad.double().norm())
+        assert abs(got - float(want)) <= 1e-4 * float(want) + 1e-9, '%s: |g| %.8g vs %.8g' % (n, got, float(want))
+    worst = 0.0
+    for k in fx.files:
+        if k.startswith('eye_grad_') or k.startswith('eye_block_'):
+            g = params[k.split('_', 2)[2]].grad.detach().double().cpu()
+            g = g[:64, :64] if k.startswith('eye_block_') else g
+            want = torch.from_numpy(fx[k]).double()
+            e = float((g - want).norm() / want.norm())
+            worst = max(worst, e)
+            assert e <= 1e-4, '%s: relative L2 %.3e' % (k, e)
+    print('worst full-tensor gradient deviation from the float64 reference: %.2e (reference float32: %.2e)' % (
+        worst, float(fx['eye_ref_f32_vs_f64_worst'])))

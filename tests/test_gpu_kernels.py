@@ -704,3 +704,44 @@ def test_heatmap_head_and_losses_match_aten():
         a, b = p_dev.grad.cpu(), p_ref.grad
         assert torch.isfinite(a).all()
         assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max()) + 1e-9, kind
+
+
+def test_eight_wave_convolution_matches_the_four_wave_kernel(tmp_path):
+    """conv3x3_wg8_kernel (conv_wg8.h: eight-wave workgroups, 32x32x16 MFMA, phase-staggered wave pairs) is the default for
+    8 x 8 x 256 / 4 x 4 x 512 layers and opt-in (EVE_CONV_WG8=2) for 16 x 16 x 128; EVE_CONV_WG8=0 sends everything to
+    conv3x3_halo_kernel.  Forward (bias + ReLU epilogue) and data gradient, ragged image counts (the last tile holds fewer
+    images than TI), several channel tiles, both 16-bit formats: the two kernels sum the same products in float32 in a
+    different order, so they agree to the format's rounding.  (The switch is read once per process.)"""
+    import os
+    import subprocess
+    import sys
+    code = r'''
+import sys, torch
+sys.path.insert(0, %r)
+from eve_amd.kernels import HipKernels
+k = HipKernels()
+g = torch.Generator().manual_seed(3)
+outs, names = [], []
+for dt in (torch.bfloat16, torch.float16):
+    for N, H, C, Co in ((13, 16, 128, 128), (9, 8, 256, 256), (27, 8, 128, 512), (70, 4, 512, 512), (35, 4, 256, 256)):
+        x = torch.randn((N, H, H, C), generator=g).to(dt).cuda()
+        w = (torch.randn((Co, 3, 3, C), generator=g) * (2.0 / (9 * C)) ** 0.5).to(dt).cuda()
+        b = torch.randn((Co,), generator=g).cuda()
+        y = k.conv2d_fwd(x, w, b, 1, 1, epi_act=1)
+        names.append(k.lib.eve_last_kernel().decode())
+        dy = torch.randn(y.shape, generator=g).to(dt).cuda()
+        dx = k.conv2d_dgrad(dy, w.permute(3, 1, 2, 0).contiguous(), (H, H), 1, 1)
+        outs += [y.float().cpu(), dx.float().cpu()]
+torch.save((outs, names), sys.argv[1])
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for mode in ('0', '2'):
+        path = os.path.join(str(tmp_path), 'wg8_%s.pt' % mode)
+        env = dict(os.environ, EVE_CONV_WG8=mode)
+        p = subprocess.run([sys.executable, '-c', code, path], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+        assert p.returncode == 0, p.stdout[-2000:]
+        res[mode] = torch.load(path)
+    assert all('wg8' in n for n in res['2'][1]) and not any('wg8' in n for n in res['0'][1]), (res['2'][1], res['0'][1])
+    for i, (a, b) in enumerate(zip(res['2'][0], res['0'][0])):
+        tol = 2e-3 if i < 10 else 3e-4                       # bf16 cases first, then float16
+        assert float((a - b).norm() / b.norm()) < tol and float((a - b).abs().max()) <= 8 * tol * float(b.abs().max()), i

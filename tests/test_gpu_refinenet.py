@@ -255,3 +255,30 @@ def test_fused_cgru_scan_backward_kernel_matches_contract(B, T, with_h0):
         rel = float((a - b).norm() / b.norm())
         # bf16 storage of every output; the recursion amplifies a rounding flip of an early frame's dg by the carry
         assert rel < 6e-3 and float((a - b).abs().max()) <= 4e-2 * float(b.abs().max()), (name, rel, float((a - b).abs().max()))
+
+
+def test_float32_refinenet_gradients_match_the_reference_float64_full_tensors():
+    """tests/golden/grads_f64.npz: the reference's RefineNet (CGRU, per-step contract over T = 3) + CrossEntropyLoss in
+    float64.  The float32 HIP path: heat-map BCE to 2e-6, the FULL gradient tensors of the conv-GRU's gates_1 / gate_2
+    banks and of the first / last convolution within 1e-4 relative L2, every parameter's norm within 2e-4."""
+    from eve_amd import losses
+    fx = np.load(os.path.join(GOLDEN, 'grads_f64.npz'))
+    rb = detweights.refinenet_batch(2, 3, seed=0, invalid_fraction=0.25)
+    drb = {k: v.cuda() for k, v in rb.items()}
+    net, cfg = make_net('CGRU')
+    hf, _ = net.forward_sequence(drb['heatmap_initial'], drb['screen_frame'])
+    terms = losses.refinenet_loss_terms(hf, drb['heatmap_final_gt'], drb['validity'], cfg)
+    np.testing.assert_allclose(float(terms['loss_ce_heatmap_final'].detach()), float(fx['refine_loss_ce']), rtol=2e-6)
+    terms['loss_ce_heatmap_final'].backward()
+    params = dict(net.named_parameters())
+    scale = float(fx['refine_norms'].max())
+    for n, want in zip(fx['refine_names'], fx['refine_norms']):
+        got = float(params[str(n)].grad.double().norm())
+        # (conv biases that only feed an InstanceNorm have an exactly-zero gradient: rounding residue on both sides)
+        assert abs(got - float(want)) <= 2e-4 * float(want) + 1e-6 * scale, '%s: |g| %.8g vs %.8g' % (n, got, float(want))
+    for k in fx.files:
+        if k.startswith('refine_grad_'):
+            g = params[k[len('refine_grad_'):]].grad.detach().double().cpu()
+            want = torch.from_numpy(fx[k]).double()
+            e = float((g - want).norm() / want.norm())
+            assert e <= 1e-4, '%s: relative L2 %.3e' % (k, e)

@@ -490,3 +490,76 @@ def test_trainer_follows_the_reference_lr_schedule(fake):
     assert seen[0] < seen[1] < seen[2] == seen[3] and seen[4] == 0.5 * seen[3]     # warm-up rises, the decay halves
     assert float(tr.lr_dev) == pytest.approx(seen[-1])
     eve_amd.reset_standalone_config()
+
+
+def test_gradient_bucket_plan_matches_the_survey(fake):
+    """the gradient all-reduce runs in a few large buckets filled back to front, so that the layers whose
+    gradients are ready first (EyeNet: layer 4 = 74 % of the bytes; RefineNet: the decoder / final convolutions) are on the
+    wire while the rest of backward still runs.  Checked on the plan itself (no process group needed): 3-5 buckets for the
+    EyeNet (configs[1]) and RefineNet (configs[2]) trainers, a partition of the flat gradient buffer, bucket 0 = the LAST
+    parameters, and every bucket except the remainder at least the configured size."""
+    from eve_amd.parallel import GradSync
+    cfg = eve_amd.reset_standalone_config()
+    cfg.import_json(os.path.join(REPO, 'configs', 'eye_net.json'))
+    eye = eve_amd.EyeNet()
+    tr = train.eyenet_trainer(eye, cfg)
+    sync = GradSync(tr.fp.grad, tr.fp.entries)
+    assert 3 <= len(sync.buckets) <= 5, [b['hi'] - b['lo'] for b in sync.buckets]
+    # a partition of [0, padded numel), back to front
+    assert sync.buckets[0]['hi'] == tr.fp.grad.numel() and sync.buckets[-1]['lo'] == 0
+    for a, b in zip(sync.buckets, sync.buckets[1:]):
+        assert a['lo'] == b['hi']
+    assert all(b['hi'] - b['lo'] >= 4 * 1024 * 1024 for b in sync.buckets[:-1])
+    names = {id(p): n for n, p in eye.named_parameters()}
+    first = [names[id(p)] for p in sync.buckets[0]['params']]
+    # the tail (heads, GRU, fc) and layer 4's last convolutions -- the first gradients backward produces -- lead
+    assert 'fc_to_gaze.2.weight' in first and 'cnn_layers.layer4.1.conv2.weight' in first
+    assert not any(n.startswith(('cnn_layers.conv1', 'cnn_layers.layer1', 'cnn_layers.layer2')) for n in first)
+    l4 = sum(p.numel() for n, p in eye.named_parameters() if n.startswith('cnn_layers.layer4'))
+    assert 0.70 < l4 / sum(p.numel() for p in eye.parameters()) < 0.78            # "74 % of the bytes"
+    last = [names[id(p)] for p in sync.buckets[-1]['params']]
+    assert 'cnn_layers.conv1.weight' in last                                      # the stem's gradient is ready last
+    # RefineNet (configs[2]): 5.27 M parameters -> the 4 M-element default gives two buckets; the DP step of configs[3]
+    # lowers the bucket size so that the transfer still overlaps backward (EVE_AMD_BUCKET_ELEMS), 3-5 buckets at 1.5 M
+    cfg = eve_amd.reset_standalone_config()
+    cfg.import_dict({'load_screen_content': True, 'refine_net_enabled': True, 'refine_net_rnn_type': 'CGRU'})
+    ref = eve_amd.RefineNet()
+    rtr = train.refinenet_trainer(ref, cfg)
+    rsync = GradSync(rtr.fp.grad, rtr.fp.entries, bucket_elems=1536 * 1024)
+    assert 3 <= len(rsync.buckets) <= 5, [b['hi'] - b['lo'] for b in rsync.buckets]
+    rnames = {id(p): n for n, p in ref.named_parameters()}
+    assert 'final.2.weight' in [rnames[id(p)] for p in rsync.buckets[0]['params']]
+    assert 'initial.0.weight' in [rnames[id(p)] for p in rsync.buckets[-1]['params']]
+    assert sum(b['hi'] - b['lo'] for b in rsync.buckets) == rtr.fp.grad.numel()
+    eve_amd.reset_standalone_config()
+
+
+def test_trainer_factories_take_the_reference_schedule_and_the_fp16_loss_scale(fake):
+    """eyenet_trainer(..., steps_per_epoch=n) steps with the reference's effective learning rate (LambdaLR quirk included,
+    eve_amd.schedule); without it the LR is the constant config.learning_rate.  A float16 module gets the static loss scale
+    (1024) and the Adam kernel's gradient scale divides it out again: the update equals the unscaled one."""
+    from eve_amd import schedule
+    cfg = eve_amd.reset_standalone_config()
+    cfg.import_json(os.path.join(REPO, 'configs', 'eye_net.json'))
+    net = detweights.fill_module(eve_amd.EyeNet())
+    tr = train.eyenet_trainer(net, cfg, steps_per_epoch=100)
+    batch = detweights.eyenet_batch(1, 2, seed=5)
+    for s in range(3):
+        tr.step(batch)
+        assert tr.lr == pytest.approx(schedule.effective_learning_rate(cfg, 100, s))
+    assert tr.lr < cfg.learning_rate                       # warm-up x the LambdaLR multiplication
+    assert train.eyenet_trainer(detweights.fill_module(eve_amd.EyeNet()), cfg).lr_schedule is None
+    # loss scale: same data, same weights, scale 1 vs 1024 -> identical updates (float32 fake kernels, exact powers of two)
+    res = []
+    for scale in (1.0, 1024.0):
+        n2 = detweights.fill_module(eve_amd.EyeNet())
+        t2 = train.Trainer([n2], cfg, lambda b, n2=n2: sequence.eyenet_losses(n2.forward_sequence(b), b, OracleConfig(
+            batch_size=16, weight_decay=0.005, base_learning_rate=0.001)), loss_scale=scale)
+        t2.step(batch)
+        res.append((t2.fp.flat.clone(), float(t2.sumsq.sqrt()) / scale))
+    assert float((res[0][0] - res[1][0]).abs().max()) < 1e-7
+    assert res[0][1] == pytest.approx(res[1][1], rel=1e-5)
+    n16 = eve_amd.EyeNet()
+    n16.compute_dtype = torch.float16
+    assert train.Trainer([n16], cfg, lambda b: None).loss_scale == 1024.0
+    eve_amd.reset_standalone_config()

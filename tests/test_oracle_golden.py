@@ -414,3 +414,43 @@ def test_product_lr_schedule_matches_reference(golden_dir, name):
     np.testing.assert_allclose([schedule.effective_learning_rate(cfg, epoch_len, s, reference_quirk=False) for s in range(len(want_s))],
                                want_s, rtol=1e-12)
     eve_amd.reset_standalone_config()
+
+
+def test_oracle_float64_gradients_match_the_reference_float64_full_tensors(golden_dir):
+    """tests/golden/grads_f64.npz: FULL gradient tensors from the reference's own EVE / RefineNet evaluated in float64
+    (make_golden_grads.py).  The oracle in float64 must reproduce them to float64 accuracy -- every stored tensor
+    element-wise and every parameter's norm -- for the EyeNet train step and the RefineNet / CGRU sequence."""
+    fx = load(golden_dir, 'grads_f64.npz')
+    cfg = eye_cfg()
+    batch = detweights.eyenet_batch(2, 3, seed=0, invalid_fraction=0.25)
+    b64 = {k: (v.double() if v.is_floating_point() else v) for k, v in batch.items()}
+    net = detweights.fill_module(EyeNet(cfg), seed=0).double()
+    terms = sequence.eyenet_losses(sequence.eyenet_sequence(net, b64), b64, cfg)
+    np.testing.assert_allclose(float(terms['full_loss'].detach()), float(fx['eye_full_loss_f64']), rtol=1e-10)
+    terms['full_loss'].backward()
+    params = dict(net.named_parameters())
+    for n, want in zip(fx['eye_names'], fx['eye_norms']):
+        np.testing.assert_allclose(float(params[str(n)].grad.norm()), float(want), rtol=1e-8, err_msg=str(n))
+    checked = 0
+    for k in fx.files:
+        if k.startswith('eye_grad_') or k.startswith('eye_block_'):
+            g = params[k.split('_', 2)[2]].grad
+            g = g[:64, :64] if k.startswith('eye_block_') else g
+            want = torch.from_numpy(fx[k]).double()
+            assert float((g - want).norm() / want.norm()) < 1e-6, k          # (the fixture stores float32 of the float64 values)
+            checked += 1
+    assert checked == 5 and float(fx['eye_ref_f32_vs_f64_worst']) > 1e-4       # why the fixture is float64: see its generator
+    ocfg = OracleConfig(load_screen_content=True, refine_net_enabled=True, refine_net_rnn_type='CGRU')
+    rb = detweights.refinenet_batch(2, 3, seed=0, invalid_fraction=0.25)
+    rnet = detweights.fill_module(RefineNet(ocfg), seed=1).double()
+    hf, _ = sequence.refinenet_sequence(rnet, rb['heatmap_initial'].double(), rb['screen_frame'].double())
+    rterms = sequence.refinenet_losses(hf, rb['heatmap_final_gt'].double(), rb['validity'], ocfg)
+    np.testing.assert_allclose(float(rterms['loss_ce_heatmap_final'].detach()), float(fx['refine_loss_ce']), rtol=1e-10)
+    rterms['loss_ce_heatmap_final'].backward()
+    rparams = dict(rnet.named_parameters())
+    for n, want in zip(fx['refine_names'], fx['refine_norms']):
+        np.testing.assert_allclose(float(rparams[str(n)].grad.norm()), float(want), rtol=1e-7, atol=1e-12, err_msg=str(n))
+    for k in fx.files:
+        if k.startswith('refine_grad_'):
+            want = torch.from_numpy(fx[k]).double()
+            assert float((rparams[k[len('refine_grad_'):]].grad - want).norm() / want.norm()) < 1e-6, k

@@ -28,6 +28,7 @@ def run_case(k, N, H, C, Co, dt, seed):
 
 
 def main():
+    os.environ.setdefault('EVE_CONV_WG8', '2')          # all three instantiations (16 x 16 is opt-in)
     from eve_amd.kernels import HipKernels
     k = HipKernels()
     ok = True
@@ -40,7 +41,7 @@ def main():
             print('%-8s N%-3d %2dx%-2d %3d->%-3d fwd %.2e dgrad %.2e  %s  [%s]' % (str(dt).split('.')[1], N, H, H, C, Co, e1, e2, flag, name))
     print('ALL OK' if ok else 'FAILURES')
     if len(sys.argv) > 1:
-        for wg8 in ('1', '0'):
+        for wg8 in ('2', '0'):
             env = dict(os.environ, EVE_CONV_WG8=wg8)
             p = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'bench_conv.py'), sys.argv[1]],
                                env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
