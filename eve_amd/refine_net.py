@@ -320,7 +320,10 @@ class RefineNet(nn.Module):
             hs = ops.CGRUScanFn.apply(xs.contiguous(), cell.gates_1.weight, cell.gates_1.bias, cell.gate_2.weight,
                                       cell.gate_2.bias, None, P[name + '.gates_1'], P[name + '.gate_2'])
             x = self._tap('rnn', hs.reshape(B * T, x.shape[1], x.shape[2], C))
-            hist = [[hs[:, t].contiguous()] for t in range(T)]
+            hf = self._decode(x, skips, P)
+            # the T hidden states leave in the reference's layout with ONE launch (they are one contiguous [B*T,5,8,C] tensor)
+            st = ops.FromNHWCFn.apply(hs.reshape(B * T, hs.shape[2], hs.shape[3], C), C)
+            return hf.view(B, T, 1, hf.shape[2], hf.shape[3]), [st.view(B, T, C, hs.shape[2], hs.shape[3])]
         else:
             outs, states, hist = [], None, []
             for t in range(T):

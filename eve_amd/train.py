@@ -75,10 +75,10 @@ class Trainer(object):
     them tiny tail/loss kernels whose host-side enqueue would otherwise leave the GPU idle at the start of every
     backward.  Shapes are static (B, T fixed), so a new batch is copied into the captured input buffers.
     With data parallelism the graph holds forward+backward only; the gradient all-reduce, clip and Adam run
-    eagerly behind it (collectives are not captured)."""
+    eagerly behind it (collectives are not captured) unless graph_collectives is set (RCCL only)."""
 
     def __init__(self, modules, config, loss_fn, distributed=False, device=None, use_graph=False, lr_schedule=None,
-                 loss_scale=None):
+                 loss_scale=None, graph_collectives=None):
         """lr_schedule: None (constant config.learning_rate) or a callable step -> learning rate, e.g.
         `lambda s: schedule.effective_learning_rate(config, steps_per_epoch, s)` for the reference's behaviour
         (src/core/training.py:382-418,436-442).  The value lives in a device scalar the Adam kernel reads, so it also
@@ -104,6 +104,15 @@ class Trainer(object):
         self.step_count = 0
         self.beta1, self.beta2, self.eps = 0.9, 0.999, 1e-8      # torch.optim.Adam defaults (train.py:49-55)
         self.use_graph = bool(use_graph)
+        # with several ranks the captured graph may also hold the bucket all-reduces (RCCL supports stream capture; gloo
+        # does not): EVE_AMD_GRAPH_COLLECTIVES=1 or graph_collectives=True.  Off by default -- replay then runs forward +
+        # backward and the collectives / clip / Adam follow eagerly -- until it has run on a multi-GPU node.
+        import os
+        import torch.distributed as dist
+        if graph_collectives is None:
+            graph_collectives = os.environ.get('EVE_AMD_GRAPH_COLLECTIVES', '0') == '1'
+        self.graph_collectives = bool(graph_collectives) and self.sync is not None and dist.is_initialized() and \
+            dist.get_backend() == 'nccl'
         self._graph = None
         self._static_batch = None
         self._static_terms = None
@@ -181,19 +190,26 @@ class Trainer(object):
         with torch.cuda.stream(side):
             snap = self._snapshot()
             for _ in range(2):
-                if self.sync is not None:
+                if self.sync is not None and not self.graph_collectives:
                     self._forward_backward(self._static_batch)
                     self._collective_and_update()
                 else:
-                    self._eager_step(self._static_batch)
+                    self._eager_step(self._static_batch)      # (with collectives: also brings the communicator up before capture)
             self._restore(snap)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self._graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self._graph):
-            self._static_terms = self._forward_backward(self._static_batch)
-            if self.sync is None:
-                self._update(1.0)
+            if self.sync is not None and self.graph_collectives:
+                # the whole distributed step in the graph: every bucket's all-reduce is captured where its gradient
+                # notification fires (RCCL work on its own stream, joined back before the clip), then clip + Adam
+                self.sync.start_step()
+                self._static_terms = self._forward_backward(self._static_batch)
+                self._update(self.sync.finish_step())
+            else:
+                self._static_terms = self._forward_backward(self._static_batch)
+                if self.sync is None:
+                    self._update(1.0)
 
     def _collective_and_update(self):
         self.sync.start_step()
@@ -213,7 +229,7 @@ class Trainer(object):
                 if isinstance(v, torch.Tensor) and v.data_ptr() != self._static_batch[k].data_ptr():
                     self._static_batch[k].copy_(v, non_blocking=True)
         self._graph.replay()
-        if self.sync is not None:
+        if self.sync is not None and not self.graph_collectives:
             self._collective_and_update()
         self.step_count += 1
         return self._static_terms

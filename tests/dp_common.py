@@ -121,13 +121,16 @@ def worker_rccl(rank, port, tmp, case, dtype, use_graph, steps):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK='0', WORLD_SIZE='1', LOCAL_RANK='0',
                       EVE_AMD_BUCKET_ELEMS='1000000', EVE_AMD_FORCE_DIST='1', HSA_ENABLE_IPC_MODE_LEGACY='0')
     os.environ.pop('EVE_AMD_DIST_BACKEND', None)
+    if use_graph == 'captured':                # the bucket all-reduces inside the hipGraph as well
+        os.environ['EVE_AMD_GRAPH_COLLECTIVES'] = '1'
     import torch.distributed as dist
     from eve_amd import parallel
     install_kernels('cuda')
     r, _, w = parallel.init_distributed(backend='nccl')
     assert (r, w) == (0, 1) and dist.get_backend() == 'nccl'
     cfg, make, full = build(case, 'cuda', dtype, 1e-7 if use_graph else None)
-    tr = make(True, use_graph)
+    tr = make(True, bool(use_graph))
+    assert tr.graph_collectives == (use_graph == 'captured')
     batch = {k: v.to('cuda') for k, v in full.items()}
     for _ in range(steps):
         terms = tr.step(batch)

@@ -33,13 +33,16 @@ def test_two_ranks_one_gpu_hipgraph_replay_with_eager_collectives(tmp_path):
     dp_common.run_and_compare(str(tmp_path), 'eyenet', 'cuda', 'bf16', use_graph=True)
 
 
-@pytest.mark.parametrize('use_graph', [False, True])
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize('use_graph', [False, True, 'captured'], ids=['eager', 'graph+eager-collectives', 'collectives-captured'])
 def test_rccl_transport_single_rank(tmp_path, use_graph):
     """backend nccl (= RCCL) with the one rank a one-GPU box allows: a world of one makes every all-reduce the identity
     and 1/world = 1, so the distributed trainer (eager launches or hipGraph replay + eager collectives, buckets launched
     from the in-place weight-gradient notifications onto the communication stream) must reproduce the plain trainer --
     up to the summation order of the weight-gradient atomics, which differs between any two runs -- and it only does if
-    the collectives are ordered correctly against the backward kernels before them and clip + Adam after them."""
+    the collectives are ordered correctly against the backward kernels before them and clip + Adam after them.
+    'collectives-captured' (EVE_AMD_GRAPH_COLLECTIVES=1): the all-reduces, the clip and Adam are part of the captured
+    hipGraph too (RCCL under stream capture), one replay = the whole distributed step."""
     import torch
     a, flat, grad, loss, lr = dp_common.run_rccl_single_rank(str(tmp_path), 'eyenet', 'bf16', use_graph)
     assert a['buckets'] >= 3
