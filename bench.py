@@ -266,11 +266,16 @@ def main():
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--no-graph', action='store_true', help='launch every kernel eagerly instead of replaying a hipGraph')
     ap.add_argument('--graph', action='store_true', help='force hipGraph replay also with several ranks')
+    ap.add_argument('--graph-collectives', action='store_true',
+                    help='several ranks: capture the bucket all-reduces, the clip and Adam into the hipGraph as well (RCCL)')
     ap.add_argument('--profile-steps', type=int, default=2)
     ap.add_argument('--no-c3', action='store_true', help='skip the configs[2] (EyeNet + RefineNet pipeline) measurement')
     ap.add_argument('--no-points', action='store_true', help='skip the extra operating points (fp32 parity mode, B=8 per GPU)')
     args = ap.parse_args()
 
+    if args.graph_collectives:
+        os.environ['EVE_AMD_GRAPH_COLLECTIVES'] = '1'
+        args.graph = True
     import eve_amd
     from eve_amd import parallel, train
     from eve_amd.kernels import default_kernels
@@ -350,7 +355,8 @@ def main():
                                    % (args.size, args.size),
                        'global_batch': world * args.batch, 'batch_per_gpu': args.batch, 'seq_len': args.seq,
                        'parallelism': 'dp%d' % world},
-            'final_loss': loss, 'hip_graph': use_graph, 'ranks_seen': ranks_seen,
+            'final_loss': loss, 'hip_graph': use_graph, 'graph_collectives': bool(getattr(trainer, 'graph_collectives', False)),
+            'ranks_seen': ranks_seen,
             'kernel_tree_sha': __import__('eve_amd.build', fromlist=['kernel_tree_sha']).kernel_tree_sha(),
         }
         peak = MFMA_PEAK_TFLOPS[args.dtype]

@@ -36,6 +36,7 @@ SIGNATURES = {
     'eve_conv2d_dgrad_acc': [POINTER(ConvDesc), P, P, P, P],
     'eve_conv2d_wgrad': [POINTER(ConvDesc), P, P, P, I, P, P],
     'eve_conv2d_wgrad_bias': [POINTER(ConvDesc), P, P, P, P, P],
+    'eve_set_workspace': [P, ctypes.c_ulonglong],
     'eve_stem_pack_input': [I, I, I, I, I, P, P, P],
     'eve_frames_u8_to_nchw': [L, I, I, I, P, F, F, I, P, P],
     'eve_frames_u8_to_stem': [I, L, I, I, I, P, F, F, P, P],

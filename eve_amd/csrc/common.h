@@ -212,6 +212,9 @@ int set_error(hipError_t e, const char* where);
 int set_error_msg(const char* msg);
 // symbol of the kernel the calling thread launched last (benchmark attribution, see eve_last_kernel)
 extern thread_local const char* g_last_kernel;
+// device scratch registered by the caller (eve_set_workspace); nullptr / 0 when none
+extern void* g_workspace;
+extern unsigned long long g_workspace_bytes;
 }  // namespace eve
 #define EVE_MARK_KERNEL(name) (eve::g_last_kernel = (name))
 #define EVE_LAUNCH(name, ...) do { EVE_MARK_KERNEL(name); hipLaunchKernelGGL(__VA_ARGS__); } while (0)

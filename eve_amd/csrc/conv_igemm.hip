@@ -68,6 +68,7 @@ template <> struct Mma<float> {
 #include "conv_fast.h"
 #include "conv_wg8.h"
 #include "wgrad_halo.h"
+#include "wgrad_wg8.h"
 namespace eve {
 
 // =================================================================================================
@@ -862,7 +863,32 @@ static int launch_wgrad(const GatherParams& p, const void* x, const void* dy, co
             // address-decode mode of the gather (see wgrad_tr_kernel): both sizes powers of two / width only / neither
             const bool pow2w = (p.OW & (p.OW - 1)) == 0;
             const int mode = pow2 ? 1 : ((pow2w && p.OH * p.OW >= 32) ? 2 : 0);
-            if (p.Cout > 64) {
+            static int wg8w = -1;
+            if (wg8w < 0) { const char* e = getenv("EVE_WGRAD_WG8"); wg8w = (e && e[0] == '0') ? 0 : 1; }
+            if (wg8w && !db && mode == 1 && p.Cout % 256 == 0 && p.K % 256 == 0) {
+                // 256 x 256 tiles, eight waves of 128 x 64, role-split wave pairs (wgrad_wg8.h): one workgroup per CU
+                const uint32_t tk = p.K / 256, tc = p.Cout / 256;
+                wgrad_split(p, tk, tc, (size_t)128 * 1024, splits, rows);
+                static bool attr_done = false;
+                if (!attr_done) {
+                    (void)hipFuncSetAttribute((const void*)wgrad_wg8_kernel<T, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                    (void)hipFuncSetAttribute((const void*)wgrad_wg8_kernel<T, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                    attr_done = true;
+                }
+                const unsigned long long n = (unsigned long long)p.Cout * p.K;
+                const bool slab = splits > 1 && g_workspace && (unsigned long long)splits * n * 4 <= g_workspace_bytes && ((uintptr_t)dw & 15) == 0;
+                if (slab) {
+                    EVE_LAUNCH(EVE_HNAME(T, "wgrad_wg8_kernel<", ", true>"), (wgrad_wg8_kernel<T, true>), dim3(tk * tc * splits), dim3(512), (size_t)128 * 1024, s, p,
+                               (const T*)x, (const T*)dy, (float*)g_workspace, rows, (uint32_t)x_bytes, (uint32_t)dy_bytes);
+                    const long long n4 = (long long)(n / 4);
+                    long long blocks = (n4 + 255) / 256;
+                    if (blocks > 2048) blocks = 2048;
+                    hipLaunchKernelGGL(wgrad_slab_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (const float*)g_workspace, dw, n4, (int)splits);
+                } else {
+                    EVE_LAUNCH(EVE_HNAME(T, "wgrad_wg8_kernel<", ", false>"), (wgrad_wg8_kernel<T, false>), dim3(tk * tc * splits), dim3(512), (size_t)128 * 1024, s, p,
+                               (const T*)x, (const T*)dy, dw, rows, (uint32_t)x_bytes, (uint32_t)dy_bytes);
+                }
+            } else if (p.Cout > 64) {
                 const uint32_t tk = (p.K + 127) / 128, tc = (p.Cout + 127) / 128;
                 wgrad_split(p, tk, tc, lds_bytes(128, 128, mode), splits, rows);
                 if (mode == 1)      EVE_WGRAD_LAUNCH(2, 2, 1, tk, tc);

@@ -49,6 +49,19 @@ class HipKernels(object):
     def __init__(self):
         self.lib = _lib.load()
         self.prof = None          # list of (tag, flops, start_event, end_event) while profiling
+        self._workspace = None
+
+    def ensure_workspace(self, device, nbytes=None):
+        """Device scratch for the library (eve_set_workspace): the split-K partial filters of the weight-gradient kernels
+        (7 splits x 512 x 4608 floats = 66 MB for ResNet layer 4).  Allocated once by torch (the library never allocates),
+        before any hipGraph capture; without it the kernels fall back to float atomics."""
+        import os
+        if nbytes is None:
+            nbytes = int(os.environ.get('EVE_AMD_WORKSPACE_MB', '128')) << 20
+        if nbytes <= 0 or (self._workspace is not None and self._workspace.numel() >= nbytes and self._workspace.device == device):
+            return
+        self._workspace = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        self._ck(self.lib.eve_set_workspace(self._p(self._workspace), nbytes))
 
     # ------------------------------------------------------------------ per-launch timing (bench roofline)
     def start_profile(self):
@@ -172,6 +185,8 @@ class HipKernels(object):
         d = self._desc(x.dtype, N, IH, IW, Cin, Cout, KH, KW, stride, pad)
         assert tuple(dy.shape) == (N, d.OH, d.OW, Cout) and dy.dtype == x.dtype
         co, kk = algo or (Cout, KH * KW * Cin)
+        if x.dtype in HALF_DTYPES:
+            self.ensure_workspace(x.device)             # (first call: an eager warm-up step, before any graph capture)
         if db is not None:
             assert ss is None and db.shape == (Cout,) and db.dtype == torch.float32 and db.is_contiguous()
             self._timed('conv_wgrad', 2.0 * N * d.OH * d.OW * co * kk, lambda: self._ck(self.lib.eve_conv2d_wgrad_bias(

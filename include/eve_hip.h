@@ -47,6 +47,11 @@ int eve_abi_version(void);
  * profiler attribute a timed launch to the row of the same name in a rocprofv3 kernel summary.            */
 const char* eve_last_kernel(void);
 const char* eve_last_error(void);
+/* Caller-owned device scratch (16-byte aligned; NULL / 0 removes it).  The library never allocates: kernels that can use
+ * scratch -- today the split-K weight gradient of the 256..512-channel layers, which then writes per-split partial filters
+ * with plain stores and sums them in a second launch instead of 16 M float atomics -- read it from here, on the stream
+ * they are launched on, and fall back to their scratch-free form when it is missing or too small.  One stream at a time.   */
+int eve_set_workspace(void* device_ptr, unsigned long long bytes);
 
 /* ------------------------------------------------------------------------------------------------
  * Convolution as implicit GEMM on MFMA.  Replaces every nn.Conv2d / nn.Linear forward on the path:
