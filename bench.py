@@ -137,6 +137,28 @@ def pmc_traffic(symbol, suffix='_pmc_hbm_per_kernel.json'):
     return None, None
 
 
+def kernel_roofline(sym, d, mfma_peak, profile_steps, overhead):
+    """Roofline of one kernel symbol from its HIP-event launch durations.  The bound is the roof the kernel's ALGORITHMIC
+    intensity puts it under: FLOP per byte (operands read once, result written once) against the ridge mfma_peak / 8 TB/s
+    (312 FLOP/B in bf16: ResNet layer 1's 3x3 convolutions sit at 288, layers 2-4 at 575 .. 2 300) -- SURVEY.md 8(d)."""
+    ms = d['ms'] * 1e-3
+    tf = d['flops'] / ms / 1e12
+    gbs = d['bytes'] / ms / 1e9
+    ai = d['flops'] / d['bytes'] if d['bytes'] else float('inf')
+    hbm = d['flops'] == 0 or ai < mfma_peak * 1e12 / (HBM_PEAK_GBS * 1e9)
+    traffic, traffic_src = pmc_traffic(sym)
+    r = {'bound': 'hbm' if hbm else 'mfma', 'kernel': 'eve::' + sym,
+         'achieved': gbs if hbm else tf, 'peak': HBM_PEAK_GBS if hbm else mfma_peak, 'unit': 'GB/s' if hbm else 'TFLOP/s',
+         'frac': (gbs / HBM_PEAK_GBS) if hbm else (tf / mfma_peak), 'traffic': traffic,
+         'traffic_unit': 'bytes per launch (FETCH_SIZE x2 + WRITE_SIZE)', 'traffic_source': traffic_src,
+         'launches_per_step': d['launches'] / profile_steps, 'avg_launch_ms': d['ms'] / d['launches'],
+         'algorithmic_gflop_per_launch': d['flops'] / d['launches'] / 1e9,
+         'algorithmic_mb_per_launch': d['bytes'] / d['launches'] / 1e6, 'flop_per_byte': ai,
+         'mfma_frac': tf / mfma_peak, 'hbm_frac': gbs / HBM_PEAK_GBS,
+         'event_pair_overhead_ms_subtracted': overhead}
+    return r
+
+
 def bench_c3(args, device, k):
     """BASELINE configs[2]: configs/refine_net.json with refine_net_rnn_type=CGRU through eve_amd.EVE --
     EyeNet frozen and forward-only, offset augmentation, gaze geometry, heat-maps, RefineNet trained (fused conv-GRU
@@ -366,17 +388,13 @@ def main():
         if prof:
             # the dominant KERNEL (one symbol = one row of the rocprofv3 kernel summary in profiles/), by total time
             dom = max(by_kernel, key=lambda t: by_kernel[t]['ms'])
-            d = by_kernel[dom]
-            achieved = d['flops'] / (d['ms'] * 1e-3) / 1e12
-            sym = 'eve::' + dom
-            traffic, traffic_src = pmc_traffic(dom)
-            out['roofline'] = {'bound': 'mfma', 'kernel': sym, 'achieved': achieved, 'peak': peak,
-                               'unit': 'TFLOP/s', 'frac': achieved / peak, 'traffic': traffic,
-                               'traffic_unit': 'bytes per launch (FETCH_SIZE x2 + WRITE_SIZE)', 'traffic_source': traffic_src,
-                               'launches_per_step': d['launches'] / args.profile_steps,
-                               'avg_launch_ms': d['ms'] / d['launches'],
-                               'algorithmic_gflop_per_launch': d['flops'] / d['launches'] / 1e9,
-                               'event_pair_overhead_ms_subtracted': event_overhead}
+            out['roofline'] = kernel_roofline(dom, by_kernel[dom], peak, args.profile_steps, event_overhead)
+            # ... and the heaviest kernel on the OTHER side of the ridge, so that both roofs are on the line
+            for t in sorted(by_kernel, key=lambda t: -by_kernel[t]['ms']):
+                r = kernel_roofline(t, by_kernel[t], peak, args.profile_steps, event_overhead)
+                if r['bound'] != out['roofline']['bound'] and by_kernel[t]['flops'] > 0:
+                    out['roofline_other_bound'] = r
+                    break
             out['kernels_ms_per_step'] = {t: round(by_kernel[t]['ms'] / args.profile_steps, 4) for t in by_kernel}
             out['kernel_groups_ms_per_step'] = {t: prof[t]['ms'] / args.profile_steps for t in prof}
             out['kernel_groups_tflops'] = {t: prof[t]['flops'] / (prof[t]['ms'] * 1e-3) / 1e12 for t in prof}

@@ -194,7 +194,7 @@ class HipKernels(object):
             return dw_ohwi
         self._timed('conv_wgrad', 2.0 * N * d.OH * d.OW * co * kk, lambda: self._ck(self.lib.eve_conv2d_wgrad(
             ctypes.byref(d), self._p(x), self._p(dy), self._p(self._f32(ss, 'scale/shift')), pro_act,
-            self._p(dw_ohwi), self._stream())))
+            self._p(dw_ohwi), self._stream())), (x, dy, dw_ohwi))
         return dw_ohwi
 
     def stem_pack_input(self, src_nchw, out=None, dtype=torch.bfloat16):
