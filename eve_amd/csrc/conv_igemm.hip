@@ -578,6 +578,10 @@ static bool launch_halo(const GatherParams& p, const void* src, const void* w, c
     // ---- eight-wave workgroups, 32x32x16 MFMA, staggered wave groups (conv_wg8.h): whole square images per tile ----
     static int wg8 = -1;
     if (wg8 < 0) { const char* e = getenv("EVE_CONV_WG8"); wg8 = e ? atoi(e) : 1; }
+    // one 512-thread workgroup per CU: below ~7/8 of the CUs' worth of tiles (B = 8 clips per GPU: 60-120 tiles) the
+    // four-wave kernels with their 128-pixel tiles fill the chip better
+    static int wg8_min_tiles = -1;
+    if (wg8_min_tiles < 0) { const char* e = getenv("EVE_CONV_WG8_MIN_TILES"); wg8_min_tiles = e ? atoi(e) : 224; }
     if (wg8 && H == W && p.Cin % 64 == 0 && ((epi_act & ~0xff) == 0) &&
         ((epi_act & 0xff) == EVE_ACT_NONE || (epi_act & 0xff) == EVE_ACT_RELU)) {
         const unsigned long long xb8 = (unsigned long long)p.N * H * W * p.Cin * 2, wb8 = (unsigned long long)p.Cout * p.K * 2;
@@ -593,6 +597,7 @@ static bool launch_halo(const GatherParams& p, const void* src, const void* w, c
             }                                                                                                            \
             g.tiles_n = (uint32_t)(p.Cout / G8::COUT_T);                                                                   \
             const uint32_t tiles8 = (uint32_t)((p.N + G8::TI - 1) / G8::TI) * g.tiles_n;                                     \
+            if ((int)tiles8 < wg8_min_tiles) break;      /* too few whole-CU workgroups (small batches): four-wave kernels */ \
             EVE_LAUNCH(EVE_HNAME(HT, "conv3x3_wg8_kernel<", ", " #WM_ ", " #WN_ ", " #W_ ">"), (conv3x3_wg8_kernel<HT, WM_, WN_, W_>), dim3(tiles8), \
                        dim3(512), G8::LDS, s, g, (const HT*)src, (const HT*)w, bias, epi_act, (HT*)out);                   \
             return true;                                                                                                 \
