@@ -28,7 +28,7 @@ class PackItem(Structure):
 
 
 PACK_BATCH_MAX = 48
-ABI_VERSION = 4          # include/eve_hip.h EVE_ABI_VERSION
+ABI_VERSION = 5          # include/eve_hip.h EVE_ABI_VERSION
 
 SIGNATURES = {
     'eve_conv2d_fwd': [POINTER(ConvDesc), P, P, P, I, P, I, P, P],
@@ -66,6 +66,8 @@ SIGNATURES = {
     'eve_instnorm_stats': [I, I, I, I, P, F, P, P],
     'eve_instnorm_act_fwd': [I, I, I, I, P, P, P, P, P, I, P, P],
     'eve_instnorm_act_bwd': [I, I, I, I, P, P, P, P, P, P, I, P, P, P, P],
+    'eve_instnorm_act2_fwd': [I, I, I, I, P, P, P, P, P, P, I, P, P, I, P],
+    'eve_instnorm_act2_bwd': [I, I, I, I, P, P, I, P, P, P, P, P, P, I, P, P, P, P],
     'eve_instnorm_fwd_fused': [I, I, I, I, P, P, P, P, I, F, P, P, P, P],
     'eve_instnorm_bwd_fused': [I, I, I, I, P, P, P, P, P, P, I, P, P, P, P, P],
     'eve_act_bwd': [I, L, P, P, I, P, P],

@@ -302,6 +302,169 @@ __global__ __launch_bounds__(256) void in_act_bwd_kernel(const T* __restrict__ d
         }
 }
 
+// ---- two heads over one normalised input (RefineNet's pre-activation blocks, /root/reference/src/models/refine_net.py:46-47,
+// 59-60: `layers` and `skip_layer` both start with InstanceNorm(affine) -> activation of the SAME block input) ----
+// Forward: x is read once, both heads are written; each head may land in a channel range of a wider tensor (pixel stride
+// ldy elements, the caller offsets the pointers): the decoder's torch.cat([upsampled, encoder]) (refine_net.py:125-126) is
+// normalised source by source -- statistics are per channel -- straight into the concatenated layout and never exists
+// un-normalised.  grid = (chunks, planes) as in_act_fwd_kernel.
+template <typename T, int ACT>
+__global__ __launch_bounds__(256) void in_act2_fwd_kernel(const T* __restrict__ x, const float* __restrict__ mr,
+                                                          const float* __restrict__ gamma_a, const float* __restrict__ beta_a,
+                                                          const float* __restrict__ gamma_b, const float* __restrict__ beta_b,
+                                                          const int act_rt, T* __restrict__ y_a, T* __restrict__ y_b,
+                                                          const int HW, const int C, const int ldy) {
+    constexpr int VEC = Elem<T>::VEC;
+    const int act = ACT >= 0 ? ACT : act_rt;
+    const int cvecs = C / VEC, per_img = HW * cvecs;
+    const int n = blockIdx.y;
+    const int stride = gridDim.x * 256;                       // a multiple of cvecs (launcher)
+    const int i0 = blockIdx.x * 256 + threadIdx.x;
+    const int cv = i0 % cvecs;
+    float aa[VEC], ba[VEC], ab[VEC], bb[VEC];
+    {
+        const float* m = mr + ((size_t)n * C + cv * VEC) * 2;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            const int c = cv * VEC + e;
+            const float rstd = m[2 * e + 1], sh = -m[2 * e] * rstd;
+            aa[e] = rstd * gamma_a[c]; ba[e] = sh * gamma_a[c] + beta_a[c];
+            ab[e] = y_b ? rstd * gamma_b[c] : 0.f; bb[e] = y_b ? sh * gamma_b[c] + beta_b[c] : 0.f;
+        }
+    }
+    const size_t xbase = (size_t)n * per_img;
+    const size_t ybase = (size_t)n * HW * ldy + (size_t)cv * VEC;
+    const int pstep = stride / cvecs;
+    int px = i0 / cvecs;
+#pragma unroll 4
+    for (int i = i0; i < per_img; i += stride, px += pstep) {
+        float f[VEC], o[VEC];
+        Elem<T>::unpack(reinterpret_cast<const uint4*>(x)[xbase + i], f);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) o[e] = act_fwd(f[e] * aa[e] + ba[e], act);
+        *reinterpret_cast<uint4*>(y_a + ybase + (size_t)px * ldy) = Elem<T>::pack(o);
+        if (y_b) {
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) o[e] = act_fwd(f[e] * ab[e] + bb[e], act);
+            *reinterpret_cast<uint4*>(y_b + ybase + (size_t)px * ldy) = Elem<T>::pack(o);
+        }
+    }
+}
+
+// Backward of the two heads: g_h = dy_h * act'(head h's output, recomputed from x), dx = sum over heads of
+// k_h * (g_h - mean g_h - xhat * mean(g_h xhat)): the fork's gradient sum is formed in registers (the single-head kernel
+// twice + an add kernel moved 13 tensor passes, this one 7).  dy_a / dy_b have pixel stride lddy (channel ranges of the
+// wider gradient).  One workgroup per image, two passes like in_act_bwd_kernel.
+template <typename T, int ACT>
+__global__ __launch_bounds__(256) void in_act2_bwd_kernel(const T* __restrict__ dy_a, const T* __restrict__ dy_b, const int lddy,
+                                                          const T* __restrict__ x, const float* __restrict__ mr,
+                                                          const float* __restrict__ gamma_a, const float* __restrict__ beta_a,
+                                                          const float* __restrict__ gamma_b, const float* __restrict__ beta_b,
+                                                          const int act_rt, T* __restrict__ dx,
+                                                          float* __restrict__ sums_a, float* __restrict__ sums_b, int HW, int C) {
+    constexpr int VEC = Elem<T>::VEC;
+    const int act = ACT >= 0 ? ACT : act_rt;
+    __shared__ float sh[4 * 256 * VEC];
+    __shared__ float sh_tot[4 * 1024];
+    const int cvecs = C / VEC, phases = 256 / cvecs;
+    const int tid = threadIdx.x, cv = tid % cvecs, ph = tid / cvecs;
+    const bool on = ph < phases;
+    const int cvc = on ? cv : 0;
+    const bool two = dy_b != nullptr;
+    const size_t xbase = (size_t)blockIdx.x * HW * C + cvc * VEC;
+    const size_t gbase = (size_t)blockIdx.x * HW * lddy + cvc * VEC;
+    float mean[VEC], rstd[VEC], za[VEC], zb[VEC], wa[VEC], wb[VEC];     // head a: x * za + zb, head b: x * wa + wb
+    {
+        const float* m = mr + ((size_t)blockIdx.x * C + cvc * VEC) * 2;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            const int c = cvc * VEC + e;
+            mean[e] = m[2 * e]; rstd[e] = m[2 * e + 1];
+            za[e] = rstd[e] * gamma_a[c]; zb[e] = -mean[e] * za[e] + beta_a[c];
+            wa[e] = two ? rstd[e] * gamma_b[c] : 0.f; wb[e] = two ? -mean[e] * wa[e] + beta_b[c] : 0.f;
+        }
+    }
+    auto grads = [&](int px, float (&ga)[VEC], float (&gb)[VEC], float (&xh)[VEC]) {
+        float xx[VEC];
+        Elem<T>::unpack(*reinterpret_cast<const uint4*>(x + xbase + (size_t)px * C), xx);
+        Elem<T>::unpack(*reinterpret_cast<const uint4*>(dy_a + gbase + (size_t)px * lddy), ga);
+        if (two) Elem<T>::unpack(*reinterpret_cast<const uint4*>(dy_b + gbase + (size_t)px * lddy), gb);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            xh[e] = (xx[e] - mean[e]) * rstd[e];
+            if (act != EVE_ACT_NONE) {
+                ga[e] *= act_grad_from_out(act_fwd(xx[e] * za[e] + zb[e], act), act);
+                gb[e] = two ? gb[e] * act_grad_from_out(act_fwd(xx[e] * wa[e] + wb[e], act), act) : 0.f;
+            } else if (!two) gb[e] = 0.f;
+        }
+    };
+    float acc[4][VEC];                  // sum g_a | sum g_a xhat | sum g_b | sum g_b xhat
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) acc[q][e] = 0.f;
+    if (on)
+#pragma unroll 2
+        for (int px = ph; px < HW; px += phases) {
+            float ga[VEC], gb[VEC], xh[VEC];
+            grads(px, ga, gb, xh);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                acc[0][e] += ga[e]; acc[1][e] += ga[e] * xh[e];
+                acc[2][e] += gb[e]; acc[3][e] += gb[e] * xh[e];
+            }
+        }
+    if (on) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) sh[q * 256 * VEC + (ph * cvecs + cv) * VEC + e] = acc[q][e];
+    }
+    __syncthreads();
+    if (on && ph == 0) {
+        for (int r = 1; r < phases; ++r)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) acc[q][e] += sh[q * 256 * VEC + (r * cvecs + cv) * VEC + e];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) sh_tot[q * 1024 + cv * VEC + e] = acc[q][e];
+        float* oa = sums_a + ((size_t)blockIdx.x * C + cv * VEC) * 2;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) { oa[2 * e] = acc[0][e]; oa[2 * e + 1] = acc[1][e]; }
+        if (two) {
+            float* ob = sums_b + ((size_t)blockIdx.x * C + cv * VEC) * 2;
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) { ob[2 * e] = acc[2][e]; ob[2 * e + 1] = acc[3][e]; }
+        }
+    }
+    __syncthreads();
+    const float inv = 1.f / (float)HW;
+    float ka[VEC], kb[VEC];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) acc[q][e] = sh_tot[q * 1024 + cvc * VEC + e] * inv;
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+        const int c = cvc * VEC + e;
+        ka[e] = rstd[e] * gamma_a[c];
+        kb[e] = two ? rstd[e] * gamma_b[c] : 0.f;
+    }
+    if (on)
+#pragma unroll 2
+        for (int px = ph; px < HW; px += phases) {
+            float ga[VEC], gb[VEC], xh[VEC];
+            grads(px, ga, gb, xh);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e)
+                ga[e] = ka[e] * (ga[e] - acc[0][e] - xh[e] * acc[1][e]) + kb[e] * (gb[e] - acc[2][e] - xh[e] * acc[3][e]);
+            *reinterpret_cast<uint4*>(dx + xbase + (size_t)px * C) = Elem<T>::pack(ga);
+        }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void act_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ y, int act,
                                                       T* __restrict__ dx, long long n) {
@@ -425,6 +588,55 @@ extern "C" int eve_instnorm_act_bwd(int dtype, int N, int HW, int C, const void*
         EVE_IN_ACT_DISPATCH(in_act_bwd_kernel, f16_t, "eve::f16_t", dim3(N), (const f16_t*)dy, (const f16_t*)y, (const f16_t*)x, mean_rstd, gamma, beta, act, (f16_t*)dx, (f16_t*)dres, sums, HW, C);
     else
         EVE_IN_ACT_DISPATCH(in_act_bwd_kernel, float, "float", dim3(N), (const float*)dy, (const float*)y, (const float*)x, mean_rstd, gamma, beta, act, (float*)dx, (float*)dres, sums, HW, C);
+    EVE_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int eve_instnorm_act2_fwd(int dtype, int N, int HW, int C, const void* x, const float* mean_rstd,
+                                     const float* gamma_a, const float* beta_a, const float* gamma_b, const float* beta_b,
+                                     int act, void* y_a, void* y_b, int ldy, eve_stream_t stream) {
+    if (int e = check_plane(dtype, N, HW, C, "instnorm_act2_fwd: bad shape")) return e;
+    const int vec = dtype != EVE_DT_F32 ? 8 : 4;
+    if (!x || !mean_rstd || !y_a || !gamma_a || !beta_a || (y_b && (!gamma_b || !beta_b)) || ldy < C || ldy % vec ||
+        ((uintptr_t)y_a & 15) || ((uintptr_t)y_b & 15))
+        return set_error_msg("instnorm_act2_fwd: null pointer / misaligned head / ldy < C");
+    const int cvecs = C / vec;
+    const long long per_img = (long long)HW * cvecs;
+    if ((long long)HW * ldy >= (1ll << 31) || N > 65535) return set_error_msg("instnorm_act2_fwd: plane / batch too large");
+    int g = cvecs, h256 = 256;
+    while (h256) { const int t = g % h256; g = h256; h256 = t; }          // gcd(cvecs, 256)
+    const int mult = cvecs / g;
+    long long chunks = (per_img + 2047) / 2048;
+    if (chunks > 32) chunks = 32;
+    chunks = (chunks + mult - 1) / mult * mult;
+    const dim3 fgrid((unsigned)chunks, (unsigned)N);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == EVE_DT_BF16)
+        EVE_IN_ACT_DISPATCH(in_act2_fwd_kernel, bf16_t, "eve::bf16_t", fgrid, (const bf16_t*)x, mean_rstd, gamma_a, beta_a, gamma_b, beta_b, act, (bf16_t*)y_a, (bf16_t*)y_b, HW, C, ldy);
+    else if (dtype == EVE_DT_F16)
+        EVE_IN_ACT_DISPATCH(in_act2_fwd_kernel, f16_t, "eve::f16_t", fgrid, (const f16_t*)x, mean_rstd, gamma_a, beta_a, gamma_b, beta_b, act, (f16_t*)y_a, (f16_t*)y_b, HW, C, ldy);
+    else
+        EVE_IN_ACT_DISPATCH(in_act2_fwd_kernel, float, "float", fgrid, (const float*)x, mean_rstd, gamma_a, beta_a, gamma_b, beta_b, act, (float*)y_a, (float*)y_b, HW, C, ldy);
+    EVE_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int eve_instnorm_act2_bwd(int dtype, int N, int HW, int C, const void* dy_a, const void* dy_b, int lddy,
+                                     const void* x, const float* mean_rstd, const float* gamma_a, const float* beta_a,
+                                     const float* gamma_b, const float* beta_b, int act, void* dx, float* sums_a,
+                                     float* sums_b, eve_stream_t stream) {
+    if (int e = check_plane(dtype, N, HW, C, "instnorm_act2_bwd: bad shape")) return e;
+    const int vec = dtype != EVE_DT_F32 ? 8 : 4;
+    if (!dy_a || !x || !mean_rstd || !dx || !gamma_a || !beta_a || !sums_a || (dy_b && (!gamma_b || !beta_b || !sums_b)) ||
+        lddy < C || lddy % vec || ((uintptr_t)dy_a & 15) || ((uintptr_t)dy_b & 15))
+        return set_error_msg("instnorm_act2_bwd: null pointer / misaligned head / lddy < C");
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == EVE_DT_BF16)
+        EVE_IN_ACT_DISPATCH(in_act2_bwd_kernel, bf16_t, "eve::bf16_t", dim3(N), (const bf16_t*)dy_a, (const bf16_t*)dy_b, lddy, (const bf16_t*)x, mean_rstd, gamma_a, beta_a, gamma_b, beta_b, act, (bf16_t*)dx, sums_a, sums_b, HW, C);
+    else if (dtype == EVE_DT_F16)
+        EVE_IN_ACT_DISPATCH(in_act2_bwd_kernel, f16_t, "eve::f16_t", dim3(N), (const f16_t*)dy_a, (const f16_t*)dy_b, lddy, (const f16_t*)x, mean_rstd, gamma_a, beta_a, gamma_b, beta_b, act, (f16_t*)dx, sums_a, sums_b, HW, C);
+    else
+        EVE_IN_ACT_DISPATCH(in_act2_bwd_kernel, float, "float", dim3(N), (const float*)dy_a, (const float*)dy_b, lddy, (const float*)x, mean_rstd, gamma_a, beta_a, gamma_b, beta_b, act, (float*)dx, sums_a, sums_b, HW, C);
     EVE_CHECK_LAUNCH();
     return 0;
 }

@@ -492,6 +492,39 @@ class HipKernels(object):
             self._p(sums), self._stream())), (dy, x, y, dy, x, y, dx, dres))
         return dx, dres, sums
 
+    def _p_at(self, t, elem_off):
+        """Pointer to element `elem_off` of a contiguous tensor (a channel range of a wider NHWC tensor)."""
+        if not t.is_cuda or not t.is_contiguous():
+            raise RuntimeError('eve_amd: strided head needs a contiguous GPU tensor')
+        return ctypes.c_void_p(t.data_ptr() + elem_off * t.element_size())
+
+    def instnorm_act2_fwd(self, x, mr, gamma_a, beta_a, gamma_b, beta_b, act, out_a, out_b, c_off):
+        """Two heads act(gamma_h * xhat + beta_h) of one input, written into channels [c_off, c_off + C) of out_a / out_b
+        ([N, H, W, Ctot] tensors, Ctot >= C; out_b / gamma_b / beta_b may be None)."""
+        N, H, W, C = x.shape
+        ldy = out_a.shape[-1]
+        assert out_a.shape[:3] == x.shape[:3] and (out_b is None or out_b.shape == out_a.shape)
+        self._timed('in_fwd', 0.0, lambda: self._ck(self.lib.eve_instnorm_act2_fwd(
+            dt_code(x.dtype), N, H * W, C, self._p(x), self._p(mr), self._p(self._f32(gamma_a, 'gamma')),
+            self._p(self._f32(beta_a, 'beta')), self._p(self._f32(gamma_b, 'gamma')), self._p(self._f32(beta_b, 'beta')), act,
+            self._p_at(out_a, c_off), None if out_b is None else self._p_at(out_b, c_off), ldy, self._stream())),
+            (x, x, None if out_b is None else x))
+
+    def instnorm_act2_bwd(self, dy_a, dy_b, c_off, x, mr, gamma_a, beta_a, gamma_b, beta_b, act):
+        """Backward of instnorm_act2_fwd for one source: dy_a / dy_b are the [N, H, W, Ctot] head gradients, of which
+        channels [c_off, c_off + C) belong to x.  Returns (dx, sums_a, sums_b)."""
+        N, H, W, C = x.shape
+        lddy = dy_a.shape[-1]
+        dx = torch.empty_like(x)
+        sums_a = torch.empty((N, C, 2), dtype=torch.float32, device=x.device)
+        sums_b = torch.empty((N, C, 2), dtype=torch.float32, device=x.device) if dy_b is not None else None
+        self._timed('in_bwd', 0.0, lambda: self._ck(self.lib.eve_instnorm_act2_bwd(
+            dt_code(x.dtype), N, H * W, C, self._p_at(dy_a, c_off), None if dy_b is None else self._p_at(dy_b, c_off), lddy,
+            self._p(x), self._p(mr), self._p(self._f32(gamma_a, 'gamma')), self._p(self._f32(beta_a, 'beta')),
+            self._p(self._f32(gamma_b, 'gamma')), self._p(self._f32(beta_b, 'beta')), act, self._p(dx), self._p(sums_a),
+            self._p(sums_b), self._stream())), (x, x, x, x, None if dy_b is None else x, None if dy_b is None else x, dx))
+        return dx, sums_a, sums_b
+
     def instnorm_fwd_fused(self, x, gamma, beta, res, act, eps=1e-5, want_mask=False):
         """Single-launch stats + apply; returns (y, mean_rstd) or None when the plane is too large.
         want_mask: also the sign mask of y (one byte per 16-byte vector) -> (y, mean_rstd, mask)."""

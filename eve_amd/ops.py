@@ -594,6 +594,56 @@ def instnorm_act(x, gamma=None, beta=None, res=None, act=ACT_NONE, eps=1e-5):
     return InstNormActFn.apply(x, gamma, beta, res, act, eps)
 
 
+class InstNormAct2Fn(torch.autograd.Function):
+    """(a, b) = act(gamma_h * IN(cat(xs)) + beta_h) for two affine heads h over the channel-concatenation of 1-2 NHWC sources.
+    RefineNet's pre-activation BasicBlock (refine_net.py:46-47,59-60) normalises its input twice -- `layers.0` and
+    `skip_layer.0` -- and the decoder's input is a torch.cat (refine_net.py:125-126): InstanceNorm statistics are per channel,
+    so each source is normalised on its own, read once for both heads and written straight into its channel range of the
+    two outputs; the backward forms the fork's gradient sum in registers (kernels: eve_instnorm_act2_{fwd,bwd})."""
+
+    @staticmethod
+    def forward(ctx, act, eps, gamma_a, beta_a, gamma_b, beta_b, *xs):
+        k = default_kernels()
+        ctot = sum(x.shape[-1] for x in xs)
+        f32 = lambda t: t.detach().float().contiguous()
+        ga, ba, gb, bb = f32(gamma_a), f32(beta_a), f32(gamma_b), f32(beta_b)
+        out_a = torch.empty(tuple(xs[0].shape[:3]) + (ctot,), dtype=xs[0].dtype, device=xs[0].device)
+        out_b = torch.empty_like(out_a)
+        mrs, off = [], 0
+        for x in xs:
+            c = x.shape[-1]
+            mr = k.instnorm_stats(x, eps)
+            k.instnorm_act2_fwd(x, mr, ga[off:off + c].contiguous(), ba[off:off + c].contiguous(),
+                                gb[off:off + c].contiguous(), bb[off:off + c].contiguous(), act, out_a, out_b, off)
+            mrs.append(mr)
+            off += c
+        ctx.act, ctx.n = act, len(xs)
+        ctx.save_for_backward(ga, ba, gb, bb, *xs, *mrs)
+        return out_a, out_b
+
+    @staticmethod
+    def backward(ctx, d_a, d_b):
+        k = default_kernels()
+        ga, ba, gb, bb = ctx.saved_tensors[:4]
+        xs, mrs = ctx.saved_tensors[4:4 + ctx.n], ctx.saved_tensors[4 + ctx.n:]
+        d_a, d_b = d_a.contiguous(), d_b.contiguous()
+        dxs, sa, sb, off = [], [], [], 0
+        for x, mr in zip(xs, mrs):
+            c = x.shape[-1]
+            dx, s_a, s_b = k.instnorm_act2_bwd(d_a, d_b, off, x, mr, ga[off:off + c].contiguous(), ba[off:off + c].contiguous(),
+                                               gb[off:off + c].contiguous(), bb[off:off + c].contiguous(), ctx.act)
+            dxs.append(dx)
+            sa.append(s_a.sum(dim=0))           # [C, 2]: tiny N-reduction of per-plane partials
+            sb.append(s_b.sum(dim=0))
+            off += c
+        sa, sb = torch.cat(sa, dim=0), torch.cat(sb, dim=0)
+        return (None, None, sa[:, 1], sa[:, 0], sb[:, 1], sb[:, 0]) + tuple(dxs)
+
+
+def instnorm_act2(xs, gamma_a, beta_a, gamma_b, beta_b, act, eps=1e-5):
+    return InstNormAct2Fn.apply(act, eps, gamma_a, beta_a, gamma_b, beta_b, *xs)
+
+
 class AddFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, a, b):

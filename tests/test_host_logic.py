@@ -39,7 +39,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), name
     lib.eve_abi_version.restype = ctypes.c_int
-    assert lib.eve_abi_version() == _lib.ABI_VERSION == 4
+    assert lib.eve_abi_version() == _lib.ABI_VERSION == 5
 
 
 def test_missing_library_fails_loudly(tmp_path, monkeypatch):

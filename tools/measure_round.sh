@@ -25,7 +25,19 @@ python tools/pmc_hbm_summary.py $O/pmc_b_FETCH_SIZE $O/pmc_b_WRITE_SIZE bench.py
 python tools/pmc_hbm_summary.py $O/pmc_c_FETCH_SIZE $O/pmc_c_WRITE_SIZE tools/bench_eve.py --steps 2 > $O/c3_pmc_hbm_per_kernel.json
 rm -rf $O/pmc_b_* $O/pmc_c_*
 # the bench lines proper (un-profiled); the fresh PMC summaries are put where bench.py looks for them
-cp $O/pmc_hbm_per_kernel.json profiles/r02_pmc_hbm_per_kernel.json
-cp $O/c3_pmc_hbm_per_kernel.json profiles/r02_c3_pmc_hbm_per_kernel.json
+RN=${ROUND:-r03}
+cp $O/pmc_hbm_per_kernel.json profiles/${RN}_pmc_hbm_per_kernel.json
+cp $O/c3_pmc_hbm_per_kernel.json profiles/${RN}_c3_pmc_hbm_per_kernel.json
 python bench.py > $O/bench.json 2> $O/bench.err
-python bench.py --batch 8 --no-cpu-baseline --no-c3 > $O/bench_b8.json 2>> $O/bench.err
+python bench.py --batch 8 --no-cpu-baseline --no-c3 --no-points > $O/bench_b8.json 2>> $O/bench.err
+python bench.py --dtype fp16 --no-cpu-baseline --no-c3 --no-points > $O/bench_fp16.json 2>> $O/bench.err
+# copies for profiles/ (gpurun_out/ is scratch; the caller commits profiles/ after the call)
+mkdir -p $O/profiles
+cp $O/bench.json $O/profiles/${RN}_bench.json
+cp $O/bench_b8.json $O/profiles/${RN}_bench_b8.json
+cp $O/bench_fp16.json $O/profiles/${RN}_bench_fp16.json
+cp $O/bench_kernel_stats.csv $O/profiles/${RN}_bench_kernel_stats.csv
+cp $O/eve_c3_kernel_stats.csv $O/profiles/${RN}_eve_c3_kernel_stats.csv
+cp $O/pmc_hbm_per_kernel.json $O/profiles/${RN}_pmc_hbm_per_kernel.json
+cp $O/c3_pmc_hbm_per_kernel.json $O/profiles/${RN}_c3_pmc_hbm_per_kernel.json
+[ -f $O/pytest_gpu.log ] && cp $O/pytest_gpu.log $O/profiles/${RN}_pytest_gpu.log
