@@ -135,7 +135,7 @@ __device__ __forceinline__ float act_fwd(float z, int act) {
 // ResNet trunk) or the general one.
 // bit 8 of the epilogue word: out += result (the data gradient of a residual branch lands on the gradient the
 // other branch already wrote)
-#define EVE_EPI_ACC 0x100
+#define EVE_EPI_ACC EVE_EPI_ACCUMULATE
 __device__ __forceinline__ bool act_is_fast(int act) { return (act & 0xff) == EVE_ACT_NONE || (act & 0xff) == EVE_ACT_RELU; }
 template <bool FAST>
 __device__ __forceinline__ void act_fwd4(float* o, int act) {

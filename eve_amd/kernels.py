@@ -14,6 +14,7 @@ from . import _lib
 from ._lib import ConvDesc
 
 ACT_NONE, ACT_RELU, ACT_LEAKY, ACT_SELU, ACT_TANH, ACT_SIGMOID = range(6)
+EPI_ACCUMULATE = 0x100          # include/eve_hip.h EVE_EPI_ACCUMULATE: y += act(conv + bias)
 DT_F32, DT_BF16, DT_F16 = 0, 1, 2
 HALF_DTYPES = (torch.bfloat16, torch.float16)      # the two 16-bit instantiations of the MFMA kernels
 
@@ -142,17 +143,26 @@ class HipKernels(object):
         return d
 
     # ------------------------------------------------------------------ convolution
-    def conv2d_fwd(self, x, w_ohwi, bias, stride, pad, epi_act=ACT_NONE, ss=None, pro_act=ACT_NONE, algo=None):
-        """algo = (true Cout, true KH*KW*Cin) when channels are zero-padded (algorithmic FLOP count)."""
+    def conv2d_fwd(self, x, w_ohwi, bias, stride, pad, epi_act=ACT_NONE, ss=None, pro_act=ACT_NONE, algo=None,
+                   accumulate_into=None):
+        """algo = (true Cout, true KH*KW*Cin) when channels are zero-padded (algorithmic FLOP count).
+        accumulate_into: a contiguous [N, OH, OW, Cout] tensor the result is ADDED to in the kernel epilogue
+        (EVE_EPI_ACCUMULATE; the block's `layers(x) + skip_layer(x)` without an add launch); returned."""
         N, IH, IW, Cin = x.shape
         Cout, KH, KW, Cin2 = w_ohwi.shape
         assert Cin2 == Cin and w_ohwi.dtype == x.dtype
         d = self._desc(x.dtype, N, IH, IW, Cin, Cout, KH, KW, stride, pad)
-        y = torch.empty((N, d.OH, d.OW, Cout), dtype=x.dtype, device=x.device)
+        if accumulate_into is not None:
+            y = accumulate_into
+            assert tuple(y.shape) == (N, d.OH, d.OW, Cout) and y.dtype == x.dtype and y.is_contiguous() and ss is None
+            epi_act = epi_act | EPI_ACCUMULATE
+        else:
+            y = torch.empty((N, d.OH, d.OW, Cout), dtype=x.dtype, device=x.device)
         co, kk = algo or (Cout, KH * KW * Cin)
         self._timed('conv_fwd', 2.0 * N * d.OH * d.OW * co * kk, lambda: self._ck(self.lib.eve_conv2d_fwd(
             ctypes.byref(d), self._p(x), self._p(w_ohwi), self._p(self._f32(bias, 'bias')), epi_act,
-            self._p(self._f32(ss, 'scale/shift')), pro_act, self._p(y), self._stream())), (x, w_ohwi, y))
+            self._p(self._f32(ss, 'scale/shift')), pro_act, self._p(y), self._stream())),
+            (x, w_ohwi, y) + ((y,) if accumulate_into is not None else ()))
         return y
 
     def conv2d_dgrad(self, dy, w_ihwo, in_hw, stride, pad, algo=None, accumulate_into=None):

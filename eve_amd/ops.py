@@ -151,7 +151,7 @@ class Conv2dFn(torch.autograd.Function):
     `pack` holds the packed copies (possibly with zero-padded Cin/Cout)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, pack, stride, pad, epi_act):
+    def forward(ctx, x, weight, bias, pack, stride, pad, epi_act, acc=None):
         k = default_kernels()
         b = bias
         cout_p = pack.ohwi.shape[0]
@@ -161,14 +161,24 @@ class Conv2dFn(torch.autograd.Function):
                 b = torch.nn.functional.pad(b, (0, cout_p - b.numel()))
             b = b.contiguous()
         ks = pack.ohwi.shape[1]
-        if _group_ok(pack.pair_fwd, x, ks, stride, pad):
+        if acc is None and _group_ok(pack.pair_fwd, x, ks, stride, pad):
             F, wg = pack.pair_fwd
             N, H, W, C = x.shape
             y = k.conv2d_fwd(x.view(N, H, W // F, F * C), wg, None if b is None else b.repeat(F), 1, pad, epi_act,
                              algo=pack.algo).view(N, H, W, cout_p)
+        elif acc is not None:
+            # y = acc + conv(x): accumulated in the kernel epilogue, `acc` (another branch's output) is updated in place
+            # (the caller hands over the other branch's freshly produced output, which nothing else reads or saved; the
+            #  result is returned as a separate tensor object over the same storage -- `acc` may itself be a view made
+            #  inside another custom Function, which autograd refuses to mark dirty)
+            assert epi_act == ACT_NONE and acc.is_contiguous()
+            k.conv2d_fwd(x, pack.ohwi, b, stride, pad, epi_act, algo=pack.algo, accumulate_into=acc)
+            y = torch.empty(0, dtype=acc.dtype, device=acc.device).set_(acc.untyped_storage(), acc.storage_offset(),
+                                                                        acc.shape, acc.stride())
         else:
             y = k.conv2d_fwd(x, pack.ohwi, b, stride, pad, epi_act, algo=pack.algo)
         ctx.pack, ctx.stride, ctx.pad, ctx.epi_act = pack, stride, pad, epi_act
+        ctx.has_acc = acc is not None
         ctx.has_bias = bias is not None
         ctx.wshape = tuple(weight.shape)
         # parameters re-homed by train.FlatParameters take their gradient straight into the flat buffer
@@ -229,7 +239,7 @@ class Conv2dFn(torch.autograd.Function):
             k.bias_grad(dy, db_pending)
         if b_direct:
             _notify_grad_ready(ctx.b_direct)
-        return dx, dw, db, None, None, None, None
+        return dx, dw, db, None, None, None, None, (dy if ctx.has_acc else None)
 
 
 class StemConvFn(torch.autograd.Function):
@@ -281,8 +291,9 @@ class StemFusedFn(torch.autograd.Function):
         return None, None, dwp[:O, :, :, :I].permute(0, 3, 1, 2), None, None
 
 
-def conv2d(x, weight, bias, pack, stride=1, pad=0, act=ACT_NONE):
-    return Conv2dFn.apply(x, weight, bias, pack, stride, pad, act)
+def conv2d(x, weight, bias, pack, stride=1, pad=0, act=ACT_NONE, acc=None):
+    """acc: a tensor of the output's shape that the result is added to IN PLACE (returned); no activation then."""
+    return Conv2dFn.apply(x, weight, bias, pack, stride, pad, act, acc)
 
 
 class LinearFn(torch.autograd.Function):

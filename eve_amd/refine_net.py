@@ -163,8 +163,8 @@ class RefineNet(nn.Module):
         self._packs, self._packs_key = P, key
         return P
 
-    def _conv(self, x, name, m, P, act=ACT_NONE):
-        return ops.conv2d(x, m.weight, m.bias, P[name], stride=1, pad=m.padding[0], act=act)
+    def _conv(self, x, name, m, P, act=ACT_NONE, acc=None):
+        return ops.conv2d(x, m.weight, m.bias, P[name], stride=1, pad=m.padding[0], act=act, acc=acc)
 
     # ------------------------------------------------------------------ blocks
     def _block(self, x, blk, prefix, P):
@@ -184,8 +184,8 @@ class RefineNet(nn.Module):
         a = self._conv(a, prefix + '.layers.2', L[2], P)
         a = ops.instnorm_act(a, L[3].weight, L[3].bias, act=blk.act)
         a = self._conv(a, prefix + '.layers.5', L[5], P)
-        if S is not None:
-            skip = self._conv(skip, prefix + '.skip_layer.2', S[2], P)
+        if S is not None:           # layers(x) + skip_layer(x): the 1x1 convolution accumulates into the 3x3 branch's output
+            return self._conv(skip, prefix + '.skip_layer.2', S[2], P, acc=a)
         return ops.add(a, skip)
 
     def _encode(self, x, P):

@@ -67,7 +67,11 @@ typedef struct eve_conv_desc {
 } eve_conv_desc;
 
 /* y = act(conv(x', w) + bias),  x' = pro_act(x * scale[n,c] + shift[n,c]) when in_scale_shift != NULL
- * (float [N][Cin][2]; padding stays zero AFTER the transform), else x' = x.  bias may be NULL.    */
+ * (float [N][Cin][2]; padding stays zero AFTER the transform), else x' = x.  bias may be NULL.
+ * epi_act = EVE_ACT_* [| EVE_EPI_ACCUMULATE]: with the flag the result is ADDED to what y holds (y += act(...)) in the
+ * kernel epilogue -- `layers(x) + skip_layer(x)` of RefineNet's BasicBlock (refine_net.py:64-67) is the 1x1 skip
+ * convolution accumulating into the 3x3 branch's output, no add launch.                                              */
+#define EVE_EPI_ACCUMULATE 0x100
 int eve_conv2d_fwd(const eve_conv_desc* d, const void* x, const void* w_ohwi, const float* bias,
                    int epi_act, const float* in_scale_shift, int pro_act, void* y,
                    eve_stream_t stream);

@@ -49,9 +49,13 @@ class FakeKernels(object):
             return x.float()
         return act_fwd(x.float() * ss[:, None, None, :, 0] + ss[:, None, None, :, 1], pro_act)
 
-    def conv2d_fwd(self, x, w_ohwi, bias, stride, pad, epi_act=ACT_NONE, ss=None, pro_act=ACT_NONE, algo=None):
+    def conv2d_fwd(self, x, w_ohwi, bias, stride, pad, epi_act=ACT_NONE, ss=None, pro_act=ACT_NONE, algo=None,
+                   accumulate_into=None):
         xin = self._pro(x, ss, pro_act).to(x.dtype)
         y = F.conv2d(nchw(xin), w_ohwi.permute(0, 3, 1, 2).float(), bias, stride, pad)
+        if accumulate_into is not None:
+            accumulate_into.copy_((accumulate_into.float() + nhwc(act_fwd(y, epi_act), torch.float32)).to(x.dtype))
+            return accumulate_into
         return nhwc(act_fwd(y, epi_act), x.dtype)
 
     def conv2d_dgrad(self, dy, w_ihwo, in_hw, stride, pad, algo=None, accumulate_into=None):

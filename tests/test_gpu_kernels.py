@@ -255,6 +255,25 @@ def test_stem_wgrad_from_packed_patches(hip, hdt):
     assert ((got - ref).norm() / ref.norm()).item() < 2e-3
 
 
+@pytest.mark.parametrize('dtype', DTYPES, ids=DT_IDS)
+@pytest.mark.parametrize('case', [(2, 72, 128, 16, 32, 1), (2, 36, 64, 32, 64, 1), (2, 18, 32, 128, 64, 1), (3, 9, 16, 256, 128, 1),
+                                  (2, 36, 64, 64, 64, 3), (2, 8, 8, 256, 256, 3)], ids=lambda c: 'x'.join(map(str, c)))
+def test_conv_forward_accumulates_into_its_output(hip, ref, dtype, case):
+    """EVE_EPI_ACCUMULATE: y += conv(x, w) + bias in the kernel epilogue (RefineNet's `layers(x) + skip_layer(x)`), for the
+    1x1 skip convolutions of every level and a 3x3; against base + the same kernel's plain result (one extra rounding)."""
+    N, H, W, Cin, Cout, K = case
+    x = rnd((N, H, W, Cin), dtype, 51)
+    w = rnd((Cout, K, K, Cin), dtype, 52, scale=0.1)
+    b = rnd((Cout,), torch.float32, 53, scale=0.1)
+    base = rnd((N, H, W, Cout), dtype, 54)
+    plain = hip.conv2d_fwd(dev(x), dev(w), dev(b), 1, K // 2)
+    got = hip.conv2d_fwd(dev(x), dev(w), dev(b), 1, K // 2, accumulate_into=dev(base).clone())
+    want = ref.conv2d_fwd(x.float(), w.float(), b, 1, K // 2).float() + base.float()
+    close(got, want.to(dtype), dtype, 'accumulating conv forward', scale=float(want.abs().max()))
+    # and exactly plain + base up to the rounding of `plain`
+    close(got, (plain.float().cpu() + base.float()).to(dtype), dtype, 'accumulating conv vs plain + base', scale=float(want.abs().max()))
+
+
 def test_conv_rejects_bad_shapes(hip):
     x = torch.zeros((1, 8, 8, 6), device='cuda')
     w = torch.zeros((8, 3, 3, 6), device='cuda')
