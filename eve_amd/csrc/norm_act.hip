@@ -308,38 +308,56 @@ __global__ __launch_bounds__(256) void in_act_bwd_kernel(const T* __restrict__ d
 // ldy elements, the caller offsets the pointers): the decoder's torch.cat([upsampled, encoder]) (refine_net.py:125-126) is
 // normalised source by source -- statistics are per channel -- straight into the concatenated layout and never exists
 // un-normalised.  grid = (chunks, planes) as in_act_fwd_kernel.
+// A launch covers ONE source (x2 == nullptr) or BOTH sources of the concatenation: source 1 owns channels [0, C) of the wide
+// tensors, source 2 [C, C + C2).  The two sources of an image write (forward) / read (backward) the two parts of the same
+// 128-byte lines: their workgroups are placed 8 planes apart in dispatch order -- same XCD, same L2 -- so a line is
+// filled / fetched once (as separate launches every line of the wide gradient crossed HBM twice: 1.12 ms per 72 x 128
+// decoder launch against 0.72 for its algorithmic bytes).
+struct In2Src { uint32_t n, src; };
+__device__ __forceinline__ In2Src in2_plane(uint32_t b, bool two, int N) {
+    if (!two) return In2Src{b, 0u};
+    const uint32_t grp = b >> 4, r = b & 15u;
+    return In2Src{grp * 8u + (r & 7u), r >> 3};
+}
+
 template <typename T, int ACT>
 __global__ __launch_bounds__(256) void in_act2_fwd_kernel(const T* __restrict__ x, const float* __restrict__ mr,
                                                           const float* __restrict__ gamma_a, const float* __restrict__ beta_a,
                                                           const float* __restrict__ gamma_b, const float* __restrict__ beta_b,
                                                           const int act_rt, T* __restrict__ y_a, T* __restrict__ y_b,
-                                                          const int HW, const int C, const int ldy) {
+                                                          const int N, const int HW, const int C, const int ldy,
+                                                          const T* __restrict__ x2, const float* __restrict__ mr2, const int C2) {
     constexpr int VEC = Elem<T>::VEC;
     const int act = ACT >= 0 ? ACT : act_rt;
-    const int cvecs = C / VEC, per_img = HW * cvecs;
-    const int n = blockIdx.y;
-    const int stride = gridDim.x * 256;                       // a multiple of cvecs (launcher)
+    const In2Src ps = in2_plane(blockIdx.y, x2 != nullptr, N);
+    if (ps.n >= (uint32_t)N) return;
+    const int n = (int)ps.n;
+    const int Cs = ps.src ? C2 : C, coff = ps.src ? C : 0;
+    const T* xs = ps.src ? x2 : x;
+    const float* mrs = ps.src ? mr2 : mr;
+    const int cvecs = Cs / VEC, per_img = HW * cvecs;
+    const int stride = gridDim.x * 256;                       // a multiple of both sources' cvecs (launcher)
     const int i0 = blockIdx.x * 256 + threadIdx.x;
     const int cv = i0 % cvecs;
     float aa[VEC], ba[VEC], ab[VEC], bb[VEC];
     {
-        const float* m = mr + ((size_t)n * C + cv * VEC) * 2;
+        const float* m = mrs + ((size_t)n * Cs + cv * VEC) * 2;
 #pragma unroll
         for (int e = 0; e < VEC; ++e) {
-            const int c = cv * VEC + e;
+            const int c = coff + cv * VEC + e;
             const float rstd = m[2 * e + 1], sh = -m[2 * e] * rstd;
             aa[e] = rstd * gamma_a[c]; ba[e] = sh * gamma_a[c] + beta_a[c];
             ab[e] = y_b ? rstd * gamma_b[c] : 0.f; bb[e] = y_b ? sh * gamma_b[c] + beta_b[c] : 0.f;
         }
     }
     const size_t xbase = (size_t)n * per_img;
-    const size_t ybase = (size_t)n * HW * ldy + (size_t)cv * VEC;
+    const size_t ybase = (size_t)n * HW * ldy + (size_t)(coff + cv * VEC);
     const int pstep = stride / cvecs;
     int px = i0 / cvecs;
 #pragma unroll 4
     for (int i = i0; i < per_img; i += stride, px += pstep) {
         float f[VEC], o[VEC];
-        Elem<T>::unpack(reinterpret_cast<const uint4*>(x)[xbase + i], f);
+        Elem<T>::unpack(reinterpret_cast<const uint4*>(xs)[xbase + i], f);
 #pragma unroll
         for (int e = 0; e < VEC; ++e) o[e] = act_fwd(f[e] * aa[e] + ba[e], act);
         *reinterpret_cast<uint4*>(y_a + ybase + (size_t)px * ldy) = Elem<T>::pack(o);
@@ -357,28 +375,36 @@ __global__ __launch_bounds__(256) void in_act2_fwd_kernel(const T* __restrict__ 
 // wider gradient).  One workgroup per image, two passes like in_act_bwd_kernel.
 template <typename T, int ACT>
 __global__ __launch_bounds__(256) void in_act2_bwd_kernel(const T* __restrict__ dy_a, const T* __restrict__ dy_b, const int lddy,
-                                                          const T* __restrict__ x, const float* __restrict__ mr,
+                                                          const T* __restrict__ x1, const float* __restrict__ mr1,
                                                           const float* __restrict__ gamma_a, const float* __restrict__ beta_a,
                                                           const float* __restrict__ gamma_b, const float* __restrict__ beta_b,
-                                                          const int act_rt, T* __restrict__ dx,
-                                                          float* __restrict__ sums_a, float* __restrict__ sums_b, int HW, int C) {
+                                                          const int act_rt, T* __restrict__ dx1,
+                                                          float* __restrict__ sums_a, float* __restrict__ sums_b, int N, int HW, int C1,
+                                                          const T* __restrict__ x2, const float* __restrict__ mr2, T* __restrict__ dx2,
+                                                          int C2) {
     constexpr int VEC = Elem<T>::VEC;
     const int act = ACT >= 0 ? ACT : act_rt;
     __shared__ float sh[4 * 256 * VEC];
     __shared__ float sh_tot[4 * 1024];
+    const In2Src ps = in2_plane(blockIdx.x, x2 != nullptr, N);
+    if (ps.n >= (uint32_t)N) return;
+    const int C = ps.src ? C2 : C1, coff = ps.src ? C1 : 0, ctot = C1 + C2;
+    const T* x = ps.src ? x2 : x1;
+    const float* mr = ps.src ? mr2 : mr1;
+    T* dx = ps.src ? dx2 : dx1;
     const int cvecs = C / VEC, phases = 256 / cvecs;
     const int tid = threadIdx.x, cv = tid % cvecs, ph = tid / cvecs;
     const bool on = ph < phases;
     const int cvc = on ? cv : 0;
     const bool two = dy_b != nullptr;
-    const size_t xbase = (size_t)blockIdx.x * HW * C + cvc * VEC;
-    const size_t gbase = (size_t)blockIdx.x * HW * lddy + cvc * VEC;
+    const size_t xbase = (size_t)ps.n * HW * C + cvc * VEC;
+    const size_t gbase = (size_t)ps.n * HW * lddy + coff + cvc * VEC;
     float mean[VEC], rstd[VEC], za[VEC], zb[VEC], wa[VEC], wb[VEC];     // head a: x * za + zb, head b: x * wa + wb
     {
-        const float* m = mr + ((size_t)blockIdx.x * C + cvc * VEC) * 2;
+        const float* m = mr + ((size_t)ps.n * C + cvc * VEC) * 2;
 #pragma unroll
         for (int e = 0; e < VEC; ++e) {
-            const int c = cvc * VEC + e;
+            const int c = coff + cvc * VEC + e;
             mean[e] = m[2 * e]; rstd[e] = m[2 * e + 1];
             za[e] = rstd[e] * gamma_a[c]; zb[e] = -mean[e] * za[e] + beta_a[c];
             wa[e] = two ? rstd[e] * gamma_b[c] : 0.f; wb[e] = two ? -mean[e] * wa[e] + beta_b[c] : 0.f;
@@ -431,11 +457,11 @@ __global__ __launch_bounds__(256) void in_act2_bwd_kernel(const T* __restrict__ 
         for (int q = 0; q < 4; ++q)
 #pragma unroll
             for (int e = 0; e < VEC; ++e) sh_tot[q * 1024 + cv * VEC + e] = acc[q][e];
-        float* oa = sums_a + ((size_t)blockIdx.x * C + cv * VEC) * 2;
+        float* oa = sums_a + ((size_t)ps.n * ctot + coff + cv * VEC) * 2;
 #pragma unroll
         for (int e = 0; e < VEC; ++e) { oa[2 * e] = acc[0][e]; oa[2 * e + 1] = acc[1][e]; }
         if (two) {
-            float* ob = sums_b + ((size_t)blockIdx.x * C + cv * VEC) * 2;
+            float* ob = sums_b + ((size_t)ps.n * ctot + coff + cv * VEC) * 2;
 #pragma unroll
             for (int e = 0; e < VEC; ++e) { ob[2 * e] = acc[2][e]; ob[2 * e + 1] = acc[3][e]; }
         }
@@ -449,7 +475,7 @@ __global__ __launch_bounds__(256) void in_act2_bwd_kernel(const T* __restrict__ 
         for (int e = 0; e < VEC; ++e) acc[q][e] = sh_tot[q * 1024 + cvc * VEC + e] * inv;
 #pragma unroll
     for (int e = 0; e < VEC; ++e) {
-        const int c = cvc * VEC + e;
+        const int c = coff + cvc * VEC + e;
         ka[e] = rstd[e] * gamma_a[c];
         kb[e] = two ? rstd[e] * gamma_b[c] : 0.f;
     }
@@ -594,29 +620,33 @@ extern "C" int eve_instnorm_act_bwd(int dtype, int N, int HW, int C, const void*
 
 extern "C" int eve_instnorm_act2_fwd(int dtype, int N, int HW, int C, const void* x, const float* mean_rstd,
                                      const float* gamma_a, const float* beta_a, const float* gamma_b, const float* beta_b,
-                                     int act, void* y_a, void* y_b, int ldy, eve_stream_t stream) {
+                                     int act, void* y_a, void* y_b, int ldy, int C2, const void* x2,
+                                     const float* mean_rstd2, eve_stream_t stream) {
     if (int e = check_plane(dtype, N, HW, C, "instnorm_act2_fwd: bad shape")) return e;
+    if (x2) { if (int e = check_plane(dtype, N, HW, C2, "instnorm_act2_fwd: bad second source")) return e; }
     const int vec = dtype != EVE_DT_F32 ? 8 : 4;
-    if (!x || !mean_rstd || !y_a || !gamma_a || !beta_a || (y_b && (!gamma_b || !beta_b)) || ldy < C || ldy % vec ||
-        ((uintptr_t)y_a & 15) || ((uintptr_t)y_b & 15))
-        return set_error_msg("instnorm_act2_fwd: null pointer / misaligned head / ldy < C");
-    const int cvecs = C / vec;
-    const long long per_img = (long long)HW * cvecs;
-    if ((long long)HW * ldy >= (1ll << 31) || N > 65535) return set_error_msg("instnorm_act2_fwd: plane / batch too large");
-    int g = cvecs, h256 = 256;
-    while (h256) { const int t = g % h256; g = h256; h256 = t; }          // gcd(cvecs, 256)
-    const int mult = cvecs / g;
+    if (!x2) C2 = 0;
+    if (!x || !mean_rstd || !y_a || !gamma_a || !beta_a || (y_b && (!gamma_b || !beta_b)) || ldy < C + C2 || ldy % vec ||
+        ((uintptr_t)y_a & 15) || ((uintptr_t)y_b & 15) || (x2 && !mean_rstd2))
+        return set_error_msg("instnorm_act2_fwd: null pointer / misaligned head / ldy < C + C2");
+    const int cv1 = C / vec, cv2 = x2 ? C2 / vec : cv1;
+    const long long per_img = (long long)HW * (cv1 > cv2 ? cv1 : cv2);
+    if ((long long)HW * ldy >= (1ll << 31) || N > 30000) return set_error_msg("instnorm_act2_fwd: plane / batch too large");
+    auto gcd = [](int a, int b) { while (b) { const int t = a % b; a = b; b = t; } return a; };
+    const int l = cv1 / gcd(cv1, cv2) * cv2;                  // chunks * 256 must be a multiple of both vector counts
+    const int mult = l / gcd(l, 256);
     long long chunks = (per_img + 2047) / 2048;
     if (chunks > 32) chunks = 32;
     chunks = (chunks + mult - 1) / mult * mult;
-    const dim3 fgrid((unsigned)chunks, (unsigned)N);
+    const unsigned planes = x2 ? (unsigned)((N + 7) / 8) * 16u : (unsigned)N;
+    const dim3 fgrid((unsigned)chunks, planes);
     hipStream_t s = (hipStream_t)stream;
     if (dtype == EVE_DT_BF16)
-        EVE_IN_ACT_DISPATCH(in_act2_fwd_kernel, bf16_t, "eve::bf16_t", fgrid, (const bf16_t*)x, mean_rstd, gamma_a, beta_a, gamma_b, beta_b, act, (bf16_t*)y_a, (bf16_t*)y_b, HW, C, ldy);
+        EVE_IN_ACT_DISPATCH(in_act2_fwd_kernel, bf16_t, "eve::bf16_t", fgrid, (const bf16_t*)x, mean_rstd, gamma_a, beta_a, gamma_b, beta_b, act, (bf16_t*)y_a, (bf16_t*)y_b, N, HW, C, ldy, (const bf16_t*)x2, mean_rstd2, C2);
     else if (dtype == EVE_DT_F16)
-        EVE_IN_ACT_DISPATCH(in_act2_fwd_kernel, f16_t, "eve::f16_t", fgrid, (const f16_t*)x, mean_rstd, gamma_a, beta_a, gamma_b, beta_b, act, (f16_t*)y_a, (f16_t*)y_b, HW, C, ldy);
+        EVE_IN_ACT_DISPATCH(in_act2_fwd_kernel, f16_t, "eve::f16_t", fgrid, (const f16_t*)x, mean_rstd, gamma_a, beta_a, gamma_b, beta_b, act, (f16_t*)y_a, (f16_t*)y_b, N, HW, C, ldy, (const f16_t*)x2, mean_rstd2, C2);
     else
-        EVE_IN_ACT_DISPATCH(in_act2_fwd_kernel, float, "float", fgrid, (const float*)x, mean_rstd, gamma_a, beta_a, gamma_b, beta_b, act, (float*)y_a, (float*)y_b, HW, C, ldy);
+        EVE_IN_ACT_DISPATCH(in_act2_fwd_kernel, float, "float", fgrid, (const float*)x, mean_rstd, gamma_a, beta_a, gamma_b, beta_b, act, (float*)y_a, (float*)y_b, N, HW, C, ldy, (const float*)x2, mean_rstd2, C2);
     EVE_CHECK_LAUNCH();
     return 0;
 }
@@ -624,19 +654,23 @@ extern "C" int eve_instnorm_act2_fwd(int dtype, int N, int HW, int C, const void
 extern "C" int eve_instnorm_act2_bwd(int dtype, int N, int HW, int C, const void* dy_a, const void* dy_b, int lddy,
                                      const void* x, const float* mean_rstd, const float* gamma_a, const float* beta_a,
                                      const float* gamma_b, const float* beta_b, int act, void* dx, float* sums_a,
-                                     float* sums_b, eve_stream_t stream) {
+                                     float* sums_b, int C2, const void* x2, const float* mean_rstd2, void* dx2,
+                                     eve_stream_t stream) {
     if (int e = check_plane(dtype, N, HW, C, "instnorm_act2_bwd: bad shape")) return e;
+    if (x2) { if (int e = check_plane(dtype, N, HW, C2, "instnorm_act2_bwd: bad second source")) return e; }
     const int vec = dtype != EVE_DT_F32 ? 8 : 4;
+    if (!x2) C2 = 0;
     if (!dy_a || !x || !mean_rstd || !dx || !gamma_a || !beta_a || !sums_a || (dy_b && (!gamma_b || !beta_b || !sums_b)) ||
-        lddy < C || lddy % vec || ((uintptr_t)dy_a & 15) || ((uintptr_t)dy_b & 15))
-        return set_error_msg("instnorm_act2_bwd: null pointer / misaligned head / lddy < C");
+        lddy < C + C2 || lddy % vec || ((uintptr_t)dy_a & 15) || ((uintptr_t)dy_b & 15) || (x2 && (!mean_rstd2 || !dx2)))
+        return set_error_msg("instnorm_act2_bwd: null pointer / misaligned head / lddy < C + C2");
+    const dim3 grid(x2 ? (unsigned)((N + 7) / 8) * 16u : (unsigned)N);
     hipStream_t s = (hipStream_t)stream;
     if (dtype == EVE_DT_BF16)
-        EVE_IN_ACT_DISPATCH(in_act2_bwd_kernel, bf16_t, "eve::bf16_t", dim3(N), (const bf16_t*)dy_a, (const bf16_t*)dy_b, lddy, (const bf16_t*)x, mean_rstd, gamma_a, beta_a, gamma_b, beta_b, act, (bf16_t*)dx, sums_a, sums_b, HW, C);
+        EVE_IN_ACT_DISPATCH(in_act2_bwd_kernel, bf16_t, "eve::bf16_t", grid, (const bf16_t*)dy_a, (const bf16_t*)dy_b, lddy, (const bf16_t*)x, mean_rstd, gamma_a, beta_a, gamma_b, beta_b, act, (bf16_t*)dx, sums_a, sums_b, N, HW, C, (const bf16_t*)x2, mean_rstd2, (bf16_t*)dx2, C2);
     else if (dtype == EVE_DT_F16)
-        EVE_IN_ACT_DISPATCH(in_act2_bwd_kernel, f16_t, "eve::f16_t", dim3(N), (const f16_t*)dy_a, (const f16_t*)dy_b, lddy, (const f16_t*)x, mean_rstd, gamma_a, beta_a, gamma_b, beta_b, act, (f16_t*)dx, sums_a, sums_b, HW, C);
+        EVE_IN_ACT_DISPATCH(in_act2_bwd_kernel, f16_t, "eve::f16_t", grid, (const f16_t*)dy_a, (const f16_t*)dy_b, lddy, (const f16_t*)x, mean_rstd, gamma_a, beta_a, gamma_b, beta_b, act, (f16_t*)dx, sums_a, sums_b, N, HW, C, (const f16_t*)x2, mean_rstd2, (f16_t*)dx2, C2);
     else
-        EVE_IN_ACT_DISPATCH(in_act2_bwd_kernel, float, "float", dim3(N), (const float*)dy_a, (const float*)dy_b, lddy, (const float*)x, mean_rstd, gamma_a, beta_a, gamma_b, beta_b, act, (float*)dx, sums_a, sums_b, HW, C);
+        EVE_IN_ACT_DISPATCH(in_act2_bwd_kernel, float, "float", grid, (const float*)dy_a, (const float*)dy_b, lddy, (const float*)x, mean_rstd, gamma_a, beta_a, gamma_b, beta_b, act, (float*)dx, sums_a, sums_b, N, HW, C, (const float*)x2, mean_rstd2, (float*)dx2, C2);
     EVE_CHECK_LAUNCH();
     return 0;
 }

@@ -502,38 +502,40 @@ class HipKernels(object):
             self._p(sums), self._stream())), (dy, x, y, dy, x, y, dx, dres))
         return dx, dres, sums
 
-    def _p_at(self, t, elem_off):
-        """Pointer to element `elem_off` of a contiguous tensor (a channel range of a wider NHWC tensor)."""
-        if not t.is_cuda or not t.is_contiguous():
-            raise RuntimeError('eve_amd: strided head needs a contiguous GPU tensor')
-        return ctypes.c_void_p(t.data_ptr() + elem_off * t.element_size())
-
-    def instnorm_act2_fwd(self, x, mr, gamma_a, beta_a, gamma_b, beta_b, act, out_a, out_b, c_off):
-        """Two heads act(gamma_h * xhat + beta_h) of one input, written into channels [c_off, c_off + C) of out_a / out_b
-        ([N, H, W, Ctot] tensors, Ctot >= C; out_b / gamma_b / beta_b may be None)."""
+    def instnorm_act2_fwd(self, xs, mrs, gamma_a, beta_a, gamma_b, beta_b, act):
+        """Two heads act(gamma_h * xhat + beta_h) of the channel-concatenation of the 1-2 NHWC sources `xs` (statistics
+        `mrs` per source); returns (y_a, y_b), [N, H, W, sum C].  gamma_b / beta_b None: one head, y_b None."""
+        x, x2 = xs[0], (xs[1] if len(xs) > 1 else None)
         N, H, W, C = x.shape
-        ldy = out_a.shape[-1]
-        assert out_a.shape[:3] == x.shape[:3] and (out_b is None or out_b.shape == out_a.shape)
+        C2 = x2.shape[-1] if x2 is not None else 0
+        y_a = torch.empty((N, H, W, C + C2), dtype=x.dtype, device=x.device)
+        y_b = torch.empty_like(y_a) if gamma_b is not None else None
         self._timed('in_fwd', 0.0, lambda: self._ck(self.lib.eve_instnorm_act2_fwd(
-            dt_code(x.dtype), N, H * W, C, self._p(x), self._p(mr), self._p(self._f32(gamma_a, 'gamma')),
+            dt_code(x.dtype), N, H * W, C, self._p(x), self._p(mrs[0]), self._p(self._f32(gamma_a, 'gamma')),
             self._p(self._f32(beta_a, 'beta')), self._p(self._f32(gamma_b, 'gamma')), self._p(self._f32(beta_b, 'beta')), act,
-            self._p_at(out_a, c_off), None if out_b is None else self._p_at(out_b, c_off), ldy, self._stream())),
-            (x, x, None if out_b is None else x))
+            self._p(y_a), self._p(y_b), C + C2, C2, self._p(x2), self._p(mrs[1] if x2 is not None else None), self._stream())),
+            (x, x2, y_a, y_b))
+        return y_a, y_b
 
-    def instnorm_act2_bwd(self, dy_a, dy_b, c_off, x, mr, gamma_a, beta_a, gamma_b, beta_b, act):
-        """Backward of instnorm_act2_fwd for one source: dy_a / dy_b are the [N, H, W, Ctot] head gradients, of which
-        channels [c_off, c_off + C) belong to x.  Returns (dx, sums_a, sums_b)."""
+    def instnorm_act2_bwd(self, dy_a, dy_b, xs, mrs, gamma_a, beta_a, gamma_b, beta_b, act):
+        """Backward of instnorm_act2_fwd: dy_a / dy_b [N, H, W, sum C] (dy_b None with one head).
+        Returns ([dx per source], sums_a, sums_b) with sums [N, sum C, 2]."""
+        x, x2 = xs[0], (xs[1] if len(xs) > 1 else None)
         N, H, W, C = x.shape
-        lddy = dy_a.shape[-1]
+        C2 = x2.shape[-1] if x2 is not None else 0
+        assert dy_a.shape[-1] == C + C2
         dx = torch.empty_like(x)
-        sums_a = torch.empty((N, C, 2), dtype=torch.float32, device=x.device)
-        sums_b = torch.empty((N, C, 2), dtype=torch.float32, device=x.device) if dy_b is not None else None
+        dx2 = torch.empty_like(x2) if x2 is not None else None
+        sums_a = torch.empty((N, C + C2, 2), dtype=torch.float32, device=x.device)
+        sums_b = torch.empty_like(sums_a) if dy_b is not None else None
+        # two passes over (dy_a, dy_b, x), then the gradient: this kernel's algorithmic traffic
         self._timed('in_bwd', 0.0, lambda: self._ck(self.lib.eve_instnorm_act2_bwd(
-            dt_code(x.dtype), N, H * W, C, self._p_at(dy_a, c_off), None if dy_b is None else self._p_at(dy_b, c_off), lddy,
-            self._p(x), self._p(mr), self._p(self._f32(gamma_a, 'gamma')), self._p(self._f32(beta_a, 'beta')),
-            self._p(self._f32(gamma_b, 'gamma')), self._p(self._f32(beta_b, 'beta')), act, self._p(dx), self._p(sums_a),
-            self._p(sums_b), self._stream())), (x, x, x, x, None if dy_b is None else x, None if dy_b is None else x, dx))
-        return dx, sums_a, sums_b
+            dt_code(x.dtype), N, H * W, C, self._p(dy_a), self._p(dy_b), C + C2, self._p(x), self._p(mrs[0]),
+            self._p(self._f32(gamma_a, 'gamma')), self._p(self._f32(beta_a, 'beta')), self._p(self._f32(gamma_b, 'gamma')),
+            self._p(self._f32(beta_b, 'beta')), act, self._p(dx), self._p(sums_a), self._p(sums_b), C2, self._p(x2),
+            self._p(mrs[1] if x2 is not None else None), self._p(dx2), self._stream())),
+            (dy_a, dy_b, x, x2, dy_a, dy_b, x, x2, dx, dx2))
+        return ([dx] if x2 is None else [dx, dx2]), sums_a, sums_b
 
     def instnorm_fwd_fused(self, x, gamma, beta, res, act, eps=1e-5, want_mask=False):
         """Single-launch stats + apply; returns (y, mean_rstd) or None when the plane is too large.

@@ -167,12 +167,19 @@ class Conv2dFn(torch.autograd.Function):
             y = k.conv2d_fwd(x.view(N, H, W // F, F * C), wg, None if b is None else b.repeat(F), 1, pad, epi_act,
                              algo=pack.algo).view(N, H, W, cout_p)
         elif acc is not None:
+            grouped = _group_ok(pack.pair_fwd, x, ks, stride, pad)
             # y = acc + conv(x): accumulated in the kernel epilogue, `acc` (another branch's output) is updated in place
             # (the caller hands over the other branch's freshly produced output, which nothing else reads or saved; the
             #  result is returned as a separate tensor object over the same storage -- `acc` may itself be a view made
             #  inside another custom Function, which autograd refuses to mark dirty)
             assert epi_act == ACT_NONE and acc.is_contiguous()
-            k.conv2d_fwd(x, pack.ohwi, b, stride, pad, epi_act, algo=pack.algo, accumulate_into=acc)
+            if grouped:             # F pixels as one (narrow layers): same memory, F * C channels per grouped pixel
+                F, wg = pack.pair_fwd
+                N, H, W, C = x.shape
+                k.conv2d_fwd(x.view(N, H, W // F, F * C), wg, None if b is None else b.repeat(F), 1, pad, epi_act,
+                             algo=pack.algo, accumulate_into=acc.view(N, H, W // F, F * cout_p))
+            else:
+                k.conv2d_fwd(x, pack.ohwi, b, stride, pad, epi_act, algo=pack.algo, accumulate_into=acc)
             y = torch.empty(0, dtype=acc.dtype, device=acc.device).set_(acc.untyped_storage(), acc.storage_offset(),
                                                                         acc.shape, acc.stride())
         else:
@@ -615,19 +622,10 @@ class InstNormAct2Fn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, act, eps, gamma_a, beta_a, gamma_b, beta_b, *xs):
         k = default_kernels()
-        ctot = sum(x.shape[-1] for x in xs)
         f32 = lambda t: t.detach().float().contiguous()
         ga, ba, gb, bb = f32(gamma_a), f32(beta_a), f32(gamma_b), f32(beta_b)
-        out_a = torch.empty(tuple(xs[0].shape[:3]) + (ctot,), dtype=xs[0].dtype, device=xs[0].device)
-        out_b = torch.empty_like(out_a)
-        mrs, off = [], 0
-        for x in xs:
-            c = x.shape[-1]
-            mr = k.instnorm_stats(x, eps)
-            k.instnorm_act2_fwd(x, mr, ga[off:off + c].contiguous(), ba[off:off + c].contiguous(),
-                                gb[off:off + c].contiguous(), bb[off:off + c].contiguous(), act, out_a, out_b, off)
-            mrs.append(mr)
-            off += c
+        mrs = [k.instnorm_stats(x, eps) for x in xs]
+        out_a, out_b = k.instnorm_act2_fwd(xs, mrs, ga, ba, gb, bb, act)      # both sources, both heads: one launch
         ctx.act, ctx.n = act, len(xs)
         ctx.save_for_backward(ga, ba, gb, bb, *xs, *mrs)
         return out_a, out_b
@@ -637,17 +635,8 @@ class InstNormAct2Fn(torch.autograd.Function):
         k = default_kernels()
         ga, ba, gb, bb = ctx.saved_tensors[:4]
         xs, mrs = ctx.saved_tensors[4:4 + ctx.n], ctx.saved_tensors[4 + ctx.n:]
-        d_a, d_b = d_a.contiguous(), d_b.contiguous()
-        dxs, sa, sb, off = [], [], [], 0
-        for x, mr in zip(xs, mrs):
-            c = x.shape[-1]
-            dx, s_a, s_b = k.instnorm_act2_bwd(d_a, d_b, off, x, mr, ga[off:off + c].contiguous(), ba[off:off + c].contiguous(),
-                                               gb[off:off + c].contiguous(), bb[off:off + c].contiguous(), ctx.act)
-            dxs.append(dx)
-            sa.append(s_a.sum(dim=0))           # [C, 2]: tiny N-reduction of per-plane partials
-            sb.append(s_b.sum(dim=0))
-            off += c
-        sa, sb = torch.cat(sa, dim=0), torch.cat(sb, dim=0)
+        dxs, sa, sb = k.instnorm_act2_bwd(d_a.contiguous(), d_b.contiguous(), xs, mrs, ga, ba, gb, bb, ctx.act)
+        sa, sb = sa.sum(dim=0), sb.sum(dim=0)           # [C, 2]: tiny N-reduction of per-plane partials
         return (None, None, sa[:, 1], sa[:, 0], sb[:, 1], sb[:, 0]) + tuple(dxs)
 
 

@@ -194,20 +194,24 @@ int eve_instnorm_act_bwd(int dtype, int N, int HW, int C, const void* dy, const 
 
 /* Two affine + activation heads over ONE normalised input: RefineNet's pre-activation BasicBlock feeds the block input to
  * `layers` (refine_net.py:46-47) and to `skip_layer` (:59-60), each starting with InstanceNorm2d(affine) -> activation.
- * y_h = act(gamma_h * (x - mean) * rstd + beta_h);  x is read once.  y_a / y_b are [N][HW][ldy] with the head's C channels
- * at the pointer (ldy >= C, pointers 16-byte aligned): with ldy > C each head lands in a channel range of a wider tensor,
- * so the decoder's torch.cat([upsampled, encoder_output]) (refine_net.py:125-126) is normalised source by source into the
- * concatenated layout and never materialised un-normalised.  y_b / gamma_b / beta_b may be NULL (one head).            */
+ * y_h = act(gamma_h * (x - mean) * rstd + beta_h);  x is read once.  y_a / y_b are [N][HW][ldy] tensors (16-byte aligned).
+ * The input may be the channel-concatenation of TWO sources (the decoder's torch.cat([upsampled, encoder_output]),
+ * refine_net.py:125-126): x [N][HW][C] owns channels [0, C) of the heads, x2 [N][HW][C2] (nullable) channels [C, C + C2);
+ * InstanceNorm statistics are per channel, so each source is normalised on its own (mean_rstd / mean_rstd2 from
+ * eve_instnorm_stats) straight into the concatenated layout and the concatenation is never materialised un-normalised.
+ * gamma_h / beta_h: C + C2 floats.  ldy >= C + C2.  y_b / gamma_b / beta_b may be NULL (one head).                     */
 int eve_instnorm_act2_fwd(int dtype, int N, int HW, int C, const void* x, const float* mean_rstd,
                           const float* gamma_a, const float* beta_a, const float* gamma_b, const float* beta_b,
-                          int act, void* y_a, void* y_b, int ldy, eve_stream_t stream);
+                          int act, void* y_a, void* y_b, int ldy, int C2, const void* x2, const float* mean_rstd2,
+                          eve_stream_t stream);
 /* g_h = dy_h * act'(y_h) (y_h recomputed from x);  dx = sum_h gamma_h*rstd*(g_h - mean_hw(g_h) - xhat*mean_hw(g_h*xhat)):
- * the gradient sum of the fork is formed in registers.  dy_a / dy_b: [N][HW][lddy], the head's C channels at the pointer.
- * sums_h[n][c] = (sum_hw g_h, sum_hw g_h*xhat).  dy_b (with gamma_b, beta_b, sums_b) may be NULL.                      */
+ * the gradient sum of the fork is formed in registers.  dy_a / dy_b: [N][HW][lddy] gradients of the heads; dx / dx2: dense
+ * gradients of the sources.  sums_h[n][c] = (sum_hw g_h, sum_hw g_h*xhat) for the C + C2 channels.
+ * dy_b (with gamma_b, beta_b, sums_b) and the second source (x2, mean_rstd2, dx2) may be NULL.                         */
 int eve_instnorm_act2_bwd(int dtype, int N, int HW, int C, const void* dy_a, const void* dy_b, int lddy,
                           const void* x, const float* mean_rstd, const float* gamma_a, const float* beta_a,
                           const float* gamma_b, const float* beta_b, int act, void* dx, float* sums_a,
-                          float* sums_b, eve_stream_t stream);
+                          float* sums_b, int C2, const void* x2, const float* mean_rstd2, void* dx2, eve_stream_t stream);
 
 /* Single-pass variants for planes that fit one workgroup's registers (HW*C <= 64 Ki elements): statistics and
  * apply in one launch (also writes mean_rstd), and the whole backward in one read of dy / y / x.

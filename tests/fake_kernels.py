@@ -156,19 +156,29 @@ class FakeKernels(object):
         dx = k * (g - s1[:, None, None] / hw - xhat * s2[:, None, None] / hw)
         return dx.to(x.dtype), (g.to(x.dtype) if want_dres else None), torch.stack([s1, s2], dim=-1)
 
-    def instnorm_act2_fwd(self, x, mr, gamma_a, beta_a, gamma_b, beta_b, act, out_a, out_b, c_off):
-        c = x.shape[-1]
-        out_a[..., c_off:c_off + c] = self.instnorm_act_fwd(x, mr, gamma_a, beta_a, None, act)
-        if out_b is not None:
-            out_b[..., c_off:c_off + c] = self.instnorm_act_fwd(x, mr, gamma_b, beta_b, None, act)
+    def instnorm_act2_fwd(self, xs, mrs, gamma_a, beta_a, gamma_b, beta_b, act):
+        outs_a, outs_b, off = [], [], 0
+        for x, mr in zip(xs, mrs):
+            sl = slice(off, off + x.shape[-1])
+            outs_a.append(self.instnorm_act_fwd(x, mr, gamma_a[sl], beta_a[sl], None, act))
+            if gamma_b is not None:
+                outs_b.append(self.instnorm_act_fwd(x, mr, gamma_b[sl], beta_b[sl], None, act))
+            off += x.shape[-1]
+        return torch.cat(outs_a, dim=-1), (torch.cat(outs_b, dim=-1) if gamma_b is not None else None)
 
-    def instnorm_act2_bwd(self, dy_a, dy_b, c_off, x, mr, gamma_a, beta_a, gamma_b, beta_b, act):
-        c = x.shape[-1]
-        dxa, _, sa = self.instnorm_act_bwd(dy_a[..., c_off:c_off + c], None, x, mr, gamma_a, act, False, beta=beta_a)
-        if dy_b is None:
-            return dxa, sa, None
-        dxb, _, sb = self.instnorm_act_bwd(dy_b[..., c_off:c_off + c], None, x, mr, gamma_b, act, False, beta=beta_b)
-        return (dxa.float() + dxb.float()).to(x.dtype), sa, sb
+    def instnorm_act2_bwd(self, dy_a, dy_b, xs, mrs, gamma_a, beta_a, gamma_b, beta_b, act):
+        dxs, sas, sbs, off = [], [], [], 0
+        for x, mr in zip(xs, mrs):
+            sl = slice(off, off + x.shape[-1])
+            dxa, _, sa = self.instnorm_act_bwd(dy_a[..., sl].float(), None, x.float(), mr, gamma_a[sl], act, False, beta=beta_a[sl])
+            sas.append(sa)
+            if dy_b is not None:
+                dxb, _, sb = self.instnorm_act_bwd(dy_b[..., sl].float(), None, x.float(), mr, gamma_b[sl], act, False, beta=beta_b[sl])
+                sbs.append(sb)
+                dxa = dxa + dxb
+            dxs.append(dxa.to(x.dtype))
+            off += x.shape[-1]
+        return dxs, torch.cat(sas, dim=1), (torch.cat(sbs, dim=1) if dy_b is not None else None)
 
     def instnorm_fwd_fused(self, x, gamma, beta, res, act, eps=1e-5, want_mask=False):
         if x.shape[1] * x.shape[2] * x.shape[3] > 65536:

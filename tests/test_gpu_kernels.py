@@ -345,13 +345,14 @@ def test_instnorm_fwd_bwd(hip, ref, dtype, shape):
 
 
 @pytest.mark.parametrize('dtype', DTYPES, ids=DT_IDS)
-@pytest.mark.parametrize('shape,c2', [((2, 72, 128, 32), 32), ((2, 36, 64, 64), 64), ((3, 18, 32, 128), 64), ((2, 72, 128, 16), 0),
-                                      ((1, 7, 5, 8), 16)], ids=['72x128x32+32', '36x64x64+64', '18x32x128+64', '72x128x16', '7x5x8+16'])
-def test_instnorm_two_heads_into_channel_ranges(hip, ref, dtype, shape, c2):
-    """eve_instnorm_act2_{fwd,bwd}: two affine heads of one input (RefineNet `layers.0` / `skip_layer.0`), each source of a
-    channel-concatenation normalised into its own channel range.  Forward: every head equals the single-head kernel bit for
-    bit (same arithmetic), the other channels of the wide outputs stay untouched.  Backward: the fork's summed gradient
-    against the float32 restatement (sum formed before rounding), per-head sums against the single-head kernel."""
+@pytest.mark.parametrize('shape,c2', [((2, 72, 128, 32), 32), ((11, 36, 64, 64), 64), ((3, 18, 32, 128), 64), ((2, 72, 128, 16), 0),
+                                      ((9, 7, 5, 8), 16)], ids=['72x128x32+32', '11x36x64x64+64', '18x32x128+64', '72x128x16', '9x7x5x8+16'])
+def test_instnorm_two_heads_over_concatenated_sources(hip, ref, dtype, shape, c2):
+    """eve_instnorm_act2_{fwd,bwd}: two affine heads (RefineNet `layers.0` / `skip_layer.0`) over the channel-concatenation
+    of one or two sources, each source normalised on its own into its channel range (one launch; the sources of an image run
+    8 workgroups apart).  Forward: every head equals the single-head kernel on the materialised concatenation's slices bit
+    for bit.  Backward: the fork's summed gradient against the float32 restatement (sum formed before rounding), per-head
+    sums against it too; one head only equals the single-head kernel."""
     N, H, W, C1 = shape
     ctot = C1 + c2
     srcs = [(rnd(shape, torch.float32, 31) * 1.3 + 0.3 * rnd((N, 1, 1, C1), torch.float32, 32)).to(dtype)]
@@ -360,37 +361,37 @@ def test_instnorm_two_heads_into_channel_ranges(hip, ref, dtype, shape, c2):
     ga, ba = 1 + 0.2 * rnd((ctot,), torch.float32, 34), 0.1 * rnd((ctot,), torch.float32, 35)
     gb, bb = 1 - 0.3 * rnd((ctot,), torch.float32, 36), 0.2 * rnd((ctot,), torch.float32, 37)
     d_a, d_b = rnd((N, H, W, ctot), dtype, 38), rnd((N, H, W, ctot), dtype, 39)
+    dsrcs = [dev(x) for x in srcs]
+    mrs = [hip.instnorm_stats(x) for x in dsrcs]
     for act in (1, 2):
-        out_a = torch.full((N, H, W, ctot), 7.0, dtype=dtype, device='cuda')
-        out_b = torch.full((N, H, W, ctot), -7.0, dtype=dtype, device='cuda')
+        y_a, y_b = hip.instnorm_act2_fwd(dsrcs, mrs, dev(ga), dev(ba), dev(gb), dev(bb), act)
         off = 0
-        for x in srcs:
-            c = x.shape[-1]
-            sl = slice(off, off + c)
-            mr = hip.instnorm_stats(dev(x))
+        for x, mr in zip(dsrcs, mrs):
+            sl = slice(off, off + x.shape[-1])
             g = lambda t: dev(t[sl].contiguous())
-            hip.instnorm_act2_fwd(dev(x), mr, g(ga), g(ba), g(gb), g(bb), act, out_a, out_b, off)
-            y_a = hip.instnorm_act_fwd(dev(x), mr, g(ga), g(ba), None, act)
-            y_b = hip.instnorm_act_fwd(dev(x), mr, g(gb), g(bb), None, act)
-            assert torch.equal(out_a[..., sl], y_a) and torch.equal(out_b[..., sl], y_b)
-            if off + c < ctot and off == 0:                # the second source's range is still the fill value
-                assert bool((out_a[..., c:] == 7.0).all()) and bool((out_b[..., c:] == -7.0).all())
-            # backward of this source
-            dx, s_a, s_b = hip.instnorm_act2_bwd(dev(d_a), dev(d_b), off, dev(x), mr, g(ga), g(ba), g(gb), g(bb), act)
-            mr_c = mr.cpu()
-            dxa, _, sa = ref.instnorm_act_bwd(d_a[..., sl].contiguous().float(), None, x.float(), mr_c, ga[sl], act, False, beta=ba[sl])
-            dxb, _, sb = ref.instnorm_act_bwd(d_b[..., sl].contiguous().float(), None, x.float(), mr_c, gb[sl], act, False, beta=bb[sl])
-            want = dxa + dxb
+            assert torch.equal(y_a[..., sl], hip.instnorm_act_fwd(x, mr, g(ga), g(ba), None, act))
+            assert torch.equal(y_b[..., sl], hip.instnorm_act_fwd(x, mr, g(gb), g(bb), None, act))
+            off += x.shape[-1]
+        y1, none = hip.instnorm_act2_fwd(dsrcs, mrs, dev(ga), dev(ba), None, None, act)
+        assert none is None and torch.equal(y1, y_a)
+        dxs, s_a, s_b = hip.instnorm_act2_bwd(dev(d_a), dev(d_b), dsrcs, mrs, dev(ga), dev(ba), dev(gb), dev(bb), act)
+        want_dx, want_a, want_b = ref.instnorm_act2_bwd(d_a.float(), d_b.float(), [x.float() for x in srcs], [m.cpu() for m in mrs],
+                                                        ga, ba, gb, bb, act)
+        for dx, want in zip(dxs, want_dx):
             close(dx, want.to(dtype), dtype, 'two-head instnorm bwd dx act=%d' % act, scale=float(want.abs().max()) + 0.05)
-            close(s_a, sa, torch.float32, 'two-head sums a', scale=float(sa.abs().max()) * 4)
-            close(s_b, sb, torch.float32, 'two-head sums b', scale=float(sb.abs().max()) * 4)
-            # one head only (dy_b = None) is the single-head kernel's gradient
-            dx1, s1, none = hip.instnorm_act2_bwd(dev(d_a), None, off, dev(x), mr, g(ga), g(ba), None, None, act)
-            dx_single, _, s_single = hip.instnorm_act_bwd(dev(d_a[..., sl].contiguous()), None, dev(x), mr, g(ga), act, False, beta=g(ba))
-            assert none is None
-            close(dx1, dx_single.cpu(), dtype, 'one-head strided bwd', scale=float(dx_single.abs().max()) + 0.05)
-            close(s1, s_single.cpu(), torch.float32, 'one-head strided sums', scale=float(s_single.abs().max()) * 4)
-            off += c
+        close(s_a, want_a, torch.float32, 'two-head sums a', scale=float(want_a.abs().max()) * 4)
+        close(s_b, want_b, torch.float32, 'two-head sums b', scale=float(want_b.abs().max()) * 4)
+        # one head only (dy_b = None): the single-head kernel's gradient of each source
+        dx1, s1, none = hip.instnorm_act2_bwd(dev(d_a), None, dsrcs, mrs, dev(ga), dev(ba), None, None, act)
+        assert none is None
+        off = 0
+        for x, mr, got in zip(dsrcs, mrs, dx1):
+            sl = slice(off, off + x.shape[-1])
+            g = lambda t: dev(t[sl].contiguous())
+            dx_single, _, s_single = hip.instnorm_act_bwd(dev(d_a[..., sl].contiguous()), None, x, mr, g(ga), act, False, beta=g(ba))
+            close(got, dx_single.cpu(), dtype, 'one-head bwd', scale=float(dx_single.abs().max()) + 0.05)
+            close(s1[:, sl], s_single.cpu(), torch.float32, 'one-head sums', scale=float(s_single.abs().max()) * 4)
+            off += x.shape[-1]
 
 
 def test_channel_split_instnorm_equals_the_single_workgroup_kernel(tmp_path):
