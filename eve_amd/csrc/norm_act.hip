@@ -526,6 +526,22 @@ __global__ __launch_bounds__(256) void add_kernel(const T* __restrict__ a, const
         Elem<T>::st(o + i, Elem<T>::ld(a + i) + Elem<T>::ld(b + i));
 }
 
+// out[j] = sum over rows of in[row][j] (float32): the N-reduction of the per-plane affine-gradient partials
+// (sums[n][c][2] -> d(beta), d(gamma): refine_net.py's InstanceNorm2d(affine=True) layers).  Fixed order: 64 columns x 4 row
+// phases per workgroup, each phase sums its rows in sequence, the phases are combined in order.
+__global__ __launch_bounds__(256) void sum_rows_kernel(const float* __restrict__ in, float* __restrict__ out, int rows, int cols) {
+    __shared__ float sh[4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), ph = threadIdx.x >> 6;
+    float s = 0.f;
+    if (c < cols) {
+#pragma unroll 8
+        for (int r = ph; r < rows; r += 4) s += in[(size_t)r * cols + c];
+    }
+    sh[ph][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (ph == 0 && c < cols) out[c] = (sh[0][threadIdx.x] + sh[1][threadIdx.x]) + (sh[2][threadIdx.x] + sh[3][threadIdx.x]);
+}
+
 // the activations the two networks use get their own instantiation (no per-element switch), the rest the run-time one
 #define EVE_IN_ACT_DISPATCH(KERNEL, T, TS, GRID, ...)                                                                                   \
     do { switch (act) {                                                                                                                 \
@@ -671,6 +687,13 @@ extern "C" int eve_instnorm_act2_bwd(int dtype, int N, int HW, int C, const void
         EVE_IN_ACT_DISPATCH(in_act2_bwd_kernel, f16_t, "eve::f16_t", grid, (const f16_t*)dy_a, (const f16_t*)dy_b, lddy, (const f16_t*)x, mean_rstd, gamma_a, beta_a, gamma_b, beta_b, act, (f16_t*)dx, sums_a, sums_b, N, HW, C, (const f16_t*)x2, mean_rstd2, (f16_t*)dx2, C2);
     else
         EVE_IN_ACT_DISPATCH(in_act2_bwd_kernel, float, "float", grid, (const float*)dy_a, (const float*)dy_b, lddy, (const float*)x, mean_rstd, gamma_a, beta_a, gamma_b, beta_b, act, (float*)dx, sums_a, sums_b, N, HW, C, (const float*)x2, mean_rstd2, (float*)dx2, C2);
+    EVE_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int eve_sum_rows(int rows, int cols, const float* in, float* out, eve_stream_t stream) {
+    if (rows <= 0 || cols <= 0 || !in || !out) return set_error_msg("sum_rows: bad arguments");
+    hipLaunchKernelGGL(sum_rows_kernel, dim3((unsigned)((cols + 63) / 64)), dim3(256), 0, (hipStream_t)stream, in, out, rows, cols);
     EVE_CHECK_LAUNCH();
     return 0;
 }

@@ -573,6 +573,13 @@ class HipKernels(object):
         self._ck(st)
         return dx, dres, sums
 
+    def sum_rows(self, t):
+        """[N, ...] float32 -> [...]: the sum over the leading dimension in a fixed order (per-plane partials -> parameter gradient)."""
+        assert t.dtype == torch.float32 and t.is_contiguous()
+        out = torch.empty(t.shape[1:], dtype=torch.float32, device=t.device)
+        self._ck(self.lib.eve_sum_rows(t.shape[0], out.numel(), self._p(t), self._p(out), self._stream()))
+        return out
+
     # ------------------------------------------------------------------ element-wise
     def act_bwd(self, dy, y, act):
         dx = torch.empty_like(dy)

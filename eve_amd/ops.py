@@ -603,7 +603,7 @@ class InstNormActFn(torch.autograd.Function):
         dx, dres, sums = out
         dgamma = dbeta = None
         if ctx.has_affine:
-            s = sums.sum(dim=0)                 # [C, 2]: tiny N-reduction of per-plane partials
+            s = k.sum_rows(sums)                # [C, 2]: N-reduction of the per-plane partials, fixed order
             dbeta, dgamma = s[:, 0], s[:, 1]
         return dx, dgamma, dbeta, dres, None, None
 
@@ -636,7 +636,7 @@ class InstNormAct2Fn(torch.autograd.Function):
         ga, ba, gb, bb = ctx.saved_tensors[:4]
         xs, mrs = ctx.saved_tensors[4:4 + ctx.n], ctx.saved_tensors[4 + ctx.n:]
         dxs, sa, sb = k.instnorm_act2_bwd(d_a.contiguous(), d_b.contiguous(), xs, mrs, ga, ba, gb, bb, ctx.act)
-        sa, sb = sa.sum(dim=0), sb.sum(dim=0)           # [C, 2]: tiny N-reduction of per-plane partials
+        sa, sb = k.sum_rows(sa), k.sum_rows(sb)         # [C, 2]: N-reduction of the per-plane partials, fixed order
         return (None, None, sa[:, 1], sa[:, 0], sb[:, 1], sb[:, 0]) + tuple(dxs)
 
 

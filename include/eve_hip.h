@@ -229,6 +229,10 @@ int eve_instnorm_bwd_fused(int dtype, int N, int HW, int C, const void* dy, cons
                            const void* x, const float* mean_rstd, const float* gamma, int act,
                            void* dx, void* dres, float* sums, const unsigned char* sign_mask, eve_stream_t stream);
 
+/* out[j] = sum_r in[r][j] (float32, fixed summation order): the batch reduction of the per-plane partials `sums` above into
+ * d(beta) / d(gamma) of an affine InstanceNorm2d (refine_net.py:46,50,59,215).                                          */
+int eve_sum_rows(int rows, int cols, const float* in, float* out, eve_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Element-wise activation gradient: dx = dy * act'(y)  (for Linear/conv epilogue activations).
  * ------------------------------------------------------------------------------------------------ */

@@ -394,6 +394,16 @@ def test_instnorm_two_heads_over_concatenated_sources(hip, ref, dtype, shape, c2
             off += x.shape[-1]
 
 
+@pytest.mark.parametrize('shape', [(960, 32, 2), (7, 1024, 2), (1, 8, 2), (1920, 130)], ids=lambda s: 'x'.join(map(str, s)))
+def test_sum_rows_is_the_fixed_order_batch_reduction(hip, shape):
+    t = rnd(shape, torch.float32, 61)
+    got = hip.sum_rows(dev(t))
+    want = t.double().sum(dim=0)
+    assert got.shape == want.shape
+    assert float((got.cpu().double() - want).abs().max()) <= 1e-5 * max(1.0, float(want.abs().max()))
+    assert torch.equal(got, hip.sum_rows(dev(t)))          # same order every time
+
+
 def test_channel_split_instnorm_equals_the_single_workgroup_kernel(tmp_path):
     """Planes of 4 097 .. 8 192 vectors run as two 512-thread workgroups, half the channels each (EVE_IN_SPLIT=0: one
     1 024-thread workgroup).  Same arithmetic per channel, only the order of the plane reductions differs: forward with
