@@ -10,18 +10,18 @@ if [ "$1" = "tests" ]; then
   (cd $R && timeout 3000 python -m pytest tests -m gpu -q -x 2>&1 | tail -8 > $O/pytest_gpu.log)
 fi
 # kernel stats (7 steps in the EyeNet trace incl. warm-up / capture; tools/kstats.py divides by the adam_kernel count)
-timeout 600 rocprofv3 --kernel-trace --stats -d $O/prof_bench -o b --output-format csv -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-c3 > $O/bench_profiled.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats -d $O/prof_bench -o b --output-format csv -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-c3 --no-points > $O/bench_profiled.log 2>&1
 cp $(find $O/prof_bench -name "*kernel_stats.csv" | head -1) $O/bench_kernel_stats.csv
 timeout 600 rocprofv3 --kernel-trace --stats -d $O/prof_c3 -o c --output-format csv -- python $R/tools/bench_eve.py --steps 5 > $O/c3_profiled.log 2>&1
 cp $(find $O/prof_c3 -name "*kernel_stats.csv" | head -1) $O/eve_c3_kernel_stats.csv
 rm -rf $O/prof_bench $O/prof_c3
 # HBM traffic counters, one counter per pass
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout 900 rocprofv3 --pmc $c -d $O/pmc_b_$c -o p --output-format csv -- python $R/bench.py --steps 2 --warmup 1 --no-graph --no-cpu-baseline --no-roofline --no-c3 > /dev/null 2>&1
+  timeout 900 rocprofv3 --pmc $c -d $O/pmc_b_$c -o p --output-format csv -- python $R/bench.py --steps 2 --warmup 1 --no-graph --no-cpu-baseline --no-roofline --no-c3 --no-points > /dev/null 2>&1
   timeout 900 rocprofv3 --pmc $c -d $O/pmc_c_$c -o p --output-format csv -- python $R/tools/bench_eve.py --steps 2 > /dev/null 2>&1
 done
 cd $R
-python tools/pmc_hbm_summary.py $O/pmc_b_FETCH_SIZE $O/pmc_b_WRITE_SIZE bench.py --steps 2 --warmup 1 --no-graph --no-cpu-baseline --no-roofline --no-c3 > $O/pmc_hbm_per_kernel.json
+python tools/pmc_hbm_summary.py $O/pmc_b_FETCH_SIZE $O/pmc_b_WRITE_SIZE bench.py --steps 2 --warmup 1 --no-graph --no-cpu-baseline --no-roofline --no-c3 --no-points > $O/pmc_hbm_per_kernel.json
 python tools/pmc_hbm_summary.py $O/pmc_c_FETCH_SIZE $O/pmc_c_WRITE_SIZE tools/bench_eve.py --steps 2 > $O/c3_pmc_hbm_per_kernel.json
 rm -rf $O/pmc_b_* $O/pmc_c_*
 # the bench lines proper (un-profiled); the fresh PMC summaries are put where bench.py looks for them
