@@ -30,7 +30,7 @@
 #define EVE_WS64_NB 2
 #endif
 #ifndef EVE_WS64_ABLATE
-#define EVE_WS64_ABLATE 0    // timing experiments only (wrong results): 1 no halo fetches, 2 no barrier, 4 no stores, 8 no fragment reads, 16 no MFMAs, 32 lane-contiguous store addresses
+#define EVE_WS64_ABLATE 0    // timing experiments only (wrong results): 1 no halo fetches, 2 no barrier, 4 no stores, 8 no fragment reads, 16 no MFMAs
 #endif
 
 namespace eve {
@@ -153,11 +153,17 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws64_kernel(const Ws64Params p
     // goes out of range and is dropped, no branch in the MFMA stream -- and every tile issues exactly 8 of them per wave,
     // which the counted wait at the top of slice 1 relies on
     const eve_int4 rs_o = make_rsrc_words(out, p.x_bytes);
-    auto tile_base = [&](uint32_t tile) -> uint32_t {            // byte offset of (tile, this wave's first row, lane's pixel, co)
-        return (((tile >> 1) * 1024u + (tile & 1u) * 512u + (uint32_t)(2 * wave) * 32u + (uint32_t)l31) * 64u + co) * 2u;
+    // A lane's accumulators are 32 consecutive channels of ONE pixel = four 16-byte chunks k = 0..3 (64 bytes): stored as they
+    // are, an instruction writes 16 bytes into 64 different 128-byte lines (15.7 M write requests per launch; lane-contiguous
+    // fake addresses measured 0.146 -> 0.136 ms).  So the four chunks of an image row are packed first (pk_row[k]), then
+    // transposed 4 x 4 across each lane quad (two DPP butterfly stages): lane q of a quad ends up with chunk q of the quad's
+    // pixels m = 0..3, and store m writes 64 contiguous bytes per quad -- 16 requests per instruction instead of 64.
+    auto tile_base = [&](uint32_t tile) -> uint32_t {            // byte offset of (tile, this wave's first row, the lane quad's first pixel, lane's chunk)
+        return (((tile >> 1) * 1024u + (tile & 1u) * 512u + (uint32_t)(2 * wave) * 32u + (uint32_t)(l31 & ~3)) * 64u + co) * 2u +
+               (uint32_t)(l31 & 3) * 16u;
     };
-    auto store_part = [&](const f32x16_t& a, uint32_t obase, bool live, int ct, int pt, int half) {
-        u32x4_t pk;
+    u32x4_t pk_row[4];
+    auto pack_part = [&](const f32x16_t& a, int ct, int half) {   // chunk k = ct * 2 + half of the lane's pixel
         float bv[8];
 #pragma unroll
         for (int c = 0; c < 8; c += 4) {
@@ -168,14 +174,36 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws64_kernel(const Ws64Params p
         for (int r = 0; r < 8; r += 2) {
             float o0 = a[half * 8 + r] + bv[r], o1 = a[half * 8 + r + 1] + bv[r + 1];
             o0 = fmaxf(o0, floor_v); o1 = fmaxf(o1, floor_v);
-            pk[r / 2] = Elem<H>::pack2(o0, o1);
+            pk_row[ct * 2 + half][r / 2] = Elem<H>::pack2(o0, o1);
         }
-        const uint32_t voff = live ? obase + (uint32_t)(pt * 32 * 128 + (ct * 16 + half * 8) * 2) : (uint32_t)EVE_OOB;
-        if (EVE_WS64_ABLATE & 32) {    // same bytes, lane-contiguous (wrong) addresses: what would coalesced stores buy?
-            const uint32_t fake = (obase & ~0xffffu) + (uint32_t)wave * 8192u + (uint32_t)((pt * 4 + ct * 2 + half) * 1024) + (uint32_t)lane * 16u;
-            asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen" :: "v"(pk), "v"(live ? fake : (uint32_t)EVE_OOB), "s"(rs_o) : "memory");
-        } else
-        asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen" :: "v"(pk), "v"(voff), "s"(rs_o) : "memory");
+    };
+    const bool q_hi = (l31 & 2) != 0, q_lo = (l31 & 1) != 0;
+    auto store_row = [&](uint32_t obase, bool live, int pt) {
+        // stage 1: 2 x 2 blocks of the 4 x 4 (register k, lane q) matrix swap across lanes q ^ 2; stage 2: inside the blocks, q ^ 1
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                const uint32_t a = pk_row[k][d], b = pk_row[k + 2][d];
+                const uint32_t recv = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(q_hi ? a : b), 0x4e, 0xf, 0xf, false);   // quad_perm [2,3,0,1]
+                pk_row[k][d] = q_hi ? recv : a;
+                pk_row[k + 2][d] = q_hi ? b : recv;
+            }
+#pragma unroll
+        for (int k = 0; k < 4; k += 2)
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                const uint32_t a = pk_row[k][d], b = pk_row[k + 1][d];
+                const uint32_t recv = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(q_lo ? a : b), 0xb1, 0xf, 0xf, false);   // quad_perm [1,0,3,2]
+                pk_row[k][d] = q_lo ? recv : a;
+                pk_row[k + 1][d] = q_lo ? b : recv;
+            }
+        // pk_row[m] = chunk (l31 & 3) of the quad's pixel m
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const uint32_t voff = live ? obase + (uint32_t)(pt * 32 * 128 + m * 128) : (uint32_t)EVE_OOB;
+            asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen" :: "v"(pk_row[m]), "v"(voff), "s"(rs_o) : "memory");
+        }
     };
     auto run_tile = [&](auto parity, uint32_t tile, uint32_t prev_base, bool prev_live) {
         constexpr int PAR = decltype(parity)::value;
@@ -216,7 +244,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws64_kernel(const Ws64Params p
                     // (the empty statement redefines the tile here: without it the compiler copies all 64 accumulators
                     //  into VGPRs at the top of the tile and carries them through the steps)
                     if ((h & 1) == 0) asm volatile("" : "+a"(acc[PAR ^ 1][((h - 2) >> 1) & 1][(h - 2) >> 2]));
-                    store_part(acc[PAR ^ 1][((h - 2) >> 1) & 1][(h - 2) >> 2], prev_base, prev_live, ((h - 2) >> 1) & 1, (h - 2) >> 2, h & 1);
+                    pack_part(acc[PAR ^ 1][((h - 2) >> 1) & 1][(h - 2) >> 2], ((h - 2) >> 1) & 1, h & 1);
+                    if (((h - 2) & 3) == 3) store_row(prev_base, prev_live, (h - 2) >> 2);     // an image row is complete: 4 stores
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
@@ -226,7 +255,11 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws64_kernel(const Ws64Params p
         asm volatile("s_nop 15\n\ts_nop 15" : "+a"(a[0][0]), "+a"(a[0][1]), "+a"(a[1][0]), "+a"(a[1][1]) :: "memory");
         const uint32_t ob = tile_base(tile);
 #pragma unroll
-        for (int q = 0; q < 8; ++q) store_part(a[(q >> 1) & 1][q >> 2], ob, true, (q >> 1) & 1, q >> 2, q & 1);
+        for (int pt = 0; pt < 2; ++pt) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) pack_part(a[k >> 1][pt], k >> 1, k & 1);
+            store_row(ob, true, pt);
+        }
     };
 
     // The stream in pairs: (even position -> set 0, storing set 1), (odd position -> set 1, storing set 0); one back edge,
