@@ -210,6 +210,33 @@ __device__ __forceinline__ uint32_t xcd_remap(uint32_t bid, uint32_t nblk) {
 namespace eve {
 int set_error(hipError_t e, const char* where);
 int set_error_msg(const char* msg);
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
+// 4 x 4 transpose of 16-byte elements across a lane quad (two DPP butterfly stages, per dword: select, quad_perm move, two
+// selects): in: r[k] of lane q = element (k, q); out: r[m] of lane q = element (q, m).  Epilogues whose lanes hold four
+// 16-byte chunks of ONE pixel use it so that a store instruction writes 64 contiguous bytes per quad (chunk q of the quad's
+// pixel m) instead of 16 bytes into 64 different lines.
+__device__ __forceinline__ void quad_transpose4x4(u32x4_t (&r)[4], const int lane) {
+    const bool q_hi = (lane & 2) != 0, q_lo = (lane & 1) != 0;
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            const uint32_t a = r[k][d], b = r[k + 2][d];
+            const uint32_t got = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(q_hi ? a : b), 0x4e, 0xf, 0xf, false);   // quad_perm [2,3,0,1]
+            r[k][d] = q_hi ? got : a;
+            r[k + 2][d] = q_hi ? b : got;
+        }
+#pragma unroll
+    for (int k = 0; k < 4; k += 2)
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            const uint32_t a = r[k][d], b = r[k + 1][d];
+            const uint32_t got = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(q_lo ? a : b), 0xb1, 0xf, 0xf, false);   // quad_perm [1,0,3,2]
+            r[k][d] = q_lo ? got : a;
+            r[k + 1][d] = q_lo ? b : got;
+        }
+}
+
 // symbol of the kernel the calling thread launched last (benchmark attribution, see eve_last_kernel)
 extern thread_local const char* g_last_kernel;
 // device scratch registered by the caller (eve_set_workspace); nullptr / 0 when none

@@ -287,20 +287,22 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wg8_kernel(const Wg8Params p, 
         const int m = wm * 128 + pt * 32 + l31;
         const int ti = m / (W * W), pix = m - ti * (W * W);
         const uint32_t n = n0 + ti;
-        uint32_t pk[16];
+        u32x4_t pk[4];                                          // the lane's pixel: chunks k = 0..3 of 8 channels
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
             for (int r = 0; r < 16; r += 2) {
                 float o0 = acc[ct][pt][r] + bv[ct * 16 + r], o1 = acc[ct][pt][r + 1] + bv[ct * 16 + r + 1];
                 if (relu) { o0 = fmaxf(o0, 0.f); o1 = fmaxf(o1, 0.f); }
-                pk[ct * 8 + r / 2] = Elem<H>::pack2(o0, o1);
+                pk[ct * 2 + (r >> 3)][(r >> 1) & 3] = Elem<H>::pack2(o0, o1);
             }
+        // across each lane quad (four consecutive pixels of one image): lane q takes chunk q of pixel m in pk[m], so a store
+        // writes 64 contiguous bytes per quad instead of 16 bytes into 64 lines (conv_ws64.h measured the difference)
+        quad_transpose4x4(pk, lane);
         if (n < (uint32_t)p.N) {
-            H* dst = out + ((size_t)n * (W * W) + pix) * p.Cout + co;
+            H* dst = out + ((size_t)n * (W * W) + (pix & ~3)) * p.Cout + co + (l31 & 3) * 8;
 #pragma unroll
-            for (int v = 0; v < 4; ++v)
-                *reinterpret_cast<uint4*>(dst + 8 * v) = make_uint4(pk[4 * v], pk[4 * v + 1], pk[4 * v + 2], pk[4 * v + 3]);
+            for (int v = 0; v < 4; ++v) *reinterpret_cast<u32x4_t*>(dst + (size_t)v * p.Cout) = pk[v];
         }
     }
 }

@@ -177,32 +177,16 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws64_kernel(const Ws64Params p
             pk_row[ct * 2 + half][r / 2] = Elem<H>::pack2(o0, o1);
         }
     };
-    const bool q_hi = (l31 & 2) != 0, q_lo = (l31 & 1) != 0;
     auto store_row = [&](uint32_t obase, bool live, int pt) {
-        // stage 1: 2 x 2 blocks of the 4 x 4 (register k, lane q) matrix swap across lanes q ^ 2; stage 2: inside the blocks, q ^ 1
-#pragma unroll
-        for (int k = 0; k < 2; ++k)
-#pragma unroll
-            for (int d = 0; d < 4; ++d) {
-                const uint32_t a = pk_row[k][d], b = pk_row[k + 2][d];
-                const uint32_t recv = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(q_hi ? a : b), 0x4e, 0xf, 0xf, false);   // quad_perm [2,3,0,1]
-                pk_row[k][d] = q_hi ? recv : a;
-                pk_row[k + 2][d] = q_hi ? b : recv;
-            }
-#pragma unroll
-        for (int k = 0; k < 4; k += 2)
-#pragma unroll
-            for (int d = 0; d < 4; ++d) {
-                const uint32_t a = pk_row[k][d], b = pk_row[k + 1][d];
-                const uint32_t recv = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(q_lo ? a : b), 0xb1, 0xf, 0xf, false);   // quad_perm [1,0,3,2]
-                pk_row[k][d] = q_lo ? recv : a;
-                pk_row[k + 1][d] = q_lo ? b : recv;
-            }
+        quad_transpose4x4(pk_row, lane);
         // pk_row[m] = chunk (l31 & 3) of the quad's pixel m
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
             const uint32_t voff = live ? obase + (uint32_t)(pt * 32 * 128 + m * 128) : (uint32_t)EVE_OOB;
-            asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen" :: "v"(pk_row[m]), "v"(voff), "s"(rs_o) : "memory");
+            // (s_nop 1: a store of more than 8 bytes reads its data registers after issue -- the ISA wants wait states before
+            //  a VALU write of them, and the compiler, which does not know this statement is a store, put `v_or v6, ...`
+            //  right behind `buffer_store_dwordx4 v[6:9]`: dword 0 of a few lanes went out with the new value)
+            asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen\n\ts_nop 1" :: "v"(pk_row[m]), "v"(voff), "s"(rs_o) : "memory");
         }
     };
     auto run_tile = [&](auto parity, uint32_t tile, uint32_t prev_base, bool prev_live) {
@@ -250,6 +234,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws64_kernel(const Ws64Params p
                 }
             }
         }
+        // The MFMAs are inline assembly: the compiler does not know their write latency, and whatever it does with this set
+        // after the tile (at the stream's end it COPIES sets between registers for the shared tail code) must find the
+        // results landed.
+        asm volatile("s_nop 15\n\ts_nop 15" : "+a"(acc[PAR][0][0]), "+a"(acc[PAR][0][1]), "+a"(acc[PAR][1][0]), "+a"(acc[PAR][1][1]) :: "memory");
     };
     auto store_tile = [&](f32x16_t (&a)[2][2], uint32_t tile) {   // the stream's last tile: nothing left to hide it under
         asm volatile("s_nop 15\n\ts_nop 15" : "+a"(a[0][0]), "+a"(a[0][1]), "+a"(a[1][0]), "+a"(a[1][1]) :: "memory");
