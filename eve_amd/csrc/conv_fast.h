@@ -377,6 +377,13 @@ __device__ __forceinline__ uint2 lds_tr_read(uint32_t lds_byte_addr) {
     return __builtin_bit_cast(uint2, r);
 }
 
+// (run-time displacement that is a constant after unrolling: same pointer arithmetic, folds the same way)
+__device__ __forceinline__ uint2 lds_tr_read_at(uint32_t lds_byte_addr, int disp) {
+    EVE_LDS char* base = (EVE_LDS char*)(size_t)lds_byte_addr;
+    bf16x4v_t r = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((EVE_LDS bf16x4v_t*)(base + disp));
+    return __builtin_bit_cast(uint2, r);
+}
+
 // MODE: 0 = any output size (mul-hi divisions per slot), 1 = OH and OW powers of two, 2 = OW a power of two only
 // BIAS: the waves of the first K tile also accumulate db[co] += sum over pixels of dy -- one more MFMA per channel
 // tile against an all-ones operand, on fragments that are in registers anyway (the separate column-sum pass re-read

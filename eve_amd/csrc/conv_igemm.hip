@@ -830,11 +830,17 @@ static bool launch_wgrad_halo(const GatherParams& p, const void* x, const void* 
     if (split) {
         static bool attr_done = false;
         if (!attr_done) {
-            (void)hipFuncSetAttribute((const void*)wgrad_halo64_kernel<HT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void*)wgrad_halo64_kernel<HT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void*)wgrad_halo64_kernel<HT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             attr_done = true;
         }
         const unsigned g64 = h.total_bands < 256u ? h.total_bands : 256u;
-        EVE_LAUNCH(EVE_HNAME(HT, "wgrad_halo64_kernel<", ">"), wgrad_halo64_kernel<HT>, dim3(g64), dim3(512), lds, s, h, (const HT*)x, (const HT*)dy, dw, db);
+        static int fixed64 = -1;
+        if (fixed64 < 0) { const char* e = getenv("EVE_WG64_FIXED"); fixed64 = (e && e[0] == '0') ? 0 : 1; }
+        if (fixed64 && W == 32 && TH == 8 && H % 8 == 0)     // ResNet layer 1: unrolled band loop, immediate fragment addresses
+            EVE_LAUNCH(EVE_HNAME(HT, "wgrad_halo64_kernel<", ", fixed>"), (wgrad_halo64_kernel<HT, true>), dim3(g64), dim3(512), lds, s, h, (const HT*)x, (const HT*)dy, dw, db);
+        else
+            EVE_LAUNCH(EVE_HNAME(HT, "wgrad_halo64_kernel<", ">"), (wgrad_halo64_kernel<HT, false>), dim3(g64), dim3(512), lds, s, h, (const HT*)x, (const HT*)dy, dw, db);
     } else if (ks == 3) {
         if (MT == 1 && CT == 1) EVE_WGRAD_HALO_LAUNCH(1, 1, 3);
         else if (MT == 1 && CT == 2) EVE_WGRAD_HALO_LAUNCH(1, 2, 3);

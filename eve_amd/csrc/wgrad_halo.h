@@ -214,13 +214,16 @@ __global__ __launch_bounds__(256) void wgrad_halo_kernel(const WgradHaloParams p
 // gradient with coalesced atomics, starting at a different offset per workgroup.
 __device__ __forceinline__ int wgrad64_swz(int col) { return ((col >> 1) & 1) | (((col >> 3) & 1) << 1); }
 
-template <typename H>
+template <typename H, bool FIXED>
 __global__ __launch_bounds__(512) void wgrad_halo64_kernel(const WgradHaloParams p, const H* __restrict__ x,
                                                            const H* __restrict__ dy, float* __restrict__ dw,
                                                            float* __restrict__ db) {
     constexpr int ROW = 128;                                 // bytes per pixel, both operands
     extern __shared__ __attribute__((aligned(16))) char lds[];
-    const int W = p.W, W2 = W + 2, TH = p.TH;
+    // FIXED = 32-pixel rows in bands of 8 (ResNet layer 1, 4 of the step's launches): the band loop below is unrolled with
+    // every fragment address a lane constant + an immediate (the run-time version spends 2.3 SALU + 1.6 VALU per MFMA on
+    // chunk / row arithmetic: 39 % matrix-pipe occupancy, profiles/r03_wgrad_wg8.md)
+    const int W = FIXED ? 32 : p.W, W2 = W + 2, TH = FIXED ? 8 : p.TH;
     const int xs_bytes = (TH + 2) * W2 * ROW, region = xs_bytes + TH * W * ROW;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -316,6 +319,45 @@ __global__ __launch_bounds__(512) void wgrad_halo64_kernel(const WgradHaloParams
         __syncthreads();                                      // ... everyone's has, and band k-1 has been consumed
         if (band + (nreg - 1) * stride < p.total_bands) issue_k(band + (nreg - 1) * stride, k + nreg - 1);
         const uint32_t xs = region_of(k), ds = xs + (uint32_t)xs_bytes;
+        if constexpr (FIXED) {
+            // chunk i of this wave = image row half + 2 i of the band (one 32-pixel chunk per row)
+            const uint32_t dbase = ds + (uint32_t)(half * (32 * ROW)), xbase = xs + (uint32_t)(half * (34 * ROW));
+            uint32_t ad[4][2], ax[3][2];
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) ad[mt][r] = dbase + (uint32_t)off_d[mt][r];
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) ax[kw][r] = xbase + (uint32_t)off_x[kw][r];
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                uint4 fp[4];
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) {
+                    const uint2 a0 = lds_tr_read_at(ad[mt][0], i * 2 * 32 * ROW);
+                    const uint2 a1 = lds_tr_read_at(ad[mt][1], i * 2 * 32 * ROW);
+                    fp[mt] = make_uint4(a0.x, a0.y, a1.x, a1.y);
+                }
+#pragma unroll
+                for (int kh = 0; kh < 3; ++kh) {
+                    uint4 fq[3];
+#pragma unroll
+                    for (int kw = 0; kw < 3; ++kw) {
+                        const uint2 b0 = lds_tr_read_at(ax[kw][0], (2 * i + kh) * 34 * ROW);
+                        const uint2 b1 = lds_tr_read_at(ax[kw][1], (2 * i + kh) * 34 * ROW);
+                        fq[kw] = make_uint4(b0.x, b0.y, b1.x, b1.y);
+                    }
+#pragma unroll
+                    for (int mt = 0; mt < 4; ++mt)
+                        mma3_inplace<H>(acc[mt][kh * 3], acc[mt][kh * 3 + 1], acc[mt][kh * 3 + 2], fp[mt], fq);
+                }
+                if (bias_wave) {
+#pragma unroll
+                    for (int mt = 0; mt < 4; ++mt) mma1_inplace<H>(accb[mt], fp[mt], ones);
+                }
+            }
+        } else
         for (int c = half; c < nchunks; c += 2) {
             const int ty = c >> p.log2_cpr, x0 = (c - (ty << p.log2_cpr)) * 32;
             uint4 fp[4];
