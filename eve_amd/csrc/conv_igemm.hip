@@ -604,9 +604,9 @@ static bool launch_halo(const GatherParams& p, const void* src, const void* w, c
         } while (0)
         if (xb8 < (1ull << 31) && wb8 < (1ull << 31)) {
             // 16 x 16 images x 128 channels (512-pixel tiles, 36 steps each): a one-tile workgroup per CU spends ~15 % of its
-            // time in the un-overlapped prologue / epilogue and measures 0.150-0.159 ms against 0.145 for the four-wave kernel
-            // with two workgroups per CU (profiles/r03_conv_wg8.md); EVE_CONV_WG8=2 selects it there as well
-            if (wg8 == 2 && W == 16 && p.Cout % 128 == 0 && p.Cout % 256 != 0) EVE_WG8_LAUNCH(4, 2, 16);
+            // time in the un-overlapped prologue / epilogue; since the epilogue stores 64 contiguous bytes per lane quad it is
+            // ahead of the four-wave kernel there too (0.141 against 0.151-0.166 ms; EVE_CONV_WG8=3 keeps the four-wave kernel)
+            if (wg8 != 3 && W == 16 && p.Cout % 128 == 0 && p.Cout % 256 != 0) EVE_WG8_LAUNCH(4, 2, 16);
             if (W == 8 && p.Cout % 256 == 0) EVE_WG8_LAUNCH(2, 4, 8);
             if (W == 4 && p.Cout % 256 == 0) EVE_WG8_LAUNCH(2, 4, 4);
         }

@@ -787,7 +787,7 @@ def test_heatmap_head_and_losses_match_aten():
 
 def test_eight_wave_convolution_matches_the_four_wave_kernel(tmp_path):
     """conv3x3_wg8_kernel (conv_wg8.h: eight-wave workgroups, 32x32x16 MFMA, phase-staggered wave pairs) is the default for
-    8 x 8 x 256 / 4 x 4 x 512 layers and opt-in (EVE_CONV_WG8=2) for 16 x 16 x 128; EVE_CONV_WG8=0 sends everything to
+    16 x 16 x 128, 8 x 8 x 256 and 4 x 4 x 512 layers whose tiles fill the chip; EVE_CONV_WG8=0 sends everything to
     conv3x3_halo_kernel.  Forward (bias + ReLU epilogue) and data gradient, ragged image counts (the last tile holds fewer
     images than TI), several channel tiles, both 16-bit formats: the two kernels sum the same products in float32 in a
     different order, so they agree to the format's rounding.  (The switch is read once per process.)"""
