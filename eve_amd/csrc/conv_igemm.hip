@@ -586,7 +586,7 @@ static bool launch_halo(const GatherParams& p, const void* src, const void* w, c
         ((epi_act & 0xff) == EVE_ACT_NONE || (epi_act & 0xff) == EVE_ACT_RELU)) {
         const unsigned long long xb8 = (unsigned long long)p.N * H * W * p.Cin * 2, wb8 = (unsigned long long)p.Cout * p.K * 2;
         Wg8Params g;
-        g.N = p.N; g.Cin = p.Cin; g.Cout = p.Cout; g.flip = bwd ? 1 : 0; g.K = p.K; g.x_bytes = (uint32_t)xb8; g.w_bytes = (uint32_t)wb8;
+        g.N = p.N; g.Cin = p.Cin; g.Cout = p.Cout; g.flip = bwd ? 1 : 0; g.K = p.K; g.x_bytes = (uint32_t)xb8; g.w_bytes = (uint32_t)wb8; g.s2_py = 0;
 #define EVE_WG8_LAUNCH(WM_, WN_, W_)                                                                                      \
         do {                                                                                                             \
             using G8 = Wg8Geom<WM_, WN_, W_>;                                                                              \
@@ -905,7 +905,8 @@ static int launch_wgrad(const GatherParams& p, const void* x, const void* dy, co
                     attr_done = true;
                 }
                 const unsigned long long n = (unsigned long long)p.Cout * p.K;
-                const bool slab = splits > 1 && g_workspace && (unsigned long long)splits * n * 4 <= g_workspace_bytes && ((uintptr_t)dw & 15) == 0;
+                // (the workspace's first half: the second holds the strided data gradient's re-packed filters, possibly on another stream)
+                const bool slab = splits > 1 && g_workspace && (unsigned long long)splits * n * 4 <= g_workspace_bytes / 2 && ((uintptr_t)dw & 15) == 0;
                 if (slab) {
                     EVE_LAUNCH(EVE_HNAME(T, "wgrad_wg8_kernel<", ", true>"), (wgrad_wg8_kernel<T, true>), dim3(tk * tc * splits), dim3(512), (size_t)128 * 1024, s, p,
                                (const T*)x, (const T*)dy, (float*)g_workspace, rows, (uint32_t)x_bytes, (uint32_t)dy_bytes);
@@ -993,6 +994,75 @@ extern "C" int eve_conv2d_fwd(const eve_conv_desc* d, const void* x, const void*
     return 0;
 }
 
+namespace eve {
+
+// Filters of the stride-2 data gradient as conv3x3_wg8_kernel<.., NT> wants them (see there): for output row parity py,
+// W'[px * Cdx + ci][t][co] = w_ihwo[ci][kh][kw][co] with kh = py + 1 - 2 dy, kw = px + 1 - 2 dx for the window position
+// t = (dy, dx) (py = 0: dy = 0 only, NT = 2; py = 1: NT = 4), zero where the tap does not exist (px = 0, dx = 1).
+template <typename H>
+__global__ __launch_bounds__(256) void s2_dgrad_pack_kernel(const H* __restrict__ w_ihwo, H* __restrict__ w0, H* __restrict__ w1,
+                                                            int Cdx, int Cout) {
+    const int kv = Cout / 8;                                  // 16-byte vectors per (row, tap)
+    const long long n0 = (long long)2 * Cdx * 2 * kv, n1 = (long long)2 * Cdx * 4 * kv;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n0 + n1; i += (long long)gridDim.x * 256) {
+        const int py = i >= n0 ? 1 : 0, nt = py ? 4 : 2;
+        const long long r = py ? i - n0 : i;
+        const int v = (int)(r % kv), t = (int)((r / kv) % nt), row = (int)(r / ((long long)kv * nt));
+        const int px = row >= Cdx ? 1 : 0, ci = row - px * Cdx;
+        const int dy = py ? t >> 1 : 0, dx = t & 1;
+        const int kh = py + 1 - 2 * dy, kw = px + 1 - 2 * dx;          // py = 0: 1;  py = 1: 2, 0;  same for kw
+        uint4 q = make_uint4(0u, 0u, 0u, 0u);
+        if (kh >= 0 && kw >= 0)
+            q = reinterpret_cast<const uint4*>(w_ihwo + (((size_t)ci * 3 + kh) * 3 + kw) * Cout)[v];
+        reinterpret_cast<uint4*>(py ? w1 : w0)[r] = q;
+    }
+}
+
+// true: launched.  dy [N][OW][OW][Cout] -> dx [N][2 OW][2 OW][Cdx]
+template <typename HT>
+static bool launch_s2_dgrad_wg8(const eve_conv_desc* d, const void* dy, const void* w_ihwo, void* dx, hipStream_t s) {
+    static int on = -1, min_tiles = -1;
+    if (on < 0) { const char* e = getenv("EVE_CONV_WG8"); on = e ? atoi(e) : 1; const char* f = getenv("EVE_CONV_WG8_MIN_TILES"); min_tiles = f ? atoi(f) : 224; }
+    const int W = d->OW, Cdx = d->Cin, Co = d->Cout;
+    if (!on || d->KH != 3 || d->KW != 3 || d->stride != 2 || d->pad != 1 || d->OH != W || d->IH != 2 * W || d->IW != 2 * W ||
+        !(W == 16 || W == 8 || W == 4) || Co % 64 || !g_workspace)
+        return false;
+    const int cout_t = W == 16 ? 128 : 256;
+    if ((2 * Cdx) % cout_t) return false;
+    const unsigned long long wbytes = (unsigned long long)2 * Cdx * 6 * Co * 2, half = (g_workspace_bytes / 2) & ~255ull;
+    const unsigned long long xb = (unsigned long long)d->N * W * W * Co * 2, ob = (unsigned long long)d->N * 4 * W * W * Cdx * 2;
+    if (wbytes > g_workspace_bytes - half || xb >= (1ull << 31) || ob >= (1ull << 31) || wbytes >= (1ull << 31)) return false;
+    const int ti = W == 16 ? 2 : (W == 8 ? 4 : 16);
+    const uint32_t tiles = (uint32_t)((d->N + ti - 1) / ti) * (uint32_t)(2 * Cdx / cout_t);
+    if ((int)tiles < min_tiles) return false;
+    HT* w0 = (HT*)((char*)g_workspace + half);
+    HT* w1 = w0 + (size_t)2 * Cdx * 2 * Co;
+    const long long nvec = (long long)2 * Cdx * 6 * (Co / 8);
+    hipLaunchKernelGGL(s2_dgrad_pack_kernel<HT>, dim3((unsigned)((nvec + 255) / 256 > 1024 ? 1024 : (nvec + 255) / 256)), dim3(256), 0, s,
+                       (const HT*)w_ihwo, w0, w1, Cdx, Co);
+    Wg8Params g;
+    g.N = d->N; g.Cin = Co; g.Cout = 2 * Cdx; g.flip = 0; g.x_bytes = (uint32_t)xb; g.tiles_n = (uint32_t)(2 * Cdx / cout_t);
+#define EVE_S2_LAUNCH(WM_, WN_, W_, NT_, WPTR, PY)                                                                          \
+    do {                                                                                                                  \
+        using G8 = Wg8Geom<WM_, WN_, W_>;                                                                                   \
+        static bool attr_done = false;                                                                                    \
+        if (!attr_done) {                                                                                                 \
+            (void)hipFuncSetAttribute((const void*)conv3x3_wg8_kernel<HT, WM_, WN_, W_, NT_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+            attr_done = true;                                                                                             \
+        }                                                                                                                 \
+        g.K = NT_ * Co; g.w_bytes = (uint32_t)((unsigned long long)2 * Cdx * NT_ * Co * 2); g.s2_py = PY;                   \
+        EVE_LAUNCH(EVE_HNAME(HT, "conv3x3_wg8_kernel<", ", " #WM_ ", " #WN_ ", " #W_ ", s2dgrad" #NT_ ">"), (conv3x3_wg8_kernel<HT, WM_, WN_, W_, NT_>), \
+                   dim3(tiles), dim3(512), G8::LDS, s, g, (const HT*)dy, (const HT*)(WPTR), (const float*)nullptr, (int)EVE_ACT_NONE, (HT*)dx); \
+    } while (0)
+    if (W == 16) { EVE_S2_LAUNCH(4, 2, 16, 2, w0, 0); EVE_S2_LAUNCH(4, 2, 16, 4, w1, 1); }
+    else if (W == 8) { EVE_S2_LAUNCH(2, 4, 8, 2, w0, 0); EVE_S2_LAUNCH(2, 4, 8, 4, w1, 1); }
+    else { EVE_S2_LAUNCH(2, 4, 4, 2, w0, 0); EVE_S2_LAUNCH(2, 4, 4, 4, w1, 1); }
+#undef EVE_S2_LAUNCH
+    return true;
+}
+
+}  // namespace eve
+
 extern "C" int eve_conv2d_dgrad(const eve_conv_desc* d, const void* dy, const void* w_ihwo, void* dx,
                                 eve_stream_t stream) {
     const int vec = (d && d->dtype != EVE_DT_F32) ? 8 : 4;
@@ -1001,6 +1071,9 @@ extern "C" int eve_conv2d_dgrad(const eve_conv_desc* d, const void* dy, const vo
     if (!dy || !w_ihwo || !dx) return set_error_msg("conv2d_dgrad: null pointer");
     GatherParams p = dgrad_params(d);
     hipStream_t s = (hipStream_t)stream;
+    // stride-2 3x3 layers: two eight-wave launches over the dy halo tile instead of four per-tap parity-class launches
+    if (d->dtype == EVE_DT_BF16 && launch_s2_dgrad_wg8<bf16_t>(d, dy, w_ihwo, dx, s)) { EVE_CHECK_LAUNCH(); return 0; }
+    if (d->dtype == EVE_DT_F16 && launch_s2_dgrad_wg8<f16_t>(d, dy, w_ihwo, dx, s)) { EVE_CHECK_LAUNCH(); return 0; }
     if (d->dtype == EVE_DT_BF16) launch_igemm<bf16_t>(p, dy, w_ihwo, nullptr, nullptr, 0, 0, dx, s);
     else if (d->dtype == EVE_DT_F16) launch_igemm<f16_t>(p, dy, w_ihwo, nullptr, nullptr, 0, 0, dx, s);
     else                         launch_igemm<float>(p, dy, w_ihwo, nullptr, nullptr, 0, 0, dx, s);

@@ -54,6 +54,7 @@ struct Wg8Params {
     int K;                        // 9 * Cin (row stride of the weight matrix [Cout][3][3][Cin])
     uint32_t x_bytes, w_bytes;
     uint32_t tiles_n;             // channel tiles; blockIdx -> (image tile, channel tile)
+    int s2_py;                    // NT != 9 (data gradient of a stride-2 convolution): output row parity of this launch
 };
 
 template <int W>
@@ -92,11 +93,17 @@ __device__ __forceinline__ void wg8_mma16(f32x16_t (&acc)[2][4], const u32x4_t (
 #undef EVE_WG8_MMA_BODY
 
 template <int N> __device__ __forceinline__ void wg8_wait_vm() {
-    static_assert(N >= 0 && N <= 3, "pieces per phase");
+    static_assert(N >= 0 && N <= 9, "pieces per phase");
     if (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     else if (N == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
     else if (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    else if (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    else if (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if (N == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+    else if (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else if (N == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+    else if (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
 }
 
 template <int WM, int WN, int W> struct Wg8Geom {
@@ -112,7 +119,13 @@ template <int WM, int WN, int W> struct Wg8Geom {
     static_assert(WM * WN == 8 && PIX % (W * W) == 0 && AP <= 7 && BP >= 1 && LDS <= 160 * 1024, "tile geometry");
 };
 
-template <typename H, int WM, int WN, int W>
+// NT = 9: the 3x3 convolution.  NT = 2 / 4: the DATA GRADIENT OF A STRIDE-2 3x3 CONVOLUTION (torchvision BasicBlock's first
+// convolution of layers 2-4, eye_net.py:48-50) as a stride-1 convolution over dy: d(x)[2 yy + py][2 xx + px] only takes the
+// filter taps kh = py + 1 - 2 dy, kw = px + 1 - 2 dx with dy, dx in {0, 1}, i.e. dy[yy + dy][xx + dx] -- a 1 x 2 (py = 0) or
+// 2 x 2 (py = 1) window over the SAME halo tile, whose 2 x Cin "output channels" are the column parities px = 0 | 1 of d(x)
+// (px = 0 uses half of those taps: its other weights are zero, 12 of 16 tap-classes do real work).  The launch pair reads dy
+// twice in total (the per-tap kernel: four launches, nine tap passes) and the epilogue scatters depth-to-space.
+template <typename H, int WM, int WN, int W, int NT = 9>
 __global__ __launch_bounds__(512, 2) void conv3x3_wg8_kernel(const Wg8Params p, const H* __restrict__ x,
                                                              const H* __restrict__ w, const float* __restrict__ bias,
                                                              const int epi_act, H* __restrict__ out) {
@@ -192,7 +205,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wg8_kernel(const Wg8Params p, 
     const int nslices = p.Cin / 32;                             // even (the launcher requires Cin % 64 == 0)
     const int cin2 = p.Cin * 2;
     // weight tile of filter position (dy, dx): forward tap dy*3+dx, data gradient tap 8 - (dy*3+dx)
-    const int tap_base = p.flip ? 8 * cin2 : 0, tap_step = p.flip ? -cin2 : cin2;
+    const int tap_base = (NT == 9 && p.flip) ? 8 * cin2 : 0, tap_step = (NT == 9 && p.flip) ? -cin2 : cin2;
     auto issue_b = [&](int s, int t, int slot) {                // this wave's BP pieces of the tile of (slice s, position t)
         const int soff = tap_base + t * tap_step + s * 64;
 #pragma unroll
@@ -228,14 +241,19 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wg8_kernel(const Wg8Params p, 
             const int s = s2 + ss;
             const bool last = s + 1 == nslices;
 #pragma unroll
-            for (int t = 0; t < 9; ++t) {
-                const int dy = t / 3, dx = t % 3;
-                const int t2 = (t + 2) % 9, sd = (t + 2) / 9;
+            for (int t = 0; t < NT; ++t) {
+                const int dy = NT == 9 ? t / 3 : (NT == 4 ? 1 + t / 2 : 1), dx = NT == 9 ? t % 3 : 1 + (t & 1);
+                const int t2 = (t + 2) % NT, sd = (t + 2) / NT;
                 const bool more_b = !(last && sd);                                       // a step g + 2 exists
-                const bool piece = t >= 1 && t <= AP;
+                // halo pieces of the next slice issued in this step: one per step from the second tap on (3x3), or all AP of
+                // them dealt over the first NT - 1 steps (short windows; a piece is waited for at the END of the step after
+                // its own, so none may be issued in a slice's last step)
+                constexpr int PPS = NT == 9 ? 1 : (AP + NT - 2) / (NT - 1);
+                const int j0 = NT == 9 ? t - 1 : t * PPS;
+                const int np = NT == 9 ? ((t >= 1 && t <= AP) ? 1 : 0) : (j0 >= AP ? 0 : (j0 + PPS <= AP ? PPS : AP - j0));
                 if (!lead) wg8_mma16<H>(acc, wf, xf);                                    // step g - 1 (zeros before step 0)
-                // ---- fragments of step g = 9 s + t ----
-                const uint32_t slot_off = (uint32_t)((s + t) & 3) * BSLOT;             // (9 s + t) & 3
+                // ---- fragments of step g = NT s + t ----
+                const uint32_t slot_off = (uint32_t)((NT * s + t) & 3) * BSLOT;
 #pragma unroll
                 for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
@@ -249,13 +267,25 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wg8_kernel(const Wg8Params p, 
                     for (int kh = 0; kh < 2; ++kh)
                         xf[pt][kh] = *reinterpret_cast<const EVE_LDS u32x4_t*>((uintptr_t)(xrd[pt][q][kh] + imm));
                 // ---- DMAs of this step (issued while the fragment reads are in flight): weight tile of step g + 2, halo
-                //      piece t - 1 of the next slice ----
-                if (more_b) issue_b(s + sd, t2, (s + t + 2) & 3);
-                if (piece && !last) wg8_dma(rs_x, ldsA + (ss ^ 1) * ASTAGE + ((t - 1) * 8 + wave) * 1024, a_goff[piece ? t - 1 : 0], (s + 1) * 64);
+                //      pieces of the next slice ----
+                if (more_b) issue_b(s + sd, t2, (NT * s + t + 2) & 3);
+                if (!last) {
+#pragma unroll
+                    for (int jj = 0; jj < PPS; ++jj)
+                        if (jj < np) wg8_dma(rs_x, ldsA + (ss ^ 1) * ASTAGE + ((j0 + jj) * 8 + wave) * 1024, a_goff[jj < np ? j0 + jj : 0], (s + 1) * 64);
+                }
                 if (lead) wg8_mma16<H>(acc, wf, xf);
                 // everything this wave issued BEFORE this step has landed once only this step's pieces are outstanding
                 if (more_b) {
-                    if (piece && !last) wg8_wait_vm<BP + 1>(); else wg8_wait_vm<BP>();
+                    if (!last) {
+                        if (np == 0) wg8_wait_vm<BP>();
+                        else if (np == 1) wg8_wait_vm<BP + 1>();
+                        else if (np == 2) wg8_wait_vm<BP + 2>();
+                        else if (np == 3) wg8_wait_vm<BP + 3>();
+                        else if (np == 4) wg8_wait_vm<BP + 4>();
+                        else if (np == 5) wg8_wait_vm<BP + 5>();
+                        else wg8_wait_vm<BP + 6>();
+                    } else wg8_wait_vm<BP>();
                 } else {
                     wg8_wait_vm<0>();
                 }
@@ -300,9 +330,18 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wg8_kernel(const Wg8Params p, 
         // writes 64 contiguous bytes per quad instead of 16 bytes into 64 lines (conv_ws64.h measured the difference)
         quad_transpose4x4(pk, lane);
         if (n < (uint32_t)p.N) {
-            H* dst = out + ((size_t)n * (W * W) + (pix & ~3)) * p.Cout + co + (l31 & 3) * 8;
+            if constexpr (NT == 9) {
+                H* dst = out + ((size_t)n * (W * W) + (pix & ~3)) * p.Cout + co + (l31 & 3) * 8;
 #pragma unroll
-            for (int v = 0; v < 4; ++v) *reinterpret_cast<u32x4_t*>(dst + (size_t)v * p.Cout) = pk[v];
+                for (int v = 0; v < 4; ++v) *reinterpret_cast<u32x4_t*>(dst + (size_t)v * p.Cout) = pk[v];
+            } else {
+                // depth-to-space: "channel" co = px * Cdx + ci of dy-grid pixel (yy, xx) is d(x)[2 yy + py][2 xx + px][ci]
+                const int cdx = p.Cout >> 1, px = (int)co >= cdx ? 1 : 0, ci = (int)co - px * cdx;
+                const int pb = pix & ~3, yy = pb / W, xx = pb - yy * W;
+                H* dst = out + (((size_t)n * (2 * W) + 2 * yy + p.s2_py) * (2 * W) + 2 * xx + px) * cdx + ci + (l31 & 3) * 8;
+#pragma unroll
+                for (int v = 0; v < 4; ++v) *reinterpret_cast<u32x4_t*>(dst + (size_t)(2 * v) * cdx) = pk[v];
+            }
         }
     }
 }

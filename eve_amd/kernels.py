@@ -175,6 +175,8 @@ class HipKernels(object):
         d = self._desc(dy.dtype, N, IH, IW, Cin, Cout, KH, KW, stride, pad)
         assert (d.OH, d.OW) == (OH, OW)
         co, kk = algo or (Cout, KH * KW * Cin)
+        if stride == 2 and dy.dtype in HALF_DTYPES:
+            self.ensure_workspace(dy.device)        # the stride-2 data gradient re-packs its filters into the workspace
         if accumulate_into is not None:
             dx = accumulate_into
             assert tuple(dx.shape) == (N, IH, IW, Cin) and dx.dtype == dy.dtype and dx.is_contiguous()

@@ -811,7 +811,17 @@ for dt in (torch.bfloat16, torch.float16):
         dy = torch.randn(y.shape, generator=g).to(dt).cuda()
         dx = k.conv2d_dgrad(dy, w.permute(3, 1, 2, 0).contiguous(), (H, H), 1, 1)
         outs += [y.float().cpu(), dx.float().cpu()]
-torch.save((outs, names), sys.argv[1])
+s2_outs, s2_names = [], []
+for dt in (torch.bfloat16, torch.float16):
+    # data gradient of the stride-2 3x3 layers (dy grid 16 / 8 / 4 wide): two eight-wave launches over the dy halo tile
+    # (conv3x3_wg8_kernel<.., NT = 2 | 4>, depth-to-space epilogue) against the four per-tap parity-class launches
+    for N, OW, Cdx, Co in ((5, 16, 64, 128), (9, 8, 128, 256), (35, 4, 256, 512), (3, 16, 128, 128)):
+        dy = torch.randn((N, OW, OW, Co), generator=g).to(dt).cuda()
+        w = (torch.randn((Co, Cdx, 3, 3), generator=g) * (2.0 / (9 * Co)) ** 0.5).to(dt).cuda()
+        dx = k.conv2d_dgrad(dy, w.permute(1, 2, 3, 0).contiguous(), (2 * OW, 2 * OW), 2, 1)
+        s2_names.append(k.lib.eve_last_kernel().decode())
+        s2_outs.append(dx.float().cpu())
+torch.save((outs, names, s2_outs, s2_names), sys.argv[1])
 ''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     res = {}
     for mode in ('0', '2'):
@@ -825,3 +835,7 @@ torch.save((outs, names), sys.argv[1])
     for i, (a, b) in enumerate(zip(res['2'][0], res['0'][0])):
         tol = 2e-3 if i < 10 else 3e-4                       # bf16 cases first, then float16
         assert float((a - b).norm() / b.norm()) < tol and float((a - b).abs().max()) <= 8 * tol * float(b.abs().max()), i
+    assert all('s2dgrad' in n for n in res['2'][3]) and not any('wg8' in n for n in res['0'][3]), (res['2'][3], res['0'][3])
+    for i, (a, b) in enumerate(zip(res['2'][2], res['0'][2])):
+        tol = 2.5e-3 if i < 4 else 3e-4
+        assert float((a - b).norm() / b.norm()) < tol and float((a - b).abs().max()) <= 8 * tol * float(b.abs().max()), ('s2', i)
