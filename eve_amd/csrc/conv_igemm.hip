@@ -1022,7 +1022,9 @@ __global__ __launch_bounds__(256) void s2_dgrad_pack_kernel(const H* __restrict_
 template <typename HT>
 static bool launch_s2_dgrad_wg8(const eve_conv_desc* d, const void* dy, const void* w_ihwo, void* dx, hipStream_t s) {
     static int on = -1, min_tiles = -1;
-    if (on < 0) { const char* e = getenv("EVE_CONV_WG8"); on = e ? atoi(e) : 1; const char* f = getenv("EVE_CONV_WG8_MIN_TILES"); min_tiles = f ? atoi(f) : 224; }
+    // (its own tile floor: against four per-tap launches the eight-wave pair is ahead from ~48 workgroups on -- B = 8 clips per
+    //  GPU: layer 3.0 0.070 -> 0.049 ms with 120 tiles, layer 4.0 0.090 -> 0.070 with 60 -- where the 3x3 convolution wants 224)
+    if (on < 0) { const char* e = getenv("EVE_CONV_WG8"); on = e ? atoi(e) : 1; const char* f = getenv("EVE_CONV_WG8_S2_MIN_TILES"); min_tiles = f ? atoi(f) : 48; }
     const int W = d->OW, Cdx = d->Cin, Co = d->Cout;
     if (!on || d->KH != 3 || d->KW != 3 || d->stride != 2 || d->pad != 1 || d->OH != W || d->IH != 2 * W || d->IW != 2 * W ||
         !(W == 16 || W == 8 || W == 4) || Co % 64 || !g_workspace)

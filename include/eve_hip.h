@@ -48,9 +48,11 @@ int eve_abi_version(void);
 const char* eve_last_kernel(void);
 const char* eve_last_error(void);
 /* Caller-owned device scratch (16-byte aligned; NULL / 0 removes it).  The library never allocates: kernels that can use
- * scratch -- today the split-K weight gradient of the 256..512-channel layers, which then writes per-split partial filters
- * with plain stores and sums them in a second launch instead of 16 M float atomics -- read it from here, on the stream
- * they are launched on, and fall back to their scratch-free form when it is missing or too small.  One stream at a time.   */
+ * scratch read it from here, on the stream they are launched on, and fall back to their scratch-free form when it is missing
+ * or too small.  Users today: the split-K weight gradient of the 256..512-channel layers (FIRST half: per-split partial
+ * filters with plain stores + a summing launch instead of 16 M float atomics) and the data gradient of the stride-2 3x3
+ * layers (SECOND half: filters re-packed per call for conv3x3_wg8_kernel<.., NT>).  The halves may be in use on two streams
+ * at once (weight gradients on a side stream); each half one stream at a time.                                          */
 int eve_set_workspace(void* device_ptr, unsigned long long bytes);
 
 /* ------------------------------------------------------------------------------------------------

@@ -827,7 +827,7 @@ torch.save((outs, names, s2_outs, s2_names), sys.argv[1])
     for mode in ('0', '2'):
         path = os.path.join(str(tmp_path), 'wg8_%s.pt' % mode)
         # (EVE_CONV_WG8_MIN_TILES=0: the launcher otherwise keeps wg8 for launches whose tiles fill the chip)
-        env = dict(os.environ, EVE_CONV_WG8=mode, EVE_CONV_WG8_MIN_TILES='0')
+        env = dict(os.environ, EVE_CONV_WG8=mode, EVE_CONV_WG8_MIN_TILES='0', EVE_CONV_WG8_S2_MIN_TILES='0')
         p = subprocess.run([sys.executable, '-c', code, path], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
         assert p.returncode == 0, p.stdout[-2000:]
         res[mode] = torch.load(path)
