@@ -67,6 +67,7 @@ template <> struct Mma<float> {
 }  // namespace eve
 #include "conv_fast.h"
 #include "conv_wg8.h"
+#include "conv_wg8s2.h"
 #include "conv_ws64.h"
 #include "wgrad_halo.h"
 #include "wgrad_wg8.h"
@@ -979,6 +980,48 @@ static int launch_wgrad(const GatherParams& p, const void* x, const void* dy, co
 
 using namespace eve;
 
+namespace eve {
+
+// 3x3 / stride 2 / pad 1 forward of the trunk's down-sampling blocks on conv3x3s2_wg8_kernel (conv_wg8s2.h).  true: launched.
+template <typename HT>
+static bool launch_s2_fwd_wg8(const eve_conv_desc* d, const void* x, const void* w, const float* bias, int epi_act, void* y, hipStream_t s) {
+    static int on = -1, min_tiles = -1;
+    if (on < 0) { const char* e = getenv("EVE_CONV_WG8"); on = e ? atoi(e) : 1; const char* f = getenv("EVE_CONV_WG8_S2_MIN_TILES"); min_tiles = f ? atoi(f) : 48; }
+    const int W = d->OW;
+    if (!on || d->KH != 3 || d->KW != 3 || d->stride != 2 || d->pad != 1 || d->OH != W || d->IH != 2 * W || d->IW != 2 * W ||
+        !(W == 16 || W == 8 || W == 4) || d->Cin % 64 || (epi_act & ~0xff) ||
+        !((epi_act & 0xff) == EVE_ACT_NONE || (epi_act & 0xff) == EVE_ACT_RELU))
+        return false;
+    const int cout_t = W == 16 ? 128 : 256;
+    if (d->Cout % cout_t) return false;
+    const unsigned long long xb = (unsigned long long)d->N * 4 * W * W * d->Cin * 2, wb = (unsigned long long)d->Cout * 9 * d->Cin * 2;
+    if (xb >= (1ull << 31) || wb >= (1ull << 31)) return false;
+    const int ti = W == 16 ? 2 : (W == 8 ? 4 : 16);
+    const uint32_t tiles = (uint32_t)((d->N + ti - 1) / ti) * (uint32_t)(d->Cout / cout_t);
+    if ((int)tiles < min_tiles) return false;
+    Wg8Params g;
+    g.N = d->N; g.Cin = d->Cin; g.Cout = d->Cout; g.flip = 0; g.K = 9 * d->Cin; g.x_bytes = (uint32_t)xb; g.w_bytes = (uint32_t)wb;
+    g.tiles_n = (uint32_t)(d->Cout / cout_t); g.s2_py = 0;
+#define EVE_S2F_LAUNCH(WM_, WN_, W_)                                                                                       \
+    do {                                                                                                                  \
+        using G8 = Wg8S2Geom<WM_, WN_, W_>;                                                                                 \
+        static bool attr_done = false;                                                                                    \
+        if (!attr_done) {                                                                                                 \
+            (void)hipFuncSetAttribute((const void*)conv3x3s2_wg8_kernel<HT, WM_, WN_, W_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+            attr_done = true;                                                                                             \
+        }                                                                                                                 \
+        EVE_LAUNCH(EVE_HNAME(HT, "conv3x3s2_wg8_kernel<", ", " #WM_ ", " #WN_ ", " #W_ ">"), (conv3x3s2_wg8_kernel<HT, WM_, WN_, W_>), \
+                   dim3(tiles), dim3(512), G8::LDS, s, g, (const HT*)x, (const HT*)w, bias, epi_act, (HT*)y);                   \
+    } while (0)
+    if (W == 16) EVE_S2F_LAUNCH(4, 2, 16);
+    else if (W == 8) EVE_S2F_LAUNCH(2, 4, 8);
+    else EVE_S2F_LAUNCH(2, 4, 4);
+#undef EVE_S2F_LAUNCH
+    return true;
+}
+
+}  // namespace eve
+
 extern "C" int eve_conv2d_fwd(const eve_conv_desc* d, const void* x, const void* w_ohwi, const float* bias,
                               int epi_act, const float* in_scale_shift, int pro_act, void* y,
                               eve_stream_t stream) {
@@ -987,6 +1030,10 @@ extern "C" int eve_conv2d_fwd(const eve_conv_desc* d, const void* x, const void*
     if (!x || !w_ohwi || !y) return set_error_msg("conv2d_fwd: null pointer");
     GatherParams p = fwd_params(d);
     hipStream_t s = (hipStream_t)stream;
+    if (!in_scale_shift) {          // the trunk's stride-2 3x3 layers: parity planes of the input as rotating halo stages
+        if (d->dtype == EVE_DT_BF16 && launch_s2_fwd_wg8<bf16_t>(d, x, w_ohwi, bias, epi_act, y, s)) { EVE_CHECK_LAUNCH(); return 0; }
+        if (d->dtype == EVE_DT_F16 && launch_s2_fwd_wg8<f16_t>(d, x, w_ohwi, bias, epi_act, y, s)) { EVE_CHECK_LAUNCH(); return 0; }
+    }
     if (d->dtype == EVE_DT_BF16) launch_igemm<bf16_t>(p, x, w_ohwi, bias, in_scale_shift, pro_act, epi_act, y, s);
     else if (d->dtype == EVE_DT_F16) launch_igemm<f16_t>(p, x, w_ohwi, bias, in_scale_shift, pro_act, epi_act, y, s);
     else                         launch_igemm<float>(p, x, w_ohwi, bias, in_scale_shift, pro_act, epi_act, y, s);
