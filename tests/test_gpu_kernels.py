@@ -77,6 +77,12 @@ CONV_CASES = [
     (5, 8, 8, 64, 48, 3, 1, 1),         # several whole images per tile, Cout not a multiple of 16
     (300, 32, 32, 64, 64, 3, 1, 1),     # more tiles than persistent workgroups
     (530, 16, 16, 32, 128, 3, 1, 1),    # persistent 2x2-wave kernel (1060 tiles), one slice, two channel blocks... of one
+    # stride-2 3x3 layers with enough tiles (>= 48) for the eight-wave kernels: conv3x3s2_wg8_kernel forward (parity planes of the
+    # input as rotating halo stages) and conv3x3_wg8_kernel<.., NT = 2 | 4> data gradient (window convolution over dy), ragged
+    # image counts (the last tile holds fewer images than its 2 / 4 / 16)
+    (101, 32, 32, 64, 128, 3, 2, 1),    # layer 2.0
+    (197, 16, 16, 128, 256, 3, 2, 1),   # layer 3.0
+    (395, 8, 8, 256, 512, 3, 2, 1),     # layer 4.0
 ]
 
 
