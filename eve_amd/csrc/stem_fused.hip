@@ -333,7 +333,8 @@ __global__ __launch_bounds__(64 * SF_WAVES) void stem_bwd_dx_kernel(const int N,
                                                                     const H* __restrict__ w8, const float* __restrict__ mr,
                                                                     const H* __restrict__ dyp, const H* __restrict__ dyp2,
                                                                     const H* __restrict__ yp,
-                                                                    const uint8_t* __restrict__ idx, H* __restrict__ dx) {
+                                                                    const uint8_t* __restrict__ idx, H* __restrict__ dx,
+                                                                    const int halves) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const sW = smem + SF_WAVES * SF_RING * SF_ROWB;
     const int tid = threadIdx.x;
@@ -352,9 +353,14 @@ __global__ __launch_bounds__(64 * SF_WAVES) void stem_bwd_dx_kernel(const int N,
 
     // images are dealt round-robin over the workgroups first (wave w of workgroup b takes image w * grid + b): a small batch
     // then puts one or two waves on every CU instead of eight waves on a fraction of them
-    for (int n = wave * gridDim.x + blockIdx.x; n < N; n += gridDim.x * SF_WAVES) {
+    // halves == 2 (small batches: fewer images than wave slots): an image is TWO work items, the upper and the lower half of its
+    // rows.  The halves share nothing but the plane sums of phase A, which are taken over the small pooled tensors and simply
+    // computed by both; with one wave per image the kernel's duration is the latency of one image whatever the batch.
+    for (int item = wave * gridDim.x + blockIdx.x; item < N * halves; item += gridDim.x * SF_WAVES) {
+        const int n = halves == 2 ? item >> 1 : item;
+        const int py0 = halves == 2 ? (item & 1) * (PH / 2) : 0, py1 = halves == 2 ? py0 + PH / 2 : PH;
         const int img_off = n * rows * SF_XROW;
-        for (int r = 0; r < 9; ++r) sf_stage_row(rs, ring, r, rows, img_off, lane);
+        for (int r = 0; r < 9; ++r) sf_stage_row(rs, ring, 4 * py0 + r, rows, img_off, lane);
         const size_t pool_base = (size_t)n * PH * 32;
         // ---- phase A: the two plane sums, over the pooled tensors; the folded per-channel constants go to LDS ----
         {
@@ -397,18 +403,18 @@ __global__ __launch_bounds__(64 * SF_WAVES) void stem_bwd_dx_kernel(const int N,
         }
         // ---- phase B: recompute the convolution row by row, emit d(conv out) ----
         SfPooledRow P0, P1;
-        sf_load_pooled<H>(P0, dyp, dyp2, yp, idx, pool_base, li, lg, true);
+        sf_load_pooled<H>(P0, dyp, dyp2, yp, idx, pool_base + (size_t)py0 * 32, li, lg, true);
         H* dimg = dx + (size_t)n * OH * 64 * 64;
-        int slot0 = 0;
-        for (int py = 0; py < PH; ++py) {
+        int slot0 = (4 * py0) % SF_RING;
+        for (int py = py0; py < py1; ++py) {
             sf_load_pooled<H>(P1, dyp, dyp2, yp, idx, pool_base + (size_t)(py + 1) * 32, li, lg, py + 1 < PH);
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
                 const int oy = 2 * py + half;
                 // rows 2oy..2oy+6 were issued two iterations ago; younger: >= 4 DMAs + 16 stores (+ pooled loads)
-                if (oy == 0)      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-                else if (oy == 1) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-                else              asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
+                if (oy == 2 * py0)          asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                else if (oy == 2 * py0 + 1) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+                else                        asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
                 sf_stage_row(rs, ring, 2 * oy + 9, rows, img_off, lane);
                 sf_stage_row(rs, ring, 2 * oy + 10, rows, img_off, lane);
                 f32x4_t acc[4][4];
@@ -497,10 +503,14 @@ extern "C" int eve_stem_bwd_dx(int dtype, int N, int IH, int IW, const void* x_p
         (void)hipFuncSetAttribute((const void*)stem_bwd_dx_kernel<f16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    unsigned blocks = N < 256 ? (unsigned)N : 256u;
+    // two work items per image while that still fits the 256 x 8 wave slots (B <= 16 clips per GPU): see the kernel
+    static int split = -1;
+    if (split < 0) { const char* e = getenv("EVE_STEM_SPLIT"); split = (e && e[0] == '0') ? 0 : 1; }
+    const int halves = (split && 2 * N <= 256 * SF_WAVES && (IH & 7) == 0) ? 2 : 1;
+    unsigned blocks = N * halves < 256 ? (unsigned)(N * halves) : 256u;
     EVE_DISPATCH_H16(dtype, EVE_LAUNCH(EVE_HNAME(H, "stem_bwd_dx_kernel<", ">"), stem_bwd_dx_kernel<H>, dim3(blocks), dim3(64 * SF_WAVES), lds,
                                        (hipStream_t)stream, N, IH, (const H*)x_padded, (uint32_t)xb, (const H*)w_ohwi8, mean_rstd, (const H*)dy_pool,
-                                       (const H*)dy_pool2, (const H*)y_pool, idx, (H*)dx));
+                                       (const H*)dy_pool2, (const H*)y_pool, idx, (H*)dx, halves));
     EVE_CHECK_LAUNCH();
     return 0;
 }
