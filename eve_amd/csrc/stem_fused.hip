@@ -121,9 +121,10 @@ __global__ __launch_bounds__(64 * SF_WAVES) void stem_fwd_fused_kernel(const int
                                                                        const H* __restrict__ xp, const uint32_t xp_bytes,
                                                                        const H* __restrict__ w8, const float eps,
                                                                        H* yp, uint8_t* __restrict__ idx,
-                                                                       float* __restrict__ mr) {
+                                                                       float* __restrict__ mr, const int halves) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const sW = smem + SF_WAVES * SF_RING * SF_ROWB;
+    float* const sX = reinterpret_cast<float*>(sW + SF_WBYTES);           // halves == 2: [wave][64 channels][sum, sum of squares]
     const int tid = threadIdx.x;
     sf_fill_weights<H>(sW, w8, tid, 64 * SF_WAVES);
     __syncthreads();
@@ -138,10 +139,27 @@ __global__ __launch_bounds__(64 * SF_WAVES) void stem_fwd_fused_kernel(const int
     const float inv_hw = 1.f / (float)(OH * 64);
 
     // images are dealt round-robin over the workgroups first (wave w of workgroup b takes image w * grid + b): a small batch
-    // then puts one or two waves on every CU instead of eight waves on a fraction of them
-    for (int n = wave * gridDim.x + blockIdx.x; n < N; n += gridDim.x * SF_WAVES) {
+    // then puts one or two waves on every CU instead of eight waves on a fraction of them.
+    // halves == 2 (fewer images than half the wave slots): waves 2k and 2k + 1 of a workgroup share an image, rows
+    // [0, OH/2) and [OH/2, OH); the lower half starts one row early for its first pooling window (that row's statistics
+    // belong to the upper half) and the two partial plane sums meet in LDS.  Every wave of the workgroup runs the same
+    // number of turns (the exchange is a workgroup barrier); a turn without an image only keeps the barriers.
+    const bool fold = (IH & 7) == 0;                              // the image has two equal halves of rows
+    const int per_turn = gridDim.x * (SF_WAVES / halves);
+    const int turns = (N + per_turn - 1) / per_turn;
+    for (int turn = 0; turn < turns; ++turn) {
+        const int n = turn * per_turn + (halves == 2 ? (wave >> 1) : wave) * (int)gridDim.x + (int)blockIdx.x;
+        const bool live = n < N;
+        const int hf = halves == 2 ? (wave & 1) : 0;
+        const int oy_first = hf ? OH / 2 - 1 : 0;                 // first convolution row this wave computes
+        const int oy_own = hf ? OH / 2 : 0;                       // first row whose statistics / pooled output are its own
+        const int oy_end = (halves == 2 && !hf) ? OH / 2 : OH;
+        if (!live) {                                              // (uniform per wave)
+            if (halves == 2) { __syncthreads(); __syncthreads(); }
+            continue;
+        }
         const int img_off = n * rows * SF_XROW;
-        for (int r = 0; r < 9; ++r) sf_stage_row(rs, ring, r, rows, img_off, lane);
+        for (int r = 0; r < 9; ++r) sf_stage_row(rs, ring, 2 * oy_first + r, rows, img_off, lane);
         float S[4][4], Q[4][4];
         uint32_t M[2][4][4];
 #pragma unroll
@@ -150,17 +168,34 @@ __global__ __launch_bounds__(64 * SF_WAVES) void stem_fwd_fused_kernel(const int
             for (int b = 0; b < 4; ++b) { S[a][b] = 0.f; Q[a][b] = 0.f; M[0][a][b] = SF_NEG; M[1][a][b] = SF_NEG; }
         H* yimg = yp + (size_t)n * PH * 32 * 64;
         uint8_t* iimg = idx + (size_t)n * PH * 32 * 64;
-        int slot0 = 0;
-        for (int oy = 0; oy < OH; ++oy) {
-            // rows 2oy .. 2oy+6 were issued two iterations ago; younger: 4 DMAs + at most 6 stores (see header)
-            if (oy < 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-            else        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        int slot0 = (2 * oy_first) % SF_RING;
+        for (int oy = oy_first; oy < oy_end; ++oy) {
+            // rows 2oy .. 2oy+6 were issued two iterations ago; younger: 4 DMAs + 6 stores of one of the last two rows (see
+            // header); the first rows of a wave's range have issued fewer stores yet: wait for everything but the last 4 DMAs
+            if (oy < oy_first + 3) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else                   asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
             sf_stage_row(rs, ring, 2 * oy + 9, rows, img_off, lane);
             sf_stage_row(rs, ring, 2 * oy + 10, rows, img_off, lane);
             f32x4_t acc[4][4];
             sf_conv_row<H, false>(acc, ring, slot0, xoff, wbase);
             slot0 = slot0 + 2 >= SF_RING ? slot0 + 2 - SF_RING : slot0 + 2;
             // ---- plane statistics ----
+            // (one wave per image: at the middle row the upper half's sums are reduced and parked in LDS, so that the plane
+            //  sums are formed as (upper half) + (lower half) exactly as the two-waves-per-image form does -- an image's
+            //  outputs must not depend on the batch it arrives in, bit for bit)
+            if (halves == 1 && fold && oy == OH / 2) {
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float su = sf_row_sum16(S[nt][r]), qu = sf_row_sum16(Q[nt][r]);
+                        if (li == 0) {
+                            float* o = sX + ((wave * 64) + lg * 16 + nt * 4 + r) * 2;
+                            o[0] = su; o[1] = qu;
+                        }
+                        S[nt][r] = 0.f; Q[nt][r] = 0.f;
+                    }
+            }
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
@@ -168,7 +203,7 @@ __global__ __launch_bounds__(64 * SF_WAVES) void stem_fwd_fused_kernel(const int
                     float s = 0.f, q = 0.f;
 #pragma unroll
                     for (int mt = 0; mt < 4; ++mt) { const float v = acc[mt][nt][r]; s += v; q += v * v; }
-                    S[nt][r] += s; Q[nt][r] += q;
+                    if (oy >= oy_own) { S[nt][r] += s; Q[nt][r] += q; }
                 }
             // ---- 3x3/2 max-pool on keys = value bits with the low 4 mantissa bits replaced by the window position ----
             const bool odd = oy & 1;
@@ -199,7 +234,7 @@ __global__ __launch_bounds__(64 * SF_WAVES) void stem_fwd_fused_kernel(const int
                         acc[2 * j][nt][r] = m;                                                      // window result (odd rows)
                     }
                 }
-            if (odd) {
+            if (odd && oy >= oy_own) {
                 const int py = oy >> 1;
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
@@ -228,21 +263,54 @@ __global__ __launch_bounds__(64 * SF_WAVES) void stem_fwd_fused_kernel(const int
         }
         // ---- plane statistics -> mean / rstd of the lane's 16 channels ----
         float mean[4][4], rstd[4][4];
+        if (halves == 1 && fold) {                                // (upper half, parked at the middle row) + (lower half)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float* o = sX + ((wave * 64) + lg * 16 + nt * 4 + r) * 2;
+                    S[nt][r] = o[0] + sf_row_sum16(S[nt][r]);
+                    Q[nt][r] = o[1] + sf_row_sum16(Q[nt][r]);
+                }
+        }
+        if (halves == 2) {                                        // the partner's partial sums (channel lg * 16 + nt * 4 + r)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    S[nt][r] = sf_row_sum16(S[nt][r]); Q[nt][r] = sf_row_sum16(Q[nt][r]);
+                    if (li == 0) {
+                        float* o = sX + ((wave * 64) + lg * 16 + nt * 4 + r) * 2;
+                        o[0] = S[nt][r]; o[1] = Q[nt][r];
+                    }
+                }
+            __syncthreads();
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float* o = sX + (((wave ^ 1) * 64) + lg * 16 + nt * 4 + r) * 2;
+                    // (the upper half's sum first in both waves: the two agree bit for bit)
+                    S[nt][r] = hf ? o[0] + S[nt][r] : S[nt][r] + o[0];
+                    Q[nt][r] = hf ? o[1] + Q[nt][r] : Q[nt][r] + o[1];
+                }
+            __syncthreads();                                      // sX may be rewritten in the next turn
+        }
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float s = sf_row_sum16(S[nt][r]) * inv_hw, q = sf_row_sum16(Q[nt][r]) * inv_hw;
+                const float s = ((halves == 2 || fold) ? S[nt][r] : sf_row_sum16(S[nt][r])) * inv_hw, q = ((halves == 2 || fold) ? Q[nt][r] : sf_row_sum16(Q[nt][r])) * inv_hw;
                 const float var = fmaxf(q - s * s, 0.f);
                 mean[nt][r] = s;
                 rstd[nt][r] = rsqrtf(var + eps);
-                if (li == 0) {
+                if (li == 0 && hf == 0) {
                     float* m = mr + ((size_t)n * 64 + lg * 16 + nt * 4 + r) * 2;
                     m[0] = s; m[1] = rstd[nt][r];
                 }
             }
         // ---- normalise the lane's own pooled values in place: y = relu((max - mean) * rstd) ----
-        for (int py = 0; py < PH; ++py)
+        for (int py = oy_own >> 1; py < (oy_end >> 1); ++py)
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 H* p = yimg + ((size_t)py * 32 + li + 16 * j) * 64 + lg * 16;
@@ -474,16 +542,20 @@ extern "C" int eve_stem_fwd_fused(int dtype, int N, int IH, int IW, const void* 
         return set_error_msg("stem_fwd_fused: needs IW == 128 and IH a multiple of 4");
     const unsigned long long xb = (unsigned long long)N * (IH + 6) * SF_XROW;
     if (xb >= (1ull << 31)) return set_error_msg("stem_fwd_fused: packed input must stay below 2 GiB");
-    const size_t lds = (size_t)SF_WAVES * SF_RING * SF_ROWB + SF_WBYTES;
+    const size_t lds = (size_t)SF_WAVES * SF_RING * SF_ROWB + SF_WBYTES + SF_WAVES * 64 * 2 * 4;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)stem_fwd_fused_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void*)stem_fwd_fused_kernel<f16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    unsigned blocks = N < 256 ? (unsigned)N : 256u;
+    // two waves per image while that still fits the 256 x 8 wave slots (B <= 16 clips per GPU): see the kernel
+    static int split = -1;
+    if (split < 0) { const char* e = getenv("EVE_STEM_SPLIT"); split = (e && e[0] == '0') ? 0 : 1; }
+    const int halves = (split && 2 * N <= 256 * SF_WAVES && (IH & 7) == 0) ? 2 : 1;
+    unsigned blocks = N < 256 ? (unsigned)N : 256u;              // images are dealt round-robin over the workgroups
     EVE_DISPATCH_H16(dtype, EVE_LAUNCH(EVE_HNAME(H, "stem_fwd_fused_kernel<", ">"), stem_fwd_fused_kernel<H>, dim3(blocks), dim3(64 * SF_WAVES), lds,
-                                       (hipStream_t)stream, N, IH, (const H*)x_padded, (uint32_t)xb, (const H*)w_ohwi8, eps, (H*)y_pool, idx, mean_rstd));
+                                       (hipStream_t)stream, N, IH, (const H*)x_padded, (uint32_t)xb, (const H*)w_ohwi8, eps, (H*)y_pool, idx, mean_rstd, halves));
     EVE_CHECK_LAUNCH();
     return 0;
 }
