@@ -29,9 +29,6 @@
 #ifndef EVE_WS64_NB
 #define EVE_WS64_NB 2
 #endif
-#ifndef EVE_WS64_ABLATE
-#define EVE_WS64_ABLATE 0    // timing experiments only (wrong results): 1 no halo fetches, 2 no barrier, 4 no stores, 8 no fragment reads, 16 no MFMAs
-#endif
 
 namespace eve {
 
@@ -197,13 +194,11 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws64_kernel(const Ws64Params p
             // is free (every wave is past its last read of it).  Slice 1: the previous tile's 8 stores were issued AFTER
             // this stage's fetch and complete after it (vector memory operations of a wave retire in order), so only they
             // may stay in flight -- waiting for their write acknowledgements cost 10 % of the kernel.
-            if (s == 1 && !(EVE_WS64_ABLATE & 5)) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            if (s == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (!(EVE_WS64_ABLATE & 2)) __builtin_amdgcn_s_barrier();
-            if (!(EVE_WS64_ABLATE & 1)) {
-                if (s == 0) issue_halo(tile, 1, 1);
-                else issue_halo(tile + G, 0, 0);
-            }
+            __builtin_amdgcn_s_barrier();
+            if (s == 0) issue_halo(tile, 1, 1);
+            else issue_halo(tile + G, 0, 0);
             constexpr int NB = EVE_WS64_NB;                       // fragment buffers: step h + NB - 1 is read before step h runs
             u32x4_t wf[NB][2], xf[NB][2];
             auto read_step = [&](int buf, int h) {
@@ -219,12 +214,12 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws64_kernel(const Ws64Params p
             for (int h = 0; h < NB - 1; ++h) read_step(h, h);
 #pragma unroll
             for (int h = 0; h < 18; ++h) {
-                if (h + NB - 1 < 18 && !((EVE_WS64_ABLATE & 8) && h > 0)) read_step((h + NB - 1) % NB, h + NB - 1);    // a later step's fragments first ...
+                if (h + NB - 1 < 18) read_step((h + NB - 1) % NB, h + NB - 1);    // a later step's fragments first ...
                 __builtin_amdgcn_sched_barrier(0);
                 if (s == 0 && h == 0) ws64_mma4<H, true>(acc[PAR], wf[h % NB], xf[h % NB]);    // ... then this step's MFMAs
-                else if (!(EVE_WS64_ABLATE & 16)) ws64_mma4<H, false>(acc[PAR], wf[h % NB], xf[h % NB]);
+                else ws64_mma4<H, false>(acc[PAR], wf[h % NB], xf[h % NB]);
                 __builtin_amdgcn_sched_barrier(0);
-                if (s == 0 && h >= 2 && h < 10 && !(EVE_WS64_ABLATE & 4)) {                 // half an accumulator tile of the previous tile per step
+                if (s == 0 && h >= 2 && h < 10) {                 // half an accumulator tile of the previous tile per step
                     // (the empty statement redefines the tile here: without it the compiler copies all 64 accumulators
                     //  into VGPRs at the top of the tile and carries them through the steps)
                     if ((h & 1) == 0) asm volatile("" : "+a"(acc[PAR ^ 1][((h - 2) >> 1) & 1][(h - 2) >> 2]));
