@@ -16,6 +16,18 @@ class ConvDesc(Structure):
                                      'KH', 'KW', 'stride', 'pad')]
 
 
+class DispatchConfig(Structure):
+    """include/eve_hip.h eve_dispatch_config: the kernel-selection table, resolved once when the library is loaded."""
+    _fields_ = [(n, c_int) for n in (
+        'struct_bytes', 'conv_impl_v1', 'conv_tile_big', 'conv_halo', 'conv_ws64', 'conv_wg8', 'conv_wg8_min_tiles',
+        'conv_wg8_s2_min_tiles', 'halo_persist', 'wgrad_target_wgs', 'wgrad_min_rows', 'wgrad_halo', 'wgrad_wg8',
+        'wg64_th', 'wg64_nreg', 'wg64_fixed', 'in_split', 'in_min_threads', 'in_stats_one_pass', 'stem_split',
+        'in_trunk_kernels')] + [('wgrad_halo_min_m', c_longlong)]
+
+    def as_dict(self):
+        return {n: int(getattr(self, n)) for n, _ in self._fields_ if n != 'struct_bytes'}
+
+
 P = c_void_p
 I = c_int
 L = c_longlong
@@ -28,15 +40,17 @@ class PackItem(Structure):
 
 
 PACK_BATCH_MAX = 48
-ABI_VERSION = 5          # include/eve_hip.h EVE_ABI_VERSION
+ABI_VERSION = 6          # include/eve_hip.h EVE_ABI_VERSION
 
 SIGNATURES = {
     'eve_conv2d_fwd': [POINTER(ConvDesc), P, P, P, I, P, I, P, P],
-    'eve_conv2d_dgrad': [POINTER(ConvDesc), P, P, P, P],
+    'eve_conv2d_dgrad': [POINTER(ConvDesc), P, P, P, P, ctypes.c_ulonglong, P],
     'eve_conv2d_dgrad_acc': [POINTER(ConvDesc), P, P, P, P],
-    'eve_conv2d_wgrad': [POINTER(ConvDesc), P, P, P, I, P, P],
-    'eve_conv2d_wgrad_bias': [POINTER(ConvDesc), P, P, P, P, P],
-    'eve_set_workspace': [P, ctypes.c_ulonglong],
+    'eve_conv2d_wgrad': [POINTER(ConvDesc), P, P, P, I, P, P, ctypes.c_ulonglong, P],
+    'eve_conv2d_wgrad_bias': [POINTER(ConvDesc), P, P, P, P, P, ctypes.c_ulonglong, P],
+    'eve_get_dispatch_config': [POINTER(DispatchConfig)],
+    'eve_get_default_dispatch_config': [POINTER(DispatchConfig)],
+    'eve_set_dispatch_config': [POINTER(DispatchConfig)],
     'eve_stem_pack_input': [I, I, I, I, I, P, P, P],
     'eve_frames_u8_to_nchw': [L, I, I, I, P, F, F, I, P, P],
     'eve_frames_u8_to_stem': [I, L, I, I, I, P, F, F, P, P],

@@ -239,9 +239,8 @@ __device__ __forceinline__ void quad_transpose4x4(u32x4_t (&r)[4], const int lan
 
 // symbol of the kernel the calling thread launched last (benchmark attribution, see eve_last_kernel)
 extern thread_local const char* g_last_kernel;
-// device scratch registered by the caller (eve_set_workspace); nullptr / 0 when none
-extern void* g_workspace;
-extern unsigned long long g_workspace_bytes;
+// kernel selection, resolved once at library load (api.hip; include/eve_hip.h: eve_dispatch_config)
+extern eve_dispatch_config g_cfg;
 }  // namespace eve
 #define EVE_MARK_KERNEL(name) (eve::g_last_kernel = (name))
 #define EVE_LAUNCH(name, ...) do { EVE_MARK_KERNEL(name); hipLaunchKernelGGL(__VA_ARGS__); } while (0)

@@ -517,9 +517,7 @@ static GatherParams dgrad_params(const eve_conv_desc* d) {
 }
 
 static bool use_v1() {
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("EVE_CONV_IMPL"); v = (e && e[0] == 'v' && e[1] == '1') ? 1 : 0; }
-    return v == 1;
+    return g_cfg.conv_impl_v1 == 1;
 }
 
 template <typename T>
@@ -527,8 +525,7 @@ static void launch_dma_one(const GatherParams& p, const TapPlan& tp, const void*
                            const float* bias, int epi_act, void* out, uint32_t src_bytes, uint32_t w_bytes,
                            hipStream_t s) {
     const T* a = (const T*)src; const T* b = (const T*)w; T* o = (T*)out;
-    static int big = -1;
-    if (big < 0) { const char* e = getenv("EVE_CONV_TILE"); big = (e && e[0] == '2') ? 1 : 0; }
+    const int big = g_cfg.conv_tile_big;
     if (p.Cout > 64 && big && p.M >= 256 * 256) {
         const uint32_t tiles = ((p.M + 255) / 256) * ((p.Cout + 127) / 128);
         EVE_LAUNCH("igemm_dma_kernel<T, 4, 2>", (igemm_dma_kernel<T, 4, 2>), dim3(tiles), dim3(512), 0, s, p, a, b, bias, epi_act, o,
@@ -550,9 +547,7 @@ static void launch_dma_one(const GatherParams& p, const TapPlan& tp, const void*
 template <typename HT>
 static bool launch_halo(const GatherParams& p, const void* src, const void* w, const float* bias, int epi_act,
                         void* out, hipStream_t s) {
-    static int enabled = -1;
-    if (enabled < 0) { const char* e = getenv("EVE_CONV_HALO"); enabled = (e && e[0] == '0') ? 0 : 1; }
-    if (!enabled) return false;
+    if (!g_cfg.conv_halo) return false;
     const bool fwd = p.k_mul == 1 && p.off == -1, bwd = p.k_mul == -1 && p.off == 1;
     if (p.KH != 3 || p.KW != 3 || p.div != 1 || p.o_mul != 1 || !(fwd || bwd) || p.OH != p.IH || p.OW != p.IW) return false;
     const int W = p.IW, H = p.IH;
@@ -560,8 +555,7 @@ static bool launch_halo(const GatherParams& p, const void* src, const void* w, c
     HaloParams h;
     h.N = p.N; h.H = H; h.W = W; h.Cin = p.Cin; h.Cout = p.Cout;
     // ---- ResNet layer 1 (32 x 32 images, 64 -> 64 channels): filter bank resident in LDS, streaming tiles (conv_ws64.h) ----
-    static int ws64 = -1;
-    if (ws64 < 0) { const char* e = getenv("EVE_CONV_WS64"); ws64 = (e && e[0] == '0') ? 0 : 1; }
+    const int ws64 = g_cfg.conv_ws64;
     if (ws64 && H == 32 && W == 32 && p.Cin == 64 && p.Cout == 64 && ((epi_act & ~0xff) == 0) &&
         ((epi_act & 0xff) == EVE_ACT_NONE || (epi_act & 0xff) == EVE_ACT_RELU) && (unsigned long long)p.N * 131072ull < (1ull << 31)) {
         Ws64Params q;
@@ -577,12 +571,10 @@ static bool launch_halo(const GatherParams& p, const void* src, const void* w, c
         return true;
     }
     // ---- eight-wave workgroups, 32x32x16 MFMA, staggered wave groups (conv_wg8.h): whole square images per tile ----
-    static int wg8 = -1;
-    if (wg8 < 0) { const char* e = getenv("EVE_CONV_WG8"); wg8 = e ? atoi(e) : 1; }
+    const int wg8 = g_cfg.conv_wg8;
     // one 512-thread workgroup per CU: below ~7/8 of the CUs' worth of tiles (B = 8 clips per GPU: 60-120 tiles) the
     // four-wave kernels with their 128-pixel tiles fill the chip better
-    static int wg8_min_tiles = -1;
-    if (wg8_min_tiles < 0) { const char* e = getenv("EVE_CONV_WG8_MIN_TILES"); wg8_min_tiles = e ? atoi(e) : 224; }
+    const int wg8_min_tiles = g_cfg.conv_wg8_min_tiles;
     if (wg8 && H == W && p.Cin % 64 == 0 && ((epi_act & ~0xff) == 0) &&
         ((epi_act & 0xff) == EVE_ACT_NONE || (epi_act & 0xff) == EVE_ACT_RELU)) {
         const unsigned long long xb8 = (unsigned long long)p.N * H * W * p.Cin * 2, wb8 = (unsigned long long)p.Cout * p.K * 2;
@@ -635,8 +627,7 @@ static bool launch_halo(const GatherParams& p, const void* src, const void* w, c
         (void)hipFuncSetAttribute((const void*)conv3x3_halo_kernel<HT, 4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    static int persist = -1;
-    if (persist < 0) { const char* e = getenv("EVE_HALO_PERSIST"); persist = (e && e[0] == '0') ? 0 : 1; }
+    const int persist = g_cfg.halo_persist;
     const uint32_t tiles = h.tiles_m * h.tiles_n;
     // (pays where a tile is short -- 18 steps at 64 channels; from 128 channels on the one-tile kernel is as fast)
     if (persist && tiles > 512 && p.Cin <= 64 && p.Cout % 8 == 0 && (epi_act == EVE_ACT_NONE || epi_act == EVE_ACT_RELU)) {           // two resident workgroups per CU walk the tiles as one stream
@@ -744,16 +735,14 @@ static void wgrad_split(const GatherParams& p, uint32_t tk, uint32_t tc, size_t 
     // filter tile, and those run at one dword per L2 channel and clock (~270 G/s: 17 M atomics of a 1 024-workgroup launch =
     // 60 us), so a second, partial round of workgroups costs its atomics and a tail.  Resident workgroups per CU: LDS-bound,
     // at most 3 by registers.  (Layers 3 / 4: 0.184 / 0.175 -> 0.160 / 0.148 ms against the former fixed target of 1 024.)
-    static int target_env = -1;
-    if (target_env < 0) { const char* e = getenv("EVE_WGRAD_TARGET_WGS"); target_env = e ? atoi(e) : 0; }
+    const int target_env = g_cfg.wgrad_target_wgs;
     uint32_t per_cu = lds_per_wg ? (uint32_t)((160 * 1024) / lds_per_wg) : 3;
     per_cu = per_cu < 1 ? 1 : (per_cu > 3 ? 3 : per_cu);
     const uint32_t target = target_env > 0 ? (uint32_t)target_env : 256u * per_cu;
     uint32_t want = target / (tk * tc);
     // ... but no split shorter than ~48 K-steps: prologue, ring fill and the 64 atomics per thread of the epilogue are per
     // workgroup (at B=8 clips the unbounded split cost 4 % of the step; B=32 is not affected)
-    static int min_rows = -1;
-    if (min_rows < 0) { const char* e = getenv("EVE_WGRAD_MIN_ROWS"); min_rows = e ? atoi(e) : 1536; }
+    const int min_rows = g_cfg.wgrad_min_rows;
     uint32_t max_splits = (p.M + (uint32_t)min_rows - 1) / (uint32_t)min_rows;
     splits = want < 1 ? 1 : (want > max_splits ? max_splits : want);
     if (splits < 1) splits = 1;
@@ -766,16 +755,13 @@ static void wgrad_split(const GatherParams& p, uint32_t tk, uint32_t tc, size_t 
 // few-channel 3x3 / stride 1 / pad 1 layers on large planes: band-resident kernel (wgrad_halo.h).  False = not this shape.
 template <typename HT>
 static bool launch_wgrad_halo(const GatherParams& p, const void* x, const void* dy, float* dw, float* db, hipStream_t s) {
-    static int enabled = -1;
-    if (enabled < 0) { const char* e = getenv("EVE_WGRAD_HALO"); enabled = (e && e[0] == '0') ? 0 : 1; }
-    if (!enabled) return false;
+    if (!g_cfg.wgrad_halo) return false;
     const int ks = p.KH;
     if ((ks != 3 && ks != 1) || p.KW != ks || p.o_mul != 1 || p.k_mul != 1 || p.off != -(ks / 2) || p.div != 1 || p.OH != p.IH ||
         p.OW != p.IW)
         return false;
     const int W = p.IW, H = p.IH;
-    long long min_m = 1ll << 20;                      // below ~1 M pixels the gather kernel's re-reads stay in L2 anyway
-    if (const char* e = getenv("EVE_WGRAD_HALO_MIN_M")) min_m = atoll(e);          // (read per call: the tests lower it)
+    const long long min_m = g_cfg.wgrad_halo_min_m;   // (1 M pixels: below, the gather kernel's re-reads stay in L2 anyway)
     if (W < 32 || W > 128 || (W & (W - 1)) || p.Cin % 16 || p.Cout % 16 || (long long)p.M < min_m) return false;
     const int MT = p.Cout / 16, CT = p.Cin / 16;
     const bool split = ks == 3 && MT == 4 && CT == 4;        // 64 -> 64 channels: wgrad_halo64_kernel (two bands resident)
@@ -790,8 +776,7 @@ static bool launch_wgrad_halo(const GatherParams& p, const void* x, const void* 
     int nreg = 0;
     if (split) {
         // wgrad_halo64_kernel: one workgroup per CU with 2 or 3 resident bands (and room for the epilogue's 9 x 64 x 64 + 64 floats)
-        static int force_th = -1, force_nreg = -1;
-        if (force_th < 0) { const char* e = getenv("EVE_WG64_TH"); force_th = e ? atoi(e) : 0; const char* f = getenv("EVE_WG64_NREG"); force_nreg = f ? atoi(f) : 0; }
+        const int force_th = g_cfg.wg64_th, force_nreg = g_cfg.wg64_nreg;
         for (int th : {8, 4, 2, 1}) {
             if (force_th && th != force_th) continue;
             const size_t need = (size_t)(th + 2) * (W + 2) * 128 + (size_t)th * W * 128;
@@ -836,8 +821,7 @@ static bool launch_wgrad_halo(const GatherParams& p, const void* x, const void* 
             attr_done = true;
         }
         const unsigned g64 = h.total_bands < 256u ? h.total_bands : 256u;
-        static int fixed64 = -1;
-        if (fixed64 < 0) { const char* e = getenv("EVE_WG64_FIXED"); fixed64 = (e && e[0] == '0') ? 0 : 1; }
+        const int fixed64 = g_cfg.wg64_fixed;
         if (fixed64 && W == 32 && TH == 8 && H % 8 == 0)     // ResNet layer 1: unrolled band loop, immediate fragment addresses
             EVE_LAUNCH(EVE_HNAME(HT, "wgrad_halo64_kernel<", ", fixed>"), (wgrad_halo64_kernel<HT, true>), dim3(g64), dim3(512), lds, s, h, (const HT*)x, (const HT*)dy, dw, db);
         else
@@ -861,7 +845,7 @@ static bool launch_wgrad_halo(const GatherParams& p, const void* x, const void* 
 
 template <typename T>
 static int launch_wgrad(const GatherParams& p, const void* x, const void* dy, const float* ss, int pro_act,
-                        float* dw, hipStream_t s, float* db = nullptr) {
+                        float* dw, hipStream_t s, float* db = nullptr, void* workspace = nullptr, unsigned long long workspace_bytes = 0) {
     if constexpr (sizeof(T) == 2) {
     if (!ss && !use_v1() && launch_wgrad_halo<T>(p, x, dy, dw, db, s)) return db ? 1 : 0;
     if (!ss && !use_v1()) {   // bf16: LDS-DMA staging + hardware-transposing fragment reads
@@ -893,8 +877,7 @@ static int launch_wgrad(const GatherParams& p, const void* x, const void* dy, co
             // address-decode mode of the gather (see wgrad_tr_kernel): both sizes powers of two / width only / neither
             const bool pow2w = (p.OW & (p.OW - 1)) == 0;
             const int mode = pow2 ? 1 : ((pow2w && p.OH * p.OW >= 32) ? 2 : 0);
-            static int wg8w = -1;
-            if (wg8w < 0) { const char* e = getenv("EVE_WGRAD_WG8"); wg8w = (e && e[0] == '0') ? 0 : 1; }
+            const int wg8w = g_cfg.wgrad_wg8;
             if (wg8w && !db && mode == 1 && p.Cout % 256 == 0 && p.K % 256 == 0) {
                 // 256 x 256 tiles, eight waves of 128 x 64, role-split wave pairs (wgrad_wg8.h): one workgroup per CU
                 const uint32_t tk = p.K / 256, tc = p.Cout / 256;
@@ -906,15 +889,16 @@ static int launch_wgrad(const GatherParams& p, const void* x, const void* dy, co
                     attr_done = true;
                 }
                 const unsigned long long n = (unsigned long long)p.Cout * p.K;
-                // (the workspace's first half: the second holds the strided data gradient's re-packed filters, possibly on another stream)
-                const bool slab = splits > 1 && g_workspace && (unsigned long long)splits * n * 4 <= g_workspace_bytes / 2 && ((uintptr_t)dw & 15) == 0;
+                // (the caller's scratch for THIS call: partial filters, consumed by the reduce launch that follows on the same stream)
+                const bool slab = splits > 1 && workspace && (unsigned long long)splits * n * 4 <= workspace_bytes && ((uintptr_t)dw & 15) == 0 &&
+                                  ((uintptr_t)workspace & 15) == 0;
                 if (slab) {
                     EVE_LAUNCH(EVE_HNAME(T, "wgrad_wg8_kernel<", ", true>"), (wgrad_wg8_kernel<T, true>), dim3(tk * tc * splits), dim3(512), (size_t)128 * 1024, s, p,
-                               (const T*)x, (const T*)dy, (float*)g_workspace, rows, (uint32_t)x_bytes, (uint32_t)dy_bytes);
+                               (const T*)x, (const T*)dy, (float*)workspace, rows, (uint32_t)x_bytes, (uint32_t)dy_bytes);
                     const long long n4 = (long long)(n / 4);
                     long long blocks = (n4 + 255) / 256;
                     if (blocks > 2048) blocks = 2048;
-                    hipLaunchKernelGGL(wgrad_slab_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (const float*)g_workspace, dw, n4, (int)splits);
+                    hipLaunchKernelGGL(wgrad_slab_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (const float*)workspace, dw, n4, (int)splits);
                 } else {
                     EVE_LAUNCH(EVE_HNAME(T, "wgrad_wg8_kernel<", ", false>"), (wgrad_wg8_kernel<T, false>), dim3(tk * tc * splits), dim3(512), (size_t)128 * 1024, s, p,
                                (const T*)x, (const T*)dy, dw, rows, (uint32_t)x_bytes, (uint32_t)dy_bytes);
@@ -985,8 +969,7 @@ namespace eve {
 // 3x3 / stride 2 / pad 1 forward of the trunk's down-sampling blocks on conv3x3s2_wg8_kernel (conv_wg8s2.h).  true: launched.
 template <typename HT>
 static bool launch_s2_fwd_wg8(const eve_conv_desc* d, const void* x, const void* w, const float* bias, int epi_act, void* y, hipStream_t s) {
-    static int on = -1, min_tiles = -1;
-    if (on < 0) { const char* e = getenv("EVE_CONV_WG8"); on = e ? atoi(e) : 1; const char* f = getenv("EVE_CONV_WG8_S2_MIN_TILES"); min_tiles = f ? atoi(f) : 48; }
+    const int on = g_cfg.conv_wg8, min_tiles = g_cfg.conv_wg8_s2_min_tiles;
     const int W = d->OW;
     if (!on || d->KH != 3 || d->KW != 3 || d->stride != 2 || d->pad != 1 || d->OH != W || d->IH != 2 * W || d->IW != 2 * W ||
         !(W == 16 || W == 8 || W == 4) || d->Cin % 64 || (epi_act & ~0xff) ||
@@ -1067,24 +1050,24 @@ __global__ __launch_bounds__(256) void s2_dgrad_pack_kernel(const H* __restrict_
 
 // true: launched.  dy [N][OW][OW][Cout] -> dx [N][2 OW][2 OW][Cdx]
 template <typename HT>
-static bool launch_s2_dgrad_wg8(const eve_conv_desc* d, const void* dy, const void* w_ihwo, void* dx, hipStream_t s) {
-    static int on = -1, min_tiles = -1;
+static bool launch_s2_dgrad_wg8(const eve_conv_desc* d, const void* dy, const void* w_ihwo, void* dx, void* workspace,
+                                unsigned long long workspace_bytes, hipStream_t s) {
     // (its own tile floor: against four per-tap launches the eight-wave pair is ahead from ~48 workgroups on -- B = 8 clips per
     //  GPU: layer 3.0 0.070 -> 0.049 ms with 120 tiles, layer 4.0 0.090 -> 0.070 with 60 -- where the 3x3 convolution wants 224)
-    if (on < 0) { const char* e = getenv("EVE_CONV_WG8"); on = e ? atoi(e) : 1; const char* f = getenv("EVE_CONV_WG8_S2_MIN_TILES"); min_tiles = f ? atoi(f) : 48; }
+    const int on = g_cfg.conv_wg8, min_tiles = g_cfg.conv_wg8_s2_min_tiles;
     const int W = d->OW, Cdx = d->Cin, Co = d->Cout;
     if (!on || d->KH != 3 || d->KW != 3 || d->stride != 2 || d->pad != 1 || d->OH != W || d->IH != 2 * W || d->IW != 2 * W ||
-        !(W == 16 || W == 8 || W == 4) || Co % 64 || !g_workspace)
+        !(W == 16 || W == 8 || W == 4) || Co % 64 || !workspace || ((uintptr_t)workspace & 255))
         return false;
     const int cout_t = W == 16 ? 128 : 256;
     if ((2 * Cdx) % cout_t) return false;
-    const unsigned long long wbytes = (unsigned long long)2 * Cdx * 6 * Co * 2, half = (g_workspace_bytes / 2) & ~255ull;
+    const unsigned long long wbytes = (unsigned long long)2 * Cdx * 6 * Co * 2;
     const unsigned long long xb = (unsigned long long)d->N * W * W * Co * 2, ob = (unsigned long long)d->N * 4 * W * W * Cdx * 2;
-    if (wbytes > g_workspace_bytes - half || xb >= (1ull << 31) || ob >= (1ull << 31) || wbytes >= (1ull << 31)) return false;
+    if (wbytes > workspace_bytes || xb >= (1ull << 31) || ob >= (1ull << 31) || wbytes >= (1ull << 31)) return false;
     const int ti = W == 16 ? 2 : (W == 8 ? 4 : 16);
     const uint32_t tiles = (uint32_t)((d->N + ti - 1) / ti) * (uint32_t)(2 * Cdx / cout_t);
     if ((int)tiles < min_tiles) return false;
-    HT* w0 = (HT*)((char*)g_workspace + half);
+    HT* w0 = (HT*)workspace;
     HT* w1 = w0 + (size_t)2 * Cdx * 2 * Co;
     const long long nvec = (long long)2 * Cdx * 6 * (Co / 8);
     hipLaunchKernelGGL(s2_dgrad_pack_kernel<HT>, dim3((unsigned)((nvec + 255) / 256 > 1024 ? 1024 : (nvec + 255) / 256)), dim3(256), 0, s,
@@ -1113,7 +1096,7 @@ static bool launch_s2_dgrad_wg8(const eve_conv_desc* d, const void* dy, const vo
 }  // namespace eve
 
 extern "C" int eve_conv2d_dgrad(const eve_conv_desc* d, const void* dy, const void* w_ihwo, void* dx,
-                                eve_stream_t stream) {
+                                void* workspace, unsigned long long workspace_bytes, eve_stream_t stream) {
     const int vec = (d && d->dtype != EVE_DT_F32) ? 8 : 4;
     if (int e = check_desc(d, vec)) return e;
     if (d->Cout % vec) return set_error_msg("conv2d_dgrad: Cout must be a multiple of the 16-byte vector");
@@ -1121,8 +1104,8 @@ extern "C" int eve_conv2d_dgrad(const eve_conv_desc* d, const void* dy, const vo
     GatherParams p = dgrad_params(d);
     hipStream_t s = (hipStream_t)stream;
     // stride-2 3x3 layers: two eight-wave launches over the dy halo tile instead of four per-tap parity-class launches
-    if (d->dtype == EVE_DT_BF16 && launch_s2_dgrad_wg8<bf16_t>(d, dy, w_ihwo, dx, s)) { EVE_CHECK_LAUNCH(); return 0; }
-    if (d->dtype == EVE_DT_F16 && launch_s2_dgrad_wg8<f16_t>(d, dy, w_ihwo, dx, s)) { EVE_CHECK_LAUNCH(); return 0; }
+    if (d->dtype == EVE_DT_BF16 && launch_s2_dgrad_wg8<bf16_t>(d, dy, w_ihwo, dx, workspace, workspace_bytes, s)) { EVE_CHECK_LAUNCH(); return 0; }
+    if (d->dtype == EVE_DT_F16 && launch_s2_dgrad_wg8<f16_t>(d, dy, w_ihwo, dx, workspace, workspace_bytes, s)) { EVE_CHECK_LAUNCH(); return 0; }
     if (d->dtype == EVE_DT_BF16) launch_igemm<bf16_t>(p, dy, w_ihwo, nullptr, nullptr, 0, 0, dx, s);
     else if (d->dtype == EVE_DT_F16) launch_igemm<f16_t>(p, dy, w_ihwo, nullptr, nullptr, 0, 0, dx, s);
     else                         launch_igemm<float>(p, dy, w_ihwo, nullptr, nullptr, 0, 0, dx, s);
@@ -1149,15 +1132,15 @@ extern "C" int eve_conv2d_dgrad_acc(const eve_conv_desc* d, const void* dy, cons
 
 extern "C" int eve_conv2d_wgrad(const eve_conv_desc* d, const void* x, const void* dy,
                                 const float* in_scale_shift, int pro_act, float* dw_ohwi,
-                                eve_stream_t stream) {
+                                void* workspace, unsigned long long workspace_bytes, eve_stream_t stream) {
     const int vec = (d && d->dtype != EVE_DT_F32) ? 8 : 4;
     if (int e = check_desc(d, vec)) return e;
     if (d->Cout % vec) return set_error_msg("conv2d_wgrad: Cout must be a multiple of the 16-byte vector");
     if (!x || !dy || !dw_ohwi) return set_error_msg("conv2d_wgrad: null pointer");
     GatherParams p = fwd_params(d);
     hipStream_t s = (hipStream_t)stream;
-    if (d->dtype == EVE_DT_BF16) launch_wgrad<bf16_t>(p, x, dy, in_scale_shift, pro_act, dw_ohwi, s);
-    else if (d->dtype == EVE_DT_F16) launch_wgrad<f16_t>(p, x, dy, in_scale_shift, pro_act, dw_ohwi, s);
+    if (d->dtype == EVE_DT_BF16) launch_wgrad<bf16_t>(p, x, dy, in_scale_shift, pro_act, dw_ohwi, s, nullptr, workspace, workspace_bytes);
+    else if (d->dtype == EVE_DT_F16) launch_wgrad<f16_t>(p, x, dy, in_scale_shift, pro_act, dw_ohwi, s, nullptr, workspace, workspace_bytes);
     else                         launch_wgrad<float>(p, x, dy, in_scale_shift, pro_act, dw_ohwi, s);
     EVE_CHECK_LAUNCH();
     return 0;
@@ -1213,7 +1196,7 @@ extern "C" int eve_bias_grad(int dtype, long long M, int C, const void* dy, floa
    sums ride on the weight-gradient MFMAs); otherwise the weight gradient followed by the column-sum kernel.
    dw and db are accumulated into. */
 extern "C" int eve_conv2d_wgrad_bias(const eve_conv_desc* d, const void* x, const void* dy, float* dw_ohwi, float* db,
-                                     eve_stream_t stream) {
+                                     void* workspace, unsigned long long workspace_bytes, eve_stream_t stream) {
     const int vec = (d && d->dtype != EVE_DT_F32) ? 8 : 4;
     if (int e = check_desc(d, vec)) return e;
     if (d->Cout % vec || d->Cout / vec > 256) return set_error_msg("conv2d_wgrad_bias: bad Cout");
@@ -1221,8 +1204,8 @@ extern "C" int eve_conv2d_wgrad_bias(const eve_conv_desc* d, const void* x, cons
     GatherParams p = fwd_params(d);
     hipStream_t s = (hipStream_t)stream;
     int fused = 0;
-    if (d->dtype == EVE_DT_BF16) fused = launch_wgrad<bf16_t>(p, x, dy, nullptr, 0, dw_ohwi, s, db);
-    else if (d->dtype == EVE_DT_F16) fused = launch_wgrad<f16_t>(p, x, dy, nullptr, 0, dw_ohwi, s, db);
+    if (d->dtype == EVE_DT_BF16) fused = launch_wgrad<bf16_t>(p, x, dy, nullptr, 0, dw_ohwi, s, db, workspace, workspace_bytes);
+    else if (d->dtype == EVE_DT_F16) fused = launch_wgrad<f16_t>(p, x, dy, nullptr, 0, dw_ohwi, s, db, workspace, workspace_bytes);
     else                         launch_wgrad<float>(p, x, dy, nullptr, 0, dw_ohwi, s);
     if (!fused) launch_bias_grad(d->dtype, (long long)p.M, d->Cout, dy, db, s);
     EVE_CHECK_LAUNCH();

@@ -575,8 +575,7 @@ extern "C" int eve_instnorm_stats(int dtype, int N, int HW, int C, const void* x
     if (!x || !mean_rstd) return set_error_msg("instnorm_stats: null pointer");
     hipStream_t s = (hipStream_t)stream;
     // bf16 planes beyond ~64 KB per image: the second pass of the two-pass kernel would come from HBM again
-    static int one_pass = -1;
-    if (one_pass < 0) { const char* e = getenv("EVE_IN_STATS_ONE_PASS"); one_pass = (e && e[0] == '0') ? 0 : 1; }
+    const int one_pass = g_cfg.in_stats_one_pass;
     if (dtype == EVE_DT_BF16 && one_pass && (long long)HW * C * 2 >= 65536)
         EVE_LAUNCH("in_stats1_kernel<eve::bf16_t>", in_stats1_kernel<bf16_t>, dim3(N), dim3(256), 0, s, (const bf16_t*)x, mean_rstd, HW, C, eps);
     else if (dtype == EVE_DT_F16 && one_pass && (long long)HW * C * 2 >= 65536)

@@ -228,19 +228,274 @@ __global__ __launch_bounds__(1024) void in_bwd_fused_kernel(const T* __restrict_
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Round 4: the ResNet trunk's instances (no affine; ReLU or identity; planes that fill their workgroup exactly) as kernels
+// whose every optional operand is a TEMPLATE flag.  The generic kernels above decide per vector, at run time, whether there
+// is a residual / a second gradient summand / a mask / a dres: hipcc turns each of those into a branch around a load, and a
+// load under a branch is followed by `s_waitcnt vmcnt(0)` -- which on gfx9 also waits for every store issued before it.  The
+// ISA of in_fwd_fused_kernel<bf16, 8, 1> had its eight residual loads and eight stores as one dependent chain (load, wait,
+// store, load, wait, ...: eight exposed HBM round trips per thread); in_bwd_fused_kernel<bf16, 8, 1> waited after EVERY one
+// of its 24-32 loads.  Here all loads of a plane part are issued back to back before the first use (8-32 x 16 bytes in flight
+// per thread), and the stores go out as one burst.  The arithmetic -- order of operations, rounding points, reduction tree --
+// is the generic kernels', so results are bit-identical (tests/test_gpu_kernels.py compares both against the ATen
+// restatement and against each other).
+// ---------------------------------------------------------------------------------------------------------------------
+// (register budget: 128 per lane = two 512-thread workgroups, or one 1 024-thread workgroup, per CU.  What has to stay live is the PACKED data -- 8 x 4 dwords
+//  per tensor -- so every phase re-unpacks from the packed registers; `opaque` keeps hipcc from carrying the unpacked floats of
+//  one phase into the next, which cost 198-252 registers or, bounded to 128, 270-560 bytes of scratch per lane.)
+__device__ __forceinline__ void opaque(uint4& q) { asm volatile("" : "+v"(q.x), "+v"(q.y), "+v"(q.z), "+v"(q.w)); }
+// ... and a fence on the running sums at the end of an iteration: volatile statements keep their order, so iteration j + 1's
+// opaque() -- and with it that iteration's unpacking -- cannot be scheduled before iteration j's arithmetic has produced the
+// sums (left alone, the scheduler unpacks all eight vectors first "to hide latency" and spills them)
+template <int VEC>
+__device__ __forceinline__ void fence_sums(float* s) {
+    if constexpr (VEC == 8) asm volatile("" : "+v"(s[0]), "+v"(s[1]), "+v"(s[2]), "+v"(s[3]), "+v"(s[4]), "+v"(s[5]), "+v"(s[6]), "+v"(s[7]));
+    else asm volatile("" : "+v"(s[0]), "+v"(s[1]), "+v"(s[2]), "+v"(s[3]));
+}
+
+// Addresses: one buffer resource per tensor and plane part (wave-uniform: four SGPRs), ONE 32-bit lane offset, and the
+// vector index j as the instruction's scalar offset j * step -- no address arithmetic per load or store at all.  (nthreads is
+// a multiple of cvecs, so vector i = tid + j * nthreads sits nthreads / cvecs pixels below vector tid.)
+typedef unsigned int v4u32_t __attribute__((ext_vector_type(4)));
+struct TrunkAddr {
+    size_t base;            // byte offset of this plane part inside the tensor (uniform)
+    uint32_t bytes;         // bytes from there to the end of the plane (buffer bound)
+    uint32_t off, step;     // this lane's byte offset; bytes between vectors j and j + 1 (uniform)
+};
+__device__ __forceinline__ TrunkAddr trunk_addr(const PlanePart pp, int HW, int cfull, int cvecs, int tid, int nthreads) {
+    const int lc = 31 - __builtin_clz(cvecs);
+    const uint32_t plane = (uint32_t)__builtin_amdgcn_readfirstlane((int)pp.plane), part = (uint32_t)__builtin_amdgcn_readfirstlane((int)pp.part);
+    TrunkAddr a;
+    a.base = ((size_t)plane * (size_t)HW * cfull + (size_t)part * cvecs) * 16;
+    a.bytes = ((uint32_t)HW * cfull - part * cvecs) * 16u;
+    a.off = ((uint32_t)(tid >> lc) * cfull + (uint32_t)(tid & (cvecs - 1))) * 16u;
+    a.step = (uint32_t)(nthreads >> lc) * cfull * 16u;
+    return a;
+}
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t trunk_rsrc(const void* tensor, size_t base, uint32_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)tensor + base), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ uint4 ldv(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff) {
+    return __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0));
+}
+// Stores take the WHOLE offset in the vector operand (one v_add per store) and an immediate 0 as the scalar offset.  With a
+// scalar-REGISTER offset hipcc (clang 22) emits no wait state between `buffer_store_dwordx4 v[58:61], .., s37 offen` and a
+// VALU write of v59 in the next instruction -- LLVM's hazard recogniser assumes that form has no store-data hazard -- and on
+// gfx950 it has one: dword 1 of ~12 lanes of dres went out with the new value, a few times per launch, run-to-run different
+// (tools/dbg_in.py; found by test_instnorm_fwd_bwd's bit-equality of the mask and y paths).  The immediate form is protected.
+__device__ __forceinline__ void stv(const uint4& q, __amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t uniform_off) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u32_t, q), r, (int)(voff + uniform_off), 0, 0);
+}
+
+template <typename T, int VPT, int ACT, bool RES, bool MASK>
+__global__ __launch_bounds__(1024) void in_fwd_trunk_kernel(const T* __restrict__ x, const T* __restrict__ res, T* __restrict__ y,
+                                                              float* __restrict__ mr, unsigned char* __restrict__ mask, int N, int HW,
+                                                              int C, int sl, float eps) {
+    constexpr int VEC = Elem<T>::VEC;
+    __shared__ float sh[1024 * VEC];
+    const int tid = threadIdx.x, nthreads = blockDim.x;
+    const PlanePart pp = plane_part(blockIdx.x, sl);
+    if (pp.plane >= (uint32_t)N) return;
+    const int Cl = C >> sl, cvecs = Cl / VEC, cfull = C / VEC;
+    const int cv = tid % cvecs;
+    const int c0 = pp.part * Cl;
+    const TrunkAddr ad = trunk_addr(pp, HW, cfull, cvecs, tid, nthreads);
+    const __amdgpu_buffer_rsrc_t rx = trunk_rsrc(x, ad.base, ad.bytes), rr_ = trunk_rsrc(RES ? (const void*)res : (const void*)x, ad.base, ad.bytes);
+    uint4 q[VPT], r[RES ? VPT : 1];
+#pragma unroll
+    for (int j = 0; j < VPT; ++j) q[j] = ldv(rx, ad.off, j * ad.step);
+    if (RES) {
+#pragma unroll
+        for (int j = 0; j < VPT; ++j) r[j] = ldv(rr_, ad.off, j * ad.step);
+    }
+    float s[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) s[e] = 0.f;
+#pragma unroll
+    for (int j = 0; j < VPT; ++j) {
+        float f[VEC];
+        Elem<T>::unpack(q[j], f);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) s[e] += f[e];
+        opaque(q[j]);
+    }
+    plane_allreduce<VEC>(s, sh, tid, nthreads, cvecs);
+    float mean[VEC];
+    const float inv = 1.f / (float)HW;
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) { mean[e] = s[e] * inv; s[e] = 0.f; }
+#pragma unroll
+    for (int j = 0; j < VPT; ++j) {
+        float f[VEC];
+        Elem<T>::unpack(q[j], f);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) { const float d = f[e] - mean[e]; s[e] += d * d; }
+        opaque(q[j]);
+    }
+    plane_allreduce<VEC>(s, sh, tid, nthreads, cvecs);
+    float a[VEC], b[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+        const float rstd = rsqrtf(s[e] * inv + eps);
+        a[e] = rstd; b[e] = -mean[e] * rstd;
+        if (tid < cvecs) {
+            const int c = c0 + cv * VEC + e;
+            mr[((size_t)pp.plane * C + c) * 2] = mean[e];
+            mr[((size_t)pp.plane * C + c) * 2 + 1] = rstd;
+        }
+    }
+    const __amdgpu_buffer_rsrc_t ry = trunk_rsrc(y, ad.base, ad.bytes);
+    // (the mask has one byte per 16-byte vector: same indices, 1/16 of the byte offsets)
+    const __amdgpu_buffer_rsrc_t rm = trunk_rsrc(MASK ? (const void*)mask : (const void*)y, ad.base >> 4, ad.bytes >> 4);
+#pragma unroll
+    for (int j = 0; j < VPT; ++j) {
+        float f[VEC], rr[VEC];
+        Elem<T>::unpack(q[j], f);
+        if (RES) Elem<T>::unpack(r[j], rr);
+        unsigned m = 0;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            float z = f[e] * a[e] + b[e];
+            if (RES) z += rr[e];
+            f[e] = ACT == EVE_ACT_RELU ? (z > 0.f ? z : 0.f) : z;
+            if (MASK) m |= (f[e] > 0.f ? 1u : 0u) << e;
+        }
+        stv(Elem<T>::pack(f), ry, ad.off, j * ad.step);
+        if (MASK) __builtin_amdgcn_raw_buffer_store_b8((unsigned char)m, rm, (int)(ad.off >> 4), (int)(j * (ad.step >> 4)), 0);
+    }
+}
+
+// MODE 0: dx from (dy, x), ReLU' recomputed from x (mid-block InstanceNorm: no affine, no residual)
+// MODE 1: dx and dres from (dy [+ dy2], sign mask, x)  (block-end InstanceNorm + residual + ReLU)
+// MODE 2: dx from (dy [+ dy2], x), no activation      (down-sample branch)
+template <typename T, int VPT, int MODE, bool DY2>
+__global__ __launch_bounds__(1024) void in_bwd_trunk_kernel(const T* __restrict__ dy, const T* __restrict__ dy2, const T* __restrict__ x,
+                                                              const float* __restrict__ mr, T* __restrict__ dx, T* __restrict__ dres,
+                                                              float* __restrict__ sums, const unsigned char* __restrict__ mask, int N,
+                                                              int HW, int C, int sl) {
+    constexpr int VEC = Elem<T>::VEC;
+    __shared__ float sh[1024 * VEC];
+    const int tid = threadIdx.x, nthreads = blockDim.x;
+    const PlanePart pp = plane_part(blockIdx.x, sl);
+    if (pp.plane >= (uint32_t)N) return;
+    const int Cl = C >> sl, cvecs = Cl / VEC, cfull = C / VEC;
+    const int cv = tid % cvecs;
+    const int c0 = pp.part * Cl;
+    const TrunkAddr ad = trunk_addr(pp, HW, cfull, cvecs, tid, nthreads);
+    const __amdgpu_buffer_rsrc_t rg = trunk_rsrc(dy, ad.base, ad.bytes), rx = trunk_rsrc(x, ad.base, ad.bytes);
+    const __amdgpu_buffer_rsrc_t rg2 = trunk_rsrc(DY2 ? (const void*)dy2 : (const void*)dy, ad.base, ad.bytes);
+    const __amdgpu_buffer_rsrc_t rm = trunk_rsrc(MODE == 1 ? (const void*)mask : (const void*)dy, ad.base >> 4, ad.bytes >> 4);
+    // ---- every load of this plane part, back to back ----
+    uint4 qg[VPT], qx[VPT], q2[DY2 ? VPT : 1];
+    unsigned mk[MODE == 1 ? VPT : 1];
+#pragma unroll
+    for (int j = 0; j < VPT; ++j) qg[j] = ldv(rg, ad.off, j * ad.step);
+    if (DY2) {
+#pragma unroll
+        for (int j = 0; j < VPT; ++j) q2[j] = ldv(rg2, ad.off, j * ad.step);
+    }
+    if (MODE == 1) {
+#pragma unroll
+        for (int j = 0; j < VPT; ++j) mk[j] = __builtin_amdgcn_raw_buffer_load_b8(rm, (int)(ad.off >> 4), (int)(j * (ad.step >> 4)), 0);
+    }
+#pragma unroll
+    for (int j = 0; j < VPT; ++j) qx[j] = ldv(rx, ad.off, j * ad.step);
+    // ---- pass 1 (needs no statistics): g = mask(dy + dy2), rounded to the storage format; dres goes out at once ----
+    if (DY2 || MODE == 1) {
+        const __amdgpu_buffer_rsrc_t rd = trunk_rsrc(MODE == 1 ? (const void*)dres : (const void*)dy, ad.base, ad.bytes);
+#pragma unroll
+        for (int j = 0; j < VPT; ++j) {
+            float g[VEC];
+            opaque(qg[j]);
+            Elem<T>::unpack(qg[j], g);
+            if (DY2) {
+                float g2[VEC];
+                Elem<T>::unpack(q2[j], g2);
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) g[e] += g2[e];
+            }
+            if (MODE == 1) {
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) g[e] = (mk[j] >> e) & 1u ? g[e] : 0.f;
+            }
+            qg[j] = Elem<T>::pack(g);
+            if (MODE == 1) stv(qg[j], rd, ad.off, j * ad.step);
+            opaque(qg[j]);
+        }
+    }
+    asm volatile("" ::: "memory");           // (the statistics' loads stay behind pass 1: 16 fewer live registers there)
+    float mean[VEC], rstd[VEC];
+    {
+        const float* m = mr + ((size_t)pp.plane * C + c0 + cv * VEC) * 2;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) { mean[e] = m[2 * e]; rstd[e] = m[2 * e + 1]; }
+    }
+    float s1[VEC], s2[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
+#pragma unroll
+    for (int j = 0; j < VPT; ++j) {
+        float g[VEC], xx[VEC];
+        opaque(qg[j]);
+        opaque(qx[j]);
+        Elem<T>::unpack(qg[j], g);
+        Elem<T>::unpack(qx[j], xx);
+        if (MODE == 0) {
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                const float z = (xx[e] - mean[e]) * rstd[e];
+                g[e] *= (z > 0.f ? z : 0.f) > 0.f ? 1.f : 0.f;
+            }
+            qg[j] = Elem<T>::pack(g);
+            Elem<T>::unpack(qg[j], g);
+        }
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            s1[e] += g[e];
+            s2[e] += g[e] * (xx[e] - mean[e]) * rstd[e];
+        }
+        fence_sums<VEC>(s1);
+        fence_sums<VEC>(s2);
+        opaque(qg[j]);
+        opaque(qx[j]);
+    }
+    plane_allreduce<VEC>(s1, sh, tid, nthreads, cvecs);
+    plane_allreduce<VEC>(s2, sh, tid, nthreads, cvecs);
+    if (sums && tid < cvecs) {
+        float* o = sums + ((size_t)pp.plane * C + c0 + cv * VEC) * 2;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) { o[2 * e] = s1[e]; o[2 * e + 1] = s2[e]; }
+    }
+    const float inv = 1.f / (float)HW;
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) { s1[e] *= inv; s2[e] *= inv; }
+    const __amdgpu_buffer_rsrc_t ro = trunk_rsrc(dx, ad.base, ad.bytes);
+#pragma unroll
+    for (int j = 0; j < VPT; ++j) {
+        float g[VEC], xx[VEC];
+        opaque(qg[j]);
+        opaque(qx[j]);
+        Elem<T>::unpack(qg[j], g);
+        Elem<T>::unpack(qx[j], xx);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) g[e] = rstd[e] * (g[e] - s1[e] - (xx[e] - mean[e]) * rstd[e] * s2[e]);
+        qg[j] = Elem<T>::pack(g);
+        opaque(qg[j]);
+        stv(qg[j], ro, ad.off, j * ad.step);
+    }
+}
+
 // threads per block and vectors per thread for a plane of nvec 16-byte vectors; false if it does not fit
 static bool fused_plan(int nvec, int cvecs, int& threads, int& vpt, int& sl, bool allow_split) {
     if (nvec <= 0 || cvecs <= 0 || cvecs > 128 || (cvecs & (cvecs - 1))) return false;
     // planes that would need a 1 024-thread workgroup go to two 512-thread ones, half the channels each
-    static int split_on = -1;
-    if (split_on < 0) { const char* e = getenv("EVE_IN_SPLIT"); split_on = (e && e[0] == '0') ? 0 : 1; }
+    const int split_on = g_cfg.in_split;
     sl = 0;
     // (bf16 only: the float32 instantiation is the parity mode and keeps its summation order)
     if (split_on && allow_split && nvec > 4096 && nvec <= 8192 && cvecs >= 2) { sl = 1; nvec /= 2; cvecs /= 2; }
     // as many vectors per thread as leaves >= `min_threads` threads: fewer, fatter workgroups per plane let several
     // planes share a CU, so one plane's reduction phase overlaps another's loads / stores
-    static int min_threads = -1;
-    if (min_threads < 0) { const char* e = getenv("EVE_IN_MIN_THREADS"); min_threads = e ? atoi(e) : 512; }
+    const int min_threads = g_cfg.in_min_threads;
     vpt = 1;
     while (vpt < 8 && ((nvec + vpt - 1) / vpt > 1024 || (nvec + 2 * vpt - 1) / (2 * vpt) >= min_threads)) vpt *= 2;
     if ((nvec + vpt - 1) / vpt > 1024) return false;
@@ -279,6 +534,28 @@ extern "C" int eve_instnorm_fwd_fused(int dtype, int N, int HW, int C, const voi
     if (!fused_plan(HW * (C / vec), C / vec, threads, vpt, sl, dtype != EVE_DT_F32)) return -1;
     const unsigned grid = sl ? (unsigned)((N + 7) / 8) * (8u << sl) : (unsigned)N;
     hipStream_t s = (hipStream_t)stream;
+    // the trunk's instances: no affine, identity / ReLU, the plane part fills its <= 512-thread workgroup exactly
+    if (g_cfg.in_trunk_kernels && !gamma && (long long)threads * vpt == ((long long)HW * (C / vec)) >> sl) {
+        const int combo = (act == EVE_ACT_RELU && !res && !sign_mask) ? 0 : (act == EVE_ACT_RELU && res && sign_mask) ? 1
+                        : (act == EVE_ACT_NONE && !res && !sign_mask) ? 2 : -1;
+#define FWD_TRUNK(T, TS, V)                                                                                                              \
+        do {                                                                                                                             \
+            if (combo == 0) EVE_LAUNCH("in_fwd_trunk_kernel<" TS ", " #V ", 1, false, false>", (in_fwd_trunk_kernel<T, V, EVE_ACT_RELU, false, false>), dim3(grid), dim3(threads), 0, s, (const T*)x, (const T*)res, (T*)y, mean_rstd, sign_mask, N, HW, C, sl, eps); \
+            else if (combo == 1) EVE_LAUNCH("in_fwd_trunk_kernel<" TS ", " #V ", 1, true, true>", (in_fwd_trunk_kernel<T, V, EVE_ACT_RELU, true, true>), dim3(grid), dim3(threads), 0, s, (const T*)x, (const T*)res, (T*)y, mean_rstd, sign_mask, N, HW, C, sl, eps); \
+            else EVE_LAUNCH("in_fwd_trunk_kernel<" TS ", " #V ", 0, false, false>", (in_fwd_trunk_kernel<T, V, EVE_ACT_NONE, false, false>), dim3(grid), dim3(threads), 0, s, (const T*)x, (const T*)res, (T*)y, mean_rstd, sign_mask, N, HW, C, sl, eps); \
+        } while (0)
+#define FWD_TRUNK_V(T, TS)                                                                                                               \
+        do { switch (vpt) { case 1: FWD_TRUNK(T, TS, 1); break; case 2: FWD_TRUNK(T, TS, 2); break; case 4: FWD_TRUNK(T, TS, 4); break; default: FWD_TRUNK(T, TS, 8); break; } } while (0)
+        if (combo >= 0) {
+            if (dtype == EVE_DT_BF16) FWD_TRUNK_V(bf16_t, "eve::bf16_t");
+            else if (dtype == EVE_DT_F16) FWD_TRUNK_V(f16_t, "eve::f16_t");
+            else FWD_TRUNK_V(float, "float");
+            EVE_CHECK_LAUNCH();
+            return 0;
+        }
+#undef FWD_TRUNK_V
+#undef FWD_TRUNK
+    }
     if (dtype == EVE_DT_BF16) {
         LAUNCH_VPT(in_fwd_fused_kernel, bf16_t, "eve::bf16_t", (const bf16_t*)x, gamma, beta, (const bf16_t*)res, act, (bf16_t*)y,
                    mean_rstd, sign_mask, N, HW, C, sl, eps)
@@ -304,6 +581,32 @@ extern "C" int eve_instnorm_bwd_fused(int dtype, int N, int HW, int C, const voi
     if (!fused_plan(HW * (C / vec), C / vec, threads, vpt, sl, dtype != EVE_DT_F32)) return -1;
     const unsigned grid = sl ? (unsigned)((N + 7) / 8) * (8u << sl) : (unsigned)N;
     hipStream_t s = (hipStream_t)stream;
+    if (g_cfg.in_trunk_kernels && !gamma && (long long)threads * vpt == ((long long)HW * (C / vec)) >> sl) {
+        // 0: mid-block (ReLU' from x)   1 / 2: block end (mask, dres) without / with a second summand   3: down-sample branch
+        const int combo = (act == EVE_ACT_RELU && !y && !sign_mask && !dres && !dy2) ? 0
+                        : (act == EVE_ACT_RELU && sign_mask && dres) ? (dy2 ? 2 : 1)
+                        : (act == EVE_ACT_NONE && !dres && !dy2) ? 3 : -1;
+#define BWD_TRUNK_ARGS(T) (const T*)dy, (const T*)dy2, (const T*)x, mean_rstd, (T*)dx, (T*)dres, sums, sign_mask, N, HW, C, sl
+#define BWD_TRUNK(T, TS, V)                                                                                                              \
+        do {                                                                                                                             \
+            if (combo == 0) EVE_LAUNCH("in_bwd_trunk_kernel<" TS ", " #V ", 0, false>", (in_bwd_trunk_kernel<T, V, 0, false>), dim3(grid), dim3(threads), 0, s, BWD_TRUNK_ARGS(T)); \
+            else if (combo == 1) EVE_LAUNCH("in_bwd_trunk_kernel<" TS ", " #V ", 1, false>", (in_bwd_trunk_kernel<T, V, 1, false>), dim3(grid), dim3(threads), 0, s, BWD_TRUNK_ARGS(T)); \
+            else if (combo == 2) EVE_LAUNCH("in_bwd_trunk_kernel<" TS ", " #V ", 1, true>", (in_bwd_trunk_kernel<T, V, 1, true>), dim3(grid), dim3(threads), 0, s, BWD_TRUNK_ARGS(T)); \
+            else EVE_LAUNCH("in_bwd_trunk_kernel<" TS ", " #V ", 2, false>", (in_bwd_trunk_kernel<T, V, 2, false>), dim3(grid), dim3(threads), 0, s, BWD_TRUNK_ARGS(T)); \
+        } while (0)
+#define BWD_TRUNK_V(T, TS)                                                                                                               \
+        do { switch (vpt) { case 1: BWD_TRUNK(T, TS, 1); break; case 2: BWD_TRUNK(T, TS, 2); break; case 4: BWD_TRUNK(T, TS, 4); break; default: BWD_TRUNK(T, TS, 8); break; } } while (0)
+        if (combo >= 0) {
+            if (dtype == EVE_DT_BF16) BWD_TRUNK_V(bf16_t, "eve::bf16_t");
+            else if (dtype == EVE_DT_F16) BWD_TRUNK_V(f16_t, "eve::f16_t");
+            else BWD_TRUNK_V(float, "float");
+            EVE_CHECK_LAUNCH();
+            return 0;
+        }
+#undef BWD_TRUNK_V
+#undef BWD_TRUNK
+#undef BWD_TRUNK_ARGS
+    }
     if (dtype == EVE_DT_BF16) {
         LAUNCH_VPT(in_bwd_fused_kernel, bf16_t, "eve::bf16_t", (const bf16_t*)dy, (const bf16_t*)dy2, (const bf16_t*)y, (const bf16_t*)x, mean_rstd, gamma,
                    act, (bf16_t*)dx, (bf16_t*)dres, sums, sign_mask, N, HW, C, sl)

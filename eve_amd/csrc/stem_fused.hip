@@ -550,8 +550,7 @@ extern "C" int eve_stem_fwd_fused(int dtype, int N, int IH, int IW, const void* 
         attr_set = true;
     }
     // two waves per image while that still fits the 256 x 8 wave slots (B <= 16 clips per GPU): see the kernel
-    static int split = -1;
-    if (split < 0) { const char* e = getenv("EVE_STEM_SPLIT"); split = (e && e[0] == '0') ? 0 : 1; }
+    const int split = g_cfg.stem_split;
     const int halves = (split && 2 * N <= 256 * SF_WAVES && (IH & 7) == 0) ? 2 : 1;
     unsigned blocks = N < 256 ? (unsigned)N : 256u;              // images are dealt round-robin over the workgroups
     EVE_DISPATCH_H16(dtype, EVE_LAUNCH(EVE_HNAME(H, "stem_fwd_fused_kernel<", ">"), stem_fwd_fused_kernel<H>, dim3(blocks), dim3(64 * SF_WAVES), lds,
@@ -576,8 +575,7 @@ extern "C" int eve_stem_bwd_dx(int dtype, int N, int IH, int IW, const void* x_p
         attr_set = true;
     }
     // two work items per image while that still fits the 256 x 8 wave slots (B <= 16 clips per GPU): see the kernel
-    static int split = -1;
-    if (split < 0) { const char* e = getenv("EVE_STEM_SPLIT"); split = (e && e[0] == '0') ? 0 : 1; }
+    const int split = g_cfg.stem_split;
     const int halves = (split && 2 * N <= 256 * SF_WAVES && (IH & 7) == 0) ? 2 : 1;
     unsigned blocks = N * halves < 256 ? (unsigned)(N * halves) : 256u;
     EVE_DISPATCH_H16(dtype, EVE_LAUNCH(EVE_HNAME(H, "stem_bwd_dx_kernel<", ">"), stem_bwd_dx_kernel<H>, dim3(blocks), dim3(64 * SF_WAVES), lds,

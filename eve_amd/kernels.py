@@ -50,19 +50,53 @@ class HipKernels(object):
     def __init__(self):
         self.lib = _lib.load()
         self.prof = None          # list of (tag, flops, start_event, end_event) while profiling
-        self._workspace = None
+        self._workspaces = {}     # device -> uint8 scratch tensor, allocated once per device and never replaced
 
-    def ensure_workspace(self, device, nbytes=None):
-        """Device scratch for the library (eve_set_workspace): the split-K partial filters of the weight-gradient kernels
-        (7 splits x 512 x 4608 floats = 66 MB for ResNet layer 4).  Allocated once by torch (the library never allocates),
-        before any hipGraph capture; without it the kernels fall back to float atomics."""
-        import os
-        if nbytes is None:
-            nbytes = int(os.environ.get('EVE_AMD_WORKSPACE_MB', '128')) << 20
-        if nbytes <= 0 or (self._workspace is not None and self._workspace.numel() >= nbytes and self._workspace.device == device):
-            return
-        self._workspace = torch.empty(nbytes, dtype=torch.uint8, device=device)
-        self._ck(self.lib.eve_set_workspace(self._p(self._workspace), nbytes))
+    WORKSPACE_BYTES = int(__import__('os').environ.get('EVE_AMD_WORKSPACE_MB', '128')) << 20
+
+    def workspace(self, device):
+        """(pointer, bytes) of this process's device scratch for the library calls that take one (include/eve_hip.h: the
+        split-K partial filters of the weight-gradient kernels -- 7 splits x 512 x 4608 floats = 66 MB for ResNet layer 4 --
+        and the re-packed filters of the stride-2 data gradient).  Passed PER CALL; allocated once per device by torch (the
+        library never allocates) and kept for the life of the process, so a pointer captured into a hipGraph stays valid.
+        Launches on one stream use it one after the other; a second stream needs its own HipKernels."""
+        if device.type != 'cuda' or self.WORKSPACE_BYTES <= 0:
+            return None, 0
+        key = device.index if device.index is not None else torch.cuda.current_device()
+        ws = self._workspaces.get(key)
+        if ws is None:
+            ws = self._workspaces[key] = torch.empty(self.WORKSPACE_BYTES, dtype=torch.uint8, device=device)
+        return ctypes.c_void_p(ws.data_ptr()), ws.numel()
+
+    # ------------------------------------------------------------------ kernel selection (eve_dispatch_config)
+    def dispatch_config(self):
+        c = _lib.DispatchConfig()
+        self._ck(self.lib.eve_get_dispatch_config(ctypes.byref(c)))
+        return c
+
+    def default_dispatch_config(self):
+        c = _lib.DispatchConfig()
+        self._ck(self.lib.eve_get_default_dispatch_config(ctypes.byref(c)))
+        return c
+
+    def dispatch_override(self, **fields):
+        """Context manager: force kernel-selection fields for the calls inside it (tests comparing two kernels on the same
+        inputs, tuning sweeps); the previous table is restored on exit."""
+        import contextlib
+
+        @contextlib.contextmanager
+        def ctx():
+            old = self.dispatch_config()
+            new = self.dispatch_config()
+            for n, v in fields.items():
+                assert hasattr(new, n), 'eve_dispatch_config has no field %r' % n
+                setattr(new, n, int(v))
+            self._ck(self.lib.eve_set_dispatch_config(ctypes.byref(new)))
+            try:
+                yield new
+            finally:
+                self._ck(self.lib.eve_set_dispatch_config(ctypes.byref(old)))
+        return ctx()
 
     # ------------------------------------------------------------------ per-launch timing (bench roofline)
     def start_profile(self):
@@ -175,17 +209,16 @@ class HipKernels(object):
         d = self._desc(dy.dtype, N, IH, IW, Cin, Cout, KH, KW, stride, pad)
         assert (d.OH, d.OW) == (OH, OW)
         co, kk = algo or (Cout, KH * KW * Cin)
-        if stride == 2 and dy.dtype in HALF_DTYPES:
-            self.ensure_workspace(dy.device)        # the stride-2 data gradient re-packs its filters into the workspace
+        # (the stride-2 data gradient re-packs its filters into the scratch; dgrad_acc takes none)
+        wsp, wsn = self.workspace(dy.device) if (stride == 2 and dy.dtype in HALF_DTYPES) else (None, 0)
         if accumulate_into is not None:
             dx = accumulate_into
             assert tuple(dx.shape) == (N, IH, IW, Cin) and dx.dtype == dy.dtype and dx.is_contiguous()
-            fn = self.lib.eve_conv2d_dgrad_acc
+            fn = lambda: self.lib.eve_conv2d_dgrad_acc(ctypes.byref(d), self._p(dy), self._p(w_ihwo), self._p(dx), self._stream())
         else:
             dx = torch.empty((N, IH, IW, Cin), dtype=dy.dtype, device=dy.device)
-            fn = self.lib.eve_conv2d_dgrad
-        self._timed('conv_dgrad', 2.0 * N * OH * OW * co * kk, lambda: self._ck(fn(
-            ctypes.byref(d), self._p(dy), self._p(w_ihwo), self._p(dx), self._stream())), (dy, w_ihwo, dx))
+            fn = lambda: self.lib.eve_conv2d_dgrad(ctypes.byref(d), self._p(dy), self._p(w_ihwo), self._p(dx), wsp, wsn, self._stream())
+        self._timed('conv_dgrad', 2.0 * N * OH * OW * co * kk, lambda: self._ck(fn()), (dy, w_ihwo, dx))
         return dx
 
     def conv2d_wgrad(self, x, dy, KH, KW, stride, pad, dw_ohwi, ss=None, pro_act=ACT_NONE, algo=None, db=None):
@@ -197,16 +230,15 @@ class HipKernels(object):
         d = self._desc(x.dtype, N, IH, IW, Cin, Cout, KH, KW, stride, pad)
         assert tuple(dy.shape) == (N, d.OH, d.OW, Cout) and dy.dtype == x.dtype
         co, kk = algo or (Cout, KH * KW * Cin)
-        if x.dtype in HALF_DTYPES:
-            self.ensure_workspace(x.device)             # (first call: an eager warm-up step, before any graph capture)
+        wsp, wsn = self.workspace(x.device) if x.dtype in HALF_DTYPES else (None, 0)
         if db is not None:
             assert ss is None and db.shape == (Cout,) and db.dtype == torch.float32 and db.is_contiguous()
             self._timed('conv_wgrad', 2.0 * N * d.OH * d.OW * co * kk, lambda: self._ck(self.lib.eve_conv2d_wgrad_bias(
-                ctypes.byref(d), self._p(x), self._p(dy), self._p(dw_ohwi), self._p(db), self._stream())), (x, dy, dw_ohwi))
+                ctypes.byref(d), self._p(x), self._p(dy), self._p(dw_ohwi), self._p(db), wsp, wsn, self._stream())), (x, dy, dw_ohwi))
             return dw_ohwi
         self._timed('conv_wgrad', 2.0 * N * d.OH * d.OW * co * kk, lambda: self._ck(self.lib.eve_conv2d_wgrad(
             ctypes.byref(d), self._p(x), self._p(dy), self._p(self._f32(ss, 'scale/shift')), pro_act,
-            self._p(dw_ohwi), self._stream())), (x, dy, dw_ohwi))
+            self._p(dw_ohwi), wsp, wsn, self._stream())), (x, dy, dw_ohwi))
         return dw_ohwi
 
     def stem_pack_input(self, src_nchw, out=None, dtype=torch.bfloat16):

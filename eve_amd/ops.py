@@ -370,49 +370,6 @@ def linear(x2d, weight, bias, pack, act=ACT_NONE):
     return y.view(M, y.shape[-1])
 
 
-# Weight gradients are off the backward's critical path (nothing downstream reads them before the optimizer), so the
-# trunk node can fork them onto a second stream (EVE_AMD_WGRAD_STREAM=1).  Measured on MI355X it LOSES 4 % (17.10 vs
-# 16.42 ms/step): the co-running kernels evict each other's workgroups from LDS/L2 instead of filling idle units, so
-# it is off by default; always off when a data-parallel hook must see the gradient on the main stream.
-_SIDE_STREAMS = {}
-
-
-def _side_stream(device):
-    if os.environ.get('EVE_AMD_WGRAD_STREAM', '0') != '1' or device.type != 'cuda':
-        return None
-    st = _SIDE_STREAMS.get(device)
-    if st is None:
-        st = _SIDE_STREAMS[device] = torch.cuda.Stream(device=device)
-    return st
-
-
-class _WgradLane:
-    """Fork/join helper: run(fn, *tensors) launches fn on the side stream after everything issued so far on the
-    main stream; the tensors stay referenced until join() so their memory cannot be recycled under the kernel."""
-
-    def __init__(self, device, enabled):
-        self.side = _side_stream(device) if enabled else None
-        self.keep = []
-        self.used = False
-
-    def run(self, fn, *tensors):
-        if self.side is None:
-            return fn()
-        self.side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(self.side):
-            out = fn()
-        self.keep.extend(tensors)
-        self.keep.append(out)
-        self.used = True
-        return out
-
-    def join(self):
-        if self.used:
-            torch.cuda.current_stream().wait_stream(self.side)
-        self.keep.clear()
-        self.used = False
-
-
 def _wgrad_into(k, x, dy, weight, pack, stride, pad, db=None):
     """Weight gradient of a conv: straight into the flat gradient buffer when the parameter lives there (returns
     None), else a fresh OIHW-shaped tensor for autograd.  `db` (float32 [Cout_padded], accumulated) also receives the
@@ -472,7 +429,7 @@ def _block_forward(k, x, packs, stride, eps):
     return y, (x, a, mr1, an, b, mr2, ymask if ymask is not None else y, d, mrd)
 
 
-def _block_backward(k, dy, dy2, saved, weights, packs, stride, need_w, lane):
+def _block_backward(k, dy, dy2, saved, weights, packs, stride, need_w):
     """Backward of _block_forward in dependency order.  The incoming gradient may arrive as two summands
     (dy + dy2: the previous fork) and the gradient of the block input is RETURNED as two summands (g, dx1) --
     residual branch and conv1 branch -- so the sum is folded into whichever kernel reads it next.
@@ -483,15 +440,15 @@ def _block_backward(k, dy, dy2, saved, weights, packs, stride, need_w, lane):
     hw = (x.shape[1], x.shape[2])
     # y = relu(IN(b) + identity): db and the residual-branch gradient g = dy * relu'(y)
     db, g = _in_bwd(k, dy, y, b, mr2, ACT_RELU, True, dy2=dy2)
-    dw2 = lane.run(lambda: _wgrad_into(k, an, db, w2, p2, 1, 1), an, db) if need_w[1] else None
+    dw2 = _wgrad_into(k, an, db, w2, p2, 1, 1) if need_w[1] else None
     dan = k.conv2d_dgrad(db, p2.ihwo, (an.shape[1], an.shape[2]), 1, 1, algo=p2.algo)
     da, _ = _in_bwd(k, dan, None, a, mr1, ACT_RELU, False)              # act' recomputed from a (no affine / residual)
-    dw1 = lane.run(lambda: _wgrad_into(k, x, da, w1, p1, stride, 1), x, da) if need_w[0] else None
+    dw1 = _wgrad_into(k, x, da, w1, p1, stride, 1) if need_w[0] else None
     dwd = None
     dx1 = k.conv2d_dgrad(da, p1.ihwo, hw, stride, 1, algo=p1.algo)
     if pd is not None:
         dd, _ = _in_bwd(k, g, None, d, mrd, ACT_NONE, False)
-        dwd = lane.run(lambda: _wgrad_into(k, x, dd, wd, pd, stride, 0), x, dd) if need_w[2] else None
+        dwd = _wgrad_into(k, x, dd, wd, pd, stride, 0) if need_w[2] else None
         # the 1x1 / stride-s branch reaches one pixel in s*s: added onto conv1's data gradient in that kernel's epilogue
         # (no zero-filled full-size tensor, and the next InstanceNorm backward reads one summand instead of two)
         dx1 = k.conv2d_dgrad(dd, pd.ihwo, hw, stride, 0, algo=pd.algo, accumulate_into=dx1)
@@ -542,15 +499,13 @@ class ResNetTrunkFn(torch.autograd.Function):
         wpos = len(weights)
         spos = len(saved)
         d_a, d_b = dy.contiguous(), None
-        hooked = any(getattr(w, '_eve_grad_ready', None) is not None for w in weights)
-        lane = _WgradLane(dy.device, enabled=not hooked)
         for packs, stride in reversed(blocks):
             nw = 3 if packs[2] is not None else 2
             wpos -= nw
             spos -= 9
             ws = tuple(weights[wpos:wpos + nw]) + ((None,) if nw == 2 else ())
             nd = tuple(need_w[wpos:wpos + nw]) + ((False,) if nw == 2 else ())
-            d_a, d_b, dw1, dw2, dwd = _block_backward(k, d_a, d_b, tuple(saved[spos:spos + 9]), ws, packs, stride, nd, lane)
+            d_a, d_b, dw1, dw2, dwd = _block_backward(k, d_a, d_b, tuple(saved[spos:spos + 9]), ws, packs, stride, nd)
             grads[wpos], grads[wpos + 1] = dw1, dw2
             if nw == 3:
                 grads[wpos + 2] = dwd
@@ -565,7 +520,6 @@ class ResNetTrunkFn(torch.autograd.Function):
                 grads[0] = dwp[:O, :, :7, :I].permute(0, 3, 1, 2)
         elif ctx.needs_input_grad[0]:
             dx = k.add(d_a, d_b) if d_b is not None else d_a
-        lane.join()
         return (dx, None, None, None, None) + tuple(grads)
 
 

@@ -7,7 +7,8 @@
  *   - raw DEVICE pointers (activations NHWC, element type selected by `dtype`),
  *   - explicit shapes,
  *   - the HIP stream to launch on (a hipStream_t passed as void*; NULL = the null stream).
- * No entry point allocates, synchronises the device, or keeps global state.  Every function
+ * No entry point allocates, synchronises the device, or keeps state between calls (the one process-wide
+ * object is the read-mostly kernel-selection table, eve_dispatch_config below).  Every function
  * returns 0 on success and a non-zero code on failure; eve_last_error() returns a thread-local
  * message for the last failure.  The Python side (eve_amd/_lib.py) raises RuntimeError from it.
  *
@@ -28,7 +29,7 @@
 extern "C" {
 #endif
 
-#define EVE_ABI_VERSION 5
+#define EVE_ABI_VERSION 6
 
 typedef void* eve_stream_t; /* hipStream_t */
 
@@ -47,13 +48,43 @@ int eve_abi_version(void);
  * profiler attribute a timed launch to the row of the same name in a rocprofv3 kernel summary.            */
 const char* eve_last_kernel(void);
 const char* eve_last_error(void);
-/* Caller-owned device scratch (16-byte aligned; NULL / 0 removes it).  The library never allocates: kernels that can use
- * scratch read it from here, on the stream they are launched on, and fall back to their scratch-free form when it is missing
- * or too small.  Users today: the split-K weight gradient of the 256..512-channel layers (FIRST half: per-split partial
- * filters with plain stores + a summing launch instead of 16 M float atomics) and the data gradient of the stride-2 3x3
- * layers (SECOND half: filters re-packed per call for conv3x3_wg8_kernel<.., NT>).  The halves may be in use on two streams
- * at once (weight gradients on a side stream); each half one stream at a time.                                          */
-int eve_set_workspace(void* device_ptr, unsigned long long bytes);
+/* Kernel selection (ABI v6).  Which kernel an entry point dispatches for a given shape is a pure function of the shape and
+ * of THIS structure.  It is filled ONCE, when the library is loaded: built-in defaults, overridden by the EVE_* environment
+ * variables named per field (tuning experiments; nothing on a call path reads the environment).  A test harness prints
+ * eve_get_dispatch_config() and asserts it equals eve_get_default_dispatch_config() before it makes a parity claim
+ * (tests/conftest.py), and forces a variant -- e.g. the four-wave convolution next to the eight-wave one -- with
+ * eve_set_dispatch_config(), never through the environment of a running process.                                        */
+typedef struct eve_dispatch_config {
+    int struct_bytes;              /* sizeof(eve_dispatch_config): ABI guard                                              */
+    int conv_impl_v1;              /* EVE_CONV_IMPL=v1      0   first-generation register-staged igemm / wgrad kernels     */
+    int conv_tile_big;             /* EVE_CONV_TILE=2       0   256 x 128 per-tap tiles                                    */
+    int conv_halo;                 /* EVE_CONV_HALO         1   halo-resident 3x3 kernels (conv_fast.h)                    */
+    int conv_ws64;                 /* EVE_CONV_WS64         1   conv3x3_ws64_kernel for 32 x 32 x 64 -> 64                 */
+    int conv_wg8;                  /* EVE_CONV_WG8          1   eight-wave kernels (0 off, 3: not for 16 x 16 x 128)       */
+    int conv_wg8_min_tiles;        /* EVE_CONV_WG8_MIN_TILES 224  fewer tiles: four-wave kernels                          */
+    int conv_wg8_s2_min_tiles;     /* EVE_CONV_WG8_S2_MIN_TILES 48  the same floor for the stride-2 forward / data grad.  */
+    int halo_persist;              /* EVE_HALO_PERSIST      1   persistent tile stream for <= 64 input channels            */
+    int wgrad_target_wgs;          /* EVE_WGRAD_TARGET_WGS  0   (0: 256 x resident workgroups per CU)                      */
+    int wgrad_min_rows;            /* EVE_WGRAD_MIN_ROWS    1536 shortest pixel range of a weight-gradient split          */
+    int wgrad_halo;                /* EVE_WGRAD_HALO        1   band-resident weight gradients (wgrad_halo.h)              */
+    int wgrad_wg8;                 /* EVE_WGRAD_WG8         1   256 x 256 eight-wave weight gradient (wgrad_wg8.h)         */
+    int wg64_th, wg64_nreg;        /* EVE_WG64_TH / _NREG   0 0 (0: largest band / region count that fits LDS)             */
+    int wg64_fixed;                /* EVE_WG64_FIXED        1   unrolled wgrad_halo64_kernel for 32-wide planes            */
+    int in_split;                  /* EVE_IN_SPLIT          1   64 Ki-element InstanceNorm planes as two channel halves    */
+    int in_min_threads;            /* EVE_IN_MIN_THREADS    512                                                            */
+    int in_stats_one_pass;         /* EVE_IN_STATS_ONE_PASS 1   shifted-moment statistics for planes beyond L2             */
+    int stem_split;                /* EVE_STEM_SPLIT        1   two waves per image in the fused stem at small batches     */
+    int in_trunk_kernels;          /* EVE_IN_TRUNK          1   branch-free InstanceNorm kernels for the ResNet trunk's cases */
+    long long wgrad_halo_min_m;    /* EVE_WGRAD_HALO_MIN_M  1<<20 pixels from which the band-resident weight gradient runs */
+} eve_dispatch_config;
+int eve_get_dispatch_config(eve_dispatch_config* out);           /* what the entry points use now                         */
+int eve_get_default_dispatch_config(eve_dispatch_config* out);   /* the built-in defaults (environment ignored)           */
+int eve_set_dispatch_config(const eve_dispatch_config* cfg);     /* explicit override (tests, tuning); struct_bytes checked */
+/* Device scratch is CALLER-OWNED and passed PER CALL (ABI v6; v5 kept one process-global pointer): the entry points that can
+ * use scratch take `workspace` (16-byte aligned device pointer, or NULL) and `workspace_bytes`, use it on the stream of that
+ * call only, and fall back to their scratch-free form when it is missing or too small.  Users: the split-K weight gradient of
+ * the 256..512-channel layers (per-split partial filters with plain stores + a summing launch instead of 16 M float atomics)
+ * and the data gradient of the stride-2 3x3 layers (filters re-packed per call for conv3x3_wg8_kernel<.., NT>).           */
 
 /* ------------------------------------------------------------------------------------------------
  * Convolution as implicit GEMM on MFMA.  Replaces every nn.Conv2d / nn.Linear forward on the path:
@@ -79,18 +110,19 @@ int eve_conv2d_fwd(const eve_conv_desc* d, const void* x, const void* w_ohwi, co
                    eve_stream_t stream);
 /* dx = conv_transpose(dy, w): gradient w.r.t. the conv INPUT.  w_ihwo is [Cin][KH][KW][Cout].    */
 int eve_conv2d_dgrad(const eve_conv_desc* d, const void* dy, const void* w_ihwo, void* dx,
-                     eve_stream_t stream);
+                     void* workspace, unsigned long long workspace_bytes, eve_stream_t stream);
 /* dx += the same data gradient (dx already holds the gradient of the block's other branch: autograd's add at
  * the residual fork of torchvision BasicBlock, fused into the epilogue).                              */
 int eve_conv2d_dgrad_acc(const eve_conv_desc* d, const void* dy, const void* w_ihwo, void* dx,
                      eve_stream_t stream);
 /* dw[Cout][KH][KW][Cin] (float, accumulated) += sum_m dy[m][co] * x'[m][(kh,kw,ci)]              */
 int eve_conv2d_wgrad(const eve_conv_desc* d, const void* x, const void* dy,
-                     const float* in_scale_shift, int pro_act, float* dw_ohwi, eve_stream_t stream);
+                     const float* in_scale_shift, int pro_act, float* dw_ohwi,
+                     void* workspace, unsigned long long workspace_bytes, eve_stream_t stream);
 /* ... together with db[Cout] (float, accumulated) += sum_m dy[m][co] in the same pass over dy: autograd of a biased
  * nn.Conv2d (refine_net.py's U-Net and conv-GRU convolutions all carry one).                                   */
 int eve_conv2d_wgrad_bias(const eve_conv_desc* d, const void* x, const void* dy, float* dw_ohwi, float* db,
-                          eve_stream_t stream);
+                          void* workspace, unsigned long long workspace_bytes, eve_stream_t stream);
 /* ResNet stem (torchvision ResNet.conv1: 7x7 / stride 2 / pad 3, 3 -> 64, no bias; eye_net.py:48-50), bf16:
  * eve_stem_pack_input writes x_padded [N][IH+6][IW+8][4] bf16 (channels 0..C-1, zero 4th channel and borders)
  * from the float NCHW patch; eve_stem7x7s2_fwd computes y [N][IH/2][IW/2][64] from it and the OHWI weights

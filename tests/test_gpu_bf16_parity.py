@@ -105,18 +105,42 @@ FORMATS = pytest.mark.parametrize('fmt', [torch.bfloat16, torch.float16], ids=['
 FP16_LOSS_SCALE = 1024.0
 
 
+# kernels the B = 32 x T = 30 batch dispatches and a small batch does not reach on its own (tile / pixel-count floors):
+# the third case forces them with the floors at zero and asserts, by symbol, that they ran
+FULL_BATCH_KERNELS = ('conv3x3_ws64_kernel<', 'conv3x3_wg8_kernel<%s, 4, 2, 16>', 'conv3x3_wg8_kernel<%s, 2, 4, 8>',
+                      'conv3x3_wg8_kernel<%s, 2, 4, 4>', 'conv3x3s2_wg8_kernel<%s, 4, 2, 16>', 'conv3x3s2_wg8_kernel<%s, 2, 4, 8>',
+                      'conv3x3s2_wg8_kernel<%s, 2, 4, 4>', 's2dgrad4>', 'wgrad_halo64_kernel<', 'wgrad_wg8_kernel<%s, true>')
+
+
 @FORMATS
-@pytest.mark.parametrize('B,T,seed,band_wgrad', [(2, 3, 0, False), (4, 30, 17, False), (2, 3, 0, True)],
-                         ids=['fixture-shape', 'configs1-slice', 'fixture-shape-band-resident-wgrad'])
-def test_eyenet_bf16_stages_teacher_forced_match_rounding_faithful_oracle(B, T, seed, band_wgrad, monkeypatch, fmt):
+@pytest.mark.parametrize('B,T,seed,full_dispatch', [(2, 3, 0, False), (4, 30, 17, False), (2, 3, 0, True), (4, 30, 17, True)],
+                         ids=['fixture-shape', 'configs1-slice', 'fixture-shape-full-batch-kernels', 'configs1-slice-full-batch-kernels'])
+def test_eyenet_bf16_stages_teacher_forced_match_rounding_faithful_oracle(B, T, seed, full_dispatch, fmt):
     """Stem, the eight residual blocks and the average pool of the bf16 trunk (BASELINE configs[1]'s kernels: fused stem
     forward / backward-by-recomputation + packed-patch weight gradient, halo and LDS-DMA convolutions, parity-class
     strided dgrad, transposing-read weight gradients, register-resident InstanceNorm forward / backward), each fed the
-    oracle's bf16-exact input and output gradient.  The second case is a B=4 slice of the benchmarked B=32 x T=30 batch;
-    the third sends layer 1's weight gradients through wgrad_halo64_kernel, which the full-size batch uses (it is selected
-    from 1 M pixels up: EVE_WGRAD_HALO_MIN_M lowers that, read per call)."""
-    if band_wgrad:
-        monkeypatch.setenv('EVE_WGRAD_HALO_MIN_M', '0')
+    oracle's bf16-exact input and output gradient.  The second case is a B=4 slice of the benchmarked B=32 x T=30 batch.
+    The `full-batch-kernels` cases put the kernels that only the full-size batch selects NEXT TO THE ORACLE: the eight-wave
+    convolutions (conv3x3_wg8_kernel stride 1, its NT = 2 / 4 strided data gradients, conv3x3s2_wg8_kernel), the band-resident
+    layer-1 weight gradient and the slab-partial wgrad_wg8_kernel with more than one split -- selected here by lowering the
+    tile / pixel floors of eve_dispatch_config, and asserted by kernel symbol."""
+    from eve_amd.kernels import default_kernels
+    if full_dispatch:
+        with default_kernels().dispatch_override(wgrad_halo_min_m=0, conv_wg8_min_tiles=0, conv_wg8_s2_min_tiles=0, wgrad_min_rows=256):
+            default_kernels().start_profile()
+            try:
+                _eyenet_stages_teacher_forced(B, T, seed, fmt)
+            finally:
+                syms = set(default_kernels().stop_profile()['_by_kernel'])
+        tn = 'eve::bf16_t' if fmt == torch.bfloat16 else 'eve::f16_t'
+        for want in FULL_BATCH_KERNELS:
+            w = want % tn if '%s' in want else want
+            assert any(w in s for s in syms), 'kernel %s did not run; ran: %s' % (w, sorted(syms))
+    else:
+        _eyenet_stages_teacher_forced(B, T, seed, fmt)
+
+
+def _eyenet_stages_teacher_forced(B, T, seed, fmt):
     from eve_amd import ops
     from eve_amd.kernels import default_kernels
     from oracle.eye_net import EyeNet as OracleEyeNet

@@ -667,7 +667,7 @@ WGRAD_HALO_CASES = [
 
 
 @pytest.mark.parametrize('case', WGRAD_HALO_CASES, ids=lambda c: 'N%d_%dx%d_c%d-%d' % c[:5] + ('_k%d' % c[5] if len(c) > 5 else ''))
-def test_band_resident_weight_gradient(hip, ref, monkeypatch, case):
+def test_band_resident_weight_gradient(hip, ref, case):
     """wgrad_halo_kernel (few channels, large planes) against the ATen restatement and against wgrad_tr_kernel on the
     same inputs, with and without the fused bias gradient, accumulating onto existing values."""
     N, H, W, Cin, Cout = case[:5]
@@ -679,12 +679,12 @@ def test_band_resident_weight_gradient(hip, ref, monkeypatch, case):
     want_db = ref.bias_grad(dy, torch.zeros(Cout))
     dw0, db0 = rnd((Cout, K, K, Cin), torch.float32, 33), rnd((Cout,), torch.float32, 34)
     res = {}
-    for mode, min_m in (('halo', '0'), ('tr', str(1 << 40))):
-        monkeypatch.setenv('EVE_WGRAD_HALO_MIN_M', min_m)
-        plain = hip.conv2d_wgrad(dev(x), dev(dy), K, K, 1, pad, dev(dw0).clone())
-        assert hip.lib.eve_last_kernel().decode().startswith('wgrad_halo' if mode == 'halo' else 'wgrad_tr_kernel')
-        fused_dw, fused_db = dev(dw0).clone(), dev(db0).clone()
-        hip.conv2d_wgrad(dev(x), dev(dy), K, K, 1, pad, fused_dw, db=fused_db)
+    for mode, min_m in (('halo', 0), ('tr', 1 << 40)):
+        with hip.dispatch_override(wgrad_halo_min_m=min_m):
+            plain = hip.conv2d_wgrad(dev(x), dev(dy), K, K, 1, pad, dev(dw0).clone())
+            assert hip.lib.eve_last_kernel().decode().startswith('wgrad_halo' if mode == 'halo' else 'wgrad_tr_kernel')
+            fused_dw, fused_db = dev(dw0).clone(), dev(db0).clone()
+            hip.conv2d_wgrad(dev(x), dev(dy), K, K, 1, pad, fused_dw, db=fused_db)
         res[mode] = (plain.cpu(), fused_dw.cpu(), fused_db.cpu())
         close(plain, want_dw + dw0, torch.bfloat16, 'wgrad ' + mode)
         close(fused_dw, want_dw + dw0, torch.bfloat16, 'wgrad+bias ' + mode)

@@ -39,7 +39,31 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), name
     lib.eve_abi_version.restype = ctypes.c_int
-    assert lib.eve_abi_version() == _lib.ABI_VERSION == 5
+    assert lib.eve_abi_version() == _lib.ABI_VERSION == 6
+    # kernel selection is resolved once at load (include/eve_hip.h eve_dispatch_config): with a clean environment the loaded
+    # table IS the default table, the Python mirror of the struct has the library's size, and a wrong-sized struct is refused
+    for n in ('eve_get_dispatch_config', 'eve_get_default_dispatch_config', 'eve_set_dispatch_config'):
+        getattr(lib, n).restype = ctypes.c_int
+    cur, dflt = _lib.DispatchConfig(), _lib.DispatchConfig()
+    assert lib.eve_get_dispatch_config(ctypes.byref(cur)) == 0 and lib.eve_get_default_dispatch_config(ctypes.byref(dflt)) == 0
+    assert dflt.struct_bytes == ctypes.sizeof(_lib.DispatchConfig)
+    if not any(k.startswith('EVE_') and not k.startswith('EVE_AMD_') and k not in ('EVE_HIP_LIB', 'EVE_CASES') for k in os.environ):
+        assert cur.as_dict() == dflt.as_dict()
+    assert dflt.as_dict()['conv_wg8_min_tiles'] == 224 and dflt.as_dict()['wgrad_halo_min_m'] == 1 << 20
+    bad = _lib.DispatchConfig()
+    bad.struct_bytes = 8
+    assert lib.eve_set_dispatch_config(ctypes.byref(bad)) != 0
+
+
+def test_no_kernel_selection_reads_the_environment_on_a_call_path():
+    """getenv appears in exactly one place of the library: the load-time initialiser of the dispatch table (api.hip)."""
+    import glob
+    hits = []
+    for path in glob.glob(os.path.join(REPO, 'eve_amd', 'csrc', '*')):
+        for i, line in enumerate(open(path), 1):
+            if 'getenv' in line and not line.lstrip().startswith('//'):
+                hits.append((os.path.basename(path), i))
+    assert hits and all(f == 'api.hip' for f, _ in hits), hits
 
 
 def test_missing_library_fails_loudly(tmp_path, monkeypatch):

@@ -24,6 +24,12 @@ def timeit(fn, reps=10):
 def main():
     N = int(sys.argv[1]) if len(sys.argv) > 1 else 1920
     k = HipKernels()
+    over = dict(a.split('=') for a in sys.argv[2:])          # e.g. in_split=0 in_trunk_kernels=0
+    with k.dispatch_override(**{n: int(v) for n, v in over.items()}):
+        run(k, N)
+
+
+def run(k, N):
     dt = torch.bfloat16
     for name, H, C in (('layer1', 32, 64), ('layer2', 16, 128), ('layer3', 8, 256), ('layer4', 4, 512)):
         x = torch.randn((N, H, H, C), device='cuda').to(dt)
@@ -38,7 +44,7 @@ def main():
         t = timeit(lambda: k.instnorm_bwd_fused(dy, None, x, mr, None, 1, False))
         print('%-7s bwd  mid-block (dy,x)   %.3f ms  %.2f TB/s' % (name, t, 3 * mb / t / 1e3))
         t = timeit(lambda: k.instnorm_bwd_fused(dy, None, x, mr, None, 1, True, mask=mask, dy2=dy2))
-        print('%-7s bwd  block end (dy,dy2,x,mask -> dx,dres) %.3f ms  %.2f TB/s' % (name, t, (5 + 1 / 16) * mb / t / 1e3))
+        print('%-7s bwd  block end (dy,dy2,x,mask -> dx,dres) %.3f ms  %.2f TB/s  %s' % (name, t, (5 + 1 / 16) * mb / t / 1e3, k.lib.eve_last_kernel().decode()))
 
 
 if __name__ == '__main__':
