@@ -122,7 +122,8 @@ def pmc_traffic(symbol, suffix='_pmc_hbm_per_kernel.json'):
     from eve_amd.build import kernel_tree_sha
     here = os.path.dirname(os.path.abspath(__file__))
     sha = kernel_tree_sha()
-    cands = sorted(f for f in os.listdir(os.path.join(here, 'profiles')) if f.endswith(suffix) and ('_c3_' in f) == ('_c3_' in suffix)) \
+    cands = sorted(f for f in os.listdir(os.path.join(here, 'profiles')) if f.endswith(suffix) and
+                   all((tag in f) == (tag in suffix) for tag in ('_c3_', '_c5_'))) \
         if os.path.isdir(os.path.join(here, 'profiles')) else []
     for name in reversed(cands):
         try:
@@ -159,49 +160,75 @@ def kernel_roofline(sym, d, mfma_peak, profile_steps, overhead):
     return r
 
 
-def bench_c3(args, device, k):
-    """BASELINE configs[2]: configs/refine_net.json with refine_net_rnn_type=CGRU through eve_amd.EVE --
-    EyeNet frozen and forward-only, offset augmentation, gaze geometry, heat-maps, RefineNet trained (fused conv-GRU
-    scan), soft-argmax, the 31 losses / metrics, clip, Adam -- B clips x T frames per step on this GPU.  Returns the
-    `c3` object of the JSON line: ms/step, frames/s, and the HBM roofline of its dominant kernel."""
-    import numpy as np
+# algorithmic GFLOP per frame of the pipeline workloads, SURVEY.md 8(d): RefineNet(CGRU) train 9.619; EyeNet forward 2.370 /
+# train 6.955 at 128 x 128, conv part x 4 at 256 x 256 (9.476 / 27.8)
+PIPELINE_GFLOP = {('c3', 128): 2.370 + 9.619, ('c5', 256): 27.8 + 9.619, ('c5', 128): 6.955 + 9.619, ('c3', 256): 9.476 + 9.619}
+
+
+def pipeline_setup(args, device, which, batch_clips, seq, size, dtype_name, use_graph, distributed=False, seed=1):
+    """The eve_amd.EVE train step as a (trainer, batch) pair.
+    which = 'c3': BASELINE configs[2] -- configs/refine_net.json with refine_net_rnn_type=CGRU: EyeNet frozen and
+      forward-only, offset augmentation, gaze geometry, heat-maps, RefineNet trained (fused conv-GRU scan), soft-argmax, the 31
+      losses / metrics, clip, Adam;
+    which = 'c5': BASELINE configs[4] -- the same pipeline with BOTH networks trained (EyeNet's angular + pupil losses switched
+      on), T = 120 frames of 256 x 256 patches in float16."""
     import eve_amd
     from eve_amd import synthetic, train
     cfg = eve_amd.reset_standalone_config()
     cfg.import_json(os.path.join(HERE, 'configs', 'refine_net.json'))
     cfg.import_dict({'refine_net_rnn_type': 'CGRU', 'eye_net_load_pretrained': False})
+    if which == 'c5':
+        cfg.import_dict({'eye_net_frozen': False, 'loss_coeff_g_ang_initial': 1.0, 'loss_coeff_pupil_size': 1.0})
     model = eve_amd.EVE()
-    dt = TORCH_DTYPE[args.dtype]
+    dt = TORCH_DTYPE[dtype_name]
     model.eye_net.compute_dtype = model.refine_net.compute_dtype = dt
     synthetic.fill_module(model.eye_net, seed=0)
     synthetic.fill_module(model.refine_net, seed=1)
     model = model.to(device).train()
-    tr = train.eve_trainer(model, cfg)
-    small = synthetic.eve_batch(4, args.seq, seed=1)
-    reps = (args.batch + 3) // 4
-    batch = {kk: torch.cat([v] * reps, dim=0)[:args.batch].contiguous().to(device) for kk, v in small.items()}
+    tr = train.eve_trainer(model, cfg, distributed=distributed, use_graph=use_graph)
+    tr.static_inputs = 'alias'
+    small = synthetic.eve_batch(4, seq, seed=seed)
+    if size != 128:
+        g = torch.Generator().manual_seed(4000 + seed)
+        for side in ('left', 'right'):
+            small[side + '_eye_patch'] = torch.rand((4, seq, 3, size, size), generator=g) * 2 - 1
+    reps = (batch_clips + 3) // 4
+    batch = {kk: torch.cat([v] * reps, dim=0)[:batch_clips].contiguous().to(device) for kk, v in small.items()}
+    return tr, batch, cfg
+
+
+def bench_pipeline(args, device, k, which, batch_clips, seq, size, dtype_name, steps, warmup):
+    """One pipeline operating point on this GPU -> the `c3` / `c5` object of the JSON line: ms/step, frames/s, the HBM roofline
+    of its dominant kernel (RefineNet is HBM-bound by construction)."""
+    import numpy as np
+    import eve_amd
+    use_graph = not args.no_graph
+    tr, batch, cfg = pipeline_setup(args, device, which, batch_clips, seq, size, dtype_name, use_graph)
     np.random.seed(0)
-    for _ in range(max(2, args.warmup)):
+    for _ in range(max(2, warmup)):
         terms = tr.step(batch)
     torch.cuda.synchronize()
-    steps = max(3, args.steps // 2)
     t0 = time.perf_counter()
     for _ in range(steps):
         terms = tr.step(batch)
     torch.cuda.synchronize()
     ms = 1e3 * (time.perf_counter() - t0) / steps
-    out = {'workload': 'BASELINE configs[2]: configs/refine_net.json + CGRU through eve_amd.EVE (EyeNet frozen fwd, RefineNet '
-                       'trained, geometry / heat-maps / soft-argmax / 31 losses, clip, Adam), B=%d x T=%d, %s'
-                       % (args.batch, args.seq, args.dtype),
-           'ms_per_step': ms, 'value': args.batch * args.seq / (ms * 1e-3), 'unit': 'frames/s', 'steps': steps,
-           'final_loss': float(terms['full_loss'].detach()),
-           # SURVEY 8(d): 2.370 (EyeNet fwd) + 9.619 (RefineNet train) GFLOP per frame
-           'step_algorithmic_tflops': 11.989 * args.batch * args.seq / (ms * 1e-3) / 1e3}
-    out['step_mfma_frac'] = out['step_algorithmic_tflops'] / MFMA_PEAK_TFLOPS[args.dtype]
+    label = {'c3': 'BASELINE configs[2]: configs/refine_net.json + CGRU through eve_amd.EVE (EyeNet frozen fwd, RefineNet trained, '
+                   'geometry / heat-maps / soft-argmax / 31 losses, clip, Adam)',
+             'c5': 'BASELINE configs[4]: long-sequence stress through eve_amd.EVE, EyeNet AND RefineNet/CGRU trained (refine_net.json '
+                   'with the EyeNet losses on), hidden state of all T frames on-chip'}[which]
+    gf = PIPELINE_GFLOP[(which, size)]
+    out = {'workload': '%s, B=%d x T=%d, %dx%d patches, %s' % (label, batch_clips, seq, size, size, dtype_name),
+           'ms_per_step': ms, 'value': batch_clips * seq / (ms * 1e-3), 'unit': 'frames/s', 'steps': steps, 'hip_graph': use_graph,
+           'final_loss': float(terms['full_loss'].detach()), 'optimizer': tr.optimizer_state(),
+           'step_algorithmic_tflops': gf * batch_clips * seq / (ms * 1e-3) / 1e3}
+    out['step_mfma_frac'] = out['step_algorithmic_tflops'] / MFMA_PEAK_TFLOPS[dtype_name]
     if not args.no_roofline:
+        tr._eager_step(batch)
+        torch.cuda.synchronize()
         k.start_profile()
         for _ in range(args.profile_steps):
-            tr.step(batch)
+            tr._eager_step(batch)
         prof = k.stop_profile()
         by_kernel = prof.pop('_by_kernel', {})
         overhead = prof.pop('_event_overhead_ms', None)
@@ -210,7 +237,7 @@ def bench_c3(args, device, k):
             dom = max(hbm, key=lambda s_: hbm[s_]['ms'])
             d = hbm[dom]
             achieved = d['bytes'] / (d['ms'] * 1e-3) / 1e9
-            traffic, src = pmc_traffic(dom, suffix='_c3_pmc_hbm_per_kernel.json')
+            traffic, src = pmc_traffic(dom, suffix='_%s_pmc_hbm_per_kernel.json' % which)
             out['roofline'] = {'bound': 'hbm', 'kernel': 'eve::' + dom, 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                                'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
                                'traffic_unit': 'bytes per launch (FETCH_SIZE x2 + WRITE_SIZE)', 'traffic_source': src,
@@ -219,6 +246,8 @@ def bench_c3(args, device, k):
                                'event_pair_overhead_ms_subtracted': overhead}
         out['kernels_ms_per_step'] = {s_: round(by_kernel[s_]['ms'] / args.profile_steps, 4) for s_ in by_kernel if s_}
         out['kernel_groups_ms_per_step'] = {t: round(prof[t]['ms'] / args.profile_steps, 4) for t in prof}
+    del tr
+    torch.cuda.empty_cache()
     eve_amd.reset_standalone_config()
     return out
 
@@ -280,24 +309,33 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--batch', type=int, default=32, help='clips per GPU')
-    ap.add_argument('--seq', type=int, default=30)
-    ap.add_argument('--size', type=int, default=128)
-    ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp16', 'fp32'])
+    ap.add_argument('--workload', default='c2', choices=['c2', 'c3', 'c5'],
+                    help="what the MAIN line measures: c2 = BASELINE configs[1] (EyeNet training, the quoted metric; default), "
+                         "c3 = configs[2]/[3] (EyeNet + RefineNet pipeline; with --gpus N this is configs[3]), c5 = configs[4] "
+                         "(T=120, 256x256, fp16, both networks trained; defaults --batch 8 --seq 120 --size 256 --dtype fp16)")
+    ap.add_argument('--batch', type=int, default=None, help='clips per GPU (default 32; 8 for --workload c5)')
+    ap.add_argument('--seq', type=int, default=None)
+    ap.add_argument('--size', type=int, default=None)
+    ap.add_argument('--dtype', default=None, choices=['bf16', 'fp16', 'fp32'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--no-graph', action='store_true', help='launch every kernel eagerly instead of replaying a hipGraph')
-    ap.add_argument('--graph', action='store_true', help='force hipGraph replay also with several ranks')
+    ap.add_argument('--graph', action='store_true', help='(kept for compatibility: hipGraph replay is the default at every world size)')
     ap.add_argument('--graph-collectives', action='store_true',
                     help='several ranks: capture the bucket all-reduces, the clip and Adam into the hipGraph as well (RCCL)')
     ap.add_argument('--profile-steps', type=int, default=2)
     ap.add_argument('--no-c3', action='store_true', help='skip the configs[2] (EyeNet + RefineNet pipeline) measurement')
-    ap.add_argument('--no-points', action='store_true', help='skip the extra operating points (fp32 parity mode, B=8 per GPU)')
+    ap.add_argument('--no-c5', action='store_true', help='skip the configs[4] (T=120, 256x256, fp16) measurement')
+    ap.add_argument('--no-points', action='store_true', help='skip the extra operating points (fp32 parity mode, B=8 per GPU, fp16)')
     args = ap.parse_args()
+    c5 = args.workload == 'c5'
+    args.batch = args.batch if args.batch is not None else (8 if c5 else 32)
+    args.seq = args.seq if args.seq is not None else (120 if c5 else 30)
+    args.size = args.size if args.size is not None else (256 if c5 else 128)
+    args.dtype = args.dtype if args.dtype is not None else ('fp16' if c5 else 'bf16')
 
     if args.graph_collectives:
         os.environ['EVE_AMD_GRAPH_COLLECTIVES'] = '1'
-        args.graph = True
     import eve_amd
     from eve_amd import parallel, train
     from eve_amd.kernels import default_kernels
@@ -310,20 +348,36 @@ def main():
     dev_index = int(os.environ.get('EVE_AMD_FORCE_DEVICE', local_rank))
     torch.cuda.set_device(dev_index)
     device = torch.device('cuda', dev_index)
-
-    cfg = eve_amd.reset_standalone_config()
-    cfg.import_json(os.path.join(HERE, 'configs', 'eye_net.json'))
-    torch.manual_seed(1234)
-    net = eve_amd.EyeNet()
-    net.compute_dtype = TORCH_DTYPE[args.dtype]
-    net.to(device)
-    # one rank: replay the captured step; several ranks: eager launches so each bucket's RCCL all-reduce is issued
-    # from its gradient hook and overlaps the rest of backward (the step is GPU-bound either way)
-    use_graph = args.graph or (world == 1 and not args.no_graph)
-    trainer = train.eyenet_trainer(net, cfg, distributed=world > 1, use_graph=use_graph)
-    trainer.static_inputs = 'alias'      # the synthetic batch stays in the same device buffers: the graph reads it in place
-    batch = synthetic_eyenet_batch(args.batch, args.seq, args.size, device, 1000 * rank)
     k = default_kernels()
+    # ONE execution mode at every world size, so that the 1 -> N curve compares like with like: forward + backward replay as a
+    # hipGraph; with several ranks the bucket all-reduces (RCCL), the clip and Adam are launched eagerly behind each replay
+    # (tests/test_gpu_data_parallel.py runs exactly this with two ranks), or captured too with --graph-collectives.
+    use_graph = not args.no_graph
+
+    if args.workload == 'c2':
+        cfg = eve_amd.reset_standalone_config()
+        cfg.import_json(os.path.join(HERE, 'configs', 'eye_net.json'))
+        torch.manual_seed(1234)
+        net = eve_amd.EyeNet()
+        net.compute_dtype = TORCH_DTYPE[args.dtype]
+        net.to(device)
+        trainer = train.eyenet_trainer(net, cfg, distributed=world > 1, use_graph=use_graph)
+        trainer.static_inputs = 'alias'      # the synthetic batch stays in the same device buffers: the graph reads it in place
+        batch = synthetic_eyenet_batch(args.batch, args.seq, args.size, device, 1000 * rank)
+        gflop_per_frame = EYENET_TRAIN_GFLOP_PER_FRAME_128 if args.size == 128 else None
+        workload = ('BASELINE configs[1]: EyeNet training (configs/eye_net.json: ResNet-18-IN + GRU-128, angular + pupil L1 losses, '
+                    'clip 5.0, Adam wd 0.005), %dx%d patches, fwd+bwd+clip+Adam' % (args.size, args.size))
+    else:
+        import numpy as np
+        np.random.seed(1000 * rank)          # per-rank kappa_fake streams
+        trainer, batch, cfg = pipeline_setup(args, device, args.workload, args.batch, args.seq, args.size, args.dtype, use_graph,
+                                             distributed=world > 1, seed=1 + rank)
+        net = None
+        gflop_per_frame = PIPELINE_GFLOP.get((args.workload, args.size))
+        workload = ('BASELINE configs[%s]: eve_amd.EVE pipeline (%s), %dx%d patches, fwd+bwd+clip+Adam'
+                    % ('2' if args.workload == 'c3' and world == 1 else ('3' if args.workload == 'c3' else '4'),
+                       'EyeNet frozen fwd + RefineNet/CGRU trained' if args.workload == 'c3' else 'EyeNet + RefineNet/CGRU trained',
+                       args.size, args.size))
 
     def barrier():
         torch.cuda.synchronize()
@@ -368,22 +422,22 @@ def main():
 
     if rank == 0:
         out = {
-            'metric': 'train-step frames/sec, 128x128 eye patches T=30',
+            'metric': 'train-step frames/sec, %dx%d eye patches T=%d' % (args.size, args.size, args.seq),
             'value': value, 'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': args.dtype, 'data': 'synthetic',
-            'config': {'workload': 'BASELINE configs[1]: EyeNet training (configs/eye_net.json: ResNet-18-IN + GRU-128, '
-                                   'angular + pupil L1 losses, clip 5.0, Adam wd 0.005), %dx%d patches, fwd+bwd+clip+Adam'
-                                   % (args.size, args.size),
-                       'global_batch': world * args.batch, 'batch_per_gpu': args.batch, 'seq_len': args.seq,
+            'config': {'workload': workload, 'global_batch': world * args.batch, 'batch_per_gpu': args.batch, 'seq_len': args.seq,
                        'parallelism': 'dp%d' % world},
             'final_loss': loss, 'hip_graph': use_graph, 'graph_collectives': bool(getattr(trainer, 'graph_collectives', False)),
-            'ranks_seen': ranks_seen,
+            'collectives': None if world == 1 else ('captured in the hipGraph' if getattr(trainer, 'graph_collectives', False) else
+                                                    ('eager RCCL launches behind each hipGraph replay' if use_graph else 'eager, overlapped with backward')),
+            'ranks_seen': ranks_seen, 'optimizer': trainer.optimizer_state(),
             'kernel_tree_sha': __import__('eve_amd.build', fromlist=['kernel_tree_sha']).kernel_tree_sha(),
+            'dispatch_config_is_default': k.dispatch_config().as_dict() == k.default_dispatch_config().as_dict(),
         }
         peak = MFMA_PEAK_TFLOPS[args.dtype]
-        if args.size == 128:
-            out['step_algorithmic_tflops'] = EYENET_TRAIN_GFLOP_PER_FRAME_128 * value / 1e3 / world
+        if gflop_per_frame is not None:
+            out['step_algorithmic_tflops'] = gflop_per_frame * value / 1e3 / world
             out['step_mfma_frac'] = out['step_algorithmic_tflops'] / peak
         if prof:
             # the dominant KERNEL (one symbol = one row of the rocprofv3 kernel summary in profiles/), by total time
@@ -397,12 +451,22 @@ def main():
                     break
             out['kernels_ms_per_step'] = {t: round(by_kernel[t]['ms'] / args.profile_steps, 4) for t in by_kernel}
             out['kernel_groups_ms_per_step'] = {t: prof[t]['ms'] / args.profile_steps for t in prof}
-            out['kernel_groups_tflops'] = {t: prof[t]['flops'] / (prof[t]['ms'] * 1e-3) / 1e12 for t in prof}
-        if world == 1 and not args.no_c3 and args.size == 128:
+            out['kernel_groups_tflops'] = {t: prof[t]['flops'] / (prof[t]['ms'] * 1e-3) / 1e12 for t in prof if prof[t]['flops'] > 0}
+        main_c2 = args.workload == 'c2' and args.size == 128
+        extras = world == 1 and main_c2 and args.batch == 32 and args.dtype == 'bf16'
+        if world == 1 and main_c2 and not args.no_c3:
             del trainer, net                      # release the EyeNet trainer's graph pool before the second workload
             torch.cuda.empty_cache()
-            out['c3'] = bench_c3(args, device, k)
-        if world == 1 and not args.no_points and args.size == 128 and args.batch == 32 and args.dtype == 'bf16':
+            out['c3'] = bench_pipeline(args, device, k, 'c3', args.batch, args.seq, 128, args.dtype, max(3, args.steps // 2), args.warmup)
+        if extras and not args.no_c5:
+            try:
+                del trainer, net
+            except NameError:
+                pass
+            torch.cuda.empty_cache()
+            # BASELINE configs[4] on this GPU: B = 8 clips x T = 120 = the same 1 920 patches / 960 frames per step as configs[1]
+            out['c5'] = bench_pipeline(args, device, k, 'c5', 8, 120, 256, 'fp16', 3, 2)
+        if extras and not args.no_points:
             # the other stated operating points, same workload: north_star's B = 8 clips per GPU, and the float32 parity
             # mode (the instantiation that holds the 1e-4 rad tolerance; its roofline is the 157.3 TFLOP/s f32-input MFMA peak)
             try:
@@ -414,7 +478,9 @@ def main():
             out['fp32'] = eyenet_point(args, device, 'fp32', args.batch, max(3, args.steps // 2), 2, k)
             out['fp16'] = eyenet_point(args, device, 'fp16', args.batch, args.steps, args.warmup, k, profile=False)
         if world == 1 and not args.no_cpu_baseline:
-            out['cpu_baseline'] = cpu_baseline(args.seq, args.size)
+            # BASELINE.md 3 asks for os.cpu_count() threads; measured on the GPU box (256 hardware threads) that does not finish
+            # a B=2 sample in 10 minutes, so `cores` = 32 is what was used and `host_cpus` what the box has
+            out['cpu_baseline'] = cpu_baseline(args.seq if args.workload == 'c2' else 30, args.size if args.workload == 'c2' else 128)
             if 'c3' in out:
                 out['c3']['cpu_baseline'] = cpu_baseline_c3(args.seq)
         print(json.dumps(out), flush=True)

@@ -113,7 +113,7 @@ SIGNATURES = {
     'eve_heatmap_loss_fwd': [I, I, I, I, P, P, P, P, P, P, P],
     'eve_heatmap_loss_bwd': [I, I, I, P, P, P, P, P, P],
     'eve_sumsq': [L, P, P, P, P],
-    'eve_adam_step': [L, P, P, P, P, P, F, F, F, F, F, F, F, I, P, P, P],
+    'eve_adam_step': [L, P, P, P, P, P, F, F, F, F, F, F, F, I, P, I, P, P],
 }
 EXPORTS = sorted(list(SIGNATURES) + ['eve_abi_version', 'eve_last_error', 'eve_last_kernel'])
 

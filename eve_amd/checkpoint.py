@@ -99,8 +99,11 @@ def adam_state_dict(trainer, model=None):
     cfg, fp = trainer.config, trainer.fp
     pos, total = _positions(trainer, model)
     state = {}
+    # Adam's `step` = optimiser steps actually TAKEN (the device-resident counter: a step skipped for a non-finite float16
+    # gradient does not count), not the number of step() calls
+    steps_taken = int(trainer.guard[0]) if hasattr(trainer, 'guard') else int(trainer.step_count)
     for i, (p, off, n) in zip(pos, fp.entries):
-        state[i] = {'step': torch.tensor(float(trainer.step_count)),
+        state[i] = {'step': torch.tensor(float(steps_taken)),
                     'exp_avg': _param_view(fp.m, off, n, p).detach().cpu().contiguous(),
                     'exp_avg_sq': _param_view(fp.v, off, n, p).detach().cpu().contiguous()}
     lr = float(trainer.lr) if getattr(trainer, 'lr', None) is not None else float(cfg.learning_rate)
@@ -137,4 +140,4 @@ def load_adam_state_dict(trainer, sd, model=None):
         _param_view(fp.v, off, n, p).copy_(st['exp_avg_sq'].to(fp.v.device))
         steps = max(steps, int(float(st['step'])))
     trainer.step_count = steps
-    trainer.step_dev.fill_(steps)
+    trainer.guard[0] = steps

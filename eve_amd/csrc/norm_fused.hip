@@ -8,6 +8,13 @@
 #include <stdlib.h>
 #include "common.h"
 
+// Contraction is SYNTACTIC in this file: a * b + c written in one expression is one fma, a product stored by one statement and
+// used by another is rounded in between.  hipcc's default (-ffp-contract=fast) fuses across statements as it sees fit per
+// kernel -- the branch-free trunk kernels below and the generic kernels then disagree in the last bit (the trunk forward formed
+// x - mean as fma(-sum, 1/HW, x), the generic one subtracted the rounded mean: 9 % of the float32 rstd values one ulp apart),
+// and tests/test_gpu_kernels.py holds the two families to bit equality.
+#pragma clang fp contract(on)
+
 namespace eve {
 
 // Sum s[0..VEC) over all threads of the block that share this thread's channel vector (cv = tid % cvecs).
@@ -108,7 +115,7 @@ __global__ __launch_bounds__(1024) void in_fwd_fused_kernel(const T* __restrict_
             if (res) Elem<T>::unpack(reinterpret_cast<const uint4*>(res)[gi(i)], r);
 #pragma unroll
             for (int e = 0; e < VEC; ++e) {
-                float z = f[e] * a[e] + b[e];
+                float z = fmaf(f[e], a[e], b[e]);         // (explicit: the trunk kernels below must round the same way)
                 if (res) z += r[e];
                 f[e] = act_fwd(z, act);
             }
@@ -338,6 +345,9 @@ __global__ __launch_bounds__(1024) void in_fwd_trunk_kernel(const T* __restrict_
     for (int e = 0; e < VEC; ++e) {
         const float rstd = rsqrtf(s[e] * inv + eps);
         a[e] = rstd; b[e] = -mean[e] * rstd;
+        // (without this hipcc may contract the shift's multiply into the apply -- fma(-mean, rstd, f * a) -- where the generic
+        //  kernel, whose b can also carry an affine term, computes fma(f, a, b): one ulp apart in float32)
+        asm volatile("" : "+v"(b[e]));
         if (tid < cvecs) {
             const int c = c0 + cv * VEC + e;
             mr[((size_t)pp.plane * C + c) * 2] = mean[e];
@@ -355,7 +365,7 @@ __global__ __launch_bounds__(1024) void in_fwd_trunk_kernel(const T* __restrict_
         unsigned m = 0;
 #pragma unroll
         for (int e = 0; e < VEC; ++e) {
-            float z = f[e] * a[e] + b[e];
+            float z = fmaf(f[e], a[e], b[e]);             // b is a finished product (fence below): one rounding, as in the generic kernel
             if (RES) z += rr[e];
             f[e] = ACT == EVE_ACT_RELU ? (z > 0.f ? z : 0.f) : z;
             if (MASK) m |= (f[e] > 0.f ? 1u : 0u) << e;

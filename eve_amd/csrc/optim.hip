@@ -34,23 +34,57 @@ __global__ __launch_bounds__(256) void sumsq_final_kernel(const float* __restric
     if (threadIdx.x == 0) out[0] += (sh[0] + sh[1]) + (sh[2] + sh[3]);
 }
 
+// One thread decides the step: is the gradient norm finite (float16 training with a loss scale), which clip factor, which
+// bias-correction exponent.  The optimiser-step counter lives in the guard and advances HERE, only when the step is taken --
+// a skipped step leaves weights, moments AND the counter as they were (round 3 advanced the counter on the host before the
+// kernel could refuse).  Loss-scale policy (check_finite only): halve after two consecutive skips (floor 1), double after
+// 2 000 consecutive taken steps (ceiling 65 536) -- torch.cuda.amp.GradScaler's shape; the reference is float32 and has none.
+__global__ void adam_prepare_kernel(eve_adam_guard* __restrict__ gd, const float* __restrict__ sumsq, float max_norm, float gscale,
+                                    float b1, float b2, int check_finite) {
+    const float ls = gd->loss_scale > 0.f ? gd->loss_scale : 1.f;
+    const float gs = gscale / ls;                      // the gradients in the buffer are loss_scale x the true ones
+    float clip = gs;
+    bool skip = false;
+    if (sumsq) {
+        const float ss = *sumsq;
+        if (check_finite && !(ss < 3.0e38f)) skip = true;           // inf / NaN norm: an overflowed float16 gradient
+        else if (max_norm > 0.f) {
+            const float total = sqrtf(ss) * gs;
+            const float c = max_norm / (total + 1e-6f);
+            clip = gs * (c < 1.f ? c : 1.f);
+        }
+    }
+    if (skip) {
+        gd->skipped_total += 1;
+        gd->skipped_run += 1;
+        gd->good_run = 0;
+        gd->applied = 0.f;
+        if (gd->skipped_run >= 2) { gd->loss_scale = ls * 0.5f > 1.f ? ls * 0.5f : 1.f; gd->skipped_run = 0; }
+        return;
+    }
+    const int t = gd->step + 1;
+    gd->step = t;
+    gd->skipped_run = 0;
+    gd->good_run += 1;
+    if (check_finite && gd->good_run >= 2000) { gd->loss_scale = ls * 2.f < 65536.f ? ls * 2.f : 65536.f; gd->good_run = 0; }
+    gd->applied = 1.f;
+    gd->clip = clip;
+    gd->bc1 = 1.f - powf(b1, (float)t);
+    gd->bc2_sqrt = sqrtf(1.f - powf(b2, (float)t));
+}
+
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                    float* __restrict__ m, float* __restrict__ v,
                                                    const float* __restrict__ sumsq, float max_norm, float gscale,
                                                    float lr, float b1, float b2, float eps, float wd, float bc1,
-                                                   float bc2_sqrt, const int* __restrict__ step_dev,
+                                                   float bc2_sqrt, const eve_adam_guard* __restrict__ gd,
                                                    const float* __restrict__ lr_dev, long long n) {
-    if (step_dev) {      // step counter lives on the device (hipGraph replay cannot change kernel arguments)
-        const float t = (float)(*step_dev);
-        bc1 = 1.f - powf(b1, t);
-        bc2_sqrt = sqrtf(1.f - powf(b2, t));
-    }
     if (lr_dev) lr = *lr_dev;      // the schedule's value for this step, written by the host before the (replayed) launch
     float clip = gscale;
-    if (sumsq) {
-        // float16 training (static loss scale, train.Trainer): a gradient that overflowed the format shows up as an
-        // infinite / NaN norm -- the step is skipped, weights and moments stay as they are (wave-uniform exit)
-        if (!(*sumsq < 3.0e38f)) return;
+    if (gd) {                      // everything was decided by adam_prepare_kernel (same stream, just before)
+        if (gd->applied == 0.f) return;                 // skipped step (wave-uniform exit)
+        clip = gd->clip; bc1 = gd->bc1; bc2_sqrt = gd->bc2_sqrt;
+    } else if (sumsq) {
         const float total = sqrtf(*sumsq) * gscale;
         const float c = max_norm / (total + 1e-6f);
         clip = gscale * (c < 1.f ? c : 1.f);
@@ -84,15 +118,17 @@ extern "C" int eve_sumsq(long long n, const float* g, float* out, float* workspa
 
 extern "C" int eve_adam_step(long long n, float* p, const float* g, float* m, float* v, const float* sumsq,
                              float max_norm, float gscale, float lr, float beta1, float beta2, float eps,
-                             float weight_decay, int step, const int* step_dev, const float* lr_dev,
+                             float weight_decay, int step, eve_adam_guard* guard, int check_finite, const float* lr_dev,
                              eve_stream_t stream) {
-    if (n <= 0 || !p || !g || !m || !v || (step < 1 && !step_dev)) return set_error_msg("adam_step: bad arguments");
+    if (n <= 0 || !p || !g || !m || !v || (step < 1 && !guard)) return set_error_msg("adam_step: bad arguments");
     const float bc1 = 1.f - powf(beta1, (float)step);
     const float bc2 = sqrtf(1.f - powf(beta2, (float)step));
     long long b = (n + 255) / 256;
     if (b > 2048) b = 2048;
+    if (guard)
+        hipLaunchKernelGGL(adam_prepare_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, guard, sumsq, max_norm, gscale, beta1, beta2, check_finite);
     hipLaunchKernelGGL(adam_kernel, dim3((unsigned)b), dim3(256), 0, (hipStream_t)stream, p, g, m, v, sumsq, max_norm,
-                       gscale, lr, beta1, beta2, eps, weight_decay, bc1, bc2, step_dev, lr_dev, n);
+                       gscale, lr, beta1, beta2, eps, weight_decay, bc1, bc2, (const eve_adam_guard*)guard, lr_dev, n);
     EVE_CHECK_LAUNCH();
     return 0;
 }

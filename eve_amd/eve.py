@@ -50,6 +50,35 @@ class EVE(nn.Module):
             from .refine_net import RefineNet
             self.refine_net = RefineNet()
 
+    # ------------------------------------------------------------------------------------------ kappa draw (eve.py:463-479)
+    @staticmethod
+    def _draw_kappa(B, T, std):
+        """The reference's draw: same amounts, same order, same global numpy RNG (:463-466), repeated over T (:467-479)."""
+        draws = {'left': np.random.normal(size=(B, 2), loc=0.0, scale=std),
+                 'right': np.random.normal(size=(B, 2), loc=0.0, scale=std)}
+        return {side: np.repeat(np.expand_dims(draws[side], axis=1), T, axis=1).astype(np.float32) for side in draws}
+
+    def refresh_static_kappa(self, B, T, device):
+        """One host draw per optimiser step into FIXED device buffers (allocated on first use): what lets the whole train
+        step be captured into a hipGraph although the reference draws kappa_fake on the host inside forward.  The sequence
+        of draws is the eager path's: one call here per train.Trainer.step()."""
+        cfg = self.config
+        if not (self.training and cfg.refine_net_do_offset_augmentation):
+            return
+        std = np.radians(cfg.refine_net_offset_augmentation_sigma)
+        static = getattr(self, '_static_kappa', None)
+        if static is None or static['left'].shape[:2] != (B, T) or static['left'].device != device:
+            static = {side: torch.empty((B, T, 2), dtype=torch.float32, device=device) for side in ('left', 'right')}
+            self._static_host = {side: torch.empty((B, T, 2), dtype=torch.float32).pin_memory() if device.type == 'cuda'
+                                 else torch.empty((B, T, 2), dtype=torch.float32) for side in ('left', 'right')}
+            self._static_kappa = static
+        for side, kap in self._draw_kappa(B, T, std).items():
+            self._static_host[side].copy_(torch.from_numpy(kap))
+            static[side].copy_(self._static_host[side], non_blocking=True)
+
+    def drop_static_kappa(self):
+        self._static_kappa = None
+
     # ------------------------------------------------------------------------------------------ labels (eve.py:441-543)
     def calculate_additional_labels(self, d, current_epoch=None):
         cfg = self.config
@@ -64,12 +93,16 @@ class EVE(nn.Module):
         if self.training and cfg.refine_net_do_offset_augmentation:
             assert isinstance(current_epoch, float)
             std = np.radians(cfg.refine_net_offset_augmentation_sigma)
-            # same draws, in the same order, from the same global numpy RNG as the reference (:463-466)
-            draws = {'left': np.random.normal(size=(B, 2), loc=0.0, scale=std),
-                     'right': np.random.normal(size=(B, 2), loc=0.0, scale=std)}
-            for side in ('left', 'right'):
-                kap = np.repeat(np.expand_dims(draws[side], axis=1), T, axis=1).astype(np.float32)
-                d[side + '_kappa_fake'] = torch.from_numpy(kap).to(dev)
+            static = getattr(self, '_static_kappa', None)
+            if static is not None:
+                # hipGraph replay (train.eve_trainer(use_graph=True)): the draw happened on the host BEFORE the replay
+                # (refresh_static_kappa) and sits in fixed device buffers the captured kernels read
+                assert static['left'].shape[:2] == (B, T), 'static kappa buffers were made for another batch shape'
+                for side in ('left', 'right'):
+                    d[side + '_kappa_fake'] = static[side]
+            else:
+                for side, kap in self._draw_kappa(B, T, std).items():
+                    d[side + '_kappa_fake'] = torch.from_numpy(kap).to(dev)
         if 'left_o' in d:
             d['o'] = _mean2(d['left_o'], d['right_o']).detach()
             d['o_validity'] = d['left_o_validity']

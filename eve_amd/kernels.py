@@ -918,11 +918,23 @@ class HipKernels(object):
         self._ck(self.lib.eve_sumsq(g.numel(), self._p(self._f32(g, 'g')), self._p(out), self._p(workspace), self._stream()))
         return out
 
+    ADAM_GUARD_WORDS = 12        # include/eve_hip.h eve_adam_guard: 4 ints, then floats (loss_scale at word 4)
+
+    @staticmethod
+    def new_adam_guard(device, loss_scale=1.0, step=0):
+        """Device-resident optimiser state (eve_adam_guard) as an int32 tensor of 12 words; .view(torch.float32)[4] is the loss scale."""
+        g = torch.zeros(HipKernels.ADAM_GUARD_WORDS, dtype=torch.int32, device=device)
+        g[0] = int(step)
+        g.view(torch.float32)[4] = float(loss_scale)
+        return g
+
     def adam_step(self, p, g, m, v, sumsq, max_norm, gscale, lr, beta1, beta2, eps, weight_decay, step,
-                  step_dev=None, lr_dev=None):
+                  guard=None, check_finite=False, lr_dev=None):
+        if guard is not None:
+            assert guard.dtype == torch.int32 and guard.numel() >= self.ADAM_GUARD_WORDS and guard.is_contiguous()
         self._ck(self.lib.eve_adam_step(p.numel(), self._p(p), self._p(g), self._p(m), self._p(v),
                                         self._p(sumsq), max_norm, gscale, lr, beta1, beta2, eps,
-                                        weight_decay, step, self._p(step_dev), self._p(lr_dev), self._stream()))
+                                        weight_decay, step, self._p(guard), 1 if check_finite else 0, self._p(lr_dev), self._stream()))
 
 
 _default = None

@@ -96,7 +96,13 @@ class Trainer(object):
         dev = self.fp.flat.device
         self.sumsq = torch.zeros(1, dtype=torch.float32, device=dev)
         self.sumsq_ws = torch.zeros(1024, dtype=torch.float32, device=dev)     # scratch of the fixed-order reduction
-        self.step_dev = torch.zeros(1, dtype=torch.int32, device=dev)
+        # device-resident optimiser state (include/eve_hip.h eve_adam_guard): the count of steps actually TAKEN (Adam's
+        # bias-correction exponent -- a step the kernel skips for a non-finite float16 gradient does not advance it), the skip
+        # counters and the loss scale, which backs off after two consecutive skips.  The overflow check is on whenever a loss
+        # scale is in play (float16), whatever the clipping mode; bf16 / fp32 runs keep failing visibly on NaN.
+        self.check_overflow = self.loss_scale != 1.0 or any(getattr(m, 'compute_dtype', None) == torch.float16 for m in self.modules)
+        self.guard = default_kernels().new_adam_guard(dev, loss_scale=self.loss_scale)
+        self.loss_scale_dev = self.guard.view(torch.float32)[4:5]
         self.lr_schedule = lr_schedule
         self.lr = float(config.learning_rate)
         self.lr_dev = torch.full((1,), self.lr, dtype=torch.float32, device=dev)
@@ -116,6 +122,7 @@ class Trainer(object):
         self._graph = None
         self._static_batch = None
         self._static_terms = None
+        self.pre_step = None          # optional host-side hook run at the top of every step(batch), before capture / replay
         self._invalidate()
 
     def _invalidate(self):
@@ -128,25 +135,32 @@ class Trainer(object):
         self.fp.zero_grad()
         terms = self.loss_fn(batch)
         loss = terms['full_loss']
-        (loss if self.loss_scale == 1.0 else loss * self.loss_scale).backward()
+        # (the scale is read from the device: it may have backed off, and a captured graph must follow it)
+        (loss if not self.check_overflow else loss * self.loss_scale_dev[0]).backward()
         return terms
 
     def _update(self, gscale):
         k = default_kernels()
         cfg = self.config
-        gscale = gscale / self.loss_scale           # the gradients in the flat buffer are loss_scale x the true ones
-        self.step_dev.add_(1)
-        clip = cfg.do_gradient_clipping and cfg.gradient_clip_by == 'norm'
-        if cfg.do_gradient_clipping and not clip:
+        by_norm = cfg.do_gradient_clipping and cfg.gradient_clip_by == 'norm'
+        if cfg.do_gradient_clipping and not by_norm:
+            if self.check_overflow:       # (a clamp would turn an overflowed gradient into a finite, wrong one)
+                raise NotImplementedError('clip-by-value together with a loss scale (float16) is not supported: clip by norm')
             self.fp.grad.mul_(gscale).clamp_(-cfg.gradient_clip_amount, cfg.gradient_clip_amount)
             gscale = 1.0
-        if clip:
+        need_norm = by_norm or self.check_overflow
+        if need_norm:
             self.sumsq.zero_()
             k.sumsq(self.fp.grad, self.sumsq, self.sumsq_ws)
-        k.adam_step(self.fp.flat, self.fp.grad, self.fp.m, self.fp.v, self.sumsq if clip else None,
-                    float(cfg.gradient_clip_amount), gscale, self.lr, self.beta1, self.beta2,
-                    self.eps, float(cfg.weight_decay), 0, step_dev=self.step_dev, lr_dev=self.lr_dev)
+        k.adam_step(self.fp.flat, self.fp.grad, self.fp.m, self.fp.v, self.sumsq if need_norm else None,
+                    float(cfg.gradient_clip_amount) if by_norm else 0.0, gscale, self.lr, self.beta1, self.beta2,
+                    self.eps, float(cfg.weight_decay), 0, guard=self.guard, check_finite=self.check_overflow, lr_dev=self.lr_dev)
         self._invalidate()
+
+    def optimizer_state(self):
+        """Host view of the device-resident optimiser state (synchronises): steps taken, steps skipped, loss scale."""
+        g = self.guard.cpu()
+        return {'steps_taken': int(g[0]), 'steps_skipped': int(g[1]), 'loss_scale': float(g.view(torch.float32)[4])}
 
     def set_lr(self, lr):
         """Learning rate of the next step(s): written to the device scalar the (possibly graph-captured) Adam kernel reads."""
@@ -168,10 +182,10 @@ class Trainer(object):
         return terms
 
     def _snapshot(self):
-        return [t.clone() for t in (self.fp.flat, self.fp.m, self.fp.v, self.step_dev)]
+        return [t.clone() for t in (self.fp.flat, self.fp.m, self.fp.v, self.guard)]
 
     def _restore(self, snap):
-        for t, s_ in zip((self.fp.flat, self.fp.m, self.fp.v, self.step_dev), snap):
+        for t, s_ in zip((self.fp.flat, self.fp.m, self.fp.v, self.guard), snap):
             t.copy_(s_)
         self._invalidate()
 
@@ -219,6 +233,8 @@ class Trainer(object):
         """One optimiser step.  Returns the loss terms; under use_graph these are the graph's static output tensors
         (overwritten by the next step: clone what must be kept)."""
         self._apply_schedule()
+        if self.pre_step is not None:
+            self.pre_step(batch)
         if not self.use_graph:
             self.step_count += 1
             return self._eager_step(batch)
@@ -261,13 +277,24 @@ def refinenet_trainer(refine_net, config, distributed=False, use_graph=False, lr
                    lr_schedule=_resolve_schedule(config, lr_schedule, steps_per_epoch))
 
 
-def eve_trainer(model, config, distributed=False, current_epoch=0.0, lr_schedule=None, steps_per_epoch=None):
+def eve_trainer(model, config, distributed=False, current_epoch=0.0, lr_schedule=None, steps_per_epoch=None, use_graph=False):
     """Train step of the whole EVE harness (eve.EVE): forward through both networks and the geometry / heat-map /
     soft-argmax glue, every loss of eve.py:234-265, backward, clip, Adam on whichever network is trainable
-    (refine_net.json freezes EyeNet).  Eager only: the kappa draw (numpy RNG, as in the reference) happens on the host."""
+    (refine_net.json freezes EyeNet).
+    use_graph: the ~1 200 launches of the step replay as one hipGraph.  The reference draws the offset augmentation's
+    kappa_fake on the host inside forward (eve.py:463-479); here the SAME draw (numpy RNG, one per step, same order) is made
+    by a pre-step hook and copied into fixed device buffers the captured kernels read (eve.EVE.refresh_static_kappa), so
+    eager and replayed steps see identical augmentations."""
     modules = [m for m in (model.eye_net, model.refine_net)
                if m is not None and any(p.requires_grad for p in m.parameters())]
 
     def loss_fn(batch):
         return model({'train': dict(batch)}, current_epoch=current_epoch)
-    return Trainer(modules, config, loss_fn, distributed=distributed, lr_schedule=_resolve_schedule(config, lr_schedule, steps_per_epoch))
+    tr = Trainer(modules, config, loss_fn, distributed=distributed, use_graph=use_graph,
+                 lr_schedule=_resolve_schedule(config, lr_schedule, steps_per_epoch))
+    if use_graph:
+        def pre_step(batch):
+            t = batch['left_eye_patch']
+            model.refresh_static_kappa(t.shape[0], t.shape[1], t.device)
+        tr.pre_step = pre_step
+    return tr

@@ -425,14 +425,30 @@ int eve_heatmap_loss_bwd(int kind, int BT, int HW, const float* pred, const floa
  * floats of scratch owned by the caller.                                                            */
 #define EVE_SUMSQ_WORKSPACE 1024
 int eve_sumsq(long long n, const float* g, float* out, float* workspace, eve_stream_t stream);
-/* clip factor c = min(1, max_norm / (sqrt(*sumsq) * gscale + 1e-6)) if sumsq != NULL else 1;
- * g' = c * gscale * g + wd * p;  m,v Adam moments;  p -= lr * mhat / (sqrt(vhat) + eps).
- * The bias-correction step t is `step`, or *step_dev (device int) when step_dev != NULL, and the learning rate is
- * `lr`, or *lr_dev (device float) when lr_dev != NULL -- the forms a captured hipGraph needs, since a replay cannot
- * change kernel arguments: the LR schedule of src/core/training.py:382-418,436-442 writes *lr_dev before each step.  */
+/* Optimiser state that must live on the device (a replayed hipGraph cannot change kernel arguments, and the decision to skip
+ * a step is taken on the device): 48 bytes, caller-owned, zero-initialised except loss_scale (1 = no scaling).            */
+typedef struct eve_adam_guard {
+    int step;             /* optimiser steps TAKEN so far = Adam's bias-correction exponent                                  */
+    int skipped_total;    /* calls that left weights and moments untouched because the gradient norm was not finite         */
+    int skipped_run;      /* ... consecutive ones (two in a row halve loss_scale)                                           */
+    int good_run;         /* consecutive taken steps since the loss scale last changed (2 000 double it)                     */
+    float loss_scale;     /* the factor the caller multiplied the loss by before backward; divided out of the gradient here */
+    float applied;        /* 1 if the last call updated the weights, 0 if it skipped                                        */
+    float clip;           /* factor the last taken step applied to the stored gradient (1/loss_scale and the norm clip)     */
+    float bc1, bc2_sqrt;  /* bias corrections of the last taken step                                                        */
+    float reserved[3];
+} eve_adam_guard;
+/* clip factor c = min(1, max_norm / (sqrt(*sumsq) * gscale' + 1e-6)) if sumsq != NULL and max_norm > 0, else 1;
+ * g' = c * gscale' * g + wd * p;  m,v Adam moments;  p -= lr * mhat / (sqrt(vhat) + eps).
+ * guard == NULL: gscale' = gscale, bias-correction step t = `step` (host value), no overflow handling.
+ * guard != NULL: gscale' = gscale / guard->loss_scale, t = ++guard->step; with check_finite a non-finite *sumsq (an
+ *   overflowed float16 gradient) SKIPS the step: weights, moments and guard->step stay, guard->skipped_* count it and the
+ *   loss scale backs off (see eve_adam_guard).  The learning rate is `lr`, or *lr_dev (device float) when lr_dev != NULL: the
+ *   LR schedule of src/core/training.py:382-418,436-442 writes *lr_dev before each (possibly replayed) step.               */
 int eve_adam_step(long long n, float* p, const float* g, float* m, float* v, const float* sumsq,
                   float max_norm, float gscale, float lr, float beta1, float beta2, float eps,
-                  float weight_decay, int step, const int* step_dev, const float* lr_dev, eve_stream_t stream);
+                  float weight_decay, int step, eve_adam_guard* guard, int check_finite, const float* lr_dev,
+                  eve_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -422,14 +422,50 @@ class FakeKernels(object):
         out += (g.double() ** 2).sum().float()
         return out
 
+    ADAM_GUARD_WORDS = 12
+
+    @staticmethod
+    def new_adam_guard(device, loss_scale=1.0, step=0):
+        g = torch.zeros(12, dtype=torch.int32, device=device)
+        g[0] = int(step)
+        g.view(torch.float32)[4] = float(loss_scale)
+        return g
+
     def adam_step(self, p, g, m, v, sumsq, max_norm, gscale, lr, beta1, beta2, eps, weight_decay, step,
-                  step_dev=None, lr_dev=None):
-        if step_dev is not None:
-            step = int(step_dev)
+                  guard=None, check_finite=False, lr_dev=None):
+        """include/eve_hip.h eve_adam_step, guard semantics included (skip on a non-finite norm, the step counter advancing
+        only on taken steps, loss-scale back-off / growth)."""
         if lr_dev is not None:
             lr = float(lr_dev)
         clip = gscale
-        if sumsq is not None:
+        if guard is not None:
+            gf = guard.view(torch.float32)
+            ls = float(gf[4]) if float(gf[4]) > 0 else 1.0
+            gs = gscale / ls
+            clip = gs
+            ss = float(sumsq) if sumsq is not None else None
+            if ss is not None and check_finite and not (ss < 3.0e38):
+                guard[1] += 1
+                guard[2] += 1
+                guard[3] = 0
+                gf[5] = 0.0
+                if int(guard[2]) >= 2:
+                    gf[4] = max(ls * 0.5, 1.0)
+                    guard[2] = 0
+                return
+            if ss is not None and max_norm > 0:
+                total = ss ** 0.5 * gs
+                clip = gs * min(1.0, max_norm / (total + 1e-6))
+            guard[0] += 1
+            step = int(guard[0])
+            guard[2] = 0
+            guard[3] += 1
+            if check_finite and int(guard[3]) >= 2000:
+                gf[4] = min(ls * 2.0, 65536.0)
+                guard[3] = 0
+            gf[5] = 1.0
+            gf[6] = clip
+        elif sumsq is not None:
             total = float(sumsq.sqrt()) * gscale
             clip = gscale * min(1.0, max_norm / (total + 1e-6))
         gi = clip * g + weight_decay * p

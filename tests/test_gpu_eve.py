@@ -134,6 +134,59 @@ def make_eve(over, dtype=torch.float32):
     return model.cuda()
 
 
+F64_TAGS = ('c3', 'joint', 'clstm', 'crnn', 'noskip', 'noaug')
+
+
+def check_grads_against_float64_reference(tag, net, module):
+    """Gradients of `module` against tests/golden/eve_grads_f64.npz: the REFERENCE's models.eve.EVE evaluated in float64
+    (make_golden_eve_grads.py) -- the complete tensors of the representative parameters (relative L2), the norms of all others.
+    Bound per parameter: max(1e-4, 4 x the largest deviation the reference's OWN float32 evaluation shows for that parameter
+    over the fixture's six cases).  Why that and not "2 x its deviation in this case": the harness differentiates through
+    softmax(100 h) and ~40 layers of ReLU / max-pool / adaptive-pool decisions, so a float32 evaluation is one DRAW -- a few
+    flipped decisions re-route gradient -- and the reference's own draws for one parameter spread 5x over the cases
+    (initial.0.weight: 4.2e-3 .. 2.3e-2).  Measured on the HIP float32 path (tools/dbg_eve_grads.py): 0.4 - 1.4 x the
+    reference's deviation typically (3.6 x at worst, on a decoder convolution whose reference deviation is 1.6e-4), 7.6e-3 ..
+    4.6e-2 on initial.0.weight.  Parameters the reference leaves without a gradient
+    (frozen EyeNet, CLSTM's gates: refine_net.py:168-174) must have none."""
+    fx = np.load(os.path.join(GOLDEN, 'eve_grads_f64.npz'))
+    params = dict(module.named_parameters())
+    for n in fx['%s_%s_dead' % (tag, net)]:
+        if str(n):
+            assert params[str(n)].grad is None, n
+    key = '%s_%s_names' % (tag, net)
+    if key not in fx.files:
+        assert all(p.grad is None for p in params.values())
+        return 0.0
+    noise = {}                                           # parameter -> its largest reference float32 deviation over the cases
+    for t in F64_TAGS:
+        if '%s_%s_names' % (t, net) in fx.files:
+            nm, dv, nr = fx['%s_%s_names' % (t, net)], fx['%s_%s_ref_f32_dev' % (t, net)], fx['%s_%s_norms' % (t, net)]
+            for n, d, w in zip(nm, dv, nr):
+                if w > 1e-9 * nr.max():
+                    noise[str(n)] = max(noise.get(str(n), 0.0), float(d))
+    names, norms = fx[key], fx['%s_%s_norms' % (tag, net)]
+    scale = float(norms.max())
+    worst = 0.0
+    for n, want in zip(names, norms):
+        g = params[str(n)].grad
+        assert g is not None, n
+        if want <= 1e-9 * scale:
+            continue
+        tol = max(1e-4, 4.0 * noise[str(n)])
+        if net == 'eye_net':
+            # (joint training: EyeNet's gradient arrives partly through RefineNet's INPUT gradient, which carries the 2 - 3 % the
+            #  reference's float32 shows on RefineNet's first layers; two HIP runs measured 6e-3 and 2e-2 on conv1.weight)
+            tol = max(tol, 3e-2)
+        full = '%s_%s_grad_%s' % (tag, net, n)
+        if full in fx.files:
+            err = float((g.detach().cpu().double() - torch.from_numpy(fx[full]).double()).norm())
+        else:
+            err = abs(float(g.detach().double().norm()) - float(want))
+        assert err <= tol * float(want), (tag, net, str(n), err / float(want), tol)
+        worst = max(worst, err / float(want) / tol)
+    return worst
+
+
 @pytest.mark.parametrize('tag', sorted(EVE_CASES))
 def test_eve_matches_reference_golden(tag):
     """float32 instantiation of eve_amd.EVE on the GPU against the REFERENCE's EVE (fixture): every loss / metric scalar,
@@ -161,19 +214,10 @@ def test_eve_matches_reference_golden(tag):
     if training:
         assert np.array_equal(batch['left_kappa_fake'].cpu().numpy(), fx[tag + '_kappa_left'])
         out['full_loss'].backward()
+        # gradients: against the reference's own float64 evaluation, bounded by its own float32 deviation (round 4; the
+        # float32 norm fixture of eve_harness.npz with a flat 3e-2 before)
         for net, mod in (('eye_net', model.eye_net), ('refine_net', model.refine_net)):
-            got = {n: (-1.0 if p.grad is None else float(p.grad.double().norm())) for n, p in mod.named_parameters()}
-            scale = max(float(w) for w in fx['%s_%s_grad_norms' % (tag, net)])
-            for n, want in zip(fx['%s_%s_grad_names' % (tag, net)], fx['%s_%s_grad_norms' % (tag, net)]):
-                if want < 0:
-                    assert got[str(n)] < 0, n
-                else:
-                    # (float32 MFMA summation order through ~40 layers, then softmax(100 h): a few per cent on single-tensor
-                    #  norms.  Measured: running three of RefineNet's InstanceNorm planes through a kernel variant that
-                    #  agrees with this one to 1e-7 relative -- a different order of the plane reductions -- moved
-                    #  |d initial.1.bias| by 3.9 %.  The float32 path therefore keeps ONE summation order (the channel-split
-                    #  InstanceNorm is bf16-only); what bounds kernel error is the per-kernel and teacher-forced tests)
-                    assert abs(got[str(n)] - want) <= 3e-2 * want + 1e-5 * max(scale, 1.0), (n, got[str(n)], want)
+            check_grads_against_float64_reference(tag, net, mod)
     else:
         for k in ('initial_gaze_history', 'refined_gaze_history', 'initial_heatmap', 'final_heatmap', 'gt_heatmap'):
             assert np.abs(out[k].detach().cpu().numpy()[..., ::4, ::4] - fx['eval_' + k]).max() < 2e-3, k
@@ -270,20 +314,15 @@ def test_eve_config_variants_match_oracle(over):
         assert abs(float(got[k].detach()) - float(v.detach())) <= 5e-4 * abs(float(v.detach())) + 1e-4, (k, float(got[k].detach()), float(v.detach()))
     for k in ('g_initial', 'g_final'):
         assert float((got[k].detach().cpu() - winter[k].detach()).abs().max()) < 1e-4, k
-    got['full_loss'].backward(); want['full_loss'].backward()
-    ref = dict(oref.named_parameters())
-    scale = max(float(p.grad.norm()) for p in ref.values() if p.grad is not None)
-    for n, p in model.refine_net.named_parameters():
-        if ref[n].grad is None:
-            assert p.grad is None, n
-        else:
-            a, b = p.grad.cpu().double(), ref[n].grad.double()
-            # (the first layers sit behind ~40 float32 layers and softmax(100 h): their per-tensor gradients carry a few
-            #  per cent of summation-order noise, CPU vs GPU)
-            # adaptive-max-pool / (leaky-)ReLU decisions on near-ties differ between the two float32 evaluation orders and
-            # re-route gradient: a few per cent per tensor on untrained weights (the reference-pinned cases in
-            # test_eve_matches_reference_golden hold 3 %); this test is about the configuration surface
-            assert float((a - b).norm()) <= 1e-1 * float(b.norm()) + 1e-5 * max(1.0, scale), n
+    got['full_loss'].backward()
+    # gradients: against the REFERENCE's float64 evaluation of this variant (eve_grads_f64.npz), bounded per parameter by the
+    # reference's own float32 deviation (round 4; 1e-1 against the float32 CPU oracle before).  CLSTM: the cell's gates get no
+    # gradient (its output never reaches the decoder, refine_net.py:168-174) -- the fixture lists them as dead.
+    vtag = {'CLSTM': 'clstm', 'CRNN': 'crnn'}.get(over['refine_net_rnn_type'])
+    if vtag is None:
+        vtag = 'noskip' if over.get('refine_net_use_skip_connections') is False else 'noaug'
+    check_grads_against_float64_reference(vtag, 'refine_net', model.refine_net)
+    assert all(p.grad is None for p in model.eye_net.parameters())
     eve_amd.reset_standalone_config()
 
 
@@ -350,4 +389,45 @@ def test_configs4_long_sequence_large_patches_whole_pipeline(half):
     assert dev < (0.08 if half == torch.bfloat16 else 0.02)
     # the recurrences matter at this length: the refined estimate at the last frame differs from the first frame's
     assert float((winter['PoG_px_final'][:, -1] - winter['PoG_px_final'][:, 0]).abs().max()) > 1.0
+    eve_amd.reset_standalone_config()
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16], ids=['fp32', 'bf16'])
+def test_eve_trainer_hipgraph_replay_equals_eager_steps(dtype):
+    """configs[2] through train.eve_trainer(use_graph=True): the whole step (label synthesis, offset augmentation, frozen
+    EyeNet forward, geometry, heat-maps, RefineNet forward + backward, soft-argmax, the 31 losses, clip, Adam) replays as one
+    hipGraph.  The reference draws kappa_fake on the host inside forward (eve.py:463-479); the graph path makes the SAME draw
+    (same numpy stream, one per step) before each replay into fixed device buffers.  Three steps eager vs three steps
+    captured + replayed from identical weights and RNG state: every step's losses agree, the augmented gaze of each step is
+    the same draw, and the weights end up equal to the noise of the weight-gradient atomics."""
+    from eve_amd import train
+    batch = {k: v.cuda() for k, v in detweights.eve_batch(2, 3, seed=23, invalid_fraction=0.1).items()}
+    runs = {}
+    for mode in ('eager', 'graph'):
+        model = make_eve({}, dtype=dtype).train()
+        cfg = eve_amd.get_config()
+        cfg.import_dict({'base_learning_rate': 1e-6})       # (Adam's ~lr * sign(g) first steps: keep the comparison about plumbing)
+        tr = train.eve_trainer(model, cfg, use_graph=(mode == 'graph'))
+        np.random.seed(7)
+        log = []
+        for _ in range(3):
+            terms = tr.step(batch)
+            log.append({k: float(terms[k].detach()) for k in ('full_loss', 'loss_ce_heatmap_final', 'metric_euc_PoG_px_initial',
+                                                              'metric_euc_PoG_px_final')})
+        torch.cuda.synchronize()
+        assert tr.optimizer_state()['steps_taken'] == 3
+        runs[mode] = (log, tr.fp.grad.clone())
+        model.drop_static_kappa()
+    tol = 2e-5 if dtype == torch.float32 else 2e-2
+    for a, b in zip(runs['eager'][0], runs['graph'][0]):
+        for k in a:
+            assert abs(a[k] - b[k]) <= tol * max(1.0, abs(a[k])), (k, a[k], b[k])
+    # the three draws differ from one another (the augmentation is live) ...
+    assert len({round(s['metric_euc_PoG_px_initial'], 3) for s in runs['graph'][0]}) == 3
+    # ... and the third step's gradient is the eager one's (weight-gradient atomics and, in bf16, the rounding flips two
+    # earlier Adam steps seed: the envelope tests/test_gpu_data_parallel.py uses for its graph cases)
+    ge, gg = runs['eager'][1], runs['graph'][1]
+    # (float32 too: ulp-level weight differences after two Adam steps move these ill-conditioned gradients by per cents --
+    #  see check_grads_against_float64_reference; the per-step LOSSES above are the tight check of the plumbing)
+    assert float((ge - gg).norm() / ge.norm()) < 5e-2
     eve_amd.reset_standalone_config()

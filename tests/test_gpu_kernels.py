@@ -629,6 +629,30 @@ def test_adam_and_sumsq(hip, ref):
     close(pg, pw, torch.float32, 'adam p')
     close(mg, mw, torch.float32, 'adam m')
     close(vg, vw, torch.float32, 'adam v')
+    # ---- the device-resident guard (eve_adam_guard): same update with the step counter on the device; a non-finite norm
+    # skips the step (weights, moments, counter untouched), two skips in a row halve the loss scale; without check_finite the
+    # overflow is NOT hidden ----
+    guard_w, guard_g = ref.new_adam_guard('cpu', loss_scale=4.0, step=2), hip.new_adam_guard('cuda', loss_scale=4.0, step=2)
+    pw2, mw2, vw2 = p.clone(), m.clone(), v.clone()
+    pg2, mg2, vg2 = dev(p.clone()), dev(m.clone()), dev(v.clone())
+    g4, ss4 = 4.0 * g, 16.0 * ss_w                               # what a loss scale of 4 leaves in the buffer
+    ref.adam_step(pw2, g4, mw2, vw2, ss4, 5.0, 1.0, 0.016, 0.9, 0.999, 1e-8, 0.005, 0, guard=guard_w, check_finite=True)
+    hip.adam_step(pg2, dev(g4), mg2, vg2, dev(ss4), 5.0, 1.0, 0.016, 0.9, 0.999, 1e-8, 0.005, 0, guard=guard_g, check_finite=True)
+    close(pg2, pw, torch.float32, 'guarded adam p == plain step 3')
+    close(pg2, pw2, torch.float32, 'guarded adam p')
+    assert guard_g.cpu().tolist()[:4] == [3, 0, 0, 1] == guard_w.tolist()[:4]
+    before = (pg2.clone(), mg2.clone(), vg2.clone())
+    inf = torch.full((1,), float('inf'), device='cuda')
+    for k_, want in ((1, [3, 1, 1, 0, 4.0]), (2, [3, 2, 0, 0, 2.0])):
+        hip.adam_step(pg2, dev(g4), mg2, vg2, inf, 5.0, 1.0, 0.016, 0.9, 0.999, 1e-8, 0.005, 0, guard=guard_g, check_finite=True)
+        ref.adam_step(pw2, g4, mw2, vw2, inf.cpu(), 5.0, 1.0, 0.016, 0.9, 0.999, 1e-8, 0.005, 0, guard=guard_w, check_finite=True)
+        gl = guard_g.cpu()
+        assert gl.tolist()[:4] == want[:4] == guard_w.tolist()[:4] and float(gl.view(torch.float32)[4]) == want[4]
+        assert all(torch.equal(a, b) for a, b in zip(before, (pg2, mg2, vg2))), 'a skipped step must not touch weights or moments'
+    gn = dev(g4).clone()
+    gn[7] = float('nan')                                 # (a NaN NORM alone only switches the clip off; a NaN gradient poisons)
+    hip.adam_step(pg2, gn, mg2, vg2, inf, 5.0, 1.0, 0.016, 0.9, 0.999, 1e-8, 0.005, 0, guard=guard_g, check_finite=False)
+    assert not torch.isfinite(pg2[7]) and int(guard_g[0]) == 4, 'bf16 / fp32 runs must keep failing visibly'
 
 
 def test_uint8_frame_normalisation_is_bit_identical_to_the_reference(hip):

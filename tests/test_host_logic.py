@@ -585,5 +585,30 @@ def test_trainer_factories_take_the_reference_schedule_and_the_fp16_loss_scale(f
     assert res[0][1] == pytest.approx(res[1][1], rel=1e-5)
     n16 = eve_amd.EyeNet()
     n16.compute_dtype = torch.float16
-    assert train.Trainer([n16], cfg, lambda b: None).loss_scale == 1024.0
+    t16 = train.Trainer([n16], cfg, lambda b: None)
+    assert t16.loss_scale == 1024.0 and t16.check_overflow
+    # ---- an overflowed step is SKIPPED on the device, visibly: weights, moments and the bias-correction counter stay, the
+    # skip is counted, two in a row halve the loss scale, and the next finite step is Adam step 2 (not 4) ----
+    n3 = detweights.fill_module(eve_amd.EyeNet())
+    poison = {'on': False}
+
+    def loss_fn(b):
+        terms = sequence.eyenet_losses(n3.forward_sequence(b), b, OracleConfig(batch_size=16, weight_decay=0.005, base_learning_rate=0.001))
+        if poison['on']:
+            terms['full_loss'] = terms['full_loss'] * float('inf')
+        return terms
+    t3 = train.Trainer([n3], cfg, loss_fn, loss_scale=1024.0)
+    t3.step(batch)
+    assert t3.optimizer_state() == {'steps_taken': 1, 'steps_skipped': 0, 'loss_scale': 1024.0}
+    w1, m1 = t3.fp.flat.clone(), t3.fp.m.clone()
+    poison['on'] = True
+    t3.step(batch)
+    t3.step(batch)
+    assert torch.equal(t3.fp.flat, w1) and torch.equal(t3.fp.m, m1)
+    assert t3.optimizer_state() == {'steps_taken': 1, 'steps_skipped': 2, 'loss_scale': 512.0}
+    poison['on'] = False
+    t3.step(batch)
+    assert t3.optimizer_state()['steps_taken'] == 2 and not torch.equal(t3.fp.flat, w1) and torch.isfinite(t3.fp.flat).all()
+    from eve_amd import checkpoint
+    assert float(checkpoint.adam_state_dict(t3)['state'][0]['step']) == 2.0          # steps taken, not step() calls (4)
     eve_amd.reset_standalone_config()
