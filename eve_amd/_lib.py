@@ -22,10 +22,10 @@ class DispatchConfig(Structure):
         'struct_bytes', 'conv_impl_v1', 'conv_tile_big', 'conv_halo', 'conv_ws64', 'conv_wg8', 'conv_wg8_min_tiles',
         'conv_wg8_s2_min_tiles', 'halo_persist', 'wgrad_target_wgs', 'wgrad_min_rows', 'wgrad_halo', 'wgrad_wg8',
         'wg64_th', 'wg64_nreg', 'wg64_fixed', 'in_split', 'in_min_threads', 'in_stats_one_pass', 'stem_split',
-        'in_trunk_kernels')] + [('wgrad_halo_min_m', c_longlong)]
+        'in_trunk_kernels', 'stem_fused_wgrad', 'reserved1')] + [('wgrad_halo_min_m', c_longlong)]
 
     def as_dict(self):
-        return {n: int(getattr(self, n)) for n, _ in self._fields_ if n != 'struct_bytes'}
+        return {n: int(getattr(self, n)) for n, _ in self._fields_ if n not in ('struct_bytes', 'reserved1')}
 
 
 P = c_void_p
@@ -58,6 +58,7 @@ SIGNATURES = {
     'eve_stem_fwd_fused': [I, I, I, I, P, P, F, P, P, P, P],
     'eve_stem_wgrad': [I, I, I, I, P, P, P, P],
     'eve_stem_bwd_dx': [I, I, I, I, P, P, P, P, P, P, P, P, P],
+    'eve_stem_bwd_wgrad': [I, I, I, I, P, P, P, P, P, P, P, P, P],
     'eve_bias_grad': [I, L, I, P, P, P],
     'eve_cgru_scan_fwd': [I, I, I, P, P, P, P, P, P, P, P, P, P, P, P],
     'eve_cgru_scan_bwd': [I, I, I, P, P, P, P, P, P, P, P, P, P, P, P],

@@ -530,6 +530,313 @@ __global__ __launch_bounds__(64 * SF_WAVES) void stem_bwd_dx_kernel(const int N,
     }
 }
 
+// =================================================================================================
+// Round 4: the stem's backward AND its weight gradient in one kernel -- d(conv1 out) never reaches HBM.
+//
+// stem_bwd_dx_kernel wrote d(conv1 out) [N][64][64][64] (1 GB at N = 1 920) for wgrad_tr_kernel to read back; the
+// stem has no data gradient, so that tensor's only reader was the weight gradient.  Here every conv row's d(conv out)
+// goes from the accumulator registers to a 4 KB LDS tile of the wave and is multiplied, on the spot, with the input
+// rows that are in the LDS ring anyway:
+//     dW[co][kh][kw][c] += sum over the row's 64 pixels x of  dconv[x][co] * patch[2 oy + kh][2 x + kw][c]
+// = 56 MFMAs per row and wave (K = pixels: both operands come out of ds_read_b64_tr_b16, exactly as in wgrad_tr_kernel),
+// next to the 56 that recompute the row.  What makes the accumulators fit: an image is shared by TWO waves, 32 output
+// channels each (wave h owns co = 16 g + 8 h + 0..7): 112 registers of dW + 32 of the recomputed row per lane instead
+// of 224 + 64.  The pair shares the input ring (each wave stages one of the two new rows per conv row) and meets at one
+// s_barrier per row; statistics, pooling routes and dW are per channel, so the waves exchange nothing else.  The arithmetic
+// per channel is stem_bwd_dx_kernel's (same MFMA sequence, same rounding of d(conv out) to the storage format before
+// it is multiplied), so dW equals the two-kernel path up to the float summation order.
+// Output: dw [64][7][8][4] float, accumulated (the layout eve_stem_wgrad writes: column kw = 7 and channel 3 do not exist).
+// =================================================================================================
+constexpr int SB_PAIRS = 4;                       // images per workgroup and turn
+constexpr int SB_DROW = 64;                       // bytes per pixel of the d(conv out) tile: 32 local channels
+constexpr int SB_DTILE = 64 * SB_DROW;            // one conv row of one wave
+constexpr int SB_KBYTES = 4 * 2 * 3 * 16;         // [lg][ntl][{rstd, B, C}][r] floats per wave
+
+struct SbPooledRow {               // one pooled row, the lane's 8 channels: columns q = li + 16 j
+    uint32_t eg[2][4];
+    uint32_t code[2][2];
+};
+template <typename H>
+__device__ __forceinline__ void sb_load_pooled(SbPooledRow& P, const H* __restrict__ dyp, const H* __restrict__ dyp2,
+                                               const H* __restrict__ yp, const uint8_t* __restrict__ idx, size_t row_base,
+                                               int li, int ch0, bool live) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const size_t o = (row_base + li + 16 * j) * 64 + ch0;
+        uint4 d0 = make_uint4(0, 0, 0, 0), y0 = d0;
+        uint2 c = make_uint2(0, 0);
+        if (live) {
+            d0 = *reinterpret_cast<const uint4*>(dyp + o);
+            y0 = *reinterpret_cast<const uint4*>(yp + o);
+            c = *reinterpret_cast<const uint2*>(idx + o);
+            if (dyp2) {
+                const uint4 e0 = *reinterpret_cast<const uint4*>(dyp2 + o);
+                d0 = make_uint4(sf_add_pairs<H>(d0.x, e0.x), sf_add_pairs<H>(d0.y, e0.y), sf_add_pairs<H>(d0.z, e0.z), sf_add_pairs<H>(d0.w, e0.w));
+            }
+        }
+        const uint32_t dd[4] = {d0.x, d0.y, d0.z, d0.w}, yy[4] = {y0.x, y0.y, y0.z, y0.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t m = ((int)(yy[k] << 16) > 0 ? 0xffffu : 0u) | ((int)(yy[k] & 0xffff0000u) > 0 ? 0xffff0000u : 0u);
+            P.eg[j][k] = dd[k] & m;
+        }
+        P.code[j][0] = c.x; P.code[j][1] = c.y;
+    }
+}
+__device__ __forceinline__ void sb_chunk(const SbPooledRow& P, int j, int ntl, uint32_t (&eg)[2], uint32_t& cd,
+                                         uint32_t (&neg)[2], uint32_t& ncd) {
+    eg[0] = P.eg[j][2 * ntl]; eg[1] = P.eg[j][2 * ntl + 1]; cd = P.code[j][ntl];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const uint32_t edge = j == 0 ? sf_dpp<0x12f>(0u, P.eg[1][2 * ntl + k]) : 0u;   // row_ror:15 = rotate left by one
+        neg[k] = sf_dpp<0x101>(edge, eg[k]);                                            // row_shl:1
+    }
+    const uint32_t edge = j == 0 ? sf_dpp<0x12f>(0u, P.code[1][ntl]) : 0u;
+    ncd = sf_dpp<0x101>(edge, cd);
+}
+__device__ __forceinline__ uint2 sb_tr_read(uint32_t lds_byte_addr) {
+    EVE_LDS char* base = (EVE_LDS char*)(size_t)lds_byte_addr;
+    bf16x4v_t r = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((EVE_LDS bf16x4v_t*)base);
+    return __builtin_bit_cast(uint2, r);
+}
+
+template <typename H>
+__global__ __launch_bounds__(512) void stem_bwd_wgrad_kernel(const int N, const int IH, const H* __restrict__ xp, const uint32_t xp_bytes,
+                                                             const H* __restrict__ w8, const float* __restrict__ mr,
+                                                             const H* __restrict__ dyp, const H* __restrict__ dyp2,
+                                                             const H* __restrict__ yp, const uint8_t* __restrict__ idx,
+                                                             float* __restrict__ dw) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const sW = smem + SB_PAIRS * SF_RING * SF_ROWB;
+    char* const sKall = sW + SF_WBYTES;
+    char* const sDall = sKall + 8 * SB_KBYTES;
+    const int tid = threadIdx.x;
+    sf_fill_weights<H>(sW, w8, tid, 512);
+    __syncthreads();
+
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int pair = wave >> 1, h = wave & 1;
+    const int li = lane & 15, lg = lane >> 4;
+    const int OH = IH / 2, PH = OH / 2, rows = IH + 6;
+    const uint32_t ring = lds_addr_of(smem) + pair * (SF_RING * SF_ROWB);
+    const uint32_t xoff = 16 * (2 * li + lg);
+    // this wave's two weight tiles: LDS rows nt * 16 + 4 g + r with nt = 2 h, 2 h + 1
+    const uint32_t wbase = lds_addr_of(sW) + (2 * h) * 1024 + li * 64 + ((lg ^ (((li >> 2) & 1) << 1)) << 4);
+    const eve_int4 rs = make_rsrc_words(xp, xp_bytes);
+    const float inv_hw = 1.f / (float)(OH * 64);
+    char* const sK = sKall + wave * SB_KBYTES;
+    const uint32_t sD = lds_addr_of(sDall) + wave * SB_DTILE;
+    const int ch0 = lg * 16 + 8 * h;                      // first of the lane's 8 channels in the pooled tensors
+
+    // transposing-read lane constants (see wgrad_tr_kernel): row 8 g + t / 4 (+ 4 for the second read), 8-byte piece t % 4
+    const int trow = 8 * lg + (li >> 2), tq = li & 3;
+
+    f32x4_t dacc[2][14];                                   // dW[co tile][kh * 2 + tap tile]: rows 4 g + r, column t
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 14; ++b) dacc[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    const int per_turn = gridDim.x * SB_PAIRS;
+    const int turns = (N + per_turn - 1) / per_turn;
+    for (int turn = 0; turn < turns; ++turn) {
+        const int n = turn * per_turn + pair * (int)gridDim.x + (int)blockIdx.x;
+        const bool live = n < N;                                  // (uniform per wave pair; idle pairs keep the barriers)
+        const int nn = live ? n : 0;
+        const int img_off = nn * rows * SF_XROW;
+        const size_t pool_base = (size_t)nn * PH * 32;
+        // rows 0 .. 8 of the image: wave h stages the rows of its parity
+        for (int r = h; r < 9; r += 2) sf_stage_row(rs, ring, r, live ? rows : 0, img_off, lane);
+        // ---- phase A: the two plane sums over the pooled tensors -> {rstd, B, C} of the lane's channels ----
+        if (live) {
+            float s1[8], s2[8];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) { s1[c] = 0.f; s2[c] = 0.f; }
+#pragma unroll 4
+            for (int py = 0; py < PH; ++py)                       // (four rows of loads in flight: the chain of 32 round trips showed)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const size_t o = (pool_base + (size_t)py * 32 + li + 16 * j) * 64 + ch0;
+                    float d[8], y[8];
+                    Elem<H>::unpack(*reinterpret_cast<const uint4*>(dyp + o), d);
+                    if (dyp2) {                                   // same rounding of the sum as sb_load_pooled
+                        float d2[8];
+                        Elem<H>::unpack(*reinterpret_cast<const uint4*>(dyp2 + o), d2);
+#pragma unroll
+                        for (int c = 0; c < 8; ++c) d[c] = Elem<H>::round(d[c] + d2[c]);
+                    }
+                    Elem<H>::unpack(*reinterpret_cast<const uint4*>(yp + o), y);
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) {
+                        const float g = y[c] > 0.f ? d[c] : 0.f;
+                        s1[c] += g; s2[c] += g * y[c];
+                    }
+                }
+            const float* m = mr + ((size_t)nn * 64 + ch0) * 2;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const float a = sf_row_sum16(s1[c]) * inv_hw, b = sf_row_sum16(s2[c]) * inv_hw;
+                const float mean = m[2 * c], r = m[2 * c + 1];
+                const float B = r * r * b, C = mean * B - r * a;
+                if (li == 0) {                                   // [lg][ntl][{rstd, B, C}][r]
+                    float* kc = reinterpret_cast<float*>(sK + ((lg * 2 + (c >> 2)) * 3) * 16) + (c & 3);
+                    kc[0] = r; kc[4] = B; kc[8] = C;
+                }
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the nine rows (and phase A's loads)
+        __syncthreads();                                          // ... and the partner's (sK is this wave's own)
+        // ---- phase B: recompute the convolution row by row; d(conv out) -> LDS tile -> weight-gradient MFMAs ----
+        SbPooledRow P0, P1;
+        sb_load_pooled<H>(P0, dyp, dyp2, yp, idx, pool_base, li, ch0, live);
+        int slot0 = 0;
+        for (int py = 0; py < PH; ++py) {
+            sb_load_pooled<H>(P1, dyp, dyp2, yp, idx, pool_base + (size_t)(py + 1) * 32, li, ch0, live && py + 1 < PH);
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                const int oy = 2 * py + half;
+                // this wave's row of two iterations ago has landed once at most the newer operations are outstanding:
+                // half 0: one row (2 DMAs) + the 6 .. 8 pooled loads just issued; half 1: one row
+                if (oy >= 2) {
+                    if (half == 0) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                    else           asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                }
+                // ... and the partner's.  (A rendezvous of just the two waves through LDS flags, which lets the pairs drift apart so
+                //  that the two waves of a SIMD are not in the same phase, was built and measured: with its extra registers the
+                //  kernel spilled inside this loop and ran 1.0 ms against 0.76.)
+                __builtin_amdgcn_s_barrier();
+                sf_stage_row(rs, ring, 2 * oy + 9 + h, live ? rows : 0, img_off, lane);
+                if (live) {
+                    // -- the row's convolution for this wave's 32 channels (acc[mt][ntl]).  Filter rows in pairs, the second row's
+                    //    fragments requested before the first row's MFMAs (a full double buffer over all seven rows spills: the
+                    //    112 weight-gradient accumulators leave ~90 registers for everything else) --
+                    f32x4_t acc[4][2];
+                    auto conv_frags = [&](int kh, uint4 (&x4)[4], uint4 (&w2)[2]) {
+                        int slot = slot0 + kh;
+                        slot = slot >= SF_RING ? slot - SF_RING : slot;
+                        const uint32_t xa = ring + slot * SF_ROWB + xoff, wa = wbase + kh * 4096;
+#pragma unroll
+                        for (int mt = 0; mt < 4; ++mt) x4[mt] = sf_lds_read(xa + (mt & 1) * 16 + (mt >> 1) * 512);
+#pragma unroll
+                        for (int nt = 0; nt < 2; ++nt) w2[nt] = sf_lds_read(wa + nt * 1024);
+                    };
+                    auto conv_mfma = [&](bool first, const uint4 (&x4)[4], const uint4 (&w2)[2]) {
+#pragma unroll
+                        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                            for (int mt = 0; mt < 4; ++mt) {
+                                if (first) acc[mt][nt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+                                Elem<H>::mfma(acc[mt][nt], w2[nt], x4[mt]);
+                            }
+                    };
+                    {
+                        uint4 fxa[4], fwa[2], fxb[4], fwb[2];
+                        conv_frags(0, fxa, fwa);
+                        conv_frags(1, fxb, fwb);
+                        conv_mfma(true, fxa, fwa);
+#pragma unroll 1
+                        for (int kh = 2; kh < 6; kh += 2) {
+                            conv_frags(kh, fxa, fwa);
+                            conv_mfma(false, fxb, fwb);
+                            conv_frags(kh + 1, fxb, fwb);
+                            conv_mfma(false, fxa, fwa);
+                        }
+                        conv_frags(6, fxa, fwa);
+                        conv_mfma(false, fxb, fwb);
+                        conv_mfma(false, fxa, fwa);
+                    }
+                    // -- d(conv out) of the lane's 4 pixel columns x 8 channels -> the wave's [pixel][channel] tile --
+                    const uint32_t k0 = half ? 6u : 3u;         // window row of this conv row inside window py
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+#pragma unroll
+                        for (int nt = 0; nt < 2; ++nt) {
+                            const f32x4_t kr = *reinterpret_cast<const f32x4_t*>(sK + ((lg * 2 + nt) * 3) * 16);
+                            const f32x4_t kB = *reinterpret_cast<const f32x4_t*>(sK + ((lg * 2 + nt) * 3 + 1) * 16);
+                            const f32x4_t kC = *reinterpret_cast<const f32x4_t*>(sK + ((lg * 2 + nt) * 3 + 2) * 16);
+                            uint32_t eg0[2], cd0, ng0[2], nc0, eg1[2], cd1, ng1[2], nc1;
+                            sb_chunk(P0, j, nt, eg0, cd0, ng0, nc0);
+                            if (half) sb_chunk(P1, j, nt, eg1, cd1, ng1, nc1);
+                            float de[4], dd[4];
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                float ge = sf_pick<H>(eg0, cd0, r, k0 + 1u);
+                                float go = sf_pick<H>(eg0, cd0, r, k0 + 2u) + sf_pick<H>(ng0, nc0, r, k0);
+                                if (half) {
+                                    ge += sf_pick<H>(eg1, cd1, r, 1u);
+                                    go += sf_pick<H>(eg1, cd1, r, 2u) + sf_pick<H>(ng1, nc1, r, 0u);
+                                }
+                                const float xe = acc[2 * j][nt][r], xo = acc[2 * j + 1][nt][r];
+                                de[r] = fmaf(-xe, kB[r], fmaf(kr[r], ge, kC[r]));
+                                dd[r] = fmaf(-xo, kB[r], fmaf(kr[r], go, kC[r]));
+                            }
+                            // pixel x = 2 (li + 16 j) (+ 1), local channels nt * 16 + 4 lg + 0..3: one 8-byte slot, swizzled by
+                            // the pixel row so that the 16 lanes of a store / the 32 of a transposing read spread over the banks
+                            const int xe_row = 2 * (li + 16 * j), slot8 = nt * 4 + lg;
+                            typedef uint32_t sb_u32x2_t __attribute__((ext_vector_type(2)));
+                            EVE_LDS sb_u32x2_t* pe = (EVE_LDS sb_u32x2_t*)(size_t)(sD + xe_row * SB_DROW + ((slot8 ^ ((xe_row >> 1) & 7)) << 3));
+                            EVE_LDS sb_u32x2_t* po = (EVE_LDS sb_u32x2_t*)(size_t)(sD + (xe_row + 1) * SB_DROW + ((slot8 ^ (((xe_row + 1) >> 1) & 7)) << 3));
+                            *pe = sb_u32x2_t{Elem<H>::pack2(de[0], de[1]), Elem<H>::pack2(de[2], de[3])};
+                            *po = sb_u32x2_t{Elem<H>::pack2(dd[0], dd[1]), Elem<H>::pack2(dd[2], dd[3])};
+                        }
+                    }
+                    // -- dW += dconv^T x patches: K = the row's 64 pixels in two chunks of 32; 28 patch fragments, each used by two
+                    //    MFMAs, requested three fragments (six MFMAs) ahead of their use --
+                    uint4 fa[2][2];
+#pragma unroll
+                    for (int kc = 0; kc < 2; ++kc)
+#pragma unroll
+                        for (int ct = 0; ct < 2; ++ct) {
+                            const int r0 = kc * 32 + trow, r1 = r0 + 4;
+                            const uint2 a0 = sb_tr_read(sD + r0 * SB_DROW + (((ct * 4 + tq) ^ ((r0 >> 1) & 7)) << 3));
+                            const uint2 a1 = sb_tr_read(sD + r1 * SB_DROW + (((ct * 4 + tq) ^ ((r1 >> 1) & 7)) << 3));
+                            fa[kc][ct] = make_uint4(a0.x, a0.y, a1.x, a1.y);
+                        }
+                    auto patch_frag = [&](int q) {               // q = (kc * 7 + kh) * 2 + tt
+                        const int tt = q & 1, kh = (q >> 1) % 7, kc = (q >> 1) / 7;
+                        int slot = slot0 + kh;
+                        slot = slot >= SF_RING ? slot - SF_RING : slot;
+                        // patch row of pixel x starts at byte 16 x of the staged input row: taps (kw, c) contiguous
+                        const uint32_t xb = ring + slot * SF_ROWB + (kc * 32 + trow) * 16 + tq * 8 + tt * 32;
+                        const uint2 b0 = sb_tr_read(xb), b1 = sb_tr_read(xb + 4 * 16);
+                        return make_uint4(b0.x, b0.y, b1.x, b1.y);
+                    };
+                    constexpr int AHEAD = 3;
+                    uint4 fb[AHEAD + 1];
+#pragma unroll
+                    for (int q = 0; q < AHEAD; ++q) fb[q] = patch_frag(q);
+#pragma unroll
+                    for (int q = 0; q < 28; ++q) {
+                        if (q + AHEAD < 28) fb[(q + AHEAD) % (AHEAD + 1)] = patch_frag(q + AHEAD);
+                        const int tt = q & 1, kh = (q >> 1) % 7, kc = (q >> 1) / 7;
+                        Elem<H>::mfma(dacc[0][kh * 2 + tt], fa[kc][0], fb[q % (AHEAD + 1)]);
+                        Elem<H>::mfma(dacc[1][kh * 2 + tt], fa[kc][1], fb[q % (AHEAD + 1)]);
+                    }
+                }
+                slot0 = slot0 + 2 >= SF_RING ? slot0 + 2 - SF_RING : slot0 + 2;
+            }
+            P0 = P1;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the zero-fill DMAs past the image's last rows
+        __syncthreads();                                          // the ring is rewritten by the next turn
+    }
+    // ---- the workgroup's dW: the four pairs' slices summed in LDS (the ring is free now), then one atomic per element ----
+    float* const sR = reinterpret_cast<float*>(smem);            // [64 co][224 taps]
+    for (int e = tid; e < 64 * 224; e += 512) sR[e] = 0.f;
+    __syncthreads();
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+        for (int tile = 0; tile < 14; ++tile)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int co = lg * 16 + (2 * h + ct) * 4 + r, tap = tile * 16 + li;
+                atomicAdd(sR + co * 224 + tap, dacc[ct][tile][r]);
+            }
+    __syncthreads();
+    for (int e = tid; e < 64 * 224; e += 512) atomicAdd(dw + e, sR[e]);
+}
+
 }  // namespace eve
 
 using namespace eve;
@@ -581,6 +888,34 @@ extern "C" int eve_stem_bwd_dx(int dtype, int N, int IH, int IW, const void* x_p
     EVE_DISPATCH_H16(dtype, EVE_LAUNCH(EVE_HNAME(H, "stem_bwd_dx_kernel<", ">"), stem_bwd_dx_kernel<H>, dim3(blocks), dim3(64 * SF_WAVES), lds,
                                        (hipStream_t)stream, N, IH, (const H*)x_padded, (uint32_t)xb, (const H*)w_ohwi8, mean_rstd, (const H*)dy_pool,
                                        (const H*)dy_pool2, (const H*)y_pool, idx, (H*)dx, halves));
+    EVE_CHECK_LAUNCH();
+    return 0;
+}
+
+/* The stem's backward and weight gradient in one launch (round 4): dw [64][7][8][4] float (accumulated; column kw = 7 and
+   channel 3 do not exist) from d(y_pool), recomputing the convolution from x_padded; d(conv1 out) is never written.
+   Replaces eve_stem_bwd_dx + eve_stem_wgrad (autograd of conv1 / bn1 / relu / maxpool, eye_net.py:48-50,106).             */
+extern "C" int eve_stem_bwd_wgrad(int dtype, int N, int IH, int IW, const void* x_padded, const void* w_ohwi8, const float* mean_rstd,
+                                  const void* dy_pool, const void* dy_pool2, const void* y_pool, const uint8_t* idx, float* dw,
+                                  eve_stream_t stream) {
+    if ((dtype != EVE_DT_BF16 && dtype != EVE_DT_F16) || N <= 0 || IH <= 0 || (IH & 3) || IW != 128 || !x_padded || !w_ohwi8 || !mean_rstd || !dy_pool || !y_pool || !idx || !dw)
+        return set_error_msg("stem_bwd_wgrad: needs IW == 128 and IH a multiple of 4");
+    const unsigned long long xb = (unsigned long long)N * (IH + 6) * SF_XROW;
+    if (xb >= (1ull << 31)) return set_error_msg("stem_bwd_wgrad: packed input must stay below 2 GiB");
+    const size_t lds = (size_t)SB_PAIRS * SF_RING * SF_ROWB + SF_WBYTES + 8 * SB_KBYTES + 8 * SB_DTILE;
+    static_assert((size_t)SB_PAIRS * SF_RING * SF_ROWB >= 64 * 224 * 4, "the dW reduction reuses the ring");
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)stem_bwd_wgrad_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)stem_bwd_wgrad_kernel<f16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    // images are dealt round-robin over the workgroups first (pair p of workgroup b takes image p * grid + b): a small batch
+    // puts one or two pairs on every CU instead of four pairs on a fraction of them
+    const unsigned blocks = N < 256 ? (unsigned)N : 256u;
+    EVE_DISPATCH_H16(dtype, EVE_LAUNCH(EVE_HNAME(H, "stem_bwd_wgrad_kernel<", ">"), stem_bwd_wgrad_kernel<H>, dim3(blocks), dim3(512), lds,
+                                       (hipStream_t)stream, N, IH, (const H*)x_padded, (uint32_t)xb, (const H*)w_ohwi8, mean_rstd, (const H*)dy_pool,
+                                       (const H*)dy_pool2, (const H*)y_pool, idx, dw));
     EVE_CHECK_LAUNCH();
     return 0;
 }

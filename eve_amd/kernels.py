@@ -293,6 +293,22 @@ class HipKernels(object):
             self._p(dy_pool2), self._p(y_pool), self._p(idx), self._p(dx), self._stream())))
         return dx
 
+    def stem_bwd_wgrad(self, x_padded, w_ohwi8, mr, dy_pool, y_pool, idx, dw, dy_pool2=None):
+        """dw [64, 7, 8, 4] float32 += the stem's weight gradient straight from d(pooled output): backward of the fused stem and
+        its weight gradient in one launch, d(conv1 out) never written (include/eve_hip.h eve_stem_bwd_wgrad)."""
+        N, Hp, Wp, _ = x_padded.shape
+        IH, IW = Hp - 6, Wp - 8
+        assert tuple(dw.shape) == (64, 7, 8, 4) and dw.dtype == torch.float32 and dw.is_contiguous()
+        assert dy_pool.dtype == x_padded.dtype and dy_pool.is_contiguous() and dy_pool.shape == y_pool.shape == idx.shape
+        # the weight gradient's FLOPs are algorithmic; the recomputed convolution is not credited
+        flops = 2.0 * N * (IH // 2) * (IW // 2) * 64 * 147
+        self._timed('conv_wgrad', flops, lambda: self._ck(self.lib.eve_stem_bwd_wgrad(
+            dt_code(x_padded.dtype), N, IH, IW, self._p(x_padded), self._p(w_ohwi8), self._p(self._f32(mr, 'mean_rstd')), self._p(dy_pool),
+            self._p(dy_pool2), self._p(y_pool), self._p(idx), self._p(dw), self._stream())), (x_padded, dy_pool, dy_pool2, y_pool, idx))
+
+    def stem_fused_wgrad_enabled(self):
+        return bool(self.dispatch_config().stem_fused_wgrad)
+
     # ------------------------------------------------------------------ decoded uint8 frames (input pipeline)
     def frames_u8_to_nchw(self, frames, scale, shift=None):
         """uint8 [N,H,W,C] -> float32 [N,C,H,W] = frames * scale (+ shift)."""

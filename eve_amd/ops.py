@@ -512,10 +512,14 @@ class ResNetTrunkFn(torch.autograd.Function):
         dx = None
         if stem_pack is not None:
             x_padded, y, idx, mr = saved[:4]
-            dconv = k.stem_bwd_dx(x_padded, stem_pack.ohwi, mr, d_a, y, idx, dy_pool2=d_b)
             if need_w[0]:
-                dwp = torch.zeros((64, 7, 8, 4), dtype=torch.float32, device=dconv.device)
-                k.stem_wgrad(x_padded, dconv, dwp)          # straight from the packed patches (no 8-channel copy)
+                dwp = torch.zeros((64, 7, 8, 4), dtype=torch.float32, device=x_padded.device)
+                if getattr(k, 'stem_fused_wgrad_enabled', lambda: False)():
+                    # backward + weight gradient in one launch: d(conv1 out) stays in LDS (round 4)
+                    k.stem_bwd_wgrad(x_padded, stem_pack.ohwi, mr, d_a, y, idx, dwp, dy_pool2=d_b)
+                else:
+                    dconv = k.stem_bwd_dx(x_padded, stem_pack.ohwi, mr, d_a, y, idx, dy_pool2=d_b)
+                    k.stem_wgrad(x_padded, dconv, dwp)          # straight from the packed patches (no 8-channel copy)
                 O, I = stem_pack.shape_oihw[0], stem_pack.shape_oihw[1]
                 grads[0] = dwp[:O, :, :7, :I].permute(0, 3, 1, 2)
         elif ctx.needs_input_grad[0]:

@@ -75,6 +75,8 @@ typedef struct eve_dispatch_config {
     int in_stats_one_pass;         /* EVE_IN_STATS_ONE_PASS 1   shifted-moment statistics for planes beyond L2             */
     int stem_split;                /* EVE_STEM_SPLIT        1   two waves per image in the fused stem at small batches     */
     int in_trunk_kernels;          /* EVE_IN_TRUNK          1   branch-free InstanceNorm kernels for the ResNet trunk's cases */
+    int stem_fused_wgrad;          /* EVE_STEM_FUSED_WGRAD  1   stem backward + weight gradient in one launch (eve_stem_bwd_wgrad) */
+    int reserved1;
     long long wgrad_halo_min_m;    /* EVE_WGRAD_HALO_MIN_M  1<<20 pixels from which the band-resident weight gradient runs */
 } eve_dispatch_config;
 int eve_get_dispatch_config(eve_dispatch_config* out);           /* what the entry points use now                         */
@@ -148,6 +150,13 @@ int eve_stem_fwd_fused(int dtype, int N, int IH, int IW, const void* x_padded, c
                        void* y_pool, uint8_t* idx, float* mean_rstd, eve_stream_t stream);
 /* Its backward up to the convolution output: dx [N][IH/2][IW/2][64] bf16 = d(conv1 out) from dy_pool, recomputing
  * the convolution from x_padded (autograd of bn1/relu/maxpool in eye_net.py:106); feed dx to eve_conv2d_wgrad. */
+/* Round 4: backward AND weight gradient of the fused stem in ONE launch -- dw [64][7][8][4] float (accumulated; filter column
+ * 7 and channel 3 do not exist) straight from d(y_pool): every recomputed convolution row's d(conv1 out) stays in LDS and is
+ * multiplied there with the input rows the recomputation has staged anyway; the 1 GB d(conv1 out) tensor of
+ * eve_stem_bwd_dx + eve_stem_wgrad is never written or read.  Same arithmetic per channel (float summation order aside).    */
+int eve_stem_bwd_wgrad(int dtype, int N, int IH, int IW, const void* x_padded, const void* w_ohwi8, const float* mean_rstd,
+                       const void* dy_pool, const void* dy_pool2, const void* y_pool, const uint8_t* idx, float* dw,
+                       eve_stream_t stream);
 /* ... and the stem's weight gradient from the same packed patches: dw [64][7][8][4] float (accumulated; filter
  * column 7 and channel 3 do not exist and are ignored by the caller).  Replaces autograd of conv1 (eye_net.py:106). */
 int eve_stem_wgrad(int dtype, int N, int IH, int IW, const void* x_padded, const void* dconv, float* dw, eve_stream_t stream);

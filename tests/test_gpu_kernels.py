@@ -218,6 +218,37 @@ def test_stem_fused_backward_matches_unfused(hip, N, hdt):
     assert (a - b).abs().max().item() < 0.05 * b.abs().max().item()
 
 
+@HALVES
+@pytest.mark.parametrize('N,two', [(2, False), (17, True), (1100, True)], ids=['N2', 'N17-two-summands', 'N1100-second-turn'])
+def test_stem_backward_and_weight_gradient_in_one_launch(hip, N, two, hdt):
+    """eve_stem_bwd_wgrad (d(conv1 out) stays in LDS: wave pairs, 32 channels each, weight-gradient MFMAs on the recomputed
+    rows) == eve_stem_bwd_dx followed by eve_stem_wgrad on the stored tensor -- same rounding of d(conv1 out) to the storage
+    format, float summation order aside -- and == torch's conv2d_weight on that tensor; accumulates onto existing values; the
+    gradient delivered as two summands; N = 1 100 > 1 024 image slots: a second turn with idle wave pairs in it."""
+    src = rnd((N, 3, 128, 128), torch.float32, 64) + 0.2
+    w = rnd((64, 7, 7, 8), hdt, 65, scale=0.08)
+    w[..., 3:] = 0
+    xp = hip.stem_pack_input(dev(src), dtype=hdt)
+    y, idx, mr = hip.stem_fwd_fused(xp, dev(w))
+    dy = dev(rnd(tuple(y.shape), hdt, 66))
+    dy2 = dev(rnd(tuple(y.shape), hdt, 69)) if two else None
+    dconv = hip.stem_bwd_dx(xp, dev(w), mr, dy, y, idx, dy_pool2=dy2)
+    want = torch.zeros((64, 7, 8, 4), device='cuda')
+    hip.stem_wgrad(xp, dconv, want)
+    base = dev(rnd((64, 7, 8, 4), torch.float32, 70))
+    got = base.clone()
+    hip.stem_bwd_wgrad(xp, dev(w), mr, dy, y, idx, got, dy_pool2=dy2)
+    assert hip.lib.eve_last_kernel().decode().startswith('stem_bwd_wgrad_kernel')
+    got = (got - base)[:, :, :7, :3]
+    assert torch.isfinite(got).all()
+    rel = ((got - want[:, :, :7, :3]).norm() / want[:, :, :7, :3].norm()).item()
+    assert rel < 2e-5 * max(1.0, (N / 16) ** 0.5), rel             # same products, float sums in another order
+    x8 = hip.nchw_to_nhwc(dev(src), hdt, 8)
+    ref = torch.nn.grad.conv2d_weight(x8.float().permute(0, 3, 1, 2)[:, :3], (64, 3, 7, 7), dconv.float().permute(0, 3, 1, 2),
+                                      stride=2, padding=3).permute(0, 2, 3, 1)
+    assert ((got - ref).norm() / ref.norm()).item() < 2e-3
+
+
 @pytest.mark.parametrize('shape', [(1920, 512, 128), (37, 130, 128), (60, 128, 384), (1920, 128, 4), (5, 7, 3)],
                          ids=lambda s: 'x'.join(map(str, s)))
 @pytest.mark.parametrize('act', [0, 1, 3, 4], ids=['none', 'relu', 'selu', 'tanh'])
