@@ -28,6 +28,31 @@ class DispatchConfig(Structure):
         return {n: int(getattr(self, n)) for n, _ in self._fields_ if n not in ('struct_bytes', 'reserved1')}
 
 
+class ChainStage(Structure):
+    """include/eve_hip.h eve_chain_stage"""
+    _fields_ = [('B', c_void_p), ('bias', c_void_p), ('C', c_void_p), ('extra', c_void_p), ('next_mul', c_void_p),
+                ('R', c_int), ('Nc', c_int), ('epi_act', c_int), ('accumulate', c_int), ('from_input', c_int), ('n_extra', c_int),
+                ('next_mul_act', c_int), ('reserved', c_int)]
+
+
+CHAIN_MAX_STAGES = 6
+
+
+class ChainParams(Structure):
+    """include/eve_hip.h eve_chain_params"""
+    _fields_ = [('A0', c_void_p), ('Y0', c_void_p), ('M', c_int), ('R0', c_int), ('Y0_act', c_int), ('nstages', c_int),
+                ('st', ChainStage * CHAIN_MAX_STAGES)]
+
+
+class WgradProblem(Structure):
+    """include/eve_hip.h eve_wgrad_problem"""
+    _fields_ = [('dY', c_void_p), ('Y', c_void_p), ('X', c_void_p), ('X2', c_void_p), ('dW', c_void_p), ('db', c_void_p),
+                ('M', c_int), ('N', c_int), ('K', c_int), ('K1', c_int), ('K2', c_int), ('act', c_int), ('rows_per_split', c_int),
+                ('ldY', c_int)]
+
+
+WGRAD_BATCH_MAX = 8
+
 P = c_void_p
 I = c_int
 L = c_longlong
@@ -78,6 +103,8 @@ SIGNATURES = {
     'eve_linear_fwd': [I, I, I, P, P, P, I, P, P],
     'eve_linear_dgrad': [I, I, I, P, P, I, P, P, P],
     'eve_linear_wgrad': [I, I, I, P, P, I, P, P, P, P],
+    'eve_linear_chain': [POINTER(ChainParams), P],
+    'eve_linear_wgrad_batch': [POINTER(WgradProblem), I, P],
     'eve_instnorm_stats': [I, I, I, I, P, F, P, P],
     'eve_instnorm_act_fwd': [I, I, I, I, P, P, P, P, P, I, P, P],
     'eve_instnorm_act_bwd': [I, I, I, I, P, P, P, P, P, P, I, P, P, P, P],

@@ -306,6 +306,54 @@ class HipKernels(object):
             dt_code(x_padded.dtype), N, IH, IW, self._p(x_padded), self._p(w_ohwi8), self._p(self._f32(mr, 'mean_rstd')), self._p(dy_pool),
             self._p(dy_pool2), self._p(y_pool), self._p(idx), self._p(dw), self._stream())), (x_padded, dy_pool, dy_pool2, y_pool, idx))
 
+    # ------------------------------------------------------------------ chains of small float32 linear layers (the tail)
+    def linear_chain(self, a0, stages, y0=None, y0_act=ACT_NONE):
+        """One launch for a chain of small linear layers (include/eve_hip.h eve_linear_chain).  a0 [M, R0] float32; stages: dicts
+        with B [R, Nc] (float32, contiguous) and optional bias, C (output tensor [M, Nc], written), extra [M, n], next_mul
+        ([M, Nc] with next_mul_act), epi_act, accumulate, from_input.  Every tensor is kept referenced until the call returns."""
+        M, R0 = a0.shape
+        p = _lib.ChainParams()
+        p.A0, p.Y0, p.M, p.R0, p.Y0_act, p.nstages = a0.data_ptr(), (y0.data_ptr() if y0 is not None else None), M, R0, y0_act, len(stages)
+        assert len(stages) <= _lib.CHAIN_MAX_STAGES and a0.dtype == torch.float32 and a0.is_contiguous()
+        for i, st in enumerate(stages):
+            B = st['B']
+            assert B.dtype == torch.float32 and B.is_contiguous() and B.dim() == 2
+            q = p.st[i]
+            q.B, q.R, q.Nc = B.data_ptr(), B.shape[0], B.shape[1]
+            for name in ('bias', 'C', 'extra', 'next_mul'):
+                t = st.get(name)
+                if t is not None:
+                    assert t.dtype == torch.float32 and t.is_contiguous() and t.is_cuda
+                setattr(q, name, t.data_ptr() if t is not None else None)
+            if st.get('C') is not None:
+                assert tuple(st['C'].shape) == (M, q.Nc)
+            q.epi_act, q.accumulate, q.from_input = st.get('epi_act', ACT_NONE), int(bool(st.get('accumulate'))), int(bool(st.get('from_input')))
+            q.n_extra = st['extra'].shape[1] if st.get('extra') is not None else 0
+            q.next_mul_act = st.get('next_mul_act', ACT_NONE)
+        self._timed('tail', 0.0, lambda: self._ck(self.lib.eve_linear_chain(ctypes.byref(p), self._stream())))
+
+    def linear_wgrad_batch(self, problems):
+        """All weight / bias gradients of the tail in one launch.  problems: dicts dY [M,N], Y (or None) + act, X [M,K1], X2 (or
+        None), dW [N,K] (accumulated), db [N] or None."""
+        n = len(problems)
+        assert 0 < n <= _lib.WGRAD_BATCH_MAX
+        arr = (_lib.WgradProblem * n)()
+        for q, pr in zip(arr, problems):
+            dY, X, dW = pr['dY'], pr['X'], pr['dW']
+            for t in (dY, X, dW, pr.get('Y'), pr.get('X2'), pr.get('db')):
+                assert t is None or (t.dtype == torch.float32 and t.is_contiguous() and t.is_cuda)
+            q.dY, q.X, q.dW = dY.data_ptr(), X.data_ptr(), dW.data_ptr()
+            q.Y = pr['Y'].data_ptr() if pr.get('Y') is not None else None
+            q.X2 = pr['X2'].data_ptr() if pr.get('X2') is not None else None
+            q.db = pr['db'].data_ptr() if pr.get('db') is not None else None
+            q.M, q.N, q.K = dY.shape[0], dW.shape[0], dW.shape[1]
+            q.K1, q.K2 = X.shape[1], (pr['X2'].shape[1] if pr.get('X2') is not None else 0)
+            q.act = pr.get('act', ACT_NONE)
+            q.ldY = dY.shape[1] if dY.shape[1] != q.N else 0
+            assert dY.shape[1] >= q.N and q.K1 + q.K2 <= q.K and X.shape[0] == q.M
+            assert pr.get('Y') is None or pr['Y'].shape == dY.shape
+        self._timed('tail', 0.0, lambda: self._ck(self.lib.eve_linear_wgrad_batch(arr, n, self._stream())))
+
     def stem_fused_wgrad_enabled(self):
         return bool(self.dispatch_config().stem_fused_wgrad)
 

@@ -173,6 +173,15 @@ class Conv2dFn(torch.autograd.Function):
             #  result is returned as a separate tensor object over the same storage -- `acc` may itself be a view made
             #  inside another custom Function, which autograd refuses to mark dirty)
             assert epi_act == ACT_NONE and acc.is_contiguous()
+            n_, h_, w_ = x.shape[0], (x.shape[1] + 2 * pad - ks) // stride + 1, (x.shape[2] + 2 * pad - ks) // stride + 1
+            assert tuple(acc.shape) == (n_, h_, w_, cout_p) and acc.dtype == x.dtype, \
+                'accumulate_into: expected %s, got %s' % ((n_, h_, w_, cout_p), tuple(acc.shape))
+            # the kernel overwrites `acc` behind autograd's back: no Function may have SAVED it (its backward would read the
+            # sum).  The contract -- the producer is a Conv2dFn with no epilogue activation, which saves no output -- is
+            # checked where it can be
+            prod = acc.grad_fn
+            assert prod is None or getattr(prod, 'epi_act', ACT_NONE) == ACT_NONE, \
+                'accumulate_into: the producer of `acc` saved its output (activation epilogue)'
             if grouped:             # F pixels as one (narrow layers): same memory, F * C channels per grouped pixel
                 F, wg = pack.pair_fwd
                 N, H, W, C = x.shape
@@ -357,6 +366,176 @@ class LinearFn(torch.autograd.Function):
             elif want_b:
                 db = dbbuf[:O]
         return dx, dw, db, None, None
+
+
+def _pad_bias(bias, n):
+    if bias is None:
+        return None
+    b = bias.detach().float()
+    if b.numel() != n:
+        b = torch.nn.functional.pad(b, (0, n - b.numel()))
+    return b.contiguous()
+
+
+class _TailGrads(object):
+    """Where the weight / bias gradients of a chain's layers go: straight into the flat gradient buffer when the parameter lives
+    there and its pack is unpadded (train.FlatParameters), else into a zeroed temporary that is sliced for autograd."""
+
+    def __init__(self, device):
+        self.device, self.items = device, []
+
+    def target(self, weight, bias, pack, want_w, want_b):
+        cout_p, _, _, cin_p = pack.ohwi.shape
+        O, I = pack.shape_oihw[0], pack.shape_oihw[1]
+        w_dir = want_w and _direct_grad_ok(weight) and (cout_p, cin_p) == (O, I)
+        b_dir = want_b and bias is not None and _direct_grad_ok(bias) and cout_p == O
+        dw = weight.grad.view(O, I) if w_dir else torch.zeros((cout_p, cin_p), dtype=torch.float32, device=self.device)
+        db = None
+        if want_b and bias is not None:
+            db = bias.grad if b_dir else torch.zeros((cout_p,), dtype=torch.float32, device=self.device)
+        self.items.append((weight, bias, pack, want_w, want_b, w_dir, b_dir, dw, db))
+        return dw, db
+
+    def results(self):
+        """-> [(dw or None, db or None)] per target() call, after the gradient launch; notifies the data-parallel bookkeeping."""
+        out = []
+        for weight, bias, pack, want_w, want_b, w_dir, b_dir, dw, db in self.items:
+            O, I = pack.shape_oihw[0], pack.shape_oihw[1]
+            gw = gb = None
+            if w_dir:
+                _notify_grad_ready(weight)
+            elif want_w:
+                gw = dw[:O, :I].reshape(tuple(weight.shape))
+            if b_dir:
+                _notify_grad_ready(bias)
+            elif want_b and bias is not None:
+                gb = db[:O]
+            out.append((gw, gb))
+        return out
+
+
+class TailPreFn(torch.autograd.Function):
+    """gi = W_ih . fc_common( [fc(feats) | head pose] ) + b_ih -- the four linear layers in front of the recurrence
+    (eye_net.py:109-119, torch.nn.GRUCell's input projection) as ONE launch (kernels.linear_chain); backward: one launch for the
+    chain of data gradients, one for the four weight / bias gradients (kernels.linear_wgrad_batch)."""
+
+    @staticmethod
+    def forward(ctx, feats, head_pose, w_fc, b_fc, w0, b0, w2, b2, w_ih, b_ih, packs):
+        k = default_kernels()
+        p_fc, p0, p2, p_ih = packs
+        M = feats.shape[0]
+        dev = feats.device
+        G = p_ih.ohwi.shape[0]
+        new = lambda n: torch.empty((M, n), dtype=torch.float32, device=dev)
+        a0, a1, a2, gi = new(128), new(128), new(128), new(G)
+        cin0 = p0.ohwi.shape[3]
+        hp = head_pose.detach().float().contiguous() if head_pose is not None else None
+        feats = feats.contiguous()
+        k.linear_chain(feats, [
+            dict(B=p_fc.ihwo.view(p_fc.ohwi.shape[3], 128), bias=_pad_bias(b_fc, 128), C=a0, extra=hp),
+            dict(B=p0.ihwo.view(cin0, 128), bias=_pad_bias(b0, 128), C=a1, epi_act=ACT_SELU),
+            dict(B=p2.ihwo.view(128, 128), bias=_pad_bias(b2, 128), C=a2),
+            dict(B=p_ih.ihwo.view(128, G), bias=_pad_bias(b_ih, G), C=gi)])
+        ctx.packs, ctx.params = packs, (w_fc, b_fc, w0, b0, w2, b2, w_ih, b_ih)
+        for i, w_ in enumerate(ctx.params):
+            if w_ is not None and _direct_grad_ok(w_):
+                _note_use(w_, ctx.needs_input_grad[2 + i])
+        ctx.save_for_backward(feats, hp, a0, a1, a2)
+        return gi
+
+    @staticmethod
+    def backward(ctx, d_gi):
+        k = default_kernels()
+        feats, hp, a0, a1, a2 = ctx.saved_tensors
+        p_fc, p0, p2, p_ih = ctx.packs
+        w_fc, b_fc, w0, b0, w2, b2, w_ih, b_ih = ctx.params
+        M, dev = feats.shape[0], feats.device
+        G, cin0 = p_ih.ohwi.shape[0], p0.ohwi.shape[3]
+        d_gi = d_gi.contiguous()
+        new = lambda n: torch.empty((M, n), dtype=torch.float32, device=dev)
+        d_a2, d_a1, d_cat = new(128), new(128), new(cin0)
+        d_feats = new(feats.shape[1]) if ctx.needs_input_grad[0] else None
+        stages = [dict(B=p_ih.ohwi.view(G, 128), C=d_a2),
+                  dict(B=p2.ohwi.view(128, 128), C=d_a1, next_mul=a1, next_mul_act=ACT_SELU),
+                  dict(B=p0.ohwi.view(128, cin0), C=d_cat)]
+        if d_feats is not None:
+            stages.append(dict(B=p_fc.ohwi.view(128, feats.shape[1]), C=d_feats))      # (uses the leading 128 of d_cat's columns)
+        k.linear_chain(d_gi, stages)
+        need = ctx.needs_input_grad
+        tg = _TailGrads(dev)
+        probs = []
+        for (w_, b_, pk, iw, dY, Y, act, X, X2) in ((w_ih, b_ih, p_ih, 8, d_gi, None, ACT_NONE, a2, None),
+                                                    (w2, b2, p2, 6, d_a2, None, ACT_NONE, a1, None),
+                                                    (w0, b0, p0, 4, d_a1, a1, ACT_SELU, a0, hp),
+                                                    (w_fc, b_fc, p_fc, 2, d_cat, None, ACT_NONE, feats, None)):
+            if need[iw] or need[iw + 1]:
+                dw, db = tg.target(w_, b_, pk, need[iw], need[iw + 1])
+                probs.append(dict(dY=dY, Y=Y, act=act, X=X, X2=X2, dW=dw, db=db))
+            else:
+                tg.items.append((w_, b_, pk, False, False, False, False, None, None))
+        if probs:
+            k.linear_wgrad_batch(probs)
+        (g_ih, gb_ih), (g2, gb2), (g0, gb0), (g_fc, gb_fc) = tg.results()
+        return d_feats, None, g_fc, gb_fc, g0, gb0, g2, gb2, g_ih, gb_ih, None
+
+
+class TailHeadsFn(torch.autograd.Function):
+    """(tanh(W_g2 selu(W_g0 h + b)), relu(W_p2 selu(W_p0 h + b) + b)) -- fc_to_gaze and fc_to_pupil (eye_net.py:137-146) on the
+    recurrent features in ONE launch (the second head restarts from the chain's input); backward: one chain per head (the second
+    accumulates onto the first one's input gradient) and one launch for the four weight gradients."""
+
+    @staticmethod
+    def forward(ctx, hs, wg0, bg0, wg2, wp0, bp0, wp2, bp2, packs):
+        k = default_kernels()
+        pg0, pg2, pp0, pp2 = packs
+        M, dev = hs.shape[0], hs.device
+        hs = hs.contiguous()
+        new = lambda n: torch.empty((M, n), dtype=torch.float32, device=dev)
+        ng, npu = pg2.ohwi.shape[0], pp2.ohwi.shape[0]
+        g1, g2, p1, p2_ = new(128), new(ng), new(128), new(npu)
+        k.linear_chain(hs, [
+            dict(B=pg0.ihwo.view(128, 128), bias=_pad_bias(bg0, 128), C=g1, epi_act=ACT_SELU),
+            dict(B=pg2.ihwo.view(128, ng), C=g2, epi_act=ACT_TANH),
+            dict(B=pp0.ihwo.view(128, 128), bias=_pad_bias(bp0, 128), C=p1, epi_act=ACT_SELU, from_input=True),
+            dict(B=pp2.ihwo.view(128, npu), bias=_pad_bias(bp2, npu), C=p2_, epi_act=ACT_RELU)])
+        ctx.packs, ctx.params = packs, (wg0, bg0, wg2, wp0, bp0, wp2, bp2)
+        for i, w_ in enumerate(ctx.params):
+            if w_ is not None and _direct_grad_ok(w_):
+                _note_use(w_, ctx.needs_input_grad[1 + i])
+        ctx.save_for_backward(hs, g1, g2, p1, p2_)
+        return g2, p2_
+
+    @staticmethod
+    def backward(ctx, dg2, dp2):
+        k = default_kernels()
+        hs, g1, g2, p1, p2_ = ctx.saved_tensors
+        pg0, pg2, pp0, pp2 = ctx.packs
+        wg0, bg0, wg2, wp0, bp0, wp2, bp2 = ctx.params
+        M, dev = hs.shape[0], hs.device
+        ng, npu = pg2.ohwi.shape[0], pp2.ohwi.shape[0]
+        dg2 = (dg2 if dg2 is not None else torch.zeros_like(g2)).contiguous()
+        dp2 = (dp2 if dp2 is not None else torch.zeros_like(p2_)).contiguous()
+        new = lambda n: torch.empty((M, n), dtype=torch.float32, device=dev)
+        d_g1, d_p1, d_hs = new(128), new(128), new(128)
+        k.linear_chain(dg2, [dict(B=pg2.ohwi.view(ng, 128), C=d_g1, next_mul=g1, next_mul_act=ACT_SELU),
+                             dict(B=pg0.ohwi.view(128, 128), C=d_hs)], y0=g2, y0_act=ACT_TANH)
+        k.linear_chain(dp2, [dict(B=pp2.ohwi.view(npu, 128), C=d_p1, next_mul=p1, next_mul_act=ACT_SELU),
+                             dict(B=pp0.ohwi.view(128, 128), C=d_hs, accumulate=True)], y0=p2_, y0_act=ACT_RELU)
+        need = ctx.needs_input_grad
+        tg = _TailGrads(dev)
+        probs = []
+        for (w_, b_, pk, iw, ib, dY, Y, act, X) in ((wg0, bg0, pg0, 1, 2, d_g1, g1, ACT_SELU, hs), (wg2, None, pg2, 3, None, dg2, g2, ACT_TANH, g1),
+                                                    (wp0, bp0, pp0, 4, 5, d_p1, p1, ACT_SELU, hs), (wp2, bp2, pp2, 6, 7, dp2, p2_, ACT_RELU, p1)):
+            want_w, want_b = need[iw], (ib is not None and need[ib])
+            if want_w or want_b:
+                dw, db = tg.target(w_, b_, pk, want_w, want_b)
+                probs.append(dict(dY=dY, Y=Y, act=act, X=X, dW=dw, db=db))
+            else:
+                tg.items.append((w_, b_, pk, False, False, False, False, None, None))
+        if probs:
+            k.linear_wgrad_batch(probs)
+        (gg0, gbg0), (gg2, _), (gp0, gbp0), (gp2, gbp2) = tg.results()
+        return (d_hs if need[0] else None), gg0, gbg0, gg2, gp0, gbp0, gp2, gbp2, None
 
 
 def linear(x2d, weight, bias, pack, act=ACT_NONE):
@@ -582,6 +761,10 @@ class InstNormAct2Fn(torch.autograd.Function):
         k = default_kernels()
         f32 = lambda t: t.detach().float().contiguous()
         ga, ba, gb, bb = f32(gamma_a), f32(beta_a), f32(gamma_b), f32(beta_b)
+        ctot = sum(x.shape[-1] for x in xs)
+        assert ga.numel() == ba.numel() == gb.numel() == bb.numel() == ctot, \
+            'affine parameters must cover the concatenated channels exactly (%d), got %d' % (ctot, ga.numel())
+        assert all(x.is_contiguous() and x.dtype == xs[0].dtype and x.shape[:3] == xs[0].shape[:3] for x in xs)
         mrs = [k.instnorm_stats(x, eps) for x in xs]
         out_a, out_b = k.instnorm_act2_fwd(xs, mrs, ga, ba, gb, bb, act)      # both sources, both heads: one launch
         ctx.act, ctx.n = act, len(xs)
@@ -593,6 +776,10 @@ class InstNormAct2Fn(torch.autograd.Function):
         k = default_kernels()
         ga, ba, gb, bb = ctx.saved_tensors[:4]
         xs, mrs = ctx.saved_tensors[4:4 + ctx.n], ctx.saved_tensors[4 + ctx.n:]
+        if d_a is None or d_b is None:                      # one head unused downstream: its gradient is zero
+            ref = d_a if d_a is not None else d_b
+            d_a = d_a if d_a is not None else torch.zeros_like(ref)
+            d_b = d_b if d_b is not None else torch.zeros_like(ref)
         dxs, sa, sb = k.instnorm_act2_bwd(d_a.contiguous(), d_b.contiguous(), xs, mrs, ga, ba, gb, bb, ctx.act)
         sa, sb = k.sum_rows(sa), k.sum_rows(sb)         # [C, 2]: N-reduction of the per-plane partials, fixed order
         return (None, None, sa[:, 1], sa[:, 0], sb[:, 1], sb[:, 0]) + tuple(dxs)
