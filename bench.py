@@ -353,6 +353,8 @@ def main():
     # hipGraph; with several ranks the bucket all-reduces (RCCL), the clip and Adam are launched eagerly behind each replay
     # (tests/test_gpu_data_parallel.py runs exactly this with two ranks), or captured too with --graph-collectives.
     use_graph = not args.no_graph
+    # (EVE_AMD_FORCE_DIST=1: a one-rank RCCL group on a one-GPU box -- the transport and the bucket launches with world = 1)
+    distributed = world > 1 or os.environ.get('EVE_AMD_FORCE_DIST', '0') == '1'
 
     if args.workload == 'c2':
         cfg = eve_amd.reset_standalone_config()
@@ -361,7 +363,7 @@ def main():
         net = eve_amd.EyeNet()
         net.compute_dtype = TORCH_DTYPE[args.dtype]
         net.to(device)
-        trainer = train.eyenet_trainer(net, cfg, distributed=world > 1, use_graph=use_graph)
+        trainer = train.eyenet_trainer(net, cfg, distributed=distributed, use_graph=use_graph)
         trainer.static_inputs = 'alias'      # the synthetic batch stays in the same device buffers: the graph reads it in place
         batch = synthetic_eyenet_batch(args.batch, args.seq, args.size, device, 1000 * rank)
         gflop_per_frame = EYENET_TRAIN_GFLOP_PER_FRAME_128 if args.size == 128 else None
@@ -371,7 +373,7 @@ def main():
         import numpy as np
         np.random.seed(1000 * rank)          # per-rank kappa_fake streams
         trainer, batch, cfg = pipeline_setup(args, device, args.workload, args.batch, args.seq, args.size, args.dtype, use_graph,
-                                             distributed=world > 1, seed=1 + rank)
+                                             distributed=distributed, seed=1 + rank)
         net = None
         gflop_per_frame = PIPELINE_GFLOP.get((args.workload, args.size))
         workload = ('BASELINE configs[%s]: eve_amd.EVE pipeline (%s), %dx%d patches, fwd+bwd+clip+Adam'
@@ -429,7 +431,7 @@ def main():
             'config': {'workload': workload, 'global_batch': world * args.batch, 'batch_per_gpu': args.batch, 'seq_len': args.seq,
                        'parallelism': 'dp%d' % world},
             'final_loss': loss, 'hip_graph': use_graph, 'graph_collectives': bool(getattr(trainer, 'graph_collectives', False)),
-            'collectives': None if world == 1 else ('captured in the hipGraph' if getattr(trainer, 'graph_collectives', False) else
+            'collectives': None if not distributed else ('captured in the hipGraph' if getattr(trainer, 'graph_collectives', False) else
                                                     ('eager RCCL launches behind each hipGraph replay' if use_graph else 'eager, overlapped with backward')),
             'ranks_seen': ranks_seen, 'optimizer': trainer.optimizer_state(),
             'kernel_tree_sha': __import__('eve_amd.build', fromlist=['kernel_tree_sha']).kernel_tree_sha(),

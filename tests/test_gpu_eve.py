@@ -410,13 +410,16 @@ def test_eve_trainer_hipgraph_replay_equals_eager_steps(dtype):
         tr = train.eve_trainer(model, cfg, use_graph=(mode == 'graph'))
         np.random.seed(7)
         log = []
+        first_grad = None
         for _ in range(3):
             terms = tr.step(batch)
             log.append({k: float(terms[k].detach()) for k in ('full_loss', 'loss_ce_heatmap_final', 'metric_euc_PoG_px_initial',
                                                               'metric_euc_PoG_px_final')})
+            if first_grad is None:
+                first_grad = tr.fp.grad.clone()         # (graph mode: capture + the first replay have run; this is step 1's)
         torch.cuda.synchronize()
         assert tr.optimizer_state()['steps_taken'] == 3
-        runs[mode] = (log, tr.fp.grad.clone())
+        runs[mode] = (log, first_grad)
         model.drop_static_kappa()
     tol = 2e-5 if dtype == torch.float32 else 2e-2
     for a, b in zip(runs['eager'][0], runs['graph'][0]):
@@ -424,13 +427,9 @@ def test_eve_trainer_hipgraph_replay_equals_eager_steps(dtype):
             assert abs(a[k] - b[k]) <= tol * max(1.0, abs(a[k])), (k, a[k], b[k])
     # the three draws differ from one another (the augmentation is live) ...
     assert len({round(s['metric_euc_PoG_px_initial'], 3) for s in runs['graph'][0]}) == 3
-    # ... and the third step's gradient is the eager one's (weight-gradient atomics and, in bf16, the rounding flips two
-    # earlier Adam steps seed: the envelope tests/test_gpu_data_parallel.py uses for its graph cases)
+    # ... and the FIRST step's gradient is the eager one's up to the weight-gradient atomics' order (later steps' gradients are
+    # not comparable: ulp-level weight differences move these ill-conditioned gradients by per cents -- 3 - 5 % measured in
+    # float32, 38 % in bf16 -- see check_grads_against_float64_reference; the per-step LOSSES above are the check for steps 2, 3)
     ge, gg = runs['eager'][1], runs['graph'][1]
-    # (float32 too: ulp-level weight differences after two Adam steps move these ill-conditioned gradients by per cents --
-    #  see check_grads_against_float64_reference; the per-step LOSSES above are the tight check of the plumbing)
-    # (bf16: rounding flips after two Adam steps decorrelate this ill-conditioned gradient altogether -- 38 % measured; the
-    #  float32 case carries the gradient check, both carry the per-step losses)
-    if dtype == torch.float32:
-        assert float((ge - gg).norm() / ge.norm()) < 5e-2
+    assert float((ge - gg).norm() / ge.norm()) < (1e-4 if dtype == torch.float32 else 2e-2)
     eve_amd.reset_standalone_config()
