@@ -22,10 +22,10 @@ class DispatchConfig(Structure):
         'struct_bytes', 'conv_impl_v1', 'conv_tile_big', 'conv_halo', 'conv_ws64', 'conv_wg8', 'conv_wg8_min_tiles',
         'conv_wg8_s2_min_tiles', 'halo_persist', 'wgrad_target_wgs', 'wgrad_min_rows', 'wgrad_halo', 'wgrad_wg8',
         'wg64_th', 'wg64_nreg', 'wg64_fixed', 'in_split', 'in_min_threads', 'in_stats_one_pass', 'stem_split',
-        'in_trunk_kernels', 'stem_fused_wgrad', 'reserved1')] + [('wgrad_halo_min_m', c_longlong)]
+        'in_trunk_kernels', 'stem_fused_wgrad', 'stem_fwd_pairs')] + [('wgrad_halo_min_m', c_longlong)]
 
     def as_dict(self):
-        return {n: int(getattr(self, n)) for n, _ in self._fields_ if n not in ('struct_bytes', 'reserved1')}
+        return {n: int(getattr(self, n)) for n, _ in self._fields_ if n != 'struct_bytes'}
 
 
 class ChainStage(Structure):
@@ -48,10 +48,10 @@ class WgradProblem(Structure):
     """include/eve_hip.h eve_wgrad_problem"""
     _fields_ = [('dY', c_void_p), ('Y', c_void_p), ('X', c_void_p), ('X2', c_void_p), ('dW', c_void_p), ('db', c_void_p),
                 ('M', c_int), ('N', c_int), ('K', c_int), ('K1', c_int), ('K2', c_int), ('act', c_int), ('rows_per_split', c_int),
-                ('ldY', c_int)]
+                ('ldY', c_int), ('ldX', c_int), ('ldW', c_int), ('x_shift_T', c_int), ('reserved', c_int)]
 
 
-WGRAD_BATCH_MAX = 8
+WGRAD_BATCH_MAX = 12
 
 P = c_void_p
 I = c_int
@@ -104,6 +104,10 @@ SIGNATURES = {
     'eve_linear_dgrad': [I, I, I, P, P, I, P, P, P],
     'eve_linear_wgrad': [I, I, I, P, P, I, P, P, P, P],
     'eve_linear_chain': [POINTER(ChainParams), P],
+    'eve_linear_fwd_ex': [I, I, I, P, I, P, P, I, I, P, I, P],
+    'eve_linear_dgrad_ex': [I, I, I, P, I, P, I, P, P, I, I, P],
+    'eve_tail_outputs_fwd': [I, P, P, P, P, P],
+    'eve_tail_outputs_bwd': [I, P, P, P, P, P, F, F, P, P, P],
     'eve_linear_wgrad_batch': [POINTER(WgradProblem), I, P],
     'eve_instnorm_stats': [I, I, I, I, P, F, P, P],
     'eve_instnorm_act_fwd': [I, I, I, I, P, P, P, P, P, I, P, P],

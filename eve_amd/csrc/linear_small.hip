@@ -18,10 +18,15 @@ constexpr int LS_TM = 8, LS_TN = 128, LS_KC = 32;     // 8 rows per workgroup: 2
 // C[M][Nc] = epi( A'[M][R] . B[R][Nc] ),  A' = A * act'(Y) if Y (same shape as A), epi = act(. + bias).
 // Both operand chunks go through LDS; the next chunk is fetched into registers while the current one is consumed
 // (each workgroup is alone on its SIMDs, so nothing else hides the L2 latency).
+// lda: row stride of A and Y (the leading R columns of a wider matrix), ldc: row stride of C (a column range of a wider one),
+// n_bias: entries of `bias` that exist (columns beyond take 0), accumulate: C += result (round 4: the tail as one autograd node
+// writes fc's output into the head-pose concatenation, reads fc's gradient out of the concatenation's, and sums the two heads'
+// input gradients in the second head's epilogue -- no cat / pad / slice / add launches)
 __global__ __launch_bounds__(256) void linear_mm_kernel(const float* __restrict__ A, const float* __restrict__ Y, const int pro_act,
                                                         const float* __restrict__ B, const float* __restrict__ bias,
                                                         const int epi_act, float* __restrict__ C, const int M, const int R,
-                                                        const int Nc) {
+                                                        const int Nc, const int lda, const int ldc, const int n_bias,
+                                                        const int accumulate) {
     __shared__ float sA[LS_TM][LS_KC + 4];
     __shared__ float sB[LS_KC][LS_TN];
     const int tid = threadIdx.x;
@@ -39,8 +44,8 @@ __global__ __launch_bounds__(256) void linear_mm_kernel(const float* __restrict_
             const int m = m0 + e / LS_KC, k = k0 + e % LS_KC;
             float v = 0.f;
             if (m < M && k < R) {
-                v = A[(size_t)m * R + k];
-                if (Y) v *= act_grad_from_out(Y[(size_t)m * R + k], pro_act);
+                v = A[(size_t)m * lda + k];
+                if (Y) v *= act_grad_from_out(Y[(size_t)m * lda + k], pro_act);
             }
             pa[i] = v;
         }
@@ -76,11 +81,16 @@ __global__ __launch_bounds__(256) void linear_mm_kernel(const float* __restrict_
         }
     }
     if (col >= Nc) return;
-    const float bv = bias ? bias[col] : 0.f;
+    const float bv = (bias && col < n_bias) ? bias[col] : 0.f;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int m = m0 + rg * 4 + i;
-        if (m < M) C[(size_t)m * Nc + col] = act_fwd(acc[i] + bv, epi_act);
+        if (m < M) {
+            float v = act_fwd(acc[i] + bv, epi_act);
+            float* c = C + (size_t)m * ldc + col;
+            if (accumulate) v += *c;
+            *c = v;
+        }
     }
 }
 
@@ -158,7 +168,7 @@ extern "C" int eve_linear_fwd(int M, int K, int N, const float* x, const float* 
     if (int e = ls_check(M, K, N, "linear_fwd: bad shape")) return e;
     if (!x || !w_in_out || !y) return set_error_msg("linear_fwd: null pointer");
     hipLaunchKernelGGL(linear_mm_kernel, dim3((M + LS_TM - 1) / LS_TM, (N + LS_TN - 1) / LS_TN), dim3(256), 0, (hipStream_t)stream,
-                       x, (const float*)nullptr, 0, w_in_out, bias, act, y, M, K, N);
+                       x, (const float*)nullptr, 0, w_in_out, bias, act, y, M, K, N, K, N, N, 0);
     EVE_CHECK_LAUNCH();
     return 0;
 }
@@ -168,7 +178,7 @@ extern "C" int eve_linear_dgrad(int M, int K, int N, const float* dy, const floa
     if (int e = ls_check(M, K, N, "linear_dgrad: bad shape")) return e;
     if (!dy || !w_out_in || !dx || (act != EVE_ACT_NONE && !y)) return set_error_msg("linear_dgrad: null pointer");
     hipLaunchKernelGGL(linear_mm_kernel, dim3((M + LS_TM - 1) / LS_TM, (K + LS_TN - 1) / LS_TN), dim3(256), 0, (hipStream_t)stream,
-                       dy, act != EVE_ACT_NONE ? y : (const float*)nullptr, act, w_out_in, (const float*)nullptr, 0, dx, M, N, K);
+                       dy, act != EVE_ACT_NONE ? y : (const float*)nullptr, act, w_out_in, (const float*)nullptr, 0, dx, M, N, K, N, K, 0, 0);
     EVE_CHECK_LAUNCH();
     return 0;
 }
@@ -350,7 +360,11 @@ __global__ __launch_bounds__(256) void linear_wgrad_batch_kernel(const eve_wgrad
                 if (k < q.K && r0 + j < rmax) {
                     const int m = mc + r0 + j;
                     // X may be a concatenation [X | X2] (fc_common.0's input: fc's output and the head pose)
-                    xv = k < q.K1 ? q.X[(size_t)m * q.K1 + k] : (k - q.K1 < q.K2 ? q.X2[(size_t)m * q.K2 + (k - q.K1)] : 0.f);
+                    if (q.x_shift_T) {                      // X row m - 1 within the sequence, zero at its first step (h_prev of a scan)
+                        xv = (m % q.x_shift_T) ? q.X[(size_t)(m - 1) * (q.ldX ? q.ldX : q.K1) + k] : 0.f;
+                    } else {
+                        xv = k < q.K1 ? q.X[(size_t)m * (q.ldX ? q.ldX : q.K1) + k] : (k - q.K1 < q.K2 ? q.X2[(size_t)m * q.K2 + (k - q.K1)] : 0.f);
+                    }
                 }
                 xr[j] = xv;
             }
@@ -372,7 +386,7 @@ __global__ __launch_bounds__(256) void linear_wgrad_batch_kernel(const eve_wgrad
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int n = n0 + ng * 8 + i;
-            if (n < q.N) atomicAdd(q.dW + (size_t)n * q.K + k, acc[i]);
+            if (n < q.N) atomicAdd(q.dW + (size_t)n * (q.ldW ? q.ldW : q.K) + k, acc[i]);
         }
     }
     if (q.db && bx == 0 && tid < 32 && n0 + tid < q.N) atomicAdd(q.db + n0 + tid, bsum);
@@ -421,6 +435,72 @@ extern "C" int eve_linear_wgrad_batch(const eve_wgrad_problem* problems, int n, 
         total += tiles * splits;
     }
     hipLaunchKernelGGL(linear_wgrad_batch_kernel, dim3(total), dim3(256), 0, (hipStream_t)stream, b);
+    EVE_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int eve_linear_fwd_ex(int M, int K, int N, const float* x, int ldx, const float* w_in_out, const float* bias, int n_bias,
+                                 int act, float* y, int ldy, eve_stream_t stream) {
+    if (int e = ls_check(M, K, N, "linear_fwd_ex: bad shape")) return e;
+    if (!x || !w_in_out || !y || ldx < K || ldy < N) return set_error_msg("linear_fwd_ex: bad arguments");
+    hipLaunchKernelGGL(linear_mm_kernel, dim3((M + LS_TM - 1) / LS_TM, (N + LS_TN - 1) / LS_TN), dim3(256), 0, (hipStream_t)stream,
+                       x, (const float*)nullptr, 0, w_in_out, bias, act, y, M, K, N, ldx, ldy, bias ? n_bias : 0, 0);
+    EVE_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int eve_linear_dgrad_ex(int M, int K, int N, const float* dy, int lddy, const float* y, int act, const float* w_out_in,
+                                   float* dx, int lddx, int accumulate, eve_stream_t stream) {
+    if (int e = ls_check(M, K, N, "linear_dgrad_ex: bad shape")) return e;
+    if (!dy || !w_out_in || !dx || (act != EVE_ACT_NONE && !y) || lddy < N || lddx < K) return set_error_msg("linear_dgrad_ex: bad arguments");
+    hipLaunchKernelGGL(linear_mm_kernel, dim3((M + LS_TM - 1) / LS_TM, (K + LS_TN - 1) / LS_TN), dim3(256), 0, (hipStream_t)stream,
+                       dy, act != EVE_ACT_NONE ? y : (const float*)nullptr, act, w_out_in, (const float*)nullptr, 0, dx, M, N, K, lddy, lddx, 0,
+                       accumulate);
+    EVE_CHECK_LAUNCH();
+    return 0;
+}
+
+namespace eve {
+// gaze = pi/2 * tanh-output columns 0, 1 and pupil = ReLU-output column 0 of the two heads' 4-wide (padded) last layers,
+// contiguous -- and the way back: d(head outputs) from the loss kernel's per-side unit gradients, scaled by d(full loss) read
+// from the device.  One launch each instead of slice / mul / select and their backward's zeros + copies + adds.
+__global__ __launch_bounds__(256) void tail_outputs_fwd_kernel(const int M, const float* __restrict__ g2, const float* __restrict__ p2,
+                                                               float* __restrict__ gaze, float* __restrict__ pupil) {
+    const int m = blockIdx.x * 256 + threadIdx.x;
+    if (m >= M) return;
+    const float4 g = reinterpret_cast<const float4*>(g2)[m];
+    gaze[2 * m] = 1.5707963267948966f * g.x;
+    gaze[2 * m + 1] = 1.5707963267948966f * g.y;
+    pupil[m] = p2[4 * m];
+}
+__global__ __launch_bounds__(256) void tail_outputs_bwd_kernel(const int BT, const float* __restrict__ dg_l, const float* __restrict__ dg_r,
+                                                               const float* __restrict__ dp_l, const float* __restrict__ dp_r,
+                                                               const float* __restrict__ g_full, const float c_ang, const float c_l1,
+                                                               float* __restrict__ d_g2, float* __restrict__ d_p2) {
+    const int m = blockIdx.x * 256 + threadIdx.x;
+    if (m >= 2 * BT) return;
+    const float up = g_full ? *g_full : 1.f;
+    const bool right = m >= BT;
+    const int i = right ? m - BT : m;
+    const float* dg = right ? dg_r : dg_l;
+    const float* dp = right ? dp_r : dp_l;
+    const float sa = 1.5707963267948966f * c_ang * up, sl = c_l1 * up;
+    reinterpret_cast<float4*>(d_g2)[m] = make_float4(sa * dg[2 * i], sa * dg[2 * i + 1], 0.f, 0.f);
+    reinterpret_cast<float4*>(d_p2)[m] = make_float4(sl * dp[i], 0.f, 0.f, 0.f);
+}
+}  // namespace eve
+
+extern "C" int eve_tail_outputs_fwd(int M, const float* g2, const float* p2, float* gaze, float* pupil, eve_stream_t stream) {
+    if (M <= 0 || !g2 || !p2 || !gaze || !pupil) return set_error_msg("tail_outputs_fwd: bad arguments");
+    hipLaunchKernelGGL(tail_outputs_fwd_kernel, dim3((M + 255) / 256), dim3(256), 0, (hipStream_t)stream, M, g2, p2, gaze, pupil);
+    EVE_CHECK_LAUNCH();
+    return 0;
+}
+extern "C" int eve_tail_outputs_bwd(int BT, const float* dg_l, const float* dg_r, const float* dp_l, const float* dp_r, const float* g_full,
+                                    float coeff_ang, float coeff_l1, float* d_g2, float* d_p2, eve_stream_t stream) {
+    if (BT <= 0 || !dg_l || !dg_r || !dp_l || !dp_r || !d_g2 || !d_p2) return set_error_msg("tail_outputs_bwd: bad arguments");
+    hipLaunchKernelGGL(tail_outputs_bwd_kernel, dim3((2 * BT + 255) / 256), dim3(256), 0, (hipStream_t)stream, BT, dg_l, dg_r, dp_l, dp_r,
+                       g_full, coeff_ang, coeff_l1, d_g2, d_p2);
     EVE_CHECK_LAUNCH();
     return 0;
 }

@@ -326,6 +326,212 @@ __global__ __launch_bounds__(64 * SF_WAVES) void stem_fwd_fused_kernel(const int
 }
 
 // =================================================================================================
+// Round 4: the fused forward with TWO waves per image, 32 output channels each (wave h owns co = 16 g + 8 h + 0..7).
+// With one wave per image the kernel's duration is the latency of one image (112 MFMAs + ~850 VALU per row in one
+// dependent chain, matrix pipe 31 % busy) and the 15 KB input ring per wave caps a CU at 8 waves.  Statistics and the
+// pooling keys are per channel, so two waves can share an image's ring (each stages one of the two new rows per conv
+// row; one workgroup barrier per row) and split the channels: 16 waves per CU on the same LDS, half the work per wave.
+// Per-channel arithmetic is stem_fwd_fused_kernel's (same MFMA sequence, same keys); the plane sums are accumulated over
+// all rows per lane and reduced once (the one-wave kernel parks the upper half's sums at the middle row for bit-equality
+// with its own row-split mode, which this kernel does not have: every batch size runs the same code).
+// =================================================================================================
+constexpr int SP_PAIRS = 8;                       // images per workgroup and turn
+
+// Rendezvous of the two waves of an image through an LDS word each (monotone counters): publish mine, wait for the partner's.
+// A workgroup barrier per row also re-aligns the OTHER pairs: all 16 waves then issue their fragment reads, their MFMAs and
+// their pooling VALU at the same moments (SQ counters of the barrier version: 25 % of the wave cycles stalled on LDS issue,
+// 44 % parked).  LDS operations of one wave are served in order, so whatever the partner issued before its publish -- its
+// reads of the ring included -- is behind it.
+__device__ __forceinline__ void sf_pair_sync(uint32_t my_flag, uint32_t partner_flag, int value) {
+    *(volatile EVE_LDS int*)(size_t)my_flag = value;
+    while (*(volatile EVE_LDS int*)(size_t)partner_flag < value) __builtin_amdgcn_s_sleep(1);
+}
+
+template <typename H>
+__global__ __launch_bounds__(1024) void stem_fwd_pairs_kernel(const int N, const int IH, const H* __restrict__ xp, const uint32_t xp_bytes,
+                                                              const H* __restrict__ w8, const float eps, H* yp, uint8_t* __restrict__ idx,
+                                                              float* __restrict__ mr) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const sW = smem + SP_PAIRS * SF_RING * SF_ROWB;
+    int* const sFlag = reinterpret_cast<int*>(sW + SF_WBYTES);
+    const int tid = threadIdx.x;
+    sf_fill_weights<H>(sW, w8, tid, 1024);
+    if (tid < 16) sFlag[tid] = 0;
+    __syncthreads();
+
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int pair = wave >> 1, h = wave & 1;
+    const int li = lane & 15, lg = lane >> 4;
+    const int OH = IH / 2, PH = OH / 2, rows = IH + 6;
+    const uint32_t ring = lds_addr_of(smem) + pair * (SF_RING * SF_ROWB);
+    const uint32_t xoff = 16 * (2 * li + lg);
+    const uint32_t wbase = lds_addr_of(sW) + (2 * h) * 1024 + li * 64 + ((lg ^ (((li >> 2) & 1) << 1)) << 4);
+    const eve_int4 rs = make_rsrc_words(xp, xp_bytes);
+    const float inv_hw = 1.f / (float)(OH * 64);
+    const int ch0 = lg * 16 + 8 * h;                      // the lane's 8 channels
+    const uint32_t my_flag = lds_addr_of(sFlag) + wave * 4, partner_flag = lds_addr_of(sFlag) + (wave ^ 1) * 4;
+    int tick = 0;
+    // stagger the pairs (nothing inside the loop re-aligns them): a quarter of a row per step of the pair index modulo 4
+    __builtin_amdgcn_s_sleep(1);
+    for (int d = 0; d < (pair & 3); ++d) __builtin_amdgcn_s_sleep(12);
+
+    const int per_turn = gridDim.x * SP_PAIRS;
+    const int turns = (N + per_turn - 1) / per_turn;
+    for (int turn = 0; turn < turns; ++turn) {
+        const int n = turn * per_turn + pair * (int)gridDim.x + (int)blockIdx.x;
+        if (n >= N) break;                                        // (uniform per pair; later turns have no image either)
+        const bool live = true;
+        const int nn = n;
+        const int img_off = nn * rows * SF_XROW;
+        for (int r = h; r < 9; r += 2) sf_stage_row(rs, ring, r, rows, img_off, lane);
+        float S[2][4], Q[2][4];
+        uint32_t M[2][2][4];
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) { S[a][b] = 0.f; Q[a][b] = 0.f; M[0][a][b] = SF_NEG; M[1][a][b] = SF_NEG; }
+        H* yimg = yp + (size_t)nn * PH * 32 * 64;
+        uint8_t* iimg = idx + (size_t)nn * PH * 32 * 64;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        sf_pair_sync(my_flag, partner_flag, ++tick);
+        int slot0 = 0;
+        for (int oy = 0; oy < OH; ++oy) {
+            // this wave's row of two iterations ago has landed once at most the newer operations are outstanding: one row
+            // (2 DMAs) and, behind an odd row, its 4 stores (the first rows of an image were waited for above)
+            if (oy >= 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            sf_pair_sync(my_flag, partner_flag, ++tick);
+            sf_stage_row(rs, ring, 2 * oy + 9 + h, rows, img_off, lane);
+            if (live) {
+                f32x4_t acc[4][2];
+                {
+                    auto conv_frags = [&](int kh, uint4 (&x4)[4], uint4 (&w2)[2]) {
+                        int slot = slot0 + kh;
+                        slot = slot >= SF_RING ? slot - SF_RING : slot;
+                        const uint32_t xa = ring + slot * SF_ROWB + xoff, wa = wbase + kh * 4096;
+#pragma unroll
+                        for (int mt = 0; mt < 4; ++mt) x4[mt] = sf_lds_read(xa + (mt & 1) * 16 + (mt >> 1) * 512);
+#pragma unroll
+                        for (int nt = 0; nt < 2; ++nt) w2[nt] = sf_lds_read(wa + nt * 1024);
+                    };
+                    auto conv_mfma = [&](bool first, const uint4 (&x4)[4], const uint4 (&w2)[2]) {
+#pragma unroll
+                        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                            for (int mt = 0; mt < 4; ++mt) {
+                                if (first) acc[mt][nt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+                                Elem<H>::mfma(acc[mt][nt], w2[nt], x4[mt]);
+                            }
+                    };
+                    uint4 fxa[4], fwa[2], fxb[4], fwb[2];
+                    conv_frags(0, fxa, fwa);
+                    conv_frags(1, fxb, fwb);
+                    conv_mfma(true, fxa, fwa);
+#pragma unroll
+                    for (int kh = 2; kh < 6; kh += 2) {
+                        conv_frags(kh, fxa, fwa);
+                        conv_mfma(false, fxb, fwb);
+                        conv_frags(kh + 1, fxb, fwb);
+                        conv_mfma(false, fxa, fwa);
+                    }
+                    conv_frags(6, fxa, fwa);
+                    conv_mfma(false, fxb, fwb);
+                    conv_mfma(false, fxa, fwa);
+                }
+                // ---- plane statistics ----
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float s = 0.f, q = 0.f;
+#pragma unroll
+                        for (int mt = 0; mt < 4; ++mt) { const float v = acc[mt][nt][r]; s += v; q += v * v; }
+                        S[nt][r] += s; Q[nt][r] += q;
+                    }
+                // ---- 3x3/2 max-pool on keys (see stem_fwd_fused_kernel) ----
+                const bool odd = oy & 1;
+                const uint32_t khbits = odd ? 0u : 4u;
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        uint32_t carry = 0;
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) {
+                            const float ef = acc[2 * j][nt][r], of = acc[2 * j + 1][nt][r];
+                            const uint32_t e = (__builtin_bit_cast(uint32_t, ef) & 0xfffffff0u) | (khbits | 1u);
+                            const uint32_t o = (__builtin_bit_cast(uint32_t, of) & 0xfffffff0u) | khbits;
+                            const uint32_t ol = (__builtin_bit_cast(uint32_t, of) & 0xfffffff0u) | (khbits | 2u);
+                            const uint32_t edge = j == 0 ? SF_NEG : sf_dpp<0x121>(0u, carry);          // row_ror:1
+                            const uint32_t l = sf_dpp<0x111>(edge, ol);                                  // row_shr:1
+                            carry = ol;
+                            const float hm = sf_fmax3(__builtin_bit_cast(float, l), __builtin_bit_cast(float, e), __builtin_bit_cast(float, o));
+                            const uint32_t hb = __builtin_bit_cast(uint32_t, hm);
+                            const float m = fmaxf(__builtin_bit_cast(float, M[j][nt][r]), hm);
+                            M[j][nt][r] = odd ? (hb | 8u) : __builtin_bit_cast(uint32_t, m);
+                            acc[2 * j][nt][r] = m;
+                        }
+                    }
+                if (odd) {
+                    const int py = oy >> 1;
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const size_t o = ((size_t)py * 32 + li + 16 * j) * 64 + ch0;
+                        uint32_t pk[4], ib[2];
+#pragma unroll
+                        for (int nt = 0; nt < 2; ++nt) {
+                            uint32_t code[4];
+                            float val[4];
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                const float kf = acc[2 * j][nt][r];
+                                const uint32_t k = __builtin_bit_cast(uint32_t, kf);
+                                val[r] = __builtin_bit_cast(float, k & 0xfffffff0u);
+                                code[r] = (uint32_t)(0x01203450678ull >> ((k & 15u) * 4)) & 15u;       // kh*3 + kw
+                            }
+                            pk[2 * nt] = Elem<H>::pack2(val[0], val[1]);
+                            pk[2 * nt + 1] = Elem<H>::pack2(val[2], val[3]);
+                            ib[nt] = code[0] | (code[1] << 8) | (code[2] << 16) | (code[3] << 24);
+                        }
+                        *reinterpret_cast<uint4*>(yimg + o) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+                        *reinterpret_cast<uint2*>(iimg + o) = make_uint2(ib[0], ib[1]);
+                    }
+                }
+            }
+            slot0 = slot0 + 2 >= SF_RING ? slot0 + 2 - SF_RING : slot0 + 2;
+        }
+        if (live) {
+            // ---- plane statistics -> mean / rstd of the lane's 8 channels; normalise the wave's own pooled values in place ----
+            float mean[2][4], rstd[2][4];
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float s = sf_row_sum16(S[nt][r]) * inv_hw, q = sf_row_sum16(Q[nt][r]) * inv_hw;
+                    const float var = fmaxf(q - s * s, 0.f);
+                    mean[nt][r] = s;
+                    rstd[nt][r] = rsqrtf(var + eps);
+                    if (li == 0) {
+                        float* m = mr + ((size_t)nn * 64 + ch0 + nt * 4 + r) * 2;
+                        m[0] = s; m[1] = rstd[nt][r];
+                    }
+                }
+            for (int py = 0; py < PH; ++py)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    H* p = yimg + ((size_t)py * 32 + li + 16 * j) * 64 + ch0;
+                    float f[8];
+                    Elem<H>::unpack(*reinterpret_cast<const uint4*>(p), f);
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) f[c] = fmaxf((f[c] - mean[c >> 2][c & 3]) * rstd[c >> 2][c & 3], 0.f);
+                    *reinterpret_cast<uint4*>(p) = Elem<H>::pack(f);
+                }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        sf_pair_sync(my_flag, partner_flag, ++tick);              // the ring is rewritten by the next turn
+    }
+}
+
+// =================================================================================================
 // Backward of the fused stem up to the convolution output:  d(conv1 out) from d(pooled output).
 // The convolution output was never stored, so the wave recomputes it row by row exactly as the forward did
 // (same MFMA sequence, bit-identical values) and applies, per pixel,
@@ -855,6 +1061,20 @@ extern "C" int eve_stem_fwd_fused(int dtype, int N, int IH, int IW, const void* 
         (void)hipFuncSetAttribute((const void*)stem_fwd_fused_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void*)stem_fwd_fused_kernel<f16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
+    }
+    if (g_cfg.stem_fwd_pairs) {      // round 4: two waves per image, 32 channels each, 16 waves per CU
+        static bool attr2 = false;
+        if (!attr2) {
+            (void)hipFuncSetAttribute((const void*)stem_fwd_pairs_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void*)stem_fwd_pairs_kernel<f16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            attr2 = true;
+        }
+        const size_t lds2 = (size_t)SP_PAIRS * SF_RING * SF_ROWB + SF_WBYTES + 64;
+        const unsigned blocks2 = N < 256 ? (unsigned)N : 256u;
+        EVE_DISPATCH_H16(dtype, EVE_LAUNCH(EVE_HNAME(H, "stem_fwd_pairs_kernel<", ">"), stem_fwd_pairs_kernel<H>, dim3(blocks2), dim3(1024), lds2,
+                                           (hipStream_t)stream, N, IH, (const H*)x_padded, (uint32_t)xb, (const H*)w_ohwi8, eps, (H*)y_pool, idx, mean_rstd));
+        EVE_CHECK_LAUNCH();
+        return 0;
     }
     // two waves per image while that still fits the 256 x 8 wave slots (B <= 16 clips per GPU): see the kernel
     const int split = g_cfg.stem_split;

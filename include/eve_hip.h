@@ -76,7 +76,7 @@ typedef struct eve_dispatch_config {
     int stem_split;                /* EVE_STEM_SPLIT        1   two waves per image in the fused stem at small batches     */
     int in_trunk_kernels;          /* EVE_IN_TRUNK          1   branch-free InstanceNorm kernels for the ResNet trunk's cases */
     int stem_fused_wgrad;          /* EVE_STEM_FUSED_WGRAD  1   stem backward + weight gradient in one launch (eve_stem_bwd_wgrad) */
-    int reserved1;
+    int stem_fwd_pairs;            /* EVE_STEM_FWD_PAIRS    1   fused stem forward with two waves per image (32 channels each)       */
     long long wgrad_halo_min_m;    /* EVE_WGRAD_HALO_MIN_M  1<<20 pixels from which the band-resident weight gradient runs */
 } eve_dispatch_config;
 int eve_get_dispatch_config(eve_dispatch_config* out);           /* what the entry points use now                         */
@@ -173,6 +173,18 @@ int eve_linear_dgrad(int M, int K, int N, const float* dy, const float* y, int a
                      float* dx, eve_stream_t stream);
 int eve_linear_wgrad(int M, int K, int N, const float* dy, const float* y, int act, const float* x,
                      float* dw_out_in, float* db, eve_stream_t stream);
+/* ... with row strides (a column range of a wider matrix on either side), a bias shorter than N (padded heads) and an
+ * accumulating data gradient (dx += ...): what lets the tail run without cat / pad / slice / add launches (round 4).            */
+int eve_linear_fwd_ex(int M, int K, int N, const float* x, int ldx, const float* w_in_out, const float* bias, int n_bias,
+                      int act, float* y, int ldy, eve_stream_t stream);
+int eve_linear_dgrad_ex(int M, int K, int N, const float* dy, int lddy, const float* y, int act, const float* w_out_in,
+                        float* dx, int lddx, int accumulate, eve_stream_t stream);
+/* gaze [M][2] = pi/2 * g2[:, :2] and pupil [M] = p2[:, 0] of the heads' 4-wide last layers (eye_net.py:139-146), and back:
+ * d_g2 / d_p2 [2*BT][4] from the loss kernel's per-side unit gradients (rows: left clips, then right), scaled by
+ * coeff * *g_full (device scalar, NULL = 1).                                                                                  */
+int eve_tail_outputs_fwd(int M, const float* g2, const float* p2, float* gaze, float* pupil, eve_stream_t stream);
+int eve_tail_outputs_bwd(int BT, const float* dg_l, const float* dg_r, const float* dp_l, const float* dp_r, const float* g_full,
+                         float coeff_ang, float coeff_l1, float* d_g2, float* d_p2, eve_stream_t stream);
 /* The EyeNet train-step losses and their gradients in one launch (losses/angular.py:33-38, losses/l1.py,
  * losses/base_loss_with_validity.py:64-73; weighted sum of eve.py:234-265).  Every pointer argument is an array of
  * two device pointers {left, right}: g_pred/g_tgt [B][T][2] (pitch, yaw), p_pred/p_tgt [B][T], validity bytes [B][T].
@@ -452,7 +464,7 @@ typedef struct eve_chain_params {
 } eve_chain_params;
 int eve_linear_chain(const eve_chain_params* p, eve_stream_t stream);
 /* ... and all their weight / bias gradients in one launch: dW[N][K] += (dY * act'(Y))^T . [X | X2], db[N] += column sums.      */
-#define EVE_WGRAD_BATCH_MAX 8
+#define EVE_WGRAD_BATCH_MAX 12
 typedef struct eve_wgrad_problem {
     const float* dY;         /* [M][N]                                                                                        */
     const float* Y;          /* [M][N] or NULL (act == EVE_ACT_NONE)                                                          */
@@ -462,6 +474,9 @@ typedef struct eve_wgrad_problem {
     float* db;               /* [N] accumulated, or NULL                                                                      */
     int M, N, K, K1, K2, act, rows_per_split /* set by the library */;
     int ldY;                 /* row stride of dY and Y in floats (0 = N): the first N columns of a wider matrix                  */
+    int ldX, ldW;            /* row strides of X (0 = K1) and dW (0 = K): K1 leading columns of a wider X, an unpadded dW        */
+    int x_shift_T;           /* > 0: X row m is replaced by row m - 1, zero where m % x_shift_T == 0 (the previous hidden state   */
+    int reserved;            /*      of a scan over sequences of x_shift_T steps: dW_hh = dpre^T . h_prev)                        */
 } eve_wgrad_problem;
 typedef struct eve_wgrad_batch { int n; int first_block[EVE_WGRAD_BATCH_MAX]; eve_wgrad_problem p[EVE_WGRAD_BATCH_MAX]; } eve_wgrad_batch;
 int eve_linear_wgrad_batch(const eve_wgrad_problem* problems, int n, eve_stream_t stream);
