@@ -106,6 +106,7 @@ SIGNATURES = {
     'eve_linear_chain': [POINTER(ChainParams), P],
     'eve_linear_fwd_ex': [I, I, I, P, I, P, P, I, I, P, I, P],
     'eve_linear_dgrad_ex': [I, I, I, P, I, P, I, P, P, I, I, P],
+    'eve_tail_head_pose': [I, P, P, P, I, I, P],
     'eve_tail_outputs_fwd': [I, P, P, P, P, P],
     'eve_tail_outputs_bwd': [I, P, P, P, P, P, F, F, P, P, P],
     'eve_linear_wgrad_batch': [POINTER(WgradProblem), I, P],

@@ -488,7 +488,22 @@ __global__ __launch_bounds__(256) void tail_outputs_bwd_kernel(const int BT, con
     reinterpret_cast<float4*>(d_g2)[m] = make_float4(sa * dg[2 * i], sa * dg[2 * i + 1], 0.f, 0.f);
     reinterpret_cast<float4*>(d_p2)[m] = make_float4(sl * dp[i], 0.f, 0.f, 0.f);
 }
+// columns 128 .. 131 of the head-pose concatenation [M][132]: (h0, h1, 0, 0) from the left clips' rows, then the right ones'
+__global__ __launch_bounds__(256) void tail_head_pose_kernel(const int BT, const float* __restrict__ hl, const float* __restrict__ hr,
+                                                             float* __restrict__ cat, const int ld, const int col) {
+    const int m = blockIdx.x * 256 + threadIdx.x;
+    if (m >= 2 * BT) return;
+    const float* h = m >= BT ? hr + 2 * (size_t)(m - BT) : hl + 2 * (size_t)m;
+    *reinterpret_cast<float4*>(cat + (size_t)m * ld + col) = make_float4(h[0], h[1], 0.f, 0.f);
+}
 }  // namespace eve
+
+extern "C" int eve_tail_head_pose(int BT, const float* h_left, const float* h_right, float* cat, int ld, int col, eve_stream_t stream) {
+    if (BT <= 0 || !h_left || !h_right || !cat || ld < col + 4 || (ld & 3) || (col & 3)) return set_error_msg("tail_head_pose: bad arguments");
+    hipLaunchKernelGGL(tail_head_pose_kernel, dim3((2 * BT + 255) / 256), dim3(256), 0, (hipStream_t)stream, BT, h_left, h_right, cat, ld, col);
+    EVE_CHECK_LAUNCH();
+    return 0;
+}
 
 extern "C" int eve_tail_outputs_fwd(int M, const float* g2, const float* p2, float* gaze, float* pupil, eve_stream_t stream) {
     if (M <= 0 || !g2 || !p2 || !gaze || !pupil) return set_error_msg("tail_outputs_fwd: bad arguments");

@@ -146,6 +146,8 @@ class EyeNet(nn.Module):
         if self.config.eye_net_use_rnn:
             for i, cell in enumerate(self.rnn_cells):
                 T['rnn.%d.ih' % i] = PackedWeight(cell.weight_ih, f32, defer=True)
+                if i == 0 and self.config.eye_net_rnn_type == 'GRU':        # W_hh and its transpose for ops.EyeTailLossFn
+                    T['rnn.0.hh'] = PackedWeight(cell.weight_hh, f32, defer=True)
         else:
             T['static_fc.0'] = PackedWeight(self.static_fc[0].weight, f32, defer=True)
         T['fc_to_gaze.0'] = PackedWeight(self.fc_to_gaze[0].weight, f32, defer=True)
@@ -275,6 +277,50 @@ class EyeNet(nn.Module):
                                      (P['fc_to_gaze.0'], P['fc_to_gaze.2'], P['fc_to_pupil.0'], P['fc_to_pupil.2']))
         return half_pi * g[:, :2], p[:, 0], states
 
+    # ------------------------------------------------------------------ train step: tail + losses as one node
+    tail_loss_node = os.environ.get('EVE_AMD_TAIL_LOSS_NODE', '1') != '0'
+
+    def _tail_loss_node_ok(self, batch, T):
+        cfg = self.config
+        k = default_kernels()
+        if not (self.tail_loss_node and hasattr(k, 'tail_outputs_fwd') and torch.is_grad_enabled() and cfg.eye_net_use_rnn and
+                cfg.eye_net_rnn_type == 'GRU' and len(self.rnn_cells) == 1 and cfg.eye_net_use_head_pose_input and
+                not cfg.eye_net_frozen and self.rnn_cells[0].hidden_size == 128 and self.fc_common[0].in_features == 130 and
+                self.cnn_layers.fc.in_features == 512 and T <= 256 and batch['left_eye_patch'].is_cuda and
+                batch['left_g_tobii'].dtype == torch.float32 and batch['left_h'].dtype == torch.float32):
+            return False
+        return all(ops._direct_grad_ok(p_) for p_ in ops.EyeTailLossFn.tail_parameters(self))
+
+    def loss_terms_sequence(self, batch, config=None):
+        """The EyeNet train step's forward: whole clips of both eyes -> the loss terms of eve.py:286-325 that carry weight in
+        eye_net.json and their weighted sum (:234-265) -- what losses.eyenet_loss_terms(self.forward_sequence(batch), ...) returns,
+        with the tail and the losses as ONE autograd node (ops.EyeTailLossFn) when the configuration is the product one
+        (train.eyenet_trainer: one GRU cell, head-pose input, parameters in the trainer's flat buffers); any other
+        configuration takes the per-layer path.  Also returns the predictions (detached) under the forward_sequence keys."""
+        from . import losses
+        config = config if config is not None else self.config
+        P = self._get_packs()
+        feats, B, T = self._sequence_features(batch, P)
+        self.last_tail_path = 'node' if self._tail_loss_node_ok(batch, T) else 'layers'
+        if self.last_tail_path == 'layers':
+            out = self._sequence_tail(feats, batch, B, T, None, P)
+            terms = losses.eyenet_loss_terms(out, batch, config)
+            terms.update({k_: v.detach() for k_, v in out.items() if torch.is_tensor(v)})
+            return terms
+        tgt = tuple(batch[k_] for k_ in ('left_g_tobii', 'right_g_tobii', 'left_g_tobii_validity', 'right_g_tobii_validity',
+                                         'left_p', 'right_p', 'left_p_validity', 'right_p_validity'))
+        packs = tuple(P[n] for n in ('fc', 'fc_common.0', 'fc_common.2', 'rnn.0.ih', 'rnn.0.hh', 'fc_to_gaze.0', 'fc_to_gaze.2',
+                                     'fc_to_pupil.0', 'fc_to_pupil.2'))
+        t = ops.EyeTailLossFn.apply(feats, batch['left_h'], batch['right_h'], tgt, float(config.loss_coeff_g_ang_initial),
+                                    float(config.loss_coeff_pupil_size), self, packs, B, T)
+        gaze, pupil, hs = t[5], t[6], t[7]
+        BT = B * T
+        return {'loss_ang_left_g_initial': t[0], 'loss_l1_left_pupil_size': t[1], 'loss_ang_right_g_initial': t[2],
+                'loss_l1_right_pupil_size': t[3], 'full_loss': t[4],
+                'left_g_initial': gaze[:BT].view(B, T, 2), 'right_g_initial': gaze[BT:].view(B, T, 2),
+                'left_pupil_size': pupil[:BT].view(B, T), 'right_pupil_size': pupil[BT:].view(B, T),
+                'left_eye_rnn_states_0': hs[:B], 'right_eye_rnn_states_0': hs[B:]}
+
     # ------------------------------------------------------------------ reference per-step contract
     def forward(self, input_dict, output_dict, side, previous_output_dict=None):
         key = side + '_eye_patch'
@@ -304,8 +350,13 @@ class EyeNet(nn.Module):
         Returns the B x T x ... tensors eve.py:174-182 would stack: <side>_g_initial [B,T,2],
         <side>_pupil_size [B,T], <side>_eye_rnn_states_<i> [B,T,H] per cell ((h, c) pair of them for LSTM).
         initial_states: {side: h [B,H]} or {side: [per-cell h | (h, c) | None]}."""
-        k = default_kernels()
         P = self._get_packs()
+        feats, B, T = self._sequence_features(batch, P)
+        return self._sequence_tail(feats, batch, B, T, initial_states, P)
+
+    def _sequence_features(self, batch, P):
+        """Both eyes' clips through the trunk: -> feats [2*B*T, 512] float32 (left clips' frames, then the right ones'), B, T."""
+        k = default_kernels()
         dt = self.compute_dtype
         left, right = batch['left_eye_patch'], batch['right_eye_patch']
         x = x_padded = None
@@ -337,7 +388,9 @@ class EyeNet(nn.Module):
                 x_padded = torch.empty((2 * B * T, Hh + 6, Ww + 8, 4), dtype=dt, device=left.device)
                 k.stem_pack_input(left.reshape(B * T, C, Hh, Ww), out=x_padded[:B * T])
                 k.stem_pack_input(right.reshape(B * T, C, Hh, Ww), out=x_padded[B * T:])
-        feats = self._trunk(x, P, x_padded)
+        return self._trunk(x, P, x_padded), B, T
+
+    def _sequence_tail(self, feats, batch, B, T, initial_states, P):
         head_pose = None
         if self.config.eye_net_use_head_pose_input:
             head_pose = torch.cat([batch['left_h'].reshape(B * T, 2), batch['right_h'].reshape(B * T, 2)], dim=0)

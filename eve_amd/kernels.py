@@ -347,10 +347,13 @@ class HipKernels(object):
             q.X2 = pr['X2'].data_ptr() if pr.get('X2') is not None else None
             q.db = pr['db'].data_ptr() if pr.get('db') is not None else None
             q.M, q.N, q.K = dY.shape[0], dW.shape[0], dW.shape[1]
-            q.K1, q.K2 = X.shape[1], (pr['X2'].shape[1] if pr.get('X2') is not None else 0)
+            q.K1, q.K2 = pr.get('K1', X.shape[1]), (pr['X2'].shape[1] if pr.get('X2') is not None else 0)
             q.act = pr.get('act', ACT_NONE)
             q.ldY = dY.shape[1] if dY.shape[1] != q.N else 0
-            assert dY.shape[1] >= q.N and q.K1 + q.K2 <= q.K and X.shape[0] == q.M
+            q.ldX = X.shape[1] if X.shape[1] != q.K1 else 0           # the leading K1 columns of a wider X
+            q.ldW, q.x_shift_T, q.reserved = 0, int(pr.get('x_shift_T', 0)), 0
+            assert dY.shape[1] >= q.N and q.K1 + q.K2 <= q.K and X.shape[0] == q.M and X.shape[1] >= q.K1
+            assert not q.x_shift_T or (q.K2 == 0 and q.M % q.x_shift_T == 0)
             assert pr.get('Y') is None or pr['Y'].shape == dY.shape
         self._timed('tail', 0.0, lambda: self._ck(self.lib.eve_linear_wgrad_batch(arr, n, self._stream())))
 
@@ -545,6 +548,57 @@ class HipKernels(object):
         self._ck(self.lib.eve_linear_fwd(M, K, N, self._p(x), self._p(w_in_out), self._p(self._f32(bias, 'bias')), act,
                                          self._p(y), self._stream()))
         return y
+
+    def linear_fwd_ex(self, x, k_cols, w_in_out, bias, act, y, n_cols=None):
+        """y[:, :N] = act(x[:, :K] @ w_in_out + bias): K leading columns of x, N leading columns of y (both may be wider), a bias
+        with fewer than N entries covers the leading columns (the zero-padded heads)."""
+        M = x.shape[0]
+        K, N = w_in_out.shape
+        assert k_cols == K and (n_cols is None or n_cols == N)
+        for t in (x, w_in_out, y, bias):
+            assert t is None or (t.dtype == torch.float32 and t.is_contiguous() and t.is_cuda)
+        assert x.shape[1] >= K and y.shape[1] >= N and y.shape[0] == M
+        self._ck(self.lib.eve_linear_fwd_ex(M, K, N, self._p(x), x.shape[1], self._p(w_in_out), self._p(bias),
+                                            bias.numel() if bias is not None else 0, act, self._p(y), y.shape[1], self._stream()))
+        return y
+
+    def linear_dgrad_ex(self, dy, n_cols, y, act, w_out_in, dx, accumulate=False):
+        """dx (+)= (dy[:, :N] * act'(y[:, :N])) @ w_out_in  -- dy / y may be wider than N, dx exactly K wide."""
+        M = dy.shape[0]
+        N, K = w_out_in.shape
+        assert n_cols == N and dy.shape[1] >= N and tuple(dx.shape) == (M, K) and (y is None or y.shape == dy.shape)
+        for t in (dy, y, w_out_in, dx):
+            assert t is None or (t.dtype == torch.float32 and t.is_contiguous() and t.is_cuda)
+        self._ck(self.lib.eve_linear_dgrad_ex(M, K, N, self._p(dy), dy.shape[1], self._p(y), act, self._p(w_out_in), self._p(dx), K,
+                                              int(bool(accumulate)), self._stream()))
+        return dx
+
+    def tail_head_pose(self, h_left, h_right, cat, col):
+        BT = h_left.numel() // 2
+        for t in (h_left, h_right, cat):
+            assert t.dtype == torch.float32 and t.is_contiguous() and t.is_cuda
+        assert h_right.numel() == 2 * BT and cat.shape[0] == 2 * BT and cat.shape[1] >= col + 4
+        self._ck(self.lib.eve_tail_head_pose(BT, self._p(h_left), self._p(h_right), self._p(cat), cat.shape[1], col, self._stream()))
+
+    def tail_outputs_fwd(self, g2, p2):
+        M = g2.shape[0]
+        assert tuple(g2.shape) == (M, 4) and tuple(p2.shape) == (M, 4) and g2.is_contiguous() and p2.is_contiguous()
+        gaze = torch.empty((M, 2), dtype=torch.float32, device=g2.device)
+        pupil = torch.empty((M,), dtype=torch.float32, device=g2.device)
+        self._ck(self.lib.eve_tail_outputs_fwd(M, self._p(g2), self._p(p2), self._p(gaze), self._p(pupil), self._stream()))
+        return gaze, pupil
+
+    def tail_outputs_bwd(self, dg, dp, g_full, coeff_ang, coeff_l1):
+        """dg / dp: the (left, right) unit gradients of eye_losses; g_full: device scalar or None -> d_g2, d_p2 [2*B*T, 4]."""
+        BT = dp[0].numel()
+        for t in (dg[0], dg[1], dp[0], dp[1]):
+            assert t.dtype == torch.float32 and t.is_contiguous()
+        assert g_full is None or (g_full.dtype == torch.float32 and g_full.numel() == 1 and g_full.is_cuda)
+        d_g2 = torch.empty((2 * BT, 4), dtype=torch.float32, device=dp[0].device)
+        d_p2 = torch.empty((2 * BT, 4), dtype=torch.float32, device=dp[0].device)
+        self._ck(self.lib.eve_tail_outputs_bwd(BT, self._p(dg[0]), self._p(dg[1]), self._p(dp[0]), self._p(dp[1]), self._p(g_full),
+                                               float(coeff_ang), float(coeff_l1), self._p(d_g2), self._p(d_p2), self._stream()))
+        return d_g2, d_p2
 
     def linear_dgrad(self, dy, y, act, w_out_in):
         M, N = dy.shape

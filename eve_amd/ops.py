@@ -414,6 +414,110 @@ class _TailGrads(object):
         return out
 
 
+class EyeTailLossFn(torch.autograd.Function):
+    """EyeNet's tail AND its losses as one autograd node (round 4): features [2*B*T, 512] (left clips, then right) -> fc -> head-pose
+    concatenation -> fc_common -> GRU cell over T -> gaze / pupil heads (eye_net.py:109-146) -> the four masked loss terms and
+    their weighted sum (eve.py:234-265, 286-325).  Every step is one launch of the float32 tail kernels, called directly: the
+    per-layer path builds the same chain out of eight LinearFn / GRUScanFn / EyeLossesFn nodes, and autograd's glue between them
+    (bias pads, cat, pad, slices, zeros, the sum of the two heads' input gradients) is ~50 tiny ATen launches per step --
+    0.2 ms of a 4.4 ms step at batch 8.  Here fc writes into the concatenation (row stride 132), the padded heads take their
+    real bias length, the second head's data gradient accumulates onto the first one's, fc's data gradient reads the leading
+    128 columns of the concatenation's, and the nine weight / bias gradients go straight into the flat gradient buffer in ONE
+    launch (the GRU's h_prev is hs shifted by one step inside the kernel).
+    Only for the product train step: one GRU cell, head-pose input, no initial state, every tail parameter living in
+    train.FlatParameters (gradients are written in place, nothing is returned for them) -- eye_net.EyeNet.loss_terms_sequence
+    checks that and falls back to the per-layer path otherwise.  Only d(full_loss) is propagated."""
+
+    @staticmethod
+    def forward(ctx, feats, h_left, h_right, targets, c_ang, c_l1, net, packs, B, T):
+        k = default_kernels()
+        cnn, cell = net.cnn_layers, net.rnn_cells[0]
+        p_fc, p0, p2, p_ih, p_hh, pg0, pg2, pp0, pp2 = packs
+        M, dev = feats.shape[0], feats.device
+        BT = B * T
+        assert M == 2 * BT and feats.dtype == torch.float32
+        f32 = lambda t: t.detach()
+        new = lambda n: torch.empty((M, n), dtype=torch.float32, device=dev)
+        feats = feats.contiguous()
+        cin0 = p0.ohwi.shape[3]                                     # 130 padded to 132
+        c0 = new(cin0)
+        k.linear_fwd_ex(feats, 512, p_fc.ihwo.view(512, 128), f32(cnn.fc.bias), ACT_NONE, c0)
+        k.tail_head_pose(h_left.detach().float().contiguous(), h_right.detach().float().contiguous(), c0, 128)
+        a1 = k.linear_fwd(c0, p0.ihwo.view(cin0, 128), f32(net.fc_common[0].bias), ACT_SELU)
+        a2 = k.linear_fwd(a1, p2.ihwo.view(128, 128), f32(net.fc_common[2].bias), ACT_NONE)
+        gi = k.linear_fwd(a2, p_ih.ihwo.view(128, 384), f32(cell.bias_ih), ACT_NONE)
+        hs, gates, hn_pre = k.gru_scan_fwd(gi.view(2 * B, T, 384), p_hh.ihwo.view(128, 384), f32(cell.bias_hh), None)
+        hs2 = hs.view(M, 128)
+        g1 = k.linear_fwd(hs2, pg0.ihwo.view(128, 128), f32(net.fc_to_gaze[0].bias), ACT_SELU)
+        g2 = k.linear_fwd_ex(g1, 128, pg2.ihwo.view(128, 4), None, ACT_TANH, new(4))
+        p1 = k.linear_fwd(hs2, pp0.ihwo.view(128, 128), f32(net.fc_to_pupil[0].bias), ACT_SELU)
+        p2_ = k.linear_fwd_ex(p1, 128, pp2.ihwo.view(128, 4), f32(net.fc_to_pupil[2].bias), ACT_RELU, new(4))
+        gaze, pupil = k.tail_outputs_fwd(g2, p2_)
+        tg_l, tg_r, vg_l, vg_r, tp_l, tp_r, vp_l, vp_r = targets
+        terms, dg, dp = k.eye_losses((gaze[:BT].view(B, T, 2), gaze[BT:].view(B, T, 2)), (tg_l, tg_r), (vg_l, vg_r),
+                                     (pupil[:BT].view(B, T), pupil[BT:].view(B, T)), (tp_l, tp_r), (vp_l, vp_r), c_ang, c_l1)
+        ctx.net, ctx.packs, ctx.coeffs, ctx.BT = net, packs, (c_ang, c_l1), (B, T)
+        ctx.params = EyeTailLossFn.tail_parameters(net)
+        for p_ in ctx.params:
+            _note_use(p_, True)
+        ctx.set_materialize_grads(False)
+        ctx.save_for_backward(feats, c0, a1, a2, hs, gates, hn_pre, g1, g2, p1, p2_, dg[0], dg[1], dp[0], dp[1])
+        ctx.mark_non_differentiable(gaze, pupil, hs)
+        return tuple(terms.unbind(0)) + (gaze, pupil, hs)
+
+    @staticmethod
+    def tail_parameters(net):
+        cnn, cell = net.cnn_layers, net.rnn_cells[0]
+        return [cnn.fc.weight, cnn.fc.bias, net.fc_common[0].weight, net.fc_common[0].bias, net.fc_common[2].weight,
+                net.fc_common[2].bias, cell.weight_ih, cell.bias_ih, cell.weight_hh, cell.bias_hh, net.fc_to_gaze[0].weight,
+                net.fc_to_gaze[0].bias, net.fc_to_gaze[2].weight, net.fc_to_pupil[0].weight, net.fc_to_pupil[0].bias,
+                net.fc_to_pupil[2].weight, net.fc_to_pupil[2].bias]
+
+    @staticmethod
+    def backward(ctx, g_ang_l, g_l1_l, g_ang_r, g_l1_r, g_full, *unused):
+        if any(g is not None for g in (g_ang_l, g_l1_l, g_ang_r, g_l1_r)):
+            raise NotImplementedError('EyeTailLossFn propagates d(full_loss) only: use losses.eyenet_loss_terms for the separate terms')
+        if g_full is None:
+            return (None,) * 10
+        k = default_kernels()
+        feats, c0, a1, a2, hs, gates, hn_pre, g1, g2, p1, p2_, dg_l, dg_r, dp_l, dp_r = ctx.saved_tensors
+        p_fc, p0, p2, p_ih, p_hh, pg0, pg2, pp0, pp2 = ctx.packs
+        (w_fc, b_fc, w0, b0, w2, b2, w_ih, b_ih, w_hh, b_hh, wg0, bg0, wg2, wp0, bp0, wp2, bp2) = ctx.params
+        B, T = ctx.BT
+        M, dev = feats.shape[0], feats.device
+        cin0 = p0.ohwi.shape[3]
+        hs2 = hs.view(M, 128)
+        g_full = g_full.detach().float().contiguous()
+        d_g2, d_p2 = k.tail_outputs_bwd((dg_l, dg_r), (dp_l, dp_r), g_full, ctx.coeffs[0], ctx.coeffs[1])
+        d_g1 = k.linear_dgrad(d_g2, g2, ACT_TANH, pg2.ohwi.view(4, 128))
+        d_hs = k.linear_dgrad(d_g1, g1, ACT_SELU, pg0.ohwi.view(128, 128))
+        d_p1 = k.linear_dgrad(d_p2, p2_, ACT_RELU, pp2.ohwi.view(4, 128))
+        k.linear_dgrad_ex(d_p1, 128, p1, ACT_SELU, pp0.ohwi.view(128, 128), d_hs, accumulate=True)
+        dgi, dgh, _ = k.gru_scan_bwd(d_hs.view(2 * B, T, 128), p_hh.ohwi.view(384, 128), None, hs, gates, hn_pre, False)
+        dgi2, dgh2 = dgi.view(M, 384), dgh.view(M, 384)
+        d_a2 = k.linear_dgrad(dgi2, None, ACT_NONE, p_ih.ohwi.view(384, 128))
+        d_a1 = k.linear_dgrad(d_a2, None, ACT_NONE, p2.ohwi.view(128, 128))
+        d_c0 = k.linear_dgrad(d_a1, a1, ACT_SELU, p0.ohwi.view(128, cin0))
+        d_feats = None
+        if ctx.needs_input_grad[0]:
+            d_feats = torch.empty((M, 512), dtype=torch.float32, device=dev)
+            k.linear_dgrad_ex(d_c0, 128, None, ACT_NONE, p_fc.ohwi.view(128, 512), d_feats)
+        gw = lambda p_: p_.grad.view(p_.shape[0], -1) if p_.dim() == 2 else p_.grad
+        k.linear_wgrad_batch([
+            dict(dY=d_c0, X=feats, dW=gw(w_fc), db=gw(b_fc)),
+            dict(dY=d_a1, Y=a1, act=ACT_SELU, X=c0, K1=w0.shape[1], dW=gw(w0), db=gw(b0)),
+            dict(dY=d_a2, X=a1, dW=gw(w2), db=gw(b2)),
+            dict(dY=dgi2, X=a2, dW=gw(w_ih), db=gw(b_ih)),
+            dict(dY=dgh2, X=hs2, x_shift_T=T, dW=gw(w_hh), db=gw(b_hh)),
+            dict(dY=d_g1, Y=g1, act=ACT_SELU, X=hs2, dW=gw(wg0), db=gw(bg0)),
+            dict(dY=d_g2, Y=g2, act=ACT_TANH, X=g1, dW=gw(wg2)),
+            dict(dY=d_p1, Y=p1, act=ACT_SELU, X=hs2, dW=gw(wp0), db=gw(bp0)),
+            dict(dY=d_p2, Y=p2_, act=ACT_RELU, X=p1, dW=gw(wp2), db=gw(bp2))])
+        for p_ in ctx.params:
+            _notify_grad_ready(p_)
+        return (d_feats,) + (None,) * 9
+
+
 class TailPreFn(torch.autograd.Function):
     """gi = W_ih . fc_common( [fc(feats) | head pose] ) + b_ih -- the four linear layers in front of the recurrence
     (eye_net.py:109-119, torch.nn.GRUCell's input projection) as ONE launch (kernels.linear_chain); backward: one launch for the

@@ -264,7 +264,8 @@ def _resolve_schedule(config, lr_schedule, steps_per_epoch):
 
 def eyenet_trainer(eye_net, config, distributed=False, use_graph=False, lr_schedule=None, steps_per_epoch=None):
     def loss_fn(batch):
-        return losses.eyenet_loss_terms(eye_net.forward_sequence(batch), batch, config)
+        # = losses.eyenet_loss_terms(eye_net.forward_sequence(batch), batch, config), tail + losses as one node when it applies
+        return eye_net.loss_terms_sequence(batch, config)
     return Trainer([eye_net], config, loss_fn, distributed=distributed, use_graph=use_graph,
                    lr_schedule=_resolve_schedule(config, lr_schedule, steps_per_epoch))
 

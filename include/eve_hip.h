@@ -182,6 +182,9 @@ int eve_linear_dgrad_ex(int M, int K, int N, const float* dy, int lddy, const fl
 /* gaze [M][2] = pi/2 * g2[:, :2] and pupil [M] = p2[:, 0] of the heads' 4-wide last layers (eye_net.py:139-146), and back:
  * d_g2 / d_p2 [2*BT][4] from the loss kernel's per-side unit gradients (rows: left clips, then right), scaled by
  * coeff * *g_full (device scalar, NULL = 1).                                                                                  */
+/* cat[m][col .. col+3] = (h[m][0], h[m][1], 0, 0), rows 0 .. BT-1 from h_left [BT][2], BT .. 2BT-1 from h_right (eye_net.py:113-114's
+ * torch.cat of fc's output and the head pose, written behind the 128 columns eve_linear_fwd_ex filled; ld, col multiples of 4).   */
+int eve_tail_head_pose(int BT, const float* h_left, const float* h_right, float* cat, int ld, int col, eve_stream_t stream);
 int eve_tail_outputs_fwd(int M, const float* g2, const float* p2, float* gaze, float* pupil, eve_stream_t stream);
 int eve_tail_outputs_bwd(int BT, const float* dg_l, const float* dg_r, const float* dp_l, const float* dp_r, const float* g_full,
                          float coeff_ang, float coeff_l1, float* d_g2, float* d_p2, eve_stream_t stream);

@@ -436,3 +436,65 @@ def test_tail_chains_equal_the_per_layer_tail(variant):
         ga, gb = a[3][n], b[3][n]
         assert float((ga - gb).norm()) <= 2e-5 * float(ga.norm()) + 1e-7, (n, float((ga - gb).norm()), float(ga.norm()))
     eve_amd.reset_standalone_config()
+
+
+@pytest.mark.parametrize('dtype,B,T', [(torch.float32, 3, 5), (torch.bfloat16, 2, 7), (torch.float32, 1, 1)])
+def test_tail_and_losses_as_one_node_equal_the_per_layer_path(dtype, B, T):
+    """Round 4: EyeNet.loss_terms_sequence runs the tail and the losses as ONE autograd node (ops.EyeTailLossFn: every layer one
+    direct launch of the float32 tail kernels, gradients written into the trainer's flat buffer by one batched launch) -- against
+    the per-layer composition it replaces (tail_loss_node = False: LinearFn x 8, GRUScanFn, EyeLossesFn and autograd's glue) on
+    the same batch and weights: the five loss terms, the predictions, and the WHOLE flat gradient (trunk included: d(features)
+    enters it).  The tail is float32 in both; same products, sums in the same order per output element except the weight
+    gradients' float atomics.  Then the product trainer's step on the golden fixture (test_train_step_matches_reference_eve_golden
+    through train.eyenet_trainer, which takes the node)."""
+    from eve_amd import train
+    batch = to_dev(detweights.eyenet_batch(B, T, seed=5, invalid_fraction=0.25))
+    res = {}
+    for node in (False, True):
+        net = make_net(dtype)
+        with torch.no_grad():                      # the reference zero-initialises the last gaze layer: give it a signal
+            g = torch.Generator().manual_seed(12)
+            net.fc_to_gaze[2].weight.copy_(0.05 * torch.randn(net.fc_to_gaze[2].weight.shape, generator=g).cuda())
+        net.tail_loss_node = node
+        tr = train.eyenet_trainer(net, net.config)
+        terms = tr._forward_backward(batch)
+        torch.cuda.synchronize()
+        assert net.last_tail_path == ('node' if node else 'layers')
+        res[node] = ({k: v.detach().clone() for k, v in terms.items()}, tr.fp.grad.clone(),
+                     {n: p.grad.detach().clone() for n, p in net.named_parameters()})
+    (ta, ga, pa), (tb, gb, pb) = res[False], res[True]
+    assert set(ta) == set(tb)
+    for k in ta:
+        d = float((ta[k].float() - tb[k].float()).abs().max())
+        assert d <= 2e-6 * max(1.0, float(ta[k].abs().max())), (k, d)
+    assert torch.isfinite(gb).all()
+    tail_names = [n for n in pa if not n.startswith('cnn_layers.') or n.startswith('cnn_layers.fc')]
+    assert len(tail_names) == 17
+    for n in tail_names:
+        assert float((pa[n] - pb[n]).norm()) <= 2e-5 * float(pa[n].norm()) + 1e-7, (n, float((pa[n] - pb[n]).norm()), float(pa[n].norm()))
+    # the trunk's gradients follow from d(features): float32 reproduces to rounding, bf16 to its own run-to-run atomics noise
+    tol = 1e-4 if dtype == torch.float32 else 2e-2
+    assert float((ga - gb).norm()) <= tol * float(ga.norm()), float((ga - gb).norm() / ga.norm())
+
+
+def test_eyenet_trainer_takes_the_one_node_tail_and_matches_the_reference_step():
+    from eve_amd import train
+    fx = np.load(os.path.join(GOLDEN, 'eyenet.npz'))
+    B, T = int(fx['B']), int(fx['T'])
+    batch = to_dev(detweights.eyenet_batch(B, T, seed=0, invalid_fraction=float(fx['invalid_fraction'])))
+    net = make_net(torch.float32)
+    trainer = train.eyenet_trainer(net, net.config)
+    terms = trainer._forward_backward(batch)
+    assert net.last_tail_path == 'node'
+    for k in ('loss_ang_left_g_initial', 'loss_ang_right_g_initial', 'loss_l1_left_pupil_size', 'loss_l1_right_pupil_size', 'full_loss'):
+        np.testing.assert_allclose(float(terms[k].detach()), float(fx['eve_' + k]), rtol=2e-5)
+    params = dict(net.named_parameters())
+    for n, ref_norm in zip(fx['grad_names'], fx['grad_norms']):
+        got = float(params[str(n)].grad.reshape(-1).double().norm())
+        assert abs(got - ref_norm) <= 1e-2 * ref_norm + 1e-5, '%s: |g| %.6g vs %.6g' % (n, got, ref_norm)
+    trainer._update(1.0)
+    np.testing.assert_allclose(float(trainer.sumsq.sqrt()), float(fx['clip_total_norm']), rtol=5e-3)
+    sd = net.state_dict()
+    for k in fx.files:
+        if k.startswith('updated_'):
+            np.testing.assert_allclose(sd[k[len('updated_'):]].reshape(-1)[:16].cpu().numpy(), fx[k], rtol=1e-3, atol=2e-5)
