@@ -69,6 +69,7 @@ template <> struct Mma<float> {
 #include "conv_wg8.h"
 #include "conv_wg8s2.h"
 #include "conv_ws64.h"
+#include "conv_1x1.h"
 #include "wgrad_halo.h"
 #include "wgrad_wg8.h"
 namespace eve {
@@ -1013,6 +1014,12 @@ extern "C" int eve_conv2d_fwd(const eve_conv_desc* d, const void* x, const void*
     if (!x || !w_ohwi || !y) return set_error_msg("conv2d_fwd: null pointer");
     GatherParams p = fwd_params(d);
     hipStream_t s = (hipStream_t)stream;
+    if (!in_scale_shift && d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad == 0 && d->dtype != EVE_DT_F32) {    // streaming 1x1
+        const long long M = (long long)d->N * d->OH * d->OW;
+        bool done = false;
+        EVE_DISPATCH_H16(d->dtype, done = launch_conv1x1_stream<H>(M, d->Cin, d->Cout, x, w_ohwi, bias, epi_act, y, s));
+        if (done) { EVE_CHECK_LAUNCH(); return 0; }
+    }
     if (!in_scale_shift) {          // the trunk's stride-2 3x3 layers: parity planes of the input as rotating halo stages
         if (d->dtype == EVE_DT_BF16 && launch_s2_fwd_wg8<bf16_t>(d, x, w_ohwi, bias, epi_act, y, s)) { EVE_CHECK_LAUNCH(); return 0; }
         if (d->dtype == EVE_DT_F16 && launch_s2_fwd_wg8<f16_t>(d, x, w_ohwi, bias, epi_act, y, s)) { EVE_CHECK_LAUNCH(); return 0; }
@@ -1103,6 +1110,12 @@ extern "C" int eve_conv2d_dgrad(const eve_conv_desc* d, const void* dy, const vo
     if (!dy || !w_ihwo || !dx) return set_error_msg("conv2d_dgrad: null pointer");
     GatherParams p = dgrad_params(d);
     hipStream_t s = (hipStream_t)stream;
+    if (d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad == 0 && d->dtype != EVE_DT_F32) {    // 1x1: a 1x1 convolution by [Cin][Cout]
+        const long long M = (long long)d->N * d->OH * d->OW;
+        bool done = false;
+        EVE_DISPATCH_H16(d->dtype, done = launch_conv1x1_stream<H>(M, d->Cout, d->Cin, dy, w_ihwo, nullptr, 0, dx, s));
+        if (done) { EVE_CHECK_LAUNCH(); return 0; }
+    }
     // stride-2 3x3 layers: two eight-wave launches over the dy halo tile instead of four per-tap parity-class launches
     if (d->dtype == EVE_DT_BF16 && launch_s2_dgrad_wg8<bf16_t>(d, dy, w_ihwo, dx, workspace, workspace_bytes, s)) { EVE_CHECK_LAUNCH(); return 0; }
     if (d->dtype == EVE_DT_F16 && launch_s2_dgrad_wg8<f16_t>(d, dy, w_ihwo, dx, workspace, workspace_bytes, s)) { EVE_CHECK_LAUNCH(); return 0; }
@@ -1123,6 +1136,12 @@ extern "C" int eve_conv2d_dgrad_acc(const eve_conv_desc* d, const void* dy, cons
     if (!dy || !w_ihwo || !dx) return set_error_msg("conv2d_dgrad_acc: null pointer");
     GatherParams p = dgrad_params(d);
     hipStream_t s = (hipStream_t)stream;
+    if (d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad == 0 && d->dtype != EVE_DT_F32) {
+        const long long M = (long long)d->N * d->OH * d->OW;
+        bool done = false;
+        EVE_DISPATCH_H16(d->dtype, done = launch_conv1x1_stream<H>(M, d->Cout, d->Cin, dy, w_ihwo, nullptr, EVE_EPI_ACC, dx, s));
+        if (done) { EVE_CHECK_LAUNCH(); return 0; }
+    }
     if (d->dtype == EVE_DT_BF16) launch_igemm<bf16_t>(p, dy, w_ihwo, nullptr, nullptr, 0, EVE_EPI_ACC, dx, s);
     else if (d->dtype == EVE_DT_F16) launch_igemm<f16_t>(p, dy, w_ihwo, nullptr, nullptr, 0, EVE_EPI_ACC, dx, s);
     else                         launch_igemm<float>(p, dy, w_ihwo, nullptr, nullptr, 0, EVE_EPI_ACC, dx, s);

@@ -496,13 +496,29 @@ __global__ __launch_bounds__(1024) void in_bwd_trunk_kernel(const T* __restrict_
 }
 
 // threads per block and vectors per thread for a plane of nvec 16-byte vectors; false if it does not fit
-static bool fused_plan(int nvec, int cvecs, int& threads, int& vpt, int& sl, bool allow_split) {
+static bool fused_plan(int nvec, int cvecs, int& threads, int& vpt, int& sl, bool allow_split, bool allow_big) {
     if (nvec <= 0 || cvecs <= 0 || cvecs > 128 || (cvecs & (cvecs - 1))) return false;
     // planes that would need a 1 024-thread workgroup go to two 512-thread ones, half the channels each
     const int split_on = g_cfg.in_split;
     sl = 0;
     // (bf16 only: the float32 instantiation is the parity mode and keeps its summation order)
     if (split_on && allow_split && nvec > 4096 && nvec <= 8192 && cvecs >= 2) { sl = 1; nvec /= 2; cvecs /= 2; }
+    // round 4: planes beyond one workgroup's registers are dealt by channels as far as it takes -- the ResNet trunk on 256 x 256
+    // patches (BASELINE configs[4]: layer 1 = 64 x 64 x 64 = 32 Ki vectors -> four parts, layer 2 = 16 Ki -> two) then runs on
+    // the branch-free trunk kernels instead of the two-pass ones (statistics pass + apply pass: every operand read twice).
+    // Only WITHOUT affine parameters (allow_big): RefineNet's planes (72x128 and 36x64 pixels, 16-64 channels: 2^k x 9 216
+    // vectors, VPT = 9) were measured through the generic kernels this way and lost to the two-pass kernels -- 16 bytes of
+    // every 32-128-byte pixel per workgroup, one 1 024-thread workgroup per CU whose load, reduce and store phases do not
+    // overlap: 2.5-3.0 TB/s against 2.9-3.5 (profiles/r04_notes.md); C3 46.2 -> 44.6 ms with it off.
+    allow_big = allow_big && g_cfg.in_big_planes && allow_split;
+    if (allow_big)
+        while (nvec > 8192 && cvecs >= 2) { ++sl; nvec /= 2; cvecs /= 2; }
+    if (nvec > 8192) {
+        if (!allow_big || nvec > 9216) return false;
+        vpt = 9;
+        threads = ((nvec + 8) / 9 + 63) / 64 * 64;
+        return true;
+    }
     // as many vectors per thread as leaves >= `min_threads` threads: fewer, fatter workgroups per plane let several
     // planes share a CU, so one plane's reduction phase overlaps another's loads / stores
     const int min_threads = g_cfg.in_min_threads;
@@ -524,6 +540,7 @@ using namespace eve;
         case 1: EVE_LAUNCH(#KERNEL "<" TS ", 1, " AS ">", (KERNEL<T, 1, A>), dim3(grid), dim3(threads), 0, s, __VA_ARGS__); break;  \
         case 2: EVE_LAUNCH(#KERNEL "<" TS ", 2, " AS ">", (KERNEL<T, 2, A>), dim3(grid), dim3(threads), 0, s, __VA_ARGS__); break;  \
         case 4: EVE_LAUNCH(#KERNEL "<" TS ", 4, " AS ">", (KERNEL<T, 4, A>), dim3(grid), dim3(threads), 0, s, __VA_ARGS__); break;  \
+        case 9: EVE_LAUNCH(#KERNEL "<" TS ", 9, " AS ">", (KERNEL<T, 9, A>), dim3(grid), dim3(threads), 0, s, __VA_ARGS__); break;  \
         default: EVE_LAUNCH(#KERNEL "<" TS ", 8, " AS ">", (KERNEL<T, 8, A>), dim3(grid), dim3(threads), 0, s, __VA_ARGS__); break; \
     }
 // the two activations of the ResNet trunk get their own instantiation; everything else takes the run-time switch
@@ -541,11 +558,11 @@ extern "C" int eve_instnorm_fwd_fused(int dtype, int N, int HW, int C, const voi
         !mean_rstd || ((gamma == nullptr) != (beta == nullptr)))
         return set_error_msg("instnorm_fwd_fused: bad arguments");
     int threads, vpt, sl;
-    if (!fused_plan(HW * (C / vec), C / vec, threads, vpt, sl, dtype != EVE_DT_F32)) return -1;
+    if (!fused_plan(HW * (C / vec), C / vec, threads, vpt, sl, dtype != EVE_DT_F32, gamma == nullptr)) return -1;
     const unsigned grid = sl ? (unsigned)((N + 7) / 8) * (8u << sl) : (unsigned)N;
     hipStream_t s = (hipStream_t)stream;
     // the trunk's instances: no affine, identity / ReLU, the plane part fills its <= 512-thread workgroup exactly
-    if (g_cfg.in_trunk_kernels && !gamma && (long long)threads * vpt == ((long long)HW * (C / vec)) >> sl) {
+    if (g_cfg.in_trunk_kernels && vpt <= 8 && !gamma && (long long)threads * vpt == ((long long)HW * (C / vec)) >> sl) {
         const int combo = (act == EVE_ACT_RELU && !res && !sign_mask) ? 0 : (act == EVE_ACT_RELU && res && sign_mask) ? 1
                         : (act == EVE_ACT_NONE && !res && !sign_mask) ? 2 : -1;
 #define FWD_TRUNK(T, TS, V)                                                                                                              \
@@ -588,10 +605,10 @@ extern "C" int eve_instnorm_bwd_fused(int dtype, int N, int HW, int C, const voi
         !mean_rstd || !dx || (act != EVE_ACT_NONE && !y && gamma && !(act == EVE_ACT_RELU && sign_mask)))
         return set_error_msg("instnorm_bwd_fused: bad arguments");
     int threads, vpt, sl;
-    if (!fused_plan(HW * (C / vec), C / vec, threads, vpt, sl, dtype != EVE_DT_F32)) return -1;
+    if (!fused_plan(HW * (C / vec), C / vec, threads, vpt, sl, dtype != EVE_DT_F32, gamma == nullptr)) return -1;
     const unsigned grid = sl ? (unsigned)((N + 7) / 8) * (8u << sl) : (unsigned)N;
     hipStream_t s = (hipStream_t)stream;
-    if (g_cfg.in_trunk_kernels && !gamma && (long long)threads * vpt == ((long long)HW * (C / vec)) >> sl) {
+    if (g_cfg.in_trunk_kernels && vpt <= 8 && !gamma && (long long)threads * vpt == ((long long)HW * (C / vec)) >> sl) {
         // 0: mid-block (ReLU' from x)   1 / 2: block end (mask, dres) without / with a second summand   3: down-sample branch
         const int combo = (act == EVE_ACT_RELU && !y && !sign_mask && !dres && !dy2) ? 0
                         : (act == EVE_ACT_RELU && sign_mask && dres) ? (dy2 ? 2 : 1)

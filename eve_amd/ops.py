@@ -44,6 +44,9 @@ class PackedWeight(object):
                 fac = _group_factors(w.shape[1])
                 if cin_p in fac:
                     self.pair_fwd = (fac[cin_p], pixel_group_weights(self.ohwi, fac[cin_p], False))
+                elif (w.shape[1], cin_p, cout_p) in PAIR_NARROW_OUT:
+                    F = PAIR_NARROW_OUT[(w.shape[1], cin_p, cout_p)]
+                    self.pair_fwd = (F, pixel_group_weights(self.ohwi, F, False))
                 if want_ihwo and cout_p in fac:
                     self.pair_dgrad = (fac[cout_p], pixel_group_weights(self.ohwi, fac[cout_p], True))
 
@@ -72,6 +75,10 @@ class PackedWeight(object):
 #  two-row halo of 520 pixels, more than its DMA schedule holds, and the gather kernel wants 64-channel K steps.)
 PAIR_FACTOR = {32: 2, 16: 2, 8: 4}          # 3x3: channels -> pixels per group
 PAIR_FACTOR_1X1 = {32: 2, 16: 4, 8: 8}
+# (kernel size, Cin, Cout) -> pixels per group, for layers whose OUTPUT is too narrow for the halo kernel's 32-channel tile: the
+# outermost decoder's first 3x3 (64 -> 16 at 72x128, refine_net.py:96-131 with the skip concatenation) ran on the first-generation
+# gather kernel at 1.15 ms (1.2 TB/s); as 128 -> 32 over pixel pairs it is a shape the halo kernel already serves at 36x64
+PAIR_NARROW_OUT = {(3, 64, 16): 2}
 _pair_index_cache = {}
 
 
@@ -109,8 +116,22 @@ def _group_factors(ks):
     return PAIR_FACTOR if ks == 3 else (PAIR_FACTOR_1X1 if ks == 1 else {})
 
 
-def _group_ok(pair, x, ks, stride, pad):
+# (Cin, Cout) pairs the streaming 1x1 kernel serves (csrc/conv_1x1.h launch_conv1x1_stream): those layers are NOT grouped
+STREAM_1X1 = {(16, 32), (32, 16), (16, 64), (64, 16), (32, 64), (64, 32), (32, 128), (128, 32), (64, 128), (128, 64), (16, 16),
+              (32, 32), (64, 64)}
+
+
+def _stream_1x1(x, c_out):
+    """True when eve_conv2d_fwd / eve_conv2d_dgrad take the 1x1 convolution x [.., Cin] -> [.., c_out] on the streaming kernel."""
+    k = default_kernels()
+    return (x.dtype in HALF_DTYPES and (x.shape[-1], c_out) in STREAM_1X1 and x.numel() // x.shape[-1] >= 16384 and
+            hasattr(k, 'dispatch_config') and bool(k.dispatch_config().conv1x1_stream))
+
+
+def _group_ok(pair, x, ks, stride, pad, c_out=None):
     if pair is None or stride != 1 or pad != (ks - 1) // 2 or x.dtype not in HALF_DTYPES:
+        return False
+    if ks == 1 and c_out is not None and _stream_1x1(x, c_out):
         return False
     wg = x.shape[2] // pair[0]
     if x.shape[2] % pair[0]:
@@ -161,13 +182,13 @@ class Conv2dFn(torch.autograd.Function):
                 b = torch.nn.functional.pad(b, (0, cout_p - b.numel()))
             b = b.contiguous()
         ks = pack.ohwi.shape[1]
-        if acc is None and _group_ok(pack.pair_fwd, x, ks, stride, pad):
+        if acc is None and _group_ok(pack.pair_fwd, x, ks, stride, pad, cout_p):
             F, wg = pack.pair_fwd
             N, H, W, C = x.shape
             y = k.conv2d_fwd(x.view(N, H, W // F, F * C), wg, None if b is None else b.repeat(F), 1, pad, epi_act,
                              algo=pack.algo).view(N, H, W, cout_p)
         elif acc is not None:
-            grouped = _group_ok(pack.pair_fwd, x, ks, stride, pad)
+            grouped = _group_ok(pack.pair_fwd, x, ks, stride, pad, cout_p)
             # y = acc + conv(x): accumulated in the kernel epilogue, `acc` (another branch's output) is updated in place
             # (the caller hands over the other branch's freshly produced output, which nothing else reads or saved; the
             #  result is returned as a separate tensor object over the same storage -- `acc` may itself be a view made
@@ -215,7 +236,7 @@ class Conv2dFn(torch.autograd.Function):
             dy = k.act_bwd(dy, y, ctx.epi_act)
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            if _group_ok(pack.pair_dgrad, dy, pack.ohwi.shape[1], ctx.stride, ctx.pad):
+            if _group_ok(pack.pair_dgrad, dy, pack.ohwi.shape[1], ctx.stride, ctx.pad, x.shape[3]):
                 F, wg = pack.pair_dgrad
                 N, H, W, C = dy.shape
                 dx = k.conv2d_fwd(dy.view(N, H, W // F, F * C), wg, None, 1, ctx.pad, ACT_NONE,

@@ -77,6 +77,8 @@ typedef struct eve_dispatch_config {
     int in_trunk_kernels;          /* EVE_IN_TRUNK          1   branch-free InstanceNorm kernels for the ResNet trunk's cases */
     int stem_fused_wgrad;          /* EVE_STEM_FUSED_WGRAD  1   stem backward + weight gradient in one launch (eve_stem_bwd_wgrad) */
     int stem_fwd_pairs;            /* EVE_STEM_FWD_PAIRS    1   fused stem forward with two waves per image (32 channels each)       */
+    int conv1x1_stream;            /* EVE_CONV1X1_STREAM    1   1x1 convolutions between 16..128 channels on the streaming kernel (no LDS)    */
+    int in_big_planes;             /* EVE_IN_BIG_PLANES     1   register-resident InstanceNorm (no affine) for planes beyond 8 192 vectors, dealt by channels */
     long long wgrad_halo_min_m;    /* EVE_WGRAD_HALO_MIN_M  1<<20 pixels from which the band-resident weight gradient runs */
 } eve_dispatch_config;
 int eve_get_dispatch_config(eve_dispatch_config* out);           /* what the entry points use now                         */

@@ -311,6 +311,82 @@ def test_conv_forward_accumulates_into_its_output(hip, ref, dtype, case):
     close(got, (plain.float().cpu() + base.float()).to(dtype), dtype, 'accumulating conv vs plain + base', scale=float(want.abs().max()))
 
 
+STREAM_1X1_CASES = [(16, 32), (32, 16), (16, 64), (64, 16), (32, 64), (64, 32), (32, 128), (128, 32), (64, 128), (128, 64),
+                    (16, 16), (32, 32), (64, 64)]
+
+
+@pytest.mark.parametrize('hdt', [torch.bfloat16, torch.float16], ids=['bf16', 'f16'])
+@pytest.mark.parametrize('cin,cout', STREAM_1X1_CASES, ids=lambda v: str(v))
+def test_streaming_1x1_convolution(hip, ref, hdt, cin, cout):
+    """Round 4: 1x1 / stride 1 convolutions between 16..128 channels on conv1x1_stream_kernel (csrc/conv_1x1.h: filter in MFMA A
+    registers, pixels straight from global memory as B operands, no LDS): forward with bias (+ ReLU), forward accumulating into
+    its output, data gradient and accumulating data gradient, against the float reference and against the gather kernel it
+    replaces on the same inputs (conv1x1_stream = 0) -- a ragged pixel count (M = 3 x 77 x 71 = 16 401: not a multiple of the
+    16-pixel tile nor of the 32 / 64-pixel batch), so the buffer bounds carry the tail."""
+    N, H, W = 3, 77, 71
+    x = rnd((N, H, W, cin), hdt, 61)
+    w = rnd((cout, 1, 1, cin), hdt, 62, scale=(2.0 / cin) ** 0.5)
+    b = rnd((cout,), torch.float32, 63, scale=0.2)
+    base = rnd((N, H, W, cout), hdt, 64)
+    dy = rnd((N, H, W, cout), hdt, 65)
+    base_dx = rnd((N, H, W, cin), hdt, 66)
+    w_ihwo = w.permute(3, 1, 2, 0).contiguous()
+
+    def run():
+        out = {}
+        out['fwd'] = hip.conv2d_fwd(dev(x), dev(w), dev(b), 1, 0)
+        used = hip.lib.eve_last_kernel().decode()
+        out['fwd_relu'] = hip.conv2d_fwd(dev(x), dev(w), dev(b), 1, 0, 1)
+        out['fwd_acc'] = hip.conv2d_fwd(dev(x), dev(w), dev(b), 1, 0, accumulate_into=dev(base).clone())
+        out['dgrad'] = hip.conv2d_dgrad(dev(dy), dev(w_ihwo), (H, W), 1, 0)
+        out['dgrad_acc'] = hip.conv2d_dgrad(dev(dy), dev(w_ihwo), (H, W), 1, 0, accumulate_into=dev(base_dx).clone())
+        return out, used
+    got, used = run()
+    assert used.startswith('conv1x1_stream_kernel<') and (', %d, %d, false>' % (cin, cout)) in used, used
+    with hip.dispatch_override(conv1x1_stream=0):
+        old, used_old = run()
+    assert 'conv1x1_stream' not in used_old
+    want = ref.conv2d_fwd(x.float(), w.float(), b, 1, 0).float()
+    wdx = ref.conv2d_dgrad(dy.float(), w_ihwo.float(), (H, W), 1, 0).float()
+    wants = {'fwd': want, 'fwd_relu': want.clamp(min=0), 'fwd_acc': want + base.float(), 'dgrad': wdx, 'dgrad_acc': wdx + base_dx.float()}
+    for name in wants:
+        close(got[name], wants[name].to(hdt), hdt, 'streaming 1x1 ' + name, scale=float(wants[name].abs().max()))
+        close(got[name], old[name], hdt, 'streaming 1x1 vs gather kernel: ' + name, scale=float(wants[name].abs().max()))
+    # nothing is written past the last pixel: a guard plane behind the output stays as it was
+    ybuf = torch.full((N * H * W + 64, cout), 7.0, dtype=hdt, device='cuda')
+    view = ybuf[:N * H * W].view(N, H, W, cout)
+    view.copy_(dev(base))
+    hip.conv2d_fwd(dev(x), dev(w), dev(b), 1, 0, accumulate_into=view)
+    assert bool((ybuf[N * H * W:] == 7.0).all())
+    assert torch.equal(view, got['fwd_acc'])
+
+
+def test_narrow_output_3x3_runs_pixel_paired(hip, ref):
+    """The outermost decoder's first 3x3 (64 -> 16 channels at 72x128): ops.PackedWeight pairs pixels (128 -> 32 over a 64-wide row,
+    ops.PAIR_NARROW_OUT) so that the halo kernel takes it instead of the first-generation gather kernel; through ops.conv2d
+    against the float reference, forward and both gradients."""
+    from eve_amd import ops
+    dt = torch.bfloat16
+    N, H, W, cin, cout = 2, 72, 128, 64, 16
+    x = dev(rnd((N, H, W, cin), dt, 71)).requires_grad_(True)
+    wt = torch.nn.Parameter(dev(rnd((cout, cin, 3, 3), torch.float32, 72, scale=(2.0 / (9 * cin)) ** 0.5)))
+    bias = torch.nn.Parameter(dev(rnd((cout,), torch.float32, 73, scale=0.1)))
+    pack = ops.PackedWeight(wt, dt)
+    assert pack.pair_fwd is not None and pack.pair_fwd[0] == 2 and tuple(pack.pair_fwd[1].shape) == (32, 3, 3, 128)
+    y = ops.conv2d(x, wt, bias, pack, stride=1, pad=1)
+    used = hip.lib.eve_last_kernel().decode()
+    assert 'halo' in used, used
+    dy = dev(rnd((N, H, W, cout), dt, 74))
+    y.backward(dy)
+    w_ohwi = wt.detach().permute(0, 2, 3, 1).to(dt)
+    want = ref.conv2d_fwd(x.detach().cpu(), w_ohwi.cpu(), bias.detach().cpu(), 1, 1)
+    close(y, want, dt, 'paired 64 -> 16 forward')
+    want_dx = ref.conv2d_dgrad(dy.cpu(), w_ohwi.permute(3, 1, 2, 0).contiguous().cpu(), (H, W), 1, 1)
+    close(x.grad, want_dx, dt, 'paired 64 -> 16 data gradient')
+    want_dw = ref.conv2d_wgrad(x.detach().cpu(), dy.cpu(), 3, 3, 1, 1, torch.zeros((cout, 3, 3, cin)))
+    close(wt.grad.permute(0, 2, 3, 1), want_dw, dt, 'paired 64 -> 16 weight gradient')
+
+
 def test_conv_rejects_bad_shapes(hip):
     x = torch.zeros((1, 8, 8, 6), device='cuda')
     w = torch.zeros((8, 3, 3, 6), device='cuda')
@@ -322,7 +398,8 @@ def test_conv_rejects_bad_shapes(hip):
 
 PLANE_CASES = [(3, 32, 32, 64), (2, 4, 4, 512), (2, 5, 8, 64), (2, 72, 128, 16), (2, 9, 16, 256), (1, 7, 5, 8),
                (2, 16, 16, 128), (3, 8, 8, 256), (2, 18, 32, 64), (2, 36, 64, 32), (2, 64, 64, 64),
-               (11, 32, 32, 64)]         # (planes of 4 097 .. 8 192 vectors are dealt to two workgroups, 8 blocks apart)
+               (11, 32, 32, 64),         # (planes of 4 097 .. 8 192 vectors are dealt to two workgroups, 8 blocks apart)
+               (9, 64, 64, 64), (3, 32, 32, 128)]    # the trunk on 256x256 patches: four / two parts of 8 192 vectors
 
 
 @pytest.mark.parametrize('dtype', DTYPES, ids=DT_IDS)
@@ -351,7 +428,13 @@ def test_instnorm_fwd_bwd(hip, ref, dtype, shape):
             close(dres_g, dres_w, dtype, 'instnorm_act bwd dres')
         fused = hip.instnorm_fwd_fused(dev(x), dev(g), dev(b), dev(r), act)
         nvec = H * W * C // (4 if dtype == torch.float32 else 8)
-        assert (fused is None) == (nvec > 8192)          # 8 vectors per thread x 1024 threads
+        # 8 vectors per thread x 1 024 threads; beyond that 16-bit planes WITHOUT affine parameters are dealt by channels to several
+        # workgroups (round 4, in_big_planes: down to one 16-byte vector per pixel and <= 9 216 vectors per part)
+        cv = C // (4 if dtype == torch.float32 else 8)
+        part = nvec
+        while part > 8192 and cv >= 2 and dtype != torch.float32 and g is None:
+            part, cv = part // 2, cv // 2
+        assert (fused is None) == (part > 8192 and not (part <= 9216 and dtype != torch.float32 and g is None))
         if fused is not None:
             close(fused[0], y_w, dtype, 'fused instnorm fwd act=%d' % act)
             close(fused[1][..., 0], mr_w[..., 0], torch.float32, 'fused mean', scale=1.0)
