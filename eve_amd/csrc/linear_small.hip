@@ -167,7 +167,7 @@ extern "C" int eve_linear_fwd(int M, int K, int N, const float* x, const float* 
                               float* y, eve_stream_t stream) {
     if (int e = ls_check(M, K, N, "linear_fwd: bad shape")) return e;
     if (!x || !w_in_out || !y) return set_error_msg("linear_fwd: null pointer");
-    hipLaunchKernelGGL(linear_mm_kernel, dim3((M + LS_TM - 1) / LS_TM, (N + LS_TN - 1) / LS_TN), dim3(256), 0, (hipStream_t)stream,
+    EVE_LAUNCH("linear_mm_kernel", linear_mm_kernel, dim3((M + LS_TM - 1) / LS_TM, (N + LS_TN - 1) / LS_TN), dim3(256), 0, (hipStream_t)stream,
                        x, (const float*)nullptr, 0, w_in_out, bias, act, y, M, K, N, K, N, N, 0);
     EVE_CHECK_LAUNCH();
     return 0;
@@ -177,7 +177,7 @@ extern "C" int eve_linear_dgrad(int M, int K, int N, const float* dy, const floa
                                 float* dx, eve_stream_t stream) {
     if (int e = ls_check(M, K, N, "linear_dgrad: bad shape")) return e;
     if (!dy || !w_out_in || !dx || (act != EVE_ACT_NONE && !y)) return set_error_msg("linear_dgrad: null pointer");
-    hipLaunchKernelGGL(linear_mm_kernel, dim3((M + LS_TM - 1) / LS_TM, (K + LS_TN - 1) / LS_TN), dim3(256), 0, (hipStream_t)stream,
+    EVE_LAUNCH("linear_mm_kernel", linear_mm_kernel, dim3((M + LS_TM - 1) / LS_TM, (K + LS_TN - 1) / LS_TN), dim3(256), 0, (hipStream_t)stream,
                        dy, act != EVE_ACT_NONE ? y : (const float*)nullptr, act, w_out_in, (const float*)nullptr, 0, dx, M, N, K, N, K, 0, 0);
     EVE_CHECK_LAUNCH();
     return 0;
@@ -195,7 +195,7 @@ extern "C" int eve_linear_wgrad(int M, int K, int N, const float* dy, const floa
     int rows = (M + splits - 1) / splits;
     rows = (rows + 31) / 32 * 32;
     splits = (M + rows - 1) / rows;
-    hipLaunchKernelGGL(linear_wgrad_kernel, dim3((K + 63) / 64, (N + 31) / 32, splits), dim3(256), 0, (hipStream_t)stream, dy,
+    EVE_LAUNCH("linear_wgrad_kernel", linear_wgrad_kernel, dim3((K + 63) / 64, (N + 31) / 32, splits), dim3(256), 0, (hipStream_t)stream, dy,
                        act != EVE_ACT_NONE ? y : (const float*)nullptr, act, x, dw_out_in, db, M, N, K, rows);
     EVE_CHECK_LAUNCH();
     return 0;
@@ -352,7 +352,7 @@ __global__ __launch_bounds__(256) void linear_wgrad_batch_kernel(const eve_wgrad
         for (int i = 0; i < 4; ++i) { const int e = tid + 256 * i; sG[e >> 5][e & 31] = g4[i]; }
         __syncthreads();
         const int rmax = min(32, m_end - mc);
-#pragma unroll
+#pragma unroll 1
         for (int r0 = 0; r0 < 32; r0 += 8) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
@@ -406,7 +406,7 @@ extern "C" int eve_linear_chain(const eve_chain_params* p, eve_stream_t stream) 
         if (s + 1 < p->nstages && !p->st[s + 1].from_input && st.Nc > 512) return set_error_msg("linear_chain: intermediate wider than 512");
         w = st.Nc;
     }
-    hipLaunchKernelGGL(linear_chain_kernel, dim3((p->M + LS_TM - 1) / LS_TM), dim3(256), 0, (hipStream_t)stream, *p);
+    EVE_LAUNCH("linear_chain_kernel", linear_chain_kernel, dim3((p->M + LS_TM - 1) / LS_TM), dim3(256), 0, (hipStream_t)stream, *p);
     EVE_CHECK_LAUNCH();
     return 0;
 }
@@ -434,7 +434,7 @@ extern "C" int eve_linear_wgrad_batch(const eve_wgrad_problem* problems, int n, 
         b.first_block[i] = total;
         total += tiles * splits;
     }
-    hipLaunchKernelGGL(linear_wgrad_batch_kernel, dim3(total), dim3(256), 0, (hipStream_t)stream, b);
+    EVE_LAUNCH("linear_wgrad_batch_kernel", linear_wgrad_batch_kernel, dim3(total), dim3(256), 0, (hipStream_t)stream, b);
     EVE_CHECK_LAUNCH();
     return 0;
 }
@@ -443,7 +443,7 @@ extern "C" int eve_linear_fwd_ex(int M, int K, int N, const float* x, int ldx, c
                                  int act, float* y, int ldy, eve_stream_t stream) {
     if (int e = ls_check(M, K, N, "linear_fwd_ex: bad shape")) return e;
     if (!x || !w_in_out || !y || ldx < K || ldy < N) return set_error_msg("linear_fwd_ex: bad arguments");
-    hipLaunchKernelGGL(linear_mm_kernel, dim3((M + LS_TM - 1) / LS_TM, (N + LS_TN - 1) / LS_TN), dim3(256), 0, (hipStream_t)stream,
+    EVE_LAUNCH("linear_mm_kernel", linear_mm_kernel, dim3((M + LS_TM - 1) / LS_TM, (N + LS_TN - 1) / LS_TN), dim3(256), 0, (hipStream_t)stream,
                        x, (const float*)nullptr, 0, w_in_out, bias, act, y, M, K, N, ldx, ldy, bias ? n_bias : 0, 0);
     EVE_CHECK_LAUNCH();
     return 0;
@@ -453,7 +453,7 @@ extern "C" int eve_linear_dgrad_ex(int M, int K, int N, const float* dy, int ldd
                                    float* dx, int lddx, int accumulate, eve_stream_t stream) {
     if (int e = ls_check(M, K, N, "linear_dgrad_ex: bad shape")) return e;
     if (!dy || !w_out_in || !dx || (act != EVE_ACT_NONE && !y) || lddy < N || lddx < K) return set_error_msg("linear_dgrad_ex: bad arguments");
-    hipLaunchKernelGGL(linear_mm_kernel, dim3((M + LS_TM - 1) / LS_TM, (K + LS_TN - 1) / LS_TN), dim3(256), 0, (hipStream_t)stream,
+    EVE_LAUNCH("linear_mm_kernel", linear_mm_kernel, dim3((M + LS_TM - 1) / LS_TM, (K + LS_TN - 1) / LS_TN), dim3(256), 0, (hipStream_t)stream,
                        dy, act != EVE_ACT_NONE ? y : (const float*)nullptr, act, w_out_in, (const float*)nullptr, 0, dx, M, N, K, lddy, lddx, 0,
                        accumulate);
     EVE_CHECK_LAUNCH();
@@ -500,21 +500,21 @@ __global__ __launch_bounds__(256) void tail_head_pose_kernel(const int BT, const
 
 extern "C" int eve_tail_head_pose(int BT, const float* h_left, const float* h_right, float* cat, int ld, int col, eve_stream_t stream) {
     if (BT <= 0 || !h_left || !h_right || !cat || ld < col + 4 || (ld & 3) || (col & 3)) return set_error_msg("tail_head_pose: bad arguments");
-    hipLaunchKernelGGL(tail_head_pose_kernel, dim3((2 * BT + 255) / 256), dim3(256), 0, (hipStream_t)stream, BT, h_left, h_right, cat, ld, col);
+    EVE_LAUNCH("tail_head_pose_kernel", tail_head_pose_kernel, dim3((2 * BT + 255) / 256), dim3(256), 0, (hipStream_t)stream, BT, h_left, h_right, cat, ld, col);
     EVE_CHECK_LAUNCH();
     return 0;
 }
 
 extern "C" int eve_tail_outputs_fwd(int M, const float* g2, const float* p2, float* gaze, float* pupil, eve_stream_t stream) {
     if (M <= 0 || !g2 || !p2 || !gaze || !pupil) return set_error_msg("tail_outputs_fwd: bad arguments");
-    hipLaunchKernelGGL(tail_outputs_fwd_kernel, dim3((M + 255) / 256), dim3(256), 0, (hipStream_t)stream, M, g2, p2, gaze, pupil);
+    EVE_LAUNCH("tail_outputs_fwd_kernel", tail_outputs_fwd_kernel, dim3((M + 255) / 256), dim3(256), 0, (hipStream_t)stream, M, g2, p2, gaze, pupil);
     EVE_CHECK_LAUNCH();
     return 0;
 }
 extern "C" int eve_tail_outputs_bwd(int BT, const float* dg_l, const float* dg_r, const float* dp_l, const float* dp_r, const float* g_full,
                                     float coeff_ang, float coeff_l1, float* d_g2, float* d_p2, eve_stream_t stream) {
     if (BT <= 0 || !dg_l || !dg_r || !dp_l || !dp_r || !d_g2 || !d_p2) return set_error_msg("tail_outputs_bwd: bad arguments");
-    hipLaunchKernelGGL(tail_outputs_bwd_kernel, dim3((2 * BT + 255) / 256), dim3(256), 0, (hipStream_t)stream, BT, dg_l, dg_r, dp_l, dp_r,
+    EVE_LAUNCH("tail_outputs_bwd_kernel", tail_outputs_bwd_kernel, dim3((2 * BT + 255) / 256), dim3(256), 0, (hipStream_t)stream, BT, dg_l, dg_r, dp_l, dp_r,
                        g_full, coeff_ang, coeff_l1, d_g2, d_p2);
     EVE_CHECK_LAUNCH();
     return 0;

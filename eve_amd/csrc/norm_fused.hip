@@ -134,7 +134,7 @@ template <typename T, int VPT, int ACT>
 __global__ __launch_bounds__(1024) void in_bwd_fused_kernel(const T* __restrict__ dy, const T* __restrict__ dy2,
                                                             const T* __restrict__ y,
                                                             const T* __restrict__ x, const float* __restrict__ mr,
-                                                            const float* __restrict__ gamma, int act_rt,
+                                                            const float* __restrict__ gamma, const float* __restrict__ beta, int act_rt,
                                                             T* __restrict__ dx, T* __restrict__ dres,
                                                             float* __restrict__ sums, const unsigned char* __restrict__ mask,
                                                             int N, int HW, int C, int sl) {
@@ -154,6 +154,13 @@ __global__ __launch_bounds__(1024) void in_bwd_fused_kernel(const T* __restrict_
         const float* m = mr + ((size_t)pp.plane * C + c0 + cv * VEC) * 2;
 #pragma unroll
         for (int e = 0; e < VEC; ++e) { mean[e] = m[2 * e]; rstd[e] = m[2 * e + 1]; }
+    }
+    // the forward's scale / shift (in_fwd_fused_kernel: same expressions, same roundings), for act' from x when y is not given
+    float za[VEC], zb[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+        za[e] = rstd[e]; zb[e] = -mean[e] * rstd[e];
+        if (gamma && beta) { const int c = c0 + cv * VEC + e; za[e] *= gamma[c]; zb[e] = zb[e] * gamma[c] + beta[c]; }
     }
     uint4 qg[VPT], qx[VPT];          // g = dy * act'(y) re-packed, and x
     float s1[VEC], s2[VEC];
@@ -186,6 +193,9 @@ __global__ __launch_bounds__(1024) void in_bwd_fused_kernel(const T* __restrict_
                 float yy[VEC];
                 if (y) {
                     Elem<T>::unpack(reinterpret_cast<const uint4*>(y)[gi(i)], yy);
+                } else if (gamma) { // affine, no residual: y = act(x * za + zb) exactly as the forward formed it
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) yy[e] = act_fwd(fmaf(xx[e], za[e], zb[e]), act);
                 } else {            // no affine, no residual: y = act(xhat), and sign(xhat) = sign(x - mean)
 #pragma unroll
                     for (int e = 0; e < VEC; ++e) yy[e] = act_fwd((xx[e] - mean[e]) * rstd[e], act);
@@ -598,11 +608,11 @@ extern "C" int eve_instnorm_fwd_fused(int dtype, int N, int HW, int C, const voi
 }
 
 extern "C" int eve_instnorm_bwd_fused(int dtype, int N, int HW, int C, const void* dy, const void* dy2, const void* y, const void* x,
-                                      const float* mean_rstd, const float* gamma, int act, void* dx, void* dres,
+                                      const float* mean_rstd, const float* gamma, const float* beta, int act, void* dx, void* dres,
                                       float* sums, const unsigned char* sign_mask, eve_stream_t stream) {
     const int vec = dtype != EVE_DT_F32 ? 8 : 4;
     if (((unsigned)dtype > (unsigned)EVE_DT_F16) || N <= 0 || HW <= 0 || C <= 0 || C % vec || !dy || !x ||
-        !mean_rstd || !dx || (act != EVE_ACT_NONE && !y && gamma && !(act == EVE_ACT_RELU && sign_mask)))
+        !mean_rstd || !dx || (act != EVE_ACT_NONE && !y && gamma && !beta && !(act == EVE_ACT_RELU && sign_mask)))
         return set_error_msg("instnorm_bwd_fused: bad arguments");
     int threads, vpt, sl;
     if (!fused_plan(HW * (C / vec), C / vec, threads, vpt, sl, dtype != EVE_DT_F32, gamma == nullptr)) return -1;
@@ -635,13 +645,13 @@ extern "C" int eve_instnorm_bwd_fused(int dtype, int N, int HW, int C, const voi
 #undef BWD_TRUNK_ARGS
     }
     if (dtype == EVE_DT_BF16) {
-        LAUNCH_VPT(in_bwd_fused_kernel, bf16_t, "eve::bf16_t", (const bf16_t*)dy, (const bf16_t*)dy2, (const bf16_t*)y, (const bf16_t*)x, mean_rstd, gamma,
+        LAUNCH_VPT(in_bwd_fused_kernel, bf16_t, "eve::bf16_t", (const bf16_t*)dy, (const bf16_t*)dy2, (const bf16_t*)y, (const bf16_t*)x, mean_rstd, gamma, beta,
                    act, (bf16_t*)dx, (bf16_t*)dres, sums, sign_mask, N, HW, C, sl)
     } else if (dtype == EVE_DT_F16) {
-        LAUNCH_VPT(in_bwd_fused_kernel, f16_t, "eve::f16_t", (const f16_t*)dy, (const f16_t*)dy2, (const f16_t*)y, (const f16_t*)x, mean_rstd, gamma,
+        LAUNCH_VPT(in_bwd_fused_kernel, f16_t, "eve::f16_t", (const f16_t*)dy, (const f16_t*)dy2, (const f16_t*)y, (const f16_t*)x, mean_rstd, gamma, beta,
                    act, (f16_t*)dx, (f16_t*)dres, sums, sign_mask, N, HW, C, sl)
     } else {
-        LAUNCH_VPT(in_bwd_fused_kernel, float, "float", (const float*)dy, (const float*)dy2, (const float*)y, (const float*)x, mean_rstd, gamma,
+        LAUNCH_VPT(in_bwd_fused_kernel, float, "float", (const float*)dy, (const float*)dy2, (const float*)y, (const float*)x, mean_rstd, gamma, beta,
                    act, (float*)dx, (float*)dres, sums, sign_mask, N, HW, C, sl)
     }
     EVE_CHECK_LAUNCH();

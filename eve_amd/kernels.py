@@ -706,9 +706,10 @@ class HipKernels(object):
         self._ck(st)
         return (y, mr, mask) if want_mask else (y, mr)
 
-    def instnorm_bwd_fused(self, dy, y, x, mr, gamma, act, want_dres, dy2=None, mask=None):
+    def instnorm_bwd_fused(self, dy, y, x, mr, gamma, act, want_dres, dy2=None, mask=None, beta=None):
         """Single-launch backward; returns (dx, dres, sums) or None when the plane is too large.
         dy2: optional second summand of the incoming gradient (added on load).
+        beta: with gamma and y = None (no residual), act' is recomputed from x with the forward's scale / shift.
         mask: the forward's sign mask (ReLU only), read instead of y."""
         N, H, W, C = x.shape
         dx = torch.empty_like(x)
@@ -716,7 +717,7 @@ class HipKernels(object):
         sums = torch.empty((N, C, 2), dtype=torch.float32, device=x.device)
         st = self._timed('in_bwd', 0.0, lambda: self.lib.eve_instnorm_bwd_fused(
             dt_code(x.dtype), N, H * W, C, self._p(dy), self._p(dy2), self._p(None if mask is not None else y), self._p(x), self._p(mr),
-            self._p(self._f32(gamma, 'gamma')), act, self._p(dx), self._p(dres), self._p(sums), self._p(mask),
+            self._p(self._f32(gamma, 'gamma')), self._p(self._f32(beta, 'beta')), act, self._p(dx), self._p(dres), self._p(sums), self._p(mask),
             self._stream()), (dy, dy2, y if mask is None else mask, x, dx, dres))
         if st == -1:
             if self.prof:

@@ -848,7 +848,7 @@ class InstNormActFn(torch.autograd.Function):
         ctx.act, ctx.has_res, ctx.has_affine = act, res is not None, gamma is not None
         # the backward needs y only to evaluate act'; without a residual it recomputes that from x (the register-resident
         # kernel does so only when there is no affine either)
-        need_y = act != ACT_NONE and (res is not None or (gamma is not None and fused is not None))
+        need_y = act != ACT_NONE and res is not None       # (else both backward kernels recompute act' from x: gamma / beta given)
         ctx.save_for_backward(x, y if need_y else None, mr, g, b)
         return y
 
@@ -857,9 +857,7 @@ class InstNormActFn(torch.autograd.Function):
         k = default_kernels()
         x, y, mr, g, b = ctx.saved_tensors
         want_dres = ctx.has_res and ctx.needs_input_grad[3]
-        out = None
-        if y is not None or ctx.act == ACT_NONE or g is None:
-            out = k.instnorm_bwd_fused(dy.contiguous(), y, x, mr, g, ctx.act, want_dres)
+        out = k.instnorm_bwd_fused(dy.contiguous(), y, x, mr, g, ctx.act, want_dres, beta=b)
         if out is None:
             out = k.instnorm_act_bwd(dy.contiguous(), y, x, mr, g, ctx.act, want_dres, beta=b)
         dx, dres, sums = out

@@ -285,8 +285,10 @@ int eve_instnorm_fwd_fused(int dtype, int N, int HW, int C, const void* x, const
 /* dy2 (nullable): a second summand of the incoming gradient, added on load -- the residual fork of a ResNet
  * block delivers d(block input) as two tensors and the sum is never materialised.                      */
 /* sign_mask (nullable; act == EVE_ACT_RELU): the forward's mask, read INSTEAD of y.                          */
+/* beta (nullable): with gamma and no y, act'(.) is recomputed from x with the forward's own scale / shift
+ * (act(x * rstd*gamma + (beta - mean*rstd*gamma))) -- no residual: one tensor less to read and to keep.       */
 int eve_instnorm_bwd_fused(int dtype, int N, int HW, int C, const void* dy, const void* dy2, const void* y,
-                           const void* x, const float* mean_rstd, const float* gamma, int act,
+                           const void* x, const float* mean_rstd, const float* gamma, const float* beta, int act,
                            void* dx, void* dres, float* sums, const unsigned char* sign_mask, eve_stream_t stream);
 
 /* out[j] = sum_r in[r][j] (float32, fixed summation order): the batch reduction of the per-plane partials `sums` above into

@@ -194,7 +194,7 @@ class FakeKernels(object):
         bits = (y.reshape(-1, vec) > 0).to(torch.int32) << torch.arange(vec, dtype=torch.int32)
         return y, mr, bits.sum(dim=1).to(torch.uint8)
 
-    def instnorm_bwd_fused(self, dy, y, x, mr, gamma, act, want_dres, dy2=None, mask=None):
+    def instnorm_bwd_fused(self, dy, y, x, mr, gamma, act, want_dres, dy2=None, mask=None, beta=None):
         if x.shape[1] * x.shape[2] * x.shape[3] > 65536:
             return None
         if dy2 is not None:
@@ -203,7 +203,7 @@ class FakeKernels(object):
             assert act == ACT_RELU and y is None
             vec = 16 // x.element_size()
             y = ((mask.to(torch.int32).unsqueeze(1) >> torch.arange(vec, dtype=torch.int32)) & 1).reshape(x.shape).to(x.dtype)
-        return self.instnorm_act_bwd(dy, y, x, mr, gamma, act, want_dres)
+        return self.instnorm_act_bwd(dy, y, x, mr, gamma, act, want_dres, beta=beta if y is None else None)
 
     def act_bwd(self, dy, y, act):
         return (dy.float() * act_grad_from_out(y.float(), act)).to(dy.dtype)

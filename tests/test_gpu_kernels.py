@@ -444,6 +444,12 @@ def test_instnorm_fwd_bwd(hip, ref, dtype, shape):
             close(fb[2], s_w, torch.float32, 'fused instnorm bwd sums', scale=float(s_w.abs().max()) * 4)
             if r is not None:
                 close(fb[1], dres_w, dtype, 'fused instnorm bwd dres')
+            if g is not None and r is None:      # affine, no residual: act' recomputed from x with the forward's scale / shift (round 4)
+                fr = hip.instnorm_bwd_fused(dev(dy), None, dev(x), fused[1], dev(g), act, False, beta=dev(b))
+                fyy = hip.instnorm_bwd_fused(dev(dy), fused[0], dev(x), fused[1], dev(g), act, False)
+                if dtype != torch.float16:      # (float16 can round a tiny positive pre-activation to 0; bf16 / float32 cannot)
+                    assert torch.equal(fr[0], fyy[0]) and torch.equal(fr[2], fyy[2])
+                close(fr[0], dx_w, dtype, 'fused instnorm bwd from x act=%d' % act, scale=float(dx_w.abs().max()) + 0.05)
             if act == 1:       # ReLU: the forward's sign mask (one byte per 16-byte vector) replaces y in the backward
                 y_m, _, mask = hip.instnorm_fwd_fused(dev(x), dev(g), dev(b), dev(r), act, want_mask=True)
                 assert torch.equal(y_m, fused[0])
