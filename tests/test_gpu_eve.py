@@ -421,10 +421,13 @@ def test_eve_trainer_hipgraph_replay_equals_eager_steps(dtype):
         assert tr.optimizer_state()['steps_taken'] == 3
         runs[mode] = (log, first_grad)
         model.drop_static_kappa()
-    tol = 2e-5 if dtype == torch.float32 else 2e-2
-    for a, b in zip(runs['eager'][0], runs['graph'][0]):
+    # step 1 starts from identical weights: 2e-5.  Steps 2 and 3 start from weights that differ in the last bits (the order of the
+    # weight-gradient atomics of step 1), and the refined point of gaze is a soft-argmax over softmax(100 h): one run in ~6 of the
+    # float32 case moved `metric_euc_PoG_px_final` by 4.5e-5 relative (610.454 vs 610.482 px) -- 2e-4 for those steps
+    for i, (a, b) in enumerate(zip(runs['eager'][0], runs['graph'][0])):
+        tol = (2e-5 if i == 0 else 2e-4) if dtype == torch.float32 else 2e-2
         for k in a:
-            assert abs(a[k] - b[k]) <= tol * max(1.0, abs(a[k])), (k, a[k], b[k])
+            assert abs(a[k] - b[k]) <= tol * max(1.0, abs(a[k])), (i, k, a[k], b[k])
     # the three draws differ from one another (the augmentation is live) ...
     assert len({round(s['metric_euc_PoG_px_initial'], 3) for s in runs['graph'][0]}) == 3
     # ... and the FIRST step's gradient is the eager one's up to the weight-gradient atomics' order (later steps' gradients are
