@@ -601,6 +601,8 @@ static bool launch_halo(const GatherParams& p, const void* src, const void* w, c
             // time in the un-overlapped prologue / epilogue; since the epilogue stores 64 contiguous bytes per lane quad it is
             // ahead of the four-wave kernel there too (0.141 against 0.151-0.166 ms; EVE_CONV_WG8=3 keeps the four-wave kernel)
             if (wg8 != 3 && W == 16 && p.Cout % 128 == 0 && p.Cout % 256 != 0) EVE_WG8_LAUNCH(4, 2, 16);
+            // 16 x 16 x 256 (the trunk's layer 3 on 256 x 256 patches, BASELINE configs[4]): one image x 256 channels per tile
+            if (W == 16 && p.Cout % 256 == 0) EVE_WG8_LAUNCH(2, 4, 16);
             if (W == 8 && p.Cout % 256 == 0) EVE_WG8_LAUNCH(2, 4, 8);
             if (W == 4 && p.Cout % 256 == 0) EVE_WG8_LAUNCH(2, 4, 4);
         }
@@ -1184,7 +1186,22 @@ extern "C" int eve_stem_wgrad(int dtype, int N, int IH, int IW, const void* x_pa
     // conv pad is 3, the packed rows carry 4 pixels of left padding: start one pixel (8 bytes) in
     const char* x1 = (const char*)x_padded + 8;
     if ((unsigned long long)N * p.IH * p.IW * 8 >= (1ull << 31)) return set_error_msg("stem_wgrad: packed input must stay below 2 GiB");
-    EVE_DISPATCH_H16(dtype, launch_wgrad<H>(p, x1, dconv, nullptr, 0, dw, (hipStream_t)stream));
+    // the transposing-read kernel addresses its operands with 32-bit buffer offsets: images are taken in chunks whose d(conv out)
+    // stays below 2 GiB (the weight gradient accumulates, so the chunks simply add up).  256 x 256 patches x 1 920 frames
+    // (BASELINE configs[4]) are 4 GiB of d(conv out): as ONE launch they fell to the first-generation kernel, 4.4 ms.
+    const unsigned long long per_img = (unsigned long long)p.OH * p.OW * 64 * 2;
+    int chunk = (int)(((1ull << 31) - 1) / per_img);
+    if (chunk < 1) return set_error_msg("stem_wgrad: one image's gradient exceeds 2 GiB");
+    const int nchunks = (N + chunk - 1) / chunk;
+    chunk = (N + nchunks - 1) / nchunks;
+    for (int n0 = 0; n0 < N; n0 += chunk) {
+        const int n = N - n0 < chunk ? N - n0 : chunk;
+        p.N = n;
+        p.M = (uint32_t)((long long)n * p.OH * p.OW);
+        const char* xc = x1 + (size_t)n0 * p.IH * p.IW * 8;
+        const char* dc = (const char*)dconv + (size_t)n0 * per_img;
+        EVE_DISPATCH_H16(dtype, launch_wgrad<H>(p, xc, dc, nullptr, 0, dw, (hipStream_t)stream));
+    }
     EVE_CHECK_LAUNCH();
     return 0;
 }

@@ -175,7 +175,7 @@ class EyeNet(nn.Module):
             blocks.append(((P[name + '.conv1'], P[name + '.conv2'], P[name + '.downsample.0'] if ds is not None else None),
                            blk.stride))
             weights += [blk.conv1.weight, blk.conv2.weight] + ([ds[0].weight] if ds is not None else [])
-        if x is None or (x_padded is not None and x_padded.shape[2] == 136 and x_padded.shape[1] % 4 == 2):
+        if x_padded is not None and x_padded.shape[2] == 136 and x_padded.shape[1] % 4 == 2:
             # 128-wide patches: conv1 -> bn1 -> relu -> maxpool in one launch, inside the trunk node
             y = ops.ResNetTrunkFn.apply(None, x, x_padded, (P['conv1'], tuple(blocks)), 1e-5, cnn.conv1.weight, *weights)
         else:
@@ -381,10 +381,15 @@ class EyeNet(nn.Module):
             k.stem_pack_input(left.reshape(B * T, C, Hh, Ww), out=x_padded[:B * T])
             k.stem_pack_input(right.reshape(B * T, C, Hh, Ww), out=x_padded[B * T:])
         else:
-            x = torch.empty((2 * B * T, Hh, Ww, cpad), dtype=dt, device=left.device)
-            k.nchw_to_nhwc(left.reshape(B * T, C, Hh, Ww), dt, cpad, out=x[:B * T])
-            k.nchw_to_nhwc(right.reshape(B * T, C, Hh, Ww), dt, cpad, out=x[B * T:])
-            if dt in HALF_DTYPES and C <= 4 and Hh % 2 == 0 and Ww % 128 == 0:  # dedicated stem conv kernel
+            stem_kernel = dt in HALF_DTYPES and C <= 4 and Hh % 2 == 0 and Ww % 128 == 0          # dedicated stem conv kernel
+            # its weight gradient reads the packed patches too (ops.StemConvFn) while they stay below 2 GiB: the 8-channel NHWC
+            # copy (2 GB at configs[4]'s 1 920 frames of 256 x 256) is then not made at all
+            packed_wgrad = stem_kernel and 2 * B * T * (Hh + 6) * (Ww + 8) * 8 < (1 << 31)
+            if not packed_wgrad:
+                x = torch.empty((2 * B * T, Hh, Ww, cpad), dtype=dt, device=left.device)
+                k.nchw_to_nhwc(left.reshape(B * T, C, Hh, Ww), dt, cpad, out=x[:B * T])
+                k.nchw_to_nhwc(right.reshape(B * T, C, Hh, Ww), dt, cpad, out=x[B * T:])
+            if stem_kernel:
                 x_padded = torch.empty((2 * B * T, Hh + 6, Ww + 8, 4), dtype=dt, device=left.device)
                 k.stem_pack_input(left.reshape(B * T, C, Hh, Ww), out=x_padded[:B * T])
                 k.stem_pack_input(right.reshape(B * T, C, Hh, Ww), out=x_padded[B * T:])

@@ -288,18 +288,28 @@ class StemConvFn(torch.autograd.Function):
     def forward(ctx, x8, x_padded, weight, pack):
         y = default_kernels().stem7x7s2_fwd(x_padded, pack.ohwi)
         ctx.pack = pack
-        ctx.save_for_backward(x8)
+        # the weight gradient reads the packed patches (K = 7 x 8 x 4 = 224: one MFMA tile row) when they stay below the kernel's
+        # 2 GiB addressing; round 4: also for patch widths other than 128 -- 256 x 256 patches (configs[4]) took the generic
+        # 8-channel path, whose K = 392 falls to the first-generation weight-gradient kernel: 8.7 ms per step
+        packed_ok = x_padded.dtype in HALF_DTYPES and x_padded.numel() * 2 < (1 << 31) and x_padded.shape[1] % 2 == 0 and \
+            hasattr(default_kernels(), 'stem_wgrad')
+        ctx.packed = packed_ok
+        ctx.save_for_backward(x_padded if packed_ok else x8)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         k = default_kernels()
-        (x8,) = ctx.saved_tensors
+        (xs,) = ctx.saved_tensors
         pack = ctx.pack
-        cout_p, KH, KW, cin_p = pack.ohwi.shape
-        dwp = torch.zeros((cout_p, KH, KW, cin_p), dtype=torch.float32, device=x8.device)
-        k.conv2d_wgrad(x8, dy.contiguous(), KH, KW, 2, 3, dwp, algo=pack.algo)
         O, I = pack.shape_oihw[0], pack.shape_oihw[1]
+        if ctx.packed:
+            dwp = torch.zeros((64, 7, 8, 4), dtype=torch.float32, device=xs.device)
+            k.stem_wgrad(xs, dy.contiguous(), dwp)
+            return None, None, dwp[:O, :, :7, :I].permute(0, 3, 1, 2), None
+        cout_p, KH, KW, cin_p = pack.ohwi.shape
+        dwp = torch.zeros((cout_p, KH, KW, cin_p), dtype=torch.float32, device=xs.device)
+        k.conv2d_wgrad(xs, dy.contiguous(), KH, KW, 2, 3, dwp, algo=pack.algo)
         return None, None, dwp[:O, :, :, :I].permute(0, 3, 1, 2), None
 
 

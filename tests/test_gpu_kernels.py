@@ -83,6 +83,7 @@ CONV_CASES = [
     (101, 32, 32, 64, 128, 3, 2, 1),    # layer 2.0
     (197, 16, 16, 128, 256, 3, 2, 1),   # layer 3.0
     (395, 8, 8, 256, 512, 3, 2, 1),     # layer 4.0
+    (229, 16, 16, 256, 256, 3, 1, 1),   # layer 3 on 256 x 256 patches (configs[4]): conv3x3_wg8_kernel<2, 4, 16>, one image per tile
 ]
 
 
@@ -290,6 +291,34 @@ def test_stem_wgrad_from_packed_patches(hip, hdt):
     ref = torch.nn.grad.conv2d_weight(x8.float().permute(0, 3, 1, 2)[:, :3], (64, 3, 7, 7), dconv.float().permute(0, 3, 1, 2),
                                       stride=2, padding=3).permute(0, 2, 3, 1)
     assert ((got - ref).norm() / ref.norm()).item() < 2e-3
+
+
+def test_stem_wgrad_takes_images_in_chunks_below_2_gib():
+    """256 x 256 patches (BASELINE configs[4]): d(conv1 out) of 1 030 frames is 2.01 GiB, beyond the transposing-read kernel's 32-bit
+    buffer offsets -- eve_stem_wgrad takes the images in chunks (round 4; as one launch it fell to the first-generation kernel).
+    The chunked call == the sum of two calls on the halves (each a single launch), and no first-generation kernel ran."""
+    hdt = torch.float16
+    N = 1030
+    g = torch.Generator(device='cuda').manual_seed(5)
+    xp = torch.zeros((N, 262, 264, 4), dtype=hdt, device='cuda')
+    xp[:, 3:259, 4:260, :3] = torch.randn((N, 256, 256, 3), generator=g, device='cuda').to(hdt)
+    dconv = (0.05 * torch.randn((N, 128, 128, 64), generator=g, device='cuda')).to(hdt)
+    from eve_amd.kernels import default_kernels
+    k = default_kernels()
+    dw = torch.zeros((64, 7, 8, 4), device='cuda')
+    k.stem_wgrad(xp, dconv, dw)
+    assert 'wgrad_tr_kernel' in k.lib.eve_last_kernel().decode(), k.lib.eve_last_kernel().decode()
+    ref = torch.zeros((64, 7, 8, 4), device='cuda')
+    k.stem_wgrad(xp[:515], dconv[:515], ref)
+    k.stem_wgrad(xp[515:], dconv[515:], ref)
+    assert float((dw - ref).norm() / ref.norm()) < 1e-5
+    # ... and a float reference on a few images of the tail of the batch
+    sub = slice(N - 3, N)
+    want = torch.nn.grad.conv2d_weight(xp[sub, 3:259, 4:260, :3].float().permute(0, 3, 1, 2), (64, 3, 7, 7),
+                                       dconv[sub].float().permute(0, 3, 1, 2), stride=2, padding=3).permute(0, 2, 3, 1)
+    got = torch.zeros((64, 7, 8, 4), device='cuda')
+    k.stem_wgrad(xp[sub].contiguous(), dconv[sub].contiguous(), got)
+    assert float((got[:, :, :7, :3] - want).norm() / want.norm()) < 2e-3
 
 
 @pytest.mark.parametrize('dtype', DTYPES, ids=DT_IDS)
