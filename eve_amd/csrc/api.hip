@@ -29,7 +29,7 @@ static eve_dispatch_config default_dispatch_config() {
     c.conv_wg8_min_tiles = 224; c.conv_wg8_s2_min_tiles = 48; c.halo_persist = 1;
     c.wgrad_target_wgs = 0; c.wgrad_min_rows = 1536; c.wgrad_halo = 1; c.wgrad_wg8 = 1;
     c.wg64_th = 0; c.wg64_nreg = 0; c.wg64_fixed = 1;
-    c.in_split = 1; c.in_min_threads = 512; c.in_stats_one_pass = 1; c.stem_split = 1; c.in_trunk_kernels = 1; c.stem_fused_wgrad = 1; c.stem_fwd_pairs = 1; c.in_big_planes = 1; c.conv1x1_stream = 1;
+    c.in_split = 1; c.in_min_threads = 512; c.in_stats_one_pass = 1; c.stem_split = 1; c.in_trunk_kernels = 1; c.stem_fused_wgrad = 1; c.stem_fwd_pairs = 1; c.in_big_planes = 1; c.conv1x1_stream = 1; c.conv3x3_stream = 1;
     c.wgrad_halo_min_m = 1ll << 20;
     return c;
 }
@@ -51,6 +51,7 @@ static eve_dispatch_config load_dispatch_config() {
     env_int("EVE_STEM_FWD_PAIRS", c.stem_fwd_pairs);
     env_int("EVE_IN_BIG_PLANES", c.in_big_planes);
     env_int("EVE_CONV1X1_STREAM", c.conv1x1_stream);
+    env_int("EVE_CONV3X3_STREAM", c.conv3x3_stream);
     if (const char* e = getenv("EVE_WGRAD_HALO_MIN_M")) c.wgrad_halo_min_m = atoll(e);
     if (c.wgrad_min_rows < 64) c.wgrad_min_rows = 64;
     if (c.in_min_threads < 64) c.in_min_threads = 64;

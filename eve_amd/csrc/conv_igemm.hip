@@ -70,6 +70,7 @@ template <> struct Mma<float> {
 #include "conv_wg8s2.h"
 #include "conv_ws64.h"
 #include "conv_1x1.h"
+#include "conv_3x3s.h"
 #include "wgrad_halo.h"
 #include "wgrad_wg8.h"
 namespace eve {
@@ -1022,6 +1023,11 @@ extern "C" int eve_conv2d_fwd(const eve_conv_desc* d, const void* x, const void*
         EVE_DISPATCH_H16(d->dtype, done = launch_conv1x1_stream<H>(M, d->Cin, d->Cout, x, w_ohwi, bias, epi_act, y, s));
         if (done) { EVE_CHECK_LAUNCH(); return 0; }
     }
+    if (!in_scale_shift && d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == 1 && d->dtype != EVE_DT_F32) {    // row-streaming 3x3
+        bool done = false;
+        EVE_DISPATCH_H16(d->dtype, done = launch_conv3x3_stream<H>(d->N, d->IH, d->IW, d->Cin, d->Cout, 0, x, w_ohwi, bias, epi_act, y, s));
+        if (done) { EVE_CHECK_LAUNCH(); return 0; }
+    }
     if (!in_scale_shift) {          // the trunk's stride-2 3x3 layers: parity planes of the input as rotating halo stages
         if (d->dtype == EVE_DT_BF16 && launch_s2_fwd_wg8<bf16_t>(d, x, w_ohwi, bias, epi_act, y, s)) { EVE_CHECK_LAUNCH(); return 0; }
         if (d->dtype == EVE_DT_F16 && launch_s2_fwd_wg8<f16_t>(d, x, w_ohwi, bias, epi_act, y, s)) { EVE_CHECK_LAUNCH(); return 0; }
@@ -1118,6 +1124,11 @@ extern "C" int eve_conv2d_dgrad(const eve_conv_desc* d, const void* dy, const vo
         EVE_DISPATCH_H16(d->dtype, done = launch_conv1x1_stream<H>(M, d->Cout, d->Cin, dy, w_ihwo, nullptr, 0, dx, s));
         if (done) { EVE_CHECK_LAUNCH(); return 0; }
     }
+    if (d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == 1 && d->dtype != EVE_DT_F32) {    // row-streaming 3x3, mirrored taps
+        bool done = false;
+        EVE_DISPATCH_H16(d->dtype, done = launch_conv3x3_stream<H>(d->N, d->IH, d->IW, d->Cout, d->Cin, 1, dy, w_ihwo, nullptr, 0, dx, s));
+        if (done) { EVE_CHECK_LAUNCH(); return 0; }
+    }
     // stride-2 3x3 layers: two eight-wave launches over the dy halo tile instead of four per-tap parity-class launches
     if (d->dtype == EVE_DT_BF16 && launch_s2_dgrad_wg8<bf16_t>(d, dy, w_ihwo, dx, workspace, workspace_bytes, s)) { EVE_CHECK_LAUNCH(); return 0; }
     if (d->dtype == EVE_DT_F16 && launch_s2_dgrad_wg8<f16_t>(d, dy, w_ihwo, dx, workspace, workspace_bytes, s)) { EVE_CHECK_LAUNCH(); return 0; }
@@ -1142,6 +1153,11 @@ extern "C" int eve_conv2d_dgrad_acc(const eve_conv_desc* d, const void* dy, cons
         const long long M = (long long)d->N * d->OH * d->OW;
         bool done = false;
         EVE_DISPATCH_H16(d->dtype, done = launch_conv1x1_stream<H>(M, d->Cout, d->Cin, dy, w_ihwo, nullptr, EVE_EPI_ACC, dx, s));
+        if (done) { EVE_CHECK_LAUNCH(); return 0; }
+    }
+    if (d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == 1 && d->dtype != EVE_DT_F32) {
+        bool done = false;
+        EVE_DISPATCH_H16(d->dtype, done = launch_conv3x3_stream<H>(d->N, d->IH, d->IW, d->Cout, d->Cin, 1, dy, w_ihwo, nullptr, EVE_EPI_ACC, dx, s));
         if (done) { EVE_CHECK_LAUNCH(); return 0; }
     }
     if (d->dtype == EVE_DT_BF16) launch_igemm<bf16_t>(p, dy, w_ihwo, nullptr, nullptr, 0, EVE_EPI_ACC, dx, s);

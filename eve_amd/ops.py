@@ -128,10 +128,24 @@ def _stream_1x1(x, c_out):
             hasattr(k, 'dispatch_config') and bool(k.dispatch_config().conv1x1_stream))
 
 
+# ... and the 3x3 layers the row-streaming kernel serves (csrc/conv_3x3s.h launch_conv3x3_stream: 64 / 128-wide images)
+STREAM_3X3 = {(16, 16), (16, 32), (32, 16), (32, 32), (16, 64), (64, 16), (32, 64), (32, 128)}
+
+
+def _stream_3x3(x, c_out):
+    k = default_kernels()
+    return (x.dtype in HALF_DTYPES and x.dim() == 4 and (x.shape[3], c_out) in STREAM_3X3 and x.shape[2] in (64, 128) and
+            x.shape[1] >= 2 and x.shape[0] * x.shape[1] * x.shape[2] >= 65536 and
+            x.shape[1] * x.shape[2] * max(x.shape[3], c_out) * 2 < (1 << 31) and
+            hasattr(k, 'dispatch_config') and bool(getattr(k.dispatch_config(), 'conv3x3_stream', 0)))
+
+
 def _group_ok(pair, x, ks, stride, pad, c_out=None):
     if pair is None or stride != 1 or pad != (ks - 1) // 2 or x.dtype not in HALF_DTYPES:
         return False
     if ks == 1 and c_out is not None and _stream_1x1(x, c_out):
+        return False
+    if ks == 3 and c_out is not None and _stream_3x3(x, c_out):
         return False
     wg = x.shape[2] // pair[0]
     if x.shape[2] % pair[0]:

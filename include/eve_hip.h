@@ -78,6 +78,7 @@ typedef struct eve_dispatch_config {
     int stem_fused_wgrad;          /* EVE_STEM_FUSED_WGRAD  1   stem backward + weight gradient in one launch (eve_stem_bwd_wgrad) */
     int stem_fwd_pairs;            /* EVE_STEM_FWD_PAIRS    1   fused stem forward with two waves per image (32 channels each)       */
     int conv1x1_stream;            /* EVE_CONV1X1_STREAM    1   1x1 convolutions between 16..128 channels on the streaming kernel (no LDS)    */
+    int conv3x3_stream;            /* EVE_CONV3X3_STREAM    1   3x3 / stride 1 between 16..64 channels on 64 / 128-wide images: row-streaming kernel */
     int in_big_planes;             /* EVE_IN_BIG_PLANES     1   register-resident InstanceNorm (no affine) for planes beyond 8 192 vectors, dealt by channels */
     long long wgrad_halo_min_m;    /* EVE_WGRAD_HALO_MIN_M  1<<20 pixels from which the band-resident weight gradient runs */
 } eve_dispatch_config;

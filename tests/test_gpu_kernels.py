@@ -390,6 +390,51 @@ def test_streaming_1x1_convolution(hip, ref, hdt, cin, cout):
     assert torch.equal(view, got['fwd_acc'])
 
 
+@pytest.mark.parametrize('hdt', [torch.bfloat16, torch.float16], ids=['bf16', 'f16'])
+@pytest.mark.parametrize('geom', [(8, 72, 128), (29, 37, 64)], ids=['72x128', '37x64'])
+@pytest.mark.parametrize('cin,cout', [(16, 16), (16, 32), (32, 16), (32, 32), (16, 64), (64, 16), (32, 64), (32, 128)],
+                         ids=lambda v: str(v))
+def test_row_streaming_3x3_convolution(hip, ref, hdt, geom, cin, cout):
+    """Round 4: 3x3 / stride 1 / pad 1 between 16..64 channels on 64 / 128-wide images on conv3x3_stream_kernel (csrc/conv_3x3s.h:
+    one workgroup walks an image with a four-row LDS ring, exact channel counts instead of pixel groups, filter in MFMA A
+    registers): forward with bias (+ ReLU), accumulating forward, data gradient (mirrored taps on the transposed filter) and
+    accumulating data gradient -- against the float reference and against the kernels it replaces on the same inputs
+    (conv3x3_stream = 0); an odd image height, borders included."""
+    N, H, W = geom
+    x = rnd((N, H, W, cin), hdt, 81)
+    w = rnd((cout, 3, 3, cin), hdt, 82, scale=(2.0 / (9 * cin)) ** 0.5)
+    b = rnd((cout,), torch.float32, 83, scale=0.2)
+    base = rnd((N, H, W, cout), hdt, 84)
+    dy = rnd((N, H, W, cout), hdt, 85)
+    base_dx = rnd((N, H, W, cin), hdt, 86)
+    w_ihwo = w.permute(3, 1, 2, 0).contiguous()
+
+    def run():
+        out = {}
+        out['fwd'] = hip.conv2d_fwd(dev(x), dev(w), dev(b), 1, 1)
+        used = hip.lib.eve_last_kernel().decode()
+        out['fwd_relu'] = hip.conv2d_fwd(dev(x), dev(w), dev(b), 1, 1, 1)
+        out['fwd_acc'] = hip.conv2d_fwd(dev(x), dev(w), dev(b), 1, 1, accumulate_into=dev(base).clone())
+        out['dgrad'] = hip.conv2d_dgrad(dev(dy), dev(w_ihwo), (H, W), 1, 1)
+        used_d = hip.lib.eve_last_kernel().decode()
+        out['dgrad_acc'] = hip.conv2d_dgrad(dev(dy), dev(w_ihwo), (H, W), 1, 1, accumulate_into=dev(base_dx).clone())
+        return out, used, used_d
+    got, used, used_d = run()
+    assert used.startswith('conv3x3_stream_kernel<') and (', %d, %d, false>' % (cin, cout)) in used, used
+    from eve_amd.ops import STREAM_3X3
+    if (cout, cin) in STREAM_3X3:          # (the data gradient of 32 -> 64 / 128 is a 64 / 128 -> 32 layer: not on this kernel)
+        assert used_d.startswith('conv3x3_stream_kernel<') and (', %d, %d, false>' % (cout, cin)) in used_d, used_d
+    with hip.dispatch_override(conv3x3_stream=0):
+        old, used_old, _ = run()
+    assert 'conv3x3_stream' not in used_old
+    want = ref.conv2d_fwd(x.float(), w.float(), b, 1, 1).float()
+    wdx = ref.conv2d_dgrad(dy.float(), w_ihwo.float(), (H, W), 1, 1).float()
+    wants = {'fwd': want, 'fwd_relu': want.clamp(min=0), 'fwd_acc': want + base.float(), 'dgrad': wdx, 'dgrad_acc': wdx + base_dx.float()}
+    for name in wants:
+        close(got[name], wants[name].to(hdt), hdt, 'row-streaming 3x3 ' + name, scale=float(wants[name].abs().max()))
+        close(got[name], old[name], hdt, 'row-streaming 3x3 vs the kernel it replaces: ' + name, scale=float(wants[name].abs().max()))
+
+
 def test_narrow_output_3x3_runs_pixel_paired(hip, ref):
     """The outermost decoder's first 3x3 (64 -> 16 channels at 72x128): ops.PackedWeight pairs pixels (128 -> 32 over a 64-wide row,
     ops.PAIR_NARROW_OUT) so that the halo kernel takes it instead of the first-generation gather kernel; through ops.conv2d
