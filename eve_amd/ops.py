@@ -281,7 +281,8 @@ class Conv2dFn(torch.autograd.Function):
                 _notify_grad_ready(wp)
             else:
                 dwp = torch.zeros((cout_p, KH, KW, cin_p), dtype=torch.float32, device=x.device)
-                k.conv2d_wgrad(x, dy, KH, KW, ctx.stride, ctx.pad, dwp, algo=pack.algo, db=db_pending)
+                if not _wgrad_pixel_pairs(k, x, dy, KH, ctx.stride, ctx.pad, dwp, db_pending):
+                    k.conv2d_wgrad(x, dy, KH, KW, ctx.stride, ctx.pad, dwp, algo=pack.algo, db=db_pending)
                 dw = dwp[:O, :, :, :I].permute(0, 3, 1, 2)          # OIHW-shaped view of OHWI memory
                 if len(ctx.wshape) == 2:
                     dw = dw.reshape(ctx.wshape)
@@ -696,6 +697,32 @@ def linear(x2d, weight, bias, pack, act=ACT_NONE):
         return LinearFn.apply(x2d, weight, bias, pack, act)
     y = Conv2dFn.apply(x2d.view(M, 1, 1, C), weight, bias, pack, 1, 0, act)
     return y.view(M, y.shape[-1])
+
+
+def _wgrad_pixel_pairs(k, x, dy, ks, stride, pad, dwp, db):
+    """Weight gradient of a layer with an 8-channel side on a >= 2 M-pixel tensor (RefineNet's first and last convolution:
+    `initial.0`, 4 -> 16 padded to 8, and `final.2`, 16 -> 1 padded to 8; refine_net.py:96-131) over PIXEL PAIRS: [W][8] is byte
+    for byte [W / 2][16], the grouped layer's filter gradient is a shape the band-resident kernel serves (it wants multiples of
+    16 channels; the 8-channel layers fell to the gather kernel at 1.3 TB/s), and the true gradient is the scatter-sum of the
+    grouped one through the same index map that builds grouped filters (adjoint of pixel_group_weights).  Accumulates into dwp
+    [Cout][ks][ks][Cin] (and db); False when it does not apply."""
+    N, H, W, ci = x.shape
+    co = dy.shape[3]
+    wg = W // 2
+    if (x.dtype not in HALF_DTYPES or stride != 1 or pad != (ks - 1) // 2 or ks not in (1, 3) or min(ci, co) != 8 or max(ci, co) > 32 or
+            W % 2 or wg < 32 or wg > 128 or (wg & (wg - 1)) or N * H * wg < (1 << 20) or tuple(dy.shape[:3]) != (N, H, W) or
+            not hasattr(k, 'dispatch_config')):
+        return False
+    dwg = torch.zeros((2 * co, ks, ks, 2 * ci), dtype=torch.float32, device=x.device)
+    dbg = torch.zeros((2 * co,), dtype=torch.float32, device=x.device) if db is not None else None
+    k.conv2d_wgrad(x.view(N, H, wg, 2 * ci), dy.view(N, H, wg, 2 * co), ks, ks, 1, pad, dwg, db=dbg)
+    idx = _pixel_group_index(co, ci, ks, 2, False, x.device)
+    flat = torch.zeros((co * ks * ks * ci + 1,), dtype=torch.float32, device=x.device)
+    flat.index_add_(0, idx.reshape(-1), dwg.reshape(-1))
+    dwp += flat[:-1].view(co, ks, ks, ci)
+    if db is not None:
+        db += dbg.view(2, co).sum(0)
+    return True
 
 
 def _wgrad_into(k, x, dy, weight, pack, stride, pad, db=None):

@@ -435,6 +435,34 @@ def test_row_streaming_3x3_convolution(hip, ref, hdt, geom, cin, cout):
         close(got[name], old[name], hdt, 'row-streaming 3x3 vs the kernel it replaces: ' + name, scale=float(wants[name].abs().max()))
 
 
+@pytest.mark.parametrize('ks,cin,cout', [(3, 8, 16), (1, 16, 8)], ids=['initial.0', 'final.2'])
+def test_eight_channel_weight_gradient_over_pixel_pairs(hip, ref, ks, cin, cout):
+    """RefineNet's first / last convolution (4 -> 16 and 16 -> 1, channels padded to 8) at 72 x 128: ops._wgrad_pixel_pairs forms
+    the weight (+ bias) gradient of the pixel-paired layer on the band-resident kernel and scatter-sums it back -- against the
+    gather kernel on the unpaired tensors and the float reference."""
+    from eve_amd import ops
+    dt = torch.bfloat16
+    N, H, W = 232, 72, 128                      # 2.1 M pixels: above the band-resident kernel's floor after pairing
+    g = torch.Generator(device='cuda').manual_seed(9)
+    x = torch.randn((N, H, W, cin), generator=g, device='cuda').to(dt)
+    dy = (0.1 * torch.randn((N, H, W, cout), generator=g, device='cuda')).to(dt)
+    dwp = torch.zeros((cout, ks, ks, cin), device='cuda')
+    db = torch.zeros((cout,), device='cuda')
+    assert ops._wgrad_pixel_pairs(hip, x, dy, ks, 1, ks // 2, dwp, db)
+    assert 'wgrad_halo_kernel' in hip.lib.eve_last_kernel().decode() or 'index' in hip.lib.eve_last_kernel().decode()
+    old_dw = torch.zeros_like(dwp)
+    old_db = torch.zeros_like(db)
+    hip.conv2d_wgrad(x, dy, ks, ks, 1, ks // 2, old_dw, db=old_db)
+    assert float((dwp - old_dw).norm() / old_dw.norm()) < 2e-4
+    assert float((db - old_db).norm() / old_db.norm()) < 2e-4
+    sub = slice(0, 3)
+    want = torch.nn.grad.conv2d_weight(x[sub].float().permute(0, 3, 1, 2), (cout, cin, ks, ks), dy[sub].float().permute(0, 3, 1, 2),
+                                       stride=1, padding=ks // 2).permute(0, 2, 3, 1)
+    got = torch.zeros((cout, ks, ks, cin), device='cuda')
+    hip.conv2d_wgrad(x[sub].contiguous(), dy[sub].contiguous(), ks, ks, 1, ks // 2, got)
+    assert float((got - want).norm() / want.norm()) < 3e-3
+
+
 def test_narrow_output_3x3_runs_pixel_paired(hip, ref):
     """The outermost decoder's first 3x3 (64 -> 16 channels at 72x128): ops.PackedWeight pairs pixels (128 -> 32 over a 64-wide row,
     ops.PAIR_NARROW_OUT) so that the halo kernel takes it instead of the first-generation gather kernel; through ops.conv2d
