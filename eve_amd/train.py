@@ -213,7 +213,12 @@ class Trainer(object):
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self._graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self._graph):
+        # with a process group alive, its watchdog THREAD polls the events of the warm-up collectives (hipEventQuery): under the
+        # default 'global' capture mode any such call from another thread while this one captures is an error that takes the
+        # process down -- seen as a rare crash of the one-rank RCCL tests (c10d::ProcessGroupNCCL::Watchdog, HIPEvent query).
+        # 'thread_local' confines the capture rules to the capturing thread.
+        mode = 'thread_local' if self.sync is not None else 'global'
+        with torch.cuda.graph(self._graph, capture_error_mode=mode):
             if self.sync is not None and self.graph_collectives:
                 # the whole distributed step in the graph: every bucket's all-reduce is captured where its gradient
                 # notification fires (RCCL work on its own stream, joined back before the clip), then clip + Adam

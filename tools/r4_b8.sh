@@ -1,5 +1,7 @@
 #!/bin/bash
-for mt in 224 120 60; do
-echo "min_tiles=$mt $(EVE_CONV_WG8_MIN_TILES=$mt python bench.py --batch 8 --steps 40 --warmup 10 --no-cpu-baseline --no-c3 --no-c5 --no-points --no-roofline 2>/dev/null | grep '^{' | python -c "import sys,json; d=json.loads(sys.stdin.readline()); print(round(d['value']), round(d['ms_per_step'],3))")"
+for mm in 1048576 400000 200000; do
+echo "wgrad_halo_min_m=$mm $(EVE_WGRAD_HALO_MIN_M=$mm python bench.py --batch 8 --steps 40 --warmup 10 --no-cpu-baseline --no-c3 --no-c5 --no-points --no-roofline 2>/dev/null | grep '^{' | python -c "import sys,json; d=json.loads(sys.stdin.readline()); print(round(d['value']), round(d['ms_per_step'],3))")"
 done
-python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1
+for mm in 1048576 400000; do
+echo "B=4 wgrad_halo_min_m=$mm $(EVE_WGRAD_HALO_MIN_M=$mm python bench.py --batch 4 --steps 40 --warmup 10 --no-cpu-baseline --no-c3 --no-c5 --no-points --no-roofline 2>/dev/null | grep '^{' | python -c "import sys,json; d=json.loads(sys.stdin.readline()); print(round(d['value']), round(d['ms_per_step'],3))")"
+done
