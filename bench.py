@@ -138,7 +138,7 @@ def pmc_traffic(symbol, suffix='_pmc_hbm_per_kernel.json'):
     return None, None
 
 
-def kernel_roofline(sym, d, mfma_peak, profile_steps, overhead):
+def kernel_roofline(sym, d, mfma_peak, profile_steps, overhead, pmc_suffix=None):
     """Roofline of one kernel symbol from its HIP-event launch durations.  The bound is the roof the kernel's ALGORITHMIC
     intensity puts it under: FLOP per byte (operands read once, result written once) against the ridge mfma_peak / 8 TB/s
     (312 FLOP/B in bf16: ResNet layer 1's 3x3 convolutions sit at 288, layers 2-4 at 575 .. 2 300) -- SURVEY.md 8(d)."""
@@ -147,7 +147,7 @@ def kernel_roofline(sym, d, mfma_peak, profile_steps, overhead):
     gbs = d['bytes'] / ms / 1e9
     ai = d['flops'] / d['bytes'] if d['bytes'] else float('inf')
     hbm = d['flops'] == 0 or ai < mfma_peak * 1e12 / (HBM_PEAK_GBS * 1e9)
-    traffic, traffic_src = pmc_traffic(sym)
+    traffic, traffic_src = pmc_traffic(sym, suffix=pmc_suffix) if pmc_suffix else pmc_traffic(sym)
     r = {'bound': 'hbm' if hbm else 'mfma', 'kernel': 'eve::' + sym,
          'achieved': gbs if hbm else tf, 'peak': HBM_PEAK_GBS if hbm else mfma_peak, 'unit': 'GB/s' if hbm else 'TFLOP/s',
          'frac': (gbs / HBM_PEAK_GBS) if hbm else (tf / mfma_peak), 'traffic': traffic,
@@ -232,18 +232,16 @@ def bench_pipeline(args, device, k, which, batch_clips, seq, size, dtype_name, s
         prof = k.stop_profile()
         by_kernel = prof.pop('_by_kernel', {})
         overhead = prof.pop('_event_overhead_ms', None)
-        hbm = {s_: d for s_, d in by_kernel.items() if d['bytes'] > 0 and s_}
-        if hbm:
-            dom = max(hbm, key=lambda s_: hbm[s_]['ms'])
-            d = hbm[dom]
-            achieved = d['bytes'] / (d['ms'] * 1e-3) / 1e9
-            traffic, src = pmc_traffic(dom, suffix='_%s_pmc_hbm_per_kernel.json' % which)
-            out['roofline'] = {'bound': 'hbm', 'kernel': 'eve::' + dom, 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                               'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
-                               'traffic_unit': 'bytes per launch (FETCH_SIZE x2 + WRITE_SIZE)', 'traffic_source': src,
-                               'launches_per_step': d['launches'] / args.profile_steps, 'avg_launch_ms': d['ms'] / d['launches'],
-                               'algorithmic_mb_per_launch': d['bytes'] / d['launches'] / 1e6,
-                               'event_pair_overhead_ms_subtracted': overhead}
+        # the heaviest kernel symbol that sits UNDER the HBM roof by its algorithmic intensity (RefineNet's outer levels, the
+        # InstanceNorm family: SURVEY 8(d)), and the heaviest one on the MFMA side (the 128-512-channel levels) next to it
+        peak = MFMA_PEAK_TFLOPS[dtype_name]
+        suffix = '_%s_pmc_hbm_per_kernel.json' % which
+        rl = {s_: kernel_roofline(s_, d, peak, args.profile_steps, overhead, pmc_suffix=suffix)
+              for s_, d in by_kernel.items() if s_ and d['bytes'] > 0 and d['ms'] > 0}
+        for bound, key in (('hbm', 'roofline'), ('mfma', 'roofline_other_bound')):
+            cand = [s_ for s_ in rl if rl[s_]['bound'] == bound]
+            if cand:
+                out[key] = rl[max(cand, key=lambda s_: by_kernel[s_]['ms'])]
         out['kernels_ms_per_step'] = {s_: round(by_kernel[s_]['ms'] / args.profile_steps, 4) for s_ in by_kernel if s_}
         out['kernel_groups_ms_per_step'] = {t: round(prof[t]['ms'] / args.profile_steps, 4) for t in prof}
     del tr
