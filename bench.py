@@ -442,10 +442,11 @@ def main():
         if prof:
             # the dominant KERNEL (one symbol = one row of the rocprofv3 kernel summary in profiles/), by total time
             dom = max(by_kernel, key=lambda t: by_kernel[t]['ms'])
-            out['roofline'] = kernel_roofline(dom, by_kernel[dom], peak, args.profile_steps, event_overhead)
+            sfx = None if args.workload == 'c2' else '_%s_pmc_hbm_per_kernel.json' % args.workload
+            out['roofline'] = kernel_roofline(dom, by_kernel[dom], peak, args.profile_steps, event_overhead, pmc_suffix=sfx)
             # ... and the heaviest kernel on the OTHER side of the ridge, so that both roofs are on the line
             for t in sorted(by_kernel, key=lambda t: -by_kernel[t]['ms']):
-                r = kernel_roofline(t, by_kernel[t], peak, args.profile_steps, event_overhead)
+                r = kernel_roofline(t, by_kernel[t], peak, args.profile_steps, event_overhead, pmc_suffix=sfx)
                 if r['bound'] != out['roofline']['bound'] and by_kernel[t]['flops'] > 0:
                     out['roofline_other_bound'] = r
                     break
