@@ -127,7 +127,7 @@ SIGNATURES = {
     'eve_avgpool_fwd': [I, I, I, I, P, P, P],
     'eve_avgpool_bwd': [I, I, I, I, P, P, P],
     'eve_adaptive_maxpool_fwd': [I, I, I, I, I, I, I, P, P, P, P],
-    'eve_adaptive_maxpool_bwd': [I, I, I, I, I, I, I, P, P, P, P],
+    'eve_adaptive_maxpool_bwd': [I, I, I, I, I, I, I, P, P, P, P, P],
     'eve_bilinear_fwd': [I, I, I, I, I, I, I, P, P, P],
     'eve_bilinear_bwd': [I, I, I, I, I, I, I, P, P, P],
     'eve_nchw_to_nhwc': [I, I, I, I, I, I, P, P, P],

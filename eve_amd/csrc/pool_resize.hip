@@ -164,7 +164,7 @@ __global__ __launch_bounds__(256) void adapool_fwd_kernel(const T* __restrict__ 
 
 template <typename T>
 __global__ __launch_bounds__(256) void adapool_bwd_kernel(const T* __restrict__ dy, const int32_t* __restrict__ idx,
-                                                          T* __restrict__ dx, int IH, int IW, int OH, int OW,
+                                                          const T* __restrict__ add, T* __restrict__ dx, int IH, int IW, int OH, int OW,
                                                           int C, long long items) {
     constexpr int VEC = Elem<T>::VEC;
     const int cvecs = C / VEC;
@@ -195,6 +195,13 @@ __global__ __launch_bounds__(256) void adapool_bwd_kernel(const T* __restrict__ 
                 for (int e = 0; e < VEC; ++e)
                     if (ip[e] == me) acc[e] += g[e];
             }
+        }
+        if (add) {              // (the pooled gradient is rounded to the storage format first: what the separate add kernel saw)
+            float r[VEC], o[VEC];
+            Elem<T>::unpack(Elem<T>::pack(acc), r);
+            Elem<T>::unpack(reinterpret_cast<const uint4*>(add)[i], o);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) acc[e] = r[e] + o[e];
         }
         reinterpret_cast<uint4*>(dx)[i] = Elem<T>::pack(acc);
     }
@@ -469,16 +476,16 @@ extern "C" int eve_adaptive_maxpool_fwd(int dtype, int N, int IH, int IW, int OH
     return 0;
 }
 extern "C" int eve_adaptive_maxpool_bwd(int dtype, int N, int IH, int IW, int OH, int OW, int C, const void* dy,
-                                        const int32_t* idx, void* dx, eve_stream_t stream) {
+                                        const int32_t* idx, const void* add, void* dx, eve_stream_t stream) {
     if (int e = chk(dtype, C, "adaptive_maxpool_bwd: bad dtype / C")) return e;
     if (N <= 0 || IH <= 0 || IW <= 0 || OH <= 0 || OW <= 0 || OH > IH || OW > IW || !dy || !dx || !idx)
         return set_error_msg("adaptive_maxpool_bwd: bad arguments");
     const int vec = dtype != EVE_DT_F32 ? 8 : 4;
     const long long items = (long long)N * IH * IW * (C / vec);
     hipStream_t s = (hipStream_t)stream;
-    if (dtype == EVE_DT_BF16) hipLaunchKernelGGL(adapool_bwd_kernel<bf16_t>, dim3(rgrid((long long)N * IH)), dim3(256), 0, s, (const bf16_t*)dy, idx, (bf16_t*)dx, IH, IW, OH, OW, C, items);
-    else if (dtype == EVE_DT_F16) hipLaunchKernelGGL(adapool_bwd_kernel<f16_t>, dim3(rgrid((long long)N * IH)), dim3(256), 0, s, (const f16_t*)dy, idx, (f16_t*)dx, IH, IW, OH, OW, C, items);
-    else                      hipLaunchKernelGGL(adapool_bwd_kernel<float>, dim3(rgrid((long long)N * IH)), dim3(256), 0, s, (const float*)dy, idx, (float*)dx, IH, IW, OH, OW, C, items);
+    if (dtype == EVE_DT_BF16) hipLaunchKernelGGL(adapool_bwd_kernel<bf16_t>, dim3(rgrid((long long)N * IH)), dim3(256), 0, s, (const bf16_t*)dy, idx, (const bf16_t*)add, (bf16_t*)dx, IH, IW, OH, OW, C, items);
+    else if (dtype == EVE_DT_F16) hipLaunchKernelGGL(adapool_bwd_kernel<f16_t>, dim3(rgrid((long long)N * IH)), dim3(256), 0, s, (const f16_t*)dy, idx, (const f16_t*)add, (f16_t*)dx, IH, IW, OH, OW, C, items);
+    else                      hipLaunchKernelGGL(adapool_bwd_kernel<float>, dim3(rgrid((long long)N * IH)), dim3(256), 0, s, (const float*)dy, idx, (const float*)add, (float*)dx, IH, IW, OH, OW, C, items);
     EVE_CHECK_LAUNCH();
     return 0;
 }

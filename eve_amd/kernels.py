@@ -804,12 +804,14 @@ class HipKernels(object):
                                                    self._p(y), self._p(idx), self._stream()))
         return y, idx
 
-    def adaptive_maxpool_bwd(self, dy, idx, in_hw):
+    def adaptive_maxpool_bwd(self, dy, idx, in_hw, add=None):
+        """add: a second gradient of the pool's input ([N, IH, IW, C]), summed in the kernel epilogue."""
         N, OH, OW, C = dy.shape
         IH, IW = in_hw
         dx = torch.empty((N, IH, IW, C), dtype=dy.dtype, device=dy.device)
+        assert add is None or (tuple(add.shape) == (N, IH, IW, C) and add.dtype == dy.dtype)
         self._ck(self.lib.eve_adaptive_maxpool_bwd(dt_code(dy.dtype), N, IH, IW, OH, OW, C, self._p(dy),
-                                                   self._p(idx), self._p(dx), self._stream()))
+                                                   self._p(idx), self._p(add), self._p(dx), self._stream()))
         return dx
 
     def bilinear_fwd(self, x, out_hw):

@@ -1033,6 +1033,28 @@ class AdaptiveMaxPoolFn(torch.autograd.Function):
         return default_kernels().adaptive_maxpool_bwd(dy.contiguous(), idx, ctx.in_hw), None
 
 
+class PoolForkFn(torch.autograd.Function):
+    """(AdaptiveMaxPool2d(x), x): the encoder output of a RefineNet level feeds the pool to the next level AND the decoder's skip
+    connection (refine_net.py:103-126).  As two consumers of one tensor autograd sums their gradients with an add launch (three
+    passes over a 70-566 MB tensor per level); here both arrive in ONE backward and the pool's adjoint adds the skip gradient
+    in its epilogue.  The second output aliases x."""
+
+    @staticmethod
+    def forward(ctx, x, out_hw):
+        y, idx = default_kernels().adaptive_maxpool_fwd(x, out_hw)
+        ctx.in_hw = (x.shape[1], x.shape[2])
+        ctx.save_for_backward(idx)
+        return y, x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, dy, dskip):
+        (idx,) = ctx.saved_tensors
+        k = default_kernels()
+        if dy is None:
+            return dskip, None
+        return k.adaptive_maxpool_bwd(dy.contiguous(), idx, ctx.in_hw, add=dskip.contiguous() if dskip is not None else None), None
+
+
 class BilinearFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, out_hw):

@@ -199,9 +199,15 @@ class RefineNet(nn.Module):
         while isinstance(level, WrapEncoderDecoder):
             for i, blk in enumerate(level.encoder_blocks):
                 x = self._tap('enc%d.%d' % (depth, i), self._block(x, blk, '%s.encoder_blocks.%d' % (prefix, i), P))
-            skips.append(x)
-            if level.downsample is not None:
-                x = self._tap('pool%d' % depth, ops.AdaptiveMaxPoolFn.apply(x, tuple(level.inner_hw)))
+            if level.downsample is not None and level.add_skip_connection and torch.is_grad_enabled() and x.requires_grad:
+                # the level's output goes to the pool and to the decoder's skip: one node, their gradients meet in its backward
+                pooled, x_skip = ops.PoolForkFn.apply(x, tuple(level.inner_hw))
+                skips.append(x_skip)
+                x = self._tap('pool%d' % depth, pooled)
+            else:
+                skips.append(x)
+                if level.downsample is not None:
+                    x = self._tap('pool%d' % depth, ops.AdaptiveMaxPoolFn.apply(x, tuple(level.inner_hw)))
             level, prefix, depth = level.between_module, prefix + '.between_module', depth + 1
         return x, skips, prefix
 

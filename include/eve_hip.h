@@ -328,8 +328,10 @@ int eve_avgpool_bwd(int dtype, int N, int HW, int C, const void* dy, void* dx, e
 /* adaptive max-pool, window i = [floor(i*I/O), ceil((i+1)*I/O)); idx = flat ih*IW+iw (int32)       */
 int eve_adaptive_maxpool_fwd(int dtype, int N, int IH, int IW, int OH, int OW, int C, const void* x,
                              void* y, int32_t* idx, eve_stream_t stream);
+/* add (nullable, [N][IH][IW][C]): a second gradient of the pooled tensor's INPUT, added in the epilogue -- the encoder output
+ * feeds the pool AND the decoder's skip connection (refine_net.py:103-126), autograd's fork add is then not launched.            */
 int eve_adaptive_maxpool_bwd(int dtype, int N, int IH, int IW, int OH, int OW, int C,
-                             const void* dy, const int32_t* idx, void* dx, eve_stream_t stream);
+                             const void* dy, const int32_t* idx, const void* add, void* dx, eve_stream_t stream);
 /* bilinear resize, align_corners=False, and its adjoint                                            */
 int eve_bilinear_fwd(int dtype, int N, int IH, int IW, int OH, int OW, int C, const void* x, void* y,
                      eve_stream_t stream);

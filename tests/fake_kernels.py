@@ -240,8 +240,9 @@ class FakeKernels(object):
         y, idx = F.adaptive_max_pool2d(nchw(x), out_hw, return_indices=True)
         return nhwc(y, x.dtype), nhwc(idx, torch.int64)
 
-    def adaptive_maxpool_bwd(self, dy, idx, in_hw):
-        return self.maxpool3x3s2_bwd(dy, idx, in_hw)
+    def adaptive_maxpool_bwd(self, dy, idx, in_hw, add=None):
+        dx = self.maxpool3x3s2_bwd(dy, idx, in_hw)
+        return dx if add is None else (dx.float() + add.float()).to(dx.dtype)
 
     def bilinear_fwd(self, x, out_hw):
         return nhwc(F.interpolate(nchw(x), size=out_hw, mode='bilinear', align_corners=False), x.dtype)

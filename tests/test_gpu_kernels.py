@@ -729,6 +729,10 @@ def test_pooling_and_resize(hip, ref, dtype):
         dy = rnd(tuple(y_w.shape), dtype, 26)
         close(hip.adaptive_maxpool_bwd(dev(dy), idx_g, (ih, iw)), ref.adaptive_maxpool_bwd(dy, idx_w, (ih, iw)),
               dtype, 'adaptive maxpool bwd')
+        # ... with a second gradient of the pool's input summed in the epilogue (ops.PoolForkFn): exactly the separate add
+        skipg = rnd((2, ih, iw, c), dtype, 30)
+        fused = hip.adaptive_maxpool_bwd(dev(dy), idx_g, (ih, iw), add=dev(skipg))
+        assert torch.equal(fused, hip.add(hip.adaptive_maxpool_bwd(dev(dy), idx_g, (ih, iw)), dev(skipg)))
         xs = rnd((2, oh, ow, c), dtype, 27)
         close(hip.bilinear_fwd(dev(xs), (ih, iw)), ref.bilinear_fwd(xs, (ih, iw)), dtype, 'bilinear fwd')
         dyu = rnd((2, ih, iw, c), dtype, 28)
