@@ -112,11 +112,11 @@ SIGNATURES = {
     'eve_linear_wgrad_batch': [POINTER(WgradProblem), I, P],
     'eve_instnorm_stats': [I, I, I, I, P, F, P, P],
     'eve_instnorm_act_fwd': [I, I, I, I, P, P, P, P, P, I, P, P],
-    'eve_instnorm_act_bwd': [I, I, I, I, P, P, P, P, P, P, I, P, P, P, P],
+    'eve_instnorm_act_bwd': [I, I, I, I, P, P, P, P, P, P, I, P, P, P, P, P],
     'eve_instnorm_act2_fwd': [I, I, I, I, P, P, P, P, P, P, I, P, P, I, I, P, P, P],
     'eve_instnorm_act2_bwd': [I, I, I, I, P, P, I, P, P, P, P, P, P, I, P, P, P, I, P, P, P, P],
     'eve_instnorm_fwd_fused': [I, I, I, I, P, P, P, P, I, F, P, P, P, P],
-    'eve_instnorm_bwd_fused': [I, I, I, I, P, P, P, P, P, P, P, I, P, P, P, P, P],
+    'eve_instnorm_bwd_fused': [I, I, I, I, P, P, P, P, P, P, P, I, P, P, P, P, P, P],
     'eve_sum_rows': [I, I, P, P, P],
     'eve_act_bwd': [I, L, P, P, I, P, P],
     'eve_add': [I, L, P, P, P, P],

@@ -192,7 +192,7 @@ __global__ __launch_bounds__(256) void in_act_bwd_kernel(const T* __restrict__ d
                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
                                                          const int act_rt,
                                                          T* __restrict__ dx, T* __restrict__ dres,
-                                                         float* __restrict__ sums, int HW, int C) {
+                                                         float* __restrict__ sums, const T* __restrict__ dx_add, int HW, int C) {
     constexpr int VEC = Elem<T>::VEC;
     const int act = ACT >= 0 ? ACT : act_rt;          // compile-time activation: no per-element switch
     __shared__ float sh[2 * 256 * VEC];
@@ -298,6 +298,13 @@ __global__ __launch_bounds__(256) void in_act_bwd_kernel(const T* __restrict__ d
 #pragma unroll
             for (int e = 0; e < VEC; ++e)
                 g[e] = k[e] * (g[e] - s1[e] - (xx[e] - mean[e]) * rstd[e] * s2[e]);
+            if (dx_add) {           // the other consumer's gradient of x; dx is rounded to the storage format first, as a separate add saw it
+                float r[VEC], o2[VEC];
+                Elem<T>::unpack(Elem<T>::pack(g), r);
+                Elem<T>::unpack(*reinterpret_cast<const uint4*>(dx_add + o), o2);
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) g[e] = r[e] + o2[e];
+            }
             *reinterpret_cast<uint4*>(dx + o) = Elem<T>::pack(g);
         }
 }
@@ -618,17 +625,17 @@ extern "C" int eve_instnorm_act_fwd(int dtype, int N, int HW, int C, const void*
 
 extern "C" int eve_instnorm_act_bwd(int dtype, int N, int HW, int C, const void* dy, const void* y, const void* x,
                                     const float* mean_rstd, const float* gamma, const float* beta, int act, void* dx, void* dres,
-                                    float* sums, eve_stream_t stream) {
+                                    float* sums, const void* dx_add, eve_stream_t stream) {
     if (int e = check_plane(dtype, N, HW, C, "instnorm_act_bwd: bad shape")) return e;
     if (!dy || !x || !mean_rstd || !dx || (act != EVE_ACT_NONE && !y && gamma && !beta) || (dres && act != EVE_ACT_NONE && !y))
         return set_error_msg("instnorm_act_bwd: null pointer (y is required with a residual, beta with gamma when y is omitted)");
     hipStream_t s = (hipStream_t)stream;
     if (dtype == EVE_DT_BF16)
-        EVE_IN_ACT_DISPATCH(in_act_bwd_kernel, bf16_t, "eve::bf16_t", dim3(N), (const bf16_t*)dy, (const bf16_t*)y, (const bf16_t*)x, mean_rstd, gamma, beta, act, (bf16_t*)dx, (bf16_t*)dres, sums, HW, C);
+        EVE_IN_ACT_DISPATCH(in_act_bwd_kernel, bf16_t, "eve::bf16_t", dim3(N), (const bf16_t*)dy, (const bf16_t*)y, (const bf16_t*)x, mean_rstd, gamma, beta, act, (bf16_t*)dx, (bf16_t*)dres, sums, (const bf16_t*)dx_add, HW, C);
     else if (dtype == EVE_DT_F16)
-        EVE_IN_ACT_DISPATCH(in_act_bwd_kernel, f16_t, "eve::f16_t", dim3(N), (const f16_t*)dy, (const f16_t*)y, (const f16_t*)x, mean_rstd, gamma, beta, act, (f16_t*)dx, (f16_t*)dres, sums, HW, C);
+        EVE_IN_ACT_DISPATCH(in_act_bwd_kernel, f16_t, "eve::f16_t", dim3(N), (const f16_t*)dy, (const f16_t*)y, (const f16_t*)x, mean_rstd, gamma, beta, act, (f16_t*)dx, (f16_t*)dres, sums, (const f16_t*)dx_add, HW, C);
     else
-        EVE_IN_ACT_DISPATCH(in_act_bwd_kernel, float, "float", dim3(N), (const float*)dy, (const float*)y, (const float*)x, mean_rstd, gamma, beta, act, (float*)dx, (float*)dres, sums, HW, C);
+        EVE_IN_ACT_DISPATCH(in_act_bwd_kernel, float, "float", dim3(N), (const float*)dy, (const float*)y, (const float*)x, mean_rstd, gamma, beta, act, (float*)dx, (float*)dres, sums, (const float*)dx_add, HW, C);
     EVE_CHECK_LAUNCH();
     return 0;
 }

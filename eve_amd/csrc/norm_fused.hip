@@ -137,7 +137,7 @@ __global__ __launch_bounds__(1024) void in_bwd_fused_kernel(const T* __restrict_
                                                             const float* __restrict__ gamma, const float* __restrict__ beta, int act_rt,
                                                             T* __restrict__ dx, T* __restrict__ dres,
                                                             float* __restrict__ sums, const unsigned char* __restrict__ mask,
-                                                            int N, int HW, int C, int sl) {
+                                                            const T* __restrict__ dx_add, int N, int HW, int C, int sl) {
     constexpr int VEC = Elem<T>::VEC;
     __shared__ float sh[1024 * VEC];
     const int act = ACT >= 0 ? ACT : act_rt;        // ACT >= 0: activation known at compile time (no per-element switch)
@@ -240,6 +240,13 @@ __global__ __launch_bounds__(1024) void in_bwd_fused_kernel(const T* __restrict_
             Elem<T>::unpack(qx[j], xx);
 #pragma unroll
             for (int e = 0; e < VEC; ++e) g[e] = k[e] * (g[e] - s1[e] - (xx[e] - mean[e]) * rstd[e] * s2[e]);
+            if (dx_add) {           // (eve_instnorm_act_bwd's dx_add: the fork's other gradient, added to the rounded dx)
+                float r[VEC], o2[VEC];
+                Elem<T>::unpack(Elem<T>::pack(g), r);
+                Elem<T>::unpack(reinterpret_cast<const uint4*>(dx_add)[gi(i)], o2);
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) g[e] = r[e] + o2[e];
+            }
             reinterpret_cast<uint4*>(dx)[gi(i)] = Elem<T>::pack(g);
         }
     }
@@ -609,7 +616,7 @@ extern "C" int eve_instnorm_fwd_fused(int dtype, int N, int HW, int C, const voi
 
 extern "C" int eve_instnorm_bwd_fused(int dtype, int N, int HW, int C, const void* dy, const void* dy2, const void* y, const void* x,
                                       const float* mean_rstd, const float* gamma, const float* beta, int act, void* dx, void* dres,
-                                      float* sums, const unsigned char* sign_mask, eve_stream_t stream) {
+                                      float* sums, const unsigned char* sign_mask, const void* dx_add, eve_stream_t stream) {
     const int vec = dtype != EVE_DT_F32 ? 8 : 4;
     if (((unsigned)dtype > (unsigned)EVE_DT_F16) || N <= 0 || HW <= 0 || C <= 0 || C % vec || !dy || !x ||
         !mean_rstd || !dx || (act != EVE_ACT_NONE && !y && gamma && !beta && !(act == EVE_ACT_RELU && sign_mask)))
@@ -618,7 +625,7 @@ extern "C" int eve_instnorm_bwd_fused(int dtype, int N, int HW, int C, const voi
     if (!fused_plan(HW * (C / vec), C / vec, threads, vpt, sl, dtype != EVE_DT_F32, gamma == nullptr)) return -1;
     const unsigned grid = sl ? (unsigned)((N + 7) / 8) * (8u << sl) : (unsigned)N;
     hipStream_t s = (hipStream_t)stream;
-    if (g_cfg.in_trunk_kernels && vpt <= 8 && !gamma && (long long)threads * vpt == ((long long)HW * (C / vec)) >> sl) {
+    if (g_cfg.in_trunk_kernels && vpt <= 8 && !gamma && !dx_add && (long long)threads * vpt == ((long long)HW * (C / vec)) >> sl) {
         // 0: mid-block (ReLU' from x)   1 / 2: block end (mask, dres) without / with a second summand   3: down-sample branch
         const int combo = (act == EVE_ACT_RELU && !y && !sign_mask && !dres && !dy2) ? 0
                         : (act == EVE_ACT_RELU && sign_mask && dres) ? (dy2 ? 2 : 1)
@@ -646,13 +653,13 @@ extern "C" int eve_instnorm_bwd_fused(int dtype, int N, int HW, int C, const voi
     }
     if (dtype == EVE_DT_BF16) {
         LAUNCH_VPT(in_bwd_fused_kernel, bf16_t, "eve::bf16_t", (const bf16_t*)dy, (const bf16_t*)dy2, (const bf16_t*)y, (const bf16_t*)x, mean_rstd, gamma, beta,
-                   act, (bf16_t*)dx, (bf16_t*)dres, sums, sign_mask, N, HW, C, sl)
+                   act, (bf16_t*)dx, (bf16_t*)dres, sums, sign_mask, (const bf16_t*)dx_add, N, HW, C, sl)
     } else if (dtype == EVE_DT_F16) {
         LAUNCH_VPT(in_bwd_fused_kernel, f16_t, "eve::f16_t", (const f16_t*)dy, (const f16_t*)dy2, (const f16_t*)y, (const f16_t*)x, mean_rstd, gamma, beta,
-                   act, (f16_t*)dx, (f16_t*)dres, sums, sign_mask, N, HW, C, sl)
+                   act, (f16_t*)dx, (f16_t*)dres, sums, sign_mask, (const f16_t*)dx_add, N, HW, C, sl)
     } else {
         LAUNCH_VPT(in_bwd_fused_kernel, float, "float", (const float*)dy, (const float*)dy2, (const float*)y, (const float*)x, mean_rstd, gamma, beta,
-                   act, (float*)dx, (float*)dres, sums, sign_mask, N, HW, C, sl)
+                   act, (float*)dx, (float*)dres, sums, sign_mask, (const float*)dx_add, N, HW, C, sl)
     }
     EVE_CHECK_LAUNCH();
     return 0;

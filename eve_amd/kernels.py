@@ -641,7 +641,7 @@ class HipKernels(object):
             self._p(self._f32(beta, 'beta')), self._p(res), act, self._p(y), self._stream())), (x, res, y))
         return y
 
-    def instnorm_act_bwd(self, dy, y, x, mr, gamma, act, want_dres, beta=None):
+    def instnorm_act_bwd(self, dy, y, x, mr, gamma, act, want_dres, beta=None, dx_add=None):
         """y may be None when the forward had no residual (beta is then needed next to gamma)."""
         N, H, W, C = x.shape
         dx = torch.empty_like(x)
@@ -651,7 +651,7 @@ class HipKernels(object):
         self._timed('in_bwd', 0.0, lambda: self._ck(self.lib.eve_instnorm_act_bwd(
             dt_code(x.dtype), N, H * W, C, self._p(dy), self._p(y), self._p(x), self._p(mr),
             self._p(self._f32(gamma, 'gamma')), self._p(self._f32(beta, 'beta')), act, self._p(dx), self._p(dres),
-            self._p(sums), self._stream())), (dy, x, y, dy, x, y, dx, dres))
+            self._p(sums), self._p(dx_add), self._stream())), (dy, x, y, dy, x, y, dx, dres, dx_add))
         return dx, dres, sums
 
     def instnorm_act2_fwd(self, xs, mrs, gamma_a, beta_a, gamma_b, beta_b, act):
@@ -706,7 +706,7 @@ class HipKernels(object):
         self._ck(st)
         return (y, mr, mask) if want_mask else (y, mr)
 
-    def instnorm_bwd_fused(self, dy, y, x, mr, gamma, act, want_dres, dy2=None, mask=None, beta=None):
+    def instnorm_bwd_fused(self, dy, y, x, mr, gamma, act, want_dres, dy2=None, mask=None, beta=None, dx_add=None):
         """Single-launch backward; returns (dx, dres, sums) or None when the plane is too large.
         dy2: optional second summand of the incoming gradient (added on load).
         beta: with gamma and y = None (no residual), act' is recomputed from x with the forward's scale / shift.
@@ -718,7 +718,7 @@ class HipKernels(object):
         st = self._timed('in_bwd', 0.0, lambda: self.lib.eve_instnorm_bwd_fused(
             dt_code(x.dtype), N, H * W, C, self._p(dy), self._p(dy2), self._p(None if mask is not None else y), self._p(x), self._p(mr),
             self._p(self._f32(gamma, 'gamma')), self._p(self._f32(beta, 'beta')), act, self._p(dx), self._p(dres), self._p(sums), self._p(mask),
-            self._stream()), (dy, dy2, y if mask is None else mask, x, dx, dres))
+            self._p(dx_add), self._stream()), (dy, dy2, y if mask is None else mask, x, dx, dres, dx_add))
         if st == -1:
             if self.prof:
                 self.prof.pop()

@@ -923,6 +923,41 @@ def instnorm_act(x, gamma=None, beta=None, res=None, act=ACT_NONE, eps=1e-5):
     return InstNormActFn.apply(x, gamma, beta, res, act, eps)
 
 
+class InstNormActSkipFn(torch.autograd.Function):
+    """(act(gamma * IN(x) + beta), x): the input of an identity-skip BasicBlock (refine_net.py:35-67, ic == oc) feeds `layers` AND the
+    block's final add.  Returned as the second output of this node, the skip's gradient arrives in the same backward as the
+    normalised branch's and the InstanceNorm backward adds it in its epilogue (`dx_add`) -- autograd's gradient-fork add (three
+    passes over the block input) is not launched.  The second output aliases x."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, act, eps):
+        k = default_kernels()
+        g, b = gamma.detach().float().contiguous(), beta.detach().float().contiguous()
+        fused = k.instnorm_fwd_fused(x, g, b, None, act, eps)
+        if fused is not None:
+            y, mr = fused
+        else:
+            mr = k.instnorm_stats(x, eps)
+            y = k.instnorm_act_fwd(x, mr, g, b, None, act)
+        ctx.act = act
+        ctx.save_for_backward(x, mr, g, b)
+        return y, x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, dy, dskip):
+        k = default_kernels()
+        x, mr, g, b = ctx.saved_tensors
+        if dy is None:
+            return dskip, None, None, None, None
+        add = dskip.contiguous() if dskip is not None else None
+        out = k.instnorm_bwd_fused(dy.contiguous(), None, x, mr, g, ctx.act, False, beta=b, dx_add=add)
+        if out is None:
+            out = k.instnorm_act_bwd(dy.contiguous(), None, x, mr, g, ctx.act, False, beta=b, dx_add=add)
+        dx, _, sums = out
+        s = k.sum_rows(sums)
+        return dx, s[:, 1], s[:, 0], None, None
+
+
 class InstNormAct2Fn(torch.autograd.Function):
     """(a, b) = act(gamma_h * IN(cat(xs)) + beta_h) for two affine heads h over the channel-concatenation of 1-2 NHWC sources.
     RefineNet's pre-activation BasicBlock (refine_net.py:46-47,59-60) normalises its input twice -- `layers.0` and

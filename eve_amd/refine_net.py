@@ -179,8 +179,12 @@ class RefineNet(nn.Module):
             a, skip = ops.instnorm_act2(xs, L[0].weight, L[0].bias, S[0].weight, S[0].bias, act=blk.act)
         else:
             x = xs[0] if len(xs) == 1 else torch.cat(xs, dim=-1)
-            a = ops.instnorm_act(x, L[0].weight, L[0].bias, act=blk.act)
-            skip = x if S is None else ops.instnorm_act(x, S[0].weight, S[0].bias, act=blk.act)
+            if S is None and torch.is_grad_enabled() and x.requires_grad and hasattr(ops, 'InstNormActSkipFn'):
+                # identity skip: x feeds `layers` and the final add -- one node, the two gradients meet in its backward
+                a, skip = ops.InstNormActSkipFn.apply(x, L[0].weight, L[0].bias, blk.act, 1e-5)
+            else:
+                a = ops.instnorm_act(x, L[0].weight, L[0].bias, act=blk.act)
+                skip = x if S is None else ops.instnorm_act(x, S[0].weight, S[0].bias, act=blk.act)
         a = self._conv(a, prefix + '.layers.2', L[2], P)
         a = ops.instnorm_act(a, L[3].weight, L[3].bias, act=blk.act)
         a = self._conv(a, prefix + '.layers.5', L[5], P)

@@ -251,7 +251,9 @@ int eve_instnorm_act_fwd(int dtype, int N, int HW, int C, const void* x, const f
  * (beta is needed for that when gamma is given) -- one tensor less to read in both passes.                    */
 int eve_instnorm_act_bwd(int dtype, int N, int HW, int C, const void* dy, const void* y,
                          const void* x, const float* mean_rstd, const float* gamma, const float* beta, int act,
-                         void* dx, void* dres, float* sums, eve_stream_t stream);
+                         void* dx, void* dres, float* sums, const void* dx_add, eve_stream_t stream);
+/* dx_add (nullable, like x): a second gradient of the normalised tensor's INPUT, added to dx in the epilogue -- the identity-skip
+ * blocks of RefineNet (refine_net.py:35-67: x feeds `layers` and the block's final add) then need no gradient-fork add launch. */
 
 /* Two affine + activation heads over ONE normalised input: RefineNet's pre-activation BasicBlock feeds the block input to
  * `layers` (refine_net.py:46-47) and to `skip_layer` (:59-60), each starting with InstanceNorm2d(affine) -> activation.
@@ -290,7 +292,7 @@ int eve_instnorm_fwd_fused(int dtype, int N, int HW, int C, const void* x, const
  * (act(x * rstd*gamma + (beta - mean*rstd*gamma))) -- no residual: one tensor less to read and to keep.       */
 int eve_instnorm_bwd_fused(int dtype, int N, int HW, int C, const void* dy, const void* dy2, const void* y,
                            const void* x, const float* mean_rstd, const float* gamma, const float* beta, int act,
-                           void* dx, void* dres, float* sums, const unsigned char* sign_mask, eve_stream_t stream);
+                           void* dx, void* dres, float* sums, const unsigned char* sign_mask, const void* dx_add, eve_stream_t stream);
 
 /* out[j] = sum_r in[r][j] (float32, fixed summation order): the batch reduction of the per-plane partials `sums` above into
  * d(beta) / d(gamma) of an affine InstanceNorm2d (refine_net.py:46,50,59,215).                                          */

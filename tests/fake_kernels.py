@@ -141,7 +141,7 @@ class FakeKernels(object):
             z = z + res.float()
         return act_fwd(z, act).to(x.dtype)
 
-    def instnorm_act_bwd(self, dy, y, x, mr, gamma, act, want_dres, beta=None):
+    def instnorm_act_bwd(self, dy, y, x, mr, gamma, act, want_dres, beta=None, dx_add=None):
         g = dy.float()
         if act != ACT_NONE:
             if y is None:
@@ -157,7 +157,10 @@ class FakeKernels(object):
         hw = x.shape[1] * x.shape[2]
         k = mr[:, None, None, :, 1] * (gamma if gamma is not None else 1.0)
         dx = k * (g - s1[:, None, None] / hw - xhat * s2[:, None, None] / hw)
-        return dx.to(x.dtype), (g.to(x.dtype) if want_dres else None), torch.stack([s1, s2], dim=-1)
+        dx = dx.to(x.dtype)
+        if dx_add is not None:
+            dx = (dx.float() + dx_add.float()).to(x.dtype)
+        return dx, (g.to(x.dtype) if want_dres else None), torch.stack([s1, s2], dim=-1)
 
     def instnorm_act2_fwd(self, xs, mrs, gamma_a, beta_a, gamma_b, beta_b, act):
         outs_a, outs_b, off = [], [], 0
@@ -194,7 +197,7 @@ class FakeKernels(object):
         bits = (y.reshape(-1, vec) > 0).to(torch.int32) << torch.arange(vec, dtype=torch.int32)
         return y, mr, bits.sum(dim=1).to(torch.uint8)
 
-    def instnorm_bwd_fused(self, dy, y, x, mr, gamma, act, want_dres, dy2=None, mask=None, beta=None):
+    def instnorm_bwd_fused(self, dy, y, x, mr, gamma, act, want_dres, dy2=None, mask=None, beta=None, dx_add=None):
         if x.shape[1] * x.shape[2] * x.shape[3] > 65536:
             return None
         if dy2 is not None:
@@ -203,7 +206,7 @@ class FakeKernels(object):
             assert act == ACT_RELU and y is None
             vec = 16 // x.element_size()
             y = ((mask.to(torch.int32).unsqueeze(1) >> torch.arange(vec, dtype=torch.int32)) & 1).reshape(x.shape).to(x.dtype)
-        return self.instnorm_act_bwd(dy, y, x, mr, gamma, act, want_dres, beta=beta if y is None else None)
+        return self.instnorm_act_bwd(dy, y, x, mr, gamma, act, want_dres, beta=beta if y is None else None, dx_add=dx_add)
 
     def act_bwd(self, dy, y, act):
         return (dy.float() * act_grad_from_out(y.float(), act)).to(dy.dtype)

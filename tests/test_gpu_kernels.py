@@ -526,6 +526,11 @@ def test_instnorm_fwd_bwd(hip, ref, dtype, shape):
         dx_g, dres_g, s_g = hip.instnorm_act_bwd(dev(dy), dev(y_w), dev(x), dev(mr_w), dev(g), act, r is not None)
         close(dx_g, dx_w, dtype, 'instnorm_act bwd dx act=%d' % act, scale=float(dx_w.abs().max()) + 0.05)
         close(s_g, s_w, torch.float32, 'instnorm_act bwd sums', scale=float(s_w.abs().max()) * 4)
+        if r is None:
+            sk2 = dev(rnd(shape, dtype, 19))
+            da, _, sa = hip.instnorm_act_bwd(dev(dy), None if g is not None else dev(y_w), dev(x), dev(mr_w), dev(g), act, False, beta=dev(b), dx_add=sk2)
+            dn, _, sn = hip.instnorm_act_bwd(dev(dy), None if g is not None else dev(y_w), dev(x), dev(mr_w), dev(g), act, False, beta=dev(b))
+            assert torch.equal(da, hip.add(dn, sk2)) and torch.equal(sa, sn)
         if r is not None:
             close(dres_g, dres_w, dtype, 'instnorm_act bwd dres')
         fused = hip.instnorm_fwd_fused(dev(x), dev(g), dev(b), dev(r), act)
@@ -546,6 +551,11 @@ def test_instnorm_fwd_bwd(hip, ref, dtype, shape):
             close(fb[2], s_w, torch.float32, 'fused instnorm bwd sums', scale=float(s_w.abs().max()) * 4)
             if r is not None:
                 close(fb[1], dres_w, dtype, 'fused instnorm bwd dres')
+            if g is not None and r is None:      # the fork's other gradient added in the epilogue (ops.InstNormActSkipFn): == a separate add
+                sk = dev(rnd(shape, dtype, 19))
+                fa = hip.instnorm_bwd_fused(dev(dy), None, dev(x), fused[1], dev(g), act, False, beta=dev(b), dx_add=sk)
+                fn = hip.instnorm_bwd_fused(dev(dy), None, dev(x), fused[1], dev(g), act, False, beta=dev(b))
+                assert torch.equal(fa[0], hip.add(fn[0], sk)) and torch.equal(fa[2], fn[2])
             if g is not None and r is None:      # affine, no residual: act' recomputed from x with the forward's scale / shift (round 4)
                 fr = hip.instnorm_bwd_fused(dev(dy), None, dev(x), fused[1], dev(g), act, False, beta=dev(b))
                 fyy = hip.instnorm_bwd_fused(dev(dy), fused[0], dev(x), fused[1], dev(g), act, False)
