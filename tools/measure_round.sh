@@ -36,8 +36,9 @@ python bench.py --workload c5 --steps 3 --warmup 2 --no-cpu-baseline > $O/bench_
 (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d $O/prof_c5 -o c --output-format csv -- python $R/bench.py --workload c5 --steps 2 --warmup 1 --no-cpu-baseline --no-roofline > $O/c5_profiled.log 2>&1)
 cp $(find $O/prof_c5 -name "*kernel_stats.csv" | head -1) $O/c5_kernel_stats.csv; rm -rf $O/prof_c5
 # one-rank RCCL group: eager launches vs hipGraph replay + eager collectives vs collectives captured, B = 8 and B = 32
+PORT=29517
 for b in 8 32; do for mode in "--no-graph" "" "--graph-collectives"; do
-  echo "B=$b mode=[$mode] $(EVE_AMD_FORCE_DIST=1 RANK=0 LOCAL_RANK=0 WORLD_SIZE=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=29517 python bench.py --batch $b $mode --no-cpu-baseline --no-c3 --no-c5 --no-points --no-roofline 2>/dev/null | python -c "import sys,json; d=json.loads([l for l in sys.stdin if l.startswith('{')][0]); print(round(d['value']), 'frames/s', round(d['ms_per_step'],3), 'ms', 'hip_graph', d['hip_graph'], 'collectives:', d['collectives'])")" >> $O/rccl_one_rank_modes.txt
+  echo "B=$b mode=[$mode] $(EVE_AMD_FORCE_DIST=1 RANK=0 LOCAL_RANK=0 WORLD_SIZE=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=$((PORT=PORT+1)) python bench.py --batch $b $mode --no-cpu-baseline --no-c3 --no-c5 --no-points --no-roofline 2>/dev/null | python -c "import sys,json; d=json.loads([l for l in sys.stdin if l.startswith('{')][0]); print(round(d['value']), 'frames/s', round(d['ms_per_step'],3), 'ms', 'hip_graph', d['hip_graph'], 'collectives:', d['collectives'])")" >> $O/rccl_one_rank_modes.txt
 done; done
 # copies for profiles/ (gpurun_out/ is scratch; the caller commits profiles/ after the call)
 mkdir -p $O/profiles
