@@ -60,9 +60,12 @@ def main():
     wrap(k, 'instnorm_act_bwd', lambda a, kw, o: (sh(a[0]) + (' y' if a[1] is not None else ''), nbytes(a[0], a[1], a[2], o[0], o[1])))
     wrap(k, 'instnorm_fwd_fused', lambda a, kw, o: (sh(a[0]), nbytes(a[0], a[3], o[0])))
     wrap(k, 'instnorm_bwd_fused', lambda a, kw, o: (sh(a[0]) + (' y' if a[1] is not None else ''), nbytes(a[0], a[1], a[2], o[0], o[1])))
-    for n in ('instnorm_act2_fwd', 'instnorm_act2_bwd'):
-        if hasattr(k, n):
-            wrap(k, n, lambda a, kw, o: ('+'.join(sh(t) for t in a[0]), 0.0))
+    if hasattr(k, 'instnorm_act2_fwd'):
+        wrap(k, 'instnorm_act2_fwd', lambda a, kw, o: ('+'.join(sh(t) for t in a[0]), nbytes(*a[0]) + nbytes(*[t for t in o if t is not None])))
+    if hasattr(k, 'instnorm_act2_bwd'):
+        # (dy_a, dy_b, xs, ...): two passes over the gradients and the sources, one write of the sources' gradients
+        wrap(k, 'instnorm_act2_bwd', lambda a, kw, o: ('+'.join(sh(t) for t in a[2]) if isinstance(a[2], (list, tuple)) else sh(a[0]),
+                                                        2 * nbytes(a[0], a[1]) + 3 * (nbytes(*a[2]) if isinstance(a[2], (list, tuple)) else 0.0)))
     tr.step(batch)
     agg = {}
     for name, desc, kern, ms, mb in ROWS:
@@ -72,7 +75,7 @@ def main():
         c[1] += ms
     tot = sum(v[1] for v in agg.values())
     print('total timed ms', tot)
-    for (name, desc, kern), (n, ms, mb) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:70]:
+    for (name, desc, kern), (n, ms, mb) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:90]:
         print('%7.3f ms  x%-2d %6.3f each  %5.2f TB/s  %-18s %-40s %s' % (ms, n, ms / n, mb / (ms / n) / 1e3 if mb else 0.0, name, desc, kern))
 
 
