@@ -28,22 +28,6 @@ class DispatchConfig(Structure):
         return {n: int(getattr(self, n)) for n, _ in self._fields_ if n != 'struct_bytes'}
 
 
-class ChainStage(Structure):
-    """include/eve_hip.h eve_chain_stage"""
-    _fields_ = [('B', c_void_p), ('bias', c_void_p), ('C', c_void_p), ('extra', c_void_p), ('next_mul', c_void_p),
-                ('R', c_int), ('Nc', c_int), ('epi_act', c_int), ('accumulate', c_int), ('from_input', c_int), ('n_extra', c_int),
-                ('next_mul_act', c_int), ('reserved', c_int)]
-
-
-CHAIN_MAX_STAGES = 6
-
-
-class ChainParams(Structure):
-    """include/eve_hip.h eve_chain_params"""
-    _fields_ = [('A0', c_void_p), ('Y0', c_void_p), ('M', c_int), ('R0', c_int), ('Y0_act', c_int), ('nstages', c_int),
-                ('st', ChainStage * CHAIN_MAX_STAGES)]
-
-
 class WgradProblem(Structure):
     """include/eve_hip.h eve_wgrad_problem"""
     _fields_ = [('dY', c_void_p), ('Y', c_void_p), ('X', c_void_p), ('X2', c_void_p), ('dW', c_void_p), ('db', c_void_p),
@@ -103,7 +87,6 @@ SIGNATURES = {
     'eve_linear_fwd': [I, I, I, P, P, P, I, P, P],
     'eve_linear_dgrad': [I, I, I, P, P, I, P, P, P],
     'eve_linear_wgrad': [I, I, I, P, P, I, P, P, P, P],
-    'eve_linear_chain': [POINTER(ChainParams), P],
     'eve_linear_fwd_ex': [I, I, I, P, I, P, P, I, I, P, I, P],
     'eve_linear_dgrad_ex': [I, I, I, P, I, P, I, P, P, I, I, P],
     'eve_tail_head_pose': [I, P, P, P, I, I, P],

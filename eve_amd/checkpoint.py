@@ -112,7 +112,15 @@ def adam_state_dict(trainer, model=None):
     group = {'lr': lr, 'initial_lr': float(cfg.learning_rate), 'betas': (trainer.beta1, trainer.beta2), 'eps': trainer.eps,
              'weight_decay': float(cfg.weight_decay), 'amsgrad': False, 'maximize': False, 'foreach': None,
              'capturable': False, 'differentiable': False, 'fused': None, 'params': list(range(total))}
-    return {'state': state, 'param_groups': [group]}
+    out = {'state': state, 'param_groups': [group]}
+    if hasattr(trainer, 'guard'):
+        # what torch.optim.Adam has no slot for (the reference is float32 and never skips): the loss scale after back-offs,
+        # the skip counters and the number of step() CALLS, which is what drives the LR schedule.  torch's load_state_dict
+        # ignores unknown top-level keys, so the file still loads into the reference's optimiser.
+        st = trainer.optimizer_state()
+        out['eve_amd'] = {'loss_scale': st['loss_scale'], 'steps_skipped': st['steps_skipped'], 'steps_taken': st['steps_taken'],
+                          'step_calls': int(trainer.step_count), 'guard': trainer.guard.detach().cpu().clone()}
+    return out
 
 
 def load_adam_state_dict(trainer, sd, model=None):
@@ -141,3 +149,11 @@ def load_adam_state_dict(trainer, sd, model=None):
         steps = max(steps, int(float(st['step'])))
     trainer.step_count = steps
     trainer.guard[0] = steps
+    extra = sd.get('eve_amd')
+    if extra is not None:
+        # resumed float16 runs keep their backed-off loss scale and skip counters; the LR schedule continues from the number
+        # of step() calls (skipped steps included), Adam's exponent from the steps taken
+        if extra.get('guard') is not None and tuple(extra['guard'].shape) == tuple(trainer.guard.shape):
+            trainer.guard.copy_(extra['guard'].to(trainer.guard.device))
+            trainer.guard[0] = steps
+        trainer.step_count = int(extra.get('step_calls', steps))

@@ -202,119 +202,10 @@ extern "C" int eve_linear_wgrad(int M, int K, int N, const float* dy, const floa
 }
 
 // =====================================================================================================================
-// Round 4: the tail as CHAINS of small linear layers in one launch each.
-// The EyeNet tail (eye_net.py:109-146) is fc -> [cat head pose] -> fc_common.0 (SELU) -> fc_common.2 -> GRU input projection
-// in front of the recurrence and two 2-layer heads behind it; every layer is a 1 920 x 128 x 128-sized problem whose own
-// launch costs ~10-13 us of mostly latency (16 forward / data-gradient launches per step, 0.2 ms at any batch size).  A chain
-// kernel keeps an 8-row tile of the activations in LDS from layer to layer: one workgroup walks all stages for its rows, writes
-// the intermediate results the backward needs (or nothing), and a stage may restart from the chain's input tile (the two heads
-// read the same GRU output) or accumulate onto an earlier stage's output (the sum of the two heads' input gradients).
-// The inner product loop is linear_mm_kernel's (same chunking, same summation order per output element).
+// Round 4: the tail's weight / bias gradients batched into one launch (the chained forward / data-gradient kernel that
+// came with it was measured slower than the per-layer launches -- profiles/r04_notes.md 3 -- and was removed in round 5).
 // =====================================================================================================================
 namespace eve {
-
-constexpr int LC_MAXW = 516;                                   // widest row tile: 512 + the 4-float pad
-
-struct ChainTile { float v[LS_TM][LC_MAXW]; };
-
-// one stage over the workgroup's 8 rows: OUT = epi( IN[8][R] . B[R][Nc] + bias ), IN from an LDS tile
-__device__ __forceinline__ void chain_stage(const eve_chain_stage& st, const float (*in)[LC_MAXW], float (*out)[LC_MAXW],
-                                            float (*sB)[LS_TN], const int m0, const int M, const int tid) {
-    const int rg = tid >> 7, bc = tid & 127, bk = tid >> 7;
-    constexpr int NB = LS_KC / 2;
-    for (int c0 = 0; c0 < st.Nc; c0 += LS_TN) {
-        float pb[NB], acc[4];
-        auto fetch = [&](int k0) {
-#pragma unroll
-            for (int i = 0; i < NB; ++i) {
-                const int k = k0 + bk + 2 * i;
-                pb[i] = (k < st.R && c0 + bc < st.Nc) ? st.B[(size_t)k * st.Nc + c0 + bc] : 0.f;
-            }
-        };
-#pragma unroll
-        for (int i = 0; i < 4; ++i) acc[i] = 0.f;
-        fetch(0);
-        for (int k0 = 0; k0 < st.R; k0 += LS_KC) {
-            __syncthreads();                               // previous chunk consumed (and the input tile complete)
-#pragma unroll
-            for (int i = 0; i < NB; ++i) sB[bk + 2 * i][bc] = pb[i];
-            __syncthreads();
-            if (k0 + LS_KC < st.R) fetch(k0 + LS_KC);
-#pragma unroll
-            for (int kk = 0; kk < LS_KC; kk += 4) {
-                const float b0 = sB[kk][bc], b1 = sB[kk + 1][bc], b2 = sB[kk + 2][bc], b3 = sB[kk + 3][bc];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    // (rows beyond R inside the last chunk multiply zero weights: the tile is zero-padded to a multiple of 4)
-                    const float4 a = *reinterpret_cast<const float4*>(&in[rg * 4 + i][k0 + kk]);
-                    acc[i] = fmaf(a.x, b0, acc[i]);
-                    acc[i] = fmaf(a.y, b1, acc[i]);
-                    acc[i] = fmaf(a.z, b2, acc[i]);
-                    acc[i] = fmaf(a.w, b3, acc[i]);
-                }
-            }
-        }
-        const int col = c0 + bc;
-        if (col < st.Nc) {
-            const float bv = st.bias ? st.bias[col] : 0.f;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int m = m0 + rg * 4 + i;
-                float v = act_fwd(acc[i] + bv, st.epi_act);
-                if (m < M) {
-                    if (st.C) {
-                        float* c = st.C + (size_t)m * st.Nc + col;
-                        if (st.accumulate) v += *c;
-                        *c = v;
-                    }
-                }
-                // the next stage's input: this value, times act'(its own layer's saved output) for a data-gradient chain
-                if (out && col < LC_MAXW) {
-                    float t = v;
-                    if (st.next_mul && m < M) t *= act_grad_from_out(st.next_mul[(size_t)m * st.Nc + col], st.next_mul_act);
-                    out[rg * 4 + i][col] = m < M ? t : 0.f;
-                }
-            }
-        }
-    }
-}
-
-__global__ __launch_bounds__(256) void linear_chain_kernel(const eve_chain_params p) {
-    __shared__ ChainTile tiles[3];                         // [0] the chain's input, [1] / [2] ping-pong between stages
-    __shared__ float sB[LS_KC][LS_TN];
-    const int tid = threadIdx.x, m0 = blockIdx.x * LS_TM;
-    // ---- the chain's input rows (optionally times act'(Y0): a data-gradient chain starts from dY * act'(Y)) ----
-    const int R0p = min(LC_MAXW, (p.R0 + LS_KC - 1) / LS_KC * LS_KC);      // (whole K chunks: see the pad fill below)
-    for (int e = tid; e < LS_TM * R0p; e += 256) {
-        const int r = e / R0p, k = e - r * R0p, m = m0 + r;
-        float v = 0.f;
-        if (m < p.M && k < p.R0) {
-            v = p.A0[(size_t)m * p.R0 + k];
-            if (p.Y0) v *= act_grad_from_out(p.Y0[(size_t)m * p.R0 + k], p.Y0_act);
-        }
-        tiles[0].v[r][k] = v;
-    }
-    int cur = 0;                                           // tile holding the previous stage's output
-    for (int s = 0; s < p.nstages; ++s) {
-        const eve_chain_stage& st = p.st[s];
-        const int src = st.from_input ? 0 : cur;
-        const bool last = s + 1 == p.nstages || p.st[s + 1].from_input;
-        const int dst = last ? -1 : (src == 1 ? 2 : 1);
-        chain_stage(st, tiles[src].v, dst < 0 ? nullptr : tiles[dst].v, sB, m0, p.M, tid);
-        if (dst >= 0) {
-            // extra input columns of the next stage (the head pose behind fc's 128 outputs) and the zero pad up to a multiple of 4
-            // (... and on to the end of the last K chunk: the product loop reads whole chunks, and 0 x stale LDS may be NaN)
-            const int w = st.Nc, wn = p.st[s + 1].R, wpad = min(LC_MAXW, (wn + LS_KC - 1) / LS_KC * LS_KC);
-            for (int e = tid; e < LS_TM * (wpad - w); e += 256) {
-                const int r = e / (wpad - w), k = w + e % (wpad - w), m = m0 + r;
-                float v = 0.f;
-                if (st.extra && k - w < st.n_extra && m < p.M) v = st.extra[(size_t)m * st.n_extra + (k - w)];
-                tiles[dst].v[r][k] = v;
-            }
-            cur = dst;
-        }
-    }
-}
 
 // several weight / bias gradients in one launch: workgroup -> (problem, tile, row split) through a prefix table
 __global__ __launch_bounds__(256) void linear_wgrad_batch_kernel(const eve_wgrad_batch b) {
@@ -393,23 +284,6 @@ __global__ __launch_bounds__(256) void linear_wgrad_batch_kernel(const eve_wgrad
 }
 
 }  // namespace eve
-
-extern "C" int eve_linear_chain(const eve_chain_params* p, eve_stream_t stream) {
-    if (!p || p->M <= 0 || p->nstages <= 0 || p->nstages > EVE_CHAIN_MAX_STAGES || !p->A0 || p->R0 <= 0 || p->R0 > 512)
-        return set_error_msg("linear_chain: bad arguments");
-    int w = p->R0;
-    for (int s = 0; s < p->nstages; ++s) {
-        const eve_chain_stage& st = p->st[s];
-        const int in_w = st.from_input ? p->R0 : w;
-        if (!st.B || st.R <= 0 || st.Nc <= 0 || st.R > 512 || st.R > in_w + 3 + ((s && !st.from_input) ? p->st[s - 1].n_extra : 0))
-            return set_error_msg("linear_chain: stage width does not follow its input");
-        if (s + 1 < p->nstages && !p->st[s + 1].from_input && st.Nc > 512) return set_error_msg("linear_chain: intermediate wider than 512");
-        w = st.Nc;
-    }
-    EVE_LAUNCH("linear_chain_kernel", linear_chain_kernel, dim3((p->M + LS_TM - 1) / LS_TM), dim3(256), 0, (hipStream_t)stream, *p);
-    EVE_CHECK_LAUNCH();
-    return 0;
-}
 
 extern "C" int eve_linear_wgrad_batch(const eve_wgrad_problem* problems, int n, eve_stream_t stream) {
     if (!problems || n <= 0 || n > EVE_WGRAD_BATCH_MAX) return set_error_msg("linear_wgrad_batch: bad arguments");

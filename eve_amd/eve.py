@@ -61,23 +61,45 @@ class EVE(nn.Module):
     def refresh_static_kappa(self, B, T, device):
         """One host draw per optimiser step into FIXED device buffers (allocated on first use): what lets the whole train
         step be captured into a hipGraph although the reference draws kappa_fake on the host inside forward.  The sequence
-        of draws is the eager path's: one call here per train.Trainer.step()."""
+        of draws is the eager path's: one call here per train.Trainer.step().
+        The host never waits for the GPU under replay, so it may be several steps ahead: the draws go through a RING of
+        pinned staging buffers, each guarded by the event of the copy that last read it -- a slot is rewritten only after
+        its DMA has run (one pinned buffer per side was torn / reused by later draws).  The static buffers are used by
+        calculate_additional_labels only while `_static_kappa_active` is set (Trainer sets it around capture / replay), so
+        an eager step on the same model draws afresh."""
         cfg = self.config
         if not (self.training and cfg.refine_net_do_offset_augmentation):
             return
         std = np.radians(cfg.refine_net_offset_augmentation_sigma)
         static = getattr(self, '_static_kappa', None)
-        if static is None or static['left'].shape[:2] != (B, T) or static['left'].device != device:
-            static = {side: torch.empty((B, T, 2), dtype=torch.float32, device=device) for side in ('left', 'right')}
-            self._static_host = {side: torch.empty((B, T, 2), dtype=torch.float32).pin_memory() if device.type == 'cuda'
-                                 else torch.empty((B, T, 2), dtype=torch.float32) for side in ('left', 'right')}
+        if static is None or static['both'].shape[1:3] != (B, T) or static['both'].device != device:
+            both = torch.empty((2, B, T, 2), dtype=torch.float32, device=device)
+            static = {'both': both, 'left': both[0], 'right': both[1]}
+            cuda = device.type == 'cuda'
+            self._static_ring = [{'host': torch.empty((2, B, T, 2), dtype=torch.float32).pin_memory() if cuda
+                                  else torch.empty((2, B, T, 2), dtype=torch.float32),
+                                  'event': torch.cuda.Event() if cuda else None, 'used': False}
+                                 for _ in range(self.STATIC_KAPPA_RING)]
+            self._static_ring_pos = 0
             self._static_kappa = static
-        for side, kap in self._draw_kappa(B, T, std).items():
-            self._static_host[side].copy_(torch.from_numpy(kap))
-            static[side].copy_(self._static_host[side], non_blocking=True)
+        slot = self._static_ring[self._static_ring_pos]
+        self._static_ring_pos = (self._static_ring_pos + 1) % len(self._static_ring)
+        if slot['used'] and slot['event'] is not None:
+            slot['event'].synchronize()              # the copy that read this slot STATIC_KAPPA_RING steps ago has run
+        kap = self._draw_kappa(B, T, std)
+        slot['host'][0].copy_(torch.from_numpy(kap['left']))
+        slot['host'][1].copy_(torch.from_numpy(kap['right']))
+        static['both'].copy_(slot['host'], non_blocking=True)
+        if slot['event'] is not None:
+            slot['event'].record()
+        slot['used'] = True
+
+    STATIC_KAPPA_RING = 4
+    _static_kappa_active = False
 
     def drop_static_kappa(self):
         self._static_kappa = None
+        self._static_kappa_active = False
 
     # ------------------------------------------------------------------------------------------ labels (eve.py:441-543)
     def calculate_additional_labels(self, d, current_epoch=None):
@@ -93,11 +115,11 @@ class EVE(nn.Module):
         if self.training and cfg.refine_net_do_offset_augmentation:
             assert isinstance(current_epoch, float)
             std = np.radians(cfg.refine_net_offset_augmentation_sigma)
-            static = getattr(self, '_static_kappa', None)
-            if static is not None:
+            static = getattr(self, '_static_kappa', None) if self._static_kappa_active else None
+            if static is not None and tuple(static['left'].shape[:2]) == (B, T):
                 # hipGraph replay (train.eve_trainer(use_graph=True)): the draw happened on the host BEFORE the replay
-                # (refresh_static_kappa) and sits in fixed device buffers the captured kernels read
-                assert static['left'].shape[:2] == (B, T), 'static kappa buffers were made for another batch shape'
+                # (refresh_static_kappa) and sits in fixed device buffers the captured kernels read; any other call (an
+                # eager step on the same model, another batch shape) draws afresh below
                 for side in ('left', 'right'):
                     d[side + '_kappa_fake'] = static[side]
             else:

@@ -195,21 +195,6 @@ class EyeNet(nn.Module):
         cfg = self.config
         cnn = self.cnn_layers
         k = default_kernels()
-        fused = (hasattr(k, 'linear_chain') and feats.is_cuda and feats.dtype == torch.float32 and cfg.eye_net_use_rnn and
-                 len(self.rnn_cells) >= 1 and self.rnn_cells[0].input_size == 128 and 'fc_common.2' in P and
-                 getattr(self, 'fuse_tail', os.environ.get('EVE_AMD_FUSE_TAIL', '0') == '1'))
-        if fused:
-            # round 4 (opt-in, fuse_tail / EVE_AMD_FUSE_TAIL=1): the four linear layers in front of the recurrence in one launch,
-            # the two heads in another (ops.TailPreFn / TailHeadsFn); stacked cells beyond the first keep their own input projection.
-            # Parity-tested, and measured SLOWER than the per-layer launches it replaces: one 8-row workgroup per CU walks its
-            # stages serially, 13 us per stage against 11 us per stand-alone launch (B = 8: 0.267 ms for 5 chain launches vs
-            # 0.180 ms for 16 linear_mm launches; only the batched weight gradient wins, 52 vs 79 us) -- profiles/r04_notes.md
-            cell0 = self.rnn_cells[0]
-            gi0 = ops.TailPreFn.apply(feats, head_pose if cfg.eye_net_use_head_pose_input else None, cnn.fc.weight, cnn.fc.bias,
-                                      self.fc_common[0].weight, self.fc_common[0].bias, self.fc_common[2].weight,
-                                      self.fc_common[2].bias, cell0.weight_ih, cell0.bias_ih,
-                                      (P['fc'], P['fc_common.0'], P['fc_common.2'], P['rnn.0.ih']))
-            return self._tail_from_gi(gi0, S, T, h0, P)
         f = ops.linear(feats, cnn.fc.weight, cnn.fc.bias, P['fc'])
         if cfg.eye_net_use_head_pose_input:
             f = torch.cat([f, head_pose.to(f.dtype)], dim=1)
@@ -250,38 +235,15 @@ class EyeNet(nn.Module):
         p = ops.linear(p, self.fc_to_pupil[2].weight, self.fc_to_pupil[2].bias, P['fc_to_pupil.2'], act=ACT_RELU)
         return gaze, p[:, 0], states
 
-    def _tail_from_gi(self, gi0, S, T, h0, P):
-        """The recurrence (every cell of the stack) and the two heads behind the fused input projection of cell 0."""
-        cfg = self.config
-        states, f = [], None
-        for i, cell in enumerate(self.rnn_cells):
-            init = h0[i] if h0 is not None else None
-            gi = gi0 if i == 0 else ops.linear(f, cell.weight_ih, cell.bias_ih, P['rnn.%d.ih' % i])
-            H = cell.hidden_size
-            kind = cfg.eye_net_rnn_type
-            if kind == 'GRU':
-                st = ops.GRUScanFn.apply(gi.view(S, T, 3 * H), cell.weight_hh, cell.bias_hh, init)
-                hs = st
-            elif kind == 'RNN':
-                st = ops.RNNScanFn.apply(gi.view(S, T, H), cell.weight_hh, cell.bias_hh, init)
-                hs = st
-            else:
-                h_init, c_init = init if init is not None else (None, None)
-                st = ops.LSTMScanFn.apply(gi.view(S, T, 4 * H), cell.weight_hh, cell.bias_hh, h_init, c_init)
-                hs = st[0]
-            states.append(st)
-            f = hs.reshape(S * T, H)
-        g, p = ops.TailHeadsFn.apply(f, self.fc_to_gaze[0].weight, self.fc_to_gaze[0].bias, self.fc_to_gaze[2].weight,
-                                     self.fc_to_pupil[0].weight, self.fc_to_pupil[0].bias, self.fc_to_pupil[2].weight,
-                                     self.fc_to_pupil[2].bias,
-                                     (P['fc_to_gaze.0'], P['fc_to_gaze.2'], P['fc_to_pupil.0'], P['fc_to_pupil.2']))
-        return half_pi * g[:, :2], p[:, 0], states
-
     # ------------------------------------------------------------------ train step: tail + losses as one node
     tail_loss_node = os.environ.get('EVE_AMD_TAIL_LOSS_NODE', '1') != '0'
 
-    def _tail_loss_node_ok(self, batch, T):
+    def _tail_loss_node_ok(self, batch, T, feats=None):
         cfg = self.config
+        if feats is not None and not feats.requires_grad:
+            # (frozen trunk + trainable tail: the node takes the tail parameters through `self`, not as autograd inputs, so
+            # its outputs would carry no graph -- the per-layer path handles that configuration)
+            return False
         k = default_kernels()
         if not (self.tail_loss_node and hasattr(k, 'tail_outputs_fwd') and torch.is_grad_enabled() and cfg.eye_net_use_rnn and
                 cfg.eye_net_rnn_type == 'GRU' and len(self.rnn_cells) == 1 and cfg.eye_net_use_head_pose_input and
@@ -301,7 +263,7 @@ class EyeNet(nn.Module):
         config = config if config is not None else self.config
         P = self._get_packs()
         feats, B, T = self._sequence_features(batch, P)
-        self.last_tail_path = 'node' if self._tail_loss_node_ok(batch, T) else 'layers'
+        self.last_tail_path = 'node' if self._tail_loss_node_ok(batch, T, feats) else 'layers'
         if self.last_tail_path == 'layers':
             out = self._sequence_tail(feats, batch, B, T, None, P)
             terms = losses.eyenet_loss_terms(out, batch, config)

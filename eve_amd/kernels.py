@@ -50,7 +50,7 @@ class HipKernels(object):
     def __init__(self):
         self.lib = _lib.load()
         self.prof = None          # list of (tag, flops, start_event, end_event) while profiling
-        self._workspaces = {}     # device -> uint8 scratch tensor, allocated once per device and never replaced
+        self._workspaces = {}     # (device, stream) -> uint8 scratch tensor, allocated once and never replaced
 
     WORKSPACE_BYTES = int(__import__('os').environ.get('EVE_AMD_WORKSPACE_MB', '128')) << 20
 
@@ -59,10 +59,18 @@ class HipKernels(object):
         split-K partial filters of the weight-gradient kernels -- 7 splits x 512 x 4608 floats = 66 MB for ResNet layer 4 --
         and the re-packed filters of the stride-2 data gradient).  Passed PER CALL; allocated once per device by torch (the
         library never allocates) and kept for the life of the process, so a pointer captured into a hipGraph stays valid.
-        Launches on one stream use it one after the other; a second stream needs its own HipKernels."""
+        Launches on one stream use it one after the other; the scratch is keyed by (device, current stream), so work issued
+        from a second stream (a warm-up side stream, another trainer) gets its own and cannot corrupt split-K partials."""
         if device.type != 'cuda' or self.WORKSPACE_BYTES <= 0:
             return None, 0
-        key = device.index if device.index is not None else torch.cuda.current_device()
+        index = device.index if device.index is not None else torch.cuda.current_device()
+        stream = torch.cuda.current_stream(index)
+        if torch.cuda.is_current_stream_capturing():
+            # a capture stream stands for the stream the graph will replay on; launches of one graph are ordered by the
+            # captured dependencies, so they share one scratch whatever stream object carried the capture
+            key = (index, 'graph')
+        else:
+            key = (index, stream.cuda_stream)
         ws = self._workspaces.get(key)
         if ws is None:
             ws = self._workspaces[key] = torch.empty(self.WORKSPACE_BYTES, dtype=torch.uint8, device=device)
@@ -307,31 +315,6 @@ class HipKernels(object):
             self._p(dy_pool2), self._p(y_pool), self._p(idx), self._p(dw), self._stream())), (x_padded, dy_pool, dy_pool2, y_pool, idx))
 
     # ------------------------------------------------------------------ chains of small float32 linear layers (the tail)
-    def linear_chain(self, a0, stages, y0=None, y0_act=ACT_NONE):
-        """One launch for a chain of small linear layers (include/eve_hip.h eve_linear_chain).  a0 [M, R0] float32; stages: dicts
-        with B [R, Nc] (float32, contiguous) and optional bias, C (output tensor [M, Nc], written), extra [M, n], next_mul
-        ([M, Nc] with next_mul_act), epi_act, accumulate, from_input.  Every tensor is kept referenced until the call returns."""
-        M, R0 = a0.shape
-        p = _lib.ChainParams()
-        p.A0, p.Y0, p.M, p.R0, p.Y0_act, p.nstages = a0.data_ptr(), (y0.data_ptr() if y0 is not None else None), M, R0, y0_act, len(stages)
-        assert len(stages) <= _lib.CHAIN_MAX_STAGES and a0.dtype == torch.float32 and a0.is_contiguous()
-        for i, st in enumerate(stages):
-            B = st['B']
-            assert B.dtype == torch.float32 and B.is_contiguous() and B.dim() == 2
-            q = p.st[i]
-            q.B, q.R, q.Nc = B.data_ptr(), B.shape[0], B.shape[1]
-            for name in ('bias', 'C', 'extra', 'next_mul'):
-                t = st.get(name)
-                if t is not None:
-                    assert t.dtype == torch.float32 and t.is_contiguous() and t.is_cuda
-                setattr(q, name, t.data_ptr() if t is not None else None)
-            if st.get('C') is not None:
-                assert tuple(st['C'].shape) == (M, q.Nc)
-            q.epi_act, q.accumulate, q.from_input = st.get('epi_act', ACT_NONE), int(bool(st.get('accumulate'))), int(bool(st.get('from_input')))
-            q.n_extra = st['extra'].shape[1] if st.get('extra') is not None else 0
-            q.next_mul_act = st.get('next_mul_act', ACT_NONE)
-        self._timed('tail', 0.0, lambda: self._ck(self.lib.eve_linear_chain(ctypes.byref(p), self._stream())))
-
     def linear_wgrad_batch(self, problems):
         """All weight / bias gradients of the tail in one launch.  problems: dicts dY [M,N], Y (or None) + act, X [M,K1], X2 (or
         None), dW [N,K] (accumulated), db [N] or None."""

@@ -564,130 +564,6 @@ class EyeTailLossFn(torch.autograd.Function):
         return (d_feats,) + (None,) * 9
 
 
-class TailPreFn(torch.autograd.Function):
-    """gi = W_ih . fc_common( [fc(feats) | head pose] ) + b_ih -- the four linear layers in front of the recurrence
-    (eye_net.py:109-119, torch.nn.GRUCell's input projection) as ONE launch (kernels.linear_chain); backward: one launch for the
-    chain of data gradients, one for the four weight / bias gradients (kernels.linear_wgrad_batch)."""
-
-    @staticmethod
-    def forward(ctx, feats, head_pose, w_fc, b_fc, w0, b0, w2, b2, w_ih, b_ih, packs):
-        k = default_kernels()
-        p_fc, p0, p2, p_ih = packs
-        M = feats.shape[0]
-        dev = feats.device
-        G = p_ih.ohwi.shape[0]
-        new = lambda n: torch.empty((M, n), dtype=torch.float32, device=dev)
-        a0, a1, a2, gi = new(128), new(128), new(128), new(G)
-        cin0 = p0.ohwi.shape[3]
-        hp = head_pose.detach().float().contiguous() if head_pose is not None else None
-        feats = feats.contiguous()
-        k.linear_chain(feats, [
-            dict(B=p_fc.ihwo.view(p_fc.ohwi.shape[3], 128), bias=_pad_bias(b_fc, 128), C=a0, extra=hp),
-            dict(B=p0.ihwo.view(cin0, 128), bias=_pad_bias(b0, 128), C=a1, epi_act=ACT_SELU),
-            dict(B=p2.ihwo.view(128, 128), bias=_pad_bias(b2, 128), C=a2),
-            dict(B=p_ih.ihwo.view(128, G), bias=_pad_bias(b_ih, G), C=gi)])
-        ctx.packs, ctx.params = packs, (w_fc, b_fc, w0, b0, w2, b2, w_ih, b_ih)
-        for i, w_ in enumerate(ctx.params):
-            if w_ is not None and _direct_grad_ok(w_):
-                _note_use(w_, ctx.needs_input_grad[2 + i])
-        ctx.save_for_backward(feats, hp, a0, a1, a2)
-        return gi
-
-    @staticmethod
-    def backward(ctx, d_gi):
-        k = default_kernels()
-        feats, hp, a0, a1, a2 = ctx.saved_tensors
-        p_fc, p0, p2, p_ih = ctx.packs
-        w_fc, b_fc, w0, b0, w2, b2, w_ih, b_ih = ctx.params
-        M, dev = feats.shape[0], feats.device
-        G, cin0 = p_ih.ohwi.shape[0], p0.ohwi.shape[3]
-        d_gi = d_gi.contiguous()
-        new = lambda n: torch.empty((M, n), dtype=torch.float32, device=dev)
-        d_a2, d_a1, d_cat = new(128), new(128), new(cin0)
-        d_feats = new(feats.shape[1]) if ctx.needs_input_grad[0] else None
-        stages = [dict(B=p_ih.ohwi.view(G, 128), C=d_a2),
-                  dict(B=p2.ohwi.view(128, 128), C=d_a1, next_mul=a1, next_mul_act=ACT_SELU),
-                  dict(B=p0.ohwi.view(128, cin0), C=d_cat)]
-        if d_feats is not None:
-            stages.append(dict(B=p_fc.ohwi.view(128, feats.shape[1]), C=d_feats))      # (uses the leading 128 of d_cat's columns)
-        k.linear_chain(d_gi, stages)
-        need = ctx.needs_input_grad
-        tg = _TailGrads(dev)
-        probs = []
-        for (w_, b_, pk, iw, dY, Y, act, X, X2) in ((w_ih, b_ih, p_ih, 8, d_gi, None, ACT_NONE, a2, None),
-                                                    (w2, b2, p2, 6, d_a2, None, ACT_NONE, a1, None),
-                                                    (w0, b0, p0, 4, d_a1, a1, ACT_SELU, a0, hp),
-                                                    (w_fc, b_fc, p_fc, 2, d_cat, None, ACT_NONE, feats, None)):
-            if need[iw] or need[iw + 1]:
-                dw, db = tg.target(w_, b_, pk, need[iw], need[iw + 1])
-                probs.append(dict(dY=dY, Y=Y, act=act, X=X, X2=X2, dW=dw, db=db))
-            else:
-                tg.items.append((w_, b_, pk, False, False, False, False, None, None))
-        if probs:
-            k.linear_wgrad_batch(probs)
-        (g_ih, gb_ih), (g2, gb2), (g0, gb0), (g_fc, gb_fc) = tg.results()
-        return d_feats, None, g_fc, gb_fc, g0, gb0, g2, gb2, g_ih, gb_ih, None
-
-
-class TailHeadsFn(torch.autograd.Function):
-    """(tanh(W_g2 selu(W_g0 h + b)), relu(W_p2 selu(W_p0 h + b) + b)) -- fc_to_gaze and fc_to_pupil (eye_net.py:137-146) on the
-    recurrent features in ONE launch (the second head restarts from the chain's input); backward: one chain per head (the second
-    accumulates onto the first one's input gradient) and one launch for the four weight gradients."""
-
-    @staticmethod
-    def forward(ctx, hs, wg0, bg0, wg2, wp0, bp0, wp2, bp2, packs):
-        k = default_kernels()
-        pg0, pg2, pp0, pp2 = packs
-        M, dev = hs.shape[0], hs.device
-        hs = hs.contiguous()
-        new = lambda n: torch.empty((M, n), dtype=torch.float32, device=dev)
-        ng, npu = pg2.ohwi.shape[0], pp2.ohwi.shape[0]
-        g1, g2, p1, p2_ = new(128), new(ng), new(128), new(npu)
-        k.linear_chain(hs, [
-            dict(B=pg0.ihwo.view(128, 128), bias=_pad_bias(bg0, 128), C=g1, epi_act=ACT_SELU),
-            dict(B=pg2.ihwo.view(128, ng), C=g2, epi_act=ACT_TANH),
-            dict(B=pp0.ihwo.view(128, 128), bias=_pad_bias(bp0, 128), C=p1, epi_act=ACT_SELU, from_input=True),
-            dict(B=pp2.ihwo.view(128, npu), bias=_pad_bias(bp2, npu), C=p2_, epi_act=ACT_RELU)])
-        ctx.packs, ctx.params = packs, (wg0, bg0, wg2, wp0, bp0, wp2, bp2)
-        for i, w_ in enumerate(ctx.params):
-            if w_ is not None and _direct_grad_ok(w_):
-                _note_use(w_, ctx.needs_input_grad[1 + i])
-        ctx.save_for_backward(hs, g1, g2, p1, p2_)
-        return g2, p2_
-
-    @staticmethod
-    def backward(ctx, dg2, dp2):
-        k = default_kernels()
-        hs, g1, g2, p1, p2_ = ctx.saved_tensors
-        pg0, pg2, pp0, pp2 = ctx.packs
-        wg0, bg0, wg2, wp0, bp0, wp2, bp2 = ctx.params
-        M, dev = hs.shape[0], hs.device
-        ng, npu = pg2.ohwi.shape[0], pp2.ohwi.shape[0]
-        dg2 = (dg2 if dg2 is not None else torch.zeros_like(g2)).contiguous()
-        dp2 = (dp2 if dp2 is not None else torch.zeros_like(p2_)).contiguous()
-        new = lambda n: torch.empty((M, n), dtype=torch.float32, device=dev)
-        d_g1, d_p1, d_hs = new(128), new(128), new(128)
-        k.linear_chain(dg2, [dict(B=pg2.ohwi.view(ng, 128), C=d_g1, next_mul=g1, next_mul_act=ACT_SELU),
-                             dict(B=pg0.ohwi.view(128, 128), C=d_hs)], y0=g2, y0_act=ACT_TANH)
-        k.linear_chain(dp2, [dict(B=pp2.ohwi.view(npu, 128), C=d_p1, next_mul=p1, next_mul_act=ACT_SELU),
-                             dict(B=pp0.ohwi.view(128, 128), C=d_hs, accumulate=True)], y0=p2_, y0_act=ACT_RELU)
-        need = ctx.needs_input_grad
-        tg = _TailGrads(dev)
-        probs = []
-        for (w_, b_, pk, iw, ib, dY, Y, act, X) in ((wg0, bg0, pg0, 1, 2, d_g1, g1, ACT_SELU, hs), (wg2, None, pg2, 3, None, dg2, g2, ACT_TANH, g1),
-                                                    (wp0, bp0, pp0, 4, 5, d_p1, p1, ACT_SELU, hs), (wp2, bp2, pp2, 6, 7, dp2, p2_, ACT_RELU, p1)):
-            want_w, want_b = need[iw], (ib is not None and need[ib])
-            if want_w or want_b:
-                dw, db = tg.target(w_, b_, pk, want_w, want_b)
-                probs.append(dict(dY=dY, Y=Y, act=act, X=X, dW=dw, db=db))
-            else:
-                tg.items.append((w_, b_, pk, False, False, False, False, None, None))
-        if probs:
-            k.linear_wgrad_batch(probs)
-        (gg0, gbg0), (gg2, _), (gp0, gbp0), (gp2, gbp2) = tg.results()
-        return (d_hs if need[0] else None), gg0, gbg0, gg2, gp0, gbp0, gp2, gbp2, None
-
-
 def linear(x2d, weight, bias, pack, act=ACT_NONE):
     """x2d: [M, Cin_padded] -> [M, Cout_padded].  float32 (the EyeNet tail) goes through the small-tile FMA kernels,
     anything else through the implicit-GEMM kernel as a 1x1 conv."""

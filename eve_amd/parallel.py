@@ -66,6 +66,9 @@ class GradSync(object):
         self._handles = []
         self._hooks = []
         self._armed = False
+        self._marking = False        # hipGraph capture: a bucket's "ready" point becomes an event-record node (begin_marks)
+        self._gated = []             # buckets in the order their ready points were captured
+        self._comm = None            # the stream the gated all-reduces are issued from
         self.launch_counts = []
         # a one-rank group has nothing to exchange; EVE_AMD_FORCE_DIST=1 runs the collectives anyway (transport test)
         self.active = self.world > 1 or (dist.is_initialized() and os.environ.get('EVE_AMD_FORCE_DIST', '0') == '1')
@@ -86,8 +89,56 @@ class GradSync(object):
         self._armed = True
         self.launch_counts = [0] * len(self.buckets)     # all-reduces issued per bucket this step (tests assert 1 each)
 
+    # ---- hipGraph replay with the collectives OUTSIDE the graph, still overlapped with backward ----------------------
+    # A captured forward + backward cannot call RCCL eagerly from its gradient notifications (they fire at capture time
+    # only).  Instead every bucket's ready point is captured as an EXTERNAL event-record node (hipEventRecordWithFlags /
+    # hipEventRecordExternal: a node of the graph that records a plain event other streams may wait on).  After each
+    # replay is enqueued, launch_gated() walks the buckets in captured order: the communication stream waits for the
+    # bucket's event of THIS replay, then the all-reduce is issued eagerly -- it starts as soon as the replay passes the
+    # bucket's last gradient, under the rest of the backward, exactly like the eager mode's notifications.
+    def begin_marks(self):
+        self.start_step()
+        self._marking = True
+        self._gated = []
+        if self._comm is None and self.flat_grad.is_cuda:
+            self._comm = torch.cuda.Stream(device=self.flat_grad.device)
+
+    def end_marks(self):
+        self._marking = False
+        self._armed = False
+
+    def launch_gated(self):
+        """Issue this step's all-reduces behind a replay whose ready points were captured by begin_marks(); buckets that
+        never reported (parameters without a gradient) follow the whole replay.  Returns like finish_step()."""
+        self.start_step()
+        self._armed = False
+        if self.active:
+            main = torch.cuda.current_stream()
+            for b in self._gated:
+                with torch.cuda.stream(self._comm):
+                    b['event'].wait()                 # (the communication stream; the collective orders itself behind it)
+                    self._launch(b)
+            rest = [b for b in self.buckets if not b['launched'] and b['hi'] > b['lo']]
+            if rest:
+                self._comm.wait_stream(main)
+                with torch.cuda.stream(self._comm):
+                    for b in rest:
+                        self._launch(b)
+            for h in self._handles:
+                h.wait()
+        self._handles = []
+        return 1.0 / self.world
+
     def _launch(self, b):
         if b['launched'] or b['hi'] <= b['lo']:
+            return
+        if self._marking:
+            # capture: the point itself, not the collective
+            b['launched'] = True
+            if b.get('event') is None:
+                b['event'] = torch.cuda.Event(external=True)
+            b['event'].record()
+            self._gated.append(b)
             return
         b['launched'] = True
         self.launch_counts[self.buckets.index(b)] += 1

@@ -74,8 +74,10 @@ class Trainer(object):
     launched on) after two eager warm-up steps and replays it afterwards: the step is ~600 launches, a third of
     them tiny tail/loss kernels whose host-side enqueue would otherwise leave the GPU idle at the start of every
     backward.  Shapes are static (B, T fixed), so a new batch is copied into the captured input buffers.
-    With data parallelism the graph holds forward+backward only; the gradient all-reduce, clip and Adam run
-    eagerly behind it (collectives are not captured) unless graph_collectives is set (RCCL only)."""
+    With data parallelism the graph holds forward+backward only; every bucket's ready point is captured as an external
+    event-record node and the bucket's all-reduce is issued eagerly on a communication stream that waits for that event
+    of the running replay, so the collectives overlap the rest of the backward (parallel.GradSync.launch_gated); clip and
+    Adam follow.  graph_collectives captures the all-reduces themselves instead (RCCL only)."""
 
     def __init__(self, modules, config, loss_fn, distributed=False, device=None, use_graph=False, lr_schedule=None,
                  loss_scale=None, graph_collectives=None):
@@ -123,6 +125,7 @@ class Trainer(object):
         self._static_batch = None
         self._static_terms = None
         self.pre_step = None          # optional host-side hook run at the top of every step(batch), before capture / replay
+        self.post_step = None         # ... and after the step's work has been enqueued
         self._invalidate()
 
     def _invalidate(self):
@@ -225,14 +228,21 @@ class Trainer(object):
                 self.sync.start_step()
                 self._static_terms = self._forward_backward(self._static_batch)
                 self._update(self.sync.finish_step())
+            elif self.sync is not None:
+                # forward + backward in the graph, every bucket's ready point as an external event-record node
+                self.sync.begin_marks()
+                self._static_terms = self._forward_backward(self._static_batch)
+                self.sync.end_marks()
             else:
                 self._static_terms = self._forward_backward(self._static_batch)
-                if self.sync is None:
-                    self._update(1.0)
+                self._update(1.0)
 
     def _collective_and_update(self):
         self.sync.start_step()
         self._update(self.sync.finish_step())
+
+    def _gated_collective_and_update(self):
+        self._update(self.sync.launch_gated())
 
     def step(self, batch):
         """One optimiser step.  Returns the loss terms; under use_graph these are the graph's static output tensors
@@ -240,20 +250,24 @@ class Trainer(object):
         self._apply_schedule()
         if self.pre_step is not None:
             self.pre_step(batch)
-        if not self.use_graph:
+        try:
+            if not self.use_graph:
+                self.step_count += 1
+                return self._eager_step(batch)
+            if self._graph is None:
+                self._capture(batch)
+            else:
+                for k, v in batch.items():
+                    if isinstance(v, torch.Tensor) and v.data_ptr() != self._static_batch[k].data_ptr():
+                        self._static_batch[k].copy_(v, non_blocking=True)
+            self._graph.replay()
+            if self.sync is not None and not self.graph_collectives:
+                self._gated_collective_and_update()
             self.step_count += 1
-            return self._eager_step(batch)
-        if self._graph is None:
-            self._capture(batch)
-        else:
-            for k, v in batch.items():
-                if isinstance(v, torch.Tensor) and v.data_ptr() != self._static_batch[k].data_ptr():
-                    self._static_batch[k].copy_(v, non_blocking=True)
-        self._graph.replay()
-        if self.sync is not None and not self.graph_collectives:
-            self._collective_and_update()
-        self.step_count += 1
-        return self._static_terms
+            return self._static_terms
+        finally:
+            if self.post_step is not None:
+                self.post_step(batch)
 
 
 def _resolve_schedule(config, lr_schedule, steps_per_epoch):
@@ -302,5 +316,9 @@ def eve_trainer(model, config, distributed=False, current_epoch=0.0, lr_schedule
         def pre_step(batch):
             t = batch['left_eye_patch']
             model.refresh_static_kappa(t.shape[0], t.shape[1], t.device)
-        tr.pre_step = pre_step
+            model._static_kappa_active = True        # (only inside Trainer.step: an eager call on the model draws afresh)
+
+        def post_step(batch):
+            model._static_kappa_active = False
+        tr.pre_step, tr.post_step = pre_step, post_step
     return tr

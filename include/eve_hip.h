@@ -450,32 +450,8 @@ int eve_heatmap_loss_bwd(int kind, int BT, int HW, const float* pred, const floa
                          const float* upstream, float* dpred, eve_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
- * Round 4: the EyeNet tail (src/models/eye_net.py:109-146) as CHAINS of small float32 linear layers, one launch per chain:
- * fc -> [cat head pose] -> fc_common.0 (SELU) -> fc_common.2 -> GRU input projection in front of the recurrence, the two
- * 2-layer heads behind it, and the same chains backwards (data gradients).  A workgroup keeps its 8 rows in LDS from stage
- * to stage.  Stage s computes  OUT = epi_act( IN . B + bias ),  IN = the previous stage's OUT (plus `n_extra` columns from
- * `extra` appended, zero-padded to a multiple of 4 = the row count R of the next stage's B) or, with from_input, the chain's
- * input A0 again (two heads on one input); a stage whose B has FEWER rows than its input has columns uses the leading ones.
- * C != NULL stores OUT ([M][Nc]; accumulate: C += OUT).  next_mul: what the NEXT
- * stage reads is OUT * act'(next_mul) (a data-gradient chain multiplies by the saved forward output's derivative).
- * ------------------------------------------------------------------------------------------------ */
-#define EVE_CHAIN_MAX_STAGES 6
-typedef struct eve_chain_stage {
-    const float* B;          /* [R][Nc]: forward chains pass the [in][out] pack, data-gradient chains the [out][in] one      */
-    const float* bias;       /* [Nc] or NULL                                                                                  */
-    float* C;                /* [M][Nc] or NULL                                                                               */
-    const float* extra;      /* [M][n_extra] columns appended to OUT for the next stage, or NULL                             */
-    const float* next_mul;   /* [M][Nc] or NULL                                                                               */
-    int R, Nc, epi_act, accumulate, from_input, n_extra, next_mul_act, reserved;
-} eve_chain_stage;
-typedef struct eve_chain_params {
-    const float* A0;         /* [M][R0] chain input                                                                           */
-    const float* Y0;         /* NULL, or [M][R0]: the chain starts from A0 * act'(Y0) (Y0_act)                               */
-    int M, R0, Y0_act, nstages;
-    eve_chain_stage st[EVE_CHAIN_MAX_STAGES];
-} eve_chain_params;
-int eve_linear_chain(const eve_chain_params* p, eve_stream_t stream);
-/* ... and all their weight / bias gradients in one launch: dW[N][K] += (dY * act'(Y))^T . [X | X2], db[N] += column sums.      */
+ * Round 4: the EyeNet tail (src/models/eye_net.py:109-146): all its weight / bias gradients in one launch:
+ * dW[N][K] += (dY * act'(Y))^T . [X | X2], db[N] += column sums.                                                      */
 #define EVE_WGRAD_BATCH_MAX 12
 typedef struct eve_wgrad_problem {
     const float* dY;         /* [M][N]                                                                                        */

@@ -86,18 +86,27 @@ def build(case, device, dtype, base_lr=None):
     return cfg, make, detweights.eve_batch(2, 2, seed=13)
 
 
-def worker(rank, world, port, tmp, case, device, dtype, use_graph):
+def worker(rank, world, port, tmp, case, device, dtype, use_graph, backend='gloo'):
     _paths()
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
-                      LOCAL_RANK=str(rank), EVE_AMD_BUCKET_ELEMS='1000000', EVE_AMD_FORCE_DEVICE='0', EVE_AMD_DIST_BACKEND='gloo')
+                      LOCAL_RANK=str(rank), EVE_AMD_BUCKET_ELEMS='1000000', EVE_AMD_DIST_BACKEND=backend)
+    if backend == 'gloo':
+        os.environ['EVE_AMD_FORCE_DEVICE'] = '0'          # every rank on GPU 0; RCCL ('nccl') needs a device per rank
+    else:
+        os.environ.pop('EVE_AMD_FORCE_DEVICE', None)
+        os.environ['HSA_ENABLE_IPC_MODE_LEGACY'] = '0'
+        if use_graph == 'captured':
+            os.environ['EVE_AMD_GRAPH_COLLECTIVES'] = '1'
+        device = 'cuda:%d' % rank
     torch.set_num_threads(2)
     import torch.distributed as dist
     from eve_amd import parallel
-    install_kernels(device)
-    r, _, w = parallel.init_distributed(backend='gloo')
-    assert (r, w) == (rank, world)
+    install_kernels('cpu' if device == 'cpu' else 'cuda')
+    r, _, w = parallel.init_distributed(backend=backend)
+    assert (r, w) == (rank, world) and dist.get_backend() == backend
     cfg, make, full = build(case, device, dtype, 1e-7 if use_graph else None)
-    tr = make(True, use_graph)
+    tr = make(True, bool(use_graph))
+    assert tr.graph_collectives == (use_graph == 'captured')
     assert len(tr.sync.buckets) >= 2
     assert tr.sync.buckets[0]['hi'] == tr.fp.flat.numel() and tr.sync.buckets[-1]['lo'] == 0
     mine = {k: v[rank:rank + 1].to(device) for k, v in full.items()}
@@ -167,9 +176,9 @@ def single_process(case, device, dtype, steps=1, base_lr=None):
     return tr.fp.flat.cpu().clone(), tr.fp.grad.cpu().clone(), float(terms['full_loss'].detach()), float(cfg.learning_rate)
 
 
-def run_and_compare(tmp, case, device, dtype, use_graph=False, grad_tol=1e-3):
+def run_and_compare(tmp, case, device, dtype, use_graph=False, grad_tol=1e-3, backend='gloo'):
     import torch.multiprocessing as mp
-    mp.spawn(worker, args=(2, free_port(), tmp, case, device, dtype, use_graph), nprocs=2, join=True)
+    mp.spawn(worker, args=(2, free_port(), tmp, case, device, dtype, use_graph, backend), nprocs=2, join=True)
     a = torch.load(os.path.join(tmp, 'rank0.pt'))
     b = torch.load(os.path.join(tmp, 'rank1.pt'))
     def where(x, y):

@@ -28,9 +28,63 @@ def test_two_ranks_one_gpu_per_frame_contract(tmp_path):
 
 
 def test_two_ranks_one_gpu_hipgraph_replay_with_eager_collectives(tmp_path):
-    """use_graph with several ranks: forward + backward are captured, the bucket all-reduces, the clip and Adam run
-    eagerly behind every replay; three steps (capture + two replays) equal three single-process steps."""
+    """use_graph with several ranks (the default mode of bench.py at every world size): forward + backward are captured with
+    every bucket's ready point as an external event-record node; behind every replay the bucket all-reduces are issued
+    eagerly on a communication stream gated by those events (so they overlap the rest of the backward), then clip and Adam;
+    three steps (capture + two replays) equal three single-process steps, every bucket reduced exactly once per step."""
     dp_common.run_and_compare(str(tmp_path), 'eyenet', 'cuda', 'bf16', use_graph=True)
+
+
+def test_external_event_node_gates_a_side_stream_on_the_running_replay():
+    """What parallel.GradSync.launch_gated relies on: an event recorded with external=True inside a captured graph is an
+    event-record NODE; a stream that waits for the event AFTER a replay was enqueued waits for that replay's node (not for
+    an earlier replay's), and is released when the replay passes the node -- before the replay ends."""
+    import torch
+    dev = torch.device('cuda', 0)
+    y = torch.zeros(1 << 20, device=dev)
+    out = torch.zeros_like(y)
+    ev = torch.cuda.Event(external=True)
+    side, cap = torch.cuda.Stream(), torch.cuda.Stream()
+    spin = 40_000_000                                    # ~20 ms at ~2 GHz
+    cap.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(cap):
+        torch.cuda._sleep(1000)
+        y.add_(0.0)
+    torch.cuda.current_stream().wait_stream(cap)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=cap):
+        torch.cuda._sleep(spin)                          # "backward up to the bucket's last gradient"
+        y.add_(1.0)
+        ev.record()
+        torch.cuda._sleep(4 * spin)                      # "the rest of the backward"
+        y.add_(100.0)
+    torch.cuda.synchronize()
+    t0, t_side, t_main = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+    for it in range(4):
+        t0.record()
+        g.replay()
+        with torch.cuda.stream(side):
+            ev.wait()
+            out.copy_(y)
+            t_side.record()
+        t_main.record()
+        torch.cuda.synchronize()
+        want = 101.0 * it + 1.0                          # this replay's first increment, not its second
+        assert float(out[0]) == want and float(out[-1]) == want, (it, float(out[0]), want)
+        assert t0.elapsed_time(t_side) < 0.6 * t0.elapsed_time(t_main), (t0.elapsed_time(t_side), t0.elapsed_time(t_main))
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize('mode', [False, True, 'captured'], ids=['eager', 'graph+gated-collectives', 'collectives-captured'])
+def test_two_rccl_ranks_two_gpus(tmp_path, mode):
+    """Two processes, two GPUs, backend nccl (= RCCL over xGMI): the transport and ordering the 2/4/8-GPU bench uses.  Needs a
+    box with at least two devices (the one-GPU test boxes skip it; the gloo variants above are the stand-in there)."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip('needs two GPUs (RCCL wants one device per rank)')
+    a = dp_common.run_and_compare(str(tmp_path), 'eyenet', 'cuda', 'bf16', use_graph=mode, backend='nccl')
+    assert a['buckets'] >= 3
 
 
 @pytest.mark.timeout(600)

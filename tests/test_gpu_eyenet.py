@@ -382,62 +382,6 @@ def test_float32_gradients_match_the_reference_float64_full_tensors():
         worst, float(fx['eye_ref_f32_vs_f64_worst'])))
 
 
-@pytest.mark.parametrize('variant', ['GRU', 'LSTM-stack2', 'no-head-pose', 'trainer-flat-grads'])
-def test_tail_chains_equal_the_per_layer_tail(variant):
-    """The tail as chains (round 4: ops.TailPreFn / TailHeadsFn -- fc, head-pose concat, fc_common, the input projection of the
-    first recurrent cell in one launch, both heads in one launch, their data gradients as chains and all weight / bias gradients
-    in one launch each) against the per-layer path (ops.linear x 8, EyeNet.fuse_tail = False) on the same features: outputs,
-    d(features) and every tail parameter's gradient.  Same products and activation derivatives, sums in the same order per
-    output element for the forward / data gradients; the weight gradients differ by their float atomics' order.  Variants: a
-    2-cell LSTM stack (only cell 0's projection is in the chain), no head-pose input (fc_common.0 takes 128 columns), and the
-    product trainer's flat gradient buffer (gradients written in place, nothing returned to autograd)."""
-    import eve_amd
-    from eve_amd import train
-    cfg = eve_amd.reset_standalone_config()
-    over = {'batch_size': 16, 'weight_decay': 0.005, 'base_learning_rate': 0.001}
-    if variant == 'LSTM-stack2':
-        over.update(eye_net_rnn_type='LSTM', eye_net_rnn_num_cells=2)
-    if variant == 'no-head-pose':
-        over.update(eye_net_use_head_pose_input=False)
-    cfg.import_dict(over)
-    S, T = 6, 5
-    g = torch.Generator().manual_seed(11)
-    feats0 = torch.randn((S * T, 512), generator=g).cuda()
-    hp = (0.1 * torch.randn((S * T, 2), generator=g)).cuda()
-    dgaze, dpup = torch.randn((S * T, 2), generator=g).cuda(), torch.randn((S * T,), generator=g).cuda()
-    res = {}
-    for fused in (False, True):
-        net = eve_amd.EyeNet()
-        net.compute_dtype = torch.float32
-        detweights.fill_module(net, seed=0)
-        net = net.cuda()
-        with torch.no_grad():                      # the reference zero-initialises the last gaze layer: give it a signal
-            g.manual_seed(12)
-            net.fc_to_gaze[2].weight.copy_(0.05 * torch.randn(net.fc_to_gaze[2].weight.shape, generator=g).cuda())
-        net.fuse_tail = fused
-        if variant == 'trainer-flat-grads':
-            tr = train.Trainer([net], cfg, lambda b: None)
-            tr.fp.zero_grad()
-        P = net._get_packs()
-        feats = feats0.clone().requires_grad_(True)
-        gaze, pupil, states = net._tail(feats, hp, S, T, None, P)
-        from eve_amd.kernels import default_kernels
-        used = default_kernels().lib.eve_last_kernel()
-        (gaze * dgaze).sum().add((pupil * dpup).sum()).backward()
-        torch.cuda.synchronize()
-        tail = {n: p.grad.detach().clone() for n, p in net.named_parameters() if not n.startswith('cnn_layers.') or n.startswith('cnn_layers.fc')}
-        res[fused] = (gaze.detach(), pupil.detach(), feats.grad.detach(), tail)
-        assert all(v is not None and torch.isfinite(v).all() for v in tail.values())
-    a, b = res[False], res[True]
-    for i, name in enumerate(('gaze', 'pupil', 'd(features)')):
-        assert float((a[i] - b[i]).abs().max()) <= 2e-6 * max(1.0, float(a[i].abs().max())), (name, float((a[i] - b[i]).abs().max()))
-    assert set(a[3]) == set(b[3]) and len(a[3]) >= 14
-    for n in a[3]:
-        ga, gb = a[3][n], b[3][n]
-        assert float((ga - gb).norm()) <= 2e-5 * float(ga.norm()) + 1e-7, (n, float((ga - gb).norm()), float(ga.norm()))
-    eve_amd.reset_standalone_config()
-
-
 @pytest.mark.parametrize('dtype,B,T', [(torch.float32, 3, 5), (torch.bfloat16, 2, 7), (torch.float32, 1, 1)])
 def test_tail_and_losses_as_one_node_equal_the_per_layer_path(dtype, B, T):
     """Round 4: EyeNet.loss_terms_sequence runs the tail and the losses as ONE autograd node (ops.EyeTailLossFn: every layer one
