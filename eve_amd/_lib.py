@@ -2,7 +2,7 @@
 product path raises -- there is no CPU implementation of the hot path in this package."""
 import ctypes
 import os
-from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_longlong, c_void_p
+from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_longlong, c_uint, c_void_p
 
 from .build import LIB_PATH
 
@@ -49,7 +49,7 @@ class PackItem(Structure):
 
 
 PACK_BATCH_MAX = 48
-ABI_VERSION = 6          # include/eve_hip.h EVE_ABI_VERSION
+ABI_VERSION = 7          # include/eve_hip.h EVE_ABI_VERSION
 
 SIGNATURES = {
     'eve_conv2d_fwd': [POINTER(ConvDesc), P, P, P, I, P, I, P, P],
@@ -71,6 +71,11 @@ SIGNATURES = {
     'eve_bias_grad': [I, L, I, P, P, P],
     'eve_cgru_scan_fwd': [I, I, I, P, P, P, P, P, P, P, P, P, P, P, P],
     'eve_cgru_scan_bwd': [I, I, I, P, P, P, P, P, P, P, P, P, P, P, P],
+    'eve_gate_signal': [P, P],
+    'eve_gate_wait': [P, c_uint, P, P],
+    'eve_crnn_scan_fwd': [I, I, P, P, P, P, P, P, P],
+    'eve_crnn_scan_bwd': [I, I, P, P, P, P, P, P, P],
+    'eve_clstm_scan_fwd': [I, I, P, P, P, P, P, P, P, P],
     'eve_rnn_scan_fwd': [I, I, I, P, P, P, P, P, P],
     'eve_rnn_scan_bwd': [I, I, I, P, P, P, P, P, P],
     'eve_lstm_scan_fwd': [I, I, I, P, P, P, P, P, P, P, P, P],

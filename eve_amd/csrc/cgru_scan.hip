@@ -519,8 +519,18 @@ using namespace eve;
    (input channels: r*h then x), biases float.  Outputs (bf16): hs [B][T][5][8][64] = hidden states in the caller's
    (sequence, frame) order; and TIME-major [T][B][5][8][.] for the backward, which walks frames: hs_tm, ru = the two
    sigmoid gates (128 channels), rh = r * h_{t-1}, og = tanh output gate. */
+// float32 instantiation (cell_scan_f32.hip): one workgroup per sequence, float state in LDS, v_mfma_f32_16x16x4_f32
+int eve_cgru_scan_f32_fwd(int B, int T, const float* xs, const float* h0, const float* w1, const float* b1, const float* w2,
+                          const float* b2, float* hs, float* hs_tm, float* ru, float* rh, float* og, hipStream_t s);
+int eve_cgru_scan_f32_bwd(int B, int T, const float* dhs_tm, const float* ru, const float* og, const float* hs_tm, const float* h0,
+                          const float* w1t, const float* w2t, float* dg1_all, float* dg2_all, float* dxs_tm, float* dh0,
+                          hipStream_t s);
+
 extern "C" int eve_cgru_scan_fwd(int dtype, int B, int T, const void* xs, const void* h0, const void* w1, const float* b1, const void* w2,
                                  const float* b2, void* hs, void* hs_tm, void* ru, void* rh, void* og, eve_stream_t stream) {
+    if (dtype == EVE_DT_F32 && B > 0 && T > 0 && xs && w1 && b1 && w2 && b2 && hs && hs_tm && ru && rh && og)
+        return eve_cgru_scan_f32_fwd(B, T, (const float*)xs, (const float*)h0, (const float*)w1, b1, (const float*)w2, b2, (float*)hs,
+                                     (float*)hs_tm, (float*)ru, (float*)rh, (float*)og, (hipStream_t)stream);
     if ((dtype != EVE_DT_BF16 && dtype != EVE_DT_F16) || B <= 0 || T <= 0 || !xs || !w1 || !b1 || !w2 || !b2 || !hs || !hs_tm || !ru || !rh || !og)
         return set_error_msg("cgru_scan_fwd: bad arguments");
     if ((long long)B * T * CG_PIX * 128 >= (1ll << 31)) return set_error_msg("cgru_scan_fwd: clip too large for 32-bit offsets");
@@ -546,6 +556,10 @@ extern "C" int eve_cgru_scan_fwd(int dtype, int B, int T, const void* xs, const 
 extern "C" int eve_cgru_scan_bwd(int dtype, int B, int T, const void* dhs_tm, const void* ru, const void* og, const void* hs_tm, const void* h0,
                                  const void* w1t, const void* w2t, void* dg1_all, void* dg2_all, void* dxs_tm, void* dh0,
                                  eve_stream_t stream) {
+    if (dtype == EVE_DT_F32 && B > 0 && T > 0 && dhs_tm && ru && og && hs_tm && w1t && w2t && dg1_all && dg2_all && dxs_tm)
+        return eve_cgru_scan_f32_bwd(B, T, (const float*)dhs_tm, (const float*)ru, (const float*)og, (const float*)hs_tm, (const float*)h0,
+                                     (const float*)w1t, (const float*)w2t, (float*)dg1_all, (float*)dg2_all, (float*)dxs_tm, (float*)dh0,
+                                     (hipStream_t)stream);
     if ((dtype != EVE_DT_BF16 && dtype != EVE_DT_F16) || B <= 0 || T <= 0 || !dhs_tm || !ru || !og || !hs_tm || !w1t || !w2t || !dg1_all || !dg2_all || !dxs_tm)
         return set_error_msg("cgru_scan_bwd: bad arguments");
     if ((long long)B * T * CG_PIX * 128 >= (1ll << 31)) return set_error_msg("cgru_scan_bwd: clip too large for 32-bit offsets");

@@ -101,9 +101,46 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
     }
 }
 
+// ---- stream gates: a point of one stream's (captured) work releases work queued on another stream --------------------------
+// signal: one release + agent-scope increment of *flag, as a kernel node behind the work it publishes;  wait: one lane polls
+// *flag with relaxed agent-scope loads and s_sleep until it has reached `value` (wrap-safe compare), then acquires.  The poll
+// is BOUNDED (~2^21 sleeps of 64 x 64 clocks: seconds): a gate whose signal never comes counts a time-out and lets the stream
+// go on instead of hanging the device; the host reads *timeouts.
+__global__ void gate_signal_kernel(unsigned* flag) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __hip_atomic_fetch_add(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__global__ void gate_wait_kernel(const unsigned* flag, const unsigned value, unsigned* timeouts) {
+    if (threadIdx.x != 0) return;
+    for (unsigned it = 0; it < (1u << 21); ++it) {
+        const unsigned v = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((int)(v - value) >= 0) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            return;
+        }
+        __builtin_amdgcn_s_sleep(64);
+    }
+    __hip_atomic_fetch_add(timeouts, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 }  // namespace eve
 
 using namespace eve;
+
+extern "C" int eve_gate_signal(unsigned* flag, eve_stream_t stream) {
+    if (!flag) return set_error_msg("gate_signal: null flag");
+    hipLaunchKernelGGL(gate_signal_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, flag);
+    EVE_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int eve_gate_wait(const unsigned* flag, unsigned value, unsigned* timeouts, eve_stream_t stream) {
+    if (!flag || !timeouts) return set_error_msg("gate_wait: null pointer");
+    hipLaunchKernelGGL(gate_wait_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, flag, value, timeouts);
+    EVE_CHECK_LAUNCH();
+    return 0;
+}
 
 extern "C" int eve_sumsq(long long n, const float* g, float* out, float* workspace, eve_stream_t stream) {
     if (n <= 0 || !g || !out || !workspace) return set_error_msg("sumsq: bad arguments");

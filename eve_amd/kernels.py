@@ -929,10 +929,11 @@ class HipKernels(object):
         return dpre, dh0, dc0
 
     def cgru_scan_fwd(self, xs, h0, w1_ohwi, b1, w2_ohwi, b2):
-        """CGRUCell over T in one launch.  xs [B, T, 5, 8, 64] bf16 / fp16 -> hs [B, T, 5, 8, 64] and, time-major [T, B, 5, 8, .]
-        for the backward: hs_tm, ru, rh, og."""
+        """CGRUCell over T in one launch.  xs [B, T, 5, 8, 64] bf16 / fp16 / float32 -> hs [B, T, 5, 8, 64] and, time-major
+        [T, B, 5, 8, .] for the backward: hs_tm, ru, rh, og.  (float32: csrc/cell_scan_f32.hip.)"""
         B, T, H, W, C = xs.shape
-        assert (H, W, C) == (5, 8, 64) and xs.dtype in HALF_DTYPES and xs.is_contiguous()
+        assert (H, W, C) == (5, 8, 64) and xs.dtype in HALF_DTYPES + (torch.float32,) and xs.is_contiguous()
+        assert w1_ohwi.dtype == w2_ohwi.dtype == xs.dtype and w1_ohwi.is_contiguous() and w2_ohwi.is_contiguous()
         assert tuple(w1_ohwi.shape) == (128, 3, 3, 128) and tuple(w2_ohwi.shape) == (64, 3, 3, 128)
         dev = xs.device
         hdt = xs.dtype
@@ -947,10 +948,12 @@ class HipKernels(object):
         return hs, hs_tm, ru, rh, og
 
     def cgru_scan_bwd(self, dhs_tm, ru, og, hs_tm, h0, w1_ihwo, w2_ihwo, want_dh0=False):
-        """Backward of cgru_scan_fwd in one launch.  Time-major [T, B, 5, 8, .] 16-bit inputs; returns (dg1_all [T,B,5,8,128],
-        dg2_all [T,B,5,8,64], dxs_tm [T,B,5,8,64], dh0 [B,5,8,64] or None)."""
+        """Backward of cgru_scan_fwd in one launch.  Time-major [T, B, 5, 8, .] inputs (16-bit or float32); returns (dg1_all
+        [T,B,5,8,128], dg2_all [T,B,5,8,64], dxs_tm [T,B,5,8,64], dh0 [B,5,8,64] or None)."""
         T, B, H, W, C = dhs_tm.shape
-        assert (H, W, C) == (5, 8, 64) and dhs_tm.dtype in HALF_DTYPES and dhs_tm.is_contiguous()
+        assert (H, W, C) == (5, 8, 64) and dhs_tm.dtype in HALF_DTYPES + (torch.float32,) and dhs_tm.is_contiguous()
+        assert w1_ihwo.dtype == w2_ihwo.dtype == dhs_tm.dtype and w1_ihwo.is_contiguous() and w2_ihwo.is_contiguous()
+        assert all(t.is_contiguous() and t.dtype == dhs_tm.dtype for t in (ru, og, hs_tm))
         assert tuple(ru.shape) == (T, B, H, W, 2 * C) and tuple(og.shape) == tuple(hs_tm.shape) == (T, B, H, W, C)
         assert tuple(w1_ihwo.shape) == (128, 3, 3, 128) and tuple(w2_ihwo.shape) == (128, 3, 3, 64)
         dev = dhs_tm.device
@@ -963,6 +966,45 @@ class HipKernels(object):
                                             self._p(w1_ihwo), self._p(w2_ihwo), self._p(dg1), self._p(dg2), self._p(dxs),
                                             self._p(dh0), self._stream()))
         return dg1, dg2, dxs, dh0
+
+    def crnn_scan_fwd(self, xs, h0, w_ohwi, bias):
+        """CRNNCell over T in one launch (float32, csrc/cell_scan_f32.hip).  xs [B, T, 5, 8, 64] -> (hs [B, T, 5, 8, 64], hs_tm
+        [T, B, 5, 8, 64])."""
+        B, T, H, W, C = xs.shape
+        assert (H, W, C) == (5, 8, 64) and xs.dtype == torch.float32 and xs.is_contiguous()
+        assert tuple(w_ohwi.shape) == (64, 3, 3, 128) and w_ohwi.dtype == torch.float32 and w_ohwi.is_contiguous()
+        assert h0 is None or (h0.dtype == torch.float32 and h0.is_contiguous() and tuple(h0.shape) == (B, H, W, C))
+        hs = torch.empty((B, T, H, W, C), dtype=torch.float32, device=xs.device)
+        hs_tm = torch.empty((T, B, H, W, C), dtype=torch.float32, device=xs.device)
+        self._ck(self.lib.eve_crnn_scan_fwd(B, T, self._p(xs), self._p(h0), self._p(w_ohwi), self._p(self._f32(bias, 'bias')),
+                                            self._p(hs), self._p(hs_tm), self._stream()))
+        return hs, hs_tm
+
+    def crnn_scan_bwd(self, dhs_tm, hs_tm, w_ihwo, want_dh0=False):
+        """Backward of crnn_scan_fwd in one launch: (dpre_all, dxs_tm [T, B, 5, 8, 64], dh0 [B, 5, 8, 64] or None)."""
+        T, B, H, W, C = dhs_tm.shape
+        assert (H, W, C) == (5, 8, 64) and dhs_tm.dtype == hs_tm.dtype == torch.float32
+        assert dhs_tm.is_contiguous() and hs_tm.is_contiguous() and tuple(hs_tm.shape) == (T, B, H, W, C)
+        assert tuple(w_ihwo.shape) == (128, 3, 3, 64) and w_ihwo.dtype == torch.float32 and w_ihwo.is_contiguous()
+        dpre = torch.empty((T, B, H, W, C), dtype=torch.float32, device=dhs_tm.device)
+        dxs = torch.empty((T, B, H, W, C), dtype=torch.float32, device=dhs_tm.device)
+        dh0 = torch.empty((B, H, W, C), dtype=torch.float32, device=dhs_tm.device) if want_dh0 else None
+        self._ck(self.lib.eve_crnn_scan_bwd(B, T, self._p(dhs_tm), self._p(hs_tm), self._p(w_ihwo), self._p(dpre), self._p(dxs),
+                                            self._p(dh0), self._stream()))
+        return dpre, dxs, dh0
+
+    def clstm_scan_fwd(self, xs, h0, c0, w_ohwi, bias):
+        """CLSTMCell over T in one launch (float32, forward only).  xs [B, T, 5, 8, 64] -> (hs, cs) [B, T, 5, 8, 64]."""
+        B, T, H, W, C = xs.shape
+        assert (H, W, C) == (5, 8, 64) and xs.dtype == torch.float32 and xs.is_contiguous()
+        assert tuple(w_ohwi.shape) == (256, 3, 3, 128) and w_ohwi.dtype == torch.float32 and w_ohwi.is_contiguous()
+        for s0 in (h0, c0):
+            assert s0 is None or (s0.dtype == torch.float32 and s0.is_contiguous() and tuple(s0.shape) == (B, H, W, C))
+        hs = torch.empty((B, T, H, W, C), dtype=torch.float32, device=xs.device)
+        cs = torch.empty((B, T, H, W, C), dtype=torch.float32, device=xs.device)
+        self._ck(self.lib.eve_clstm_scan_fwd(B, T, self._p(xs), self._p(h0), self._p(c0), self._p(w_ohwi),
+                                             self._p(self._f32(bias, 'bias')), self._p(hs), self._p(cs), self._stream()))
+        return hs, cs
 
     def cgru_gates1(self, g1, h):
         C = h.shape[-1]
@@ -1012,6 +1054,19 @@ class HipKernels(object):
         return h, c
 
     # ------------------------------------------------------------------ optimiser
+    # ------------------------------------------------------------------ stream gates (parallel.GradSync)
+    def gate_signal(self, flags, index):
+        """One-thread kernel on the current stream (capturable): release, then flags[index] += 1."""
+        assert flags.dtype == torch.int32 and flags.is_contiguous() and 0 <= index < flags.numel()
+        self._ck(self.lib.eve_gate_signal(ctypes.c_void_p(flags.data_ptr() + 4 * index), self._stream()))
+
+    def gate_wait(self, flags, index, value, timeouts):
+        """One-wave kernel on the current stream that returns once flags[index] has reached `value` (bounded poll: a gate
+        that never opens increments timeouts[0] after a few seconds instead of hanging the device)."""
+        assert flags.dtype == timeouts.dtype == torch.int32 and 0 <= index < flags.numel()
+        self._ck(self.lib.eve_gate_wait(ctypes.c_void_p(flags.data_ptr() + 4 * index), int(value) & 0xffffffff, self._p(timeouts),
+                                        self._stream()))
+
     SUMSQ_WORKSPACE = 1024          # include/eve_hip.h EVE_SUMSQ_WORKSPACE
 
     def sumsq(self, g, out, workspace=None):

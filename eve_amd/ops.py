@@ -1135,6 +1135,77 @@ class CGRUGates1Fn(torch.autograd.Function):
         return dg1, dh
 
 
+def _bias_grad_into(k, dy, bias):
+    """Bias gradient of a convolution whose output gradient is `dy` [..., C]: straight into the flat gradient buffer when the
+    parameter lives there (returns None), else a fresh float32 vector."""
+    if _direct_grad_ok(bias):
+        k.bias_grad(dy, bias.grad)
+        _notify_grad_ready(bias)
+        return None
+    db = torch.zeros((dy.shape[-1],), dtype=torch.float32, device=dy.device)
+    k.bias_grad(dy, db)
+    return db
+
+
+def _float_banks(weight, pack):
+    """(OHWI, IHWO) float32 copies of a convolution's filter bank for the float32 clip scans (csrc/cell_scan_f32.hip): the
+    pack's own tensors in the float32 instantiation, otherwise formed from the parameter (295-590 KB)."""
+    if pack is not None and pack.ohwi.dtype == torch.float32 and pack.ihwo is not None:
+        return pack.ohwi, pack.ihwo
+    w = weight.detach().float()
+    return w.permute(0, 2, 3, 1).contiguous(), w.permute(1, 2, 3, 0).contiguous()
+
+
+class CRNNScanFn(torch.autograd.Function):
+    """hs[:, t] = CRNNCell(xs[:, t], hs[:, t-1]) = tanh(conv3x3([x_t | h_{t-1}]) + b) for the whole clip in ONE launch, and the
+    frame-reversed backward in one more (kernels.crnn_scan_{fwd,bwd}, float32: csrc/cell_scan_f32.hip; common.py:331-352 applied
+    per frame by refine_net.py:132-176).  The weight and bias gradients are one batched launch each over all T*B frames.
+    xs float32 [B, T, 5, 8, 64] (16-bit callers convert: the bottleneck is 2 560 values per frame)."""
+
+    @staticmethod
+    def forward(ctx, xs, w, b, h0, pack):
+        k = default_kernels()
+        h0c = h0.detach().contiguous() if h0 is not None else None
+        w_ohwi, w_ihwo = _float_banks(w, pack)
+        xs = xs.contiguous()
+        hs, hs_tm = k.crnn_scan_fwd(xs, h0c, w_ohwi, b.detach().float().contiguous())
+        ctx.pack = pack
+        ctx.params = (w, b)
+        ctx.has_h0 = h0 is not None
+        ctx.save_for_backward(xs, h0c, hs_tm, w_ihwo)
+        return hs
+
+    @staticmethod
+    def backward(ctx, dhs):
+        k = default_kernels()
+        xs, h0, hs_tm, w_ihwo = ctx.saved_tensors
+        w, b = ctx.params
+        B, T, H, W, C = xs.shape
+        need = ctx.needs_input_grad
+        dhs_tm = dhs.float().transpose(0, 1).contiguous()
+        want_dh0 = bool(ctx.has_h0 and need[3])
+        dpre, dxs_tm, dh0 = k.crnn_scan_bwd(dhs_tm, hs_tm, w_ihwo, want_dh0)
+        dxs = dxs_tm.transpose(0, 1).contiguous() if need[0] else None
+        first = h0 if h0 is not None else torch.zeros_like(hs_tm[0])
+        h_prev_all = torch.cat([first.unsqueeze(0), hs_tm[:-1]], dim=0)
+        cat1 = torch.cat([xs.transpose(0, 1), h_prev_all], dim=-1).reshape(T * B, H, W, 2 * C)
+        gpre = dpre.view(T * B, H, W, C)
+        dw = _wgrad_into(k, cat1, gpre, w, ctx.pack, 1, 1) if need[1] else None
+        db = _bias_grad_into(k, gpre, b) if need[2] else None
+        return dxs, dw, db, dh0, None
+
+
+def clstm_scan(xs, weight, bias, pack, h0=None, c0=None):
+    """CLSTMCell over a clip in one launch, forward only (kernels.clstm_scan_fwd; common.py:355-385): the reference stores
+    the (h, c) tuple and never feeds it to the decoder (refine_net.py:168-174), so nothing is differentiated.
+    xs [B, T, 5, 8, 64] any dtype -> (hs, cs) float32 [B, T, 5, 8, 64]."""
+    k = default_kernels()
+    with torch.no_grad():
+        w_ohwi, _ = _float_banks(weight, pack)
+        f = lambda t: None if t is None else t.detach().float().contiguous()
+        return k.clstm_scan_fwd(xs.detach().float().contiguous(), f(h0), f(c0), w_ohwi, bias.detach().float().contiguous())
+
+
 class CGRUScanFn(torch.autograd.Function):
     """hs[:, t] = CGRUCell(xs[:, t], hs[:, t-1]) for the whole clip in ONE launch (kernels.cgru_scan_fwd: hidden state
     resident in LDS, both gate convolutions and their sigmoid / tanh / blend epilogues fused; common.py:388-415 applied
@@ -1197,19 +1268,10 @@ class CGRUScanFn(torch.autograd.Function):
         cat2 = torch.cat([rh, xs_tm], dim=-1).view(T * B, H, W, 2 * C)
         g1f, g2f = dg1_all.view(T * B, H, W, 2 * C), dg2_all.view(T * B, H, W, C)
 
-        def bgrad(dy, bias):
-            if _direct_grad_ok(bias):
-                k.bias_grad(dy, bias.grad)
-                _notify_grad_ready(bias)
-                return None
-            db = torch.zeros((dy.shape[-1],), dtype=torch.float32, device=dy.device)
-            k.bias_grad(dy, db)
-            return db
-
         dw1 = _wgrad_into(k, cat1, g1f, w1, p1, 1, 1) if need[1] else None
-        db1 = bgrad(g1f, b1) if need[2] else None
+        db1 = _bias_grad_into(k, g1f, b1) if need[2] else None
         dw2 = _wgrad_into(k, cat2, g2f, w2, p2, 1, 1) if need[3] else None
-        db2 = bgrad(g2f, b2) if need[4] else None
+        db2 = _bias_grad_into(k, g2f, b2) if need[4] else None
         return dxs, dw1, db1, dw2, db2, dh0, None, None
 
 

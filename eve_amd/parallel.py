@@ -69,6 +69,9 @@ class GradSync(object):
         self._marking = False        # hipGraph capture: a bucket's "ready" point becomes an event-record node (begin_marks)
         self._gated = []             # buckets in the order their ready points were captured
         self._comm = None            # the stream the gated all-reduces are issued from
+        self._flags = None           # one gate word per bucket (device int32), incremented once per replay by the bucket's node
+        self._timeouts = None
+        self._replays = 0
         self.launch_counts = []
         # a one-rank group has nothing to exchange; EVE_AMD_FORCE_DIST=1 runs the collectives anyway (transport test)
         self.active = self.world > 1 or (dist.is_initialized() and os.environ.get('EVE_AMD_FORCE_DIST', '0') == '1')
@@ -91,17 +94,23 @@ class GradSync(object):
 
     # ---- hipGraph replay with the collectives OUTSIDE the graph, still overlapped with backward ----------------------
     # A captured forward + backward cannot call RCCL eagerly from its gradient notifications (they fire at capture time
-    # only).  Instead every bucket's ready point is captured as an EXTERNAL event-record node (hipEventRecordWithFlags /
-    # hipEventRecordExternal: a node of the graph that records a plain event other streams may wait on).  After each
-    # replay is enqueued, launch_gated() walks the buckets in captured order: the communication stream waits for the
-    # bucket's event of THIS replay, then the all-reduce is issued eagerly -- it starts as soon as the replay passes the
-    # bucket's last gradient, under the rest of the backward, exactly like the eager mode's notifications.
+    # only), and torch on ROCm refuses external event-record nodes ("External events are disallowed in rocm").  So every
+    # bucket's ready point is captured as a GATE SIGNAL: a one-thread kernel node behind the weight-gradient kernel that
+    # completes the bucket, which releases and increments a device word (csrc/optim.hip: eve_gate_signal).  After each
+    # replay is enqueued, launch_gated() walks the buckets in captured order: the communication stream gets a one-wave
+    # gate-wait kernel for the bucket's word of THIS replay (value = replay count; bounded poll), then the all-reduce is
+    # issued eagerly behind it -- it starts as soon as the replay passes the bucket's last gradient, under the rest of
+    # the backward, exactly like the eager mode's notifications.  The RCCL calls themselves stay ordinary eager calls.
     def begin_marks(self):
         self.start_step()
         self._marking = True
         self._gated = []
-        if self._comm is None and self.flat_grad.is_cuda:
-            self._comm = torch.cuda.Stream(device=self.flat_grad.device)
+        if self.flat_grad.is_cuda:
+            if self._comm is None:
+                self._comm = torch.cuda.Stream(device=self.flat_grad.device)
+            self._flags = torch.zeros((len(self.buckets) + 1,), dtype=torch.int32, device=self.flat_grad.device)
+            self._timeouts = torch.zeros((1,), dtype=torch.int32, device=self.flat_grad.device)
+            self._replays = 0
 
     def end_marks(self):
         self._marking = False
@@ -113,10 +122,16 @@ class GradSync(object):
         self.start_step()
         self._armed = False
         if self.active:
+            from .kernels import default_kernels
+            k = default_kernels()
             main = torch.cuda.current_stream()
+            self._replays += 1
             for b in self._gated:
                 with torch.cuda.stream(self._comm):
-                    b['event'].wait()                 # (the communication stream; the collective orders itself behind it)
+                    if self._flags is not None:
+                        k.gate_wait(self._flags, self.buckets.index(b), self._replays, self._timeouts)
+                    else:                             # (CPU stand-in of the tests: nothing runs asynchronously)
+                        pass
                     self._launch(b)
             rest = [b for b in self.buckets if not b['launched'] and b['hi'] > b['lo']]
             if rest:
@@ -129,15 +144,19 @@ class GradSync(object):
         self._handles = []
         return 1.0 / self.world
 
+    def gate_timeouts(self):
+        """Gates that gave up waiting since begin_marks() (host sync; 0 in a healthy run)."""
+        return 0 if self._timeouts is None else int(self._timeouts.item())
+
     def _launch(self, b):
         if b['launched'] or b['hi'] <= b['lo']:
             return
         if self._marking:
-            # capture: the point itself, not the collective
+            # capture: the point itself (a gate signal node), not the collective
             b['launched'] = True
-            if b.get('event') is None:
-                b['event'] = torch.cuda.Event(external=True)
-            b['event'].record()
+            if self._flags is not None:
+                from .kernels import default_kernels
+                default_kernels().gate_signal(self._flags, self.buckets.index(b))
             self._gated.append(b)
             return
         b['launched'] = True

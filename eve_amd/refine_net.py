@@ -330,18 +330,30 @@ class RefineNet(nn.Module):
         while isinstance(bott, WrapEncoderDecoder):
             bott = bott.between_module
         cells = list(bott.rnn_cells) if self.config.refine_net_use_rnn else []
-        fused = (len(cells) == 1 and isinstance(cells[0], CGRUCell) and xs.dtype in HALF_DTYPES and
-                 tuple(xs.shape[2:]) == (5, 8, 64) and os.environ.get('EVE_AMD_CGRU_SCAN', '1') != '0')
-        if fused:
-            # the whole clip through the conv-GRU in one persistent launch (hidden state resident in LDS)
+        # one cell on the model's 5 x 8 x 64 bottleneck: the whole clip goes through it in ONE persistent launch (hidden state
+        # resident in LDS); CGRU in the 16-bit formats on cgru_scan.hip, CGRU in float32 and CRNN / CLSTM in any format on the
+        # float32 scans of cell_scan_f32.hip (round 5; the per-frame loop below remains for stacked cells / other geometries)
+        scan = (len(cells) == 1 and tuple(xs.shape[2:]) == (5, 8, 64) and os.environ.get('EVE_AMD_CGRU_SCAN', '1') != '0' and
+                xs.dtype in HALF_DTYPES + (torch.float32,))
+        if scan:
             cell, name = cells[0], '%s.rnn_cells.0' % prefix
-            hs = ops.CGRUScanFn.apply(xs.contiguous(), cell.gates_1.weight, cell.gates_1.bias, cell.gate_2.weight,
-                                      cell.gate_2.bias, None, P[name + '.gates_1'], P[name + '.gate_2'])
-            x = self._tap('rnn', hs.reshape(B * T, x.shape[1], x.shape[2], C))
+            h5, w5 = x.shape[1], x.shape[2]
+            to_ref = lambda t: ops.FromNHWCFn.apply(t.reshape(B * T, h5, w5, C), C).view(B, T, C, h5, w5)
+            if isinstance(cell, CGRUCell):
+                hs = ops.CGRUScanFn.apply(xs.contiguous(), cell.gates_1.weight, cell.gates_1.bias, cell.gate_2.weight,
+                                          cell.gate_2.bias, None, P[name + '.gates_1'], P[name + '.gate_2'])
+                states = [to_ref(hs)]
+            elif isinstance(cell, CRNNCell):
+                hs = ops.CRNNScanFn.apply(xs.float(), cell.cell.weight, cell.cell.bias, None, P[name + '.cell'])
+                states = [to_ref(hs)]
+                hs = hs.to(xs.dtype)
+            else:                       # CLSTM: the state is computed and stored, the features pass through (refine_net.py:168-174)
+                hcs = ops.clstm_scan(xs, cell.gates.weight, cell.gates.bias, P[name + '.gates'])
+                states = [tuple(to_ref(t) for t in hcs)]
+                hs = xs
+            x = self._tap('rnn', hs.reshape(B * T, h5, w5, C))
             hf = self._decode(x, skips, P)
-            # the T hidden states leave in the reference's layout with ONE launch (they are one contiguous [B*T,5,8,C] tensor)
-            st = ops.FromNHWCFn.apply(hs.reshape(B * T, hs.shape[2], hs.shape[3], C), C)
-            return hf.view(B, T, 1, hf.shape[2], hf.shape[3]), [st.view(B, T, C, hs.shape[2], hs.shape[3])]
+            return hf.view(B, T, 1, hf.shape[2], hf.shape[3]), states
         else:
             outs, states, hist = [], None, []
             for t in range(T):

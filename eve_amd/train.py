@@ -74,8 +74,8 @@ class Trainer(object):
     launched on) after two eager warm-up steps and replays it afterwards: the step is ~600 launches, a third of
     them tiny tail/loss kernels whose host-side enqueue would otherwise leave the GPU idle at the start of every
     backward.  Shapes are static (B, T fixed), so a new batch is copied into the captured input buffers.
-    With data parallelism the graph holds forward+backward only; every bucket's ready point is captured as an external
-    event-record node and the bucket's all-reduce is issued eagerly on a communication stream that waits for that event
+    With data parallelism the graph holds forward+backward only; every bucket's ready point is captured as a gate-signal
+    node and the bucket's all-reduce is issued eagerly on a communication stream behind a gate-wait kernel for that node
     of the running replay, so the collectives overlap the rest of the backward (parallel.GradSync.launch_gated); clip and
     Adam follow.  graph_collectives captures the all-reduces themselves instead (RCCL only)."""
 
@@ -229,7 +229,7 @@ class Trainer(object):
                 self._static_terms = self._forward_backward(self._static_batch)
                 self._update(self.sync.finish_step())
             elif self.sync is not None:
-                # forward + backward in the graph, every bucket's ready point as an external event-record node
+                # forward + backward in the graph, every bucket's ready point as a gate-signal node (csrc/optim.hip)
                 self.sync.begin_marks()
                 self._static_terms = self._forward_backward(self._static_batch)
                 self.sync.end_marks()

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define EVE_ABI_VERSION 6
+#define EVE_ABI_VERSION 7
 
 typedef void* eve_stream_t; /* hipStream_t */
 
@@ -394,15 +394,17 @@ int eve_lstm_scan_bwd(int S, int T, int H, const float* dhs, const float* dcs, c
 /* conv-GRU gate math of CGRUCell.forward (common.py:409-414), NHWC, C = hidden size:
  *   step 1: (r, u) = sigmoid(g1[..., 0:C], g1[..., C:2C]);  rh = r * h
  *   step 2: o = tanh(g2);  h' = (1 - u) * o + u * h                                                */
-/* CGRUCell over all T frames of a clip in ONE persistent launch (bf16; the 5x8x64 bottleneck of refine_net.py:132-176):
+/* CGRUCell over all T frames of a clip in ONE persistent launch (the 5x8x64 bottleneck of refine_net.py:132-176):
  * hidden state resident in LDS, both gate GEMMs on MFMA with the filter banks streamed through an LDS-DMA ring,
- * sigmoid / tanh / blend as epilogues.  xs [B][T][5][8][64]; h0 [B][5][8][64] or NULL; w1 = gates_1 OHWI
+ * sigmoid / tanh / blend as epilogues.  dtype bf16 / f16: cgru_scan.hip (three sequences per workgroup, 16-bit MFMA);
+ * dtype f32 (ABI v7): cell_scan_f32.hip (one workgroup per sequence, float state, v_mfma_f32_16x16x4_f32 -- the parity
+ * mode's 1e-4 rad runs on one launch per clip as well).  xs [B][T][5][8][64]; h0 [B][5][8][64] or NULL; w1 = gates_1 OHWI
  * [128][3][3][128] (inputs x|h), w2 = gate_2 OHWI [64][3][3][128] (inputs r*h|x); outputs: hs [B][T][5][8][64]
  * (state, caller's order) and, TIME-major [T][B][5][8][.] for the frame-reversed backward: hs_tm, ru (both sigmoid
  * gates, 128 ch), rh (r*h), og (tanh gate).                                                               */
 int eve_cgru_scan_fwd(int dtype, int B, int T, const void* xs, const void* h0, const void* w1, const float* b1, const void* w2,
                       const float* b2, void* hs, void* hs_tm, void* ru, void* rh, void* og, eve_stream_t stream);
-/* Backward of eve_cgru_scan_fwd in ONE persistent launch (bf16; common.py:400-415 differentiated): frames last to first, the
+/* Backward of eve_cgru_scan_fwd in ONE persistent launch (bf16 / f16 / f32; common.py:400-415 differentiated): frames last to first, the
  * gradient into the previous hidden state carried in registers.  Time-major inputs [T][B][5][8][.]: dhs_tm (d hs), and the
  * forward's ru / og / hs_tm; h0 or NULL; w1t = gates_1 bank IHWO [128][3][3][128], w2t = gate_2 bank IHWO [128][3][3][64].
  * Outputs (time-major): dg1_all [..][128], dg2_all [..][64] (pre-activation gradients: the operands of the batched weight /
@@ -410,6 +412,21 @@ int eve_cgru_scan_fwd(int dtype, int B, int T, const void* xs, const void* h0, c
 int eve_cgru_scan_bwd(int dtype, int B, int T, const void* dhs_tm, const void* ru, const void* og, const void* hs_tm, const void* h0,
                       const void* w1t, const void* w2t, void* dg1_all, void* dg2_all, void* dxs_tm, void* dh0,
                       eve_stream_t stream);
+/* CRNNCell (common.py:331-352: h_t = tanh(conv3x3([x_t | h_{t-1}]) + b)) over all T frames of a clip in ONE launch, float32
+ * (ABI v7; 16-bit callers convert the 5x8x64 bottleneck tensors).  xs [B][T][5][8][64]; h0 [B][5][8][64] or NULL; w OHWI
+ * [64][3][3][128]; bias [64].  Outputs hs [B][T][5][8][64] and its time-major copy hs_tm [T][B][5][8][64].                 */
+int eve_crnn_scan_fwd(int B, int T, const float* xs, const float* h0, const float* w, const float* bias, float* hs,
+                      float* hs_tm, eve_stream_t stream);
+/* Backward of eve_crnn_scan_fwd, one launch: time-major dhs_tm / hs_tm; wt = the bank IHWO [128][3][3][64].  Outputs
+ * (time-major) dpre_all [T][B][5][8][64] = gradient of the pre-activation (operand of the batched weight / bias gradient),
+ * dxs_tm; dh0 [B][5][8][64] or NULL.                                                                                       */
+int eve_crnn_scan_bwd(int B, int T, const float* dhs_tm, const float* hs_tm, const float* wt, float* dpre_all, float* dxs_tm,
+                      float* dh0, eve_stream_t stream);
+/* CLSTMCell (common.py:355-385; gates in / forget / out / cell) over all T frames of a clip in ONE launch, float32, forward
+ * only -- the reference's Bottleneck stores the (h, c) tuple and never feeds it on (refine_net.py:168-174), so no gradient
+ * reaches the cell.  w OHWI [256][3][3][128]; bias [256]; h0 / c0 or NULL.  Outputs hs, cs [B][T][5][8][64].               */
+int eve_clstm_scan_fwd(int B, int T, const float* xs, const float* h0, const float* c0, const float* w, const float* bias,
+                       float* hs, float* cs, eve_stream_t stream);
 int eve_cgru_gates1(int dtype, long long P, int C, const void* g1, const void* h, void* ru, void* rh,
                     eve_stream_t stream);
 int eve_cgru_gates2(int dtype, long long P, int C, const void* g2, const void* ru, const void* h,
@@ -473,6 +490,16 @@ int eve_linear_wgrad_batch(const eve_wgrad_problem* problems, int n, eve_stream_
  * Optimiser step over flat float buffers.  torch.optim.Adam with coupled L2 weight decay
  * (src/train.py:49-55) after nn.utils.clip_grad_norm_ (src/core/training.py:492-498).
  * ------------------------------------------------------------------------------------------------ */
+/* Stream gates (ABI v7) -- how a hipGraph replay of forward + backward releases each gradient bucket's all-reduce on the
+ * communication stream the moment the bucket's last gradient has been written, with the RCCL calls left OUTSIDE the graph
+ * (north_star: "RCCL all-reduce of gradients ... overlapped with backward"; the reference's backward -> clip -> step sequence is
+ * src/core/training.py:489-502).  eve_gate_signal: a one-thread kernel (capturable: it becomes a node of the graph behind the
+ * weight-gradient kernel that completes the bucket) that releases and increments *flag.  eve_gate_wait: a one-wave kernel on the
+ * OTHER stream that polls *flag until it has reached `value` (the replay count), bounded: after ~seconds it increments
+ * *timeouts and returns, so a missing signal cannot hang the device.  flag / timeouts: device words, zeroed by the caller.    */
+int eve_gate_signal(unsigned* flag, eve_stream_t stream);
+int eve_gate_wait(const unsigned* flag, unsigned value, unsigned* timeouts, eve_stream_t stream);
+
 /* out[0] += sum g^2 (caller zeroes out[0]; take sqrt on the host or in eve_adam_step).  Fixed summation order: the
  * result is bit-reproducible, so data-parallel replicas clip by the identical factor.  workspace: EVE_SUMSQ_WORKSPACE
  * floats of scratch owned by the caller.                                                            */

@@ -403,6 +403,36 @@ class FakeKernels(object):
             dg1_all[t], dg2_all[t], dxs[t] = dg1, dg2, (dcat1[..., :C] + dx2).to(dt)
         return torch.stack(dg1_all, 0), torch.stack(dg2_all, 0), torch.stack(dxs, 0), (carry.to(dt) if want_dh0 else None)
 
+    def crnn_scan_fwd(self, xs, h0, w_ohwi, bias):
+        B, T = xs.shape[:2]
+        h = torch.zeros_like(xs[:, 0]) if h0 is None else h0
+        hs = []
+        for t in range(T):
+            h = self.conv2d_fwd(torch.cat([xs[:, t], h], -1), w_ohwi, bias, 1, 1, ACT_TANH)
+            hs.append(h)
+        return torch.stack(hs, 1), torch.stack(hs, 0)
+
+    def crnn_scan_bwd(self, dhs_tm, hs_tm, w_ihwo, want_dh0=False):
+        T, B, H, W, C = dhs_tm.shape
+        carry = torch.zeros((B, H, W, C))
+        dpre, dxs = [None] * T, [None] * T
+        for t in range(T - 1, -1, -1):
+            a = (dhs_tm[t] + carry) * (1 - hs_tm[t] * hs_tm[t])
+            dcat = torch.nn.grad.conv2d_input((B, 2 * C, H, W), w_ihwo.permute(3, 0, 1, 2).float(), nchw(a), 1, 1).permute(0, 2, 3, 1)
+            dpre[t], dxs[t], carry = a, dcat[..., :C].contiguous(), dcat[..., C:]
+        return torch.stack(dpre, 0), torch.stack(dxs, 0), (carry.contiguous() if want_dh0 else None)
+
+    def clstm_scan_fwd(self, xs, h0, c0, w_ohwi, bias):
+        B, T = xs.shape[:2]
+        h = torch.zeros_like(xs[:, 0]) if h0 is None else h0
+        c = torch.zeros_like(xs[:, 0]) if c0 is None else c0
+        hs, cs = [], []
+        for t in range(T):
+            gates = self.conv2d_fwd(torch.cat([xs[:, t], h], -1), w_ohwi, bias, 1, 1)
+            h, c = self.clstm_gates_fwd(gates, c)
+            hs.append(h); cs.append(c)
+        return torch.stack(hs, 1), torch.stack(cs, 1)
+
     def cgru_gates2_bwd(self, dhnew, ru, h, o):
         C = h.shape[-1]
         d, u, of = dhnew.float(), ru.float()[..., C:], o.float()

@@ -29,21 +29,25 @@ def test_two_ranks_one_gpu_per_frame_contract(tmp_path):
 
 def test_two_ranks_one_gpu_hipgraph_replay_with_eager_collectives(tmp_path):
     """use_graph with several ranks (the default mode of bench.py at every world size): forward + backward are captured with
-    every bucket's ready point as an external event-record node; behind every replay the bucket all-reduces are issued
-    eagerly on a communication stream gated by those events (so they overlap the rest of the backward), then clip and Adam;
+    every bucket's ready point as a gate-signal node; behind every replay the bucket all-reduces are issued eagerly on a
+    communication stream behind gate-wait kernels for those nodes (so they overlap the rest of the backward), then clip and Adam;
     three steps (capture + two replays) equal three single-process steps, every bucket reduced exactly once per step."""
     dp_common.run_and_compare(str(tmp_path), 'eyenet', 'cuda', 'bf16', use_graph=True)
 
 
-def test_external_event_node_gates_a_side_stream_on_the_running_replay():
-    """What parallel.GradSync.launch_gated relies on: an event recorded with external=True inside a captured graph is an
-    event-record NODE; a stream that waits for the event AFTER a replay was enqueued waits for that replay's node (not for
-    an earlier replay's), and is released when the replay passes the node -- before the replay ends."""
+def test_gate_signal_node_releases_a_side_stream_during_the_running_replay():
+    """What parallel.GradSync.launch_gated relies on (csrc/optim.hip: eve_gate_signal / eve_gate_wait): a gate signal captured
+    into a graph is a kernel NODE; a stream that gets a gate-wait for the replay count AFTER the replay was enqueued is released
+    when THAT replay passes the node -- not by an earlier replay's signal, and before the replay ends.  (torch on ROCm refuses
+    external event-record nodes: "External events are disallowed in rocm".)  A gate that never opens gives up and counts."""
     import torch
+    from eve_amd.kernels import HipKernels
+    k = HipKernels()
     dev = torch.device('cuda', 0)
     y = torch.zeros(1 << 20, device=dev)
     out = torch.zeros_like(y)
-    ev = torch.cuda.Event(external=True)
+    flags = torch.zeros(2, dtype=torch.int32, device=dev)
+    timeouts = torch.zeros(1, dtype=torch.int32, device=dev)
     side, cap = torch.cuda.Stream(), torch.cuda.Stream()
     spin = 40_000_000                                    # ~20 ms at ~2 GHz
     cap.wait_stream(torch.cuda.current_stream())
@@ -56,16 +60,17 @@ def test_external_event_node_gates_a_side_stream_on_the_running_replay():
     with torch.cuda.graph(g, stream=cap):
         torch.cuda._sleep(spin)                          # "backward up to the bucket's last gradient"
         y.add_(1.0)
-        ev.record()
+        k.gate_signal(flags, 1)
         torch.cuda._sleep(4 * spin)                      # "the rest of the backward"
         y.add_(100.0)
     torch.cuda.synchronize()
+    assert int(flags[1]) == 0                            # capturing does not run the node
     t0, t_side, t_main = (torch.cuda.Event(enable_timing=True) for _ in range(3))
     for it in range(4):
         t0.record()
         g.replay()
         with torch.cuda.stream(side):
-            ev.wait()
+            k.gate_wait(flags, 1, it + 1, timeouts)
             out.copy_(y)
             t_side.record()
         t_main.record()
@@ -73,6 +78,12 @@ def test_external_event_node_gates_a_side_stream_on_the_running_replay():
         want = 101.0 * it + 1.0                          # this replay's first increment, not its second
         assert float(out[0]) == want and float(out[-1]) == want, (it, float(out[0]), want)
         assert t0.elapsed_time(t_side) < 0.6 * t0.elapsed_time(t_main), (t0.elapsed_time(t_side), t0.elapsed_time(t_main))
+    assert int(flags[1]) == 4 and int(timeouts[0]) == 0
+    # a gate nobody signals: bounded, the stream goes on and the time-out is counted
+    with torch.cuda.stream(side):
+        k.gate_wait(flags, 0, 1, timeouts)
+    torch.cuda.synchronize()
+    assert int(timeouts[0]) == 1
 
 
 @pytest.mark.timeout(900)

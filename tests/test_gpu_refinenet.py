@@ -257,6 +257,90 @@ def test_fused_cgru_scan_backward_kernel_matches_contract(B, T, with_h0):
         assert rel < 6e-3 and float((a - b).abs().max()) <= 4e-2 * float(b.abs().max()), (name, rel, float((a - b).abs().max()))
 
 
+@pytest.mark.parametrize('B,T,with_h0', [(2, 3, False), (7, 5, True), (3, 1, True), (32, 30, False)])
+def test_float32_clip_scans_match_the_per_frame_contract(B, T, with_h0):
+    """Round 5: the float32 clip-long scans (csrc/cell_scan_f32.hip: CGRU forward + backward, CRNN forward + backward, CLSTM
+    forward; one persistent launch per clip and direction, v_mfma_f32_16x16x4_f32) against the ATen restatement of the per-frame
+    contract (two / one convolutions + gate math per frame, common.py:331-415), float32 tolerances."""
+    from eve_amd.kernels import HipKernels
+    import fake_kernels
+    hip, ref = HipKernels(), fake_kernels.FakeKernels()
+    g = torch.Generator().manual_seed(23)
+    rn = lambda *shape, scale=1.0: torch.randn(shape, generator=g) * scale
+    cu = lambda t: None if t is None else t.cuda()
+    xs, h0 = rn(B, T, 5, 8, 64, scale=0.8), (rn(B, 5, 8, 64, scale=0.5) if with_h0 else None)
+    c0 = rn(B, 5, 8, 64, scale=0.5) if with_h0 else None
+
+    def close(tag, got, want, tol=2e-5):
+        for name, a, b in zip(tag, got, want):
+            if b is None:
+                assert a is None, name
+                continue
+            a, b = a.float().cpu(), b.float()
+            assert tuple(a.shape) == tuple(b.shape), name
+            err, ref_max = float((a - b).abs().max()), float(b.abs().max())
+            assert err <= tol * max(1.0, ref_max), (name, err, ref_max)
+
+    # CGRU forward
+    w1, w2 = rn(128, 3, 3, 128, scale=0.04), rn(64, 3, 3, 128, scale=0.04)
+    b1, b2 = rn(128, scale=0.2), rn(64, scale=0.2)
+    want = ref.cgru_scan_fwd(xs, h0, w1, b1, w2, b2)
+    got = hip.cgru_scan_fwd(cu(xs), cu(h0), cu(w1), cu(b1), cu(w2), cu(b2))
+    assert hip.lib.eve_last_kernel().decode() == 'cgru_scan_f32_fwd_kernel'
+    close(('hs', 'hs_tm', 'ru', 'rh', 'og'), got, want)
+    # CGRU backward, on the forward's own tensors
+    dhs = rn(T, B, 5, 8, 64)
+    w1t, w2t = w1.permute(3, 1, 2, 0).contiguous(), w2.permute(3, 1, 2, 0).contiguous()
+    hs_tm, ru, _, og = want[1:]
+    want_b = ref.cgru_scan_bwd(dhs, ru, og, hs_tm, h0, w1t, w2t, want_dh0=with_h0)
+    got_b = hip.cgru_scan_bwd(cu(dhs), cu(ru), cu(og), cu(hs_tm), cu(h0), cu(w1t), cu(w2t), want_dh0=with_h0)
+    assert hip.lib.eve_last_kernel().decode() == 'cgru_scan_f32_bwd_kernel'
+    close(('dg1', 'dg2', 'dxs', 'dh0'), got_b, want_b, tol=1e-4 if T > 8 else 3e-5)
+    # CRNN forward + backward
+    w, bias = rn(64, 3, 3, 128, scale=0.04), rn(64, scale=0.2)
+    want = ref.crnn_scan_fwd(xs, h0, w, bias)
+    got = hip.crnn_scan_fwd(cu(xs), cu(h0), cu(w), cu(bias))
+    close(('hs', 'hs_tm'), got, want)
+    wt = w.permute(3, 1, 2, 0).contiguous()
+    want_b = ref.crnn_scan_bwd(dhs, want[1], wt, want_dh0=with_h0)
+    got_b = hip.crnn_scan_bwd(cu(dhs), cu(want[1]), cu(wt), want_dh0=with_h0)
+    close(('dpre', 'dxs', 'dh0'), got_b, want_b, tol=1e-4 if T > 8 else 3e-5)
+    # CLSTM forward (state (h, c); gate order in / forget / out / cell)
+    w, bias = rn(256, 3, 3, 128, scale=0.04), rn(256, scale=0.2)
+    want = ref.clstm_scan_fwd(xs, h0, c0, w, bias)
+    got = hip.clstm_scan_fwd(cu(xs), cu(h0), cu(c0), cu(w), cu(bias))
+    close(('hs', 'cs'), got, want)
+
+
+@pytest.mark.parametrize('kind', ['CGRU', 'CRNN', 'CLSTM'])
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_refinenet_clip_scans_train_like_the_per_frame_path(monkeypatch, kind, dtype):
+    """RefineNet forward + backward through the clip-long scans vs EVE_AMD_CGRU_SCAN=0 (the per-frame launches), every cell
+    type, float32 (tight) and bf16 (CRNN / CLSTM: the float32 scan behind 16-bit convolutions)."""
+    rb = detweights.refinenet_batch(3, 4, seed=3)
+    outs = {}
+    for mode in ('1', '0'):
+        monkeypatch.setenv('EVE_AMD_CGRU_SCAN', mode)
+        net, _ = make_net(kind, dtype=dtype)
+        hf, states = net.forward_sequence(rb['heatmap_initial'].cuda(), rb['screen_frame'].cuda())
+        (hf.float() * rb['heatmap_final_gt'].cuda()).sum().backward()
+        st = states[0]
+        outs[mode] = (hf.detach().float().cpu(), [t.detach().float().cpu() for t in (st if isinstance(st, tuple) else (st,))],
+                      {n: p.grad.detach().float().cpu() for n, p in net.named_parameters() if p.grad is not None})
+    a, b = outs['1'], outs['0']
+    f32 = dtype == torch.float32
+    assert float((a[0] - b[0]).abs().max()) < (2e-5 if f32 else 0.05)
+    for sa, sb in zip(a[1], b[1]):
+        assert tuple(sa.shape) == tuple(sb.shape)
+        assert float((sa - sb).abs().max()) < (2e-5 if f32 else 0.06)
+    assert set(a[2]) == set(b[2])
+    for n in b[2]:
+        ga, gb = a[2][n], b[2][n]
+        if ga.dim() < 2:
+            continue          # biases feeding an InstanceNorm have an exactly-zero gradient: what is computed is rounding noise
+        assert float((ga - gb).norm()) <= (2e-3 if f32 else 0.15) * float(gb.norm()) + 1e-4, n
+
+
 def test_float32_refinenet_gradients_match_the_reference_float64_full_tensors():
     """tests/golden/grads_f64.npz: the reference's RefineNet (CGRU, per-step contract over T = 3) + CrossEntropyLoss in
     float64.  The float32 HIP path: heat-map BCE to 2e-6; the FULL gradient tensors of the conv-GRU's gates_1 / gate_2

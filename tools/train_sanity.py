@@ -68,9 +68,9 @@ def main():
     dt = {'bf16': torch.bfloat16, 'fp16': torch.float16}[dt_name]
     net, batch = train_eyenet(steps, dt)
     held_out = {k: v.cuda() for k, v in detweights.eyenet_batch(8, 10, seed=41).items()}
-    fresh = eve_amd.EyeNet().cuda()
+    fresh = detweights.fill_module(eve_amd.EyeNet(), seed=0).cuda()     # (the constructor zero-initialises the gaze head's last layer)
     print('%s vs float32 through the HIP path, same weights (gaze in rad; spread = std of the float32 predictions):' % dt_name)
-    for tag, n_ in (('untrained (He-random) weights', fresh), ('weights after %d %s steps' % (steps, dt_name), net)):
+    for tag, n_ in (('untrained (deterministic random) weights', fresh), ('weights after %d %s steps' % (steps, dt_name), net)):
         dev = eyenet_16bit_vs_fp32(n_, dt, {'training clips': batch, 'held-out clips': held_out})
         for name, d in dev.items():
             print('  %-34s %-15s gaze max %.3e rms %.3e (spread %.3e)  pupil max %.3e rms %.3e' % (
