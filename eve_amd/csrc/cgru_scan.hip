@@ -51,7 +51,7 @@ __global__ __launch_bounds__(256) void cgru_scan_fwd_kernel(const int B, const i
     // ---- lane constants -------------------------------------------------------------------------------------
     // interior LDS byte offset (inside a plane) of the lane's pixel for each of its four 16-pixel MFMA column tiles
     int pix_lds[4], pix_glob[4], pix_tm[4];          // pix_glob: (sequence * T) * 40 + pixel, or -1; pix_tm: sequence * 40 + pixel
-    int aaddr[9][4];
+    int abase[2][4];
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) {
         const int m = wm * 64 + mt * 16 + li;
@@ -62,11 +62,10 @@ __global__ __launch_bounds__(256) void cgru_scan_fwd_kernel(const int B, const i
         pix_lds[mt] = ((hr0 * 10 + px + 1) << 6) | ((hr0 & 1) << 16);          // row parity kept in bit 16
         pix_glob[mt] = ok ? (b0 + ti) * T * CG_PIX + rem : -1;
         pix_tm[mt] = (b0 + ti) * CG_PIX + rem;
+        // fragment address of tap (dy, dx) = abase[dy & 1][mt] + (dy * 10 + dx) * 64: the chunk key is the halo row's parity
+        const int hrt = ti * 7 + py;
 #pragma unroll
-        for (int t = 0; t < 9; ++t) {
-            const int hr = ti * 7 + py + t / 3, hx = px + t % 3;
-            aaddr[t][mt] = ((hr * 10 + hx) << 6) + ((lg ^ ((hr & 1) << 1)) << 4);
-        }
+        for (int q = 0; q < 2; ++q) abase[q][mt] = ((hrt * 10 + px) << 6) + ((lg ^ (((hrt + q) & 1) << 1)) << 4);
     }
     int brow1[4], brow2[4];
 #pragma unroll
@@ -134,9 +133,17 @@ __global__ __launch_bounds__(256) void cgru_scan_fwd_kernel(const int B, const i
     issue_w(0, 0, 0, 0, true);
     issue_w(0, 0, 1, 1, true);
     issue_w(0, 0, 2, 2, true);
-    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    issue_w(0, 0, 3, 3, true);
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");             // tiles 0 and 1 have landed
     __syncthreads();
 
+    // Round 5: the step loop is software-pipelined.  One wave per SIMD means nothing else hides a step's fragment reads
+    // (8 x ds_read_b128: ~250 cycles of LDS latency before the first of 16 MFMAs = 272 matrix-pipe cycles; 33 us per frame
+    // where the MFMAs need ~12), so step g+1's fragments are read into a second register set under step g's MFMAs.  The
+    // filter ring runs one tile further ahead for it (tile g+4 is issued in step g into the slot of tile g, whose reads
+    // every wave completed before the barrier of step g-1: each step ends lgkmcnt(0), vmcnt(4), barrier) and tile g+1 is
+    // published one step earlier.  The pipeline does not cross the conv1 -> conv2 and frame boundaries (the planes a
+    // convolution reads are written by the epilogue before it): each convolution's first step reads its own fragments.
     uint32_t gs = 0;                                  // stream position (ring phase)
     for (int t = 0; t < T; ++t) {
         const bool more_t = t + 1 < T;
@@ -145,7 +152,8 @@ __global__ __launch_bounds__(256) void cgru_scan_fwd_kernel(const int B, const i
         for (int j = 0; j < 4; ++j)
             xq[j] = (more_t && x_glob[j] >= 0) ? *reinterpret_cast<const uint4*>(xs + x_glob[j] + (size_t)(t + 1) * CG_PIX * CG_C)
                                                : make_uint4(0, 0, 0, 0);
-        f32x4_t acc[4][4], ug[4][4];
+        f32x4_t acc[4][4];
+        uint2 ug[4][4];                                // update gate of the wn = 1 waves, as stored (16-bit pairs)
 #pragma unroll
         for (int conv = 0; conv < 2; ++conv) {
 #pragma unroll
@@ -153,33 +161,50 @@ __global__ __launch_bounds__(256) void cgru_scan_fwd_kernel(const int B, const i
 #pragma unroll
                 for (int b = 0; b < 4; ++b) acc[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
             const bool active = conv == 0 || wn == 1;             // conv2 has 64 output channels: one wave column
-            for (int sl = 0; sl < 4; ++sl, gs += 9) {
-                // conv1 reads cat[x, h] = planes 0,1,2,3;  conv2 reads cat[r*h, x] = planes 4,5,0,1
+            uint4 fxA[4], fwA[4], fxB[4], fwB[4];
+            // fragments of (slice sl, tap) from ring position gpos; conv1 reads cat[x, h] = planes 0,1,2,3, conv2 cat[r*h, x] = 4,5,0,1
+            auto load = [&](int sl, int tap, uint32_t gpos, uint4 (&fx)[4], uint4 (&fw)[4]) {
                 const int plane = conv == 0 ? sl : (sl < 2 ? 4 + sl : sl - 2);
-                const uint32_t la = lds0 + plane * CG_SLICE;
+                const uint32_t la = lds0 + plane * CG_SLICE, lb = ldsB + (gpos & 3) * CG_BSLOT;
 #pragma unroll
-                for (int tap = 0; tap < 9; ++tap) {
-                    // weight tile of stream position +3
-                    int nsl = sl + (tap + 3) / 9, nconv = conv, live = 1;
-                    if (nsl == 4) { nsl = 0; nconv = conv + 1; if (nconv == 2) { nconv = 0; live = more_t; } }
-                    issue_w(nconv, nsl, (tap + 3) % 9, (int)((gs + tap + 3) & 3), live != 0);
+                for (int mt = 0; mt < 4; ++mt)
+                    fx[mt] = __builtin_bit_cast(uint4, *reinterpret_cast<const EVE_LDS cg_u32x4_t*>((uintptr_t)(la + abase[(tap / 3) & 1][mt] + ((tap / 3) * 10 + tap % 3) * 64)));
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt)
+                    fw[nt] = __builtin_bit_cast(uint4, *reinterpret_cast<const EVE_LDS cg_u32x4_t*>(
+                        (uintptr_t)(lb + (conv == 0 ? brow1[nt] : brow2[nt]))));
+            };
+            auto mma = [&](const uint4 (&fx)[4], const uint4 (&fw)[4]) {
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                    for (int mt = 0; mt < 4; ++mt)
+                        Elem<H>::mfma(acc[mt][nt], fw[nt], fx[mt]);
+            };
+            if (active) load(0, 0, gs, fxA, fwA);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // every wave is done with this tile's slot before step 0 refills it
+            __syncthreads();
+            for (int sl = 0; sl < 4; sl += 2, gs += 18) {
+#pragma unroll
+                for (int i = 0; i < 18; ++i) {
+                    const int s_ = sl + i / 9, tap = i % 9;
+                    // weight tile of stream position +4
+                    int nsl = s_ + (tap + 4) / 9, nconv = conv, live = 1;
+                    if (nsl >= 4) { nsl -= 4; nconv = conv + 1; if (nconv == 2) { nconv = 0; live = more_t; } }
+                    issue_w(nconv, nsl, (tap + 4) % 9, (int)((gs + i + 4) & 3), live != 0);
                     if (active) {
-                        const uint32_t lb = ldsB + ((gs + tap) & 3) * CG_BSLOT;
-                        uint4 fx[4], fw[4];
-#pragma unroll
-                        for (int mt = 0; mt < 4; ++mt)
-                            fx[mt] = __builtin_bit_cast(uint4, *reinterpret_cast<const EVE_LDS cg_u32x4_t*>((uintptr_t)(la + aaddr[tap][mt])));
-#pragma unroll
-                        for (int nt = 0; nt < 4; ++nt)
-                            fw[nt] = __builtin_bit_cast(uint4, *reinterpret_cast<const EVE_LDS cg_u32x4_t*>(
-                                (uintptr_t)(lb + (conv == 0 ? brow1[nt] : brow2[nt]))));
-#pragma unroll
-                        for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-                            for (int mt = 0; mt < 4; ++mt)
-                                Elem<H>::mfma(acc[mt][nt], fw[nt], fx[mt]);
+                        const bool has_next = i < 17 || sl == 0;
+                        if (has_next) {
+                            if (i & 1) load(s_ + (tap + 1) / 9, (tap + 1) % 9, gs + i + 1, fxA, fwA);
+                            else       load(s_ + (tap + 1) / 9, (tap + 1) % 9, gs + i + 1, fxB, fwB);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);        // the reads above are issued BEFORE the MFMAs (hipcc would sink them)
+                        if (i & 1) mma(fxB, fwB);
+                        else       mma(fxA, fwA);
+                        __builtin_amdgcn_sched_barrier(0);
                     }
-                    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // tile of the next step (issued 2 steps ago) landed
+                    // this wave's reads of tile g+1 are complete; tile g+2 (issued 2 steps ago) has landed
+                    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_waitcnt vmcnt(4)" ::: "memory");
                     __syncthreads();
                 }
             }
@@ -210,7 +235,7 @@ __global__ __launch_bounds__(256) void cgru_scan_fwd_kernel(const int B, const i
                                 *reinterpret_cast<uint2*>(rh + ptm * CG_C + c) = make_uint2(q0, q1);
                             }
                         } else {
-                            ug[mt][nt] = f32x4_t{v[0], v[1], v[2], v[3]};
+                            ug[mt][nt] = make_uint2(p0, p1);
                         }
                     }
                 }
@@ -236,9 +261,10 @@ __global__ __launch_bounds__(256) void cgru_scan_fwd_kernel(const int B, const i
                     const cg_u32x2_t hq = *reinterpret_cast<const EVE_LDS cg_u32x2_t*>((uintptr_t)ha);
                     const float hv[4] = {Elem<H>::lo(hq.x), Elem<H>::hi(hq.x),
                                          Elem<H>::lo(hq.y), Elem<H>::hi(hq.y)};
+                    const float uv[4] = {Elem<H>::lo(ug[mt][nt].x), Elem<H>::hi(ug[mt][nt].x), Elem<H>::lo(ug[mt][nt].y), Elem<H>::hi(ug[mt][nt].y)};
                     float hn[4];
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) hn[r] = (1.f - ug[mt][nt][r]) * o[r] + ug[mt][nt][r] * hv[r];
+                    for (int r = 0; r < 4; ++r) hn[r] = (1.f - uv[r]) * o[r] + uv[r] * hv[r];
                     const uint32_t n0 = Elem<H>::pack2(hn[0], hn[1]), n1 = Elem<H>::pack2(hn[2], hn[3]);
                     *reinterpret_cast<EVE_LDS cg_u32x2_t*>((uintptr_t)ha) = cg_u32x2_t{n0, n1};
                     const size_t go = ((size_t)pg + (size_t)t * CG_PIX) * CG_C + c;
@@ -303,7 +329,7 @@ __global__ __launch_bounds__(256) void cgru_scan_bwd_kernel(const int B, const i
 
     int pix_lds[4], pix_tm[4];
     bool pix_ok[4];
-    int aaddr[9][4];
+    int abase[2][4];
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) {
         const int m = wm * 64 + mt * 16 + li;
@@ -314,11 +340,9 @@ __global__ __launch_bounds__(256) void cgru_scan_bwd_kernel(const int B, const i
         pix_ok[mt] = ok;
         pix_lds[mt] = ((hr0 * 10 + px + 1) << 6) | ((hr0 & 1) << 16);
         pix_tm[mt] = (b0 + ti) * CG_PIX + rem;
+        const int hrt = ti * 7 + py;
 #pragma unroll
-        for (int t = 0; t < 9; ++t) {
-            const int hr = ti * 7 + py + t / 3, hx = px + t % 3;
-            aaddr[t][mt] = ((hr * 10 + hx) << 6) + ((lg ^ ((hr & 1) << 1)) << 4);
-        }
+        for (int q = 0; q < 2; ++q) abase[q][mt] = ((hrt * 10 + px) << 6) + ((lg ^ (((hrt + q) & 1) << 1)) << 4);
     }
     int brow[4];
 #pragma unroll
@@ -356,15 +380,19 @@ __global__ __launch_bounds__(256) void cgru_scan_bwd_kernel(const int B, const i
         f[2] = Elem<H>::lo(q.y); f[3] = Elem<H>::hi(q.y);
     };
 
-    f32x4_t cy[4][4], dxk[4][4];                              // carry (wn = 1 waves), dx_2 (wn = 0 waves)
+    // one register array, two uses that never meet in a wave: the carry of the wn = 1 waves (across frames), dx_2 of the wn = 0
+    // waves (from conv A to the end of the frame)
+    f32x4_t cy[4][4];
+    f32x4_t (&dxk)[4][4] = cy;
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
-        for (int b = 0; b < 4; ++b) { cy[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f}; dxk[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
+        for (int b = 0; b < 4; ++b) cy[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
     issue_pos(0, 0, true);
     issue_pos(1, 1, true);
     issue_pos(2, 2, true);
+    issue_pos(3, 3, true);
     __syncthreads();
 
     uint32_t gs = 0;                                          // stream position (ring phase)
@@ -403,8 +431,8 @@ __global__ __launch_bounds__(256) void cgru_scan_bwd_kernel(const int B, const i
                 }
             }
         }
-        // the weight tile of this frame's first step (issued three steps ago, or in the prologue): loads return in order,
-        // so "at most the two younger tiles outstanding" covers it for every wave, whatever it stored above
+        // the weight tiles of this frame's first TWO steps (issued four / three steps ago, or in the prologue): loads return
+        // in order, so "at most the two younger tiles outstanding" covers them for every wave, whatever it stored above
         asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         __syncthreads();
         f32x4_t acc[4][4];
@@ -415,28 +443,47 @@ __global__ __launch_bounds__(256) void cgru_scan_bwd_kernel(const int B, const i
 #pragma unroll
                 for (int b = 0; b < 4; ++b) acc[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
             const int nsl = conv == 0 ? 2 : 4, base = conv == 0 ? 0 : 18, pl0 = conv == 0 ? 0 : 2;
-            for (int sl = 0; sl < nsl; ++sl, gs += 9) {
-                const uint32_t la = lds0 + (pl0 + sl) * CG_SLICE;
+            // software-pipelined step loop (see cgru_scan_fwd_kernel): step g+1's fragments are read under step g's MFMAs, the
+            // filter ring runs four tiles ahead, no pipelining across the conv A -> conv B and frame boundaries
+            uint4 fxA[4], fwA[4], fxB[4], fwB[4];
+            auto load = [&](int sl, int tap, uint32_t gpos, uint4 (&fx)[4], uint4 (&fw)[4]) {
+                const uint32_t la = lds0 + (pl0 + sl) * CG_SLICE, lb = ldsB + (gpos & 3) * CG_BSLOT;
 #pragma unroll
-                for (int tap = 0; tap < 9; ++tap) {
-                    int npos = base + sl * 9 + tap + 3;       // weight tile of stream position +3
-                    bool live = true;
-                    if (npos >= 54) { npos -= 54; live = more_t; }
-                    issue_pos(npos, (int)((gs + tap + 3) & 3), live);
-                    const uint32_t lb = ldsB + ((gs + tap) & 3) * CG_BSLOT;
-                    uint4 fx[4], fw[4];
+                for (int mt = 0; mt < 4; ++mt)
+                    fx[mt] = __builtin_bit_cast(uint4, *reinterpret_cast<const EVE_LDS cg_u32x4_t*>((uintptr_t)(la + abase[(tap / 3) & 1][mt] + ((tap / 3) * 10 + tap % 3) * 64)));
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt)
+                    fw[nt] = __builtin_bit_cast(uint4, *reinterpret_cast<const EVE_LDS cg_u32x4_t*>((uintptr_t)(lb + brow[nt])));
+            };
+            auto mma = [&](const uint4 (&fx)[4], const uint4 (&fw)[4]) {
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
                     for (int mt = 0; mt < 4; ++mt)
-                        fx[mt] = __builtin_bit_cast(uint4, *reinterpret_cast<const EVE_LDS cg_u32x4_t*>((uintptr_t)(la + aaddr[tap][mt])));
+                        Elem<H>::mfma(acc[mt][nt], fw[nt], fx[mt]);
+            };
+            load(0, 0, gs, fxA, fwA);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // every wave is done with this tile's slot before step 0 refills it
+            __syncthreads();
+            for (int sl = 0; sl < nsl; sl += 2, gs += 18) {
 #pragma unroll
-                    for (int nt = 0; nt < 4; ++nt)
-                        fw[nt] = __builtin_bit_cast(uint4, *reinterpret_cast<const EVE_LDS cg_u32x4_t*>((uintptr_t)(lb + brow[nt])));
-#pragma unroll
-                    for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-                        for (int mt = 0; mt < 4; ++mt)
-                            Elem<H>::mfma(acc[mt][nt], fw[nt], fx[mt]);
-                    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // tile of the next step (issued 2 steps ago) landed
+                for (int i = 0; i < 18; ++i) {
+                    const int s_ = sl + i / 9, tap = i % 9;
+                    int npos = base + s_ * 9 + tap + 4;       // weight tile of stream position +4
+                    bool live = true;
+                    if (npos >= 54) { npos -= 54; live = more_t; }
+                    issue_pos(npos, (int)((gs + i + 4) & 3), live);
+                    const bool has_next = i < 17 || sl + 2 < nsl;
+                    if (has_next) {
+                        if (i & 1) load(s_ + (tap + 1) / 9, (tap + 1) % 9, gs + i + 1, fxA, fwA);
+                        else       load(s_ + (tap + 1) / 9, (tap + 1) % 9, gs + i + 1, fxB, fwB);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);            // the reads above are issued BEFORE the MFMAs (hipcc would sink them)
+                    if (i & 1) mma(fxB, fwB);
+                    else       mma(fxA, fwA);
+                    __builtin_amdgcn_sched_barrier(0);
+                    // this wave's reads of tile g+1 are complete; tile g+2 (issued 2 steps ago) has landed
+                    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_waitcnt vmcnt(4)" ::: "memory");
                     __syncthreads();
                 }
             }

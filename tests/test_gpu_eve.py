@@ -392,6 +392,62 @@ def test_configs4_long_sequence_large_patches_whole_pipeline(half):
     eve_amd.reset_standalone_config()
 
 
+def _configs4_clip(seed):
+    batch = detweights.eve_batch(1, 120, seed=seed, invalid_fraction=0.1)
+    patches = detweights.eyenet_batch(1, 120, size=256, seed=seed + 1)
+    for k in ('left_eye_patch', 'right_eye_patch'):
+        batch[k] = patches[k]
+    return batch
+
+
+def test_configs4_at_the_bench_batch_runs_the_kernels_the_bench_dispatches_and_equals_the_oracle_checked_clip():
+    """configs[4]'s parity case above is B = 1, and kernel selection depends on the image count (register-
+    resident InstanceNorm on 16-32 Ki-vector planes, the stem weight gradient in chunks below 2 GiB, conv3x3_wg8_kernel<2,4,16>
+    only fill the chip from a few hundred images on).  Clips are independent units (InstanceNorm per frame, recurrences per
+    clip), so: B = 4 x T = 120 x 256 x 256 (960 patches per eye: bench.py's c5 is B = 8) whose clip 0 IS the oracle-checked clip
+    of the B = 1 case -- float32: clip 0's gaze / heat-map PoG equal the B = 1 run to float rounding (1e-5 rad / 0.05 px, hence
+    the oracle to 1e-4); fp16 (what configs[4] names): within the format's envelope of float32; and the data-parallel identity
+    grad(4 clips) = mean of the 4 single-clip gradients for the fp16 train step (both networks trained)."""
+    from eve_amd import train
+    over = dict(refine_net_rnn_type='CGRU', eye_net_load_pretrained=False, eye_net_frozen=False, loss_coeff_g_ang_initial=1.0,
+                loss_coeff_pupil_size=1.0, refine_net_do_offset_augmentation=False)
+    clips = [_configs4_clip(41 + 2 * i) for i in range(4)]
+    full = {k: (torch.cat([c[k] for c in clips], dim=0) if torch.is_tensor(clips[0][k]) else clips[0][k]) for k in clips[0]}
+    keys = ('g_initial', 'g_final', 'PoG_px_final')
+
+    def forward(dt, batch):
+        model = make_eve(over, dtype=dt)
+        with torch.no_grad():
+            model.eval()
+            got = model({k: (v.cuda() if torch.is_tensor(v) else v) for k, v in batch.items()}, current_epoch=0.0)
+        return {k: got[k].detach().float().cpu() for k in keys}
+    one = _CONFIGS4.get('f32') or forward(torch.float32, clips[0])
+    four = forward(torch.float32, full)
+    for k in ('g_initial', 'g_final'):
+        assert float((four[k][:1] - one[k]).abs().max()) < 1e-5, k
+    assert float((four['PoG_px_final'][:1] - one['PoG_px_final']).abs().max()) < 0.05
+    h16 = forward(torch.float16, full)
+    dev = float((h16['g_initial'] - four['g_initial']).abs().max())
+    print('fp16 gaze vs float32 at B = 4: %.3e rad' % dev)
+    assert dev < 0.02
+
+    def grads(batch):
+        model = make_eve(over, dtype=torch.float16)
+        tr = train.eve_trainer(model.train(), eve_amd.get_config())
+        tr.fp.grad.zero_()
+        terms = tr._forward_backward({k: (v.cuda() if torch.is_tensor(v) else v) for k, v in batch.items()})
+        torch.cuda.synchronize()
+        assert bool(torch.isfinite(terms['full_loss']).all())
+        return tr.fp.grad.detach().float().clone() / tr.loss_scale
+    whole = grads(full)
+    parts = sum(grads(c) for c in clips) / 4.0
+    assert bool(torch.isfinite(whole).all()) and float(whole.abs().max()) > 0
+    rel = float((whole - parts).norm() / parts.norm())
+    print('fp16 grad(4 clips) vs mean of single-clip gradients: %.3e' % rel)
+    assert rel < 2e-2, rel
+    eve_amd.reset_standalone_config()
+
+
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16], ids=['fp32', 'bf16'])
 def test_eve_trainer_hipgraph_replay_equals_eager_steps(dtype):
     """configs[2] through train.eve_trainer(use_graph=True): the whole step (label synthesis, offset augmentation, frozen
