@@ -48,6 +48,12 @@ class PackItem(Structure):
                 ('Cout', c_int), ('taps', c_int), ('Cin', c_int)]
 
 
+class VecTerm(Structure):
+    """include/eve_hip.h eve_vec_term"""
+    _fields_ = [('pred', c_void_p), ('tgt', c_void_p), ('valid', c_void_p), ('dpred', c_void_p), ('D', c_int), ('kind', c_int)]
+
+
+VEC_TERMS_MAX = 32
 PACK_BATCH_MAX = 48
 ABI_VERSION = 7          # include/eve_hip.h EVE_ABI_VERSION
 
@@ -71,6 +77,7 @@ SIGNATURES = {
     'eve_bias_grad': [I, L, I, P, P, P],
     'eve_cgru_scan_fwd': [I, I, I, P, P, P, P, P, P, P, P, P, P, P, P],
     'eve_cgru_scan_bwd': [I, I, I, P, P, P, P, P, P, P, P, P, P, P, P],
+    'eve_vector_terms': [POINTER(VecTerm), I, I, I, P, P],
     'eve_gate_signal': [P, P],
     'eve_gate_wait': [P, c_uint, P, P],
     'eve_crnn_scan_fwd': [I, I, P, P, P, P, P, P, P],

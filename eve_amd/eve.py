@@ -300,10 +300,25 @@ class EVE(nn.Module):
         augment = self.training and cfg.refine_net_do_offset_augmentation
         un = '_unaugmented' if augment else ''
 
+        # the [B, T, D <= 3] terms are collected and evaluated by ONE kernel launch (ops.VectorTermsFn); heat-map terms, CPU
+        # tensors and Euclidean terms that would need a gradient keep their own path
+        batched = []
+        kinds = {losses.mse_loss: 'mse', losses.euclidean_loss: 'euclidean', losses.l1_loss: 'l1', losses.angular_loss: 'angular'}
+
         def term(name, fn, interm_key, input_key, ref=None):
             ref = d if ref is None else ref
             if interm_key in inter and input_key in ref:
-                out[name] = fn(inter[interm_key], ref[input_key], ref[input_key + '_validity'])
+                pred, tgt, val = inter[interm_key], ref[input_key], ref[input_key + '_validity']
+                kind = kinds.get(fn)
+                if (kind is not None and pred.is_cuda and pred.dim() <= 3 and pred.dtype == torch.float32 and
+                        tgt.dtype == torch.float32 and tuple(tgt.shape) == tuple(pred.shape) and not tgt.requires_grad and
+                        (pred.dim() == 2 or pred.shape[2] <= 3) and not (kind == 'euclidean' and pred.requires_grad and
+                                                                          torch.is_grad_enabled()) and
+                        hasattr(default_kernels(), 'vector_terms')):
+                    out[name] = None                         # (keeps the reference's key order)
+                    batched.append((name, kind, pred, tgt, val))
+                else:
+                    out[name] = fn(pred, tgt, val)
 
         for side in ('left', 'right'):
             term('loss_ang_%s_g_initial' % side, losses.angular_loss, '%s_g_initial%s' % (side, un), side + '_g_tobii')
@@ -328,6 +343,10 @@ class EVE(nn.Module):
             term('loss_mse_PoG_cm_' + stage, losses.mse_loss, 'PoG_cm_' + stage, 'PoG_cm_tobii')
             term('metric_euc_PoG_cm_' + stage, losses.euclidean_loss, 'PoG_cm_' + stage, 'PoG_cm_tobii')
             term('metric_ang_g_' + stage, losses.angular_loss, 'g_' + stage, 'g')
+        if batched:
+            vals = ops.VectorTermsFn.apply(tuple((kind, tgt, val) for _, kind, _, tgt, val in batched), *[b[2] for b in batched])
+            for (name, _, _, _, _), v in zip(batched, vals):
+                out[name] = v
 
     def _full_loss(self, out, device):                                # eve.py:234-265
         cfg = self.config

@@ -1054,6 +1054,33 @@ class HipKernels(object):
         return h, c
 
     # ------------------------------------------------------------------ optimiser
+    # ------------------------------------------------------------------ masked [B, T, D] loss / metric terms, batched
+    VEC_KINDS = {'mse': 0, 'euclidean': 1, 'l1': 2, 'angular': 3}
+
+    def vector_terms(self, items, want_grad):
+        """items: list of (kind, pred [B, T(, D)], target, validity [B, T]) float32 / bool on the GPU; want_grad: per item, whether
+        d term / d pred is wanted (not for 'euclidean').  ONE launch per 32 terms -> (out [n] float32, [dpred or None])."""
+        B, T = items[0][3].shape
+        dev = items[0][1].device
+        out = torch.empty((len(items),), dtype=torch.float32, device=dev)
+        keep, dps, recs = [], [], []
+        for (kind, pred, tgt, val), wg in zip(items, want_grad):
+            D = 1 if pred.dim() == 2 else pred.shape[2]
+            pred, tgt = pred.contiguous(), tgt.contiguous()
+            val = val.contiguous()
+            val = val.view(torch.uint8) if val.dtype == torch.bool else val.to(torch.uint8)
+            assert pred.dtype == tgt.dtype == torch.float32 and tuple(pred.shape) == tuple(tgt.shape) and tuple(val.shape) == (B, T)
+            assert tuple(pred.shape[:2]) == (B, T) and 1 <= D <= 3 and pred.dim() <= 3
+            dp = torch.empty_like(pred) if wg else None
+            keep.append((pred, tgt, val))
+            dps.append(dp)
+            recs.append(_lib.VecTerm(self._p(pred), self._p(tgt), self._p(val), self._p(dp), D, self.VEC_KINDS[kind]))
+        for i in range(0, len(recs), _lib.VEC_TERMS_MAX):
+            chunk = recs[i:i + _lib.VEC_TERMS_MAX]
+            arr = (_lib.VecTerm * len(chunk))(*chunk)
+            self._ck(self.lib.eve_vector_terms(arr, len(chunk), B, T, ctypes.c_void_p(out.data_ptr() + 4 * i), self._stream()))
+        return out, dps
+
     # ------------------------------------------------------------------ stream gates (parallel.GradSync)
     def gate_signal(self, flags, index):
         """One-thread kernel on the current stream (capturable): release, then flags[index] += 1."""

@@ -1291,6 +1291,34 @@ class CGRUGates2Fn(torch.autograd.Function):
         return dg2, dru, dh
 
 
+class VectorTermsFn(torch.autograd.Function):
+    """The validity-masked [B, T, D <= 3] loss / metric terms of EVE.calculate_losses_and_metrics (eve.py:286-439) in one launch
+    (kernels.vector_terms).  apply(spec, *preds): spec = tuple of (kind, target, validity) per prediction; returns one scalar per
+    term.  Gradients w.r.t. the predictions for 'mse', 'l1', 'angular' (the caller keeps 'euclidean' terms whose prediction
+    requires a gradient on the tensor-expression path)."""
+
+    @staticmethod
+    def forward(ctx, spec, *preds):
+        k = default_kernels()
+        need = [bool(n) for n in ctx.needs_input_grad[1:]]
+        items = [(kind, p.detach(), tgt, val) for (kind, tgt, val), p in zip(spec, preds)]
+        out, dps = k.vector_terms(items, need)
+        ctx.set_materialize_grads(False)
+        ctx.n = len(preds)
+        ctx.has = [d is not None for d in dps]
+        ctx.save_for_backward(*[d for d in dps if d is not None])
+        return tuple(out.unbind(0))
+
+    @staticmethod
+    def backward(ctx, *grads):
+        saved = iter(ctx.saved_tensors)
+        res = [None]
+        for i in range(ctx.n):
+            d = next(saved) if ctx.has[i] else None
+            res.append(d * grads[i] if (d is not None and grads[i] is not None) else None)
+        return tuple(res)
+
+
 # ---- gaze geometry / heat-maps / soft-argmax around the two networks (kernels in csrc/gaze_geometry.hip) -------------
 class GazeToPoGFn(torch.autograd.Function):
     """(g_out, PoG_mm, PoG_px) of a flat batch of frames: to_screen_coordinates (models/common.py:157-187), after

@@ -101,16 +101,22 @@ class GradSync(object):
     # gate-wait kernel for the bucket's word of THIS replay (value = replay count; bounded poll), then the all-reduce is
     # issued eagerly behind it -- it starts as soon as the replay passes the bucket's last gradient, under the rest of
     # the backward, exactly like the eager mode's notifications.  The RCCL calls themselves stay ordinary eager calls.
-    def begin_marks(self):
-        self.start_step()
-        self._marking = True
-        self._gated = []
+    def prepare_marks(self):
+        """Allocate the gate words.  Call BEFORE the capture begins: an allocation inside the capture would come from the graph's
+        private pool and its zero-fill would become a node of the graph -- every replay would then reset the words it is
+        supposed to count up (seen as every gate timing out from the second replay on)."""
         if self.flat_grad.is_cuda:
             if self._comm is None:
                 self._comm = torch.cuda.Stream(device=self.flat_grad.device)
             self._flags = torch.zeros((len(self.buckets) + 1,), dtype=torch.int32, device=self.flat_grad.device)
             self._timeouts = torch.zeros((1,), dtype=torch.int32, device=self.flat_grad.device)
             self._replays = 0
+
+    def begin_marks(self):
+        assert self._flags is not None or not self.flat_grad.is_cuda, 'prepare_marks() before the capture'
+        self.start_step()
+        self._marking = True
+        self._gated = []
 
     def end_marks(self):
         self._marking = False

@@ -216,6 +216,9 @@ class Trainer(object):
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self._graph = torch.cuda.CUDAGraph()
+        if self.sync is not None and not self.graph_collectives:
+            self.sync.prepare_marks()                          # gate words: allocated and zeroed OUTSIDE the capture
+            torch.cuda.synchronize()
         # with a process group alive, its watchdog THREAD polls the events of the warm-up collectives (hipEventQuery): under the
         # default 'global' capture mode any such call from another thread while this one captures is an error that takes the
         # process down -- seen as a rare crash of the one-rank RCCL tests (c10d::ProcessGroupNCCL::Watchdog, HIPEvent query).

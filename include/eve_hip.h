@@ -200,6 +200,14 @@ int eve_eye_losses(int B, int T, const float* const* g_pred, const float* const*
                    const float* const* p_pred, const float* const* p_tgt, const uint8_t* const* p_val,
                    float coeff_ang, float coeff_l1, float* terms, float* const* dg, float* const* dp,
                    eve_stream_t stream);
+/* Every validity-masked term of EVE.calculate_losses_and_metrics over [B][T][D <= 3] predictions (eve.py:286-439: the gaze /
+ * PoG / pupil losses and metrics; src/losses/{mse,euclidean,l1,angular}.py with the clip reduction of
+ * base_loss_with_validity.py:64-73) in ONE launch (ABI v7).  terms[i]: pred, tgt [B][T][D] float, valid [B][T] bytes, kind
+ * 0 MSE | 1 Euclidean distance | 2 L1 | 3 angular error in degrees (D = 2: pitch, yaw), dpred = NULL or [B][T][D] <-
+ * d term_i / d pred for a unit upstream gradient (kinds 0, 2, 3).  out[i] = term i.  n <= EVE_VEC_TERMS_MAX.                */
+#define EVE_VEC_TERMS_MAX 32
+typedef struct eve_vec_term { const float* pred; const float* tgt; const unsigned char* valid; float* dpred; int D; int kind; } eve_vec_term;
+int eve_vector_terms(const eve_vec_term* terms, int n, int B, int T, float* out, eve_stream_t stream);
 /* ------------------------------------------------------------------------------------------------
  * Gaze geometry, heat-maps and soft-argmax: the per-frame glue of EVE.forward either side of the two networks
  * (eve.py:114-166, 545-601).  Flat batches of N = B*T frames, float32, row-major small matrices.

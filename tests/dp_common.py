@@ -116,6 +116,7 @@ def worker(rank, world, port, tmp, case, device, dtype, use_graph, backend='gloo
     if device != 'cpu':
         torch.cuda.synchronize()
     assert all(c == 1 for c in tr.sync.launch_counts), tr.sync.launch_counts        # every bucket exactly once per step
+    assert tr.sync.gate_timeouts() == 0, 'a gate of the replay never opened (the collective ran after the time-out)'
     torch.save({'flat': tr.fp.flat.cpu().clone(), 'grad': tr.fp.grad.cpu().clone(), 'loss': float(terms['full_loss'].detach()),
                 'buckets': len(tr.sync.buckets)}, os.path.join(tmp, 'rank%d.pt' % rank))
     dist.barrier()
@@ -145,6 +146,7 @@ def worker_rccl(rank, port, tmp, case, dtype, use_graph, steps):
         terms = tr.step(batch)
     torch.cuda.synchronize()
     assert all(c == 1 for c in tr.sync.launch_counts), tr.sync.launch_counts
+    assert tr.sync.gate_timeouts() == 0, 'a gate of the replay never opened (the collective ran after the time-out)'
     torch.save({'flat': tr.fp.flat.cpu().clone(), 'grad': tr.fp.grad.cpu().clone(), 'loss': float(terms['full_loss'].detach()),
                 'buckets': len(tr.sync.buckets)}, os.path.join(tmp, 'rccl.pt'))
     dist.barrier()

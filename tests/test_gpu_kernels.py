@@ -1111,3 +1111,48 @@ torch.save((outs, names, s2_outs, s2_names), sys.argv[1])
     for i, (a, b) in enumerate(zip(res['2'][2], res['0'][2])):
         tol = 2.5e-3 if i < 8 else 3e-4
         assert float((a - b).norm() / b.norm()) < tol and float((a - b).abs().max()) <= 8 * tol * float(b.abs().max()), ('s2', i)
+
+
+@pytest.mark.parametrize('B,T', [(2, 4), (7, 30), (32, 120), (3, 1)])
+def test_batched_vector_terms_match_the_tensor_expressions(B, T):
+    """Round 5: eve_vector_terms (every masked [B, T, D <= 3] loss / metric of eve.py:286-439 in one launch, ops.VectorTermsFn)
+    against the tensor expressions of eve_amd/losses.py it replaces (themselves pinned by the reference's golden scalars):
+    MSE, Euclidean, L1 (D = 1, 2, 3) and the angular error, clips with 0 / 1 / several valid steps, values and gradients."""
+    from eve_amd import losses, ops
+    g = torch.Generator().manual_seed(5)
+    dev = 'cuda'
+    items, fns = [], []
+    for kind, fn, D in (('mse', losses.mse_loss, 2), ('mse', losses.mse_loss, 3), ('euclidean', losses.euclidean_loss, 2),
+                        ('l1', losses.l1_loss, 1), ('l1', losses.l1_loss, 2), ('angular', losses.angular_loss, 2),
+                        ('angular', losses.angular_loss, 2)):
+        shape = (B, T) if (D == 1 and kind == 'l1') else (B, T, D)
+        scale = 0.4 if kind == 'angular' else 30.0
+        pred = (torch.randn(shape, generator=g) * scale).to(dev).requires_grad_(kind != 'euclidean')
+        tgt = (torch.randn(shape, generator=g) * scale).to(dev)
+        val = (torch.rand((B, T), generator=g) < 0.7).to(dev)
+        val[0] = False                                   # a clip without a valid step
+        if B > 1:
+            val[1] = False
+            val[1, 0] = True                             # exactly one valid step: not divided by the count
+        items.append((kind, pred, tgt, val))
+        fns.append(fn)
+    if T > 2:                                            # identical vectors: cos = 1, the clamp's zero-gradient branch
+        with torch.no_grad():
+            items[-1][1][:, 2] = items[-1][2][:, 2]
+    got = ops.VectorTermsFn.apply(tuple((k_, t_, v_) for k_, _, t_, v_ in items), *[it[1] for it in items])
+    weights = [float(i + 1) for i in range(len(items))]
+    sum(w * v for w, v in zip(weights, got) if v.requires_grad).backward()
+    mine = [None if it[1].grad is None else it[1].grad.clone() for it in items]
+    for (kind, pred, tgt, val), fn, gv, w, gm in zip(items, fns, got, weights, mine):
+        p2 = pred.detach().clone().requires_grad_(True)
+        want = fn(p2, tgt, val)
+        assert abs(float(gv) - float(want)) <= 2e-5 * max(1.0, abs(float(want))), (kind, float(gv), float(want))
+        if kind != 'euclidean':
+            (w * want).backward()
+            ref = p2.grad
+            if kind == 'angular':                        # torch's acos / cosine_similarity backward is NaN-prone at cos = +-1
+                ok = torch.isfinite(ref).all(dim=-1)
+                assert float((gm - ref)[ok].abs().max()) <= 2e-3 * float(ref[ok].abs().max()) + 1e-6
+                assert bool(torch.isfinite(gm).all())
+            else:
+                assert float((gm - ref).abs().max()) <= 2e-5 * float(ref.abs().max()) + 1e-7, kind

@@ -1,0 +1,22 @@
+#!/bin/bash
+# round-5 fourth GPU call: DP gate fix, batched vector terms, per-kernel view of the c3 / c5 steps
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+O=$R/gpurun_out/r5d
+rm -rf $O; mkdir -p $O
+cd $R
+timeout 900 python -m pytest tests/test_gpu_data_parallel.py tests/test_gpu_kernels.py tests/test_gpu_eve.py -m gpu -q -x --timeout 800 -k "hipgraph or rccl or gate or vector_terms or golden or float64 or configs4" 2>&1 | tail -15 > $O/pytest.log
+tail -6 $O/pytest.log
+Q="--no-cpu-baseline --no-c3 --no-c5 --no-points --no-roofline"
+line() { python -c "import sys,json; d=json.loads([l for l in sys.stdin if l.startswith('{')][0]); print('$1', round(d['value']), 'frames/s', round(d['ms_per_step'],3), 'ms', 'gate_timeouts', d.get('gate_timeouts'))"; }
+PORT=29717
+for b in 8 32; do for mode in "--no-graph" "" "--graph-collectives"; do
+  EVE_AMD_FORCE_DIST=1 RANK=0 LOCAL_RANK=0 WORLD_SIZE=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=$((PORT=PORT+1)) timeout 300 python bench.py --batch $b $mode $Q 2>>$O/err.log | line "rccl1 B=$b mode=[$mode]" >> $O/sweep.txt
+done; done
+for w in c3 c5; do python bench.py --workload $w --steps 5 --warmup 2 --no-cpu-baseline --no-roofline 2>>$O/err.log | line "$w" >> $O/sweep.txt; done
+cd /tmp && export TMPDIR=/tmp
+timeout 600 rocprofv3 --kernel-trace --stats -d $O/prof_c5 -o c --output-format csv -- python $R/bench.py --workload c5 --steps 2 --warmup 1 --no-cpu-baseline --no-roofline > $O/c5_profiled.log 2>&1
+cp $(find $O/prof_c5 -name "*kernel_stats.csv" | head -1) $O/c5_kernel_stats.csv; rm -rf $O/prof_c5
+timeout 600 rocprofv3 --kernel-trace --stats -d $O/prof_c3 -o c --output-format csv -- python $R/tools/bench_eve.py --steps 5 > $O/c3_profiled.log 2>&1
+cp $(find $O/prof_c3 -name "*kernel_stats.csv" | head -1) $O/c3_kernel_stats.csv; rm -rf $O/prof_c3
+cd $R
+cat $O/sweep.txt; tail -3 $O/err.log
