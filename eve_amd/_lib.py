@@ -79,7 +79,7 @@ SIGNATURES = {
     'eve_cgru_scan_bwd': [I, I, I, P, P, P, P, P, P, P, P, P, P, P, P],
     'eve_vector_terms': [POINTER(VecTerm), I, I, I, P, P],
     'eve_gate_signal': [P, P],
-    'eve_gate_wait': [P, c_uint, P, P],
+    'eve_gate_wait': [P, c_uint, P, P, P],
     'eve_crnn_scan_fwd': [I, I, P, P, P, P, P, P, P],
     'eve_crnn_scan_bwd': [I, I, P, P, P, P, P, P, P],
     'eve_clstm_scan_fwd': [I, I, P, P, P, P, P, P, P, P],

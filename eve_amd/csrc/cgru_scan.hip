@@ -24,7 +24,13 @@ constexpr int CG_LDS = 6 * CG_SLICE + 4 * CG_BSLOT;
 typedef uint32_t cg_u32x2_t __attribute__((ext_vector_type(2)));
 typedef uint32_t cg_u32x4_t __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ float cg_sigmoid(float z) { return 1.f / (1.f + __expf(-z)); }
+// Gate non-linearities of the 16-bit scan.  The results are rounded to 16 bits on the spot, so one-ulp float building blocks
+// (v_exp_f32, v_rcp_f32) are exact enough -- and the epilogues are where this kernel's time is: per frame a wave runs 72 MFMA
+// steps of ~60 instructions and two epilogues that were ~1 750 + ~3 800 instructions with tanhf and IEEE divisions expanded 64
+// times each (round 5; the float32 scan of cell_scan_f32.hip keeps tanhf / the division).
+__device__ __forceinline__ float cg_sigmoid(float z) { return __builtin_amdgcn_rcpf(1.f + __expf(-z)); }
+// tanh(z) = 1 - 2 / (1 + e^(2z)): saturates correctly (e^(2z) = inf -> 1, 0 -> -1); absolute error ~1e-7
+__device__ __forceinline__ float cg_tanh(float z) { return 1.f - 2.f * __builtin_amdgcn_rcpf(1.f + __expf(2.f * z)); }
 
 template <typename H>
 __global__ __launch_bounds__(256) void cgru_scan_fwd_kernel(const int B, const int T, const H* __restrict__ xs,
@@ -252,8 +258,8 @@ __global__ __launch_bounds__(256) void cgru_scan_fwd_kernel(const int B, const i
                 for (int mt = 0; mt < 4; ++mt) {
                     const int pg = pix_glob[mt];
                     if (pg < 0) continue;
-                    float o[4] = {tanhf(acc[mt][nt][0] + bv.x), tanhf(acc[mt][nt][1] + bv.y), tanhf(acc[mt][nt][2] + bv.z),
-                                  tanhf(acc[mt][nt][3] + bv.w)};
+                    float o[4] = {cg_tanh(acc[mt][nt][0] + bv.x), cg_tanh(acc[mt][nt][1] + bv.y), cg_tanh(acc[mt][nt][2] + bv.z),
+                                  cg_tanh(acc[mt][nt][3] + bv.w)};
                     const uint32_t o0 = Elem<H>::pack2(o[0], o[1]), o1 = Elem<H>::pack2(o[2], o[3]);
                     o[0] = Elem<H>::lo(o0); o[1] = Elem<H>::hi(o0);
                     o[2] = Elem<H>::lo(o1); o[3] = Elem<H>::hi(o1);

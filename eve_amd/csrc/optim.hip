@@ -111,8 +111,9 @@ __global__ void gate_signal_kernel(unsigned* flag) {
     __hip_atomic_fetch_add(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-__global__ void gate_wait_kernel(const unsigned* flag, const unsigned value, unsigned* timeouts) {
+__global__ void gate_wait_kernel(const unsigned* flag, unsigned value, const unsigned* value_ref, unsigned* timeouts) {
     if (threadIdx.x != 0) return;
+    if (value_ref) value = __hip_atomic_load(value_ref, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (written earlier on this stream)
     for (unsigned it = 0; it < (1u << 21); ++it) {
         const unsigned v = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if ((int)(v - value) >= 0) {
@@ -135,9 +136,9 @@ extern "C" int eve_gate_signal(unsigned* flag, eve_stream_t stream) {
     return 0;
 }
 
-extern "C" int eve_gate_wait(const unsigned* flag, unsigned value, unsigned* timeouts, eve_stream_t stream) {
+extern "C" int eve_gate_wait(const unsigned* flag, unsigned value, const unsigned* value_ref, unsigned* timeouts, eve_stream_t stream) {
     if (!flag || !timeouts) return set_error_msg("gate_wait: null pointer");
-    hipLaunchKernelGGL(gate_wait_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, flag, value, timeouts);
+    hipLaunchKernelGGL(gate_wait_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, flag, value, value_ref, timeouts);
     EVE_CHECK_LAUNCH();
     return 0;
 }

@@ -1087,11 +1087,13 @@ class HipKernels(object):
         assert flags.dtype == torch.int32 and flags.is_contiguous() and 0 <= index < flags.numel()
         self._ck(self.lib.eve_gate_signal(ctypes.c_void_p(flags.data_ptr() + 4 * index), self._stream()))
 
-    def gate_wait(self, flags, index, value, timeouts):
-        """One-wave kernel on the current stream that returns once flags[index] has reached `value` (bounded poll: a gate
-        that never opens increments timeouts[0] after a few seconds instead of hanging the device)."""
+    def gate_wait(self, flags, index, value, timeouts, value_index=None):
+        """One-wave kernel on the current stream that returns once flags[index] has reached `value` -- or flags[value_index],
+        read on the device, when value_index is given (a capturable wait: the target is not baked into the node).  Bounded poll:
+        a gate that never opens increments timeouts[0] after a few seconds instead of hanging the device."""
         assert flags.dtype == timeouts.dtype == torch.int32 and 0 <= index < flags.numel()
-        self._ck(self.lib.eve_gate_wait(ctypes.c_void_p(flags.data_ptr() + 4 * index), int(value) & 0xffffffff, self._p(timeouts),
+        ref = None if value_index is None else ctypes.c_void_p(flags.data_ptr() + 4 * value_index)
+        self._ck(self.lib.eve_gate_wait(ctypes.c_void_p(flags.data_ptr() + 4 * index), int(value) & 0xffffffff, ref, self._p(timeouts),
                                         self._stream()))
 
     SUMSQ_WORKSPACE = 1024          # include/eve_hip.h EVE_SUMSQ_WORKSPACE

@@ -235,7 +235,8 @@ class Trainer(object):
                 # forward + backward in the graph, every bucket's ready point as a gate-signal node (csrc/optim.hip)
                 self.sync.begin_marks()
                 self._static_terms = self._forward_backward(self._static_batch)
-                self.sync.end_marks()
+                if self.sync.end_marks():
+                    self._update(1.0 / self.sync.world)       # the join is in the graph: clip + Adam follow it there
             else:
                 self._static_terms = self._forward_backward(self._static_batch)
                 self._update(1.0)
@@ -245,7 +246,9 @@ class Trainer(object):
         self._update(self.sync.finish_step())
 
     def _gated_collective_and_update(self):
-        self._update(self.sync.launch_gated())
+        gscale = self.sync.launch_gated()
+        if gscale is not None:                                 # (None: clip + Adam are nodes of the replay, behind its join)
+            self._update(gscale)
 
     def step(self, batch):
         """One optimiser step.  Returns the loss terms; under use_graph these are the graph's static output tensors

@@ -503,10 +503,13 @@ int eve_linear_wgrad_batch(const eve_wgrad_problem* problems, int n, eve_stream_
  * (north_star: "RCCL all-reduce of gradients ... overlapped with backward"; the reference's backward -> clip -> step sequence is
  * src/core/training.py:489-502).  eve_gate_signal: a one-thread kernel (capturable: it becomes a node of the graph behind the
  * weight-gradient kernel that completes the bucket) that releases and increments *flag.  eve_gate_wait: a one-wave kernel on the
- * OTHER stream that polls *flag until it has reached `value` (the replay count), bounded: after ~seconds it increments
- * *timeouts and returns, so a missing signal cannot hang the device.  flag / timeouts: device words, zeroed by the caller.    */
+ * OTHER stream that polls *flag until it has reached `value` (the replay count) -- or *value_ref when value_ref != NULL: a
+ * device word, which is what lets the wait itself be a node of the graph (the replay's first node counts the replays there, and
+ * the graph's clip + Adam nodes sit behind gate-waits for the "bucket reduced" words the communication stream signals) --
+ * bounded: after ~seconds it increments *timeouts and returns, so a missing signal cannot hang the device.  flag / timeouts /
+ * value_ref: device words, zeroed by the caller.                                                                              */
 int eve_gate_signal(unsigned* flag, eve_stream_t stream);
-int eve_gate_wait(const unsigned* flag, unsigned value, unsigned* timeouts, eve_stream_t stream);
+int eve_gate_wait(const unsigned* flag, unsigned value, const unsigned* value_ref, unsigned* timeouts, eve_stream_t stream);
 
 /* out[0] += sum g^2 (caller zeroes out[0]; take sqrt on the host or in eve_adam_step).  Fixed summation order: the
  * result is bit-reproducible, so data-parallel replicas clip by the identical factor.  workspace: EVE_SUMSQ_WORKSPACE
