@@ -113,6 +113,7 @@ SIGNATURES = {
     'eve_instnorm_fwd_fused': [I, I, I, I, P, P, P, P, I, F, P, P, P, P],
     'eve_instnorm_bwd_fused': [I, I, I, I, P, P, P, P, P, P, P, I, P, P, P, P, P, P],
     'eve_sum_rows': [I, I, P, P, P],
+    'eve_sum_rows_pairs': [I, I, P, P, P, P],
     'eve_act_bwd': [I, L, P, P, I, P, P],
     'eve_add': [I, L, P, P, P, P],
     'eve_maxpool3x3s2_fwd': [I, I, I, I, I, P, P, P, P],

@@ -549,6 +549,27 @@ __global__ __launch_bounds__(256) void sum_rows_kernel(const float* __restrict__
     if (ph == 0 && c < cols) out[c] = (sh[0][threadIdx.x] + sh[1][threadIdx.x]) + (sh[2][threadIdx.x] + sh[3][threadIdx.x]);
 }
 
+// the same reduction for the (d beta, d gamma) PAIRS of an affine InstanceNorm, ADDED straight into the two gradient vectors
+// (the trainer's flat gradient buffer: the autograd route returned two strided views and paid one accumulate launch each)
+__global__ __launch_bounds__(256) void sum_rows_pairs_kernel(const float* __restrict__ in, float* __restrict__ out0,
+                                                             float* __restrict__ out1, int rows, int C) {
+    __shared__ float sh[4][64];
+    const int cols = 2 * C;
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), ph = threadIdx.x >> 6;
+    float s = 0.f;
+    if (c < cols) {
+#pragma unroll 8
+        for (int r = ph; r < rows; r += 4) s += in[(size_t)r * cols + c];
+    }
+    sh[ph][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (ph == 0 && c < cols) {
+        const float v = (sh[0][threadIdx.x] + sh[1][threadIdx.x]) + (sh[2][threadIdx.x] + sh[3][threadIdx.x]);
+        float* const dst = (c & 1) ? out1 + (c >> 1) : out0 + (c >> 1);
+        *dst += v;
+    }
+}
+
 // the activations the two networks use get their own instantiation (no per-element switch), the rest the run-time one
 #define EVE_IN_ACT_DISPATCH(KERNEL, T, TS, GRID, ...)                                                                                   \
     do { switch (act) {                                                                                                                 \
@@ -700,6 +721,13 @@ extern "C" int eve_instnorm_act2_bwd(int dtype, int N, int HW, int C, const void
 extern "C" int eve_sum_rows(int rows, int cols, const float* in, float* out, eve_stream_t stream) {
     if (rows <= 0 || cols <= 0 || !in || !out) return set_error_msg("sum_rows: bad arguments");
     hipLaunchKernelGGL(sum_rows_kernel, dim3((unsigned)((cols + 63) / 64)), dim3(256), 0, (hipStream_t)stream, in, out, rows, cols);
+    EVE_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int eve_sum_rows_pairs(int rows, int C, const float* in, float* out0, float* out1, eve_stream_t stream) {
+    if (rows <= 0 || C <= 0 || !in || !out0 || !out1) return set_error_msg("sum_rows_pairs: bad arguments");
+    hipLaunchKernelGGL(sum_rows_pairs_kernel, dim3((unsigned)((2 * C + 63) / 64)), dim3(256), 0, (hipStream_t)stream, in, out0, out1, rows, C);
     EVE_CHECK_LAUNCH();
     return 0;
 }

@@ -716,6 +716,15 @@ class HipKernels(object):
         self._ck(self.lib.eve_sum_rows(t.shape[0], out.numel(), self._p(t), self._p(out), self._stream()))
         return out
 
+    def sum_rows_pairs(self, sums, out0, out1):
+        """sums [N, C, 2] float32: out0 += sums[:, :, 0].sum(0), out1 += sums[:, :, 1].sum(0), fixed order, in place (contiguous
+        float32 [C] vectors: an affine InstanceNorm's d beta / d gamma inside the flat gradient buffer)."""
+        N, C, two = sums.shape
+        assert two == 2 and sums.dtype == torch.float32 and sums.is_contiguous()
+        for o in (out0, out1):
+            assert o.dtype == torch.float32 and o.is_contiguous() and o.numel() == C
+        self._ck(self.lib.eve_sum_rows_pairs(N, C, self._p(sums), self._p(out0), self._p(out1), self._stream()))
+
     # ------------------------------------------------------------------ element-wise
     def act_bwd(self, dy, y, act):
         dx = torch.empty_like(dy)

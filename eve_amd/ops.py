@@ -13,13 +13,35 @@ from .kernels import (ACT_LEAKY, ACT_NONE, ACT_RELU, ACT_SELU, ACT_SIGMOID, ACT_
                       HALF_DTYPES, default_kernels)
 
 
+class _LazyGroup(object):
+    """(F, grouped filter) of a PackedWeight, the filter built on first use: pair[0] (what _group_ok asks) costs nothing, and the
+    layers the streaming kernels took over never build theirs (each is a cat + fill + gather: 75 launches per configs[2] step
+    when every candidate layer built both of its grouped filters eagerly, round 5)."""
+    __slots__ = ('F', 'ohwi', 'transpose', 'w')
+
+    def __init__(self, F, ohwi, transpose):
+        self.F, self.ohwi, self.transpose, self.w = F, ohwi, transpose, None
+
+    def weights(self):
+        if self.w is None:
+            self.w = pixel_group_weights(self.ohwi, self.F, self.transpose)
+        return self.w
+
+    def __getitem__(self, i):
+        return self.F if i == 0 else self.weights()
+
+    def __iter__(self):
+        yield self.F
+        yield self.weights()
+
+
 class PackedWeight(object):
     """Compute-dtype copies of one conv/linear weight: OHWI for forward/wgrad, IHWO for dgrad.
 
     `param` has the reference's OIHW (or [out, in]) SHAPE; its memory may already be OHWI (the
     flat-parameter harness stores it that way), in which case no permute copy is made."""
 
-    __slots__ = ('ohwi', 'ihwo', 'shape_oihw', 'algo', 'pair_fwd', 'pair_dgrad')
+    __slots__ = ('ohwi', 'ihwo', 'shape_oihw', 'algo', 'pair_fwd', 'pair_dgrad', '_pairs_for')
 
     def __init__(self, param, dtype, cin_pad=None, cout_pad=None, want_ihwo=True, defer=False):
         k = default_kernels()
@@ -35,20 +57,27 @@ class PackedWeight(object):
             w = torch.nn.functional.pad(w, (0, 0, 0, 0, 0, 0, 0, cout_pad - w.shape[0]))
         w = w.contiguous().float()
         self.pair_fwd = self.pair_dgrad = None
+        self._pairs_for = (dtype, param.dim(), want_ihwo)
         if defer:                                     # packed later, together with others (pack_many)
             self.ohwi, self.ihwo = (w, want_ihwo), None
         else:
             self.ohwi, self.ihwo = k.pack_weights(w, dtype, want_ihwo=want_ihwo)
-            if dtype in HALF_DTYPES and w.shape[1] == w.shape[2] and param.dim() == 4:
-                cout_p, cin_p = w.shape[0], w.shape[3]
-                fac = _group_factors(w.shape[1])
-                if cin_p in fac:
-                    self.pair_fwd = (fac[cin_p], pixel_group_weights(self.ohwi, fac[cin_p], False))
-                elif (w.shape[1], cin_p, cout_p) in PAIR_NARROW_OUT:
-                    F = PAIR_NARROW_OUT[(w.shape[1], cin_p, cout_p)]
-                    self.pair_fwd = (F, pixel_group_weights(self.ohwi, F, False))
-                if want_ihwo and cout_p in fac:
-                    self.pair_dgrad = (fac[cout_p], pixel_group_weights(self.ohwi, fac[cout_p], True))
+            self._make_pairs()
+
+    def _make_pairs(self):
+        """Grouped filters (built lazily, see _LazyGroup) of the layers narrow enough to run over pixel groups."""
+        dtype, pdim, want_ihwo = self._pairs_for
+        w = self.ohwi
+        if dtype in HALF_DTYPES and w.shape[1] == w.shape[2] and pdim == 4:
+            cout_p, cin_p = w.shape[0], w.shape[3]
+            fac = _group_factors(w.shape[1])
+            if cin_p in fac:
+                self.pair_fwd = _LazyGroup(fac[cin_p], self.ohwi, False)
+            elif (w.shape[1], cin_p, cout_p) in PAIR_NARROW_OUT:
+                F = PAIR_NARROW_OUT[(w.shape[1], cin_p, cout_p)]
+                self.pair_fwd = _LazyGroup(F, self.ohwi, False)
+            if want_ihwo and cout_p in fac:
+                self.pair_dgrad = _LazyGroup(fac[cout_p], self.ohwi, True)
 
     @staticmethod
     def pack_many(packs, dtype):
@@ -59,6 +88,7 @@ class PackedWeight(object):
         res = default_kernels().pack_weights_batch([p.ohwi[0] for p in todo], dtype, [p.ohwi[1] for p in todo])
         for p, (ohwi, ihwo) in zip(todo, res):
             p.ohwi, p.ihwo = ohwi, ihwo
+            p._make_pairs()
 
 
 # ---- 3x3 / stride 1 / pad 1 convolutions over 8- or 16-channel tensors (RefineNet's 72x128 level, refine_net.py:
@@ -758,6 +788,21 @@ class ResNetTrunkFn(torch.autograd.Function):
         return (dx, None, None, None, None) + tuple(grads)
 
 
+def _affine_grads(k, sums, gamma_p, beta_p):
+    """(d gamma, d beta) of an affine InstanceNorm from the backward kernel's per-plane partials `sums` [N, C, 2] = (d beta, d
+    gamma): added in place into the flat gradient buffer when both parameters live there (-> (None, None); the autograd
+    route returned two strided views and paid one accumulate launch per parameter: ~80 launches per configs[2] step), else two
+    fresh vectors for autograd."""
+    if (gamma_p is not None and beta_p is not None and _direct_grad_ok(gamma_p) and _direct_grad_ok(beta_p) and
+            hasattr(k, 'sum_rows_pairs') and sums.dim() == 3 and gamma_p.grad.is_contiguous() and beta_p.grad.is_contiguous()):
+        k.sum_rows_pairs(sums, beta_p.grad, gamma_p.grad)
+        _notify_grad_ready(gamma_p)
+        _notify_grad_ready(beta_p)
+        return None, None
+    s = k.sum_rows(sums)                # [C, 2]: N-reduction of the per-plane partials, fixed order
+    return s[:, 1], s[:, 0]
+
+
 class InstNormActFn(torch.autograd.Function):
     """y = act(gamma * IN(x) + beta + res);  gamma/beta/res optional.  eps 1e-5, biased variance."""
 
@@ -773,6 +818,7 @@ class InstNormActFn(torch.autograd.Function):
             mr = k.instnorm_stats(x, eps)
             y = k.instnorm_act_fwd(x, mr, g, b, res, act)
         ctx.act, ctx.has_res, ctx.has_affine = act, res is not None, gamma is not None
+        ctx.affine_params = (gamma, beta)
         # the backward needs y only to evaluate act'; without a residual it recomputes that from x (the register-resident
         # kernel does so only when there is no affine either)
         need_y = act != ACT_NONE and res is not None       # (else both backward kernels recompute act' from x: gamma / beta given)
@@ -790,8 +836,7 @@ class InstNormActFn(torch.autograd.Function):
         dx, dres, sums = out
         dgamma = dbeta = None
         if ctx.has_affine:
-            s = k.sum_rows(sums)                # [C, 2]: N-reduction of the per-plane partials, fixed order
-            dbeta, dgamma = s[:, 0], s[:, 1]
+            dgamma, dbeta = _affine_grads(k, sums, *ctx.affine_params)
         return dx, dgamma, dbeta, dres, None, None
 
 
@@ -816,6 +861,7 @@ class InstNormActSkipFn(torch.autograd.Function):
             mr = k.instnorm_stats(x, eps)
             y = k.instnorm_act_fwd(x, mr, g, b, None, act)
         ctx.act = act
+        ctx.affine_params = (gamma, beta)
         ctx.save_for_backward(x, mr, g, b)
         return y, x.view_as(x)
 
@@ -830,8 +876,8 @@ class InstNormActSkipFn(torch.autograd.Function):
         if out is None:
             out = k.instnorm_act_bwd(dy.contiguous(), None, x, mr, g, ctx.act, False, beta=b, dx_add=add)
         dx, _, sums = out
-        s = k.sum_rows(sums)
-        return dx, s[:, 1], s[:, 0], None, None
+        dgamma, dbeta = _affine_grads(k, sums, *ctx.affine_params)
+        return dx, dgamma, dbeta, None, None
 
 
 class InstNormAct2Fn(torch.autograd.Function):
@@ -853,6 +899,7 @@ class InstNormAct2Fn(torch.autograd.Function):
         mrs = [k.instnorm_stats(x, eps) for x in xs]
         out_a, out_b = k.instnorm_act2_fwd(xs, mrs, ga, ba, gb, bb, act)      # both sources, both heads: one launch
         ctx.act, ctx.n = act, len(xs)
+        ctx.affine_params = (gamma_a, beta_a, gamma_b, beta_b)
         ctx.save_for_backward(ga, ba, gb, bb, *xs, *mrs)
         return out_a, out_b
 
@@ -866,8 +913,10 @@ class InstNormAct2Fn(torch.autograd.Function):
             d_a = d_a if d_a is not None else torch.zeros_like(ref)
             d_b = d_b if d_b is not None else torch.zeros_like(ref)
         dxs, sa, sb = k.instnorm_act2_bwd(d_a.contiguous(), d_b.contiguous(), xs, mrs, ga, ba, gb, bb, ctx.act)
-        sa, sb = k.sum_rows(sa), k.sum_rows(sb)         # [C, 2]: N-reduction of the per-plane partials, fixed order
-        return (None, None, sa[:, 1], sa[:, 0], sb[:, 1], sb[:, 0]) + tuple(dxs)
+        pa, pb = ctx.affine_params[:2], ctx.affine_params[2:]
+        dga, dba = _affine_grads(k, sa, *pa)
+        dgb, dbb = _affine_grads(k, sb, *pb)
+        return (None, None, dga, dba, dgb, dbb) + tuple(dxs)
 
 
 def instnorm_act2(xs, gamma_a, beta_a, gamma_b, beta_b, act, eps=1e-5):

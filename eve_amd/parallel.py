@@ -72,7 +72,6 @@ class GradSync(object):
         self._flags = None           # one gate word per bucket (device int32), incremented once per replay by the bucket's node
         self._timeouts = None
         self._replays = 0
-        self._joined = False         # the graph also holds the join (gate-waits for "bucket reduced") and clip + Adam
         self.launch_counts = []
         # a one-rank group has nothing to exchange; EVE_AMD_FORCE_DIST=1 runs the collectives anyway (transport test)
         self.active = self.world > 1 or (dist.is_initialized() and os.environ.get('EVE_AMD_FORCE_DIST', '0') == '1')
@@ -102,82 +101,68 @@ class GradSync(object):
     # gate-wait kernel for the bucket's word of THIS replay (value = replay count; bounded poll), then the all-reduce is
     # issued eagerly behind it -- it starts as soon as the replay passes the bucket's last gradient, under the rest of
     # the backward, exactly like the eager mode's notifications.  The RCCL calls themselves stay ordinary eager calls.
-    # Round 5, second half: the JOIN is in the graph as well.  When every bucket reported during the capture, end_marks() appends
-    # one gate-wait node per bucket for a second word, "bucket k reduced" (target = the replay counter, a device word the
-    # graph's first node increments), and the trainer captures clip + Adam behind them: one replay is the whole step again and
-    # nothing is launched eagerly behind it except the collectives, each followed on the communication stream by the signal
-    # of its "reduced" word.  (With the join outside, every step ended in cross-queue event waits and eager clip / Adam launches:
-    # 0.2 ms of a 4.2 ms step on a one-rank RCCL group.)
+    # The gate-wait kernels SPIN, so the stream they run on must not share a hardware queue with the streams they wait for (the
+    # HIP runtime multiplexes streams onto a few hardware queues; a spinning kernel at the head of a queue blocks whatever else
+    # was mapped onto it until its bounded poll gives up).  The communication stream is therefore created with HIGH priority:
+    # ROCm keeps separate queues per priority level, the replay and RCCL's own stream are normal-priority.  For the same reason
+    # the JOIN stays outside the graph: gate-wait nodes inside the replay, waiting for "bucket reduced" words, were built and
+    # measured (round 5) -- RCCL's internal stream shared the replay's queue on the test box and every join ran into its
+    # time-out.  Behind the replay the main stream waits ONCE for the communication stream (which has waited for every
+    # collective) and replays a second small graph holding clip + Adam.
     def prepare_marks(self):
         """Allocate the gate words.  Call BEFORE the capture begins: an allocation inside the capture would come from the graph's
         private pool and its zero-fill would become a node of the graph -- every replay would then reset the words it is
         supposed to count up (seen as every gate timing out from the second replay on)."""
         if self.flat_grad.is_cuda:
             if self._comm is None:
-                self._comm = torch.cuda.Stream(device=self.flat_grad.device)
-            nb = len(self.buckets)
-            # words: [0, nb) "bucket ready", [nb, 2 nb) "bucket reduced", 2 nb = replay counter
-            self._flags = torch.zeros((2 * nb + 1,), dtype=torch.int32, device=self.flat_grad.device)
+                self._comm = torch.cuda.Stream(device=self.flat_grad.device, priority=int(os.environ.get('EVE_AMD_COMM_PRIORITY', '0')))
+            self._flags = torch.zeros((len(self.buckets) + 1,), dtype=torch.int32, device=self.flat_grad.device)
             self._timeouts = torch.zeros((1,), dtype=torch.int32, device=self.flat_grad.device)
             self._replays = 0
-            self._joined = False
 
     def begin_marks(self):
         assert self._flags is not None or not self.flat_grad.is_cuda, 'prepare_marks() before the capture'
         self.start_step()
         self._marking = True
         self._gated = []
-        if self._flags is not None:
-            from .kernels import default_kernels
-            default_kernels().gate_signal(self._flags, 2 * len(self.buckets))          # first node: count this replay
 
-    def end_marks(self, join=True):
-        """End of the captured backward.  Returns True when the join was captured too (gate-wait nodes for every bucket's
-        "reduced" word): the caller then captures clip + Adam behind it and launch_gated() leaves nothing to wait for."""
+    def end_marks(self):
         self._marking = False
         self._armed = False
-        nonempty = [b for b in self.buckets if b['hi'] > b['lo']]
-        self._joined = bool(join and self.active and self._flags is not None and len(self._gated) == len(nonempty))
-        if self._joined:
-            from .kernels import default_kernels
-            k, nb = default_kernels(), len(self.buckets)
-            for b in self._gated:
-                k.gate_wait(self._flags, nb + self.buckets.index(b), 0, self._timeouts, value_index=2 * nb)
-        return self._joined
 
     def launch_gated(self):
         """Issue this step's all-reduces behind a replay whose ready points were captured by begin_marks(); buckets that
-        never reported (parameters without a gradient) follow the whole replay.  Returns like finish_step(), or None when the
-        join is part of the graph (clip + Adam already follow the collectives inside the replay)."""
+        never reported (parameters without a gradient) follow the whole replay.  Returns like finish_step()."""
         self.start_step()
         self._armed = False
         if self.active:
             from .kernels import default_kernels
             k = default_kernels()
             main = torch.cuda.current_stream()
-            nb = len(self.buckets)
             self._replays += 1
-            for b in self._gated:
-                with torch.cuda.stream(self._comm):
+            with torch.cuda.stream(self._comm):
+                for b in self._gated:
                     if self._flags is not None:
                         k.gate_wait(self._flags, self.buckets.index(b), self._replays, self._timeouts)
                     self._launch(b)
-                    if self._joined:
-                        self._handles.pop().wait()       # the communication stream waits for the collective ...
-                        k.gate_signal(self._flags, nb + self.buckets.index(b))          # ... and opens the graph's join
-            if self._joined:
-                self._handles = []
-                return None
             rest = [b for b in self.buckets if not b['launched'] and b['hi'] > b['lo']]
             if rest:
                 self._comm.wait_stream(main)
                 with torch.cuda.stream(self._comm):
                     for b in rest:
                         self._launch(b)
-            for h in self._handles:
-                h.wait()
+            with torch.cuda.stream(self._comm):
+                for h in self._handles:
+                    h.wait()                          # the communication stream waits for every collective ...
+            main.wait_stream(self._comm)              # ... and the main stream once for it
         self._handles = []
         return 1.0 / self.world
+
+    def disable_gating(self):
+        """Fall back to "collectives behind the whole replay": every bucket is launched once the replay has finished (the mode
+        of round 4).  The trainer does this when a gate of the first replays ran into its time-out -- the communication stream
+        shares a hardware queue with the replay on this box, so its spinning gate-wait blocked the very work it waits for."""
+        self._gated = []
 
     def gate_timeouts(self):
         """Gates that gave up waiting since begin_marks() (host sync; 0 in a healthy run)."""

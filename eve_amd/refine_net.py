@@ -159,7 +159,8 @@ class RefineNet(nn.Module):
             if isinstance(m, nn.Conv2d):
                 cin_pad = pad_channels(m.in_channels, dt)
                 cout_pad = pad_channels(m.out_channels, dt)
-                P[name] = PackedWeight(m.weight, dt, cin_pad=cin_pad, cout_pad=cout_pad)
+                P[name] = PackedWeight(m.weight, dt, cin_pad=cin_pad, cout_pad=cout_pad, defer=True)
+        PackedWeight.pack_many(list(P.values()), dt)      # every filter bank of the network in one launch per 48 (was one each)
         self._packs, self._packs_key = P, key
         return P
 

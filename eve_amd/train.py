@@ -9,6 +9,8 @@ as OIHW-shaped views, so `state_dict()` is unchanged): the wgrad kernel's output
 bf16 copies, the gradient all-reduce buckets and the fused Adam kernel all work on flat memory with no
 per-tensor launches and no layout permutes in the step.
 """
+import os
+
 import torch
 
 from . import losses
@@ -115,13 +117,14 @@ class Trainer(object):
         # with several ranks the captured graph may also hold the bucket all-reduces (RCCL supports stream capture; gloo
         # does not): EVE_AMD_GRAPH_COLLECTIVES=1 or graph_collectives=True.  Off by default -- replay then runs forward +
         # backward and the collectives / clip / Adam follow eagerly -- until it has run on a multi-GPU node.
-        import os
         import torch.distributed as dist
         if graph_collectives is None:
             graph_collectives = os.environ.get('EVE_AMD_GRAPH_COLLECTIVES', '0') == '1'
         self.graph_collectives = bool(graph_collectives) and self.sync is not None and dist.is_initialized() and \
             dist.get_backend() == 'nccl'
         self._graph = None
+        self._graph_update = None
+        self._gate_checks = 2
         self._static_batch = None
         self._static_terms = None
         self.pre_step = None          # optional host-side hook run at the top of every step(batch), before capture / replay
@@ -235,11 +238,17 @@ class Trainer(object):
                 # forward + backward in the graph, every bucket's ready point as a gate-signal node (csrc/optim.hip)
                 self.sync.begin_marks()
                 self._static_terms = self._forward_backward(self._static_batch)
-                if self.sync.end_marks():
-                    self._update(1.0 / self.sync.world)       # the join is in the graph: clip + Adam follow it there
+                self.sync.end_marks()
             else:
                 self._static_terms = self._forward_backward(self._static_batch)
                 self._update(1.0)
+        if (self.sync is not None and not self.graph_collectives and torch.cuda.is_available() and self.fp.flat.is_cuda and
+                os.environ.get('EVE_AMD_UPDATE_GRAPH', '1') != '0'):
+            # clip + Adam as their own graph, replayed behind the eager collectives (4-5 launches and their gaps otherwise).
+            # Captured on the state the main capture left behind; nothing runs, the first replay follows the first all-reduce.
+            self._graph_update = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self._graph_update, pool=self._graph.pool(), capture_error_mode=mode):
+                self._update(1.0 / self.sync.world)
 
     def _collective_and_update(self):
         self.sync.start_step()
@@ -247,7 +256,9 @@ class Trainer(object):
 
     def _gated_collective_and_update(self):
         gscale = self.sync.launch_gated()
-        if gscale is not None:                                 # (None: clip + Adam are nodes of the replay, behind its join)
+        if self._graph_update is not None:
+            self._graph_update.replay()                        # clip + Adam: a second small graph behind the collectives
+        else:
             self._update(gscale)
 
     def step(self, batch):
@@ -269,6 +280,16 @@ class Trainer(object):
             self._graph.replay()
             if self.sync is not None and not self.graph_collectives:
                 self._gated_collective_and_update()
+                if self._gate_checks > 0:
+                    # the first replays are checked (a host sync each): a gate that timed out means the gate kernels cannot
+                    # run beside the replay on this box (stream -> hardware queue aliasing); the collectives then follow the replay
+                    self._gate_checks -= 1
+                    if self.sync.gate_timeouts() > 0:
+                        import sys
+                        print('eve_amd: a gradient-bucket gate timed out; the all-reduces are issued behind the whole replay '
+                              'from now on (no overlap with backward)', file=sys.stderr)
+                        self.sync.disable_gating()
+                        self._gate_checks = 0
             self.step_count += 1
             return self._static_terms
         finally:

@@ -305,6 +305,9 @@ int eve_instnorm_bwd_fused(int dtype, int N, int HW, int C, const void* dy, cons
 /* out[j] = sum_r in[r][j] (float32, fixed summation order): the batch reduction of the per-plane partials `sums` above into
  * d(beta) / d(gamma) of an affine InstanceNorm2d (refine_net.py:46,50,59,215).                                          */
 int eve_sum_rows(int rows, int cols, const float* in, float* out, eve_stream_t stream);
+/* in [rows][C][2] (per-plane (d beta, d gamma) partials of an affine InstanceNorm backward) -> out0[c] += sum_r in[r][c][0],
+ * out1[c] += sum_r in[r][c][1], fixed order (ABI v7): the two parameter gradients land in the caller's gradient buffer.  */
+int eve_sum_rows_pairs(int rows, int C, const float* in, float* out0, float* out1, eve_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Element-wise activation gradient: dx = dy * act'(y)  (for Linear/conv epilogue activations).

@@ -1,10 +1,10 @@
 #!/bin/bash
 # round-5 fifth GPU call: in-graph join of the gated collectives, fast gate math in the 16-bit scan, ATen launch census
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-O=$R/gpurun_out/r5e
+O=$R/gpurun_out/r5f
 rm -rf $O; mkdir -p $O
 cd $R
-timeout 900 python -m pytest tests/test_gpu_data_parallel.py tests/test_gpu_refinenet.py tests/test_gpu_bf16_parity.py -m gpu -q -x --timeout 800 2>&1 | tail -15 > $O/pytest.log
+timeout 1200 python -m pytest tests/test_gpu_data_parallel.py tests/test_gpu_refinenet.py tests/test_gpu_bf16_parity.py tests/test_gpu_eve.py -m gpu -q -x --timeout 800 2>&1 | tail -15 > $O/pytest.log
 tail -6 $O/pytest.log
 Q="--no-cpu-baseline --no-c3 --no-c5 --no-points --no-roofline"
 line() { python -c "import sys,json; d=json.loads([l for l in sys.stdin if l.startswith('{')][0]); print('$1', round(d['value']), 'frames/s', round(d['ms_per_step'],3), 'ms', 'gate_timeouts', d.get('gate_timeouts'))"; }
