@@ -101,21 +101,22 @@ class GradSync(object):
     # gate-wait kernel for the bucket's word of THIS replay (value = replay count; bounded poll), then the all-reduce is
     # issued eagerly behind it -- it starts as soon as the replay passes the bucket's last gradient, under the rest of
     # the backward, exactly like the eager mode's notifications.  The RCCL calls themselves stay ordinary eager calls.
-    # The gate-wait kernels SPIN, so the stream they run on must not share a hardware queue with the streams they wait for (the
-    # HIP runtime multiplexes streams onto a few hardware queues; a spinning kernel at the head of a queue blocks whatever else
-    # was mapped onto it until its bounded poll gives up).  The communication stream is therefore created with HIGH priority:
-    # ROCm keeps separate queues per priority level, the replay and RCCL's own stream are normal-priority.  For the same reason
-    # the JOIN stays outside the graph: gate-wait nodes inside the replay, waiting for "bucket reduced" words, were built and
-    # measured (round 5) -- RCCL's internal stream shared the replay's queue on the test box and every join ran into its
-    # time-out.  Behind the replay the main stream waits ONCE for the communication stream (which has waited for every
-    # collective) and replays a second small graph holding clip + Adam.
+    # The gate-wait kernels SPIN (bounded), which has two consequences, both measured in round 5 on a one-rank RCCL group:
+    #  * the communication stream must be a NORMAL-priority stream.  As a high-priority stream (to keep it off the replay's
+    #    hardware queue) its resident gate kernel made the hardware throttle the normal-priority replay for as long as it
+    #    spun: 4.3 -> 10.7 ms per step at B = 8, 11.3 -> 18.0 at B = 32;
+    #  * the JOIN stays outside the graph.  Gate-wait nodes INSIDE the replay, waiting for "bucket reduced" words the
+    #    communication stream would signal (with clip + Adam captured behind them), ran into their time-outs: RCCL's own
+    #    stream shared the replay's hardware queue on the test box, so the spinning node blocked the collective it waited
+    #    for.  The same aliasing could in principle hit the communication stream itself on another box: the trainer checks
+    #    the time-out counter after its first replays and falls back to "collectives behind the replay" (disable_gating).
     def prepare_marks(self):
         """Allocate the gate words.  Call BEFORE the capture begins: an allocation inside the capture would come from the graph's
         private pool and its zero-fill would become a node of the graph -- every replay would then reset the words it is
         supposed to count up (seen as every gate timing out from the second replay on)."""
         if self.flat_grad.is_cuda:
             if self._comm is None:
-                self._comm = torch.cuda.Stream(device=self.flat_grad.device, priority=int(os.environ.get('EVE_AMD_COMM_PRIORITY', '0')))
+                self._comm = torch.cuda.Stream(device=self.flat_grad.device)          # NORMAL priority (see above)
             self._flags = torch.zeros((len(self.buckets) + 1,), dtype=torch.int32, device=self.flat_grad.device)
             self._timeouts = torch.zeros((1,), dtype=torch.int32, device=self.flat_grad.device)
             self._replays = 0

@@ -123,7 +123,6 @@ class Trainer(object):
         self.graph_collectives = bool(graph_collectives) and self.sync is not None and dist.is_initialized() and \
             dist.get_backend() == 'nccl'
         self._graph = None
-        self._graph_update = None
         self._gate_checks = 2
         self._static_batch = None
         self._static_terms = None
@@ -242,24 +241,14 @@ class Trainer(object):
             else:
                 self._static_terms = self._forward_backward(self._static_batch)
                 self._update(1.0)
-        if (self.sync is not None and not self.graph_collectives and torch.cuda.is_available() and self.fp.flat.is_cuda and
-                os.environ.get('EVE_AMD_UPDATE_GRAPH', '1') != '0'):
-            # clip + Adam as their own graph, replayed behind the eager collectives (4-5 launches and their gaps otherwise).
-            # Captured on the state the main capture left behind; nothing runs, the first replay follows the first all-reduce.
-            self._graph_update = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self._graph_update, pool=self._graph.pool(), capture_error_mode=mode):
-                self._update(1.0 / self.sync.world)
 
     def _collective_and_update(self):
         self.sync.start_step()
         self._update(self.sync.finish_step())
 
     def _gated_collective_and_update(self):
-        gscale = self.sync.launch_gated()
-        if self._graph_update is not None:
-            self._graph_update.replay()                        # clip + Adam: a second small graph behind the collectives
-        else:
-            self._update(gscale)
+        # (clip + Adam as a second small graph behind the collectives was measured: no gain over the four eager launches)
+        self._update(self.sync.launch_gated())
 
     def step(self, batch):
         """One optimiser step.  Returns the loss terms; under use_graph these are the graph's static output tensors
