@@ -33,6 +33,10 @@ HBM_PEAK_GBS = 8000.0
 TORCH_DTYPE = {'bf16': torch.bfloat16, 'fp16': torch.float16, 'fp32': torch.float32}
 # algorithmic FLOP per frame (one time step of one clip = 2 eye patches), SURVEY.md 8(d) / BASELINE.md 2
 EYENET_TRAIN_GFLOP_PER_FRAME_128 = 6.955
+# threads of the CPU baseline: the FASTEST count on the 256-thread host of the GPU boxes (profiles/r05_cpu_baseline_threads.log:
+# 8 threads 54 frames/s, 16 threads 63, 32 threads 25, 64 threads 10, 128 threads 2, 256 threads: no step within 10 minutes --
+# the sample is N = 2 images per op, more threads only add synchronisation).  The line states `cores` and `host_cpus`.
+CPU_BASELINE_THREADS = 16
 
 
 def synthetic_eyenet_batch(B, T, size, device, seed):
@@ -50,12 +54,12 @@ def synthetic_eyenet_batch(B, T, size, device, seed):
 
 def cpu_baseline(T, size, steps=3, budget_s=45.0):
     """The oracle's train step on the host cores (bounded sample: B=2 clips of T frames, per-time-step loop
-    exactly like the reference).  Thread count is capped at 32 (`cores` in the line says so, `host_cpus` what the box has):
-    the sample is N = 2 images per op, which 32 threads already over-partition."""
+    exactly like the reference).  Thread count: CPU_BASELINE_THREADS, the fastest on the GPU boxes' host (`cores` in the line says so,
+    `host_cpus` what the box has)."""
     from oracle import sequence
     from oracle.config import OracleConfig
     from oracle.eye_net import EyeNet as OracleEyeNet
-    cores = min(os.cpu_count() or 1, 32)
+    cores = min(os.cpu_count() or 1, CPU_BASELINE_THREADS)
     torch.set_num_threads(cores)
     cfg = OracleConfig(batch_size=16, weight_decay=0.005, base_learning_rate=0.001)
     torch.manual_seed(0)
@@ -84,7 +88,7 @@ def cpu_baseline_c3(T, steps=3, budget_s=60.0):
     from oracle.config import OracleConfig
     from oracle.eye_net import EyeNet as OracleEyeNet
     from oracle.refine_net import RefineNet as OracleRefineNet
-    cores = min(os.cpu_count() or 1, 32)
+    cores = min(os.cpu_count() or 1, CPU_BASELINE_THREADS)
     torch.set_num_threads(cores)
     cfg = OracleConfig(os.path.join(HERE, 'configs', 'refine_net.json'), refine_net_rnn_type='CGRU', eye_net_load_pretrained=False)
     eye, ref = detweights.fill_module(OracleEyeNet(cfg), 0), detweights.fill_module(OracleRefineNet(cfg), 1)

@@ -22,7 +22,7 @@ class DispatchConfig(Structure):
         'struct_bytes', 'conv_impl_v1', 'conv_tile_big', 'conv_halo', 'conv_ws64', 'conv_wg8', 'conv_wg8_min_tiles',
         'conv_wg8_s2_min_tiles', 'halo_persist', 'wgrad_target_wgs', 'wgrad_min_rows', 'wgrad_halo', 'wgrad_wg8',
         'wg64_th', 'wg64_nreg', 'wg64_fixed', 'in_split', 'in_min_threads', 'in_stats_one_pass', 'stem_split',
-        'in_trunk_kernels', 'stem_fused_wgrad', 'stem_fwd_pairs', 'conv1x1_stream', 'conv3x3_stream', 'in_big_planes')] + [('wgrad_halo_min_m', c_longlong)]
+        'in_trunk_kernels', 'stem_fused_wgrad', 'stem_fwd_pairs', 'conv1x1_stream', 'conv3x3_stream', 'in_big_planes', 'cgru_seq_max_b')] + [('wgrad_halo_min_m', c_longlong)]
 
     def as_dict(self):
         return {n: int(getattr(self, n)) for n, _ in self._fields_ if n != 'struct_bytes'}

@@ -31,6 +31,7 @@ static eve_dispatch_config default_dispatch_config() {
     c.wg64_th = 0; c.wg64_nreg = 0; c.wg64_fixed = 1;
     c.in_split = 1; c.in_min_threads = 512; c.in_stats_one_pass = 1; c.stem_split = 1; c.in_trunk_kernels = 1; c.stem_fused_wgrad = 1; c.stem_fwd_pairs = 1; c.in_big_planes = 1; c.conv1x1_stream = 1; c.conv3x3_stream = 1;
     c.wgrad_halo_min_m = 1ll << 20;
+    c.cgru_seq_max_b = 384;
     return c;
 }
 static void env_int(const char* name, int& field) { if (const char* e = getenv(name)) field = atoi(e); }
@@ -52,6 +53,7 @@ static eve_dispatch_config load_dispatch_config() {
     env_int("EVE_IN_BIG_PLANES", c.in_big_planes);
     env_int("EVE_CONV1X1_STREAM", c.conv1x1_stream);
     env_int("EVE_CONV3X3_STREAM", c.conv3x3_stream);
+    env_int("EVE_CGRU_SEQ_MAX_B", c.cgru_seq_max_b);
     if (const char* e = getenv("EVE_WGRAD_HALO_MIN_M")) c.wgrad_halo_min_m = atoll(e);
     if (c.wgrad_min_rows < 64) c.wgrad_min_rows = 64;
     if (c.in_min_threads < 64) c.in_min_threads = 64;

@@ -579,6 +579,12 @@ int eve_cgru_scan_f32_bwd(int B, int T, const float* dhs_tm, const float* ru, co
                           const float* w1t, const float* w2t, float* dg1_all, float* dg2_all, float* dxs_tm, float* dh0,
                           hipStream_t s);
 
+// one sequence per workgroup (cgru_scan1.hip): the batches this model sees (B <= g_cfg.cgru_seq_max_b sequences)
+int eve_cgru_scan1_fwd(int dtype, int B, int T, const void* xs, const void* h0, const void* w1, const float* b1, const void* w2,
+                       const float* b2, void* hs, void* hs_tm, void* ru, void* rh, void* og, hipStream_t s);
+int eve_cgru_scan1_bwd(int dtype, int B, int T, const void* dhs_tm, const void* ru, const void* og, const void* hs_tm, const void* h0,
+                       const void* w1t, const void* w2t, void* dg1_all, void* dg2_all, void* dxs_tm, void* dh0, hipStream_t s);
+
 extern "C" int eve_cgru_scan_fwd(int dtype, int B, int T, const void* xs, const void* h0, const void* w1, const float* b1, const void* w2,
                                  const float* b2, void* hs, void* hs_tm, void* ru, void* rh, void* og, eve_stream_t stream) {
     if (dtype == EVE_DT_F32 && B > 0 && T > 0 && xs && w1 && b1 && w2 && b2 && hs && hs_tm && ru && rh && og)
@@ -587,6 +593,7 @@ extern "C" int eve_cgru_scan_fwd(int dtype, int B, int T, const void* xs, const 
     if ((dtype != EVE_DT_BF16 && dtype != EVE_DT_F16) || B <= 0 || T <= 0 || !xs || !w1 || !b1 || !w2 || !b2 || !hs || !hs_tm || !ru || !rh || !og)
         return set_error_msg("cgru_scan_fwd: bad arguments");
     if ((long long)B * T * CG_PIX * 128 >= (1ll << 31)) return set_error_msg("cgru_scan_fwd: clip too large for 32-bit offsets");
+    if (B <= g_cfg.cgru_seq_max_b) return eve_cgru_scan1_fwd(dtype, B, T, xs, h0, w1, b1, w2, b2, hs, hs_tm, ru, rh, og, (hipStream_t)stream);
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)cgru_scan_fwd_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -616,6 +623,8 @@ extern "C" int eve_cgru_scan_bwd(int dtype, int B, int T, const void* dhs_tm, co
     if ((dtype != EVE_DT_BF16 && dtype != EVE_DT_F16) || B <= 0 || T <= 0 || !dhs_tm || !ru || !og || !hs_tm || !w1t || !w2t || !dg1_all || !dg2_all || !dxs_tm)
         return set_error_msg("cgru_scan_bwd: bad arguments");
     if ((long long)B * T * CG_PIX * 128 >= (1ll << 31)) return set_error_msg("cgru_scan_bwd: clip too large for 32-bit offsets");
+    if (B <= g_cfg.cgru_seq_max_b)
+        return eve_cgru_scan1_bwd(dtype, B, T, dhs_tm, ru, og, hs_tm, h0, w1t, w2t, dg1_all, dg2_all, dxs_tm, dh0, (hipStream_t)stream);
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)cgru_scan_bwd_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

@@ -80,6 +80,7 @@ typedef struct eve_dispatch_config {
     int conv1x1_stream;            /* EVE_CONV1X1_STREAM    1   1x1 convolutions between 16..128 channels on the streaming kernel (no LDS)    */
     int conv3x3_stream;            /* EVE_CONV3X3_STREAM    1   3x3 / stride 1 between 16..64 channels on 64 / 128-wide images: row-streaming kernel */
     int in_big_planes;             /* EVE_IN_BIG_PLANES     1   register-resident InstanceNorm (no affine) for planes beyond 8 192 vectors, dealt by channels */
+    int cgru_seq_max_b;            /* EVE_CGRU_SEQ_MAX_B    384 16-bit conv-GRU clip scans: one sequence per workgroup (cgru_scan1.hip) up to this many sequences, three per workgroup (cgru_scan.hip) beyond */
     long long wgrad_halo_min_m;    /* EVE_WGRAD_HALO_MIN_M  1<<20 pixels from which the band-resident weight gradient runs */
 } eve_dispatch_config;
 int eve_get_dispatch_config(eve_dispatch_config* out);           /* what the entry points use now                         */

@@ -461,8 +461,8 @@ def test_bf16_costs_less_on_a_trained_network_than_on_random_weights():
     """what the 16-bit instantiation costs on TRAINED weights.  tools/train_sanity.py's EyeNet run (8 clips x 10
     frames memorised in 400 bf16 steps through the product trainer, hipGraph replay), then the SAME weights evaluated through the
     HIP path in float32 and in bf16: the gaze deviation on the training clips and on held-out clips, against the same comparison
-    on the untrained deterministic weights.  Bounds = profiles/r05_train_sanity.log (training clips 6.0e-4 rad max, held-out
-    7.3e-3, untrained ~3e-2) with a factor 4-5 of head room; the float32 instantiation is the one that carries the 1e-4 rad
+    on the untrained deterministic weights.  Bounds = two runs of it (profiles/r05_train_sanity.log: training clips 6.0e-4 / 8.3e-4 rad max,
+    held-out 7.3e-3 / 1.45e-2 -- the training itself is not bit-reproducible -- untrained ~3e-2) with a factor 3-5 of head room; the float32 instantiation is the one that carries the 1e-4 rad
     parity statement, this test only says how far the throughput format sits from it where it matters."""
     import importlib.util
     import os
@@ -479,7 +479,7 @@ def test_bf16_costs_less_on_a_trained_network_than_on_random_weights():
     untrained = ts.eyenet_16bit_vs_fp32(fresh, torch.bfloat16, {'train': batch, 'held_out': held_out})
     print('bf16 vs float32 gaze (rad): trained %s | untrained %s' % (
         {k: '%.2e' % v['gaze_max_rad'] for k, v in trained.items()}, {k: '%.2e' % v['gaze_max_rad'] for k, v in untrained.items()}))
-    assert trained['train']['gaze_max_rad'] < 3e-3 and trained['train']['gaze_rms_rad'] < 1e-3
-    assert trained['held_out']['gaze_max_rad'] < 3e-2 and trained['held_out']['gaze_rms_rad'] < 6e-3
+    assert trained['train']['gaze_max_rad'] < 4e-3 and trained['train']['gaze_rms_rad'] < 1e-3
+    assert trained['held_out']['gaze_max_rad'] < 5e-2 and trained['held_out']['gaze_rms_rad'] < 1e-2
     assert untrained['held_out']['gaze_max_rad'] < 0.1
     eve_amd.reset_standalone_config()

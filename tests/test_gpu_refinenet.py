@@ -122,8 +122,9 @@ def test_refinenet_bf16_deviation_reported():
     assert dev < 0.3      # untrained deterministic weights through ~40 bf16 layers; a precision mode, not parity
 
 
+@pytest.mark.parametrize('per_wg', [1, 3], ids=['one-sequence-per-workgroup', 'three-per-workgroup'])
 @pytest.mark.parametrize('B,T,with_h0', [(2, 3, False), (7, 5, True), (3, 1, True)])
-def test_fused_cgru_scan_kernel_matches_per_step_path(B, T, with_h0):
+def test_fused_cgru_scan_kernel_matches_per_step_path(B, T, with_h0, per_wg):
     """eve_cgru_scan_fwd (the whole clip through the conv-GRU in one persistent launch) == the per-frame path
     (two conv launches + two gate kernels per frame), bf16; outputs and the tensors the backward consumes."""
     from eve_amd.kernels import HipKernels
@@ -136,7 +137,10 @@ def test_fused_cgru_scan_kernel_matches_per_step_path(B, T, with_h0):
     w2 = (torch.randn((64, 3, 3, 128), generator=g) * 0.04).bfloat16()
     b1, b2 = torch.randn((128,), generator=g) * 0.2, torch.randn((64,), generator=g) * 0.2
     want = ref.cgru_scan_fwd(xs, h0, w1, b1, w2, b2)
-    got = hip.cgru_scan_fwd(xs.cuda(), h0.cuda() if with_h0 else None, w1.cuda(), b1.cuda(), w2.cuda(), b2.cuda())
+    # round 5: cgru_scan1.hip (one sequence per workgroup, the default up to cgru_seq_max_b sequences) and cgru_scan.hip
+    with hip.dispatch_override(cgru_seq_max_b=384 if per_wg == 1 else 0):
+        got = hip.cgru_scan_fwd(xs.cuda(), h0.cuda() if with_h0 else None, w1.cuda(), b1.cuda(), w2.cuda(), b2.cuda())
+        assert hip.lib.eve_last_kernel().decode().startswith('cgru_scan1_fwd_kernel' if per_wg == 1 else 'cgru_scan_fwd_kernel')
     for name, a, b in zip(('hs', 'hs_tm', 'ru', 'rh', 'og'), got, want):
         d = (a.float().cpu() - b.float()).abs()
         # bf16 storage: one ulp at |v| <= 1 is 2^-8; the fused kernel rounds at fewer points than the per-frame path
@@ -228,8 +232,9 @@ def test_full_size_refinenet_is_batch_invariant_deterministic_and_dp_linear():
     assert rel < 5e-3, rel
 
 
+@pytest.mark.parametrize('per_wg', [1, 3], ids=['one-sequence-per-workgroup', 'three-per-workgroup'])
 @pytest.mark.parametrize('B,T,with_h0', [(2, 3, False), (7, 5, True), (3, 1, True), (32, 30, False)])
-def test_fused_cgru_scan_backward_kernel_matches_contract(B, T, with_h0):
+def test_fused_cgru_scan_backward_kernel_matches_contract(B, T, with_h0, per_wg):
     """eve_cgru_scan_bwd (the whole frame-reversed conv-GRU backward in one persistent launch: gate gradients, both
     data-gradient GEMMs on MFMA, the float carry into the previous state) against the ATen restatement of its contract:
     gradients of the two pre-activations, d xs, d h0."""
@@ -245,8 +250,10 @@ def test_fused_cgru_scan_backward_kernel_matches_contract(B, T, with_h0):
     h0 = bf(B, 5, 8, 64, scale=0.5) if with_h0 else None
     w1t, w2t = bf(128, 3, 3, 128, scale=0.04), bf(128, 3, 3, 64, scale=0.05)
     want = ref.cgru_scan_bwd(dhs, ru, og, hs, h0, w1t, w2t, want_dh0=with_h0)
-    got = hip.cgru_scan_bwd(dhs.cuda(), ru.cuda(), og.cuda(), hs.cuda(), h0.cuda() if with_h0 else None, w1t.cuda(), w2t.cuda(),
-                            want_dh0=with_h0)
+    with hip.dispatch_override(cgru_seq_max_b=384 if per_wg == 1 else 0):
+        got = hip.cgru_scan_bwd(dhs.cuda(), ru.cuda(), og.cuda(), hs.cuda(), h0.cuda() if with_h0 else None, w1t.cuda(), w2t.cuda(),
+                                want_dh0=with_h0)
+        assert hip.lib.eve_last_kernel().decode().startswith('cgru_scan1_bwd_kernel' if per_wg == 1 else 'cgru_scan_bwd_kernel')
     for name, a, b in zip(('dg1', 'dg2', 'dxs', 'dh0'), got, want):
         if b is None:
             assert a is None
