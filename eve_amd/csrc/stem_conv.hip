@@ -74,8 +74,12 @@ __global__ __launch_bounds__(256) void stem7x7_kernel(const int N, const int IH,
         const int kw = e & 7, kh = (e >> 3) % 7, co = e / 56;
         uint2 v = make_uint2(0u, 0u);
         if (kw < 7) v = *reinterpret_cast<const uint2*>(w8 + ((co * 7 + kh) * 7 + kw) * 8);   // channels 0..3
-        const int row = co >> 1;
-        const int slot = (((co & 1) << 2) + (kw >> 1)) ^ (row & 7);
+        // LDS channel row c_lds = nt * 16 + 4 g + r holds output channel g * 16 + nt * 4 + r (as stem_fused.hip does): an MFMA lane
+        // then owns the 16 CONSECUTIVE channels 16 lg .. 16 lg + 15 of its pixel -- two 16-byte stores per pixel instead of four
+        // 8-byte ones into four different 32-byte sectors (round 5: the 4 GB output of configs[4] went out in 8-byte pieces)
+        const int c_lds = ((co >> 2) & 3) * 16 + (co >> 4) * 4 + (co & 3);
+        const int row = c_lds >> 1;
+        const int slot = (((c_lds & 1) << 2) + (kw >> 1)) ^ (row & 7);
         reinterpret_cast<uint2*>(sW)[(kh * 256 + row * 8 + slot) * 2 + (kw & 1)] = v;
     }
     __syncthreads();
@@ -124,14 +128,17 @@ __global__ __launch_bounds__(256) void stem7x7_kernel(const int N, const int IH,
         }
         H* orow = y + (((size_t)n * OH + oy) * OW + xb * 64) * 64;
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
+        for (int mt = 0; mt < 4; ++mt) {
+            uint32_t pk[8];                                     // channels 16 lg + 4 nt + r of pixel 16 mt + li
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) {
-                uint2 pk;
-                pk.x = Elem<H>::pack2(acc[mt][nt][0], acc[mt][nt][1]);
-                pk.y = Elem<H>::pack2(acc[mt][nt][2], acc[mt][nt][3]);
-                *reinterpret_cast<uint2*>(orow + (mt * 16 + li) * 64 + nt * 16 + lg * 4) = pk;
+                pk[2 * nt] = Elem<H>::pack2(acc[mt][nt][0], acc[mt][nt][1]);
+                pk[2 * nt + 1] = Elem<H>::pack2(acc[mt][nt][2], acc[mt][nt][3]);
             }
+            H* dst = orow + (mt * 16 + li) * 64 + lg * 16;
+            *reinterpret_cast<uint4*>(dst) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+            *reinterpret_cast<uint4*>(dst + 8) = make_uint4(pk[4], pk[5], pk[6], pk[7]);
+        }
     }
 }
 
