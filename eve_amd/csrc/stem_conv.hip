@@ -63,8 +63,11 @@ __global__ __launch_bounds__(256) void stem_pack4_kernel(const float* __restrict
     }
 }
 
-template <typename H>
-__global__ __launch_bounds__(256) void stem7x7_kernel(const int N, const int IH, const int IW,
+// MT: 16-pixel tiles per wave tile.  Round 5: 2 instead of 4 -- the kernel is latency-bound (a wave loads a tile's 14 MT
+// fragments, multiplies, stores; nothing overlaps inside a wave), so what counts is waves per SIMD: 32-pixel tiles fit 3
+// (168 registers; at 128 it spills) where 64-pixel tiles fit 2.
+template <typename H, int MT>
+__global__ __launch_bounds__(256, MT == 2 ? 3 : 2) void stem7x7_kernel(const int N, const int IH, const int IW,
                                                       const uint2* __restrict__ xp, const H* __restrict__ w8,
                                                       H* __restrict__ y, const uint32_t ntiles) {
     __shared__ uint4 sW[7 * 256];                              // 7 filter rows x (64 output channels x 64 B)
@@ -87,7 +90,7 @@ __global__ __launch_bounds__(256) void stem7x7_kernel(const int N, const int IH,
     const int lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, lg = lane >> 4;
     const int OH = IH / 2, OW = IW / 2, IWp = IW + 8, IHp = IH + 6;
-    const int xblocks = OW / 64;
+    const int xblocks = OW / (16 * MT);
     int brow[4];
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) {
@@ -101,19 +104,19 @@ __global__ __launch_bounds__(256) void stem7x7_kernel(const int N, const int IH,
         const uint32_t r = tile / xblocks;
         const uint32_t oy = r % OH, n = r / OH;
         // padded pixel index of the lane's first fragment pixel for filter row 0: (2*oy, 2*ox + 1 + 2*lg)
-        const uint2* base = xp + ((size_t)n * IHp + 2 * oy) * IWp + 2 * (xb * 64 + li) + 1 + 2 * lg;
-        uint4 fx[7][4];
+        const uint2* base = xp + ((size_t)n * IHp + 2 * oy) * IWp + 2 * (xb * (16 * MT) + li) + 1 + 2 * lg;
+        uint4 fx[7][MT];
 #pragma unroll
         for (int kh = 0; kh < 7; ++kh)
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt) {
+            for (int mt = 0; mt < MT; ++mt) {
                 const uint2* p = base + (size_t)kh * IWp + mt * 32;     // 16 output pixels = 32 input pixels further
                 const uint2 a = p[0], b = p[1];                          // 8-byte aligned pair (odd pixel index)
                 fx[kh][mt] = make_uint4(a.x, a.y, b.x, b.y);
             }
-        f32x4_t acc[4][4];
+        f32x4_t acc[MT][4];
 #pragma unroll
-        for (int a = 0; a < 4; ++a)
+        for (int a = 0; a < MT; ++a)
 #pragma unroll
             for (int b = 0; b < 4; ++b) acc[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -122,13 +125,13 @@ __global__ __launch_bounds__(256) void stem7x7_kernel(const int N, const int IH,
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) fw[nt] = sW[kh * 256 + brow[nt]];
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt)
+            for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                 for (int nt = 0; nt < 4; ++nt) Elem<H>::mfma(acc[mt][nt], fw[nt], fx[kh][mt]);
         }
-        H* orow = y + (((size_t)n * OH + oy) * OW + xb * 64) * 64;
+        H* orow = y + (((size_t)n * OH + oy) * OW + xb * (16 * MT)) * 64;
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt) {
+        for (int mt = 0; mt < MT; ++mt) {
             uint32_t pk[8];                                     // channels 16 lg + 4 nt + r of pixel 16 mt + li
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) {
@@ -167,11 +170,11 @@ extern "C" int eve_stem7x7s2_fwd(int dtype, int N, int IH, int IW, const void* x
                                  eve_stream_t stream) {
     if ((dtype != EVE_DT_BF16 && dtype != EVE_DT_F16) || N <= 0 || IH <= 0 || IW <= 0 || (IH & 1) || (IW % 128) || !x_padded || !w_ohwi8 || !y)
         return set_error_msg("stem7x7s2_fwd: needs even IH and IW a multiple of 128");
-    const unsigned long long tiles = (unsigned long long)N * (IH / 2) * (IW / 128);
+    const unsigned long long tiles = (unsigned long long)N * (IH / 2) * (IW / 64);                 // 32 output pixels per wave tile
     if (tiles >= (1ull << 32)) return set_error_msg("stem7x7s2_fwd: too many tiles");
-    unsigned blocks = 512;
+    unsigned blocks = 768;                                                                         // three workgroups per CU
     if ((tiles + 3) / 4 < blocks) blocks = (unsigned)((tiles + 3) / 4);
-    EVE_DISPATCH_H16(dtype, EVE_LAUNCH(EVE_HNAME(H, "stem7x7_kernel<", ">"), stem7x7_kernel<H>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, N, IH, IW,
+    EVE_DISPATCH_H16(dtype, EVE_LAUNCH(EVE_HNAME(H, "stem7x7_kernel<", ", 2>"), (stem7x7_kernel<H, 2>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, N, IH, IW,
                                        (const uint2*)x_padded, (const H*)w_ohwi8, (H*)y, (uint32_t)tiles));
     EVE_CHECK_LAUNCH();
     return 0;
