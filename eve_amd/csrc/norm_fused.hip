@@ -711,9 +711,15 @@ __global__ __launch_bounds__(256) void in_relu_pool_fwd_kernel(const T* __restri
             best[e] = z > 0.f ? z : 0.f;
         }
         reinterpret_cast<uint4*>(y)[i] = Elem<T>::pack(best);
-        uint8_t* ip = idx + i * VEC;
+        // the window positions of the VEC channels as ONE store (round 5: eight single-byte stores per thread before)
+        uint32_t w0 = 0u, w1 = 0u;
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) ip[e] = (uint8_t)bi[e];
+        for (int e = 0; e < VEC; ++e) {
+            if (e < 4) w0 |= (bi[e] & 0xffu) << (8 * e);
+            else       w1 |= (bi[e] & 0xffu) << (8 * (e - 4));
+        }
+        if (VEC == 8) *reinterpret_cast<uint2*>(idx + i * VEC) = make_uint2(w0, w1);
+        else          *reinterpret_cast<uint32_t*>(idx + i * VEC) = w0;
     }
 }
 

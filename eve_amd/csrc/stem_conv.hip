@@ -63,11 +63,13 @@ __global__ __launch_bounds__(256) void stem_pack4_kernel(const float* __restrict
     }
 }
 
-// MT: 16-pixel tiles per wave tile.  Round 5: 2 instead of 4 -- the kernel is latency-bound (a wave loads a tile's 14 MT
-// fragments, multiplies, stores; nothing overlaps inside a wave), so what counts is waves per SIMD: 32-pixel tiles fit 3
-// (168 registers; at 128 it spills) where 64-pixel tiles fit 2.
+// MT: 16-pixel tiles per wave tile (2: a wave tile is two output rows x 32 pixels, see the tile loop).  Round 5 measured the
+// kernel latency-bound -- a wave loads a tile's fragments, multiplies, stores, nothing overlaps inside a wave -- so what counts is
+// the loads a SIMD keeps in flight and how few it needs: 64-pixel one-row tiles at two waves per SIMD 3.36 ms (configs[4]), 32-pixel
+// one-row tiles at three waves 2.57 ms, two-row tiles (nine input rows for two outputs instead of seven for one) at two waves: see
+// profiles/r05_notes.md.
 template <typename H, int MT>
-__global__ __launch_bounds__(256, MT == 2 ? 3 : 2) void stem7x7_kernel(const int N, const int IH, const int IW,
+__global__ __launch_bounds__(256, 2) void stem7x7_kernel(const int N, const int IH, const int IW,
                                                       const uint2* __restrict__ xp, const H* __restrict__ w8,
                                                       H* __restrict__ y, const uint32_t ntiles) {
     __shared__ uint4 sW[7 * 256];                              // 7 filter rows x (64 output channels x 64 B)
@@ -98,49 +100,60 @@ __global__ __launch_bounds__(256, MT == 2 ? 3 : 2) void stem7x7_kernel(const int
         const int row = c >> 1;
         brow[nt] = row * 8 + ((((c & 1) << 2) + lg) ^ (row & 7));
     }
+    // A wave tile is TWO output rows x 16 MT pixels (round 5): output rows 2q and 2q + 1 read input rows 4q .. 4q + 8, nine rows
+    // for two outputs where one row per tile fetched seven for one -- 36 % fewer fragment loads on a kernel whose time is load
+    // latency; filter row kh multiplies fx[kh] for the upper output row and fx[kh + 2] for the lower one.
     const uint32_t gw = blockIdx.x * 4 + wave, nw = gridDim.x * 4;
+    const uint32_t OH2 = (uint32_t)OH / 2;
     for (uint32_t tile = gw; tile < ntiles; tile += nw) {
         const uint32_t xb = tile % xblocks;
         const uint32_t r = tile / xblocks;
-        const uint32_t oy = r % OH, n = r / OH;
+        const uint32_t oy = 2 * (r % OH2), n = r / OH2;
         // padded pixel index of the lane's first fragment pixel for filter row 0: (2*oy, 2*ox + 1 + 2*lg)
         const uint2* base = xp + ((size_t)n * IHp + 2 * oy) * IWp + 2 * (xb * (16 * MT) + li) + 1 + 2 * lg;
-        uint4 fx[7][MT];
+        uint4 fx[9][MT];
 #pragma unroll
-        for (int kh = 0; kh < 7; ++kh)
+        for (int kh = 0; kh < 9; ++kh)
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
                 const uint2* p = base + (size_t)kh * IWp + mt * 32;     // 16 output pixels = 32 input pixels further
                 const uint2 a = p[0], b = p[1];                          // 8-byte aligned pair (odd pixel index)
                 fx[kh][mt] = make_uint4(a.x, a.y, b.x, b.y);
             }
-        f32x4_t acc[MT][4];
+        f32x4_t acc[2][MT][4];
 #pragma unroll
-        for (int a = 0; a < MT; ++a)
+        for (int q = 0; q < 2; ++q)
 #pragma unroll
-            for (int b = 0; b < 4; ++b) acc[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+            for (int a = 0; a < MT; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) acc[q][a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int kh = 0; kh < 7; ++kh) {
             uint4 fw[4];
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) fw[nt] = sW[kh * 256 + brow[nt]];
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
+            for (int q = 0; q < 2; ++q)
 #pragma unroll
-                for (int nt = 0; nt < 4; ++nt) Elem<H>::mfma(acc[mt][nt], fw[nt], fx[kh][mt]);
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt) Elem<H>::mfma(acc[q][mt][nt], fw[nt], fx[kh + 2 * q][mt]);
         }
-        H* orow = y + (((size_t)n * OH + oy) * OW + xb * (16 * MT)) * 64;
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            uint32_t pk[8];                                     // channels 16 lg + 4 nt + r of pixel 16 mt + li
+        for (int q = 0; q < 2; ++q) {
+            H* orow = y + (((size_t)n * OH + oy + q) * OW + xb * (16 * MT)) * 64;
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt) {
-                pk[2 * nt] = Elem<H>::pack2(acc[mt][nt][0], acc[mt][nt][1]);
-                pk[2 * nt + 1] = Elem<H>::pack2(acc[mt][nt][2], acc[mt][nt][3]);
+            for (int mt = 0; mt < MT; ++mt) {
+                uint32_t pk[8];                                 // channels 16 lg + 4 nt + r of pixel 16 mt + li
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) {
+                    pk[2 * nt] = Elem<H>::pack2(acc[q][mt][nt][0], acc[q][mt][nt][1]);
+                    pk[2 * nt + 1] = Elem<H>::pack2(acc[q][mt][nt][2], acc[q][mt][nt][3]);
+                }
+                H* dst = orow + (mt * 16 + li) * 64 + lg * 16;
+                *reinterpret_cast<uint4*>(dst) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+                *reinterpret_cast<uint4*>(dst + 8) = make_uint4(pk[4], pk[5], pk[6], pk[7]);
             }
-            H* dst = orow + (mt * 16 + li) * 64 + lg * 16;
-            *reinterpret_cast<uint4*>(dst) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
-            *reinterpret_cast<uint4*>(dst + 8) = make_uint4(pk[4], pk[5], pk[6], pk[7]);
         }
     }
 }
@@ -168,11 +181,11 @@ extern "C" int eve_stem_pack_input(int dtype, int N, int C, int IH, int IW, cons
 
 extern "C" int eve_stem7x7s2_fwd(int dtype, int N, int IH, int IW, const void* x_padded, const void* w_ohwi8, void* y,
                                  eve_stream_t stream) {
-    if ((dtype != EVE_DT_BF16 && dtype != EVE_DT_F16) || N <= 0 || IH <= 0 || IW <= 0 || (IH & 1) || (IW % 128) || !x_padded || !w_ohwi8 || !y)
-        return set_error_msg("stem7x7s2_fwd: needs even IH and IW a multiple of 128");
-    const unsigned long long tiles = (unsigned long long)N * (IH / 2) * (IW / 64);                 // 32 output pixels per wave tile
+    if ((dtype != EVE_DT_BF16 && dtype != EVE_DT_F16) || N <= 0 || IH <= 0 || IW <= 0 || (IH & 3) || (IW % 128) || !x_padded || !w_ohwi8 || !y)
+        return set_error_msg("stem7x7s2_fwd: needs IH a multiple of 4 and IW a multiple of 128");
+    const unsigned long long tiles = (unsigned long long)N * (IH / 4) * (IW / 64);                 // two output rows x 32 pixels per wave tile
     if (tiles >= (1ull << 32)) return set_error_msg("stem7x7s2_fwd: too many tiles");
-    unsigned blocks = 768;                                                                         // three workgroups per CU
+    unsigned blocks = 512;                                                                         // two workgroups per CU
     if ((tiles + 3) / 4 < blocks) blocks = (unsigned)((tiles + 3) / 4);
     EVE_DISPATCH_H16(dtype, EVE_LAUNCH(EVE_HNAME(H, "stem7x7_kernel<", ", 2>"), (stem7x7_kernel<H, 2>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, N, IH, IW,
                                        (const uint2*)x_padded, (const H*)w_ohwi8, (H*)y, (uint32_t)tiles));

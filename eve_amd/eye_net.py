@@ -343,7 +343,7 @@ class EyeNet(nn.Module):
             k.stem_pack_input(left.reshape(B * T, C, Hh, Ww), out=x_padded[:B * T])
             k.stem_pack_input(right.reshape(B * T, C, Hh, Ww), out=x_padded[B * T:])
         else:
-            stem_kernel = dt in HALF_DTYPES and C <= 4 and Hh % 2 == 0 and Ww % 128 == 0          # dedicated stem conv kernel
+            stem_kernel = dt in HALF_DTYPES and C <= 4 and Hh % 4 == 0 and Ww % 128 == 0          # dedicated stem conv kernel
             # its weight gradient reads the packed patches too (ops.StemConvFn) while they stay below 2 GiB: the 8-channel NHWC
             # copy (2 GB at configs[4]'s 1 920 frames of 256 x 256) is then not made at all
             packed_wgrad = stem_kernel and 2 * B * T * (Hh + 6) * (Ww + 8) * 8 < (1 << 31)

@@ -1,6 +1,6 @@
 #!/bin/bash
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-O=$R/gpurun_out/r5k
+O=$R/gpurun_out/r5l
 rm -rf $O; mkdir -p $O
 cd $R
 timeout 900 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_eyenet.py -m gpu -q -x --timeout 600 -k "stem or trunk or configs or independent or instnorm" 2>&1 | tail -6 > $O/pytest.log
