@@ -646,15 +646,16 @@ def _wgrad_into(k, x, dy, weight, pack, stride, pad, db=None):
     return dwp[:O, :, :, :I].permute(0, 3, 1, 2)
 
 
-# ---- weight gradients of the ResNet trunk on a second stream (round 5) ------------------------------------------------------
+# ---- weight gradients of the ResNet trunk on a second stream (round 5; measured, OFF by default) --------------------------------
 # A trunk weight gradient depends on nothing the rest of the backward waits for: it reads a saved activation and one gradient
 # tensor the data-gradient chain reads as well.  At small batches the chain's kernels do not fill the chip (B = 8 per GPU: layer 3
-# is 120 tiles, layer 4 60, an InstanceNorm 480 planes on 256 CUs), so the weight gradients are issued on a side stream forked
-# from the current one -- parallel branches of the captured hipGraph -- and joined at the end of the trunk's backward.  Only in
-# the trainer's configuration (every gradient written in place into the flat buffer: nothing is allocated on the side stream)
-# and only up to SIDE_WGRAD_MAX_IMAGES images (at B = 32 the kernels fill the chip and co-running ones evict each other's data:
-# measured in round 1 and again in round 5, profiles/r05_notes.md).
-SIDE_WGRAD_MAX_IMAGES = int(os.environ.get('EVE_AMD_SIDE_WGRAD_MAX_IMAGES', '960'))
+# is 120 tiles, layer 4 60, an InstanceNorm 480 planes on 256 CUs), so the weight gradients can be issued on a side stream forked
+# from the current one and joined at the end of the trunk's backward (trainer configuration only: every gradient is written in
+# place into the flat buffer, nothing is allocated on the side stream).  Measured (profiles/r05_notes.md 7): with EAGER launches
+# it pays at B = 8 (4.13 -> 4.04 ms), but as parallel branches of the captured hipGraph -- the default execution mode -- the
+# same step gets SLOWER at every batch size (B = 8: 4.13 -> 4.30 ms, B = 16: 6.37 -> 6.49, B = 32: 10.81 -> 10.85), so the
+# default is 0 = off; EVE_AMD_SIDE_WGRAD_MAX_IMAGES=960 switches it on up to that many images.
+SIDE_WGRAD_MAX_IMAGES = int(os.environ.get('EVE_AMD_SIDE_WGRAD_MAX_IMAGES', '0'))
 _side_streams = {}
 _side_state = {'main': None, 'side': None}          # the two streams of a trunk backward in progress (parallel.GradSync joins them)
 
