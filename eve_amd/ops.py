@@ -654,7 +654,8 @@ def _wgrad_into(k, x, dy, weight, pack, stride, pad, db=None):
 # place into the flat buffer, nothing is allocated on the side stream).  Measured (profiles/r05_notes.md 7): with EAGER launches
 # it pays at B = 8 (4.13 -> 4.04 ms), but as parallel branches of the captured hipGraph -- the default execution mode -- the
 # same step gets SLOWER at every batch size (B = 8: 4.13 -> 4.30 ms, B = 16: 6.37 -> 6.49, B = 32: 10.81 -> 10.85), so the
-# default is 0 = off; EVE_AMD_SIDE_WGRAD_MAX_IMAGES=960 switches it on up to that many images.
+# default is 0 = off; EVE_AMD_SIDE_WGRAD_MAX_IMAGES=960 switches it on up to that many images (single-process runs only: one
+# data-parallel test fails with it on, profiles/r05_notes.md 7).  The second form -- one fork per ResNet stage -- is what is here.
 SIDE_WGRAD_MAX_IMAGES = int(os.environ.get('EVE_AMD_SIDE_WGRAD_MAX_IMAGES', '0'))
 _side_streams = {}
 _side_state = {'main': None, 'side': None}          # the two streams of a trunk backward in progress (parallel.GradSync joins them)
@@ -686,22 +687,34 @@ def _side_end(x):
 
 
 def _on_side_stream(k, side, fn, *tensors):
-    """Run fn() (kernel launches writing in place, no allocation) on `side`, ordered after everything issued so far on the
-    current stream; `tensors` (read by fn, allocated on the current stream) are kept from being recycled under it."""
+    """Queue fn() (kernel launches writing in place, no allocation) for the side stream; `tensors` (read by fn, allocated on
+    the current stream) stay referenced until _side_flush issues the queue.  side None: run fn() now on the current stream."""
     if side is None:
         return fn()
+    _side_state.setdefault('pending', []).append((fn, tensors))
+    return None
+
+
+def _side_flush(k, side):
+    """Issue the queued weight gradients on `side`, ordered after everything issued so far on the current stream: ONE fork
+    per ResNet stage (a fork per weight gradient made 20 cross-branch edges in the captured graph)."""
+    pending = _side_state.get('pending') or []
+    _side_state['pending'] = []
+    if side is None or not pending:
+        return
     cur = torch.cuda.current_stream()
     side.wait_stream(cur)
     k.workspace_branch = 'side'
     try:
         with torch.cuda.stream(side):
-            out = fn()
+            for fn, _ in pending:
+                fn()
     finally:
         k.workspace_branch = None
-    for t in tensors:
-        if t is not None:
-            t.record_stream(side)
-    return out
+    for _, tensors in pending:
+        for t in tensors:
+            if t is not None:
+                t.record_stream(side)
 
 
 def _in_fwd(k, x, res, act, eps, want_mask=False):
@@ -831,6 +844,8 @@ class ResNetTrunkFn(torch.autograd.Function):
             ws = tuple(weights[wpos:wpos + nw]) + ((None,) if nw == 2 else ())
             nd = tuple(need_w[wpos:wpos + nw]) + ((False,) if nw == 2 else ())
             d_a, d_b, dw1, dw2, dwd = _block_backward(k, d_a, d_b, tuple(saved[spos:spos + 9]), ws, packs, stride, nd, side)
+            if side is not None and (packs[2] is not None or spos == (4 if stem_pack is not None else 0)):
+                _side_flush(k, side)                  # a stage's weight gradients: one fork behind its last data gradient
             grads[wpos], grads[wpos + 1] = dw1, dw2
             if nw == 3:
                 grads[wpos + 2] = dwd
@@ -850,6 +865,7 @@ class ResNetTrunkFn(torch.autograd.Function):
         elif ctx.needs_input_grad[0]:
             dx = k.add(d_a, d_b) if d_b is not None else d_a
         if side is not None:
+            _side_flush(k, side)
             _side_end(saved[-9])                      # join: everything behind this node sees the weight gradients
         return (dx, None, None, None, None) + tuple(grads)
 
