@@ -53,3 +53,7 @@ cp $O/eve_c3_kernel_stats.csv $O/profiles/${RN}_eve_c3_kernel_stats.csv
 cp $O/pmc_hbm_per_kernel.json $O/profiles/${RN}_pmc_hbm_per_kernel.json
 cp $O/c3_pmc_hbm_per_kernel.json $O/profiles/${RN}_c3_pmc_hbm_per_kernel.json
 [ -f $O/pytest_gpu.log ] && cp $O/pytest_gpu.log $O/profiles/${RN}_pytest_gpu.log
+# what the 16-bit format costs on a trained network, the CPU baseline at several thread counts, the ATen launch census of configs[2]
+timeout 900 python tools/train_sanity.py 400 bf16 > $O/profiles/${RN}_train_sanity.log 2>&1
+timeout 600 python tools/cpu_baseline_threads.py 50 > $O/profiles/${RN}_cpu_baseline_threads.log 2>&1
+timeout 300 python tools/aten_ops_eve.py 8 > $O/profiles/${RN}_aten_ops_c3.txt 2>/dev/null
