@@ -59,6 +59,7 @@ ABI_VERSION = 7          # include/eve_hip.h EVE_ABI_VERSION
 
 SIGNATURES = {
     'eve_conv2d_fwd': [POINTER(ConvDesc), P, P, P, I, P, I, P, P],
+    'eve_conv2d_fwd_stats': [POINTER(ConvDesc), P, P, P, I, P, P, F, POINTER(c_int), P],
     'eve_conv2d_dgrad': [POINTER(ConvDesc), P, P, P, P, ctypes.c_ulonglong, P],
     'eve_conv2d_dgrad_acc': [POINTER(ConvDesc), P, P, P, P],
     'eve_conv2d_wgrad': [POINTER(ConvDesc), P, P, P, I, P, P, ctypes.c_ulonglong, P],

@@ -31,6 +31,8 @@ struct C3Geom {
 
 struct C3Params {
     int N, H, W;
+    float* stats;             // round 5: NULL, or [N][COUT][2] <- (mean, rstd) of every output plane (InstanceNorm2d statistics, biased
+    float eps;                //   variance): the workgroup walks a whole image anyway, so the consumer's statistics pass is not needed
     int flip;                 // 0: forward (filter [COUT][3][3][CIN]);  1: data gradient (filter [rows = COUT][3][3][k = CIN] of the
                               //    transposed layout [Cin][3][3][Cout], taps mirrored)
     int act;
@@ -112,6 +114,11 @@ __global__ __launch_bounds__(256) void conv3x3_stream_kernel(const C3Params p, c
     }
     __syncthreads();
     const int tiles = W >> 4;
+    float st1[NP][8], st2[NP][8];                  // per-lane sums of the STORED (rounded) outputs and of their squares
+#pragma unroll
+    for (int a = 0; a < NP; ++a)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { st1[a][e] = 0.f; st2[a][e] = 0.f; }
     for (int y = 0; y < Himg; ++y) {
         uint4 qn[LPT];
         load_row(y + 2, qn);                       // (zeros below the image)
@@ -155,7 +162,14 @@ __global__ __launch_bounds__(256) void conv3x3_stream_kernel(const C3Params p, c
 #pragma unroll
                         for (int e = 0; e < 8; ++e) o[e] += pv[e];
                     }
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(c1_v4u32, Elem<H_>::pack(o)), ro, off, 0, 0);
+                    const uint4 qo = Elem<H_>::pack(o);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(c1_v4u32, qo), ro, off, 0, 0);
+                    if (p.stats) {
+                        float ro8[8];
+                        Elem<H_>::unpack(qo, ro8);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) { st1[a][e] += ro8[e]; st2[a][e] += ro8[e] * ro8[e]; }
+                    }
                 } else {
                     const int off = (int)(pix * 32u + 8u * g);
                     if constexpr (ACC) {
@@ -169,11 +183,51 @@ __global__ __launch_bounds__(256) void conv3x3_stream_kernel(const C3Params p, c
                     c1_v2u32 v;
                     v.x = q.x; v.y = q.y;
                     __builtin_amdgcn_raw_buffer_store_b64(v, ro, off, 0, 0);
+                    if (p.stats) {
+                        float ro8[8];
+                        Elem<H_>::unpack(q, ro8);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { st1[a][e] += ro8[e]; st2[a][e] += ro8[e] * ro8[e]; }
+                    }
                 }
             }
         }
         store_row(y + 2, qn);                      // slot of row y - 2: last read in iteration y - 1 (barrier below / above)
         __syncthreads();
+    }
+    if (p.stats) {
+        // plane statistics in a fixed order: 16 pixel lanes of a row (butterfly), then the waves that share a channel slice
+        // (the ring is free: every wave is past the loop's last barrier)
+        float* red = reinterpret_cast<float*>(smem);             // [wave][NP][4 g][8 e][2]
+        constexpr int EV = NT >= 2 ? 8 : 4;
+#pragma unroll
+        for (int a = 0; a < NP; ++a)
+#pragma unroll
+            for (int e = 0; e < EV; ++e) {
+                float v1 = st1[a][e], v2 = st2[a][e];
+#pragma unroll
+                for (int m = 1; m < 16; m <<= 1) { v1 += __shfl_xor(v1, m, 64); v2 += __shfl_xor(v2, m, 64); }
+                if (t == 0) {
+                    red[(((wave * NP + a) * 4 + g) * 8 + e) * 2] = v1;
+                    red[(((wave * NP + a) * 4 + g) * 8 + e) * 2 + 1] = v2;
+                }
+            }
+        __syncthreads();
+        if (tid < COUT) {
+            const int c = tid, slice = c / COUT_W, cl = c - slice * COUT_W;
+            int a, gg, e;
+            if constexpr (NT >= 2) { a = cl >> 5; gg = (cl >> 3) & 3; e = cl & 7; }
+            else { a = 0; gg = cl >> 2; e = cl & 3; }
+            float s1 = 0.f, s2 = 0.f;
+            for (int wv = slice; wv < 4; wv += CS) {               // the waves of this channel slice, in order
+                s1 += red[(((wv * NP + a) * 4 + gg) * 8 + e) * 2];
+                s2 += red[(((wv * NP + a) * 4 + gg) * 8 + e) * 2 + 1];
+            }
+            const float inv = 1.f / (float)(Himg * W);
+            const float mean = s1 * inv, var = fmaxf(s2 * inv - mean * mean, 0.f);
+            p.stats[((size_t)n * COUT + c) * 2] = mean;
+            p.stats[((size_t)n * COUT + c) * 2 + 1] = rsqrtf(var + p.eps);
+        }
     }
 }
 
@@ -181,12 +235,12 @@ __global__ __launch_bounds__(256) void conv3x3_stream_kernel(const C3Params p, c
 // the data gradient (rows = this launch's output channels)
 template <typename H_>
 static bool launch_conv3x3_stream(int N, int Himg, int W, int Cin, int Cout, int flip, const void* x, const void* w, const float* bias,
-                                  int epi_act, void* out, hipStream_t s) {
+                                  int epi_act, void* out, hipStream_t s, float* stats = nullptr, float eps = 1e-5f) {
     if (!g_cfg.conv3x3_stream || (W != 64 && W != 128) || Himg < 2 || (long long)N * Himg * W < 65536 ||
         (long long)Himg * W * (Cin > Cout ? Cin : Cout) * 2 >= (1ll << 31))
         return false;
     C3Params p;
-    p.N = N; p.H = Himg; p.W = W; p.flip = flip; p.act = epi_act & 0xff;
+    p.N = N; p.H = Himg; p.W = W; p.flip = flip; p.act = epi_act & 0xff; p.stats = stats; p.eps = eps;
     const bool accf = (epi_act & EVE_EPI_ACC) != 0;
 #define EVE_C3_CASE(CI, CO)                                                                                                        \
     if (Cin == CI && Cout == CO) {                                                                                                 \

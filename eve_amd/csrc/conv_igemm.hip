@@ -1039,6 +1039,27 @@ extern "C" int eve_conv2d_fwd(const eve_conv_desc* d, const void* x, const void*
     return 0;
 }
 
+/* eve_conv2d_fwd that ALSO emits the InstanceNorm2d statistics of its output (mean, rstd per (n, c); biased variance) when the
+   kernel it dispatches walks whole images -- the row-streaming 3x3 kernel (conv_3x3s.h): RefineNet's pre-activation blocks
+   normalise every convolution's output (refine_net.py:45-53), and on the big planes that statistics pass was a launch of its
+   own.  *stats_written = 1 when mean_rstd [N][Cout][2] was filled, 0 when the shape went to another kernel (the caller then
+   runs eve_instnorm_stats as before). */
+extern "C" int eve_conv2d_fwd_stats(const eve_conv_desc* d, const void* x, const void* w_ohwi, const float* bias, int epi_act,
+                                    void* y, float* mean_rstd, float eps, int* stats_written, eve_stream_t stream) {
+    if (!stats_written || !mean_rstd) return set_error_msg("conv2d_fwd_stats: null pointer");
+    *stats_written = 0;
+    const int vec = (d && d->dtype != EVE_DT_F32) ? 8 : 4;
+    if (int e = check_desc(d, vec)) return e;
+    if (!x || !w_ohwi || !y) return set_error_msg("conv2d_fwd_stats: null pointer");
+    if (d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == 1 && d->dtype != EVE_DT_F32 && !(epi_act & EVE_EPI_ACC)) {
+        bool done = false;
+        EVE_DISPATCH_H16(d->dtype, done = launch_conv3x3_stream<H>(d->N, d->IH, d->IW, d->Cin, d->Cout, 0, x, w_ohwi, bias, epi_act, y,
+                                                                   (hipStream_t)stream, mean_rstd, eps));
+        if (done) { *stats_written = 1; EVE_CHECK_LAUNCH(); return 0; }
+    }
+    return eve_conv2d_fwd(d, x, w_ohwi, bias, epi_act, nullptr, 0, y, stream);
+}
+
 namespace eve {
 
 // Filters of the stride-2 data gradient as conv3x3_wg8_kernel<.., NT> wants them (see there): for output row parity py,

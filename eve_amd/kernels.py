@@ -208,6 +208,22 @@ class HipKernels(object):
             (x, w_ohwi, y) + ((y,) if accumulate_into is not None else ()))
         return y
 
+    def conv2d_fwd_stats(self, x, w_ohwi, bias, stride, pad, epi_act=ACT_NONE, eps=1e-5, algo=None):
+        """conv2d_fwd that also returns the InstanceNorm statistics (mean, rstd) [N, Cout, 2] of its output when the dispatched
+        kernel can form them in its epilogue (the row-streaming 3x3 kernel walks whole images), else None: -> (y, mean_rstd | None)."""
+        N, IH, IW, Cin = x.shape
+        Cout, KH, KW, Cin2 = w_ohwi.shape
+        assert Cin2 == Cin and w_ohwi.dtype == x.dtype
+        d = self._desc(x.dtype, N, IH, IW, Cin, Cout, KH, KW, stride, pad)
+        y = torch.empty((N, d.OH, d.OW, Cout), dtype=x.dtype, device=x.device)
+        mr = torch.empty((N, Cout, 2), dtype=torch.float32, device=x.device)
+        written = ctypes.c_int(0)
+        co, kk = algo or (Cout, KH * KW * Cin)
+        self._timed('conv_fwd', 2.0 * N * d.OH * d.OW * co * kk, lambda: self._ck(self.lib.eve_conv2d_fwd_stats(
+            ctypes.byref(d), self._p(x), self._p(w_ohwi), self._p(self._f32(bias, 'bias')), epi_act, self._p(y), self._p(mr),
+            float(eps), ctypes.byref(written), self._stream())), (x, w_ohwi, y))
+        return y, (mr if written.value else None)
+
     def conv2d_dgrad(self, dy, w_ihwo, in_hw, stride, pad, algo=None, accumulate_into=None):
         """Data gradient; with accumulate_into (a contiguous [N, IH, IW, Cin] tensor) it is ADDED to that tensor in
         the kernel epilogue and the same tensor is returned."""

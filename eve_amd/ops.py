@@ -216,8 +216,11 @@ class Conv2dFn(torch.autograd.Function):
     `pack` holds the packed copies (possibly with zero-padded Cin/Cout)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, pack, stride, pad, epi_act, acc=None):
+    def forward(ctx, x, weight, bias, pack, stride, pad, epi_act, acc=None, want_stats=False):
+        """want_stats: also return the InstanceNorm statistics (mean, rstd) [N, Cout, 2] of the output, or None when the
+        dispatched kernel cannot form them in its epilogue (round 5: the row-streaming 3x3 kernel can) -> (y, stats)."""
         k = default_kernels()
+        stats = None
         b = bias
         cout_p = pack.ohwi.shape[0]
         if bias is not None:
@@ -256,6 +259,8 @@ class Conv2dFn(torch.autograd.Function):
                 k.conv2d_fwd(x, pack.ohwi, b, stride, pad, epi_act, algo=pack.algo, accumulate_into=acc)
             y = torch.empty(0, dtype=acc.dtype, device=acc.device).set_(acc.untyped_storage(), acc.storage_offset(),
                                                                         acc.shape, acc.stride())
+        elif want_stats and epi_act == ACT_NONE and x.dtype in HALF_DTYPES and hasattr(k, 'conv2d_fwd_stats'):
+            y, stats = k.conv2d_fwd_stats(x, pack.ohwi, b, stride, pad, epi_act, algo=pack.algo)
         else:
             y = k.conv2d_fwd(x, pack.ohwi, b, stride, pad, epi_act, algo=pack.algo)
         ctx.pack, ctx.stride, ctx.pad, ctx.epi_act = pack, stride, pad, epi_act
@@ -268,10 +273,14 @@ class Conv2dFn(torch.autograd.Function):
         _note_use(ctx.w_direct, ctx.needs_input_grad[1])
         _note_use(ctx.b_direct, ctx.needs_input_grad[2])
         ctx.save_for_backward(x, y if epi_act != ACT_NONE else None)
+        if want_stats:
+            if stats is not None:
+                ctx.mark_non_differentiable(stats)
+            return y, stats
         return y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, *_):
         k = default_kernels()
         x, y = ctx.saved_tensors
         pack = ctx.pack
@@ -321,7 +330,7 @@ class Conv2dFn(torch.autograd.Function):
             k.bias_grad(dy, db_pending)
         if b_direct:
             _notify_grad_ready(ctx.b_direct)
-        return dx, dw, db, None, None, None, None, (dy if ctx.has_acc else None)
+        return dx, dw, db, None, None, None, None, (dy if ctx.has_acc else None), None
 
 
 class StemConvFn(torch.autograd.Function):
@@ -383,8 +392,11 @@ class StemFusedFn(torch.autograd.Function):
         return None, None, dwp[:O, :, :, :I].permute(0, 3, 1, 2), None, None
 
 
-def conv2d(x, weight, bias, pack, stride=1, pad=0, act=ACT_NONE, acc=None):
-    """acc: a tensor of the output's shape that the result is added to IN PLACE (returned); no activation then."""
+def conv2d(x, weight, bias, pack, stride=1, pad=0, act=ACT_NONE, acc=None, want_stats=False):
+    """acc: a tensor of the output's shape that the result is added to IN PLACE (returned); no activation then.
+    want_stats: -> (y, InstanceNorm statistics of y or None), see Conv2dFn."""
+    if want_stats:
+        return Conv2dFn.apply(x, weight, bias, pack, stride, pad, act, acc, True)
     return Conv2dFn.apply(x, weight, bias, pack, stride, pad, act, acc)
 
 
@@ -889,15 +901,17 @@ class InstNormActFn(torch.autograd.Function):
     """y = act(gamma * IN(x) + beta + res);  gamma/beta/res optional.  eps 1e-5, biased variance."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, res, act, eps):
+    def forward(ctx, x, gamma, beta, res, act, eps, stats=None):
+        """stats: (mean, rstd) [N, C, 2] of x already formed by its producer (ops.conv2d(want_stats=True)): the statistics pass
+        of the multi-pass path is skipped."""
         k = default_kernels()
         g = gamma.detach().float().contiguous() if gamma is not None else None
         b = beta.detach().float().contiguous() if beta is not None else None
-        fused = k.instnorm_fwd_fused(x, g, b, res, act, eps)     # one launch when the plane fits in registers
+        fused = k.instnorm_fwd_fused(x, g, b, res, act, eps) if stats is None else None     # one launch when the plane fits in registers
         if fused is not None:
             y, mr = fused
         else:
-            mr = k.instnorm_stats(x, eps)
+            mr = stats if stats is not None else k.instnorm_stats(x, eps)
             y = k.instnorm_act_fwd(x, mr, g, b, res, act)
         ctx.act, ctx.has_res, ctx.has_affine = act, res is not None, gamma is not None
         ctx.affine_params = (gamma, beta)
@@ -919,10 +933,12 @@ class InstNormActFn(torch.autograd.Function):
         dgamma = dbeta = None
         if ctx.has_affine:
             dgamma, dbeta = _affine_grads(k, sums, *ctx.affine_params)
-        return dx, dgamma, dbeta, dres, None, None
+        return dx, dgamma, dbeta, dres, None, None, None
 
 
-def instnorm_act(x, gamma=None, beta=None, res=None, act=ACT_NONE, eps=1e-5):
+def instnorm_act(x, gamma=None, beta=None, res=None, act=ACT_NONE, eps=1e-5, stats=None):
+    if stats is not None:
+        return InstNormActFn.apply(x, gamma, beta, res, act, eps, stats)
     return InstNormActFn.apply(x, gamma, beta, res, act, eps)
 
 

@@ -164,8 +164,8 @@ class RefineNet(nn.Module):
         self._packs, self._packs_key = P, key
         return P
 
-    def _conv(self, x, name, m, P, act=ACT_NONE, acc=None):
-        return ops.conv2d(x, m.weight, m.bias, P[name], stride=1, pad=m.padding[0], act=act, acc=acc)
+    def _conv(self, x, name, m, P, act=ACT_NONE, acc=None, want_stats=False):
+        return ops.conv2d(x, m.weight, m.bias, P[name], stride=1, pad=m.padding[0], act=act, acc=acc, want_stats=want_stats)
 
     # ------------------------------------------------------------------ blocks
     def _block(self, x, blk, prefix, P):
@@ -186,8 +186,10 @@ class RefineNet(nn.Module):
             else:
                 a = ops.instnorm_act(x, L[0].weight, L[0].bias, act=blk.act)
                 skip = x if S is None else ops.instnorm_act(x, S[0].weight, S[0].bias, act=blk.act)
-        a = self._conv(a, prefix + '.layers.2', L[2], P)
-        a = ops.instnorm_act(a, L[3].weight, L[3].bias, act=blk.act)
+        # the mid-block InstanceNorm's statistics come out of the convolution's own epilogue where its kernel walks whole
+        # images (the row-streaming 3x3 kernel of the two outer levels): no statistics pass over the plane
+        a, mr = self._conv(a, prefix + '.layers.2', L[2], P, want_stats=True)
+        a = ops.instnorm_act(a, L[3].weight, L[3].bias, act=blk.act, stats=mr)
         a = self._conv(a, prefix + '.layers.5', L[5], P)
         if S is not None:           # layers(x) + skip_layer(x): the 1x1 convolution accumulates into the 3x3 branch's output
             return self._conv(skip, prefix + '.skip_layer.2', S[2], P, acc=a)

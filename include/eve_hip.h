@@ -114,6 +114,12 @@ typedef struct eve_conv_desc {
 int eve_conv2d_fwd(const eve_conv_desc* d, const void* x, const void* w_ohwi, const float* bias,
                    int epi_act, const float* in_scale_shift, int pro_act, void* y,
                    eve_stream_t stream);
+/* The same, and the InstanceNorm2d statistics of the output -- mean_rstd [N][Cout][2] = (mean, 1 / sqrt(biased variance + eps)) per
+ * plane, taken on the stored (rounded) values -- from the convolution's own epilogue when the dispatched kernel walks whole
+ * images (the row-streaming 3x3 kernel; ABI v7).  *stats_written = 1 if filled, 0 if the shape took another kernel (run
+ * eve_instnorm_stats then).  refine_net.py:45-53: every convolution of a pre-activation block is followed by InstanceNorm2d. */
+int eve_conv2d_fwd_stats(const eve_conv_desc* d, const void* x, const void* w_ohwi, const float* bias, int epi_act, void* y,
+                         float* mean_rstd, float eps, int* stats_written, eve_stream_t stream);
 /* dx = conv_transpose(dy, w): gradient w.r.t. the conv INPUT.  w_ihwo is [Cin][KH][KW][Cout].    */
 int eve_conv2d_dgrad(const eve_conv_desc* d, const void* dy, const void* w_ihwo, void* dx,
                      void* workspace, unsigned long long workspace_bytes, eve_stream_t stream);

@@ -1156,3 +1156,37 @@ def test_batched_vector_terms_match_the_tensor_expressions(B, T):
                 assert bool(torch.isfinite(gm).all())
             else:
                 assert float((gm - ref).abs().max()) <= 2e-5 * float(ref.abs().max()) + 1e-7, kind
+
+
+@pytest.mark.parametrize('hdt', [torch.bfloat16, torch.float16], ids=['bf16', 'f16'])
+@pytest.mark.parametrize('geom', [(8, 72, 128), (29, 37, 64)], ids=['72x128', '37x64'])
+@pytest.mark.parametrize('cin,cout', [(16, 16), (16, 32), (32, 16), (32, 32), (16, 64), (64, 16), (32, 64), (32, 128), (64, 64)],
+                         ids=lambda v: str(v))
+def test_convolution_epilogue_emits_instancenorm_statistics(hip, hdt, geom, cin, cout):
+    """Round 5: eve_conv2d_fwd_stats -- the row-streaming 3x3 kernel walks whole images, so it forms the InstanceNorm statistics
+    (mean, rstd per plane, on the STORED values) of its output in its epilogue and the consumer's statistics pass is dropped
+    (refine_net.py:45-53: every convolution of a pre-activation block is followed by InstanceNorm2d).  Against eve_instnorm_stats
+    on the output it wrote, with a bias large against the spread (the one-pass sum of squares must survive mean >> std); a shape
+    the kernel does not serve reports "not written" and gives the plain convolution."""
+    N, H, W = geom
+    x = rnd((N, H, W, cin), hdt, 91)
+    w = rnd((cout, 3, 3, cin), hdt, 92, scale=(2.0 / (9 * cin)) ** 0.5)
+    b = rnd((cout,), torch.float32, 93, scale=0.2) + 3.0
+    y, mr = hip.conv2d_fwd_stats(dev(x), dev(w), dev(b), 1, 1)
+    used = hip.lib.eve_last_kernel().decode()
+    plain = hip.conv2d_fwd(dev(x), dev(w), dev(b), 1, 1)
+    assert torch.equal(y, plain)
+    if (cin, cout) == (64, 64):
+        assert mr is None and 'conv3x3_stream' not in used
+        return
+    assert used.startswith('conv3x3_stream_kernel<') and mr is not None and tuple(mr.shape) == (N, cout, 2)
+    want = hip.instnorm_stats(y, 1e-5)
+    assert float((mr[..., 0] - want[..., 0]).abs().max()) <= 2e-5 * float(want[..., 0].abs().max())
+    assert float(((mr[..., 1] - want[..., 1]) / want[..., 1]).abs().max()) <= 2e-3      # rstd: var = E[x^2] - mean^2 at mean ~ 5 std
+    # the module path: RefineNet's mid-block InstanceNorm on these statistics == on its own statistics pass
+    from eve_amd import ops
+    g = rnd((cout,), torch.float32, 94).abs() + 0.5
+    be = rnd((cout,), torch.float32, 95)
+    a1 = ops.instnorm_act(y, dev(g), dev(be), act=1, stats=mr)
+    a2 = ops.instnorm_act(y, dev(g), dev(be), act=1)
+    close(a1, a2, hdt, 'InstanceNorm on epilogue statistics', scale=float(a2.float().abs().max()))
