@@ -67,9 +67,8 @@ class HipKernels(object):
         stream = torch.cuda.current_stream(index)
         if torch.cuda.is_current_stream_capturing():
             # a capture stream stands for the stream the graph will replay on; launches of one graph are ordered by the
-            # captured dependencies, so they share one scratch whatever stream object carried the capture -- except the
-            # launches of a parallel BRANCH of the graph (ops._on_side_stream sets `workspace_branch`), which get their own
-            key = (index, 'graph', getattr(self, 'workspace_branch', None))
+            # captured dependencies, so they share one scratch whatever stream object carried the capture
+            key = (index, 'graph')
         else:
             key = (index, stream.cuda_stream)
         ws = self._workspaces.get(key)

@@ -658,77 +658,6 @@ def _wgrad_into(k, x, dy, weight, pack, stride, pad, db=None):
     return dwp[:O, :, :, :I].permute(0, 3, 1, 2)
 
 
-# ---- weight gradients of the ResNet trunk on a second stream (round 5; measured, OFF by default) --------------------------------
-# A trunk weight gradient depends on nothing the rest of the backward waits for: it reads a saved activation and one gradient
-# tensor the data-gradient chain reads as well.  At small batches the chain's kernels do not fill the chip (B = 8 per GPU: layer 3
-# is 120 tiles, layer 4 60, an InstanceNorm 480 planes on 256 CUs), so the weight gradients can be issued on a side stream forked
-# from the current one and joined at the end of the trunk's backward (trainer configuration only: every gradient is written in
-# place into the flat buffer, nothing is allocated on the side stream).  Measured (profiles/r05_notes.md 7): with EAGER launches
-# it pays at B = 8 (4.13 -> 4.04 ms), but as parallel branches of the captured hipGraph -- the default execution mode -- the
-# same step gets SLOWER at every batch size (B = 8: 4.13 -> 4.30 ms, B = 16: 6.37 -> 6.49, B = 32: 10.81 -> 10.85), so the
-# default is 0 = off; EVE_AMD_SIDE_WGRAD_MAX_IMAGES=960 switches it on up to that many images (single-process runs only: one
-# data-parallel test fails with it on, profiles/r05_notes.md 7).  The second form -- one fork per ResNet stage -- is what is here.
-SIDE_WGRAD_MAX_IMAGES = int(os.environ.get('EVE_AMD_SIDE_WGRAD_MAX_IMAGES', '0'))
-_side_streams = {}
-_side_state = {'main': None, 'side': None}          # the two streams of a trunk backward in progress (parallel.GradSync joins them)
-
-
-def side_streams_in_flight():
-    """(main, side) while a trunk backward with a forked weight-gradient branch is in progress, else (None, None): whoever
-    publishes gradients from one of the two streams (parallel.GradSync._launch) must first wait for the other."""
-    return _side_state['main'], _side_state['side']
-
-
-def _side_begin(x):
-    if not x.is_cuda or SIDE_WGRAD_MAX_IMAGES <= 0:
-        return None
-    dev = x.device.index if x.device.index is not None else torch.cuda.current_device()
-    side = _side_streams.get(dev)
-    if side is None:
-        side = _side_streams[dev] = torch.cuda.Stream(device=x.device)
-    main = torch.cuda.current_stream(x.device)
-    _side_state['main'], _side_state['side'] = main, side
-    return side
-
-
-def _side_end(x):
-    main, side = _side_state['main'], _side_state['side']
-    if side is not None:
-        main.wait_stream(side)
-    _side_state['main'] = _side_state['side'] = None
-
-
-def _on_side_stream(k, side, fn, *tensors):
-    """Queue fn() (kernel launches writing in place, no allocation) for the side stream; `tensors` (read by fn, allocated on
-    the current stream) stay referenced until _side_flush issues the queue.  side None: run fn() now on the current stream."""
-    if side is None:
-        return fn()
-    _side_state.setdefault('pending', []).append((fn, tensors))
-    return None
-
-
-def _side_flush(k, side):
-    """Issue the queued weight gradients on `side`, ordered after everything issued so far on the current stream: ONE fork
-    per ResNet stage (a fork per weight gradient made 20 cross-branch edges in the captured graph)."""
-    pending = _side_state.get('pending') or []
-    _side_state['pending'] = []
-    if side is None or not pending:
-        return
-    cur = torch.cuda.current_stream()
-    side.wait_stream(cur)
-    k.workspace_branch = 'side'
-    try:
-        with torch.cuda.stream(side):
-            for fn, _ in pending:
-                fn()
-    finally:
-        k.workspace_branch = None
-    for _, tensors in pending:
-        for t in tensors:
-            if t is not None:
-                t.record_stream(side)
-
-
 def _in_fwd(k, x, res, act, eps, want_mask=False):
     """-> (y, mean_rstd[, sign mask or None]).  The mask (one byte per 16-byte vector of y) only comes out of the
     register-resident kernel; planes too large for it take the multi-pass kernels and the backward reads y."""
@@ -773,7 +702,7 @@ def _block_forward(k, x, packs, stride, eps):
     return y, (x, a, mr1, an, b, mr2, ymask if ymask is not None else y, d, mrd)
 
 
-def _block_backward(k, dy, dy2, saved, weights, packs, stride, need_w, side=None):
+def _block_backward(k, dy, dy2, saved, weights, packs, stride, need_w):
     """Backward of _block_forward in dependency order.  The incoming gradient may arrive as two summands
     (dy + dy2: the previous fork) and the gradient of the block input is RETURNED as two summands (g, dx1) --
     residual branch and conv1 branch -- so the sum is folded into whichever kernel reads it next.
@@ -784,15 +713,15 @@ def _block_backward(k, dy, dy2, saved, weights, packs, stride, need_w, side=None
     hw = (x.shape[1], x.shape[2])
     # y = relu(IN(b) + identity): db and the residual-branch gradient g = dy * relu'(y)
     db, g = _in_bwd(k, dy, y, b, mr2, ACT_RELU, True, dy2=dy2)
-    dw2 = _on_side_stream(k, side, lambda: _wgrad_into(k, an, db, w2, p2, 1, 1), db) if need_w[1] else None
+    dw2 = _wgrad_into(k, an, db, w2, p2, 1, 1) if need_w[1] else None
     dan = k.conv2d_dgrad(db, p2.ihwo, (an.shape[1], an.shape[2]), 1, 1, algo=p2.algo)
     da, _ = _in_bwd(k, dan, None, a, mr1, ACT_RELU, False)              # act' recomputed from a (no affine / residual)
-    dw1 = _on_side_stream(k, side, lambda: _wgrad_into(k, x, da, w1, p1, stride, 1), da) if need_w[0] else None
+    dw1 = _wgrad_into(k, x, da, w1, p1, stride, 1) if need_w[0] else None
     dwd = None
     dx1 = k.conv2d_dgrad(da, p1.ihwo, hw, stride, 1, algo=p1.algo)
     if pd is not None:
         dd, _ = _in_bwd(k, g, None, d, mrd, ACT_NONE, False)
-        dwd = _on_side_stream(k, side, lambda: _wgrad_into(k, x, dd, wd, pd, stride, 0), dd) if need_w[2] else None
+        dwd = _wgrad_into(k, x, dd, wd, pd, stride, 0) if need_w[2] else None
         # the 1x1 / stride-s branch reaches one pixel in s*s: added onto conv1's data gradient in that kernel's epilogue
         # (no zero-filled full-size tensor, and the next InstanceNorm backward reads one summand instead of two)
         dx1 = k.conv2d_dgrad(dd, pd.ihwo, hw, stride, 0, algo=pd.algo, accumulate_into=dx1)
@@ -843,21 +772,13 @@ class ResNetTrunkFn(torch.autograd.Function):
         wpos = len(weights)
         spos = len(saved)
         d_a, d_b = dy.contiguous(), None
-        # weight gradients as a parallel branch (see _on_side_stream): trainer configuration, small image counts
-        n_img = saved[-9].shape[0] if blocks else 0
-        side = None
-        if blocks and n_img <= SIDE_WGRAD_MAX_IMAGES and all(w is None or not nd_ or _direct_grad_ok(w) for w, nd_ in zip(weights, need_w)) \
-                and any(need_w) and hasattr(k, 'lib'):
-            side = _side_begin(saved[-9])
         for packs, stride in reversed(blocks):
             nw = 3 if packs[2] is not None else 2
             wpos -= nw
             spos -= 9
             ws = tuple(weights[wpos:wpos + nw]) + ((None,) if nw == 2 else ())
             nd = tuple(need_w[wpos:wpos + nw]) + ((False,) if nw == 2 else ())
-            d_a, d_b, dw1, dw2, dwd = _block_backward(k, d_a, d_b, tuple(saved[spos:spos + 9]), ws, packs, stride, nd, side)
-            if side is not None and (packs[2] is not None or spos == (4 if stem_pack is not None else 0)):
-                _side_flush(k, side)                  # a stage's weight gradients: one fork behind its last data gradient
+            d_a, d_b, dw1, dw2, dwd = _block_backward(k, d_a, d_b, tuple(saved[spos:spos + 9]), ws, packs, stride, nd)
             grads[wpos], grads[wpos + 1] = dw1, dw2
             if nw == 3:
                 grads[wpos + 2] = dwd
@@ -876,9 +797,6 @@ class ResNetTrunkFn(torch.autograd.Function):
                 grads[0] = dwp[:O, :, :7, :I].permute(0, 3, 1, 2)
         elif ctx.needs_input_grad[0]:
             dx = k.add(d_a, d_b) if d_b is not None else d_a
-        if side is not None:
-            _side_flush(k, side)
-            _side_end(saved[-9])                      # join: everything behind this node sees the weight gradients
         return (dx, None, None, None, None) + tuple(grads)
 
 

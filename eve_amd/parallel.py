@@ -172,15 +172,6 @@ class GradSync(object):
     def _launch(self, b):
         if b['launched'] or b['hi'] <= b['lo']:
             return
-        # the trunk's weight gradients may be running on a forked side stream (ops._on_side_stream): the bucket's publication --
-        # gate signal or collective -- goes out on the current stream, which first waits for the other of the two
-        from . import ops
-        main, side = ops.side_streams_in_flight()
-        if side is not None and self.flat_grad.is_cuda:
-            cur = torch.cuda.current_stream()
-            for other in (main, side):
-                if other is not None and other.cuda_stream != cur.cuda_stream:
-                    cur.wait_stream(other)
         if self._marking:
             # capture: the point itself (a gate signal node), not the collective
             b['launched'] = True
