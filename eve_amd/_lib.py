@@ -55,7 +55,7 @@ class VecTerm(Structure):
 
 VEC_TERMS_MAX = 32
 PACK_BATCH_MAX = 48
-ABI_VERSION = 7          # include/eve_hip.h EVE_ABI_VERSION
+ABI_VERSION = 8          # include/eve_hip.h EVE_ABI_VERSION
 
 SIGNATURES = {
     'eve_conv2d_fwd': [POINTER(ConvDesc), P, P, P, I, P, I, P, P],
@@ -74,7 +74,8 @@ SIGNATURES = {
     'eve_stem_fwd_fused': [I, I, I, I, P, P, F, P, P, P, P],
     'eve_stem_wgrad': [I, I, I, I, P, P, P, P],
     'eve_stem_bwd_dx': [I, I, I, I, P, P, P, P, P, P, P, P, P],
-    'eve_stem_bwd_wgrad': [I, I, I, I, P, P, P, P, P, P, P, P, P],
+    'eve_stem_bwd_wgrad': [I, I, I, I, P, P, P, P, P, P, P, P, P, ctypes.c_ulonglong, P],
+    'eve_stem_bwd_wgrad_workspace': [I, I, I],
     'eve_bias_grad': [I, L, I, P, P, P],
     'eve_cgru_scan_fwd': [I, I, I, P, P, P, P, P, P, P, P, P, P, P, P],
     'eve_cgru_scan_bwd': [I, I, I, P, P, P, P, P, P, P, P, P, P, P, P],
@@ -165,6 +166,7 @@ def load(path=None):
         fn = getattr(lib, name)
         fn.argtypes = argtypes
         fn.restype = c_int
+    lib.eve_stem_bwd_wgrad_workspace.restype = ctypes.c_ulonglong
     lib.eve_last_kernel.argtypes = []
     lib.eve_last_kernel.restype = ctypes.c_char_p
     lib.eve_abi_version.argtypes = []

@@ -753,7 +753,7 @@ __global__ __launch_bounds__(64 * SF_WAVES) void stem_bwd_dx_kernel(const int N,
 // it is multiplied), so dW equals the two-kernel path up to the float summation order.
 // Output: dw [64][7][8][4] float, accumulated (the layout eve_stem_wgrad writes: column kw = 7 and channel 3 do not exist).
 // =================================================================================================
-constexpr int SB_PAIRS = 4;                       // images per workgroup and turn
+constexpr int SB_PAIRS = 2;                       // images per workgroup and turn; two workgroups of 4 waves per CU
 constexpr int SB_DROW = 64;                       // bytes per pixel of the d(conv out) tile: 32 local channels
 constexpr int SB_DTILE = 64 * SB_DROW;            // one conv row of one wave
 constexpr int SB_KBYTES = 4 * 2 * 3 * 16;         // [lg][ntl][{rstd, B, C}][r] floats per wave
@@ -762,7 +762,7 @@ struct SbPooledRow {               // one pooled row, the lane's 8 channels: col
     uint32_t eg[2][4];
     uint32_t code[2][2];
 };
-template <typename H>
+template <typename H, bool PREP>
 __device__ __forceinline__ void sb_load_pooled(SbPooledRow& P, const H* __restrict__ dyp, const H* __restrict__ dyp2,
                                                const H* __restrict__ yp, const uint8_t* __restrict__ idx, size_t row_base,
                                                int li, int ch0, bool live) {
@@ -771,6 +771,15 @@ __device__ __forceinline__ void sb_load_pooled(SbPooledRow& P, const H* __restri
         const size_t o = (row_base + li + 16 * j) * 64 + ch0;
         uint4 d0 = make_uint4(0, 0, 0, 0), y0 = d0;
         uint2 c = make_uint2(0, 0);
+        if (PREP) {                              // dyp is stem_grad_prep_kernel's output: summed and masked already
+            if (live) {
+                d0 = *reinterpret_cast<const uint4*>(dyp + o);
+                c = *reinterpret_cast<const uint2*>(idx + o);
+            }
+            P.eg[j][0] = d0.x; P.eg[j][1] = d0.y; P.eg[j][2] = d0.z; P.eg[j][3] = d0.w;
+            P.code[j][0] = c.x; P.code[j][1] = c.y;
+            continue;
+        }
         if (live) {
             d0 = *reinterpret_cast<const uint4*>(dyp + o);
             y0 = *reinterpret_cast<const uint4*>(yp + o);
@@ -806,18 +815,83 @@ __device__ __forceinline__ uint2 sb_tr_read(uint32_t lds_byte_addr) {
     return __builtin_bit_cast(uint2, r);
 }
 
+// The two plane sums of the stem's backward as a streaming pass of their own (round 5).  Inside stem_bwd_wgrad_kernel they are
+// "phase A": every wave pair reads its image's three pooled tensors once for the sums and again, row by row, for the routing,
+// with 2 048 images in flight (the second read comes from HBM) and nothing else running on the pair meanwhile.  Here one
+// workgroup per image reads d(pooled) (+ its second summand) and y once, writes  eg = (d + d2) where y > 0, else 0  (what the
+// routing needs) and the folded constants {rstd, B, C} per (image, channel); the fused kernel then reads eg and the arg-max codes
+// only.  Thread (column q, channel group cg) walks the pooled rows: a wave's load covers 8 pixels x 128 B = 1 KB of whole lines.
+// The sums over the 32 columns: xor-butterfly over the wave's 8, then the four waves' partials in a fixed order through LDS
+// (reproducible; not phase A's order -- the constants differ from the one-launch form's in the last float bit).
 template <typename H>
-__global__ __launch_bounds__(512) void stem_bwd_wgrad_kernel(const int N, const int IH, const H* __restrict__ xp, const uint32_t xp_bytes,
+__global__ __launch_bounds__(256) void stem_grad_prep_kernel(const int N, const int PH, const H* __restrict__ dyp, const H* __restrict__ dyp2,
+                                                             const H* __restrict__ yp, const float* __restrict__ mr,
+                                                             H* __restrict__ eg, float* __restrict__ kout) {
+    __shared__ float part[4][2][64];
+    const int tid = threadIdx.x, n = blockIdx.x;
+    const int cg = tid & 7, q = tid >> 3;
+    const size_t pool_base = (size_t)n * PH * 32;
+    const float inv_hw = 1.f / (float)(PH * 2 * 64);
+    float s1[8], s2[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) { s1[c] = 0.f; s2[c] = 0.f; }
+#pragma unroll 4
+    for (int py = 0; py < PH; ++py) {
+        const size_t o = (pool_base + (size_t)py * 32 + q) * 64 + cg * 8;
+        uint4 d0 = *reinterpret_cast<const uint4*>(dyp + o);
+        const uint4 y0 = *reinterpret_cast<const uint4*>(yp + o);
+        if (dyp2) {                                       // same rounding of the sum as sb_load_pooled
+            const uint4 e0 = *reinterpret_cast<const uint4*>(dyp2 + o);
+            d0 = make_uint4(sf_add_pairs<H>(d0.x, e0.x), sf_add_pairs<H>(d0.y, e0.y), sf_add_pairs<H>(d0.z, e0.z), sf_add_pairs<H>(d0.w, e0.w));
+        }
+        const uint32_t dd[4] = {d0.x, d0.y, d0.z, d0.w}, yy[4] = {y0.x, y0.y, y0.z, y0.w};
+        uint32_t gg[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t m = ((int)(yy[k] << 16) > 0 ? 0xffffu : 0u) | ((int)(yy[k] & 0xffff0000u) > 0 ? 0xffff0000u : 0u);
+            gg[k] = dd[k] & m;
+        }
+        const uint4 g4 = make_uint4(gg[0], gg[1], gg[2], gg[3]);
+        *reinterpret_cast<uint4*>(eg + o) = g4;
+        float g[8], y[8];
+        Elem<H>::unpack(g4, g);
+        Elem<H>::unpack(y0, y);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) { s1[c] += g[c]; s2[c] += g[c] * y[c]; }
+    }
+#pragma unroll
+    for (int c = 0; c < 8; ++c)
+#pragma unroll
+        for (int m = 8; m < 64; m <<= 1) { s1[c] += __shfl_xor(s1[c], m); s2[c] += __shfl_xor(s2[c], m); }
+    if ((tid & 63) < 8) {
+#pragma unroll
+        for (int c = 0; c < 8; ++c) { part[tid >> 6][0][cg * 8 + c] = s1[c]; part[tid >> 6][1][cg * 8 + c] = s2[c]; }
+    }
+    __syncthreads();
+    if (tid < 64) {
+        const float a = (((part[0][0][tid] + part[1][0][tid]) + part[2][0][tid]) + part[3][0][tid]) * inv_hw;
+        const float b = (((part[0][1][tid] + part[1][1][tid]) + part[2][1][tid]) + part[3][1][tid]) * inv_hw;
+        const float mean = mr[((size_t)n * 64 + tid) * 2], r = mr[((size_t)n * 64 + tid) * 2 + 1];
+        const float B = r * r * b, C = mean * B - r * a;
+        float* kc = kout + ((size_t)n * 64 + tid) * 3;
+        kc[0] = r; kc[1] = B; kc[2] = C;
+    }
+}
+
+// PREP: dyp = stem_grad_prep_kernel's eg, mr = its constants [N][64][{rstd, B, C}]; dyp2 / yp are not read
+template <typename H, int PAIRS, bool PREP>
+__global__ __launch_bounds__(128 * PAIRS, 2) void stem_bwd_wgrad_kernel(const int N, const int IH, const H* __restrict__ xp, const uint32_t xp_bytes,
                                                              const H* __restrict__ w8, const float* __restrict__ mr,
                                                              const H* __restrict__ dyp, const H* __restrict__ dyp2,
                                                              const H* __restrict__ yp, const uint8_t* __restrict__ idx,
                                                              float* __restrict__ dw) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* const sW = smem + SB_PAIRS * SF_RING * SF_ROWB;
+    constexpr int NT = 128 * PAIRS;
+    char* const sW = smem + PAIRS * SF_RING * SF_ROWB;
     char* const sKall = sW + SF_WBYTES;
-    char* const sDall = sKall + 8 * SB_KBYTES;
+    char* const sDall = sKall + 2 * PAIRS * SB_KBYTES;
     const int tid = threadIdx.x;
-    sf_fill_weights<H>(sW, w8, tid, 512);
+    sf_fill_weights<H>(sW, w8, tid, NT);
     __syncthreads();
 
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -843,7 +917,7 @@ __global__ __launch_bounds__(512) void stem_bwd_wgrad_kernel(const int N, const 
 #pragma unroll
         for (int b = 0; b < 14; ++b) dacc[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-    const int per_turn = gridDim.x * SB_PAIRS;
+    const int per_turn = gridDim.x * PAIRS;
     const int turns = (N + per_turn - 1) / per_turn;
     for (int turn = 0; turn < turns; ++turn) {
         const int n = turn * per_turn + pair * (int)gridDim.x + (int)blockIdx.x;
@@ -854,7 +928,13 @@ __global__ __launch_bounds__(512) void stem_bwd_wgrad_kernel(const int N, const 
         // rows 0 .. 8 of the image: wave h stages the rows of its parity
         for (int r = h; r < 9; r += 2) sf_stage_row(rs, ring, r, live ? rows : 0, img_off, lane);
         // ---- phase A: the two plane sums over the pooled tensors -> {rstd, B, C} of the lane's channels ----
-        if (live) {
+        if (PREP) {
+            if (live && li < 8) {                                 // taken from the prep pass: channel ch0 + li
+                const float* kg = mr + ((size_t)nn * 64 + ch0 + li) * 3;
+                float* kc = reinterpret_cast<float*>(sK + ((lg * 2 + (li >> 2)) * 3) * 16) + (li & 3);
+                kc[0] = kg[0]; kc[4] = kg[1]; kc[8] = kg[2];
+            }
+        } else if (live) {
             float s1[8], s2[8];
 #pragma unroll
             for (int c = 0; c < 8; ++c) { s1[c] = 0.f; s2[c] = 0.f; }
@@ -894,18 +974,21 @@ __global__ __launch_bounds__(512) void stem_bwd_wgrad_kernel(const int N, const 
         __syncthreads();                                          // ... and the partner's (sK is this wave's own)
         // ---- phase B: recompute the convolution row by row; d(conv out) -> LDS tile -> weight-gradient MFMAs ----
         SbPooledRow P0, P1;
-        sb_load_pooled<H>(P0, dyp, dyp2, yp, idx, pool_base, li, ch0, live);
+        sb_load_pooled<H, PREP>(P0, dyp, dyp2, yp, idx, pool_base, li, ch0, live);
         int slot0 = 0;
         for (int py = 0; py < PH; ++py) {
-            sb_load_pooled<H>(P1, dyp, dyp2, yp, idx, pool_base + (size_t)(py + 1) * 32, li, ch0, live && py + 1 < PH);
+            sb_load_pooled<H, PREP>(P1, dyp, dyp2, yp, idx, pool_base + (size_t)(py + 1) * 32, li, ch0, live && py + 1 < PH);
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
                 const int oy = 2 * py + half;
                 // this wave's row of two iterations ago has landed once at most the newer operations are outstanding:
-                // half 0: one row (2 DMAs) + the 6 .. 8 pooled loads just issued; half 1: one row
+                // half 0: one row (2 DMAs) + the 6 .. 8 (PREP: 4) pooled loads just issued; half 1: one row
+                // (the last pooled row issues no pooled loads: one row only there too)
                 if (oy >= 2) {
-                    if (half == 0) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-                    else           asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                    if (half == 0 && py + 1 < PH) {
+                        if (PREP) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+                        else      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                    } else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
                 }
                 // ... and the partner's.  (A rendezvous of just the two waves through LDS flags, which lets the pairs drift apart so
                 //  that the two waves of a SIMD are not in the same phase, was built and measured: with its extra registers the
@@ -951,6 +1034,22 @@ __global__ __launch_bounds__(512) void stem_bwd_wgrad_kernel(const int N, const 
                         conv_mfma(false, fxb, fwb);
                         conv_mfma(false, fxa, fwa);
                     }
+                    // the first patch fragments of the weight-gradient loop do not depend on d(conv out): requested here, they
+                    // arrive under the gradient routing's VALU work instead of in front of the first MFMA
+                    auto patch_frag = [&](int q) {               // q = (kc * 7 + kh) * 2 + tt
+                        const int tt = q & 1, kh = (q >> 1) % 7, kc = (q >> 1) / 7;
+                        int slot = slot0 + kh;
+                        slot = slot >= SF_RING ? slot - SF_RING : slot;
+                        // patch row of pixel x starts at byte 16 x of the staged input row: taps (kw, c) contiguous
+                        const uint32_t xb = ring + slot * SF_ROWB + (kc * 32 + trow) * 16 + tq * 8 + tt * 32;
+                        const uint2 b0 = sb_tr_read(xb), b1 = sb_tr_read(xb + 4 * 16);
+                        return make_uint4(b0.x, b0.y, b1.x, b1.y);
+                    };
+                    constexpr int AHEAD = 3;
+                    uint4 fb[AHEAD + 1];
+#pragma unroll
+                    for (int q = 0; q < AHEAD; ++q) fb[q] = patch_frag(q);
+                    __builtin_amdgcn_sched_barrier(0);
                     // -- d(conv out) of the lane's 4 pixel columns x 8 channels -> the wave's [pixel][channel] tile --
                     const uint32_t k0 = half ? 6u : 3u;         // window row of this conv row inside window py
 #pragma unroll
@@ -998,19 +1097,6 @@ __global__ __launch_bounds__(512) void stem_bwd_wgrad_kernel(const int N, const 
                             const uint2 a1 = sb_tr_read(sD + r1 * SB_DROW + (((ct * 4 + tq) ^ ((r1 >> 1) & 7)) << 3));
                             fa[kc][ct] = make_uint4(a0.x, a0.y, a1.x, a1.y);
                         }
-                    auto patch_frag = [&](int q) {               // q = (kc * 7 + kh) * 2 + tt
-                        const int tt = q & 1, kh = (q >> 1) % 7, kc = (q >> 1) / 7;
-                        int slot = slot0 + kh;
-                        slot = slot >= SF_RING ? slot - SF_RING : slot;
-                        // patch row of pixel x starts at byte 16 x of the staged input row: taps (kw, c) contiguous
-                        const uint32_t xb = ring + slot * SF_ROWB + (kc * 32 + trow) * 16 + tq * 8 + tt * 32;
-                        const uint2 b0 = sb_tr_read(xb), b1 = sb_tr_read(xb + 4 * 16);
-                        return make_uint4(b0.x, b0.y, b1.x, b1.y);
-                    };
-                    constexpr int AHEAD = 3;
-                    uint4 fb[AHEAD + 1];
-#pragma unroll
-                    for (int q = 0; q < AHEAD; ++q) fb[q] = patch_frag(q);
 #pragma unroll
                     for (int q = 0; q < 28; ++q) {
                         if (q + AHEAD < 28) fb[(q + AHEAD) % (AHEAD + 1)] = patch_frag(q + AHEAD);
@@ -1027,8 +1113,9 @@ __global__ __launch_bounds__(512) void stem_bwd_wgrad_kernel(const int N, const 
         __syncthreads();                                          // the ring is rewritten by the next turn
     }
     // ---- the workgroup's dW: the four pairs' slices summed in LDS (the ring is free now), then one atomic per element ----
-    float* const sR = reinterpret_cast<float*>(smem);            // [64 co][224 taps]
-    for (int e = tid; e < 64 * 224; e += 512) sR[e] = 0.f;
+    float* const sR = reinterpret_cast<float*>(smem);            // [64 co][224 taps] (over the ring and, with two pairs, the filters)
+    static_assert((size_t)PAIRS * SF_RING * SF_ROWB + SF_WBYTES >= 64 * 224 * 4, "the dW reduction reuses the ring and the filter bank");
+    for (int e = tid; e < 64 * 224; e += NT) sR[e] = 0.f;
     __syncthreads();
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct)
@@ -1040,7 +1127,7 @@ __global__ __launch_bounds__(512) void stem_bwd_wgrad_kernel(const int N, const 
                 atomicAdd(sR + co * 224 + tap, dacc[ct][tile][r]);
             }
     __syncthreads();
-    for (int e = tid; e < 64 * 224; e += 512) atomicAdd(dw + e, sR[e]);
+    for (int e = tid; e < 64 * 224; e += NT) atomicAdd(dw + e, sR[e]);
 }
 
 }  // namespace eve
@@ -1117,25 +1204,49 @@ extern "C" int eve_stem_bwd_dx(int dtype, int N, int IH, int IW, const void* x_p
    Replaces eve_stem_bwd_dx + eve_stem_wgrad (autograd of conv1 / bn1 / relu / maxpool, eye_net.py:48-50,106).             */
 extern "C" int eve_stem_bwd_wgrad(int dtype, int N, int IH, int IW, const void* x_padded, const void* w_ohwi8, const float* mean_rstd,
                                   const void* dy_pool, const void* dy_pool2, const void* y_pool, const uint8_t* idx, float* dw,
-                                  eve_stream_t stream) {
+                                  void* workspace, unsigned long long workspace_bytes, eve_stream_t stream) {
     if ((dtype != EVE_DT_BF16 && dtype != EVE_DT_F16) || N <= 0 || IH <= 0 || (IH & 3) || IW != 128 || !x_padded || !w_ohwi8 || !mean_rstd || !dy_pool || !y_pool || !idx || !dw)
         return set_error_msg("stem_bwd_wgrad: needs IW == 128 and IH a multiple of 4");
     const unsigned long long xb = (unsigned long long)N * (IH + 6) * SF_XROW;
     if (xb >= (1ull << 31)) return set_error_msg("stem_bwd_wgrad: packed input must stay below 2 GiB");
-    const size_t lds = (size_t)SB_PAIRS * SF_RING * SF_ROWB + SF_WBYTES + 8 * SB_KBYTES + 8 * SB_DTILE;
-    static_assert((size_t)SB_PAIRS * SF_RING * SF_ROWB >= 64 * 224 * 4, "the dW reduction reuses the ring");
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)stem_bwd_wgrad_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)stem_bwd_wgrad_kernel<f16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)stem_bwd_wgrad_kernel<bf16_t, SB_PAIRS, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)stem_bwd_wgrad_kernel<f16_t, SB_PAIRS, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)stem_bwd_wgrad_kernel<bf16_t, SB_PAIRS, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)stem_bwd_wgrad_kernel<f16_t, SB_PAIRS, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    // images are dealt round-robin over the workgroups first (pair p of workgroup b takes image p * grid + b): a small batch
-    // puts one or two pairs on every CU instead of four pairs on a fraction of them
-    const unsigned blocks = N < 256 ? (unsigned)N : 256u;
-    EVE_DISPATCH_H16(dtype, EVE_LAUNCH(EVE_HNAME(H, "stem_bwd_wgrad_kernel<", ">"), stem_bwd_wgrad_kernel<H>, dim3(blocks), dim3(512), lds,
+    // Two workgroups of two pairs per CU (2 x 77 KB of LDS): the per-row barrier only ties the four waves of a workgroup, so the two
+    // waves of a SIMD are in different phases of the row (fragment reads / MFMAs / gradient routing) most of the time (one workgroup
+    // of four pairs: 0.866 ms at N = 1 920, two of two: 0.814).  Images are dealt round-robin over the workgroups first (pair p of
+    // workgroup b takes image p * grid + b): a small batch puts one pair on every CU before it puts two on any.
+    const size_t lds = (size_t)SB_PAIRS * SF_RING * SF_ROWB + SF_WBYTES + 2 * SB_PAIRS * SB_KBYTES + 2 * SB_PAIRS * SB_DTILE;
+    const unsigned blocks = (N + SB_PAIRS - 1) / SB_PAIRS < 512 ? (unsigned)((N + SB_PAIRS - 1) / SB_PAIRS) : 512u;
+    // With scratch for it (workspace: eve_stem_bwd_wgrad_workspace(dtype, N, IH) bytes), the plane sums and the masked gradient
+    // come from a streaming pass of their own and the fused kernel reads one pooled tensor + the codes, once.
+    const int PH = IH / 4;
+    const unsigned long long eg_bytes = ((unsigned long long)N * PH * 32 * 64 * 2 + 255) & ~255ull, k_bytes = (unsigned long long)N * 64 * 3 * 4;
+    if (workspace && workspace_bytes >= eg_bytes + k_bytes && !((uintptr_t)workspace & 15)) {
+        float* const kc = reinterpret_cast<float*>((char*)workspace + eg_bytes);
+        EVE_DISPATCH_H16(dtype, EVE_LAUNCH(EVE_HNAME(H, "stem_grad_prep_kernel<", ">"), stem_grad_prep_kernel<H>, dim3(N), dim3(256), 0,
+                                           (hipStream_t)stream, N, PH, (const H*)dy_pool, (const H*)dy_pool2, (const H*)y_pool, mean_rstd, (H*)workspace, kc));
+        EVE_CHECK_LAUNCH();
+        EVE_DISPATCH_H16(dtype, EVE_LAUNCH(EVE_HNAME(H, "stem_bwd_wgrad_kernel<", ",prep>"), (stem_bwd_wgrad_kernel<H, SB_PAIRS, true>), dim3(blocks), dim3(128 * SB_PAIRS), lds,
+                                           (hipStream_t)stream, N, IH, (const H*)x_padded, (uint32_t)xb, (const H*)w_ohwi8, (const float*)kc, (const H*)workspace,
+                                           (const H*)nullptr, (const H*)nullptr, idx, dw));
+        EVE_CHECK_LAUNCH();
+        return 0;
+    }
+    EVE_DISPATCH_H16(dtype, EVE_LAUNCH(EVE_HNAME(H, "stem_bwd_wgrad_kernel<", ">"), (stem_bwd_wgrad_kernel<H, SB_PAIRS, false>), dim3(blocks), dim3(128 * SB_PAIRS), lds,
                                        (hipStream_t)stream, N, IH, (const H*)x_padded, (uint32_t)xb, (const H*)w_ohwi8, mean_rstd, (const H*)dy_pool,
                                        (const H*)dy_pool2, (const H*)y_pool, idx, dw));
     EVE_CHECK_LAUNCH();
     return 0;
+}
+/* bytes of scratch with which eve_stem_bwd_wgrad takes its two-launch form (masked gradient [N][IH/4][32][64] + constants) */
+extern "C" unsigned long long eve_stem_bwd_wgrad_workspace(int dtype, int N, int IH) {
+    (void)dtype;
+    if (N <= 0 || IH <= 0) return 0;
+    return (((unsigned long long)N * (IH / 4) * 32 * 64 * 2 + 255) & ~255ull) + (unsigned long long)N * 64 * 3 * 4;
 }

@@ -44,3 +44,10 @@ if hasattr(k.lib, 'eve_stem_fwd_fused'):
 if hasattr(k.lib, 'eve_stem_bwd_dx'):
     yf, idf, mrf = k.stem_fwd_fused(xp, w8)
     print(f"stem bwd dx     {timeit(lambda: k.stem_bwd_dx(xp, w8, mrf, dyp, yf, idf)):.3f} ms")
+if hasattr(k.lib, 'eve_stem_bwd_wgrad'):
+    dw = torch.zeros((64, 7, 8, 4), device='cuda')
+    dyp2 = torch.randn_like(yp)
+    for prep in (False, True):
+        print(f"stem bwd+wgrad  prep={prep}  {timeit(lambda: k.stem_bwd_wgrad(xp, w8, mrf, dyp, yf, idf, dw, prep=prep)):.3f} ms (one summand)")
+        print(f"stem bwd+wgrad  prep={prep}  {timeit(lambda: k.stem_bwd_wgrad(xp, w8, mrf, dyp, yf, idf, dw, dy_pool2=dyp2, prep=prep)):.3f} ms (two summands, as in the training step)")
+    print('kernel', k.lib.eve_last_kernel().decode())
