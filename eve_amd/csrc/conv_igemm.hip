@@ -556,20 +556,25 @@ static bool launch_halo(const GatherParams& p, const void* src, const void* w, c
     if (p.Cin % 32 || W > 128 || (W & (W - 1)) || W < 4) return false;
     HaloParams h;
     h.N = p.N; h.H = H; h.W = W; h.Cin = p.Cin; h.Cout = p.Cout;
-    // ---- ResNet layer 1 (32 x 32 images, 64 -> 64 channels): filter bank resident in LDS, streaming tiles (conv_ws64.h) ----
+    // ---- ResNet layer 1 (32 x 32 | 64 x 64 images, 64 -> 64 channels): filter bank resident in LDS, streaming tiles (conv_ws64.h) ----
     const int ws64 = g_cfg.conv_ws64;
-    if (ws64 && H == 32 && W == 32 && p.Cin == 64 && p.Cout == 64 && ((epi_act & ~0xff) == 0) &&
-        ((epi_act & 0xff) == EVE_ACT_NONE || (epi_act & 0xff) == EVE_ACT_RELU) && (unsigned long long)p.N * 131072ull < (1ull << 31)) {
+    if (ws64 && H == W && (W == 32 || W == 64) && p.Cin == 64 && p.Cout == 64 && ((epi_act & ~0xff) == 0) &&
+        ((epi_act & 0xff) == EVE_ACT_NONE || (epi_act & 0xff) == EVE_ACT_RELU) && (unsigned long long)p.N * W * W * 128ull < (1ull << 31)) {
         Ws64Params q;
-        q.N = p.N; q.flip = bwd ? 1 : 0; q.x_bytes = (uint32_t)((unsigned long long)p.N * 131072ull); q.w_bytes = 64u * 576u * 2u;
+        q.N = p.N; q.flip = bwd ? 1 : 0; q.x_bytes = (uint32_t)((unsigned long long)p.N * W * W * 128ull); q.w_bytes = 64u * 576u * 2u;
         static bool attr_done = false;
         if (!attr_done) {
-            (void)hipFuncSetAttribute((const void*)conv3x3_ws64_kernel<HT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void*)conv3x3_ws64_kernel<HT, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void*)conv3x3_ws64_kernel<HT, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             attr_done = true;
         }
-        const uint32_t T64 = 2u * (uint32_t)p.N;
-        EVE_LAUNCH(EVE_HNAME(HT, "conv3x3_ws64_kernel<", ">"), (conv3x3_ws64_kernel<HT>), dim3(T64 < 256u ? T64 : 256u), dim3(512),
-                   (size_t)(2 * 9 * 4096 + 2 * 5 * 8 * 1024 + 256), s, q, (const HT*)src, (const HT*)w, bias, epi_act, (HT*)out);
+        const uint32_t T64 = (uint32_t)(W * W / 512) * (uint32_t)p.N;
+        if (W == 32)
+            EVE_LAUNCH(EVE_HNAME(HT, "conv3x3_ws64_kernel<", ">"), (conv3x3_ws64_kernel<HT, 32>), dim3(T64 < 256u ? T64 : 256u), dim3(512),
+                       (size_t)Ws64Geom<32>::LDS, s, q, (const HT*)src, (const HT*)w, bias, epi_act, (HT*)out);
+        else
+            EVE_LAUNCH(EVE_HNAME(HT, "conv3x3_ws64_kernel<", ", 64>"), (conv3x3_ws64_kernel<HT, 64>), dim3(T64 < 256u ? T64 : 256u), dim3(512),
+                       (size_t)Ws64Geom<64>::LDS, s, q, (const HT*)src, (const HT*)w, bias, epi_act, (HT*)out);
         return true;
     }
     // ---- eight-wave workgroups, 32x32x16 MFMA, staggered wave groups (conv_wg8.h): whole square images per tile ----

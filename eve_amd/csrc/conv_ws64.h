@@ -33,7 +33,7 @@
 namespace eve {
 
 struct Ws64Params {
-    int N;                        // images [N][32][32][64] -> [N][32][32][64]
+    int N;                        // images [N][W][W][64] -> [N][W][W][64], W = 32 | 64
     int flip;                     // 0: forward taps, 1: data-gradient taps (filter position t reads weight tap 8 - t)
     uint32_t x_bytes, w_bytes;
 };
@@ -64,20 +64,35 @@ __device__ __forceinline__ void ws64_mma4(f32x16_t (&acc)[2][2], const u32x4_t (
 #undef EVE_WS64_MMA
 #undef EVE_WS64_MMA0
 
-template <typename H>
+// W = 64 (round 5: layer 1 on 256 x 256 patches, BASELINE configs[4]): the same stream over tiles of 8 rows x 64 columns -- a
+// wave owns ONE image row (its two 32-pixel halves), eight row bands per image, a 10 x 66 halo = 42 pieces per slice: the sixth
+// piece of waves 2..7 does not exist and is sent to a 1 KB dummy slot (every wave issues the same number of DMAs, which the
+// counted waits rely on); 72 KB filters + 2 x 42 KB stages + bias + dummy = 157.25 of the 160 KB.
+template <int W> struct Ws64Geom {
+    static_assert(W == 32 || W == 64, "layer-1 planes of 128 x 128 and 256 x 256 patches");
+    static constexpr int TH = 512 / W, W2 = W + 2, HP = (TH + 2) * W2;   // 612 | 660 halo pixels per tile and slice
+    static constexpr int NP = (HP + 15) / 16;                            // 39 | 42 pieces of 16 pixels
+    static constexpr int AP = (NP + 7) / 8;                              // 5 | 6 per wave
+    static constexpr int ASTAGE = (W == 32 ? AP * 8 : NP) * 1024;        // 40 | 42 KB
+    static constexpr int TPI = W * W / 512;                              // row bands (tiles) per image
+    static constexpr int WBYTES = 2 * 9 * 4096;                          // [slice][filter position][64 rows x 64 B]
+    static constexpr int BIAS_OFF = WBYTES + 2 * ASTAGE, DUMMY_OFF = BIAS_OFF + 256;
+    static constexpr int LDS = DUMMY_OFF + (AP * 8 * 1024 > ASTAGE ? 1024 : 0);
+};
+
+template <typename H, int W>
 __global__ __launch_bounds__(512, 2) void conv3x3_ws64_kernel(const Ws64Params p, const H* __restrict__ x,
                                                               const H* __restrict__ w, const float* __restrict__ bias,
                                                               const int epi_act, H* __restrict__ out) {
-    constexpr int W = 32, TH = 16, W2 = 34, HP = (TH + 2) * W2;   // 612 halo pixels per tile and slice
-    constexpr int AP = 5;                                         // 40 pieces of 16 pixels, 5 per wave
-    constexpr int ASTAGE = AP * 8 * 1024;                         // 40 KB
-    constexpr int WBYTES = 2 * 9 * 4096;                          // [slice][filter position][64 rows x 64 B]
+    using Geo = Ws64Geom<W>;
+    constexpr int TH = Geo::TH, W2 = Geo::W2, HP = Geo::HP, NP = Geo::NP, AP = Geo::AP, ASTAGE = Geo::ASTAGE, TPI = Geo::TPI;
+    constexpr int WBYTES = Geo::WBYTES;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63, l31 = lane & 31, l5 = lane >> 5;
-    const uint32_t G = gridDim.x, T = 2u * (uint32_t)p.N;
+    const uint32_t G = gridDim.x, T = (uint32_t)TPI * (uint32_t)p.N;
     const uint32_t lid = xcd_remap(blockIdx.x, G);
     const eve_int4 rs_x = make_rsrc_words(x, p.x_bytes);
     const eve_int4 rs_w = make_rsrc_words(w, p.w_bytes);
@@ -96,24 +111,26 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws64_kernel(const Ws64Params p
     }
     // ---- halo slots (lane constants): byte offset relative to pixel (row y0, column 0) of the tile's image, validity per band ----
     int a_rel[AP];
-    uint32_t a_ok = 0;                                            // bit 2j: valid in band 0 (rows 0..15), bit 2j+1: band 1
+    uint32_t a_ok = 0;                                            // bit 2j: valid in every band but the first, bit 2j+1: ... but the last
 #pragma unroll
     for (int j = 0; j < AP; ++j) {
         const int hp = (j * 8 + wave) * 16 + (lane >> 2), pc = lane & 3;
         const int hy = hp / W2, hx = hp - hy * W2;
         a_rel[j] = ((hy - 1) * W + (hx - 1)) * 128 + ((pc ^ wg8_key<W>(hy, hx)) << 4);
         const bool col_ok = hp < HP && hx >= 1 && hx <= W;
-        a_ok |= (uint32_t)(col_ok && hy >= 1) << (2 * j);         // band 0: image row y0 - 1 + hy = hy - 1 >= 0
-        a_ok |= (uint32_t)(col_ok && hy <= TH) << (2 * j + 1);    // band 1: 15 + hy <= 31
+        a_ok |= (uint32_t)(col_ok && hy >= 1) << (2 * j);         // first band: image row y0 - 1 + hy = hy - 1 >= 0
+        a_ok |= (uint32_t)(col_ok && hy <= TH) << (2 * j + 1);    // last band: W - TH - 1 + hy <= W - 1
     }
-    auto issue_halo = [&](uint32_t tile, int s, int stage) {      // this wave's 5 pieces of (tile, slice s)
-        const uint32_t n = tile >> 1, band = tile & 1u;
-        const int base = (int)((n * 1024u + band * 512u) * 128u) + s * 64;
+    auto issue_halo = [&](uint32_t tile, int s, int stage) {      // this wave's AP pieces of (tile, slice s)
+        const uint32_t n = tile / TPI, band = tile % TPI;
+        const int base = (int)((n * (uint32_t)(W * W) + band * 512u) * 128u) + s * 64;
         const bool live = tile < T;
+        const uint32_t need = (band == 0 ? 1u : 0u) | (band == TPI - 1 ? 2u : 0u);   // the validity bits this band asks for
 #pragma unroll
         for (int j = 0; j < AP; ++j) {
-            const bool ok = live && ((a_ok >> (2 * j + band)) & 1u);
-            lds_dma16_asm(rs_x, ldsA + stage * ASTAGE + (j * 8 + wave) * 1024, ok ? base + a_rel[j] : EVE_OOB);
+            const bool ok = live && (((a_ok >> (2 * j)) & need) == need) && (((a_ok >> (2 * j)) & 3u) != 0u);
+            const uint32_t dst = (j * 8 + wave) * 1024 < ASTAGE ? ldsA + stage * ASTAGE + (j * 8 + wave) * 1024 : ldsW + Geo::DUMMY_OFF;
+            lds_dma16_asm(rs_x, dst, ok ? base + a_rel[j] : EVE_OOB);
         }
     };
 
@@ -130,7 +147,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws64_kernel(const Ws64Params p
     for (int dx = 0; dx < 3; ++dx)
 #pragma unroll
         for (int kh = 0; kh < 2; ++kh) {
-            const int hy = 2 * wave, hx = l31 + dx;
+            const int hy = (W == 32 ? 2 : 1) * wave, hx = l31 + dx;     // W = 64: the wave's two pixel tiles are the halves of one row
             xrd[dx][kh] = ldsA + (hy * W2 + hx) * 64 + (((2 * kh + l5) ^ wg8_key<W>(hy, hx)) << 4);
         }
 
@@ -143,7 +160,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws64_kernel(const Ws64Params p
     const uint32_t co = (uint32_t)l5 * 32;
     const float floor_v = (epi_act & 0xff) == EVE_ACT_RELU ? 0.f : __builtin_nanf("");   // max(o, floor): ReLU; max(o, NaN) = o
     // bias: 64 floats behind the halo stages, read back 16 at a time by the part that needs them (32 VGPRs otherwise)
-    constexpr int BIAS_OFF = WBYTES + 2 * ASTAGE;
+    constexpr int BIAS_OFF = Geo::BIAS_OFF;
     if (tid < 64) *reinterpret_cast<float*>(smem + BIAS_OFF + tid * 4) = bias ? bias[tid] : 0.f;
     // one accumulator tile (channel tile ct, image row pt of the wave) of a finished tile: 16 channels of one pixel per lane
     // stores are raw-buffer stores: a part that has nothing to store (the first tile of the stream has no predecessor)
@@ -156,7 +173,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws64_kernel(const Ws64Params p
     // transposed 4 x 4 across each lane quad (two DPP butterfly stages): lane q of a quad ends up with chunk q of the quad's
     // pixels m = 0..3, and store m writes 64 contiguous bytes per quad -- 16 requests per instruction instead of 64.
     auto tile_base = [&](uint32_t tile) -> uint32_t {            // byte offset of (tile, this wave's first row, the lane quad's first pixel, lane's chunk)
-        return (((tile >> 1) * 1024u + (tile & 1u) * 512u + (uint32_t)(2 * wave) * 32u + (uint32_t)(l31 & ~3)) * 64u + co) * 2u +
+        // (a tile is 512 consecutive pixels of its image in both geometries; the wave's are 64 w .. 64 w + 63, pixel tile pt the upper 32)
+        return (((tile / TPI) * (uint32_t)(W * W) + (tile % TPI) * 512u + (uint32_t)wave * 64u + (uint32_t)(l31 & ~3)) * 64u + co) * 2u +
                (uint32_t)(l31 & 3) * 16u;
     };
     u32x4_t pk_row[4];
@@ -208,7 +226,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws64_kernel(const Ws64Params p
                     wf[buf][ct] = *reinterpret_cast<const EVE_LDS u32x4_t*>((uintptr_t)(wrd[s][kh] + t * 4096 + ct * 2048));
 #pragma unroll
                 for (int pt = 0; pt < 2; ++pt)
-                    xf[buf][pt] = *reinterpret_cast<const EVE_LDS u32x4_t*>((uintptr_t)(xrd[dx][kh] + s * ASTAGE + (dy + pt) * W2 * 64));
+                    xf[buf][pt] = *reinterpret_cast<const EVE_LDS u32x4_t*>((uintptr_t)(xrd[dx][kh] + s * ASTAGE +
+                                                                                         (W == 32 ? (dy + pt) * W2 * 64 : dy * W2 * 64 + pt * 2048)));
             };
 #pragma unroll
             for (int h = 0; h < NB - 1; ++h) read_step(h, h);

@@ -84,6 +84,7 @@ CONV_CASES = [
     (197, 16, 16, 128, 256, 3, 2, 1),   # layer 3.0
     (395, 8, 8, 256, 512, 3, 2, 1),     # layer 4.0
     (229, 16, 16, 256, 256, 3, 1, 1),   # layer 3 on 256 x 256 patches (configs[4]): conv3x3_wg8_kernel<2, 4, 16>, one image per tile
+    (3, 64, 64, 64, 64, 3, 1, 1),       # layer 1 on 256 x 256 patches (configs[4]): conv3x3_ws64_kernel<.., 64>, 8 row bands per image
 ]
 
 
@@ -391,6 +392,43 @@ def test_streaming_1x1_convolution(hip, ref, hdt, cin, cout):
     hip.conv2d_fwd(dev(x), dev(w), dev(b), 1, 0, accumulate_into=view)
     assert bool((ybuf[N * H * W:] == 7.0).all())
     assert torch.equal(view, got['fwd_acc'])
+
+
+@pytest.mark.parametrize('hdt', [torch.bfloat16, torch.float16], ids=['bf16', 'f16'])
+@pytest.mark.parametrize('N,W', [(1, 32), (37, 64), (300, 32), (1, 64), (67, 64)], ids=lambda v: str(v))
+def test_filter_resident_streaming_convolution_of_layer_one(hip, ref, hdt, N, W):
+    """conv3x3_ws64_kernel (csrc/conv_ws64.h: the 64 -> 64 filter bank resident in LDS, half-image tiles of 32 x 32 planes or
+    8-row bands of 64 x 64 planes streaming under it): forward with bias (+ ReLU) and data gradient against the float reference
+    and against the kernel it replaces on the same inputs (conv_ws64 = 0); one image (fewer tiles than workgroups, a stream of
+    one tile), 37 / 67 images of 64 x 64 (296 / 536 tiles on 256 workgroups: streams of one, two and three tiles, both
+    accumulator sets, the first and the last band's missing halo rows), borders included."""
+    x = rnd((N, W, W, 64), hdt, 91)
+    w = rnd((64, 3, 3, 64), hdt, 92, scale=(2.0 / 576) ** 0.5)
+    b = rnd((64,), torch.float32, 93, scale=0.2)
+    dy = rnd((N, W, W, 64), hdt, 94)
+    w_ihwo = w.permute(3, 1, 2, 0).contiguous()
+
+    def run():
+        out = {}
+        out['fwd'] = hip.conv2d_fwd(dev(x), dev(w), dev(b), 1, 1)
+        used = hip.lib.eve_last_kernel().decode()
+        out['fwd_relu'] = hip.conv2d_fwd(dev(x), dev(w), None, 1, 1, 1)
+        out['dgrad'] = hip.conv2d_dgrad(dev(dy), dev(w_ihwo), (W, W), 1, 1)
+        return out, used, hip.lib.eve_last_kernel().decode()
+    got, used, used_d = run()
+    for u in (used, used_d):
+        assert u.startswith('conv3x3_ws64_kernel<') and u.endswith(', 64>') == (W == 64), u
+    with hip.dispatch_override(conv_ws64=0):
+        old, used_old, _ = run()
+    assert 'ws64' not in used_old
+    want = ref.conv2d_fwd(x.float(), w.float(), b, 1, 1).float()
+    wants = {'fwd': want, 'fwd_relu': ref.conv2d_fwd(x.float(), w.float(), None, 1, 1).float().clamp(min=0),
+             'dgrad': ref.conv2d_dgrad(dy.float(), w_ihwo.float(), (W, W), 1, 1).float()}
+    for name in wants:
+        close(got[name], wants[name].to(hdt), hdt, 'filter-resident 3x3 ' + name, scale=float(wants[name].abs().max()))
+        close(got[name], old[name], hdt, 'filter-resident 3x3 vs the halo kernel: ' + name, scale=float(wants[name].abs().max()))
+    # the same launch twice: no accumulator or stage state leaks between streams
+    assert torch.equal(hip.conv2d_fwd(dev(x), dev(w), dev(b), 1, 1), got['fwd'])
 
 
 @pytest.mark.parametrize('hdt', [torch.bfloat16, torch.float16], ids=['bf16', 'f16'])
