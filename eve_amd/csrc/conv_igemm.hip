@@ -570,7 +570,7 @@ static bool launch_halo(const GatherParams& p, const void* src, const void* w, c
         }
         const uint32_t T64 = (uint32_t)(W * W / 512) * (uint32_t)p.N;
         if (W == 32)
-            EVE_LAUNCH(EVE_HNAME(HT, "conv3x3_ws64_kernel<", ">"), (conv3x3_ws64_kernel<HT, 32>), dim3(T64 < 256u ? T64 : 256u), dim3(512),
+            EVE_LAUNCH(EVE_HNAME(HT, "conv3x3_ws64_kernel<", ", 32>"), (conv3x3_ws64_kernel<HT, 32>), dim3(T64 < 256u ? T64 : 256u), dim3(512),
                        (size_t)Ws64Geom<32>::LDS, s, q, (const HT*)src, (const HT*)w, bias, epi_act, (HT*)out);
         else
             EVE_LAUNCH(EVE_HNAME(HT, "conv3x3_ws64_kernel<", ", 64>"), (conv3x3_ws64_kernel<HT, 64>), dim3(T64 < 256u ? T64 : 256u), dim3(512),

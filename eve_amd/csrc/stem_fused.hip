@@ -753,7 +753,7 @@ __global__ __launch_bounds__(64 * SF_WAVES) void stem_bwd_dx_kernel(const int N,
 // it is multiplied), so dW equals the two-kernel path up to the float summation order.
 // Output: dw [64][7][8][4] float, accumulated (the layout eve_stem_wgrad writes: column kw = 7 and channel 3 do not exist).
 // =================================================================================================
-constexpr int SB_PAIRS = 2;                       // images per workgroup and turn; two workgroups of 4 waves per CU
+constexpr int SB_PAIRS = 2;                       // images per workgroup and turn; two workgroups of 4 waves per CU (the launch names say 2)
 constexpr int SB_DROW = 64;                       // bytes per pixel of the d(conv out) tile: 32 local channels
 constexpr int SB_DTILE = 64 * SB_DROW;            // one conv row of one wave
 constexpr int SB_KBYTES = 4 * 2 * 3 * 16;         // [lg][ntl][{rstd, B, C}][r] floats per wave
@@ -1232,13 +1232,13 @@ extern "C" int eve_stem_bwd_wgrad(int dtype, int N, int IH, int IW, const void* 
         EVE_DISPATCH_H16(dtype, EVE_LAUNCH(EVE_HNAME(H, "stem_grad_prep_kernel<", ">"), stem_grad_prep_kernel<H>, dim3(N), dim3(256), 0,
                                            (hipStream_t)stream, N, PH, (const H*)dy_pool, (const H*)dy_pool2, (const H*)y_pool, mean_rstd, (H*)workspace, kc));
         EVE_CHECK_LAUNCH();
-        EVE_DISPATCH_H16(dtype, EVE_LAUNCH(EVE_HNAME(H, "stem_bwd_wgrad_kernel<", ",prep>"), (stem_bwd_wgrad_kernel<H, SB_PAIRS, true>), dim3(blocks), dim3(128 * SB_PAIRS), lds,
+        EVE_DISPATCH_H16(dtype, EVE_LAUNCH(EVE_HNAME(H, "stem_bwd_wgrad_kernel<", ", 2, true>"), (stem_bwd_wgrad_kernel<H, SB_PAIRS, true>), dim3(blocks), dim3(128 * SB_PAIRS), lds,
                                            (hipStream_t)stream, N, IH, (const H*)x_padded, (uint32_t)xb, (const H*)w_ohwi8, (const float*)kc, (const H*)workspace,
                                            (const H*)nullptr, (const H*)nullptr, idx, dw));
         EVE_CHECK_LAUNCH();
         return 0;
     }
-    EVE_DISPATCH_H16(dtype, EVE_LAUNCH(EVE_HNAME(H, "stem_bwd_wgrad_kernel<", ">"), (stem_bwd_wgrad_kernel<H, SB_PAIRS, false>), dim3(blocks), dim3(128 * SB_PAIRS), lds,
+    EVE_DISPATCH_H16(dtype, EVE_LAUNCH(EVE_HNAME(H, "stem_bwd_wgrad_kernel<", ", 2, false>"), (stem_bwd_wgrad_kernel<H, SB_PAIRS, false>), dim3(blocks), dim3(128 * SB_PAIRS), lds,
                                        (hipStream_t)stream, N, IH, (const H*)x_padded, (uint32_t)xb, (const H*)w_ohwi8, mean_rstd, (const H*)dy_pool,
                                        (const H*)dy_pool2, (const H*)y_pool, idx, dw));
     EVE_CHECK_LAUNCH();

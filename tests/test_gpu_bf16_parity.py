@@ -230,7 +230,7 @@ def test_eyenet_bf16_end_to_end_within_the_bf16_noise_envelope(B, T, seed):
         dev = float((out[k].detach().float().cpu() - fo[k].detach()).pow(2).mean().sqrt())
         print('%s: rms deviation from the faithful oracle %.3e, bf16 noise (faithful vs float32) %.3e' % (k, dev, noise))
         assert dev <= ENVELOPE * noise, '%s: %.3e vs noise %.3e' % (k, dev, noise)
-        assert float((out[k].detach().float().cpu() - fo[k].detach()).abs().max()) <= 3 * ENVELOPE * float((fo[k] - po[k]).abs().max())
+        assert float((out[k].detach().float().cpu() - fo[k].detach()).abs().max()) <= 3 * ENVELOPE * float((fo[k] - po[k]).detach().abs().max())
     lnoise = abs(float(ft['full_loss']) - float(pt['full_loss']))
     assert abs(float(terms['full_loss']) - float(ft['full_loss'])) <= max(3 * lnoise, 5e-3 * abs(float(ft['full_loss'])))
     worst = 0.0
