@@ -611,6 +611,22 @@ static bool launch_halo(const GatherParams& p, const void* src, const void* w, c
             if (W == 16 && p.Cout % 256 == 0) EVE_WG8_LAUNCH(2, 4, 16);
             if (W == 8 && p.Cout % 256 == 0) EVE_WG8_LAUNCH(2, 4, 8);
             if (W == 4 && p.Cout % 256 == 0) EVE_WG8_LAUNCH(2, 4, 4);
+            // 32 x 32 x 128 (the trunk's layer 2 on 256 x 256 patches, BASELINE configs[4]): half-image bands of 16 rows x 128 channels
+            if (W == 32 && p.Cout % 128 == 0) {
+                using G8 = Wg8Geom<4, 2, 32, 2>;
+                static bool attr_done = false;
+                if (!attr_done) {
+                    (void)hipFuncSetAttribute((const void*)conv3x3_wg8_kernel<HT, 4, 2, 32, 9, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                    attr_done = true;
+                }
+                g.tiles_n = (uint32_t)(p.Cout / G8::COUT_T);
+                const uint32_t tiles8 = (uint32_t)p.N * 2u * g.tiles_n;
+                if ((int)tiles8 >= wg8_min_tiles) {
+                    EVE_LAUNCH(EVE_HNAME(HT, "conv3x3_wg8_kernel<", ", 4, 2, 32, 9, 2>"), (conv3x3_wg8_kernel<HT, 4, 2, 32, 9, 2>), dim3(tiles8),
+                               dim3(512), G8::LDS, s, g, (const HT*)src, (const HT*)w, bias, epi_act, (HT*)out);
+                    return true;
+                }
+            }
         }
 #undef EVE_WG8_LAUNCH
     }

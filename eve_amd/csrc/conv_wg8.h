@@ -106,17 +106,21 @@ template <int N> __device__ __forceinline__ void wg8_wait_vm() {
     else asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
 }
 
-template <int WM, int WN, int W> struct Wg8Geom {
+// BANDS > 1 (round 5: 32 x 32 x 128, layer 2 on 256 x 256 patches): the tile's unit is a band of W / BANDS rows of one image instead
+// of a whole image (its halo rows above / below come from the neighbouring bands or are the image border).
+template <int WM, int WN, int W, int BANDS = 1> struct Wg8Geom {
     static constexpr int PIX = 128 * WM, COUT_T = 64 * WN;
-    static constexpr int TI = PIX / (W * W);                         // whole images per tile
-    static constexpr int W2 = W + 2, HPI = W2 * W2, HP = TI * HPI;   // halo pixels per image / per tile
+    static constexpr int TH = W / BANDS, UPIX = TH * W;              // rows / pixels of a unit (whole image or band)
+    static constexpr int TI = PIX / UPIX;                            // units per tile
+    static constexpr int W2 = W + 2, HPI = (TH + 2) * W2, HP = TI * HPI;   // halo pixels per unit / per tile
     static constexpr int APT = (HP + 15) / 16;                       // 1 KB halo pieces per slice
     static constexpr int AP = (APT + 7) / 8;                         // ... per wave
     static constexpr int ASTAGE = AP * 8 * 1024;
     static constexpr int BSLOT = COUT_T * 64;
     static constexpr int BP = COUT_T / 16 / 8;                       // weight pieces per wave and step
     static constexpr int LDS = 2 * ASTAGE + 4 * BSLOT;
-    static_assert(WM * WN == 8 && PIX % (W * W) == 0 && AP <= 7 && BP >= 1 && LDS <= 160 * 1024, "tile geometry");
+    static_assert(WM * WN == 8 && W % BANDS == 0 && PIX % UPIX == 0 && TI >= 1 && (BANDS == 1 || TI == 1) && AP <= 7 && BP >= 1 &&
+                  LDS <= 160 * 1024, "tile geometry");
 };
 
 // NT = 9: the 3x3 convolution.  NT = 2 / 4: the DATA GRADIENT OF A STRIDE-2 3x3 CONVOLUTION (torchvision BasicBlock's first
@@ -125,12 +129,14 @@ template <int WM, int WN, int W> struct Wg8Geom {
 // 2 x 2 (py = 1) window over the SAME halo tile, whose 2 x Cin "output channels" are the column parities px = 0 | 1 of d(x)
 // (px = 0 uses half of those taps: its other weights are zero, 12 of 16 tap-classes do real work).  The launch pair reads dy
 // twice in total (the per-tap kernel: four launches, nine tap passes) and the epilogue scatters depth-to-space.
-template <typename H, int WM, int WN, int W, int NT = 9>
+template <typename H, int WM, int WN, int W, int NT = 9, int BANDS = 1>
 __global__ __launch_bounds__(512, 2) void conv3x3_wg8_kernel(const Wg8Params p, const H* __restrict__ x,
                                                              const H* __restrict__ w, const float* __restrict__ bias,
                                                              const int epi_act, H* __restrict__ out) {
-    using G = Wg8Geom<WM, WN, W>;
+    using G = Wg8Geom<WM, WN, W, BANDS>;
+    static_assert(BANDS == 1 || (NT == 9 && W >= 8), "row bands: the 3x3 convolution on W >= 8");
     constexpr int W2 = G::W2, HPI = G::HPI, HP = G::HP, AP = G::AP, BP = G::BP, ASTAGE = G::ASTAGE, BSLOT = G::BSLOT;
+    constexpr int TH = G::TH, UPIX = G::UPIX;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x;
@@ -152,8 +158,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wg8_kernel(const Wg8Params p, 
         int off = EVE_OOB;
         if (hp < HP) {
             const int ti = hp / HPI, r = hp - ti * HPI, hy = r / W2, hx = r - hy * W2;
-            const int gy = hy - 1, gx = hx - 1;
-            const uint32_t n = n0 + ti;
+            const uint32_t u = n0 + ti, n = u / BANDS;
+            const int gy = (int)(u % BANDS) * TH + hy - 1, gx = hx - 1;
             if (gy >= 0 && gy < W && gx >= 0 && gx < W && n < (uint32_t)p.N)
                 off = (int)((((n * W + gy) * W + gx) * p.Cin) * 2) + ((pc ^ wg8_key<W>(hy, hx)) << 4);
         }
@@ -184,7 +190,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wg8_kernel(const Wg8Params p, 
 #pragma unroll
     for (int pt = 0; pt < 4; ++pt) {
         const int m = wm * 128 + pt * 32 + l31;
-        const int ti = m / (W * W), ty = (m / W) % W, tx = m % W;
+        const int ti = m / UPIX, ty = (m / W) % TH, tx = m % W;
 #pragma unroll
         for (int q = 0; q < 3; ++q) {
             const int hy = W >= 8 ? ty : ty + q, hx = W >= 8 ? tx + q : tx;
@@ -315,8 +321,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wg8_kernel(const Wg8Params p, 
     for (int pt = 0; pt < 4; ++pt) {
         __builtin_amdgcn_sched_barrier(0);                      // one pixel tile at a time: 32 accumulators live, not 128
         const int m = wm * 128 + pt * 32 + l31;
-        const int ti = m / (W * W), pix = m - ti * (W * W);
-        const uint32_t n = n0 + ti;
+        const int ti = m / UPIX;
+        const uint32_t u = n0 + ti, n = u / BANDS;
+        const int pix = m - ti * UPIX + (int)(u % BANDS) * UPIX;      // pixel index inside image n
         u32x4_t pk[4];                                          // the lane's pixel: chunks k = 0..3 of 8 channels
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct)

@@ -85,6 +85,7 @@ CONV_CASES = [
     (395, 8, 8, 256, 512, 3, 2, 1),     # layer 4.0
     (229, 16, 16, 256, 256, 3, 1, 1),   # layer 3 on 256 x 256 patches (configs[4]): conv3x3_wg8_kernel<2, 4, 16>, one image per tile
     (3, 64, 64, 64, 64, 3, 1, 1),       # layer 1 on 256 x 256 patches (configs[4]): conv3x3_ws64_kernel<.., 64>, 8 row bands per image
+    (131, 32, 32, 128, 128, 3, 1, 1),   # layer 2 on 256 x 256 patches (configs[4]): conv3x3_wg8_kernel<4, 2, 32, 9, 2>, half-image bands (262 tiles)
 ]
 
 
@@ -392,6 +393,41 @@ def test_streaming_1x1_convolution(hip, ref, hdt, cin, cout):
     hip.conv2d_fwd(dev(x), dev(w), dev(b), 1, 0, accumulate_into=view)
     assert bool((ybuf[N * H * W:] == 7.0).all())
     assert torch.equal(view, got['fwd_acc'])
+
+
+@pytest.mark.parametrize('hdt', [torch.bfloat16, torch.float16], ids=['bf16', 'f16'])
+@pytest.mark.parametrize('N,cout', [(131, 128), (75, 256)], ids=['131x128', '75x256'])
+def test_eight_wave_convolution_on_half_image_bands(hip, ref, hdt, N, cout):
+    """conv3x3_wg8_kernel<4, 2, 32, 9, 2> (csrc/conv_wg8.h, BANDS = 2): 32 x 32 planes of 128-channel layers (ResNet layer 2 on
+    256 x 256 patches) as half-image bands of 16 rows -- the halo rows between the bands come from the other band, the outer ones
+    are the image border; forward with bias (+ ReLU) and data gradient against the float reference and against the four-wave
+    kernel on the same inputs (conv_wg8 = 0); an odd image count, one and two channel tiles."""
+    x = rnd((N, 32, 32, 128), hdt, 95)
+    w = rnd((cout, 3, 3, 128), hdt, 96, scale=(2.0 / 1152) ** 0.5)
+    b = rnd((cout,), torch.float32, 97, scale=0.2)
+
+    def run():
+        out = {'fwd': hip.conv2d_fwd(dev(x), dev(w), dev(b), 1, 1)}
+        used = hip.lib.eve_last_kernel().decode()
+        out['fwd_relu'] = hip.conv2d_fwd(dev(x), dev(w), None, 1, 1, 1)
+        if cout == 128:
+            dy = rnd((N, 32, 32, 128), hdt, 98)
+            out['dgrad'] = hip.conv2d_dgrad(dev(dy), dev(w.permute(3, 1, 2, 0).contiguous()), (32, 32), 1, 1)
+            assert hip.lib.eve_last_kernel().decode() == used
+        return out, used
+    got, used = run()
+    assert used.startswith('conv3x3_wg8_kernel<') and used.endswith(', 4, 2, 32, 9, 2>'), used
+    with hip.dispatch_override(conv_wg8=0):
+        old, used_old = run()
+    assert 'wg8' not in used_old
+    wants = {'fwd': ref.conv2d_fwd(x.float(), w.float(), b, 1, 1).float(),
+             'fwd_relu': ref.conv2d_fwd(x.float(), w.float(), None, 1, 1).float().clamp(min=0)}
+    if cout == 128:
+        dy = rnd((N, 32, 32, 128), hdt, 98)
+        wants['dgrad'] = ref.conv2d_dgrad(dy.float(), w.permute(3, 1, 2, 0).contiguous().float(), (32, 32), 1, 1).float()
+    for name in wants:
+        close(got[name], wants[name].to(hdt), hdt, 'banded eight-wave 3x3 ' + name, scale=float(wants[name].abs().max()))
+        close(got[name], old[name], hdt, 'banded eight-wave 3x3 vs the four-wave kernel: ' + name, scale=float(wants[name].abs().max()))
 
 
 @pytest.mark.parametrize('hdt', [torch.bfloat16, torch.float16], ids=['bf16', 'f16'])

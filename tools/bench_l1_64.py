@@ -10,9 +10,11 @@ from eve_amd.kernels import HipKernels  # noqa: E402
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 960
 W = int(sys.argv[2]) if len(sys.argv) > 2 else 64
+C = int(sys.argv[3]) if len(sys.argv) > 3 else 64
+KNOB = 'conv_ws64' if C == 64 else 'conv_wg8'
 k = HipKernels()
-x = torch.randn((N, W, W, 64), device='cuda').half()
-w = (torch.randn((64, 3, 3, 64), device='cuda') * 0.05).half()
+x = torch.randn((N, W, W, C), device='cuda').half()
+w = (torch.randn((C, 3, 3, C), device='cuda') * 0.05).half()
 wt = w.permute(3, 1, 2, 0).contiguous()
 
 
@@ -29,9 +31,9 @@ def timeit(fn, reps=10):
     return s.elapsed_time(e) / reps
 
 
-flops = 2.0 * N * W * W * 64 * 64 * 9
+flops = 2.0 * N * W * W * C * C * 9
 for on in (1, 0):
-    with k.dispatch_override(conv_ws64=on):
+    with k.dispatch_override(**{KNOB: on}):
         tf = timeit(lambda: k.conv2d_fwd(x, w, None, 1, 1))
         name = k.lib.eve_last_kernel().decode()
         td = timeit(lambda: k.conv2d_dgrad(x, wt, (W, W), 1, 1))
