@@ -117,12 +117,23 @@ def cpu_baseline_c3(T, steps=3, budget_s=60.0):
                       'B=%d clips x T=%d, %d timed step(s) after 1 warm-up' % (B, T, done)}
 
 
-def pmc_traffic(symbol, suffix='_pmc_hbm_per_kernel.json'):
+def _profiled_shape(command):
+    """(batch, seq, size, dtype) of the workload a profiles/ summary was taken on, from the command line stamped into it (the
+    defaults of bench.py / tools/bench_eve.py where a flag is absent)."""
+    words = (command or '').split()
+    get = lambda flag, dflt: words[words.index(flag) + 1] if flag in words and words.index(flag) + 1 < len(words) else dflt
+    c5 = get('--workload', 'c2') == 'c5'
+    return (int(get('--batch', 8 if c5 else 32)), int(get('--seq', 120 if c5 else 30)), int(get('--size', 256 if c5 else 128)),
+            get('--dtype', 'fp16' if c5 else 'bf16'))
+
+
+def pmc_traffic(symbol, suffix='_pmc_hbm_per_kernel.json', shape=None):
     """HBM bytes per launch of `symbol` from a committed rocprofv3 --pmc summary (two separate passes, FETCH_SIZE and
     WRITE_SIZE, of this same workload; FETCH doubled as MI355X_MICROARCH.md prescribes for wide reads).  Counters cannot be
     collected from inside the timed process, so this is a measured profile from profiles/ -- but ONLY one taken on exactly
-    these kernel sources (tools/pmc_hbm_summary.py stamps eve_amd.build.kernel_tree_sha() into the file); anything else
-    is stale evidence and gives None."""
+    these kernel sources (tools/pmc_hbm_summary.py stamps eve_amd.build.kernel_tree_sha() into the file) AND on the same
+    (batch, seq, size, dtype) as the point that quotes it (`shape`): a symbol's bytes per launch scale with the image count, so
+    the B = 32 profile says nothing about a B = 8 launch of the same symbol.  Anything else gives None."""
     from eve_amd.build import kernel_tree_sha
     here = os.path.dirname(os.path.abspath(__file__))
     sha = kernel_tree_sha()
@@ -136,13 +147,15 @@ def pmc_traffic(symbol, suffix='_pmc_hbm_per_kernel.json'):
             continue
         if (table.get('_meta') or {}).get('kernel_tree_sha') != sha:
             continue
+        if shape is not None and _profiled_shape((table.get('_meta') or {}).get('command')) != tuple(shape):
+            continue
         for k, v in table.items():
             if k.replace('void ', '').strip() == 'eve::' + symbol and v.get('fetch_mb_avg_x2') is not None:
                 return (v['fetch_mb_avg_x2'] + (v.get('write_mb_avg') or 0.0)) * 1024 * 1024, 'profiles/' + name
     return None, None
 
 
-def kernel_roofline(sym, d, mfma_peak, profile_steps, overhead, pmc_suffix=None):
+def kernel_roofline(sym, d, mfma_peak, profile_steps, overhead, pmc_suffix=None, shape=None):
     """Roofline of one kernel symbol from its HIP-event launch durations.  The bound is the roof the kernel's ALGORITHMIC
     intensity puts it under: FLOP per byte (operands read once, result written once) against the ridge mfma_peak / 8 TB/s
     (312 FLOP/B in bf16: ResNet layer 1's 3x3 convolutions sit at 288, layers 2-4 at 575 .. 2 300) -- SURVEY.md 8(d)."""
@@ -151,7 +164,7 @@ def kernel_roofline(sym, d, mfma_peak, profile_steps, overhead, pmc_suffix=None)
     gbs = d['bytes'] / ms / 1e9
     ai = d['flops'] / d['bytes'] if d['bytes'] else float('inf')
     hbm = d['flops'] == 0 or ai < mfma_peak * 1e12 / (HBM_PEAK_GBS * 1e9)
-    traffic, traffic_src = pmc_traffic(sym, suffix=pmc_suffix) if pmc_suffix else pmc_traffic(sym)
+    traffic, traffic_src = pmc_traffic(sym, suffix=pmc_suffix, shape=shape) if pmc_suffix else pmc_traffic(sym, shape=shape)
     r = {'bound': 'hbm' if hbm else 'mfma', 'kernel': 'eve::' + sym,
          'achieved': gbs if hbm else tf, 'peak': HBM_PEAK_GBS if hbm else mfma_peak, 'unit': 'GB/s' if hbm else 'TFLOP/s',
          'frac': (gbs / HBM_PEAK_GBS) if hbm else (tf / mfma_peak), 'traffic': traffic,
@@ -169,7 +182,7 @@ def kernel_roofline(sym, d, mfma_peak, profile_steps, overhead, pmc_suffix=None)
 PIPELINE_GFLOP = {('c3', 128): 2.370 + 9.619, ('c5', 256): 27.8 + 9.619, ('c5', 128): 6.955 + 9.619, ('c3', 256): 9.476 + 9.619}
 
 
-def pipeline_setup(args, device, which, batch_clips, seq, size, dtype_name, use_graph, distributed=False, seed=1):
+def pipeline_setup(args, device, which, batch_clips, seq, size, dtype_name, use_graph, distributed=False, seed=1, rnn='CGRU'):
     """The eve_amd.EVE train step as a (trainer, batch) pair.
     which = 'c3': BASELINE configs[2] -- configs/refine_net.json with refine_net_rnn_type=CGRU: EyeNet frozen and
       forward-only, offset augmentation, gaze geometry, heat-maps, RefineNet trained (fused conv-GRU scan), soft-argmax, the 31
@@ -180,7 +193,7 @@ def pipeline_setup(args, device, which, batch_clips, seq, size, dtype_name, use_
     from eve_amd import synthetic, train
     cfg = eve_amd.reset_standalone_config()
     cfg.import_json(os.path.join(HERE, 'configs', 'refine_net.json'))
-    cfg.import_dict({'refine_net_rnn_type': 'CGRU', 'eye_net_load_pretrained': False})
+    cfg.import_dict({'refine_net_rnn_type': rnn, 'eye_net_load_pretrained': False})
     if which == 'c5':
         cfg.import_dict({'eye_net_frozen': False, 'loss_coeff_g_ang_initial': 1.0, 'loss_coeff_pupil_size': 1.0})
     model = eve_amd.EVE()
@@ -201,13 +214,15 @@ def pipeline_setup(args, device, which, batch_clips, seq, size, dtype_name, use_
     return tr, batch, cfg
 
 
-def bench_pipeline(args, device, k, which, batch_clips, seq, size, dtype_name, steps, warmup):
+def bench_pipeline(args, device, k, which, batch_clips, seq, size, dtype_name, steps, warmup, rnn='CGRU', profile=True):
     """One pipeline operating point on this GPU -> the `c3` / `c5` object of the JSON line: ms/step, frames/s, the HBM roofline
-    of its dominant kernel (RefineNet is HBM-bound by construction)."""
+    of its dominant kernel (RefineNet is HBM-bound by construction).  rnn = 'CLSTM': the cell the reference's
+    shipped src/configs/refine_net.json:55 names (SURVEY 8(d) quotes configs[2] on the CGRU override; `c3_clstm` is the point that
+    shows the shipped configuration is not a slow path)."""
     import numpy as np
     import eve_amd
     use_graph = not args.no_graph
-    tr, batch, cfg = pipeline_setup(args, device, which, batch_clips, seq, size, dtype_name, use_graph)
+    tr, batch, cfg = pipeline_setup(args, device, which, batch_clips, seq, size, dtype_name, use_graph, rnn=rnn)
     np.random.seed(0)
     for _ in range(max(2, warmup)):
         terms = tr.step(batch)
@@ -221,13 +236,15 @@ def bench_pipeline(args, device, k, which, batch_clips, seq, size, dtype_name, s
                    'geometry / heat-maps / soft-argmax / 31 losses, clip, Adam)',
              'c5': 'BASELINE configs[4]: long-sequence stress through eve_amd.EVE, EyeNet AND RefineNet/CGRU trained (refine_net.json '
                    'with the EyeNet losses on), hidden state of all T frames on-chip'}[which]
-    gf = PIPELINE_GFLOP[(which, size)]
+    gf = PIPELINE_GFLOP[(which, size)]        # (CGRU figure; the CLSTM cell's one 128 -> 256 convolution is within 0.1 % of it)
+    if rnn != 'CGRU':
+        label = label.replace('CGRU', rnn)
     out = {'workload': '%s, B=%d x T=%d, %dx%d patches, %s' % (label, batch_clips, seq, size, size, dtype_name),
            'ms_per_step': ms, 'value': batch_clips * seq / (ms * 1e-3), 'unit': 'frames/s', 'steps': steps, 'hip_graph': use_graph,
            'final_loss': float(terms['full_loss'].detach()), 'optimizer': tr.optimizer_state(),
            'step_algorithmic_tflops': gf * batch_clips * seq / (ms * 1e-3) / 1e3}
     out['step_mfma_frac'] = out['step_algorithmic_tflops'] / MFMA_PEAK_TFLOPS[dtype_name]
-    if not args.no_roofline:
+    if profile and not args.no_roofline:
         tr._eager_step(batch)
         torch.cuda.synchronize()
         k.start_profile()
@@ -240,7 +257,7 @@ def bench_pipeline(args, device, k, which, batch_clips, seq, size, dtype_name, s
         # InstanceNorm family: SURVEY 8(d)), and the heaviest one on the MFMA side (the 128-512-channel levels) next to it
         peak = MFMA_PEAK_TFLOPS[dtype_name]
         suffix = '_%s_pmc_hbm_per_kernel.json' % which
-        rl = {s_: kernel_roofline(s_, d, peak, args.profile_steps, overhead, pmc_suffix=suffix)
+        rl = {s_: kernel_roofline(s_, d, peak, args.profile_steps, overhead, pmc_suffix=suffix, shape=(batch_clips, seq, size, dtype_name))
               for s_, d in by_kernel.items() if s_ and d['bytes'] > 0 and d['ms'] > 0}
         # `roofline` = the heaviest symbol by TIME, whichever roof its intensity puts it under; `roofline_other_bound` = the
         # heaviest symbol on the other side of the ridge
@@ -315,18 +332,20 @@ LONG_KEYS = ('kernels_ms_per_step', 'kernel_groups_ms_per_step', 'kernel_groups_
 
 
 def order_line(out):
-    """The JSON line with everything a reader (or a log tail) needs up front: the contract keys, `roofline`, `cpu_baseline`,
-    a `summary` of every operating point (ms per step, frames/s, fraction of the MFMA peak), then the operating points with
-    their long per-kernel maps moved to the end of each object."""
+    """The JSON line ordered for a reader AND for a log tail: the contract keys, `roofline` and `cpu_baseline` lead; the operating
+    points follow with their long per-kernel maps moved to the end of each object; `summary` -- one short object with every
+    operating point's {ms per step, frames/s, fraction of the MFMA peak, its dominant kernel's roofline fraction} -- is the LAST
+    key of the line, because the driver's record keeps a parsed subset plus the last ~1 000 characters."""
+    points = ('c3', 'c3_clstm', 'c5', 'b8', 'fp32', 'fp16')
     summary = {}
-    for key in ('c3', 'c5', 'b8', 'fp32', 'fp16'):
+    for key in points:
         if key in out:
             o = out[key]
-            summary[key] = {'ms_per_step': round(o['ms_per_step'], 3), 'frames_per_s': round(o['value'], 1)}
+            summary[key] = {'ms': round(o['ms_per_step'], 3), 'fps': round(o['value'])}
             if 'step_mfma_frac' in o:
-                summary[key]['step_mfma_frac'] = round(o['step_mfma_frac'], 4)
+                summary[key]['mfma'] = round(o['step_mfma_frac'], 4)
             if 'roofline' in o:
-                summary[key]['roofline'] = {k_: o['roofline'].get(k_) for k_ in ('kernel', 'bound', 'frac')}
+                summary[key]['roof'] = '%s %.3f' % (o['roofline'].get('bound'), o['roofline'].get('frac'))
 
     def tail_long(o):
         if not isinstance(o, dict):
@@ -335,18 +354,21 @@ def order_line(out):
     head = ['metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline',
             'dtype', 'data', 'config', 'roofline', 'cpu_baseline']
     line = {k_: out[k_] for k_ in head if k_ in out}
-    if summary:
-        line['summary'] = summary
-    points = ('c3', 'c5', 'b8', 'fp32', 'fp16')
     for k_, v in out.items():
         if k_ not in line and k_ not in points and k_ not in LONG_KEYS:
             line[k_] = v
-    for k_ in points:
-        if k_ in out:
-            line[k_] = tail_long(out[k_])
     for k_ in LONG_KEYS:
         if k_ in out and k_ not in line:
             line[k_] = out[k_]
+    for k_ in points:
+        if k_ in out:
+            line[k_] = tail_long(out[k_])
+    if summary:
+        groups = out.get('kernel_groups_tflops') or {}
+        if groups:
+            summary['tflops'] = {k_: round(v) for k_, v in groups.items()}
+        line.pop('summary', None)
+        line['summary'] = summary
     return line
 
 
@@ -385,6 +407,11 @@ def main():
     import eve_amd
     from eve_amd import parallel, train
     from eve_amd.kernels import default_kernels
+    import warnings
+    # (the capture's warm-up runs on a side stream by design; torch's per-process warning about it would fill the log tail)
+    warnings.filterwarnings('ignore', message=".*AccumulateGrad node's stream does not match.*")
+    if hasattr(torch.autograd.graph, 'set_warn_on_accumulate_grad_stream_mismatch'):
+        torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)
 
     rank, local_rank, world = parallel.init_distributed()
     if world != args.gpus:
@@ -492,10 +519,11 @@ def main():
             # the dominant KERNEL (one symbol = one row of the rocprofv3 kernel summary in profiles/), by total time
             dom = max(by_kernel, key=lambda t: by_kernel[t]['ms'])
             sfx = None if args.workload == 'c2' else '_%s_pmc_hbm_per_kernel.json' % args.workload
-            out['roofline'] = kernel_roofline(dom, by_kernel[dom], peak, args.profile_steps, event_overhead, pmc_suffix=sfx)
+            shape = (args.batch, args.seq, args.size, args.dtype)
+            out['roofline'] = kernel_roofline(dom, by_kernel[dom], peak, args.profile_steps, event_overhead, pmc_suffix=sfx, shape=shape)
             # ... and the heaviest kernel on the OTHER side of the ridge, so that both roofs are on the line
             for t in sorted(by_kernel, key=lambda t: -by_kernel[t]['ms']):
-                r = kernel_roofline(t, by_kernel[t], peak, args.profile_steps, event_overhead, pmc_suffix=sfx)
+                r = kernel_roofline(t, by_kernel[t], peak, args.profile_steps, event_overhead, pmc_suffix=sfx, shape=shape)
                 if r['bound'] != out['roofline']['bound'] and by_kernel[t]['flops'] > 0:
                     out['roofline_other_bound'] = r
                     break
@@ -508,6 +536,10 @@ def main():
             del trainer, net                      # release the EyeNet trainer's graph pool before the second workload
             torch.cuda.empty_cache()
             out['c3'] = bench_pipeline(args, device, k, 'c3', args.batch, args.seq, 128, args.dtype, max(3, args.steps // 2), args.warmup)
+            if extras and not args.no_points:
+                # the reference's SHIPPED cell (src/configs/refine_net.json:55 "CLSTM"; its hidden state is computed and stored,
+                # the features pass through: refine_net.py:168-174), same pipeline otherwise
+                out['c3_clstm'] = bench_pipeline(args, device, k, 'c3', args.batch, args.seq, 128, args.dtype, 3, 2, rnn='CLSTM', profile=False)
         if extras and not args.no_c5:
             try:
                 del trainer, net
@@ -528,7 +560,7 @@ def main():
             out['fp32'] = eyenet_point(args, device, 'fp32', args.batch, max(3, args.steps // 2), 2, k)
             out['fp16'] = eyenet_point(args, device, 'fp16', args.batch, args.steps, args.warmup, k, profile=False)
         if world == 1 and not args.no_cpu_baseline:
-            # (`cores` = the threads actually used: 32; `host_cpus` = what the box has)
+            # (`cores` = the threads actually used: CPU_BASELINE_THREADS; `host_cpus` = what the box has)
             out['cpu_baseline'] = cpu_baseline(args.seq if args.workload == 'c2' else 30, args.size if args.workload == 'c2' else 128)
             if 'c3' in out:
                 out['c3']['cpu_baseline'] = cpu_baseline_c3(args.seq)

@@ -22,7 +22,8 @@ class DispatchConfig(Structure):
         'struct_bytes', 'conv_impl_v1', 'conv_tile_big', 'conv_halo', 'conv_ws64', 'conv_wg8', 'conv_wg8_min_tiles',
         'conv_wg8_s2_min_tiles', 'halo_persist', 'wgrad_target_wgs', 'wgrad_min_rows', 'wgrad_halo', 'wgrad_wg8',
         'wg64_th', 'wg64_nreg', 'wg64_fixed', 'in_split', 'in_min_threads', 'in_stats_one_pass', 'stem_split',
-        'in_trunk_kernels', 'stem_fused_wgrad', 'stem_fwd_pairs', 'conv1x1_stream', 'conv3x3_stream', 'in_big_planes', 'cgru_seq_max_b')] + [('wgrad_halo_min_m', c_longlong)]
+        'in_trunk_kernels', 'stem_fused_wgrad', 'stem_fwd_pairs', 'conv1x1_stream', 'conv3x3_stream', 'in_big_planes', 'cgru_seq_max_b',
+        'cgru_scan', 'small_linear', 'tail_loss_node', 'bucket_elems', 'gate_wait_polls')] + [('wgrad_halo_min_m', c_longlong)]
 
     def as_dict(self):
         return {n: int(getattr(self, n)) for n, _ in self._fields_ if n != 'struct_bytes'}
@@ -55,7 +56,7 @@ class VecTerm(Structure):
 
 VEC_TERMS_MAX = 32
 PACK_BATCH_MAX = 48
-ABI_VERSION = 8          # include/eve_hip.h EVE_ABI_VERSION
+ABI_VERSION = 9          # include/eve_hip.h EVE_ABI_VERSION
 
 SIGNATURES = {
     'eve_conv2d_fwd': [POINTER(ConvDesc), P, P, P, I, P, I, P, P],
@@ -81,7 +82,7 @@ SIGNATURES = {
     'eve_cgru_scan_bwd': [I, I, I, P, P, P, P, P, P, P, P, P, P, P, P],
     'eve_vector_terms': [POINTER(VecTerm), I, I, I, P, P],
     'eve_gate_signal': [P, P],
-    'eve_gate_wait': [P, c_uint, P, P, P],
+    'eve_gate_wait': [P, c_uint, P, P, P, c_uint, P],
     'eve_crnn_scan_fwd': [I, I, P, P, P, P, P, P, P],
     'eve_crnn_scan_bwd': [I, I, P, P, P, P, P, P, P],
     'eve_clstm_scan_fwd': [I, I, P, P, P, P, P, P, P, P],
@@ -144,7 +145,7 @@ SIGNATURES = {
     'eve_heatmap_loss_fwd': [I, I, I, I, P, P, P, P, P, P, P],
     'eve_heatmap_loss_bwd': [I, I, I, P, P, P, P, P, P],
     'eve_sumsq': [L, P, P, P, P],
-    'eve_adam_step': [L, P, P, P, P, P, F, F, F, F, F, F, F, I, P, I, P, P],
+    'eve_adam_step': [L, P, P, P, P, P, F, F, F, F, F, F, F, I, P, I, P, P, P],
 }
 EXPORTS = sorted(list(SIGNATURES) + ['eve_abi_version', 'eve_last_error', 'eve_last_kernel'])
 

@@ -32,6 +32,7 @@ static eve_dispatch_config default_dispatch_config() {
     c.in_split = 1; c.in_min_threads = 512; c.in_stats_one_pass = 1; c.stem_split = 1; c.in_trunk_kernels = 1; c.stem_fused_wgrad = 1; c.stem_fwd_pairs = 1; c.in_big_planes = 1; c.conv1x1_stream = 1; c.conv3x3_stream = 1;
     c.wgrad_halo_min_m = 1ll << 20;
     c.cgru_seq_max_b = 384;
+    c.cgru_scan = 1; c.small_linear = 1; c.tail_loss_node = 1; c.bucket_elems = 4 * 1024 * 1024; c.gate_wait_polls = 1 << 21;
     return c;
 }
 static void env_int(const char* name, int& field) { if (const char* e = getenv(name)) field = atoi(e); }
@@ -54,9 +55,13 @@ static eve_dispatch_config load_dispatch_config() {
     env_int("EVE_CONV1X1_STREAM", c.conv1x1_stream);
     env_int("EVE_CONV3X3_STREAM", c.conv3x3_stream);
     env_int("EVE_CGRU_SEQ_MAX_B", c.cgru_seq_max_b);
+    env_int("EVE_CGRU_SCAN", c.cgru_scan); env_int("EVE_SMALL_LINEAR", c.small_linear); env_int("EVE_TAIL_LOSS_NODE", c.tail_loss_node);
+    env_int("EVE_BUCKET_ELEMS", c.bucket_elems); env_int("EVE_GATE_WAIT_POLLS", c.gate_wait_polls);
     if (const char* e = getenv("EVE_WGRAD_HALO_MIN_M")) c.wgrad_halo_min_m = atoll(e);
     if (c.wgrad_min_rows < 64) c.wgrad_min_rows = 64;
     if (c.in_min_threads < 64) c.in_min_threads = 64;
+    if (c.bucket_elems < 1) c.bucket_elems = 1;
+    if (c.gate_wait_polls < 1) c.gate_wait_polls = 1;
     return c;
 }
 eve_dispatch_config g_cfg = load_dispatch_config();
@@ -75,6 +80,7 @@ extern "C" int eve_get_default_dispatch_config(eve_dispatch_config* out) {
 extern "C" int eve_set_dispatch_config(const eve_dispatch_config* cfg) {
     if (!cfg || cfg->struct_bytes != (int)sizeof(eve_dispatch_config)) return eve::set_error_msg("set_dispatch_config: struct size mismatch (ABI)");
     if (cfg->wgrad_min_rows < 64 || cfg->in_min_threads < 64) return eve::set_error_msg("set_dispatch_config: wgrad_min_rows / in_min_threads must be >= 64");
+    if (cfg->bucket_elems < 1 || cfg->gate_wait_polls < 1) return eve::set_error_msg("set_dispatch_config: bucket_elems / gate_wait_polls must be >= 1");
     eve::g_cfg = *cfg;
     return 0;
 }

@@ -114,11 +114,15 @@ __global__ __launch_bounds__(256) void conv3x3_stream_kernel(const C3Params p, c
     }
     __syncthreads();
     const int tiles = W >> 4;
-    float st1[NP][8], st2[NP][8];                  // per-lane sums of the STORED (rounded) outputs and of their squares
+    // per-lane sums of the STORED (rounded) outputs and of their squares, both taken about the lane's FIRST value of the channel
+    // (sh): a plane whose mean is far from zero against its spread -- a large bias -- would lose var = E[x^2] - mean^2 to
+    // cancellation in float; the lanes' (mean, M2) pairs are combined pairwise at the end (Chan et al.)
+    float st1[NP][8], st2[NP][8], sh[NP][8];
+    int cnt = 0;                                   // pixels this lane has summed (the same for every lane of the wave)
 #pragma unroll
     for (int a = 0; a < NP; ++a)
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { st1[a][e] = 0.f; st2[a][e] = 0.f; }
+        for (int e = 0; e < 8; ++e) { st1[a][e] = 0.f; st2[a][e] = 0.f; sh[a][e] = 0.f; }
     for (int y = 0; y < Himg; ++y) {
         uint4 qn[LPT];
         load_row(y + 2, qn);                       // (zeros below the image)
@@ -168,7 +172,11 @@ __global__ __launch_bounds__(256) void conv3x3_stream_kernel(const C3Params p, c
                         float ro8[8];
                         Elem<H_>::unpack(qo, ro8);
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) { st1[a][e] += ro8[e]; st2[a][e] += ro8[e] * ro8[e]; }
+                        for (int e = 0; e < 8; ++e) {
+                            if (cnt == 0) sh[a][e] = ro8[e];
+                            const float d = ro8[e] - sh[a][e];
+                            st1[a][e] += d; st2[a][e] += d * d;
+                        }
                     }
                 } else {
                     const int off = (int)(pix * 32u + 8u * g);
@@ -187,10 +195,15 @@ __global__ __launch_bounds__(256) void conv3x3_stream_kernel(const C3Params p, c
                         float ro8[8];
                         Elem<H_>::unpack(q, ro8);
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) { st1[a][e] += ro8[e]; st2[a][e] += ro8[e] * ro8[e]; }
+                        for (int e = 0; e < 4; ++e) {
+                            if (cnt == 0) sh[a][e] = ro8[e];
+                            const float d = ro8[e] - sh[a][e];
+                            st1[a][e] += d; st2[a][e] += d * d;
+                        }
                     }
                 }
             }
+            ++cnt;
         }
         store_row(y + 2, qn);                      // slot of row y - 2: last read in iteration y - 1 (barrier below / above)
         __syncthreads();
@@ -198,18 +211,27 @@ __global__ __launch_bounds__(256) void conv3x3_stream_kernel(const C3Params p, c
     if (p.stats) {
         // plane statistics in a fixed order: 16 pixel lanes of a row (butterfly), then the waves that share a channel slice
         // (the ring is free: every wave is past the loop's last barrier)
-        float* red = reinterpret_cast<float*>(smem);             // [wave][NP][4 g][8 e][2]
+        float* red = reinterpret_cast<float*>(smem);             // [wave][NP][4 g][8 e][{mean, M2, count}]
         constexpr int EV = NT >= 2 ? 8 : 4;
+        const float fc = (float)cnt, rc = cnt > 0 ? 1.f / fc : 0.f;
 #pragma unroll
         for (int a = 0; a < NP; ++a)
 #pragma unroll
             for (int e = 0; e < EV; ++e) {
-                float v1 = st1[a][e], v2 = st2[a][e];
+                // the lane's (mean, M2 = sum of squared deviations from it) over its cnt pixels ...
+                const float d1 = st1[a][e] * rc;
+                float mu = sh[a][e] + d1, m2 = fmaxf(st2[a][e] - st1[a][e] * d1, 0.f), nn = fc;
+                // ... merged with the 15 other pixel lanes of the row group, equal counts at every level
 #pragma unroll
-                for (int m = 1; m < 16; m <<= 1) { v1 += __shfl_xor(v1, m, 64); v2 += __shfl_xor(v2, m, 64); }
+                for (int m = 1; m < 16; m <<= 1) {
+                    const float omu = __shfl_xor(mu, m, 64), om2 = __shfl_xor(m2, m, 64), dl = omu - mu;
+                    m2 = (m2 + om2) + dl * dl * (0.5f * nn);
+                    mu = 0.5f * (mu + omu);
+                    nn *= 2.f;
+                }
                 if (t == 0) {
-                    red[(((wave * NP + a) * 4 + g) * 8 + e) * 2] = v1;
-                    red[(((wave * NP + a) * 4 + g) * 8 + e) * 2 + 1] = v2;
+                    float* r3 = red + (((wave * NP + a) * 4 + g) * 8 + e) * 3;
+                    r3[0] = mu; r3[1] = m2; r3[2] = nn;
                 }
             }
         __syncthreads();
@@ -218,14 +240,19 @@ __global__ __launch_bounds__(256) void conv3x3_stream_kernel(const C3Params p, c
             int a, gg, e;
             if constexpr (NT >= 2) { a = cl >> 5; gg = (cl >> 3) & 3; e = cl & 7; }
             else { a = 0; gg = cl >> 2; e = cl & 3; }
-            float s1 = 0.f, s2 = 0.f;
+            float mu = 0.f, m2 = 0.f, nn = 0.f;
             for (int wv = slice; wv < 4; wv += CS) {               // the waves of this channel slice, in order
-                s1 += red[(((wv * NP + a) * 4 + gg) * 8 + e) * 2];
-                s2 += red[(((wv * NP + a) * 4 + gg) * 8 + e) * 2 + 1];
+                const float* r3 = red + (((wv * NP + a) * 4 + gg) * 8 + e) * 3;
+                const float nb = r3[2];
+                if (nb > 0.f) {
+                    const float nt = nn + nb, dl = r3[0] - mu;
+                    m2 = (m2 + r3[1]) + dl * dl * (nn * nb / nt);
+                    mu += dl * (nb / nt);
+                    nn = nt;
+                }
             }
-            const float inv = 1.f / (float)(Himg * W);
-            const float mean = s1 * inv, var = fmaxf(s2 * inv - mean * mean, 0.f);
-            p.stats[((size_t)n * COUT + c) * 2] = mean;
+            const float var = nn > 0.f ? m2 / nn : 0.f;
+            p.stats[((size_t)n * COUT + c) * 2] = mu;
             p.stats[((size_t)n * COUT + c) * 2 + 1] = rsqrtf(var + p.eps);
         }
     }

@@ -40,7 +40,16 @@ __global__ __launch_bounds__(256) void sumsq_final_kernel(const float* __restric
 // kernel could refuse).  Loss-scale policy (check_finite only): halve after two consecutive skips (floor 1), double after
 // 2 000 consecutive taken steps (ceiling 65 536) -- torch.cuda.amp.GradScaler's shape; the reference is float32 and has none.
 __global__ void adam_prepare_kernel(eve_adam_guard* __restrict__ gd, const float* __restrict__ sumsq, float max_norm, float gscale,
-                                    float b1, float b2, int check_finite) {
+                                    float b1, float b2, int check_finite, const float* __restrict__ poison) {
+    if (poison && !(*poison == 0.f)) {
+        // a stream gate of this step's gradient exchange timed out (gate_wait_kernel): some bucket was all-reduced before its
+        // last gradient was written.  The slot is part of the all-reduced buffer, so EVERY rank reads non-zero here and skips;
+        // nothing else changes (the gradient was not an overflow: the loss scale stays, and so does the run of good steps).
+        gd->skipped_total += 1;
+        gd->skipped_gate += 1;
+        gd->applied = 0.f;
+        return;
+    }
     const float ls = gd->loss_scale > 0.f ? gd->loss_scale : 1.f;
     const float gs = gscale / ls;                      // the gradients in the buffer are loss_scale x the true ones
     float clip = gs;
@@ -104,17 +113,19 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
 // ---- stream gates: a point of one stream's (captured) work releases work queued on another stream --------------------------
 // signal: one release + agent-scope increment of *flag, as a kernel node behind the work it publishes;  wait: one lane polls
 // *flag with relaxed agent-scope loads and s_sleep until it has reached `value` (wrap-safe compare), then acquires.  The poll
-// is BOUNDED (~2^21 sleeps of 64 x 64 clocks: seconds): a gate whose signal never comes counts a time-out and lets the stream
-// go on instead of hanging the device; the host reads *timeouts.
+// is BOUNDED (max_polls sleeps of 64 x 64 clocks; default 2^21: seconds): a gate whose signal never comes counts a time-out,
+// POISONS the step (*poison = +inf: a float inside the last all-reduced gradient bucket, read by adam_prepare_kernel on every
+// rank after the exchange) and lets the stream go on instead of hanging the device; the host reads *timeouts when it likes.
 __global__ void gate_signal_kernel(unsigned* flag) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     __hip_atomic_fetch_add(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-__global__ void gate_wait_kernel(const unsigned* flag, unsigned value, const unsigned* value_ref, unsigned* timeouts) {
+__global__ void gate_wait_kernel(const unsigned* flag, unsigned value, const unsigned* value_ref, unsigned* timeouts, float* poison,
+                                 unsigned max_polls) {
     if (threadIdx.x != 0) return;
     if (value_ref) value = __hip_atomic_load(value_ref, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (written earlier on this stream)
-    for (unsigned it = 0; it < (1u << 21); ++it) {
+    for (unsigned it = 0; it < max_polls; ++it) {
         const unsigned v = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if ((int)(v - value) >= 0) {
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
@@ -123,6 +134,7 @@ __global__ void gate_wait_kernel(const unsigned* flag, unsigned value, const uns
         __builtin_amdgcn_s_sleep(64);
     }
     __hip_atomic_fetch_add(timeouts, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (poison) *poison = __builtin_inff();        // (same stream as the collective that follows: ordinary stream order)
 }
 
 }  // namespace eve
@@ -136,9 +148,11 @@ extern "C" int eve_gate_signal(unsigned* flag, eve_stream_t stream) {
     return 0;
 }
 
-extern "C" int eve_gate_wait(const unsigned* flag, unsigned value, const unsigned* value_ref, unsigned* timeouts, eve_stream_t stream) {
+extern "C" int eve_gate_wait(const unsigned* flag, unsigned value, const unsigned* value_ref, unsigned* timeouts, float* poison,
+                             unsigned max_polls, eve_stream_t stream) {
     if (!flag || !timeouts) return set_error_msg("gate_wait: null pointer");
-    hipLaunchKernelGGL(gate_wait_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, flag, value, value_ref, timeouts);
+    if (max_polls == 0) max_polls = g_cfg.gate_wait_polls > 0 ? (unsigned)g_cfg.gate_wait_polls : (1u << 21);
+    hipLaunchKernelGGL(gate_wait_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, flag, value, value_ref, timeouts, poison, max_polls);
     EVE_CHECK_LAUNCH();
     return 0;
 }
@@ -157,14 +171,15 @@ extern "C" int eve_sumsq(long long n, const float* g, float* out, float* workspa
 extern "C" int eve_adam_step(long long n, float* p, const float* g, float* m, float* v, const float* sumsq,
                              float max_norm, float gscale, float lr, float beta1, float beta2, float eps,
                              float weight_decay, int step, eve_adam_guard* guard, int check_finite, const float* lr_dev,
-                             eve_stream_t stream) {
+                             const float* poison, eve_stream_t stream) {
     if (n <= 0 || !p || !g || !m || !v || (step < 1 && !guard)) return set_error_msg("adam_step: bad arguments");
+    if (poison && !guard) return set_error_msg("adam_step: a poison word needs the device-resident guard");
     const float bc1 = 1.f - powf(beta1, (float)step);
     const float bc2 = sqrtf(1.f - powf(beta2, (float)step));
     long long b = (n + 255) / 256;
     if (b > 2048) b = 2048;
     if (guard)
-        hipLaunchKernelGGL(adam_prepare_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, guard, sumsq, max_norm, gscale, beta1, beta2, check_finite);
+        hipLaunchKernelGGL(adam_prepare_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, guard, sumsq, max_norm, gscale, beta1, beta2, check_finite, poison);
     hipLaunchKernelGGL(adam_kernel, dim3((unsigned)b), dim3(256), 0, (hipStream_t)stream, p, g, m, v, sumsq, max_norm,
                        gscale, lr, beta1, beta2, eps, weight_decay, bc1, bc2, (const eve_adam_guard*)guard, lr_dev, n);
     EVE_CHECK_LAUNCH();

@@ -26,7 +26,7 @@ from torch import nn
 
 from . import ops
 from .config import get_config
-from .kernels import ACT_NONE, ACT_RELU, ACT_SELU, ACT_TANH, HALF_DTYPES, default_kernels, pad_channels
+from .kernels import ACT_NONE, ACT_RELU, ACT_SELU, ACT_TANH, HALF_DTYPES, default_kernels, dispatch_flag, pad_channels
 from .ops import PackedWeight
 
 half_pi = 0.5 * math.pi
@@ -236,7 +236,7 @@ class EyeNet(nn.Module):
         return gaze, p[:, 0], states
 
     # ------------------------------------------------------------------ train step: tail + losses as one node
-    tail_loss_node = os.environ.get('EVE_AMD_TAIL_LOSS_NODE', '1') != '0'
+    tail_loss_node = None        # None: eve_dispatch_config.tail_loss_node (default on); a test sets True / False on the instance
 
     def _tail_loss_node_ok(self, batch, T, feats=None):
         cfg = self.config
@@ -245,7 +245,8 @@ class EyeNet(nn.Module):
             # its outputs would carry no graph -- the per-layer path handles that configuration)
             return False
         k = default_kernels()
-        if not (self.tail_loss_node and hasattr(k, 'tail_outputs_fwd') and torch.is_grad_enabled() and cfg.eye_net_use_rnn and
+        on = self.tail_loss_node if self.tail_loss_node is not None else bool(dispatch_flag(k, 'tail_loss_node', 1))
+        if not (on and hasattr(k, 'tail_outputs_fwd') and torch.is_grad_enabled() and cfg.eye_net_use_rnn and
                 cfg.eye_net_rnn_type == 'GRU' and len(self.rnn_cells) == 1 and cfg.eye_net_use_head_pose_input and
                 not cfg.eye_net_frozen and self.rnn_cells[0].hidden_size == 128 and self.fc_common[0].in_features == 130 and
                 self.cnn_layers.fc.in_features == 512 and T <= 256 and batch['left_eye_patch'].is_cuda and

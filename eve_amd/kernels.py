@@ -76,6 +76,14 @@ class HipKernels(object):
             ws = self._workspaces[key] = torch.empty(self.WORKSPACE_BYTES, dtype=torch.uint8, device=device)
         return ctypes.c_void_p(ws.data_ptr()), ws.numel()
 
+    def prepare_graph_workspace(self, device):
+        """Allocate the scratch of captured launches BEFORE a capture begins: first touched inside one it would come out of the
+        graph's private memory pool and keep that pool's segment alive after the graph is destroyed."""
+        if device.type == 'cuda' and self.WORKSPACE_BYTES > 0:
+            index = device.index if device.index is not None else torch.cuda.current_device()
+            if (index, 'graph') not in self._workspaces:
+                self._workspaces[(index, 'graph')] = torch.empty(self.WORKSPACE_BYTES, dtype=torch.uint8, device=device)
+
     # ------------------------------------------------------------------ kernel selection (eve_dispatch_config)
     def dispatch_config(self):
         c = _lib.DispatchConfig()
@@ -1117,14 +1125,17 @@ class HipKernels(object):
         assert flags.dtype == torch.int32 and flags.is_contiguous() and 0 <= index < flags.numel()
         self._ck(self.lib.eve_gate_signal(ctypes.c_void_p(flags.data_ptr() + 4 * index), self._stream()))
 
-    def gate_wait(self, flags, index, value, timeouts, value_index=None):
+    def gate_wait(self, flags, index, value, timeouts, value_index=None, poison=None, max_polls=0):
         """One-wave kernel on the current stream that returns once flags[index] has reached `value` -- or flags[value_index],
-        read on the device, when value_index is given (a capturable wait: the target is not baked into the node).  Bounded poll:
-        a gate that never opens increments timeouts[0] after a few seconds instead of hanging the device."""
+        read on the device, when value_index is given (a capturable wait: the target is not baked into the node).  Bounded poll
+        (max_polls; 0 = eve_dispatch_config.gate_wait_polls, seconds): a gate that never opens increments timeouts[0] and writes
+        +inf to poison[0] (a float32 tensor inside the last all-reduced gradient bucket: adam_step(poison=...) then skips the
+        update on every rank) instead of hanging the device."""
         assert flags.dtype == timeouts.dtype == torch.int32 and 0 <= index < flags.numel()
+        assert poison is None or (poison.dtype == torch.float32 and poison.numel() >= 1)
         ref = None if value_index is None else ctypes.c_void_p(flags.data_ptr() + 4 * value_index)
         self._ck(self.lib.eve_gate_wait(ctypes.c_void_p(flags.data_ptr() + 4 * index), int(value) & 0xffffffff, ref, self._p(timeouts),
-                                        self._stream()))
+                                        self._p(poison), int(max_polls), self._stream()))
 
     SUMSQ_WORKSPACE = 1024          # include/eve_hip.h EVE_SUMSQ_WORKSPACE
 
@@ -1136,7 +1147,7 @@ class HipKernels(object):
         self._ck(self.lib.eve_sumsq(g.numel(), self._p(self._f32(g, 'g')), self._p(out), self._p(workspace), self._stream()))
         return out
 
-    ADAM_GUARD_WORDS = 12        # include/eve_hip.h eve_adam_guard: 4 ints, then floats (loss_scale at word 4)
+    ADAM_GUARD_WORDS = 12        # include/eve_hip.h eve_adam_guard: 4 ints, then floats (loss_scale at word 4), skipped_gate (int) at word 9
 
     @staticmethod
     def new_adam_guard(device, loss_scale=1.0, step=0):
@@ -1147,12 +1158,23 @@ class HipKernels(object):
         return g
 
     def adam_step(self, p, g, m, v, sumsq, max_norm, gscale, lr, beta1, beta2, eps, weight_decay, step,
-                  guard=None, check_finite=False, lr_dev=None):
+                  guard=None, check_finite=False, lr_dev=None, poison=None):
+        """poison: float32 device word (gate_wait writes +inf there on a time-out); non-zero skips the step on the device."""
         if guard is not None:
             assert guard.dtype == torch.int32 and guard.numel() >= self.ADAM_GUARD_WORDS and guard.is_contiguous()
+        assert poison is None or (guard is not None and poison.dtype == torch.float32)
         self._ck(self.lib.eve_adam_step(p.numel(), self._p(p), self._p(g), self._p(m), self._p(v),
                                         self._p(sumsq), max_norm, gscale, lr, beta1, beta2, eps,
-                                        weight_decay, step, self._p(guard), 1 if check_finite else 0, self._p(lr_dev), self._stream()))
+                                        weight_decay, step, self._p(guard), 1 if check_finite else 0, self._p(lr_dev), self._p(poison),
+                                        self._stream()))
+
+
+def dispatch_flag(k, name, default):
+    """Field `name` of k's kernel-selection table (include/eve_hip.h eve_dispatch_config: resolved once when the library is
+    loaded, overridden only through eve_set_dispatch_config); `default` for a test stand-in that has no table."""
+    if hasattr(k, 'dispatch_config'):
+        return int(getattr(k.dispatch_config(), name))
+    return default
 
 
 _default = None

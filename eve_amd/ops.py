@@ -4,13 +4,12 @@ backward are HIP kernels launched through the C ABI (eve_amd/kernels.py -> inclu
 All activations here are NHWC in the compute dtype.  Autograd is used only to order the backward
 launches and to sum gradient fan-in; no arithmetic on the path is done by ATen.
 """
-import os
 
 import torch
 
 from . import kernels as K
 from .kernels import (ACT_LEAKY, ACT_NONE, ACT_RELU, ACT_SELU, ACT_SIGMOID, ACT_TANH,  # noqa: F401
-                      HALF_DTYPES, default_kernels)
+                      HALF_DTYPES, default_kernels, dispatch_flag)
 
 
 class _LazyGroup(object):
@@ -611,7 +610,7 @@ def linear(x2d, weight, bias, pack, act=ACT_NONE):
     anything else through the implicit-GEMM kernel as a 1x1 conv."""
     M, C = x2d.shape
     if x2d.dtype == torch.float32 and pack.ohwi.dtype == torch.float32 and pack.ihwo is not None \
-            and os.environ.get('EVE_AMD_SMALL_LINEAR', '1') != '0':
+            and dispatch_flag(default_kernels(), 'small_linear', 1):
         return LinearFn.apply(x2d, weight, bias, pack, act)
     y = Conv2dFn.apply(x2d.view(M, 1, 1, C), weight, bias, pack, 1, 0, act)
     return y.view(M, y.shape[-1])
@@ -800,14 +799,33 @@ class ResNetTrunkFn(torch.autograd.Function):
         return (dx, None, None, None, None) + tuple(grads)
 
 
+def _affine_direct(k, gamma_p, beta_p):
+    """True when an affine InstanceNorm's (d gamma, d beta) are ADDED IN PLACE into the trainer's flat gradient buffer."""
+    return (gamma_p is not None and beta_p is not None and _direct_grad_ok(gamma_p) and _direct_grad_ok(beta_p) and
+            hasattr(k, 'sum_rows_pairs') and gamma_p.grad.is_contiguous() and beta_p.grad.is_contiguous())
+
+
+def _note_affine_use(k, gamma_p, beta_p, want_gamma, want_beta):
+    """Forward-side twin of _affine_grads' in-place route: count this use (see _note_use), so that a parameter pair that
+    normalises several times per step -- the per-frame contract: RefineNet.forward() once per time step -- reports to the
+    data-parallel bookkeeping after its LAST backward, not its first."""
+    if _affine_direct(k, gamma_p, beta_p):
+        _note_use(gamma_p, want_gamma)
+        _note_use(beta_p, want_beta)
+
+
 def _affine_grads(k, sums, gamma_p, beta_p):
     """(d gamma, d beta) of an affine InstanceNorm from the backward kernel's per-plane partials `sums` [N, C, 2] = (d beta, d
     gamma): added in place into the flat gradient buffer when both parameters live there (-> (None, None); the autograd
     route returned two strided views and paid one accumulate launch per parameter: ~80 launches per configs[2] step), else two
     fresh vectors for autograd."""
-    if (gamma_p is not None and beta_p is not None and _direct_grad_ok(gamma_p) and _direct_grad_ok(beta_p) and
-            hasattr(k, 'sum_rows_pairs') and sums.dim() == 3 and gamma_p.grad.is_contiguous() and beta_p.grad.is_contiguous()):
-        k.sum_rows_pairs(sums, beta_p.grad, gamma_p.grad)
+    if _affine_direct(k, gamma_p, beta_p):
+        if sums.dim() == 3:
+            k.sum_rows_pairs(sums, beta_p.grad, gamma_p.grad)
+        else:
+            s = k.sum_rows(sums)
+            gamma_p.grad.add_(s[:, 1])
+            beta_p.grad.add_(s[:, 0])
         _notify_grad_ready(gamma_p)
         _notify_grad_ready(beta_p)
         return None, None
@@ -833,6 +851,7 @@ class InstNormActFn(torch.autograd.Function):
             y = k.instnorm_act_fwd(x, mr, g, b, res, act)
         ctx.act, ctx.has_res, ctx.has_affine = act, res is not None, gamma is not None
         ctx.affine_params = (gamma, beta)
+        _note_affine_use(k, gamma, beta, ctx.needs_input_grad[1], ctx.needs_input_grad[2])
         # the backward needs y only to evaluate act'; without a residual it recomputes that from x (the register-resident
         # kernel does so only when there is no affine either)
         need_y = act != ACT_NONE and res is not None       # (else both backward kernels recompute act' from x: gamma / beta given)
@@ -878,6 +897,7 @@ class InstNormActSkipFn(torch.autograd.Function):
             y = k.instnorm_act_fwd(x, mr, g, b, None, act)
         ctx.act = act
         ctx.affine_params = (gamma, beta)
+        _note_affine_use(k, gamma, beta, ctx.needs_input_grad[1], ctx.needs_input_grad[2])
         ctx.save_for_backward(x, mr, g, b)
         return y, x.view_as(x)
 
@@ -916,6 +936,8 @@ class InstNormAct2Fn(torch.autograd.Function):
         out_a, out_b = k.instnorm_act2_fwd(xs, mrs, ga, ba, gb, bb, act)      # both sources, both heads: one launch
         ctx.act, ctx.n = act, len(xs)
         ctx.affine_params = (gamma_a, beta_a, gamma_b, beta_b)
+        _note_affine_use(k, gamma_a, beta_a, ctx.needs_input_grad[2], ctx.needs_input_grad[3])
+        _note_affine_use(k, gamma_b, beta_b, ctx.needs_input_grad[4], ctx.needs_input_grad[5])
         ctx.save_for_backward(ga, ba, gb, bb, *xs, *mrs)
         return out_a, out_b
 
@@ -1275,7 +1297,7 @@ class CGRUScanFn(torch.autograd.Function):
     """hs[:, t] = CGRUCell(xs[:, t], hs[:, t-1]) for the whole clip in ONE launch (kernels.cgru_scan_fwd: hidden state
     resident in LDS, both gate convolutions and their sigmoid / tanh / blend epilogues fused; common.py:388-415 applied
     per frame by refine_net.py:132-176).  The backward is one persistent launch as well (kernels.cgru_scan_bwd: frames in
-    reverse, gate gradients + both data-gradient GEMMs + the carry into the previous state fused; EVE_AMD_CGRU_SCAN_BWD=0
+    reverse, gate gradients + both data-gradient GEMMs + the carry into the previous state fused; eve_dispatch_config.cgru_scan = 2
     selects the per-frame kernels on time-major tensors); the two weight gradients and bias gradients are ONE batched
     launch each over all T*B frames."""
 
@@ -1303,7 +1325,7 @@ class CGRUScanFn(torch.autograd.Function):
         xs_tm = xs.transpose(0, 1).contiguous()
         first = h0 if h0 is not None else torch.zeros_like(xs_tm[0])
         want_dh0 = bool(ctx.has_h0 and need[5])
-        if hasattr(k, 'cgru_scan_bwd') and os.environ.get('EVE_AMD_CGRU_SCAN_BWD', '1') != '0':
+        if hasattr(k, 'cgru_scan_bwd') and dispatch_flag(k, 'cgru_scan', 1) != 2:
             # the whole frame-reversed recursion in one persistent launch (kernels.cgru_scan_bwd): gate gradients, both
             # data-gradient GEMMs, the carry into the previous state; gradients of the two pre-activations come back for
             # the batched weight / bias gradients below

@@ -37,13 +37,21 @@ def init_distributed(backend=None):
 class GradSync(object):
     """Bucketed, backward-overlapped all-reduce(sum) of a flat gradient buffer."""
 
-    def __init__(self, flat_grad, entries, bucket_elems=None, group=None):
-        """entries: list of (param, offset, numel) in flat order (forward order of the network)."""
+    default_bucket_elems = None      # None: eve_dispatch_config.bucket_elems (4 Mi floats); tests shrink it on the class
+
+    def __init__(self, flat_grad, entries, bucket_elems=None, group=None, poison=None):
+        """entries: list of (param, offset, numel) in flat order (forward order of the network).
+        poison: a one-element float view INSIDE flat_grad below the first entry (train.FlatParameters keeps four leading pad
+        floats) -- it travels with the last bucket's all-reduce; a gate that times out writes +inf there (launch_gated)."""
         self.flat_grad = flat_grad
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         if bucket_elems is None:
-            bucket_elems = int(os.environ.get('EVE_AMD_BUCKET_ELEMS', str(4 * 1024 * 1024)))
+            bucket_elems = self.default_bucket_elems
+        if bucket_elems is None:
+            from .kernels import default_kernels, dispatch_flag
+            bucket_elems = dispatch_flag(default_kernels(), 'bucket_elems', 4 * 1024 * 1024)
+        self.poison = poison
         # walk back-to-front, closing a bucket once it holds >= bucket_elems
         self.buckets = []            # dicts: lo, hi, params, pending
         hi = flat_grad.numel()
@@ -108,8 +116,14 @@ class GradSync(object):
     #  * the JOIN stays outside the graph.  Gate-wait nodes INSIDE the replay, waiting for "bucket reduced" words the
     #    communication stream would signal (with clip + Adam captured behind them), ran into their time-outs: RCCL's own
     #    stream shared the replay's hardware queue on the test box, so the spinning node blocked the collective it waited
-    #    for.  The same aliasing could in principle hit the communication stream itself on another box: the trainer checks
-    #    the time-out counter after its first replays and falls back to "collectives behind the replay" (disable_gating).
+    #    for.  The same aliasing could in principle hit the communication stream itself on another box, and a gate can also
+    #    run into its bound later in a run (a pre-empted queue, a stalled peer).  A gate that gives up therefore POISONS the
+    #    step on the device: it writes +inf into `poison`, a pad float at the head of the flat gradient buffer that the LAST
+    #    bucket's all-reduce carries, so that after the exchange every rank holds a non-zero value there and the Adam guard
+    #    skips the update on every rank alike (eve_adam_step(.., poison); counted in eve_adam_guard.skipped_gate) -- the
+    #    all-reduce that ran on a half-written bucket is never applied.  The trainer reads that counter after its first
+    #    replays and every `gate_check_every` steps; it is the same number on every rank, so all ranks fall back to
+    #    "collectives behind the replay" (disable_gating) at the same step.
     def prepare_marks(self):
         """Allocate the gate words.  Call BEFORE the capture begins: an allocation inside the capture would come from the graph's
         private pool and its zero-fill would become a node of the graph -- every replay would then reset the words it is
@@ -141,12 +155,16 @@ class GradSync(object):
             k = default_kernels()
             main = torch.cuda.current_stream()
             self._replays += 1
+            # the bucket that carries the poison word (lo == 0: the last one) goes last, behind every gate that could poison
+            last = self.buckets[-1]
+            order = [b for b in self._gated if b is not last] + [b for b in self._gated if b is last]
             with torch.cuda.stream(self._comm):
-                for b in self._gated:
+                for b in order:
                     if self._flags is not None:
-                        k.gate_wait(self._flags, self.buckets.index(b), self._replays, self._timeouts)
+                        k.gate_wait(self._flags, self.buckets.index(b), self._replays, self._timeouts, poison=self.poison)
                     self._launch(b)
             rest = [b for b in self.buckets if not b['launched'] and b['hi'] > b['lo']]
+            rest = [b for b in rest if b is not last] + [b for b in rest if b is last]
             if rest:
                 self._comm.wait_stream(main)
                 with torch.cuda.stream(self._comm):
@@ -161,8 +179,10 @@ class GradSync(object):
 
     def disable_gating(self):
         """Fall back to "collectives behind the whole replay": every bucket is launched once the replay has finished (the mode
-        of round 4).  The trainer does this when a gate of the first replays ran into its time-out -- the communication stream
-        shares a hardware queue with the replay on this box, so its spinning gate-wait blocked the very work it waits for."""
+        of round 4), in self.buckets order -- the same on every rank.  The trainer does this when the Adam guard has counted a
+        poisoned step (a gate ran into its time-out: e.g. the communication stream shares a hardware queue with the replay on
+        this box, so its spinning gate-wait blocked the very work it waits for); that count is identical on all ranks, so they
+        switch at the same step."""
         self._gated = []
 
     def gate_timeouts(self):

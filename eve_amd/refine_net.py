@@ -17,7 +17,6 @@ is per-sample) and runs only the 64x5x8 conv-RNN sequentially.
 
 nn.Conv2d / nn.InstanceNorm2d objects are PARAMETER HOLDERS; their ATen forward is never called.
 """
-import os
 
 import torch
 from torch import nn
@@ -25,7 +24,7 @@ from torch import nn
 from . import ops
 from .config import get_config
 from .eye_net import default_compute_dtype
-from .kernels import ACT_LEAKY, ACT_NONE, ACT_RELU, ACT_TANH, HALF_DTYPES, default_kernels, pad_channels
+from .kernels import ACT_LEAKY, ACT_NONE, ACT_RELU, ACT_TANH, HALF_DTYPES, default_kernels, dispatch_flag, pad_channels
 from .ops import PackedWeight
 
 
@@ -336,7 +335,7 @@ class RefineNet(nn.Module):
         # one cell on the model's 5 x 8 x 64 bottleneck: the whole clip goes through it in ONE persistent launch (hidden state
         # resident in LDS); CGRU in the 16-bit formats on cgru_scan.hip, CGRU in float32 and CRNN / CLSTM in any format on the
         # float32 scans of cell_scan_f32.hip (round 5; the per-frame loop below remains for stacked cells / other geometries)
-        scan = (len(cells) == 1 and tuple(xs.shape[2:]) == (5, 8, 64) and os.environ.get('EVE_AMD_CGRU_SCAN', '1') != '0' and
+        scan = (len(cells) == 1 and tuple(xs.shape[2:]) == (5, 8, 64) and dispatch_flag(default_kernels(), 'cgru_scan', 1) != 0 and
                 xs.dtype in HALF_DTYPES + (torch.float32,))
         if scan:
             cell, name = cells[0], '%s.rnn_cells.0' % prefix

@@ -19,7 +19,11 @@ from .parallel import GradSync
 
 
 class FlatParameters(object):
-    """Moves every parameter of `modules` into one flat buffer (and its gradient into another)."""
+    """Moves every parameter of `modules` into one flat buffer (and its gradient into another).  The buffers start with LEAD
+    pad floats (zero weights with zero gradients): grad[0] is the data-parallel exchange's POISON word -- inside the last
+    gradient bucket, written by a stream gate that timed out, read by the Adam guard (parallel.GradSync.launch_gated)."""
+
+    LEAD = 4
 
     def __init__(self, modules, device=None):
         params, seen = [], set()
@@ -31,14 +35,15 @@ class FlatParameters(object):
         if not params:
             raise ValueError('no trainable parameters')
         device = device or params[0].device
-        total = sum(p.numel() for p in params)
+        total = self.LEAD + sum(p.numel() for p in params)
         total_padded = (total + 3) // 4 * 4
         self.flat = torch.zeros(total_padded, dtype=torch.float32, device=device)
         self.grad = torch.zeros(total_padded, dtype=torch.float32, device=device)
         self.m = torch.zeros(total_padded, dtype=torch.float32, device=device)
         self.v = torch.zeros(total_padded, dtype=torch.float32, device=device)
         self.entries = []
-        off = 0
+        off = self.LEAD
+        self.poison = self.grad[0:1]
         with torch.no_grad():
             for p in params:
                 n = p.numel()
@@ -110,7 +115,7 @@ class Trainer(object):
         self.lr_schedule = lr_schedule
         self.lr = float(config.learning_rate)
         self.lr_dev = torch.full((1,), self.lr, dtype=torch.float32, device=dev)
-        self.sync = GradSync(self.fp.grad, self.fp.entries) if distributed else None
+        self.sync = GradSync(self.fp.grad, self.fp.entries, poison=self.fp.poison) if distributed else None
         self.step_count = 0
         self.beta1, self.beta2, self.eps = 0.9, 0.999, 1e-8      # torch.optim.Adam defaults (train.py:49-55)
         self.use_graph = bool(use_graph)
@@ -123,7 +128,9 @@ class Trainer(object):
         self.graph_collectives = bool(graph_collectives) and self.sync is not None and dist.is_initialized() and \
             dist.get_backend() == 'nccl'
         self._graph = None
-        self._gate_checks = 2
+        self._gate_checks = 2         # replays after a capture whose gate outcome is read back (a host sync each) ...
+        self.gate_check_every = 64    # ... and then every this many steps
+        self._gate_skips_seen = 0
         self._static_batch = None
         self._static_terms = None
         self.pre_step = None          # optional host-side hook run at the top of every step(batch), before capture / replay
@@ -159,13 +166,15 @@ class Trainer(object):
             k.sumsq(self.fp.grad, self.sumsq, self.sumsq_ws)
         k.adam_step(self.fp.flat, self.fp.grad, self.fp.m, self.fp.v, self.sumsq if need_norm else None,
                     float(cfg.gradient_clip_amount) if by_norm else 0.0, gscale, self.lr, self.beta1, self.beta2,
-                    self.eps, float(cfg.weight_decay), 0, guard=self.guard, check_finite=self.check_overflow, lr_dev=self.lr_dev)
+                    self.eps, float(cfg.weight_decay), 0, guard=self.guard, check_finite=self.check_overflow, lr_dev=self.lr_dev,
+                    poison=self.fp.poison if self.sync is not None and self.fp.poison.is_cuda else None)
         self._invalidate()
 
     def optimizer_state(self):
         """Host view of the device-resident optimiser state (synchronises): steps taken, steps skipped, loss scale."""
         g = self.guard.cpu()
-        return {'steps_taken': int(g[0]), 'steps_skipped': int(g[1]), 'loss_scale': float(g.view(torch.float32)[4])}
+        return {'steps_taken': int(g[0]), 'steps_skipped': int(g[1]), 'loss_scale': float(g.view(torch.float32)[4]),
+                'steps_skipped_gate_timeout': int(g[9])}
 
     def set_lr(self, lr):
         """Learning rate of the next step(s): written to the device scalar the (possibly graph-captured) Adam kernel reads."""
@@ -200,8 +209,14 @@ class Trainer(object):
         # place, or a resident synthetic batch) the per-step device-to-device copy of the clips (378 MB at B=32) is then gone
         alias = getattr(self, 'static_inputs', 'copy') == 'alias'
         self._static_batch = {k: (v if alias else v.clone()) if isinstance(v, torch.Tensor) else v for k, v in batch.items()}
-        side = torch.cuda.Stream()
+        # ONE warm-up stream per device for the life of the process: the kernels' scratch is keyed by stream and never freed, so a
+        # fresh stream per capture (several trainers in one process, re-captures) would pin another workspace each time
+        dev_index = self.fp.flat.device.index if self.fp.flat.device.index is not None else torch.cuda.current_device()
+        side = _WARMUP_STREAMS.get(dev_index)
+        if side is None:
+            side = _WARMUP_STREAMS[dev_index] = torch.cuda.Stream(device=dev_index)
         side.wait_stream(torch.cuda.current_stream())
+        self._gate_checks = 2
         # two eager warm-up passes (allocator, lazy initialisation) off the default stream, as capture requires; they
         # must not train: parameters, moments and the step counter are put back afterwards, so the first replay IS the
         # first optimiser step (one update on the first batch, exactly like the eager path and the reference).
@@ -218,6 +233,9 @@ class Trainer(object):
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self._graph = torch.cuda.CUDAGraph()
+        k = default_kernels()
+        if hasattr(k, 'prepare_graph_workspace'):
+            k.prepare_graph_workspace(self.fp.flat.device)     # the captured launches' scratch: from the ordinary pool, not the graph's
         if self.sync is not None and not self.graph_collectives:
             self.sync.prepare_marks()                          # gate words: allocated and zeroed OUTSIDE the capture
             torch.cuda.synchronize()
@@ -269,21 +287,29 @@ class Trainer(object):
             self._graph.replay()
             if self.sync is not None and not self.graph_collectives:
                 self._gated_collective_and_update()
-                if self._gate_checks > 0:
-                    # the first replays are checked (a host sync each): a gate that timed out means the gate kernels cannot
-                    # run beside the replay on this box (stream -> hardware queue aliasing); the collectives then follow the replay
-                    self._gate_checks -= 1
-                    if self.sync.gate_timeouts() > 0:
+                if self._gate_checks > 0 or (self.gate_check_every and (self.step_count + 1) % self.gate_check_every == 0):
+                    # A gate that timed out has poisoned its step on the device: the Adam guard skipped it on EVERY rank (the
+                    # poison word rides in the last bucket's all-reduce), nothing wrong was applied.  What is left for the host
+                    # is the policy: the first replays after a capture and every gate_check_every-th step read the guard's count
+                    # (a host sync); it is the same number on all ranks, so they all fall back to "collectives behind the whole
+                    # replay" at the same step -- e.g. on a box whose communication stream shares a hardware queue with the replay.
+                    self._gate_checks = max(0, self._gate_checks - 1)
+                    skips = int(self.guard[9].item())
+                    if skips > self._gate_skips_seen:
                         import sys
-                        print('eve_amd: a gradient-bucket gate timed out; the all-reduces are issued behind the whole replay '
-                              'from now on (no overlap with backward)', file=sys.stderr)
+                        print('eve_amd: %d step(s) skipped because a gradient-bucket gate timed out; the all-reduces are issued '
+                              'behind the whole replay from now on (no overlap with backward)' % (skips - self._gate_skips_seen),
+                              file=sys.stderr)
+                        self._gate_skips_seen = skips
                         self.sync.disable_gating()
-                        self._gate_checks = 0
             self.step_count += 1
             return self._static_terms
         finally:
             if self.post_step is not None:
                 self.post_step(batch)
+
+
+_WARMUP_STREAMS = {}      # device index -> the side stream every Trainer's capture warm-up runs on
 
 
 def _resolve_schedule(config, lr_schedule, steps_per_epoch):

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define EVE_ABI_VERSION 8
+#define EVE_ABI_VERSION 9
 
 typedef void* eve_stream_t; /* hipStream_t */
 
@@ -81,6 +81,11 @@ typedef struct eve_dispatch_config {
     int conv3x3_stream;            /* EVE_CONV3X3_STREAM    1   3x3 / stride 1 between 16..64 channels on 64 / 128-wide images: row-streaming kernel */
     int in_big_planes;             /* EVE_IN_BIG_PLANES     1   register-resident InstanceNorm (no affine) for planes beyond 8 192 vectors, dealt by channels */
     int cgru_seq_max_b;            /* EVE_CGRU_SEQ_MAX_B    384 16-bit conv-GRU clip scans: one sequence per workgroup (cgru_scan1.hip) up to this many sequences, three per workgroup (cgru_scan.hip) beyond */
+    int cgru_scan;                 /* EVE_CGRU_SCAN         1   conv-RNN bottleneck as ONE clip-long launch per direction (0: per-frame launches; bit 1 cleared = 2: forward scan only, per-frame backward) */
+    int small_linear;              /* EVE_SMALL_LINEAR      1   float32 nn.Linear of the tail on the small-tile FMA kernels (linear_small.hip)  */
+    int tail_loss_node;            /* EVE_TAIL_LOSS_NODE    1   EyeNet tail + losses as one autograd node (ops.EyeTailLossFn)                   */
+    int bucket_elems;              /* EVE_BUCKET_ELEMS      4194304  floats per data-parallel gradient bucket (parallel.GradSync)              */
+    int gate_wait_polls;           /* EVE_GATE_WAIT_POLLS   1<<21    polls (64 x 64 clocks apart) before a stream gate gives up and poisons the step */
     long long wgrad_halo_min_m;    /* EVE_WGRAD_HALO_MIN_M  1<<20 pixels from which the band-resident weight gradient runs */
 } eve_dispatch_config;
 int eve_get_dispatch_config(eve_dispatch_config* out);           /* what the entry points use now                         */
@@ -522,10 +527,14 @@ int eve_linear_wgrad_batch(const eve_wgrad_problem* problems, int n, eve_stream_
  * OTHER stream that polls *flag until it has reached `value` (the replay count) -- or *value_ref when value_ref != NULL: a
  * device word, which is what lets the wait itself be a node of the graph (the replay's first node counts the replays there, and
  * the graph's clip + Adam nodes sit behind gate-waits for the "bucket reduced" words the communication stream signals) --
- * bounded: after ~seconds it increments *timeouts and returns, so a missing signal cannot hang the device.  flag / timeouts /
- * value_ref: device words, zeroed by the caller.                                                                              */
+ * bounded: after max_polls polls (0: eve_dispatch_config.gate_wait_polls, ~seconds) it increments *timeouts, writes +inf to
+ * *poison (when not NULL) and returns, so a missing signal cannot hang the device -- and cannot be trained on either (ABI v9):
+ * `poison` is a float the caller keeps INSIDE the last gradient bucket it all-reduces, so after the collectives every rank
+ * holds a non-zero value there and eve_adam_step(.., poison) skips the update on every rank alike (the all-reduce that ran on
+ * the half-written bucket is discarded with it).  flag / timeouts / value_ref: device words, zeroed by the caller.           */
 int eve_gate_signal(unsigned* flag, eve_stream_t stream);
-int eve_gate_wait(const unsigned* flag, unsigned value, const unsigned* value_ref, unsigned* timeouts, eve_stream_t stream);
+int eve_gate_wait(const unsigned* flag, unsigned value, const unsigned* value_ref, unsigned* timeouts, float* poison,
+                  unsigned max_polls, eve_stream_t stream);
 
 /* out[0] += sum g^2 (caller zeroes out[0]; take sqrt on the host or in eve_adam_step).  Fixed summation order: the
  * result is bit-reproducible, so data-parallel replicas clip by the identical factor.  workspace: EVE_SUMSQ_WORKSPACE
@@ -543,7 +552,8 @@ typedef struct eve_adam_guard {
     float applied;        /* 1 if the last call updated the weights, 0 if it skipped                                        */
     float clip;           /* factor the last taken step applied to the stored gradient (1/loss_scale and the norm clip)     */
     float bc1, bc2_sqrt;  /* bias corrections of the last taken step                                                        */
-    float reserved[3];
+    int skipped_gate;     /* calls skipped because *poison != 0: a gradient bucket's stream gate timed out (ABI v9); also in skipped_total */
+    float reserved[2];
 } eve_adam_guard;
 /* clip factor c = min(1, max_norm / (sqrt(*sumsq) * gscale' + 1e-6)) if sumsq != NULL and max_norm > 0, else 1;
  * g' = c * gscale' * g + wd * p;  m,v Adam moments;  p -= lr * mhat / (sqrt(vhat) + eps).
@@ -551,11 +561,13 @@ typedef struct eve_adam_guard {
  * guard != NULL: gscale' = gscale / guard->loss_scale, t = ++guard->step; with check_finite a non-finite *sumsq (an
  *   overflowed float16 gradient) SKIPS the step: weights, moments and guard->step stay, guard->skipped_* count it and the
  *   loss scale backs off (see eve_adam_guard).  The learning rate is `lr`, or *lr_dev (device float) when lr_dev != NULL: the
- *   LR schedule of src/core/training.py:382-418,436-442 writes *lr_dev before each (possibly replayed) step.               */
+ *   LR schedule of src/core/training.py:382-418,436-442 writes *lr_dev before each (possibly replayed) step.
+ *   poison != NULL (guard required): *poison != 0 (or NaN) -- a stream gate of this step's gradient exchange timed out,
+ *   eve_gate_wait -- SKIPS the step like a non-finite norm does, counted in guard->skipped_gate; the loss scale is left alone. */
 int eve_adam_step(long long n, float* p, const float* g, float* m, float* v, const float* sumsq,
                   float max_norm, float gscale, float lr, float beta1, float beta2, float eps,
                   float weight_decay, int step, eve_adam_guard* guard, int check_finite, const float* lr_dev,
-                  eve_stream_t stream);
+                  const float* poison, eve_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -89,7 +89,7 @@ def build(case, device, dtype, base_lr=None):
 def worker(rank, world, port, tmp, case, device, dtype, use_graph, backend='gloo'):
     _paths()
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
-                      LOCAL_RANK=str(rank), EVE_AMD_BUCKET_ELEMS='1000000', EVE_AMD_DIST_BACKEND=backend)
+                      LOCAL_RANK=str(rank), EVE_AMD_DIST_BACKEND=backend)
     if backend == 'gloo':
         os.environ['EVE_AMD_FORCE_DEVICE'] = '0'          # every rank on GPU 0; RCCL ('nccl') needs a device per rank
     else:
@@ -101,6 +101,7 @@ def worker(rank, world, port, tmp, case, device, dtype, use_graph, backend='gloo
     torch.set_num_threads(2)
     import torch.distributed as dist
     from eve_amd import parallel
+    parallel.GradSync.default_bucket_elems = 1000000          # several buckets on these small batches
     install_kernels('cpu' if device == 'cpu' else 'cuda')
     r, _, w = parallel.init_distributed(backend=backend)
     assert (r, w) == (rank, world) and dist.get_backend() == backend
@@ -129,12 +130,13 @@ def worker_rccl(rank, port, tmp, case, dtype, use_graph, steps):
     the communication stream, their ordering against clip + Adam, and (use_graph) their coexistence with hipGraph replay."""
     _paths()
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK='0', WORLD_SIZE='1', LOCAL_RANK='0',
-                      EVE_AMD_BUCKET_ELEMS='1000000', EVE_AMD_FORCE_DIST='1', HSA_ENABLE_IPC_MODE_LEGACY='0')
+                      EVE_AMD_FORCE_DIST='1', HSA_ENABLE_IPC_MODE_LEGACY='0')
     os.environ.pop('EVE_AMD_DIST_BACKEND', None)
     if use_graph == 'captured':                # the bucket all-reduces inside the hipGraph as well
         os.environ['EVE_AMD_GRAPH_COLLECTIVES'] = '1'
     import torch.distributed as dist
     from eve_amd import parallel
+    parallel.GradSync.default_bucket_elems = 1000000
     install_kernels('cuda')
     r, _, w = parallel.init_distributed(backend='nccl')
     assert (r, w) == (0, 1) and dist.get_backend() == 'nccl'
@@ -151,6 +153,63 @@ def worker_rccl(rank, port, tmp, case, dtype, use_graph, steps):
                 'buckets': len(tr.sync.buckets)}, os.path.join(tmp, 'rccl.pt'))
     dist.barrier()
     dist.destroy_process_group()
+
+
+def worker_gate_timeout(rank, port, tmp):
+    """One RCCL rank, hipGraph replay + gated collectives, and a bucket whose ready signal comes LATE in one step: the capture
+    holds a long sleep in front of one bucket's gate-signal node; while the gates wait with their default bound (seconds) the
+    step is a normal one, with the bound cut below the sleep (eve_dispatch_config.gate_wait_polls) the gate gives up, the
+    all-reduce runs on the half-written bucket -- and the step must NOT be applied: the gate poisons it, the Adam guard skips."""
+    _paths()
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK='0', WORLD_SIZE='1', LOCAL_RANK='0',
+                      EVE_AMD_FORCE_DIST='1', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    os.environ.pop('EVE_AMD_DIST_BACKEND', None)
+    os.environ.pop('EVE_AMD_GRAPH_COLLECTIVES', None)
+    import torch.distributed as dist
+    from eve_amd import parallel
+    from eve_amd.kernels import default_kernels
+    parallel.GradSync.default_bucket_elems = 1000000
+    install_kernels('cuda')
+    parallel.init_distributed(backend='nccl')
+    cfg, make, full = build('eyenet', 'cuda', 'bf16', 1e-3)
+    tr = make(True, True)
+    k = default_kernels()
+    late = tr.sync.buckets[1]
+    plain_launch = tr.sync._launch
+
+    def launch(b):
+        if tr.sync._marking and b is late and not b['launched']:
+            torch.cuda._sleep(300_000_000)                  # ~0.15 s in front of this bucket's gate-signal node, every replay
+        plain_launch(b)
+    tr.sync._launch = launch
+    batch = {kk: v.to('cuda') for kk, v in full.items()}
+    rec = {}
+    tr.step(batch)                                          # capture + replay 1
+    tr.step(batch)                                          # replay 2: default bound, the gates sit the sleep out
+    torch.cuda.synchronize()
+    rec['after_two'] = dict(tr.optimizer_state(), timeouts=tr.sync.gate_timeouts(), gated=len(tr.sync._gated))
+    before = tr.fp.flat.clone()
+    m_before = tr.fp.m.clone()
+    tr.gate_check_every = 1
+    with k.dispatch_override(gate_wait_polls=2000):         # a few ms: far above this tiny backward, far below the sleep
+        tr.step(batch)
+        torch.cuda.synchronize()
+    rec['after_late'] = dict(tr.optimizer_state(), timeouts=tr.sync.gate_timeouts(), gated=len(tr.sync._gated),
+                             weights_unchanged=bool(torch.equal(tr.fp.flat, before) and torch.equal(tr.fp.m, m_before)),
+                             poison=float(tr.fp.poison[0]))
+    tr.step(batch)                                          # the trainer has fallen back: collectives behind the replay
+    torch.cuda.synchronize()
+    rec['after_fallback'] = dict(tr.optimizer_state(), timeouts=tr.sync.gate_timeouts(), gated=len(tr.sync._gated),
+                                 weights_moved=bool(not torch.equal(tr.fp.flat, before)), launch_counts=list(tr.sync.launch_counts))
+    torch.save(rec, os.path.join(tmp, 'gate.pt'))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def run_gate_timeout(tmp):
+    import torch.multiprocessing as mp
+    mp.spawn(worker_gate_timeout, args=(free_port(), tmp), nprocs=1, join=True)
+    return torch.load(os.path.join(tmp, 'gate.pt'))
 
 
 def run_rccl_single_rank(tmp, case, dtype, use_graph):

@@ -466,14 +466,19 @@ class FakeKernels(object):
         return g
 
     def adam_step(self, p, g, m, v, sumsq, max_norm, gscale, lr, beta1, beta2, eps, weight_decay, step,
-                  guard=None, check_finite=False, lr_dev=None):
-        """include/eve_hip.h eve_adam_step, guard semantics included (skip on a non-finite norm, the step counter advancing
-        only on taken steps, loss-scale back-off / growth)."""
+                  guard=None, check_finite=False, lr_dev=None, poison=None):
+        """include/eve_hip.h eve_adam_step, guard semantics included (skip on a non-finite norm or a poisoned gradient exchange,
+        the step counter advancing only on taken steps, loss-scale back-off / growth)."""
         if lr_dev is not None:
             lr = float(lr_dev)
         clip = gscale
         if guard is not None:
             gf = guard.view(torch.float32)
+            if poison is not None and not (float(poison[0]) == 0.0):
+                guard[1] += 1
+                guard[9] += 1
+                gf[5] = 0.0
+                return
             ls = float(gf[4]) if float(gf[4]) > 0 else 1.0
             gs = gscale / ls
             clip = gs

@@ -79,11 +79,66 @@ def test_gate_signal_node_releases_a_side_stream_during_the_running_replay():
         assert float(out[0]) == want and float(out[-1]) == want, (it, float(out[0]), want)
         assert t0.elapsed_time(t_side) < 0.6 * t0.elapsed_time(t_main), (t0.elapsed_time(t_side), t0.elapsed_time(t_main))
     assert int(flags[1]) == 4 and int(timeouts[0]) == 0
-    # a gate nobody signals: bounded, the stream goes on and the time-out is counted
+    # a gate nobody signals: bounded, the stream goes on, the time-out is counted and the step is poisoned (ABI v9)
+    poison = torch.zeros(4, dtype=torch.float32, device=dev)
     with torch.cuda.stream(side):
-        k.gate_wait(flags, 0, 1, timeouts)
+        k.gate_wait(flags, 0, 1, timeouts, poison=poison[1:2], max_polls=500)
     torch.cuda.synchronize()
-    assert int(timeouts[0]) == 1
+    assert int(timeouts[0]) == 1 and poison.tolist() == [0.0, float('inf'), 0.0, 0.0]
+    # ... and a gate that opens leaves the poison word alone
+    with torch.cuda.stream(side):
+        k.gate_wait(flags, 1, 4, timeouts, poison=poison[0:1], max_polls=500)
+    torch.cuda.synchronize()
+    assert int(timeouts[0]) == 1 and float(poison[0]) == 0.0
+
+
+def test_adam_guard_skips_a_poisoned_step():
+    """eve_adam_step(.., poison): a non-zero poison word (a gate of the gradient exchange timed out) leaves weights, moments and
+    the step counter alone and counts the skip -- on the device, no host decision involved; zero poison = the ordinary step."""
+    import torch
+    from eve_amd.kernels import HipKernels
+    k = HipKernels()
+    dev = torch.device('cuda', 0)
+    torch.manual_seed(0)
+    n = 10_000
+    p, g = torch.randn(n, device=dev), torch.randn(n, device=dev)
+    m, v = torch.zeros(n, device=dev), torch.zeros(n, device=dev)
+    ss = torch.zeros(1, device=dev)
+    k.sumsq(g, ss)
+    guard = k.new_adam_guard(dev)
+    poison = torch.zeros(1, device=dev)
+    p0 = p.clone()
+    for bad in (float('inf'), float('nan'), 3.0):
+        poison.fill_(bad)
+        k.adam_step(p, g, m, v, ss, 5.0, 1.0, 1e-2, 0.9, 0.999, 1e-8, 0.0, 0, guard=guard, poison=poison)
+    torch.cuda.synchronize()
+    assert torch.equal(p, p0) and float(m.abs().max()) == 0.0 and float(v.abs().max()) == 0.0
+    gl = guard.cpu()
+    assert (int(gl[0]), int(gl[1]), int(gl[9])) == (0, 3, 3) and float(gl.view(torch.float32)[5]) == 0.0
+    poison.zero_()
+    k.adam_step(p, g, m, v, ss, 5.0, 1.0, 1e-2, 0.9, 0.999, 1e-8, 0.0, 0, guard=guard, poison=poison)
+    torch.cuda.synchronize()
+    gl = guard.cpu()
+    assert (int(gl[0]), int(gl[1]), int(gl[9])) == (1, 3, 3) and not torch.equal(p, p0)
+    q, m2, v2, g2 = p0.clone(), torch.zeros_like(m), torch.zeros_like(v), k.new_adam_guard(dev)
+    k.adam_step(q, g, m2, v2, ss, 5.0, 1.0, 1e-2, 0.9, 0.999, 1e-8, 0.0, 0, guard=g2)
+    assert torch.equal(q, p)                      # the same update as without a poison word
+
+
+@pytest.mark.timeout(600)
+def test_late_gate_signal_poisons_the_step_and_the_trainer_falls_back(tmp_path):
+    """VERDICT r5 item 4 / ADVICE r5: a gate that times out in the middle of a run (here: a 0.15 s stall in front of one bucket's
+    signal node and a bound of a few ms for ONE step) used to let the all-reduce run on the half-written bucket and the step be
+    applied.  Now the gate poisons the step: weights and moments are untouched, the guard counts it (steps_skipped == 1), and the
+    trainer -- which reads that count, the same on every rank -- falls back to collectives behind the replay and trains on."""
+    rec = dp_common.run_gate_timeout(str(tmp_path))
+    a, b, c = rec['after_two'], rec['after_late'], rec['after_fallback']
+    assert a['steps_taken'] == 2 and a['steps_skipped'] == 0 and a['timeouts'] == 0 and a['gated'] >= 3, a
+    assert b['steps_taken'] == 2 and b['steps_skipped'] == 1 and b['steps_skipped_gate_timeout'] == 1, b
+    assert b['timeouts'] >= 1 and b['weights_unchanged'] and b['poison'] == float('inf'), b
+    assert b['gated'] == 0                                      # the policy switched right after the poisoned step
+    assert c['steps_taken'] == 3 and c['steps_skipped'] == 1 and c['timeouts'] == b['timeouts'] and c['weights_moved'], c
+    assert all(n == 1 for n in c['launch_counts']), c
 
 
 @pytest.mark.timeout(900)

@@ -1239,16 +1239,18 @@ def test_batched_vector_terms_match_the_tensor_expressions(B, T):
 @pytest.mark.parametrize('geom', [(8, 72, 128), (29, 37, 64)], ids=['72x128', '37x64'])
 @pytest.mark.parametrize('cin,cout', [(16, 16), (16, 32), (32, 16), (32, 32), (16, 64), (64, 16), (32, 64), (32, 128), (64, 64)],
                          ids=lambda v: str(v))
-def test_convolution_epilogue_emits_instancenorm_statistics(hip, hdt, geom, cin, cout):
+@pytest.mark.parametrize('offset', [3.0, 60.0], ids=['bias3', 'bias60'])
+def test_convolution_epilogue_emits_instancenorm_statistics(hip, hdt, geom, cin, cout, offset):
     """Round 5: eve_conv2d_fwd_stats -- the row-streaming 3x3 kernel walks whole images, so it forms the InstanceNorm statistics
     (mean, rstd per plane, on the STORED values) of its output in its epilogue and the consumer's statistics pass is dropped
     (refine_net.py:45-53: every convolution of a pre-activation block is followed by InstanceNorm2d).  Against eve_instnorm_stats
-    on the output it wrote, with a bias large against the spread (the one-pass sum of squares must survive mean >> std); a shape
-    the kernel does not serve reports "not written" and gives the plain convolution."""
+    on the output it wrote, with a bias large against the spread -- 5 and (round 6) ~100 standard deviations: the sums
+    are taken about each lane's first value and merged as (mean, M2) pairs, a plain E[x^2] - mean^2 in float does not survive the
+    second case; a shape the kernel does not serve reports "not written" and gives the plain convolution."""
     N, H, W = geom
     x = rnd((N, H, W, cin), hdt, 91)
     w = rnd((cout, 3, 3, cin), hdt, 92, scale=(2.0 / (9 * cin)) ** 0.5)
-    b = rnd((cout,), torch.float32, 93, scale=0.2) + 3.0
+    b = rnd((cout,), torch.float32, 93, scale=0.2) + offset
     y, mr = hip.conv2d_fwd_stats(dev(x), dev(w), dev(b), 1, 1)
     used = hip.lib.eve_last_kernel().decode()
     plain = hip.conv2d_fwd(dev(x), dev(w), dev(b), 1, 1)

@@ -147,15 +147,15 @@ def test_fused_cgru_scan_kernel_matches_per_step_path(B, T, with_h0, per_wg):
         assert float(d.max()) < 3e-2 and float(d.mean()) < 2e-3, (name, float(d.max()), float(d.mean()))
 
 
-def test_refinenet_fused_scan_trains_like_the_per_step_path(monkeypatch):
-    """RefineNet bf16 forward + backward with the fused conv-GRU scan vs EVE_AMD_CGRU_SCAN=0: heat-maps and gradients."""
+def test_refinenet_fused_scan_trains_like_the_per_step_path():
+    """RefineNet bf16 forward + backward with the fused conv-GRU scan vs eve_dispatch_config.cgru_scan = 0: heat-maps and gradients."""
     rb = detweights.refinenet_batch(3, 4, seed=3)
     outs = {}
     for mode in ('1', '0'):
-        monkeypatch.setenv('EVE_AMD_CGRU_SCAN', mode)
-        net, _ = make_net('CGRU', dtype=torch.bfloat16)
-        hf, states = net.forward_sequence(rb['heatmap_initial'].cuda(), rb['screen_frame'].cuda())
-        (hf.float() * rb['heatmap_final_gt'].cuda()).sum().backward()
+        with hip.dispatch_override(cgru_scan=int(mode)):
+            net, _ = make_net('CGRU', dtype=torch.bfloat16)
+            hf, states = net.forward_sequence(rb['heatmap_initial'].cuda(), rb['screen_frame'].cuda())
+            (hf.float() * rb['heatmap_final_gt'].cuda()).sum().backward()
         outs[mode] = (hf.detach().float().cpu(), states[0].detach().float().cpu(),
                       {n: p.grad.detach().float().cpu() for n, p in net.named_parameters()})
     a, b = outs['1'], outs['0']
@@ -321,16 +321,16 @@ def test_float32_clip_scans_match_the_per_frame_contract(B, T, with_h0):
 
 @pytest.mark.parametrize('kind', ['CGRU', 'CRNN', 'CLSTM'])
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
-def test_refinenet_clip_scans_train_like_the_per_frame_path(monkeypatch, kind, dtype):
-    """RefineNet forward + backward through the clip-long scans vs EVE_AMD_CGRU_SCAN=0 (the per-frame launches), every cell
-    type, float32 (tight) and bf16 (CRNN / CLSTM: the float32 scan behind 16-bit convolutions)."""
+def test_refinenet_clip_scans_train_like_the_per_frame_path(kind, dtype):
+    """RefineNet forward + backward through the clip-long scans vs eve_dispatch_config.cgru_scan = 0 (the per-frame launches),
+    every cell type, float32 (tight) and bf16 (CRNN / CLSTM: the float32 scan behind 16-bit convolutions)."""
     rb = detweights.refinenet_batch(3, 4, seed=3)
     outs = {}
     for mode in ('1', '0'):
-        monkeypatch.setenv('EVE_AMD_CGRU_SCAN', mode)
-        net, _ = make_net(kind, dtype=dtype)
-        hf, states = net.forward_sequence(rb['heatmap_initial'].cuda(), rb['screen_frame'].cuda())
-        (hf.float() * rb['heatmap_final_gt'].cuda()).sum().backward()
+        with hip.dispatch_override(cgru_scan=int(mode)):
+            net, _ = make_net(kind, dtype=dtype)
+            hf, states = net.forward_sequence(rb['heatmap_initial'].cuda(), rb['screen_frame'].cuda())
+            (hf.float() * rb['heatmap_final_gt'].cuda()).sum().backward()
         st = states[0]
         outs[mode] = (hf.detach().float().cpu(), [t.detach().float().cpu() for t in (st if isinstance(st, tuple) else (st,))],
                       {n: p.grad.detach().float().cpu() for n, p in net.named_parameters() if p.grad is not None})

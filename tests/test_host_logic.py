@@ -39,7 +39,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), name
     lib.eve_abi_version.restype = ctypes.c_int
-    assert lib.eve_abi_version() == _lib.ABI_VERSION == 8
+    assert lib.eve_abi_version() == _lib.ABI_VERSION == 9
     # kernel selection is resolved once at load (include/eve_hip.h eve_dispatch_config): with a clean environment the loaded
     # table IS the default table, the Python mirror of the struct has the library's size, and a wrong-sized struct is refused
     for n in ('eve_get_dispatch_config', 'eve_get_default_dispatch_config', 'eve_set_dispatch_config'):
@@ -544,7 +544,7 @@ def test_gradient_bucket_plan_matches_the_survey(fake):
     last = [names[id(p)] for p in sync.buckets[-1]['params']]
     assert 'cnn_layers.conv1.weight' in last                                      # the stem's gradient is ready last
     # RefineNet (configs[2]): 5.27 M parameters -> the 4 M-element default gives two buckets; the DP step of configs[3]
-    # lowers the bucket size so that the transfer still overlaps backward (EVE_AMD_BUCKET_ELEMS), 3-5 buckets at 1.5 M
+    # lowers the bucket size so that the transfer still overlaps backward (eve_dispatch_config.bucket_elems), 3-5 buckets at 1.5 M
     cfg = eve_amd.reset_standalone_config()
     cfg.import_dict({'load_screen_content': True, 'refine_net_enabled': True, 'refine_net_rnn_type': 'CGRU'})
     ref = eve_amd.RefineNet()
@@ -599,16 +599,59 @@ def test_trainer_factories_take_the_reference_schedule_and_the_fp16_loss_scale(f
         return terms
     t3 = train.Trainer([n3], cfg, loss_fn, loss_scale=1024.0)
     t3.step(batch)
-    assert t3.optimizer_state() == {'steps_taken': 1, 'steps_skipped': 0, 'loss_scale': 1024.0}
+    assert t3.optimizer_state() == {'steps_taken': 1, 'steps_skipped': 0, 'loss_scale': 1024.0, 'steps_skipped_gate_timeout': 0}
     w1, m1 = t3.fp.flat.clone(), t3.fp.m.clone()
     poison['on'] = True
     t3.step(batch)
     t3.step(batch)
     assert torch.equal(t3.fp.flat, w1) and torch.equal(t3.fp.m, m1)
-    assert t3.optimizer_state() == {'steps_taken': 1, 'steps_skipped': 2, 'loss_scale': 512.0}
+    assert t3.optimizer_state() == {'steps_taken': 1, 'steps_skipped': 2, 'loss_scale': 512.0, 'steps_skipped_gate_timeout': 0}
     poison['on'] = False
     t3.step(batch)
     assert t3.optimizer_state()['steps_taken'] == 2 and not torch.equal(t3.fp.flat, w1) and torch.isfinite(t3.fp.flat).all()
     from eve_amd import checkpoint
     assert float(checkpoint.adam_state_dict(t3)['state'][0]['step']) == 2.0          # steps taken, not step() calls (4)
+    # ---- a POISONED gradient exchange (a stream gate of the data-parallel replay timed out: parallel.GradSync.launch_gated) is
+    # skipped the same way, without touching the loss scale: the poison word is the first of FlatParameters' leading pad floats,
+    # inside the last bucket, so every rank reads it after the all-reduce (stand-in semantics = csrc/optim.hip adam_prepare_kernel)
+    assert train.FlatParameters.LEAD == 4 and t3.fp.entries[0][1] == 4 and t3.fp.poison.data_ptr() == t3.fp.grad.data_ptr()
+    k = kernels.default_kernels()
+    w2, st = t3.fp.flat.clone(), t3.optimizer_state()
+    t3.fp.poison.fill_(float('inf'))
+    k.adam_step(t3.fp.flat, t3.fp.grad, t3.fp.m, t3.fp.v, None, 0.0, 1.0, 1e-3, 0.9, 0.999, 1e-8, 0.0, 0, guard=t3.guard, poison=t3.fp.poison)
+    assert torch.equal(t3.fp.flat, w2)
+    assert t3.optimizer_state() == dict(st, steps_skipped=st['steps_skipped'] + 1, steps_skipped_gate_timeout=1)
+    t3.step(batch)                                                                   # zero_grad clears the word: training goes on
+    assert float(t3.fp.poison[0]) == 0.0 and t3.optimizer_state()['steps_taken'] == 3
     eve_amd.reset_standalone_config()
+
+
+def test_gated_launch_order_puts_the_poison_bucket_last():
+    """parallel.GradSync.launch_gated: whatever order the ready points were captured in, the bucket that carries the poison word
+    (lo == 0) is all-reduced behind every gate that could still write it, and a fall-back issues self.buckets order on every rank."""
+    from eve_amd.parallel import GradSync
+    flat = torch.zeros(4 + 3000)
+    ps = [torch.nn.Parameter(torch.zeros(1000)) for _ in range(3)]
+    sync = GradSync(flat, [(p, 4 + 1000 * i, 1000) for i, p in enumerate(ps)], bucket_elems=1000, poison=flat[0:1])
+    assert [(b['lo'], b['hi']) for b in sync.buckets] == [(2004, 3004), (1004, 2004), (0, 1004)]
+    calls = []
+    sync.active = True
+    sync._flags = None
+    sync._comm = None
+    sync._launch = lambda b: (calls.append(sync.buckets.index(b)), b.__setitem__('launched', True))
+
+    class _Ctx(object):
+        def __enter__(self): return self
+        def __exit__(self, *a): return False
+    import unittest.mock as um
+    with um.patch('torch.cuda.stream', lambda s: _Ctx()), um.patch('torch.cuda.current_stream', lambda: um.MagicMock()):
+        sync._comm = um.MagicMock()
+        sync._gated = [sync.buckets[2], sync.buckets[0]]          # captured order: the poison bucket reported FIRST
+        sync.launch_gated()
+    # gated buckets first, the poison bucket behind the other GATED one; bucket 1 never reported, follows the whole replay ungated
+    assert calls == [0, 2, 1], calls
+    calls.clear()
+    with um.patch('torch.cuda.stream', lambda s: _Ctx()), um.patch('torch.cuda.current_stream', lambda: um.MagicMock()):
+        sync.disable_gating()                                     # the fall-back: self.buckets order, poison bucket last
+        sync.launch_gated()
+    assert calls == [0, 1, 2], calls
