@@ -508,6 +508,7 @@ def main():
                                                     ('eager RCCL launches behind gate kernels released by signal nodes of the running hipGraph replay (overlapped with backward)' if use_graph else 'eager, overlapped with backward')),
             'ranks_seen': ranks_seen, 'optimizer': trainer.optimizer_state(),
             'gate_timeouts': (trainer.sync.gate_timeouts() if getattr(trainer, 'sync', None) is not None else None),
+            'comm_stream_runs_beside_replay': (trainer.sync.overlaps if getattr(trainer, 'sync', None) is not None else None),
             'kernel_tree_sha': __import__('eve_amd.build', fromlist=['kernel_tree_sha']).kernel_tree_sha(),
             'dispatch_config_is_default': k.dispatch_config().as_dict() == k.default_dispatch_config().as_dict(),
         }

@@ -45,10 +45,20 @@ def needs_build():
     return any(os.path.getmtime(p) > t for p in sources() + headers())
 
 
-def build(force=False, verbose=True):
-    """hipcc --offload-arch=gfx950 -O3 -c csrc/X.hip (each) ; hipcc -shared -> eve_amd/lib/libeve_hip.so"""
+def build(force=False, verbose=True, variant=None, extra_flags=()):
+    """hipcc --offload-arch=gfx950 -O3 -c csrc/X.hip (each) ; hipcc -shared -> eve_amd/lib/libeve_hip.so
+    variant: a tuning experiment's second library, eve_amd/lib/libeve_hip_<variant>.so built with `extra_flags` on top (objects
+    in lib/obj_<variant>/); load it for an A/B on one box with EVE_HIP_LIB=<path> (eve_amd/_lib.py).  Not the product build."""
+    if variant:
+        return _build_into(os.path.join(LIB_DIR, 'libeve_hip_%s.so' % variant), os.path.join(LIB_DIR, 'obj_' + variant), True, verbose,
+                           list(extra_flags))
     if not force and not needs_build():
         return LIB_PATH
+    return _build_into(LIB_PATH, OBJ_DIR, force, verbose, [])
+
+
+def _build_into(LIB_PATH, OBJ_DIR, force, verbose, extra):
+    FLAGS = globals()['FLAGS'] + extra
     os.makedirs(OBJ_DIR, exist_ok=True)
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
     hdr_time = max(os.path.getmtime(p) for p in headers())
@@ -82,4 +92,8 @@ def build(force=False, verbose=True):
 
 if __name__ == '__main__':
     import sys
-    build(force='--force' in sys.argv)
+    if '--variant' in sys.argv:          # python -m eve_amd.build --variant NAME -flag ...
+        i = sys.argv.index('--variant')
+        print(build(variant=sys.argv[i + 1], extra_flags=sys.argv[i + 2:]))
+    else:
+        build(force='--force' in sys.argv)

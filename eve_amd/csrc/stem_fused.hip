@@ -16,10 +16,19 @@
 // block's 8 waves.
 #include <stdlib.h>
 
+#include <type_traits>
+#include <utility>
+
 #include "common.h"
 #include "lds_dma.h"
 
 namespace eve {
+
+// f(std::integral_constant<int, 0>{}), ..., f(std::integral_constant<int, N - 1>{}): a loop whose index is a compile-time constant
+template <typename F, int... I>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
 
 constexpr int SF_ROWB = 1280;                    // bytes staged per input row: padded pixels 1..160
 constexpr int SF_RING = 12;                      // rows per wave: 7 live + 2 x 2 in flight (+1 spare)
@@ -526,6 +535,277 @@ __global__ __launch_bounds__(1024) void stem_fwd_pairs_kernel(const int N, const
                     *reinterpret_cast<uint4*>(p) = Elem<H>::pack(f);
                 }
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        sf_pair_sync(my_flag, partner_flag, ++tick);              // the ring is rewritten by the next turn
+    }
+}
+
+// =================================================================================================
+// Round 6: the wave-pair forward, SOFTWARE-PIPELINED -- the convolution of row r + 1 is issued under the statistics / pooling
+// VALU of row r (two accumulator sets), and the pooling itself costs ~40 % fewer instructions.
+//
+// What the counters of stem_fwd_pairs_kernel said (profiles/r05_notes.md 9, 13): matrix pipe 31 % busy, VALU
+// ~30 %, 43 % of the wave cycles at a counter wait -- 240 half-rows per SIMD take 3 100 cycles each where their 56 MFMAs need
+// 950: a wave runs [fragment reads -> 56 MFMAs -> ~410 VALU -> stores] as ONE dependent chain per row, and four such chains per
+// SIMD do not cover each other.  Here a wave keeps TWO rows in flight: while the matrix pipe works on row r + 1 (accumulator set
+// B) the wave's VALU slots between the MFMAs carry row r's statistics and pooling (set A), then the sets swap.  That costs 32
+// more accumulator registers and the double-buffered fragments stay (~190 VGPRs: two waves per SIMD, four pairs per CU instead
+// of eight) -- fewer, fatter waves, each near the matrix pipe's pace instead of a third of it.
+//
+// The pooling arithmetic is stem_fwd_pairs_kernel's, bit for bit (same 28-bit value keys, same winner under ties: the window
+// position that comes first in scan order), re-encoded so that it costs less:
+//   * the four key bits hold code = 8 - (kh * 3 + kw) directly (row part {8, 5, 2} for kh = {0, 1, 2}, minus kw), so the stored
+//     arg-max byte is 8 - code -- one packed subtraction per four channels instead of a 64-bit table shift per value;
+//   * an odd column's key is prepared once (kw = 2 for its own window) and handed to the right-hand neighbour as key + 2 (kw = 0);
+//     an odd row's window maximum h becomes the next window's top row as h + 6 (kh 2 -> 0): no second masking pass, no select.
+// Statistics: S += v, Q = fma(v, v, Q) per value (the pairs kernel summed four values first and squared separately; the plane
+// sums differ from it in the last float bits, like any two of the stem kernels).
+// =================================================================================================
+constexpr int SQ_PAIRS = 4;                       // images per workgroup and turn: eight waves, two per SIMD
+
+// The statistics + pooling work of ONE convolution row (the wave's 4 column tiles x 8 channels), cut into 56 chunks of ~4 VALU
+// instructions -- one per MFMA of the row that is being convolved meanwhile.  Chunk c = 7 * (4 nt + r) + phase works on channel
+// (nt, r): phases 0-1 statistics, 2-3 keys, 3-4 the left neighbours (DPP) and the row maxima, 5 the window, 6 (odd rows) the output.
+template <typename H, bool ODD>
+struct SqPool {
+    // (scalars, not arrays: every member must end up in a register of its own -- an indexed member array stayed in scratch)
+    uint32_t ke0, ke1, ko0, ko1, kl0, kl1, l0, l1, wk0, wk1, vp0, vp1;
+    float hm0, hm1;
+    uint32_t pk00, pk01, pk02, pk03, pk10, pk11, pk12, pk13, cb00, cb01, cb10, cb11;
+
+    static __device__ __forceinline__ uint32_t key(float v, uint32_t code) { return (__builtin_bit_cast(uint32_t, v) & 0xfffffff0u) | code; }
+    static __device__ __forceinline__ float fk(uint32_t k) { return __builtin_bit_cast(float, k); }
+
+    template <int C>
+    __device__ __forceinline__ void chunk(const f32x4_t (&acc)[4][2], float (&S)[2][4], float (&Q)[2][4], uint32_t (&M)[2][2][4]) {
+        constexpr int nt = (C / 7) >> 2, r = (C / 7) & 3, ph = C % 7;
+        constexpr uint32_t CE = ODD ? 1u : 4u, CO = ODD ? 0u : 3u;      // even column kw = 1, odd column kw = 2 of its own window
+        if constexpr (ph == 0 || ph == 1) {
+#pragma unroll
+            for (int mt = 2 * ph; mt < 2 * ph + 2; ++mt) {
+                const float v = acc[mt][nt][r];
+                S[nt][r] += v;
+                Q[nt][r] = __builtin_fmaf(v, v, Q[nt][r]);
+            }
+        } else if constexpr (ph == 2) {
+            const float e0 = acc[0][nt][r], o0 = acc[1][nt][r], e1 = acc[2][nt][r];
+            ke0 = key(e0, CE);
+            ko0 = key(o0, CO);
+            kl0 = ko0 + 2u;                                             // the same column as kw = 0 of the window to its right
+            ke1 = key(e1, CE);
+        } else if constexpr (ph == 3) {
+            const float o1 = acc[3][nt][r];
+            ko1 = key(o1, CO);
+            kl1 = ko1 + 2u;
+            // column 2q - 1 = the odd column of lane li - 1; lane 0 of the first tile: the padding -- its own even key stands in
+            l0 = sf_dpp<0x111>(ke0, kl0);                                                // row_shr:1
+        } else if constexpr (ph == 4) {
+            // ... lane 0 of the second tile: the last lane of the first
+            l1 = sf_dpp<0x111>(sf_dpp<0x121>(0u, kl0), kl1);                             // row_ror:1, then row_shr:1 over it
+            hm0 = sf_fmax3(fk(l0), fk(ke0), fk(ko0));
+            hm1 = sf_fmax3(fk(l1), fk(ke1), fk(ko1));
+        } else if constexpr (ph == 5) {
+            const float m0 = fmaxf(fk(M[0][nt][r]), hm0), m1 = fmaxf(fk(M[1][nt][r]), hm1);
+            if constexpr (ODD) {
+                wk0 = __builtin_bit_cast(uint32_t, m0);                                  // the finished windows
+                wk1 = __builtin_bit_cast(uint32_t, m1);
+                M[0][nt][r] = __builtin_bit_cast(uint32_t, hm0) + 6u;                    // this row as kh = 0 of the next ones
+                M[1][nt][r] = __builtin_bit_cast(uint32_t, hm1) + 6u;
+            } else {
+                M[0][nt][r] = __builtin_bit_cast(uint32_t, m0);
+                M[1][nt][r] = __builtin_bit_cast(uint32_t, m1);
+            }
+        } else if constexpr (ODD) {
+            const uint32_t v0 = wk0 & 0xfffffff0u, v1 = wk1 & 0xfffffff0u, c0 = wk0 & 15u, c1 = wk1 & 15u;
+            uint32_t& cb0 = nt == 0 ? cb00 : cb01;
+            uint32_t& cb1 = nt == 0 ? cb10 : cb11;
+            if constexpr (r == 0) { cb0 = c0; cb1 = c1; }
+            else { cb0 |= c0 << (8 * r); cb1 |= c1 << (8 * r); }
+            if constexpr ((r & 1) == 0) { vp0 = v0; vp1 = v1; }
+            else {
+                const uint32_t p0 = Elem<H>::pack2(fk(vp0), fk(v0)), p1 = Elem<H>::pack2(fk(vp1), fk(v1));
+                if constexpr (nt == 0 && r == 1) { pk00 = p0; pk10 = p1; }
+                else if constexpr (nt == 0) { pk01 = p0; pk11 = p1; }
+                else if constexpr (r == 1) { pk02 = p0; pk12 = p1; }
+                else { pk03 = p0; pk13 = p1; }
+            }
+        }
+    }
+    // the pooled row leaves: 8 channels x 2 columns per lane, arg-max bytes kh * 3 + kw = 8 - code
+    __device__ __forceinline__ void store(H* __restrict__ yrow, uint8_t* __restrict__ irow) {
+        *reinterpret_cast<uint4*>(yrow) = make_uint4(pk00, pk01, pk02, pk03);
+        *reinterpret_cast<uint2*>(irow) = make_uint2(0x08080808u - cb00, 0x08080808u - cb01);
+        *reinterpret_cast<uint4*>(yrow + (size_t)16 * 64) = make_uint4(pk10, pk11, pk12, pk13);
+        *reinterpret_cast<uint2*>(irow + (size_t)16 * 64) = make_uint2(0x08080808u - cb10, 0x08080808u - cb11);
+    }
+};
+
+template <typename H>
+__global__ __launch_bounds__(128 * SQ_PAIRS) void stem_fwd_pipe_kernel(const int N, const int IH, const H* __restrict__ xp, const uint32_t xp_bytes,
+                                                                       const H* __restrict__ w8, const float eps, H* yp, uint8_t* __restrict__ idx,
+                                                                       float* __restrict__ mr) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const sW = smem + SQ_PAIRS * SF_RING * SF_ROWB;
+    int* const sFlag = reinterpret_cast<int*>(sW + SF_WBYTES);
+    const int tid = threadIdx.x;
+    sf_fill_weights<H>(sW, w8, tid, 128 * SQ_PAIRS);
+    if (tid < 2 * SQ_PAIRS) sFlag[tid] = 0;
+    __syncthreads();
+
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int pair = wave >> 1, h = wave & 1;
+    const int li = lane & 15, lg = lane >> 4;
+    const int OH = IH / 2, PH = OH / 2, rows = IH + 6;
+    const uint32_t ring = lds_addr_of(smem) + pair * (SF_RING * SF_ROWB);
+    const uint32_t xoff = 16 * (2 * li + lg);
+    const uint32_t wbase = lds_addr_of(sW) + (2 * h) * 1024 + li * 64 + ((lg ^ (((li >> 2) & 1) << 1)) << 4);
+    const eve_int4 rs = make_rsrc_words(xp, xp_bytes);
+    const float inv_hw = 1.f / (float)(OH * 64);
+    const int ch0 = lg * 16 + 8 * h;                      // the lane's 8 channels
+    const uint32_t my_flag = lds_addr_of(sFlag) + wave * 4, partner_flag = lds_addr_of(sFlag) + (wave ^ 1) * 4;
+    int tick = 0;
+
+    const int per_turn = gridDim.x * SQ_PAIRS;
+    const int turns = (N + per_turn - 1) / per_turn;
+    for (int turn = 0; turn < turns; ++turn) {
+        const int n = turn * per_turn + pair * (int)gridDim.x + (int)blockIdx.x;
+        if (n >= N) break;                                        // (uniform per pair; later turns have no image either)
+        const int img_off = n * rows * SF_XROW;
+        for (int r = h; r < 9; r += 2) sf_stage_row(rs, ring, r, rows, img_off, lane);
+        float S[2][4], Q[2][4];
+        uint32_t M[2][2][4];
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) { S[a][b] = 0.f; Q[a][b] = 0.f; M[0][a][b] = SF_NEG; M[1][a][b] = SF_NEG; }
+        H* const yimg = yp + (size_t)n * PH * 32 * 64 + (size_t)li * 64 + ch0;
+        uint8_t* const iimg = idx + (size_t)n * PH * 32 * 64 + (size_t)li * 64 + ch0;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        sf_pair_sync(my_flag, partner_flag, ++tick);
+        // the top of a convolution row: my staged row of two rows ago has landed (only the newest row's 2 DMAs may still be in
+        // flight), the partner is past the previous row's ring reads, the next input row is requested
+        auto row_top = [&](int oy) {
+            if (oy >= 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            sf_pair_sync(my_flag, partner_flag, ++tick);
+            sf_stage_row(rs, ring, 2 * oy + 9 + h, rows, img_off, lane);
+        };
+        // ---- the pipeline ----
+        // A row is TWO half-steps of 28 MFMAs, one per weight tile (nt = 0: the lane's channels 0-3, nt = 1: channels 4-7), and
+        // every MFMA is followed by one ~4-instruction chunk of the statistics / pooling of the tile that was finished one
+        // half-step earlier: an in-order wave overlaps its own matrix and vector work only when they alternate in program order.
+        //     H0(r): conv(row r, nt 0) -> X   with  pool(row r - 1, nt 1) on Y
+        //     H1(r): conv(row r, nt 1) -> Y   with  pool(row r,     nt 0) on X
+        // so two 16-register accumulator sets do (a whole row in flight next to a whole row being pooled needs 64 and spills).
+        // The input fragments are read once per half-step (twice per row: 70 instead of 42 fragment reads per row and wave);
+        // each is used by one MFMA per filter row and re-requested right behind it for the next filter row -- or for filter
+        // row 0 of the NEXT half-step, whose input rows are resident already (a new convolution row only adds rows kh = 5, 6) --
+        // four MFMA slots ahead of its use; the weight tile is double-buffered (requested one filter row ahead).
+        uint4 fx[4], fw[2];
+        int slot0 = 0;                                            // ring slot of input row 2 * (current convolution row)
+        auto frag_x = [&](int s0, int kh, int mt) {
+            int slot = s0 + kh;
+            slot = slot >= SF_RING ? slot - SF_RING : slot;
+            fx[mt] = sf_lds_read(ring + slot * SF_ROWB + xoff + (mt & 1) * 16 + (mt >> 1) * 512);
+        };
+        auto frag_w = [&](int kh, int nt, int buf) { fw[buf] = sf_lds_read(wbase + kh * 4096 + nt * 1024); };
+        // half-step NT of the current row; `next_s0`: ring slot of the row the following half-step convolves
+        auto conv_half = [&](auto nt_tag, auto cc, f32x4_t (&cv)[4], int next_s0) {
+            constexpr int NT = decltype(nt_tag)::value, C = decltype(cc)::value, kh = C >> 2, mt = C & 3;
+            constexpr int buf = (kh + NT) & 1;                    // seven filter rows per half-step: the buffer parity alternates
+            if (mt == 0) {
+                if (kh + 1 < 7) frag_w(kh + 1, NT, buf ^ 1);
+                else frag_w(0, NT ^ 1, buf ^ 1);
+            }
+            if (kh == 0) cv[mt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+            Elem<H>::mfma(cv[mt], fw[buf], fx[mt]);
+            if (kh + 1 < 7) frag_x(slot0, kh + 1, mt);
+            else frag_x(next_s0, 0, mt);
+        };
+        auto pool_view = [&](const f32x4_t (&t)[4], auto nt_tag, f32x4_t (&full)[4][2]) {   // SqPool indexes acc[mt][nt]
+            constexpr int NT = decltype(nt_tag)::value;
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) full[mt][NT] = t[mt];
+        };
+        f32x4_t X[4], Y[4];
+        SqPool<H, false> Pe;
+        SqPool<H, true> Po;
+        using T0 = std::integral_constant<int, 0>;
+        using T1 = std::integral_constant<int, 1>;
+        // one half-step: 28 x (MFMA, pool chunk); POOLNT = the weight tile whose previous result is pooled meanwhile
+        auto half = [&](auto nt_tag, f32x4_t (&cv)[4], const f32x4_t (&pl)[4], auto& P, int next_s0) {
+            constexpr int NT = decltype(nt_tag)::value, PNT = NT ^ 1;
+            f32x4_t view[4][2];
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) view[mt][PNT] = pl[mt];
+            static_for<28>([&](auto cc) {
+                conv_half(nt_tag, cc, cv, next_s0);
+                __builtin_amdgcn_sched_barrier(0);
+                P.template chunk<PNT * 28 + decltype(cc)::value>(view, S, Q, M);
+                __builtin_amdgcn_sched_barrier(0);
+            });
+        };
+        auto conv_only = [&](auto nt_tag, f32x4_t (&cv)[4], int next_s0) {
+            static_for<28>([&](auto cc) { conv_half(nt_tag, cc, cv, next_s0); });
+        };
+        auto pool_only = [&](auto nt_tag, const f32x4_t (&pl)[4], auto& P) {
+            constexpr int PNT = decltype(nt_tag)::value;
+            f32x4_t view[4][2];
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) view[mt][PNT] = pl[mt];
+            static_for<28>([&](auto cc) { P.template chunk<PNT * 28 + decltype(cc)::value>(view, S, Q, M); });
+        };
+        auto next_slot = [&]() { return slot0 + 2 >= SF_RING ? slot0 + 2 - SF_RING : slot0 + 2; };
+        // row 0, tile 0: nothing to pool yet
+        row_top(0);
+        frag_w(0, 0, 0);
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) frag_x(0, 0, mt);
+        conv_only(T0{}, X, slot0);
+        for (int oy = 0; oy < OH; oy += 2) {
+            // ---- even row oy ----
+            half(T1{}, Y, X, Pe, next_slot());                    // H1(oy): tile 1 of row oy   | pool tile 0 of row oy
+            slot0 = next_slot();
+            row_top(oy + 1);
+            half(T0{}, X, Y, Pe, slot0);                          // H0(oy + 1): tile 0 of row oy + 1 | pool tile 1 of row oy
+            // ---- odd row oy + 1: it closes pooling window oy / 2 ----
+            half(T1{}, Y, X, Po, next_slot());                    // H1(oy + 1)                 | pool tile 0 of row oy + 1
+            slot0 = next_slot();
+            H* const yrow = yimg + (size_t)(oy >> 1) * 32 * 64;
+            uint8_t* const irow = iimg + (size_t)(oy >> 1) * 32 * 64;
+            if (oy + 2 < OH) {
+                row_top(oy + 2);
+                half(T0{}, X, Y, Po, slot0);                      // H0(oy + 2): tile 0 of row oy + 2 | pool tile 1 of row oy + 1
+            } else {
+                pool_only(T1{}, Y, Po);                           // the image's last row: nothing left to convolve
+            }
+            Po.store(yrow, irow);
+        }
+        // ---- plane statistics -> mean / rstd of the lane's 8 channels; normalise the wave's own pooled values in place ----
+        float mean[2][4], rstd[2][4];
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float s = sf_row_sum16(S[nt][r]) * inv_hw, q = sf_row_sum16(Q[nt][r]) * inv_hw;
+                const float var = fmaxf(q - s * s, 0.f);
+                mean[nt][r] = s;
+                rstd[nt][r] = rsqrtf(var + eps);
+                if (li == 0) {
+                    float* m = mr + ((size_t)n * 64 + ch0 + nt * 4 + r) * 2;
+                    m[0] = s; m[1] = rstd[nt][r];
+                }
+            }
+#pragma unroll 4
+        for (int py = 0; py < PH; ++py)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                H* p = yimg + ((size_t)py * 32 + 16 * j) * 64;
+                float f[8];
+                Elem<H>::unpack(*reinterpret_cast<const uint4*>(p), f);
+#pragma unroll
+                for (int c = 0; c < 8; ++c) f[c] = fmaxf((f[c] - mean[c >> 2][c & 3]) * rstd[c >> 2][c & 3], 0.f);
+                *reinterpret_cast<uint4*>(p) = Elem<H>::pack(f);
+            }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         sf_pair_sync(my_flag, partner_flag, ++tick);              // the ring is rewritten by the next turn
     }
@@ -1148,6 +1428,21 @@ extern "C" int eve_stem_fwd_fused(int dtype, int N, int IH, int IW, const void* 
         (void)hipFuncSetAttribute((const void*)stem_fwd_fused_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void*)stem_fwd_fused_kernel<f16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
+    }
+    if (g_cfg.stem_fwd_pairs == 2) { // round 6: the wave-pair kernel software-pipelined over rows (two accumulator sets), 8 waves per CU
+        static bool attr3 = false;
+        if (!attr3) {
+            (void)hipFuncSetAttribute((const void*)stem_fwd_pipe_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void*)stem_fwd_pipe_kernel<f16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            attr3 = true;
+        }
+        const size_t lds3 = (size_t)SQ_PAIRS * SF_RING * SF_ROWB + SF_WBYTES + 64;
+        const unsigned want = (unsigned)((N + SQ_PAIRS - 1) / SQ_PAIRS);
+        const unsigned blocks3 = want < 256u ? (want ? want : 1u) : 256u;
+        EVE_DISPATCH_H16(dtype, EVE_LAUNCH(EVE_HNAME(H, "stem_fwd_pipe_kernel<", ">"), stem_fwd_pipe_kernel<H>, dim3(blocks3), dim3(128 * SQ_PAIRS), lds3,
+                                           (hipStream_t)stream, N, IH, (const H*)x_padded, (uint32_t)xb, (const H*)w_ohwi8, eps, (H*)y_pool, idx, mean_rstd));
+        EVE_CHECK_LAUNCH();
+        return 0;
     }
     if (g_cfg.stem_fwd_pairs) {      // round 4: two waves per image, 32 channels each, 16 waves per CU
         static bool attr2 = false;

@@ -80,6 +80,7 @@ class GradSync(object):
         self._flags = None           # one gate word per bucket (device int32), incremented once per replay by the bucket's node
         self._timeouts = None
         self._replays = 0
+        self.overlaps = None         # does the communication stream run beside the replay's stream on this box (prepare_marks)
         self.launch_counts = []
         # a one-rank group has nothing to exchange; EVE_AMD_FORCE_DIST=1 runs the collectives anyway (transport test)
         self.active = self.world > 1 or (dist.is_initialized() and os.environ.get('EVE_AMD_FORCE_DIST', '0') == '1')
@@ -130,10 +131,38 @@ class GradSync(object):
         supposed to count up (seen as every gate timing out from the second replay on)."""
         if self.flat_grad.is_cuda:
             if self._comm is None:
-                self._comm = torch.cuda.Stream(device=self.flat_grad.device)          # NORMAL priority (see above)
+                self._comm = self._pick_concurrent_stream(self.flat_grad.device)      # NORMAL priority (see above)
             self._flags = torch.zeros((len(self.buckets) + 1,), dtype=torch.int32, device=self.flat_grad.device)
             self._timeouts = torch.zeros((1,), dtype=torch.int32, device=self.flat_grad.device)
             self._replays = 0
+
+    def _pick_concurrent_stream(self, device, candidates=8):
+        """A stream whose kernels run BESIDE the current stream's.  HIP multiplexes streams onto a few hardware queues (4 by
+        default, GPU_MAX_HW_QUEUES), handed out in creation order: a communication stream that lands on the replay's queue runs
+        its gate-wait kernels only after the whole replay -- correct, but every all-reduce is then exposed (measured in round 6 on
+        the one-rank RCCL test process: a kernel on the communication stream finished 6 us after a 42 ms spin on the main stream).
+        So each candidate is tried with the gate kernels themselves: the current stream waits (bounded, ~10 ms) for a word only the
+        candidate's signal kernel can set; a wait that opens proves the two streams run concurrently.  None does: the last
+        candidate is used anyway (`overlaps` says False; the collectives then follow the replay)."""
+        from .kernels import default_kernels
+        k = default_kernels()
+        self.overlaps = False
+        if not hasattr(k, 'gate_wait'):
+            return torch.cuda.Stream(device=device)
+        words = torch.zeros((candidates + 1,), dtype=torch.int32, device=device)
+        cand = None
+        for i in range(candidates):
+            cand = torch.cuda.Stream(device=device)
+            torch.cuda.synchronize(device)
+            before = int(words[candidates].item())
+            k.gate_wait(words, i, 1, words[candidates:candidates + 1], max_polls=5000)       # on the current stream
+            with torch.cuda.stream(cand):
+                k.gate_signal(words, i)
+            torch.cuda.synchronize(device)
+            if int(words[candidates].item()) == before:       # the wait opened: the candidate ran while the current stream was busy
+                self.overlaps = True
+                break
+        return cand
 
     def begin_marks(self):
         assert self._flags is not None or not self.flat_grad.is_cuda, 'prepare_marks() before the capture'

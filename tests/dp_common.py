@@ -174,27 +174,45 @@ def worker_gate_timeout(rank, port, tmp):
     cfg, make, full = build('eyenet', 'cuda', 'bf16', 1e-3)
     tr = make(True, True)
     k = default_kernels()
-    late = tr.sync.buckets[1]
     plain_launch = tr.sync._launch
+    slept = []
 
     def launch(b):
-        if tr.sync._marking and b is late and not b['launched']:
-            torch.cuda._sleep(300_000_000)                  # ~0.15 s in front of this bucket's gate-signal node, every replay
+        # the SECOND bucket whose ready point is captured gets the stall in front of its gate-signal node
+        if tr.sync._marking and not b['launched'] and b['hi'] > b['lo'] and len(tr.sync._gated) == 1:
+            torch.cuda._sleep(300_000_000)                  # ~0.15 s, every replay
+            slept.append(tr.sync.buckets.index(b))
         plain_launch(b)
     tr.sync._launch = launch
     batch = {kk: v.to('cuda') for kk, v in full.items()}
     rec = {}
+    import time
     tr.step(batch)                                          # capture + replay 1
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
     tr.step(batch)                                          # replay 2: default bound, the gates sit the sleep out
     torch.cuda.synchronize()
-    rec['after_two'] = dict(tr.optimizer_state(), timeouts=tr.sync.gate_timeouts(), gated=len(tr.sync._gated))
+    rec['after_two'] = dict(tr.optimizer_state(), timeouts=tr.sync.gate_timeouts(), gated=len(tr.sync._gated), slept=list(slept),
+                            replay_s=time.perf_counter() - t0, order=[tr.sync.buckets.index(b) for b in tr.sync._gated])
+    # diagnostics: does the communication stream run BESIDE the main stream on this box (or behind it: hardware-queue aliasing)?
+    main, comm = torch.cuda.current_stream(), tr.sync._comm
+    e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+    probe = torch.zeros(64, device='cuda')
+    e0.record(main)
+    torch.cuda._sleep(100_000_000)
+    e1.record(main)
+    with torch.cuda.stream(comm):
+        probe.add_(1.0)
+        e2.record(comm)
+    torch.cuda.synchronize()
+    rec['probe_ms'] = dict(main_sleep=e0.elapsed_time(e1), comm_kernel_done=e0.elapsed_time(e2), overlaps=tr.sync.overlaps)
     before = tr.fp.flat.clone()
     m_before = tr.fp.m.clone()
     tr.gate_check_every = 1
     with k.dispatch_override(gate_wait_polls=2000):         # a few ms: far above this tiny backward, far below the sleep
         tr.step(batch)
         torch.cuda.synchronize()
-    rec['after_late'] = dict(tr.optimizer_state(), timeouts=tr.sync.gate_timeouts(), gated=len(tr.sync._gated),
+    rec['after_late'] = dict(tr.optimizer_state(), timeouts=tr.sync.gate_timeouts(), gated=len(tr.sync._gated), polls=k.dispatch_config().gate_wait_polls,
                              weights_unchanged=bool(torch.equal(tr.fp.flat, before) and torch.equal(tr.fp.m, m_before)),
                              poison=float(tr.fp.poison[0]))
     tr.step(batch)                                          # the trainer has fallen back: collectives behind the replay

@@ -133,6 +133,12 @@ def test_late_gate_signal_poisons_the_step_and_the_trainer_falls_back(tmp_path):
     trainer -- which reads that count, the same on every rank -- falls back to collectives behind the replay and trains on."""
     rec = dp_common.run_gate_timeout(str(tmp_path))
     a, b, c = rec['after_two'], rec['after_late'], rec['after_fallback']
+    print(rec)
+    assert len(a['slept']) == 1 and a['replay_s'] > 0.05, a         # the stall is in the graph
+    # the communication stream was PROBED to run beside the replay's stream (parallel.GradSync._pick_concurrent_stream): a kernel on
+    # it finishes while the main stream still spins (round 6 found the first stream torch handed out aliased onto the replay's
+    # hardware queue in this very process: every gate then opened only after the whole replay, and nothing overlapped)
+    assert rec['probe_ms']['overlaps'] and rec['probe_ms']['comm_kernel_done'] < 0.5 * rec['probe_ms']['main_sleep'], rec['probe_ms']
     assert a['steps_taken'] == 2 and a['steps_skipped'] == 0 and a['timeouts'] == 0 and a['gated'] >= 3, a
     assert b['steps_taken'] == 2 and b['steps_skipped'] == 1 and b['steps_skipped_gate_timeout'] == 1, b
     assert b['timeouts'] >= 1 and b['weights_unchanged'] and b['poison'] == float('inf'), b

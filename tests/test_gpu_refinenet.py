@@ -5,6 +5,7 @@ import os
 import numpy as np
 import pytest
 import torch
+from eve_amd.kernels import default_kernels
 
 from oracle import detweights, sequence
 from oracle.config import OracleConfig
@@ -152,7 +153,7 @@ def test_refinenet_fused_scan_trains_like_the_per_step_path():
     rb = detweights.refinenet_batch(3, 4, seed=3)
     outs = {}
     for mode in ('1', '0'):
-        with hip.dispatch_override(cgru_scan=int(mode)):
+        with default_kernels().dispatch_override(cgru_scan=int(mode)):
             net, _ = make_net('CGRU', dtype=torch.bfloat16)
             hf, states = net.forward_sequence(rb['heatmap_initial'].cuda(), rb['screen_frame'].cuda())
             (hf.float() * rb['heatmap_final_gt'].cuda()).sum().backward()
@@ -327,7 +328,7 @@ def test_refinenet_clip_scans_train_like_the_per_frame_path(kind, dtype):
     rb = detweights.refinenet_batch(3, 4, seed=3)
     outs = {}
     for mode in ('1', '0'):
-        with hip.dispatch_override(cgru_scan=int(mode)):
+        with default_kernels().dispatch_override(cgru_scan=int(mode)):
             net, _ = make_net(kind, dtype=dtype)
             hf, states = net.forward_sequence(rb['heatmap_initial'].cuda(), rb['screen_frame'].cuda())
             (hf.float() * rb['heatmap_final_gt'].cuda()).sum().backward()
