@@ -562,90 +562,20 @@ __global__ __launch_bounds__(1024) void stem_fwd_pairs_kernel(const int N, const
 // sums differ from it in the last float bits, like any two of the stem kernels).
 // =================================================================================================
 constexpr int SQ_PAIRS = 4;                       // images per workgroup and turn: eight waves, two per SIMD
+constexpr int SQ_AHEAD = 6;                       // convolution rows of input staged ahead ON TOP of stem_fwd_pairs_kernel's two
+constexpr int SQ_RING = 24;                       // ring slots per pair (>= 11 + 2 * SQ_AHEAD): 4 x 30 KB + 28 KB of filters
 
-// The statistics + pooling work of ONE convolution row (the wave's 4 column tiles x 8 channels), cut into 56 chunks of ~4 VALU
-// instructions -- one per MFMA of the row that is being convolved meanwhile.  Chunk c = 7 * (4 nt + r) + phase works on channel
-// (nt, r): phases 0-1 statistics, 2-3 keys, 3-4 the left neighbours (DPP) and the row maxima, 5 the window, 6 (odd rows) the output.
-template <typename H, bool ODD>
-struct SqPool {
-    // (scalars, not arrays: every member must end up in a register of its own -- an indexed member array stayed in scratch)
-    uint32_t ke0, ke1, ko0, ko1, kl0, kl1, l0, l1, wk0, wk1, vp0, vp1;
-    float hm0, hm1;
-    uint32_t pk00, pk01, pk02, pk03, pk10, pk11, pk12, pk13, cb00, cb01, cb10, cb11;
-
-    static __device__ __forceinline__ uint32_t key(float v, uint32_t code) { return (__builtin_bit_cast(uint32_t, v) & 0xfffffff0u) | code; }
-    static __device__ __forceinline__ float fk(uint32_t k) { return __builtin_bit_cast(float, k); }
-
-    template <int C>
-    __device__ __forceinline__ void chunk(const f32x4_t (&acc)[4][2], float (&S)[2][4], float (&Q)[2][4], uint32_t (&M)[2][2][4]) {
-        constexpr int nt = (C / 7) >> 2, r = (C / 7) & 3, ph = C % 7;
-        constexpr uint32_t CE = ODD ? 1u : 4u, CO = ODD ? 0u : 3u;      // even column kw = 1, odd column kw = 2 of its own window
-        if constexpr (ph == 0 || ph == 1) {
-#pragma unroll
-            for (int mt = 2 * ph; mt < 2 * ph + 2; ++mt) {
-                const float v = acc[mt][nt][r];
-                S[nt][r] += v;
-                Q[nt][r] = __builtin_fmaf(v, v, Q[nt][r]);
-            }
-        } else if constexpr (ph == 2) {
-            const float e0 = acc[0][nt][r], o0 = acc[1][nt][r], e1 = acc[2][nt][r];
-            ke0 = key(e0, CE);
-            ko0 = key(o0, CO);
-            kl0 = ko0 + 2u;                                             // the same column as kw = 0 of the window to its right
-            ke1 = key(e1, CE);
-        } else if constexpr (ph == 3) {
-            const float o1 = acc[3][nt][r];
-            ko1 = key(o1, CO);
-            kl1 = ko1 + 2u;
-            // column 2q - 1 = the odd column of lane li - 1; lane 0 of the first tile: the padding -- its own even key stands in
-            l0 = sf_dpp<0x111>(ke0, kl0);                                                // row_shr:1
-        } else if constexpr (ph == 4) {
-            // ... lane 0 of the second tile: the last lane of the first
-            l1 = sf_dpp<0x111>(sf_dpp<0x121>(0u, kl0), kl1);                             // row_ror:1, then row_shr:1 over it
-            hm0 = sf_fmax3(fk(l0), fk(ke0), fk(ko0));
-            hm1 = sf_fmax3(fk(l1), fk(ke1), fk(ko1));
-        } else if constexpr (ph == 5) {
-            const float m0 = fmaxf(fk(M[0][nt][r]), hm0), m1 = fmaxf(fk(M[1][nt][r]), hm1);
-            if constexpr (ODD) {
-                wk0 = __builtin_bit_cast(uint32_t, m0);                                  // the finished windows
-                wk1 = __builtin_bit_cast(uint32_t, m1);
-                M[0][nt][r] = __builtin_bit_cast(uint32_t, hm0) + 6u;                    // this row as kh = 0 of the next ones
-                M[1][nt][r] = __builtin_bit_cast(uint32_t, hm1) + 6u;
-            } else {
-                M[0][nt][r] = __builtin_bit_cast(uint32_t, m0);
-                M[1][nt][r] = __builtin_bit_cast(uint32_t, m1);
-            }
-        } else if constexpr (ODD) {
-            const uint32_t v0 = wk0 & 0xfffffff0u, v1 = wk1 & 0xfffffff0u, c0 = wk0 & 15u, c1 = wk1 & 15u;
-            uint32_t& cb0 = nt == 0 ? cb00 : cb01;
-            uint32_t& cb1 = nt == 0 ? cb10 : cb11;
-            if constexpr (r == 0) { cb0 = c0; cb1 = c1; }
-            else { cb0 |= c0 << (8 * r); cb1 |= c1 << (8 * r); }
-            if constexpr ((r & 1) == 0) { vp0 = v0; vp1 = v1; }
-            else {
-                const uint32_t p0 = Elem<H>::pack2(fk(vp0), fk(v0)), p1 = Elem<H>::pack2(fk(vp1), fk(v1));
-                if constexpr (nt == 0 && r == 1) { pk00 = p0; pk10 = p1; }
-                else if constexpr (nt == 0) { pk01 = p0; pk11 = p1; }
-                else if constexpr (r == 1) { pk02 = p0; pk12 = p1; }
-                else { pk03 = p0; pk13 = p1; }
-            }
-        }
-    }
-    // the pooled row leaves: 8 channels x 2 columns per lane, arg-max bytes kh * 3 + kw = 8 - code
-    __device__ __forceinline__ void store(H* __restrict__ yrow, uint8_t* __restrict__ irow) {
-        *reinterpret_cast<uint4*>(yrow) = make_uint4(pk00, pk01, pk02, pk03);
-        *reinterpret_cast<uint2*>(irow) = make_uint2(0x08080808u - cb00, 0x08080808u - cb01);
-        *reinterpret_cast<uint4*>(yrow + (size_t)16 * 64) = make_uint4(pk10, pk11, pk12, pk13);
-        *reinterpret_cast<uint2*>(irow + (size_t)16 * 64) = make_uint2(0x08080808u - cb10, 0x08080808u - cb11);
-    }
-};
-
+// The statistics + pooling work of ONE convolution row (the wave's 4 column tiles x 8 channels) is cut into 56 chunks of ~4 VALU
+// instructions -- one per MFMA of the tile that is being convolved meanwhile (sq_chunk below, inside the kernel: its state is
+// plain local variables; as members of a struct the compiler merged two neighbours into one vector load and left them in scratch).
+// Chunk C = 7 * (4 nt + r) + phase works on channel (nt, r): phases 0-1 statistics, 2-3 keys, 3-4 the left neighbours (DPP) and
+// the row maxima, 5 the window, 6 (odd rows) the output.
 template <typename H>
 __global__ __launch_bounds__(128 * SQ_PAIRS) void stem_fwd_pipe_kernel(const int N, const int IH, const H* __restrict__ xp, const uint32_t xp_bytes,
                                                                        const H* __restrict__ w8, const float eps, H* yp, uint8_t* __restrict__ idx,
                                                                        float* __restrict__ mr) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* const sW = smem + SQ_PAIRS * SF_RING * SF_ROWB;
+    char* const sW = smem + SQ_PAIRS * SQ_RING * SF_ROWB;
     int* const sFlag = reinterpret_cast<int*>(sW + SF_WBYTES);
     const int tid = threadIdx.x;
     sf_fill_weights<H>(sW, w8, tid, 128 * SQ_PAIRS);
@@ -656,7 +586,7 @@ __global__ __launch_bounds__(128 * SQ_PAIRS) void stem_fwd_pipe_kernel(const int
     const int pair = wave >> 1, h = wave & 1;
     const int li = lane & 15, lg = lane >> 4;
     const int OH = IH / 2, PH = OH / 2, rows = IH + 6;
-    const uint32_t ring = lds_addr_of(smem) + pair * (SF_RING * SF_ROWB);
+    const uint32_t ring = lds_addr_of(smem) + pair * (SQ_RING * SF_ROWB);
     const uint32_t xoff = 16 * (2 * li + lg);
     const uint32_t wbase = lds_addr_of(sW) + (2 * h) * 1024 + li * 64 + ((lg ^ (((li >> 2) & 1) << 1)) << 4);
     const eve_int4 rs = make_rsrc_words(xp, xp_bytes);
@@ -671,7 +601,15 @@ __global__ __launch_bounds__(128 * SQ_PAIRS) void stem_fwd_pipe_kernel(const int
         const int n = turn * per_turn + pair * (int)gridDim.x + (int)blockIdx.x;
         if (n >= N) break;                                        // (uniform per pair; later turns have no image either)
         const int img_off = n * rows * SF_XROW;
-        for (int r = h; r < 9; r += 2) sf_stage_row(rs, ring, r, rows, img_off, lane);
+        // stage padded input row `row` into its slot of the deeper ring (rows past the image: zeros)
+        auto stage = [&](int row) {
+            const int slot = row % SQ_RING;
+            const bool in = row < rows;
+            const int soff = in ? img_off + row * SF_XROW : 0;
+            sf_dma16(rs, ring + slot * SF_ROWB, in ? lane * 16 + 8 : EVE_OOB, soff);
+            sf_dma4(rs, ring + slot * SF_ROWB + 1024, in ? lane * 4 + 8 + 1024 : EVE_OOB, soff);
+        };
+        for (int r = h; r < 9 + 2 * SQ_AHEAD; r += 2) stage(r);
         float S[2][4], Q[2][4];
         uint32_t M[2][2][4];
 #pragma unroll
@@ -682,12 +620,14 @@ __global__ __launch_bounds__(128 * SQ_PAIRS) void stem_fwd_pipe_kernel(const int
         uint8_t* const iimg = idx + (size_t)n * PH * 32 * 64 + (size_t)li * 64 + ch0;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         sf_pair_sync(my_flag, partner_flag, ++tick);
-        // the top of a convolution row: my staged row of two rows ago has landed (only the newest row's 2 DMAs may still be in
-        // flight), the partner is past the previous row's ring reads, the next input row is requested
+        // the top of a convolution row: the input rows it reads have landed -- mine were requested SQ_AHEAD + 2 rows ago, so the
+        // DMAs of the SQ_AHEAD + 1 newest requests may still be in flight (pooled-row stores among them only make the wait stricter)
+        // --, the partner is past the previous row's ring reads, the next input row is requested.  (A wave of this kernel wants a
+        // row every ~0.5 us; the two rows of look-ahead of stem_fwd_pairs_kernel are less than one HBM round trip then.)
         auto row_top = [&](int oy) {
-            if (oy >= 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            if (oy >= 2) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * (SQ_AHEAD + 1)) : "memory");
             sf_pair_sync(my_flag, partner_flag, ++tick);
-            sf_stage_row(rs, ring, 2 * oy + 9 + h, rows, img_off, lane);
+            stage(2 * oy + 9 + 2 * SQ_AHEAD + h);
         };
         // ---- the pipeline ----
         // A row is TWO half-steps of 28 MFMAs, one per weight tile (nt = 0: the lane's channels 0-3, nt = 1: channels 4-7), and
@@ -704,7 +644,7 @@ __global__ __launch_bounds__(128 * SQ_PAIRS) void stem_fwd_pipe_kernel(const int
         int slot0 = 0;                                            // ring slot of input row 2 * (current convolution row)
         auto frag_x = [&](int s0, int kh, int mt) {
             int slot = s0 + kh;
-            slot = slot >= SF_RING ? slot - SF_RING : slot;
+            slot = slot >= SQ_RING ? slot - SQ_RING : slot;
             fx[mt] = sf_lds_read(ring + slot * SF_ROWB + xoff + (mt & 1) * 16 + (mt >> 1) * 512);
         };
         auto frag_w = [&](int kh, int nt, int buf) { fw[buf] = sf_lds_read(wbase + kh * 4096 + nt * 1024); };
@@ -727,12 +667,76 @@ __global__ __launch_bounds__(128 * SQ_PAIRS) void stem_fwd_pipe_kernel(const int
             for (int mt = 0; mt < 4; ++mt) full[mt][NT] = t[mt];
         };
         f32x4_t X[4], Y[4];
-        SqPool<H, false> Pe;
-        SqPool<H, true> Po;
         using T0 = std::integral_constant<int, 0>;
         using T1 = std::integral_constant<int, 1>;
+        uint32_t ke0, ke1, ko0, ko1, kl0, kl1, l0, l1, wk0, wk1, vp0, vp1, hm0, hm1;    // one channel's keys (hm: row maxima)
+        uint32_t pk00, pk01, pk02, pk03, pk10, pk11, pk12, pk13, cb00, cb01, cb10, cb11;  // an odd row's output, as it forms
+        auto key = [](float v, uint32_t code) { return (__builtin_bit_cast(uint32_t, v) & 0xfffffff0u) | code; };
+        auto fk = [](uint32_t k) { return __builtin_bit_cast(float, k); };
+        auto sq_chunk = [&](auto odd_tag, auto cc, const f32x4_t (&acc)[4][2]) {
+            constexpr bool ODD = decltype(odd_tag)::value;
+            constexpr int C = decltype(cc)::value, nt = (C / 7) >> 2, r = (C / 7) & 3, ph = C % 7;
+            constexpr uint32_t CE = ODD ? 1u : 4u, CO = ODD ? 0u : 3u;  // even column kw = 1, odd column kw = 2 of its own window
+            if constexpr (ph == 0 || ph == 1) {
+#pragma unroll
+                for (int mt = 2 * ph; mt < 2 * ph + 2; ++mt) {
+                    const float v = acc[mt][nt][r];
+                    S[nt][r] += v;
+                    Q[nt][r] = __builtin_fmaf(v, v, Q[nt][r]);
+                }
+            } else if constexpr (ph == 2) {
+                const float e0 = acc[0][nt][r], o0 = acc[1][nt][r], e1 = acc[2][nt][r];
+                ke0 = key(e0, CE);
+                ko0 = key(o0, CO);
+                kl0 = ko0 + 2u;                                         // the same column as kw = 0 of the window to its right
+                ke1 = key(e1, CE);
+            } else if constexpr (ph == 3) {
+                const float o1 = acc[3][nt][r];
+                ko1 = key(o1, CO);
+                kl1 = ko1 + 2u;
+                // column 2q - 1 = the odd column of lane li - 1; lane 0 of the first tile: the padding -- its own even key stands in
+                l0 = sf_dpp<0x111>(ke0, kl0);                                            // row_shr:1
+            } else if constexpr (ph == 4) {
+                // ... lane 0 of the second tile: the last lane of the first
+                l1 = sf_dpp<0x111>(sf_dpp<0x121>(0u, kl0), kl1);                         // row_ror:1, then row_shr:1 over it
+                hm0 = __builtin_bit_cast(uint32_t, sf_fmax3(fk(l0), fk(ke0), fk(ko0)));
+                hm1 = __builtin_bit_cast(uint32_t, sf_fmax3(fk(l1), fk(ke1), fk(ko1)));
+            } else if constexpr (ph == 5) {
+                const float m0 = fmaxf(fk(M[0][nt][r]), fk(hm0)), m1 = fmaxf(fk(M[1][nt][r]), fk(hm1));
+                if constexpr (ODD) {
+                    wk0 = __builtin_bit_cast(uint32_t, m0);                              // the finished windows
+                    wk1 = __builtin_bit_cast(uint32_t, m1);
+                    M[0][nt][r] = hm0 + 6u;                                              // this row as kh = 0 of the next ones
+                    M[1][nt][r] = hm1 + 6u;
+                } else {
+                    M[0][nt][r] = __builtin_bit_cast(uint32_t, m0);
+                    M[1][nt][r] = __builtin_bit_cast(uint32_t, m1);
+                }
+            } else if constexpr (ODD) {
+                const uint32_t v0 = wk0 & 0xfffffff0u, v1 = wk1 & 0xfffffff0u, c0 = wk0 & 15u, c1 = wk1 & 15u;
+                uint32_t& cb0 = nt == 0 ? cb00 : cb01;
+                uint32_t& cb1 = nt == 0 ? cb10 : cb11;
+                if constexpr (r == 0) { cb0 = c0; cb1 = c1; }
+                else { cb0 |= c0 << (8 * r); cb1 |= c1 << (8 * r); }
+                if constexpr ((r & 1) == 0) { vp0 = v0; vp1 = v1; }
+                else {
+                    const uint32_t p0 = Elem<H>::pack2(fk(vp0), fk(v0)), p1 = Elem<H>::pack2(fk(vp1), fk(v1));
+                    if constexpr (nt == 0 && r == 1) { pk00 = p0; pk10 = p1; }
+                    else if constexpr (nt == 0) { pk01 = p0; pk11 = p1; }
+                    else if constexpr (r == 1) { pk02 = p0; pk12 = p1; }
+                    else { pk03 = p0; pk13 = p1; }
+                }
+            }
+        };
+        // the pooled row leaves: 8 channels x 2 columns per lane, arg-max bytes kh * 3 + kw = 8 - code
+        auto sq_store = [&](H* __restrict__ yrow, uint8_t* __restrict__ irow) {
+            *reinterpret_cast<uint4*>(yrow) = make_uint4(pk00, pk01, pk02, pk03);
+            *reinterpret_cast<uint2*>(irow) = make_uint2(0x08080808u - cb00, 0x08080808u - cb01);
+            *reinterpret_cast<uint4*>(yrow + (size_t)16 * 64) = make_uint4(pk10, pk11, pk12, pk13);
+            *reinterpret_cast<uint2*>(irow + (size_t)16 * 64) = make_uint2(0x08080808u - cb10, 0x08080808u - cb11);
+        };
         // one half-step: 28 x (MFMA, pool chunk); POOLNT = the weight tile whose previous result is pooled meanwhile
-        auto half = [&](auto nt_tag, f32x4_t (&cv)[4], const f32x4_t (&pl)[4], auto& P, int next_s0) {
+        auto half = [&](auto nt_tag, f32x4_t (&cv)[4], const f32x4_t (&pl)[4], auto odd_tag, int next_s0) {
             constexpr int NT = decltype(nt_tag)::value, PNT = NT ^ 1;
             f32x4_t view[4][2];
 #pragma unroll
@@ -740,21 +744,21 @@ __global__ __launch_bounds__(128 * SQ_PAIRS) void stem_fwd_pipe_kernel(const int
             static_for<28>([&](auto cc) {
                 conv_half(nt_tag, cc, cv, next_s0);
                 __builtin_amdgcn_sched_barrier(0);
-                P.template chunk<PNT * 28 + decltype(cc)::value>(view, S, Q, M);
+                sq_chunk(odd_tag, std::integral_constant<int, PNT * 28 + decltype(cc)::value>{}, view);
                 __builtin_amdgcn_sched_barrier(0);
             });
         };
         auto conv_only = [&](auto nt_tag, f32x4_t (&cv)[4], int next_s0) {
             static_for<28>([&](auto cc) { conv_half(nt_tag, cc, cv, next_s0); });
         };
-        auto pool_only = [&](auto nt_tag, const f32x4_t (&pl)[4], auto& P) {
+        auto pool_only = [&](auto nt_tag, const f32x4_t (&pl)[4], auto odd_tag) {
             constexpr int PNT = decltype(nt_tag)::value;
             f32x4_t view[4][2];
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt) view[mt][PNT] = pl[mt];
-            static_for<28>([&](auto cc) { P.template chunk<PNT * 28 + decltype(cc)::value>(view, S, Q, M); });
+            static_for<28>([&](auto cc) { sq_chunk(odd_tag, std::integral_constant<int, PNT * 28 + decltype(cc)::value>{}, view); });
         };
-        auto next_slot = [&]() { return slot0 + 2 >= SF_RING ? slot0 + 2 - SF_RING : slot0 + 2; };
+        auto next_slot = [&]() { return slot0 + 2 >= SQ_RING ? slot0 + 2 - SQ_RING : slot0 + 2; };
         // row 0, tile 0: nothing to pool yet
         row_top(0);
         frag_w(0, 0, 0);
@@ -763,22 +767,22 @@ __global__ __launch_bounds__(128 * SQ_PAIRS) void stem_fwd_pipe_kernel(const int
         conv_only(T0{}, X, slot0);
         for (int oy = 0; oy < OH; oy += 2) {
             // ---- even row oy ----
-            half(T1{}, Y, X, Pe, next_slot());                    // H1(oy): tile 1 of row oy   | pool tile 0 of row oy
+            half(T1{}, Y, X, std::false_type{}, next_slot());     // H1(oy): tile 1 of row oy   | pool tile 0 of row oy
             slot0 = next_slot();
             row_top(oy + 1);
-            half(T0{}, X, Y, Pe, slot0);                          // H0(oy + 1): tile 0 of row oy + 1 | pool tile 1 of row oy
+            half(T0{}, X, Y, std::false_type{}, slot0);           // H0(oy + 1): tile 0 of row oy + 1 | pool tile 1 of row oy
             // ---- odd row oy + 1: it closes pooling window oy / 2 ----
-            half(T1{}, Y, X, Po, next_slot());                    // H1(oy + 1)                 | pool tile 0 of row oy + 1
+            half(T1{}, Y, X, std::true_type{}, next_slot());      // H1(oy + 1)                 | pool tile 0 of row oy + 1
             slot0 = next_slot();
             H* const yrow = yimg + (size_t)(oy >> 1) * 32 * 64;
             uint8_t* const irow = iimg + (size_t)(oy >> 1) * 32 * 64;
             if (oy + 2 < OH) {
                 row_top(oy + 2);
-                half(T0{}, X, Y, Po, slot0);                      // H0(oy + 2): tile 0 of row oy + 2 | pool tile 1 of row oy + 1
+                half(T0{}, X, Y, std::true_type{}, slot0);        // H0(oy + 2): tile 0 of row oy + 2 | pool tile 1 of row oy + 1
             } else {
-                pool_only(T1{}, Y, Po);                           // the image's last row: nothing left to convolve
+                pool_only(T1{}, Y, std::true_type{});             // the image's last row: nothing left to convolve
             }
-            Po.store(yrow, irow);
+            sq_store(yrow, irow);
         }
         // ---- plane statistics -> mean / rstd of the lane's 8 channels; normalise the wave's own pooled values in place ----
         float mean[2][4], rstd[2][4];
@@ -1436,7 +1440,7 @@ extern "C" int eve_stem_fwd_fused(int dtype, int N, int IH, int IW, const void* 
             (void)hipFuncSetAttribute((const void*)stem_fwd_pipe_kernel<f16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             attr3 = true;
         }
-        const size_t lds3 = (size_t)SQ_PAIRS * SF_RING * SF_ROWB + SF_WBYTES + 64;
+        const size_t lds3 = (size_t)SQ_PAIRS * SQ_RING * SF_ROWB + SF_WBYTES + 64;
         const unsigned want = (unsigned)((N + SQ_PAIRS - 1) / SQ_PAIRS);
         const unsigned blocks3 = want < 256u ? (want ? want : 1u) : 256u;
         EVE_DISPATCH_H16(dtype, EVE_LAUNCH(EVE_HNAME(H, "stem_fwd_pipe_kernel<", ">"), stem_fwd_pipe_kernel<H>, dim3(blocks3), dim3(128 * SQ_PAIRS), lds3,
