@@ -41,8 +41,17 @@ __device__ __forceinline__ int s1_c4(int m, int c) {
     const int hr = (m >> 3) + 1, hc = (m & 7) + 1;
     return (c >> 5) * S1_PLANE + ((hr * 10 + hc) << 6) + (((((c & 31) >> 3)) ^ ((hr & 1) << 1)) << 4) + (c & 7) * 2;
 }
-__device__ __forceinline__ uint4 s1_lds16(uint32_t a) {
-    return __builtin_bit_cast(uint4, *reinterpret_cast<const EVE_LDS s1_u32x4_t*>((uintptr_t)a));
+// A fragment stays one 16-byte VECTOR value from the LDS load to the MFMA operand (round 6: as HIP's uint4 struct the load was
+// split in the middle end and part of the fragments came back as ds_read2_b64 -- twice the LDS cycles of ds_read_b128 and
+// banked differently from what the chunk swizzle is built for; see stem_fused.hip).
+typedef s1_u32x4_t s1_frag_t;
+__device__ __forceinline__ s1_frag_t s1_lds16(uint32_t a) { return *reinterpret_cast<const EVE_LDS s1_u32x4_t*>((uintptr_t)a); }
+template <typename H>
+__device__ __forceinline__ void s1_mfma(f32x4_t& acc, const s1_frag_t& a, const s1_frag_t& b) {
+    if constexpr (Elem<H>::IS_BF16)
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), acc, 0, 0, 0);
+    else
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), acc, 0, 0, 0);
 }
 __device__ __forceinline__ s1_u32x2_t s1_lds8(uint32_t a) { return *reinterpret_cast<const EVE_LDS s1_u32x2_t*>((uintptr_t)a); }
 __device__ __forceinline__ void s1_st8(uint32_t a, uint32_t x, uint32_t y) {
@@ -68,13 +77,13 @@ struct S1Lane {
 
 // One K = 64 step: acc[mt][nt] += W[rows of this wave][tap, 64 k] x X[pixels][tap, 64 k].  fx / fw: [slice][tile].
 template <typename H, int NTL>
-__device__ __forceinline__ void s1_mma(f32x4_t (&acc)[3][NTL], const uint4 (&fx)[2][3], const uint4 (&fw)[2][NTL]) {
+__device__ __forceinline__ void s1_mma(f32x4_t (&acc)[3][NTL], const s1_frag_t (&fx)[2][3], const s1_frag_t (&fw)[2][NTL]) {
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int nt = 0; nt < NTL; ++nt)
 #pragma unroll
-            for (int mt = 0; mt < 3; ++mt) Elem<H>::mfma(acc[mt][nt], fw[j][nt], fx[j][mt]);
+            for (int mt = 0; mt < 3; ++mt) s1_mfma<H>(acc[mt][nt], fw[j][nt], fx[j][mt]);
 }
 
 // ------------------------------------------------------------------------------------------------------------------------
@@ -184,8 +193,8 @@ __global__ __launch_bounds__(S1_NT) void cgru_scan1_fwd_kernel(const int B, cons
             for (int a = 0; a < 3; ++a)
 #pragma unroll
                 for (int c = 0; c < 2; ++c) acc[a][c] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-            uint4 fxA[2][3], fwA[2][2], fxB[2][3], fwB[2][2];
-            auto load = [&](int q, uint32_t gpos, uint4 (&fx)[2][3], uint4 (&fw)[2][2]) {
+            s1_frag_t fxA[2][3], fwA[2][2], fxB[2][3], fwB[2][2];
+            auto load = [&](int q, uint32_t gpos, s1_frag_t (&fx)[2][3], s1_frag_t (&fw)[2][2]) {
                 const int pair = q / 9, tap = q - 9 * pair;       // (q is a compile-time constant after unrolling)
                 const int dy = tap / 3, dx = tap - 3 * dy;
                 const uint32_t la = lds0 + (2 * pair) * S1_PLANE + (dy * 10 + dx) * 64, lb = ldsB + (gpos & 3) * S1_SLOT;
@@ -247,8 +256,8 @@ __global__ __launch_bounds__(S1_NT) void cgru_scan1_fwd_kernel(const int B, cons
             f32x4_t acc[3][1];
 #pragma unroll
             for (int a = 0; a < 3; ++a) acc[a][0] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-            uint4 fxA[2][3], fwA[2][1], fxB[2][3], fwB[2][1];
-            auto load = [&](int q, uint32_t gpos, uint4 (&fx)[2][3], uint4 (&fw)[2][1]) {
+            s1_frag_t fxA[2][3], fwA[2][1], fxB[2][3], fwB[2][1];
+            auto load = [&](int q, uint32_t gpos, s1_frag_t (&fx)[2][3], s1_frag_t (&fw)[2][1]) {
                 const int pair = q / 9, tap = q - 9 * pair;
                 const int dy = tap / 3, dx = tap - 3 * dy;
                 const int plane = pair == 0 ? 4 : 0;              // r * h, then x
@@ -415,8 +424,8 @@ __global__ __launch_bounds__(S1_NT) void cgru_scan1_bwd_kernel(const int B, cons
         asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         __syncthreads();
         f32x4_t acc[3][2];
-        uint4 fxA[2][3], fwA[2][2], fxB[2][3], fwB[2][2];
-        auto load = [&](int pl0, int tap, uint32_t gpos, uint4 (&fx)[2][3], uint4 (&fw)[2][2]) {
+        s1_frag_t fxA[2][3], fwA[2][2], fxB[2][3], fwB[2][2];
+        auto load = [&](int pl0, int tap, uint32_t gpos, s1_frag_t (&fx)[2][3], s1_frag_t (&fw)[2][2]) {
             const int dy = tap / 3, dx = tap - 3 * dy;
             const uint32_t la = lds0 + pl0 * S1_PLANE + (dy * 10 + dx) * 64, lb = ldsB + (gpos & 3) * S1_SLOT;
 #pragma unroll

@@ -47,8 +47,21 @@ __device__ __forceinline__ void sf_dma4(const eve_int4& rsrc, uint32_t lds, int 
                  :: "s"(lds), "v"(voff), "s"(rsrc), "s"(soff) : "memory", "m0");
 }
 typedef uint32_t sf_u32x4_t __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ uint4 sf_lds_read(uint32_t addr) {
-    return __builtin_bit_cast(uint4, *reinterpret_cast<const EVE_LDS sf_u32x4_t*>((uintptr_t)addr));
+typedef uint32_t sf_u32x2_t __attribute__((ext_vector_type(2)));
+// A 16-byte fragment stays ONE vector value from the LDS load to the MFMA operand.  (Round 6: as HIP's uint4 -- a struct -- the
+// load was split into two 8-byte halves by the middle end and the back end re-merged the filter fragments as ds_read2_b64: twice
+// the LDS cycles of ds_read_b128 and banked differently from what the swizzle is built for.  SQ counters of the forward: 59 % of
+// the LDS-array cycles were bank conflicts, the array 70 % busy, 23 % of the wave cycles stalled on LDS issue.)
+typedef sf_u32x4_t sf_frag_t;
+__device__ __forceinline__ sf_frag_t sf_lds_read(uint32_t addr) {
+    return *reinterpret_cast<const EVE_LDS sf_u32x4_t*>((uintptr_t)addr);
+}
+template <typename H>
+__device__ __forceinline__ void sf_mfma(f32x4_t& acc, const sf_frag_t& a, const sf_frag_t& b) {
+    if constexpr (Elem<H>::IS_BF16)
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), acc, 0, 0, 0);
+    else
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), acc, 0, 0, 0);
 }
 template <int CTRL>
 __device__ __forceinline__ uint32_t sf_dpp(uint32_t old, uint32_t src) {
@@ -87,7 +100,7 @@ __device__ __forceinline__ void sf_conv_tap_row(f32x4_t (&acc)[4][4], uint32_t r
     int slot = slot0 + kh;
     slot = slot >= SF_RING ? slot - SF_RING : slot;
     const uint32_t xa = ring + slot * SF_ROWB + xoff, wa = wbase + kh * 4096;
-    uint4 fx[4], fw[4];
+    sf_frag_t fx[4], fw[4];
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) fx[mt] = sf_lds_read(xa + (mt & 1) * 16 + (mt >> 1) * 512);
 #pragma unroll
@@ -99,7 +112,7 @@ __device__ __forceinline__ void sf_conv_tap_row(f32x4_t (&acc)[4][4], uint32_t r
         for (int mt = 0; mt < 4; ++mt)
         {
             if (FIRST) acc[mt][nt] = zero;
-            Elem<H>::mfma(acc[mt][nt], fw[nt], fx[mt]);
+            sf_mfma<H>(acc[mt][nt], fw[nt], fx[mt]);
         }
 }
 // COMPACT keeps the filter-row loop rolled (one set of fragment registers) for the register-hungry backward
@@ -356,6 +369,14 @@ __device__ __forceinline__ void sf_pair_sync(uint32_t my_flag, uint32_t partner_
     while (*(volatile EVE_LDS int*)(size_t)partner_flag < value) __builtin_amdgcn_s_sleep(1);
 }
 
+// Round 6: stem_fwd_fused_kernel's pooling arithmetic, bit for bit, in fewer instructions (the kernel is bound by instruction
+// issue: per SIMD its MFMA, VALU and SALU issue cycles ADD UP to the measured time, profiles/r06_stem.md; 410 -> ~280 VALU per
+// convolution row and wave, 0.372 -> 0.312 ms at N = 1 920 together with the fragment-read fix above) -- the four key bits hold code = 8 - (kh * 3 + kw)
+// directly (row part {8, 5, 2} for kh = {0, 1, 2}, minus kw; larger code = earlier in scan order, as before), so the stored arg-max
+// byte is 8 - code: one packed subtraction per four channels instead of a 64-bit table shift per value; an odd column's key is
+// prepared once (kw = 2 of its own window) and handed to the right-hand neighbour as key + 2 (kw = 0); an odd row's window
+// maximum h becomes the next window's top row as h + 6 (kh 2 -> 0) instead of a second masking pass and a select; even / odd
+// rows are two straight code paths.  Statistics: S += v, Q = fma(v, v, Q) per value.
 template <typename H>
 __global__ __launch_bounds__(1024) void stem_fwd_pairs_kernel(const int N, const int IH, const H* __restrict__ xp, const uint32_t xp_bytes,
                                                               const H* __restrict__ w8, const float eps, H* yp, uint8_t* __restrict__ idx,
@@ -401,6 +422,9 @@ __global__ __launch_bounds__(1024) void stem_fwd_pairs_kernel(const int N, const
             for (int b = 0; b < 4; ++b) { S[a][b] = 0.f; Q[a][b] = 0.f; M[0][a][b] = SF_NEG; M[1][a][b] = SF_NEG; }
         H* yimg = yp + (size_t)nn * PH * 32 * 64;
         uint8_t* iimg = idx + (size_t)nn * PH * 32 * 64;
+        const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)yimg, 0, PH * 32 * 64 * 2, 0x00020000);
+        const __amdgpu_buffer_rsrc_t ri = __builtin_amdgcn_make_buffer_rsrc((void*)iimg, 0, PH * 32 * 64, 0x00020000);
+        const int lane_off = li * 64 + ch0;                       // the lane's first channel of pooled column li, in elements
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         sf_pair_sync(my_flag, partner_flag, ++tick);
         int slot0 = 0;
@@ -413,7 +437,7 @@ __global__ __launch_bounds__(1024) void stem_fwd_pairs_kernel(const int N, const
             if (live) {
                 f32x4_t acc[4][2];
                 {
-                    auto conv_frags = [&](int kh, uint4 (&x4)[4], uint4 (&w2)[2]) {
+                    auto conv_frags = [&](int kh, sf_frag_t (&x4)[4], sf_frag_t (&w2)[2]) {
                         int slot = slot0 + kh;
                         slot = slot >= SF_RING ? slot - SF_RING : slot;
                         const uint32_t xa = ring + slot * SF_ROWB + xoff, wa = wbase + kh * 4096;
@@ -422,16 +446,16 @@ __global__ __launch_bounds__(1024) void stem_fwd_pairs_kernel(const int N, const
 #pragma unroll
                         for (int nt = 0; nt < 2; ++nt) w2[nt] = sf_lds_read(wa + nt * 1024);
                     };
-                    auto conv_mfma = [&](bool first, const uint4 (&x4)[4], const uint4 (&w2)[2]) {
+                    auto conv_mfma = [&](bool first, const sf_frag_t (&x4)[4], const sf_frag_t (&w2)[2]) {
 #pragma unroll
                         for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
                             for (int mt = 0; mt < 4; ++mt) {
                                 if (first) acc[mt][nt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-                                Elem<H>::mfma(acc[mt][nt], w2[nt], x4[mt]);
+                                sf_mfma<H>(acc[mt][nt], w2[nt], x4[mt]);
                             }
                     };
-                    uint4 fxa[4], fwa[2], fxb[4], fwb[2];
+                    sf_frag_t fxa[4], fwa[2], fxb[4], fwb[2];
                     conv_frags(0, fxa, fwa);
                     conv_frags(1, fxb, fwb);
                     conv_mfma(true, fxa, fwa);
@@ -450,61 +474,72 @@ __global__ __launch_bounds__(1024) void stem_fwd_pairs_kernel(const int N, const
 #pragma unroll
                 for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        float s = 0.f, q = 0.f;
+                    for (int r = 0; r < 4; ++r)
 #pragma unroll
-                        for (int mt = 0; mt < 4; ++mt) { const float v = acc[mt][nt][r]; s += v; q += v * v; }
-                        S[nt][r] += s; Q[nt][r] += q;
-                    }
-                // ---- 3x3/2 max-pool on keys (see stem_fwd_fused_kernel) ----
-                const bool odd = oy & 1;
-                const uint32_t khbits = odd ? 0u : 4u;
+                        for (int mt = 0; mt < 4; ++mt) {
+                            const float v = acc[mt][nt][r];
+                            S[nt][r] += v;
+                            Q[nt][r] = __builtin_fmaf(v, v, Q[nt][r]);
+                        }
+                // ---- 3x3/2 max-pool on keys = value bits with the low 4 mantissa bits replaced by 8 - (window position) ----
+                auto pool_row = [&](auto odd_tag) {
+                    constexpr bool ODD = decltype(odd_tag)::value;
+                    constexpr uint32_t CE = ODD ? 1u : 4u, CO = ODD ? 0u : 3u;      // even column kw = 1, odd column kw = 2 (own window)
 #pragma unroll
-                for (int nt = 0; nt < 2; ++nt)
+                    for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        uint32_t carry = 0;
+                        for (int r = 0; r < 4; ++r) {
+                            const float e0 = acc[0][nt][r], o0 = acc[1][nt][r], e1 = acc[2][nt][r], o1 = acc[3][nt][r];
+                            const uint32_t ke0 = (__builtin_bit_cast(uint32_t, e0) & 0xfffffff0u) | CE, ko0 = (__builtin_bit_cast(uint32_t, o0) & 0xfffffff0u) | CO;
+                            const uint32_t ke1 = (__builtin_bit_cast(uint32_t, e1) & 0xfffffff0u) | CE, ko1 = (__builtin_bit_cast(uint32_t, o1) & 0xfffffff0u) | CO;
+                            const uint32_t kl0 = ko0 + 2u, kl1 = ko1 + 2u;          // the same columns as kw = 0 of the windows to their right
+                            // column 2q - 1 = the odd column of lane li - 1; lane 0 of the first tile: the padding (its own even key
+                            // stands in: no maximum changes), of the second tile: the last lane of the first
+                            const uint32_t l0 = sf_dpp<0x111>(ke0, kl0);                                   // row_shr:1
+                            const uint32_t l1 = sf_dpp<0x111>(sf_dpp<0x121>(0u, kl0), kl1);                // row_ror:1, row_shr:1 over it
+                            const float h0 = sf_fmax3(__builtin_bit_cast(float, l0), __builtin_bit_cast(float, ke0), __builtin_bit_cast(float, ko0));
+                            const float h1 = sf_fmax3(__builtin_bit_cast(float, l1), __builtin_bit_cast(float, ke1), __builtin_bit_cast(float, ko1));
+                            const float m0 = fmaxf(__builtin_bit_cast(float, M[0][nt][r]), h0), m1 = fmaxf(__builtin_bit_cast(float, M[1][nt][r]), h1);
+                            if constexpr (ODD) {
+                                acc[0][nt][r] = m0;                                                        // the finished windows, parked in
+                                acc[2][nt][r] = m1;                                                        // the even columns' registers
+                                M[0][nt][r] = __builtin_bit_cast(uint32_t, h0) + 6u;                       // this row as kh = 0 of the next ones
+                                M[1][nt][r] = __builtin_bit_cast(uint32_t, h1) + 6u;
+                            } else {
+                                M[0][nt][r] = __builtin_bit_cast(uint32_t, m0);
+                                M[1][nt][r] = __builtin_bit_cast(uint32_t, m1);
+                            }
+                            if (r & 1) __builtin_amdgcn_sched_barrier(0);            // (two channels' temporaries live at a time, not eight)
+                        }
+                    if constexpr (ODD) {
+                        const int py = oy >> 1;
 #pragma unroll
                         for (int j = 0; j < 2; ++j) {
-                            const float ef = acc[2 * j][nt][r], of = acc[2 * j + 1][nt][r];
-                            const uint32_t e = (__builtin_bit_cast(uint32_t, ef) & 0xfffffff0u) | (khbits | 1u);
-                            const uint32_t o = (__builtin_bit_cast(uint32_t, of) & 0xfffffff0u) | khbits;
-                            const uint32_t ol = (__builtin_bit_cast(uint32_t, of) & 0xfffffff0u) | (khbits | 2u);
-                            const uint32_t edge = j == 0 ? SF_NEG : sf_dpp<0x121>(0u, carry);          // row_ror:1
-                            const uint32_t l = sf_dpp<0x111>(edge, ol);                                  // row_shr:1
-                            carry = ol;
-                            const float hm = sf_fmax3(__builtin_bit_cast(float, l), __builtin_bit_cast(float, e), __builtin_bit_cast(float, o));
-                            const uint32_t hb = __builtin_bit_cast(uint32_t, hm);
-                            const float m = fmaxf(__builtin_bit_cast(float, M[j][nt][r]), hm);
-                            M[j][nt][r] = odd ? (hb | 8u) : __builtin_bit_cast(uint32_t, m);
-                            acc[2 * j][nt][r] = m;
-                        }
-                    }
-                if (odd) {
-                    const int py = oy >> 1;
+                            const size_t o = ((size_t)py * 32 + li + 16 * j) * 64 + ch0;
+                            uint32_t pk[4], ib[2];
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) {
-                        const size_t o = ((size_t)py * 32 + li + 16 * j) * 64 + ch0;
-                        uint32_t pk[4], ib[2];
-#pragma unroll
-                        for (int nt = 0; nt < 2; ++nt) {
-                            uint32_t code[4];
-                            float val[4];
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) {
-                                const float kf = acc[2 * j][nt][r];
-                                const uint32_t k = __builtin_bit_cast(uint32_t, kf);
-                                val[r] = __builtin_bit_cast(float, k & 0xfffffff0u);
-                                code[r] = (uint32_t)(0x01203450678ull >> ((k & 15u) * 4)) & 15u;       // kh*3 + kw
+                            for (int nt = 0; nt < 2; ++nt) {
+                                const float f0 = acc[2 * j][nt][0], f1 = acc[2 * j][nt][1], f2 = acc[2 * j][nt][2], f3 = acc[2 * j][nt][3];
+                                const uint32_t k0 = __builtin_bit_cast(uint32_t, f0), k1 = __builtin_bit_cast(uint32_t, f1);
+                                const uint32_t k2 = __builtin_bit_cast(uint32_t, f2), k3 = __builtin_bit_cast(uint32_t, f3);
+                                pk[2 * nt] = Elem<H>::pack2(__builtin_bit_cast(float, k0 & 0xfffffff0u), __builtin_bit_cast(float, k1 & 0xfffffff0u));
+                                pk[2 * nt + 1] = Elem<H>::pack2(__builtin_bit_cast(float, k2 & 0xfffffff0u), __builtin_bit_cast(float, k3 & 0xfffffff0u));
+                                // arg-max bytes kh * 3 + kw = 8 - code, four channels at once
+                                ib[nt] = 0x08080808u - ((k0 & 15u) | ((k1 & 15u) << 8) | ((k2 & 15u) << 16) | ((k3 & 15u) << 24));
                             }
-                            pk[2 * nt] = Elem<H>::pack2(val[0], val[1]);
-                            pk[2 * nt + 1] = Elem<H>::pack2(val[2], val[3]);
-                            ib[nt] = code[0] | (code[1] << 8) | (code[2] << 16) | (code[3] << 24);
+                            // (buffer stores: the image's base in scalar registers, one 32-bit lane offset, the pooled row and
+                            //  column tile as the scalar offset -- the per-lane 64-bit addresses of the plain stores were spilled)
+                            (void)o;
+                            const int so = (py * 32 + 16 * j) * 64;
+                            sf_u32x4_t pv = {pk[0], pk[1], pk[2], pk[3]};
+                            sf_u32x2_t iv = {ib[0], ib[1]};
+                            __builtin_amdgcn_raw_buffer_store_b128(pv, ry, lane_off * 2, so * 2, 0);
+                            __builtin_amdgcn_raw_buffer_store_b64(iv, ri, lane_off, so, 0);
                         }
-                        *reinterpret_cast<uint4*>(yimg + o) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
-                        *reinterpret_cast<uint2*>(iimg + o) = make_uint2(ib[0], ib[1]);
                     }
-                }
+                };
+                if (oy & 1) pool_row(std::true_type{});
+                else pool_row(std::false_type{});
             }
             slot0 = slot0 + 2 >= SF_RING ? slot0 + 2 - SF_RING : slot0 + 2;
         }
@@ -524,292 +559,18 @@ __global__ __launch_bounds__(1024) void stem_fwd_pairs_kernel(const int N, const
                         m[0] = s; m[1] = rstd[nt][r];
                     }
                 }
-            for (int py = 0; py < PH; ++py)
+#pragma unroll 4
+            for (int py = 0; py < PH; ++py)                       // (four pooled rows of loads in flight)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
-                    H* p = yimg + ((size_t)py * 32 + li + 16 * j) * 64 + ch0;
+                    const int so = (py * 32 + 16 * j) * 64 * 2;
                     float f[8];
-                    Elem<H>::unpack(*reinterpret_cast<const uint4*>(p), f);
+                    Elem<H>::unpack(__builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(ry, lane_off * 2, so, 0)), f);
 #pragma unroll
                     for (int c = 0; c < 8; ++c) f[c] = fmaxf((f[c] - mean[c >> 2][c & 3]) * rstd[c >> 2][c & 3], 0.f);
-                    *reinterpret_cast<uint4*>(p) = Elem<H>::pack(f);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(sf_u32x4_t, Elem<H>::pack(f)), ry, lane_off * 2, so, 0);
                 }
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        sf_pair_sync(my_flag, partner_flag, ++tick);              // the ring is rewritten by the next turn
-    }
-}
-
-// =================================================================================================
-// Round 6: the wave-pair forward, SOFTWARE-PIPELINED -- the convolution of row r + 1 is issued under the statistics / pooling
-// VALU of row r (two accumulator sets), and the pooling itself costs ~40 % fewer instructions.
-//
-// What the counters of stem_fwd_pairs_kernel said (profiles/r05_notes.md 9, 13): matrix pipe 31 % busy, VALU
-// ~30 %, 43 % of the wave cycles at a counter wait -- 240 half-rows per SIMD take 3 100 cycles each where their 56 MFMAs need
-// 950: a wave runs [fragment reads -> 56 MFMAs -> ~410 VALU -> stores] as ONE dependent chain per row, and four such chains per
-// SIMD do not cover each other.  Here a wave keeps TWO rows in flight: while the matrix pipe works on row r + 1 (accumulator set
-// B) the wave's VALU slots between the MFMAs carry row r's statistics and pooling (set A), then the sets swap.  That costs 32
-// more accumulator registers and the double-buffered fragments stay (~190 VGPRs: two waves per SIMD, four pairs per CU instead
-// of eight) -- fewer, fatter waves, each near the matrix pipe's pace instead of a third of it.
-//
-// The pooling arithmetic is stem_fwd_pairs_kernel's, bit for bit (same 28-bit value keys, same winner under ties: the window
-// position that comes first in scan order), re-encoded so that it costs less:
-//   * the four key bits hold code = 8 - (kh * 3 + kw) directly (row part {8, 5, 2} for kh = {0, 1, 2}, minus kw), so the stored
-//     arg-max byte is 8 - code -- one packed subtraction per four channels instead of a 64-bit table shift per value;
-//   * an odd column's key is prepared once (kw = 2 for its own window) and handed to the right-hand neighbour as key + 2 (kw = 0);
-//     an odd row's window maximum h becomes the next window's top row as h + 6 (kh 2 -> 0): no second masking pass, no select.
-// Statistics: S += v, Q = fma(v, v, Q) per value (the pairs kernel summed four values first and squared separately; the plane
-// sums differ from it in the last float bits, like any two of the stem kernels).
-// =================================================================================================
-constexpr int SQ_PAIRS = 4;                       // images per workgroup and turn: eight waves, two per SIMD
-constexpr int SQ_AHEAD = 6;                       // convolution rows of input staged ahead ON TOP of stem_fwd_pairs_kernel's two
-constexpr int SQ_RING = 24;                       // ring slots per pair (>= 11 + 2 * SQ_AHEAD): 4 x 30 KB + 28 KB of filters
-
-// The statistics + pooling work of ONE convolution row (the wave's 4 column tiles x 8 channels) is cut into 56 chunks of ~4 VALU
-// instructions -- one per MFMA of the tile that is being convolved meanwhile (sq_chunk below, inside the kernel: its state is
-// plain local variables; as members of a struct the compiler merged two neighbours into one vector load and left them in scratch).
-// Chunk C = 7 * (4 nt + r) + phase works on channel (nt, r): phases 0-1 statistics, 2-3 keys, 3-4 the left neighbours (DPP) and
-// the row maxima, 5 the window, 6 (odd rows) the output.
-template <typename H>
-__global__ __launch_bounds__(128 * SQ_PAIRS) void stem_fwd_pipe_kernel(const int N, const int IH, const H* __restrict__ xp, const uint32_t xp_bytes,
-                                                                       const H* __restrict__ w8, const float eps, H* yp, uint8_t* __restrict__ idx,
-                                                                       float* __restrict__ mr) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* const sW = smem + SQ_PAIRS * SQ_RING * SF_ROWB;
-    int* const sFlag = reinterpret_cast<int*>(sW + SF_WBYTES);
-    const int tid = threadIdx.x;
-    sf_fill_weights<H>(sW, w8, tid, 128 * SQ_PAIRS);
-    if (tid < 2 * SQ_PAIRS) sFlag[tid] = 0;
-    __syncthreads();
-
-    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int pair = wave >> 1, h = wave & 1;
-    const int li = lane & 15, lg = lane >> 4;
-    const int OH = IH / 2, PH = OH / 2, rows = IH + 6;
-    const uint32_t ring = lds_addr_of(smem) + pair * (SQ_RING * SF_ROWB);
-    const uint32_t xoff = 16 * (2 * li + lg);
-    const uint32_t wbase = lds_addr_of(sW) + (2 * h) * 1024 + li * 64 + ((lg ^ (((li >> 2) & 1) << 1)) << 4);
-    const eve_int4 rs = make_rsrc_words(xp, xp_bytes);
-    const float inv_hw = 1.f / (float)(OH * 64);
-    const int ch0 = lg * 16 + 8 * h;                      // the lane's 8 channels
-    const uint32_t my_flag = lds_addr_of(sFlag) + wave * 4, partner_flag = lds_addr_of(sFlag) + (wave ^ 1) * 4;
-    int tick = 0;
-
-    const int per_turn = gridDim.x * SQ_PAIRS;
-    const int turns = (N + per_turn - 1) / per_turn;
-    for (int turn = 0; turn < turns; ++turn) {
-        const int n = turn * per_turn + pair * (int)gridDim.x + (int)blockIdx.x;
-        if (n >= N) break;                                        // (uniform per pair; later turns have no image either)
-        const int img_off = n * rows * SF_XROW;
-        // stage padded input row `row` into its slot of the deeper ring (rows past the image: zeros)
-        auto stage = [&](int row) {
-            const int slot = row % SQ_RING;
-            const bool in = row < rows;
-            const int soff = in ? img_off + row * SF_XROW : 0;
-            sf_dma16(rs, ring + slot * SF_ROWB, in ? lane * 16 + 8 : EVE_OOB, soff);
-            sf_dma4(rs, ring + slot * SF_ROWB + 1024, in ? lane * 4 + 8 + 1024 : EVE_OOB, soff);
-        };
-        for (int r = h; r < 9 + 2 * SQ_AHEAD; r += 2) stage(r);
-        float S[2][4], Q[2][4];
-        uint32_t M[2][2][4];
-#pragma unroll
-        for (int a = 0; a < 2; ++a)
-#pragma unroll
-            for (int b = 0; b < 4; ++b) { S[a][b] = 0.f; Q[a][b] = 0.f; M[0][a][b] = SF_NEG; M[1][a][b] = SF_NEG; }
-        H* const yimg = yp + (size_t)n * PH * 32 * 64 + (size_t)li * 64 + ch0;
-        uint8_t* const iimg = idx + (size_t)n * PH * 32 * 64 + (size_t)li * 64 + ch0;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        sf_pair_sync(my_flag, partner_flag, ++tick);
-        // the top of a convolution row: the input rows it reads have landed -- mine were requested SQ_AHEAD + 2 rows ago, so the
-        // DMAs of the SQ_AHEAD + 1 newest requests may still be in flight (pooled-row stores among them only make the wait stricter)
-        // --, the partner is past the previous row's ring reads, the next input row is requested.  (A wave of this kernel wants a
-        // row every ~0.5 us; the two rows of look-ahead of stem_fwd_pairs_kernel are less than one HBM round trip then.)
-        auto row_top = [&](int oy) {
-            if (oy >= 2) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * (SQ_AHEAD + 1)) : "memory");
-            sf_pair_sync(my_flag, partner_flag, ++tick);
-            stage(2 * oy + 9 + 2 * SQ_AHEAD + h);
-        };
-        // ---- the pipeline ----
-        // A row is TWO half-steps of 28 MFMAs, one per weight tile (nt = 0: the lane's channels 0-3, nt = 1: channels 4-7), and
-        // every MFMA is followed by one ~4-instruction chunk of the statistics / pooling of the tile that was finished one
-        // half-step earlier: an in-order wave overlaps its own matrix and vector work only when they alternate in program order.
-        //     H0(r): conv(row r, nt 0) -> X   with  pool(row r - 1, nt 1) on Y
-        //     H1(r): conv(row r, nt 1) -> Y   with  pool(row r,     nt 0) on X
-        // so two 16-register accumulator sets do (a whole row in flight next to a whole row being pooled needs 64 and spills).
-        // The input fragments are read once per half-step (twice per row: 70 instead of 42 fragment reads per row and wave);
-        // each is used by one MFMA per filter row and re-requested right behind it for the next filter row -- or for filter
-        // row 0 of the NEXT half-step, whose input rows are resident already (a new convolution row only adds rows kh = 5, 6) --
-        // four MFMA slots ahead of its use; the weight tile is double-buffered (requested one filter row ahead).
-        uint4 fx[4], fw[2];
-        int slot0 = 0;                                            // ring slot of input row 2 * (current convolution row)
-        auto frag_x = [&](int s0, int kh, int mt) {
-            int slot = s0 + kh;
-            slot = slot >= SQ_RING ? slot - SQ_RING : slot;
-            fx[mt] = sf_lds_read(ring + slot * SF_ROWB + xoff + (mt & 1) * 16 + (mt >> 1) * 512);
-        };
-        auto frag_w = [&](int kh, int nt, int buf) { fw[buf] = sf_lds_read(wbase + kh * 4096 + nt * 1024); };
-        // half-step NT of the current row; `next_s0`: ring slot of the row the following half-step convolves
-        auto conv_half = [&](auto nt_tag, auto cc, f32x4_t (&cv)[4], int next_s0) {
-            constexpr int NT = decltype(nt_tag)::value, C = decltype(cc)::value, kh = C >> 2, mt = C & 3;
-            constexpr int buf = (kh + NT) & 1;                    // seven filter rows per half-step: the buffer parity alternates
-            if (mt == 0) {
-                if (kh + 1 < 7) frag_w(kh + 1, NT, buf ^ 1);
-                else frag_w(0, NT ^ 1, buf ^ 1);
-            }
-            if (kh == 0) cv[mt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-            Elem<H>::mfma(cv[mt], fw[buf], fx[mt]);
-            if (kh + 1 < 7) frag_x(slot0, kh + 1, mt);
-            else frag_x(next_s0, 0, mt);
-        };
-        auto pool_view = [&](const f32x4_t (&t)[4], auto nt_tag, f32x4_t (&full)[4][2]) {   // SqPool indexes acc[mt][nt]
-            constexpr int NT = decltype(nt_tag)::value;
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt) full[mt][NT] = t[mt];
-        };
-        f32x4_t X[4], Y[4];
-        using T0 = std::integral_constant<int, 0>;
-        using T1 = std::integral_constant<int, 1>;
-        uint32_t ke0, ke1, ko0, ko1, kl0, kl1, l0, l1, wk0, wk1, vp0, vp1, hm0, hm1;    // one channel's keys (hm: row maxima)
-        uint32_t pk00, pk01, pk02, pk03, pk10, pk11, pk12, pk13, cb00, cb01, cb10, cb11;  // an odd row's output, as it forms
-        auto key = [](float v, uint32_t code) { return (__builtin_bit_cast(uint32_t, v) & 0xfffffff0u) | code; };
-        auto fk = [](uint32_t k) { return __builtin_bit_cast(float, k); };
-        auto sq_chunk = [&](auto odd_tag, auto cc, const f32x4_t (&acc)[4][2]) {
-            constexpr bool ODD = decltype(odd_tag)::value;
-            constexpr int C = decltype(cc)::value, nt = (C / 7) >> 2, r = (C / 7) & 3, ph = C % 7;
-            constexpr uint32_t CE = ODD ? 1u : 4u, CO = ODD ? 0u : 3u;  // even column kw = 1, odd column kw = 2 of its own window
-            if constexpr (ph == 0 || ph == 1) {
-#pragma unroll
-                for (int mt = 2 * ph; mt < 2 * ph + 2; ++mt) {
-                    const float v = acc[mt][nt][r];
-                    S[nt][r] += v;
-                    Q[nt][r] = __builtin_fmaf(v, v, Q[nt][r]);
-                }
-            } else if constexpr (ph == 2) {
-                const float e0 = acc[0][nt][r], o0 = acc[1][nt][r], e1 = acc[2][nt][r];
-                ke0 = key(e0, CE);
-                ko0 = key(o0, CO);
-                kl0 = ko0 + 2u;                                         // the same column as kw = 0 of the window to its right
-                ke1 = key(e1, CE);
-            } else if constexpr (ph == 3) {
-                const float o1 = acc[3][nt][r];
-                ko1 = key(o1, CO);
-                kl1 = ko1 + 2u;
-                // column 2q - 1 = the odd column of lane li - 1; lane 0 of the first tile: the padding -- its own even key stands in
-                l0 = sf_dpp<0x111>(ke0, kl0);                                            // row_shr:1
-            } else if constexpr (ph == 4) {
-                // ... lane 0 of the second tile: the last lane of the first
-                l1 = sf_dpp<0x111>(sf_dpp<0x121>(0u, kl0), kl1);                         // row_ror:1, then row_shr:1 over it
-                hm0 = __builtin_bit_cast(uint32_t, sf_fmax3(fk(l0), fk(ke0), fk(ko0)));
-                hm1 = __builtin_bit_cast(uint32_t, sf_fmax3(fk(l1), fk(ke1), fk(ko1)));
-            } else if constexpr (ph == 5) {
-                const float m0 = fmaxf(fk(M[0][nt][r]), fk(hm0)), m1 = fmaxf(fk(M[1][nt][r]), fk(hm1));
-                if constexpr (ODD) {
-                    wk0 = __builtin_bit_cast(uint32_t, m0);                              // the finished windows
-                    wk1 = __builtin_bit_cast(uint32_t, m1);
-                    M[0][nt][r] = hm0 + 6u;                                              // this row as kh = 0 of the next ones
-                    M[1][nt][r] = hm1 + 6u;
-                } else {
-                    M[0][nt][r] = __builtin_bit_cast(uint32_t, m0);
-                    M[1][nt][r] = __builtin_bit_cast(uint32_t, m1);
-                }
-            } else if constexpr (ODD) {
-                const uint32_t v0 = wk0 & 0xfffffff0u, v1 = wk1 & 0xfffffff0u, c0 = wk0 & 15u, c1 = wk1 & 15u;
-                uint32_t& cb0 = nt == 0 ? cb00 : cb01;
-                uint32_t& cb1 = nt == 0 ? cb10 : cb11;
-                if constexpr (r == 0) { cb0 = c0; cb1 = c1; }
-                else { cb0 |= c0 << (8 * r); cb1 |= c1 << (8 * r); }
-                if constexpr ((r & 1) == 0) { vp0 = v0; vp1 = v1; }
-                else {
-                    const uint32_t p0 = Elem<H>::pack2(fk(vp0), fk(v0)), p1 = Elem<H>::pack2(fk(vp1), fk(v1));
-                    if constexpr (nt == 0 && r == 1) { pk00 = p0; pk10 = p1; }
-                    else if constexpr (nt == 0) { pk01 = p0; pk11 = p1; }
-                    else if constexpr (r == 1) { pk02 = p0; pk12 = p1; }
-                    else { pk03 = p0; pk13 = p1; }
-                }
-            }
-        };
-        // the pooled row leaves: 8 channels x 2 columns per lane, arg-max bytes kh * 3 + kw = 8 - code
-        auto sq_store = [&](H* __restrict__ yrow, uint8_t* __restrict__ irow) {
-            *reinterpret_cast<uint4*>(yrow) = make_uint4(pk00, pk01, pk02, pk03);
-            *reinterpret_cast<uint2*>(irow) = make_uint2(0x08080808u - cb00, 0x08080808u - cb01);
-            *reinterpret_cast<uint4*>(yrow + (size_t)16 * 64) = make_uint4(pk10, pk11, pk12, pk13);
-            *reinterpret_cast<uint2*>(irow + (size_t)16 * 64) = make_uint2(0x08080808u - cb10, 0x08080808u - cb11);
-        };
-        // one half-step: 28 x (MFMA, pool chunk); POOLNT = the weight tile whose previous result is pooled meanwhile
-        auto half = [&](auto nt_tag, f32x4_t (&cv)[4], const f32x4_t (&pl)[4], auto odd_tag, int next_s0) {
-            constexpr int NT = decltype(nt_tag)::value, PNT = NT ^ 1;
-            f32x4_t view[4][2];
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt) view[mt][PNT] = pl[mt];
-            static_for<28>([&](auto cc) {
-                conv_half(nt_tag, cc, cv, next_s0);
-                __builtin_amdgcn_sched_barrier(0);
-                sq_chunk(odd_tag, std::integral_constant<int, PNT * 28 + decltype(cc)::value>{}, view);
-                __builtin_amdgcn_sched_barrier(0);
-            });
-        };
-        auto conv_only = [&](auto nt_tag, f32x4_t (&cv)[4], int next_s0) {
-            static_for<28>([&](auto cc) { conv_half(nt_tag, cc, cv, next_s0); });
-        };
-        auto pool_only = [&](auto nt_tag, const f32x4_t (&pl)[4], auto odd_tag) {
-            constexpr int PNT = decltype(nt_tag)::value;
-            f32x4_t view[4][2];
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt) view[mt][PNT] = pl[mt];
-            static_for<28>([&](auto cc) { sq_chunk(odd_tag, std::integral_constant<int, PNT * 28 + decltype(cc)::value>{}, view); });
-        };
-        auto next_slot = [&]() { return slot0 + 2 >= SQ_RING ? slot0 + 2 - SQ_RING : slot0 + 2; };
-        // row 0, tile 0: nothing to pool yet
-        row_top(0);
-        frag_w(0, 0, 0);
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt) frag_x(0, 0, mt);
-        conv_only(T0{}, X, slot0);
-        for (int oy = 0; oy < OH; oy += 2) {
-            // ---- even row oy ----
-            half(T1{}, Y, X, std::false_type{}, next_slot());     // H1(oy): tile 1 of row oy   | pool tile 0 of row oy
-            slot0 = next_slot();
-            row_top(oy + 1);
-            half(T0{}, X, Y, std::false_type{}, slot0);           // H0(oy + 1): tile 0 of row oy + 1 | pool tile 1 of row oy
-            // ---- odd row oy + 1: it closes pooling window oy / 2 ----
-            half(T1{}, Y, X, std::true_type{}, next_slot());      // H1(oy + 1)                 | pool tile 0 of row oy + 1
-            slot0 = next_slot();
-            H* const yrow = yimg + (size_t)(oy >> 1) * 32 * 64;
-            uint8_t* const irow = iimg + (size_t)(oy >> 1) * 32 * 64;
-            if (oy + 2 < OH) {
-                row_top(oy + 2);
-                half(T0{}, X, Y, std::true_type{}, slot0);        // H0(oy + 2): tile 0 of row oy + 2 | pool tile 1 of row oy + 1
-            } else {
-                pool_only(T1{}, Y, std::true_type{});             // the image's last row: nothing left to convolve
-            }
-            sq_store(yrow, irow);
-        }
-        // ---- plane statistics -> mean / rstd of the lane's 8 channels; normalise the wave's own pooled values in place ----
-        float mean[2][4], rstd[2][4];
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float s = sf_row_sum16(S[nt][r]) * inv_hw, q = sf_row_sum16(Q[nt][r]) * inv_hw;
-                const float var = fmaxf(q - s * s, 0.f);
-                mean[nt][r] = s;
-                rstd[nt][r] = rsqrtf(var + eps);
-                if (li == 0) {
-                    float* m = mr + ((size_t)n * 64 + ch0 + nt * 4 + r) * 2;
-                    m[0] = s; m[1] = rstd[nt][r];
-                }
-            }
-#pragma unroll 4
-        for (int py = 0; py < PH; ++py)
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                H* p = yimg + ((size_t)py * 32 + 16 * j) * 64;
-                float f[8];
-                Elem<H>::unpack(*reinterpret_cast<const uint4*>(p), f);
-#pragma unroll
-                for (int c = 0; c < 8; ++c) f[c] = fmaxf((f[c] - mean[c >> 2][c & 3]) * rstd[c >> 2][c & 3], 0.f);
-                *reinterpret_cast<uint4*>(p) = Elem<H>::pack(f);
-            }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         sf_pair_sync(my_flag, partner_flag, ++tick);              // the ring is rewritten by the next turn
     }
@@ -1284,7 +1045,7 @@ __global__ __launch_bounds__(128 * PAIRS, 2) void stem_bwd_wgrad_kernel(const in
                     //    fragments requested before the first row's MFMAs (a full double buffer over all seven rows spills: the
                     //    112 weight-gradient accumulators leave ~90 registers for everything else) --
                     f32x4_t acc[4][2];
-                    auto conv_frags = [&](int kh, uint4 (&x4)[4], uint4 (&w2)[2]) {
+                    auto conv_frags = [&](int kh, sf_frag_t (&x4)[4], sf_frag_t (&w2)[2]) {
                         int slot = slot0 + kh;
                         slot = slot >= SF_RING ? slot - SF_RING : slot;
                         const uint32_t xa = ring + slot * SF_ROWB + xoff, wa = wbase + kh * 4096;
@@ -1293,17 +1054,17 @@ __global__ __launch_bounds__(128 * PAIRS, 2) void stem_bwd_wgrad_kernel(const in
 #pragma unroll
                         for (int nt = 0; nt < 2; ++nt) w2[nt] = sf_lds_read(wa + nt * 1024);
                     };
-                    auto conv_mfma = [&](bool first, const uint4 (&x4)[4], const uint4 (&w2)[2]) {
+                    auto conv_mfma = [&](bool first, const sf_frag_t (&x4)[4], const sf_frag_t (&w2)[2]) {
 #pragma unroll
                         for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
                             for (int mt = 0; mt < 4; ++mt) {
                                 if (first) acc[mt][nt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-                                Elem<H>::mfma(acc[mt][nt], w2[nt], x4[mt]);
+                                sf_mfma<H>(acc[mt][nt], w2[nt], x4[mt]);
                             }
                     };
                     {
-                        uint4 fxa[4], fwa[2], fxb[4], fwb[2];
+                        sf_frag_t fxa[4], fwa[2], fxb[4], fwb[2];
                         conv_frags(0, fxa, fwa);
                         conv_frags(1, fxb, fwb);
                         conv_mfma(true, fxa, fwa);
@@ -1432,21 +1193,6 @@ extern "C" int eve_stem_fwd_fused(int dtype, int N, int IH, int IW, const void* 
         (void)hipFuncSetAttribute((const void*)stem_fwd_fused_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void*)stem_fwd_fused_kernel<f16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
-    }
-    if (g_cfg.stem_fwd_pairs == 2) { // round 6: the wave-pair kernel software-pipelined over rows (two accumulator sets), 8 waves per CU
-        static bool attr3 = false;
-        if (!attr3) {
-            (void)hipFuncSetAttribute((const void*)stem_fwd_pipe_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            (void)hipFuncSetAttribute((const void*)stem_fwd_pipe_kernel<f16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            attr3 = true;
-        }
-        const size_t lds3 = (size_t)SQ_PAIRS * SQ_RING * SF_ROWB + SF_WBYTES + 64;
-        const unsigned want = (unsigned)((N + SQ_PAIRS - 1) / SQ_PAIRS);
-        const unsigned blocks3 = want < 256u ? (want ? want : 1u) : 256u;
-        EVE_DISPATCH_H16(dtype, EVE_LAUNCH(EVE_HNAME(H, "stem_fwd_pipe_kernel<", ">"), stem_fwd_pipe_kernel<H>, dim3(blocks3), dim3(128 * SQ_PAIRS), lds3,
-                                           (hipStream_t)stream, N, IH, (const H*)x_padded, (uint32_t)xb, (const H*)w_ohwi8, eps, (H*)y_pool, idx, mean_rstd));
-        EVE_CHECK_LAUNCH();
-        return 0;
     }
     if (g_cfg.stem_fwd_pairs) {      // round 4: two waves per image, 32 channels each, 16 waves per CU
         static bool attr2 = false;

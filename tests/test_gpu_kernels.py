@@ -204,22 +204,21 @@ def test_stem_fused_forward_matches_unfused(hip, N, hdt):
 
 @HALVES
 @pytest.mark.parametrize('N', [3, 19, 1100])
-def test_stem_forward_software_pipelined_equals_the_pairs_kernel(hip, N, hdt):
-    """Round 6: stem_fwd_pipe_kernel (the wave-pair forward with the convolution of row r + 1 issued under the statistics / pooling
-    of row r, dense arg-max codes) against stem_fwd_pairs_kernel on the same inputs: the SAME pooling arithmetic -- pooled tensor
-    and arg-max bit for bit (normalised with its own statistics, so those must agree to the last bits too) -- statistics in another
-    float summation order; N = 1 100 > 1 024 image slots: a second turn.  (The pairs kernel is tied to the unfused path and to the
-    float reference by test_stem_fused_forward_matches_unfused.)"""
+def test_stem_forward_lean_pooling_equals_the_table_coded_kernel(hip, N, hdt):
+    """Round 6: stem_fwd_pairs_kernel pools with dense arg-max codes 8 - (kh * 3 + kw) in the key bits, one key per odd column, h + 6
+    for the next window's top row and straight even / odd row paths; stem_fwd_fused_kernel (one wave per image, stem_fwd_pairs = 0)
+    keeps the round-1 table-coded form.  Same inputs: the SAME pooling arithmetic -- arg-max bit for bit, pooled values equal
+    wherever the two kernels' statistics round alike (they sum in different float orders); N = 1 100 > 1 024 image slots: a second
+    turn.  (test_stem_fused_forward_matches_unfused ties the shipped kernel to the unfused path and to the float reference.)"""
     src = rnd((N, 3, 128, 128), torch.float32, 62) + 0.3
     w = rnd((64, 7, 7, 8), hdt, 63, scale=0.08)
     w[..., 3:] = 0
     xp = hip.stem_pack_input(dev(src), dtype=hdt)
-    with hip.dispatch_override(stem_fwd_pairs=1):
+    with hip.dispatch_override(stem_fwd_pairs=0, stem_split=0):
         y1, i1, m1 = hip.stem_fwd_fused(xp, dev(w))
-        assert hip.lib.eve_last_kernel().decode().startswith('stem_fwd_pairs_kernel')
-    with hip.dispatch_override(stem_fwd_pairs=2):
-        y2, i2, m2 = hip.stem_fwd_fused(xp, dev(w))
-        assert hip.lib.eve_last_kernel().decode().startswith('stem_fwd_pipe_kernel')
+        assert hip.lib.eve_last_kernel().decode().startswith('stem_fwd_fused_kernel')
+    y2, i2, m2 = hip.stem_fwd_fused(xp, dev(w))
+    assert hip.lib.eve_last_kernel().decode().startswith('stem_fwd_pairs_kernel')
     assert torch.equal(i1, i2)
     assert float((m1[..., 0] - m2[..., 0]).abs().max()) <= 2e-6 * max(1.0, float(m1[..., 0].abs().max()))
     assert float(((m1[..., 1] - m2[..., 1]) / m1[..., 1]).abs().max()) <= 2e-5
