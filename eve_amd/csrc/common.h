@@ -5,9 +5,18 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+#include <utility>
+
 #include "../../include/eve_hip.h"
 
 namespace eve {
+// f(std::integral_constant<int, 0>{}), ..., f(std::integral_constant<int, N - 1>{}): a loop whose index is a compile-time constant
+template <typename F, int... I>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
+
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;

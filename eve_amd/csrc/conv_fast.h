@@ -483,6 +483,33 @@ __global__ __launch_bounds__(64 * WCO * WK) void wgrad_tr_kernel(const GatherPar
         q_tx[j] = ox_t * p.o_mul + q_dx[j];
         q_const[j] = q_col[j] == EVE_OOB ? EVE_OOB : ((n_t * p.IH + q_ty[j]) * p.IW + q_tx[j]) * cin2 + q_col[j];
     }
+    // ---- MODE 1, round 6: validity as bit masks.  SQ counters of wgrad_tr_kernel<., 2, 2, 1> on ResNet layer 2 (profiles/r06_notes.md):
+    // 3.7 VALU + 2.8 SALU per 16-cycle MFMA -- the SIMDs' issue slots, not the matrix pipe (38 % busy), set its time, and most of
+    // those instructions decide, per DMA slot and stage, whether the gathered pixel lies inside the image.  With power-of-two
+    // sizes and a padding that does not exceed the stride, a stage (32 consecutive output pixels = part of a row, whole rows or
+    // whole images) can only leave the image at the image's FIRST / LAST rows or columns, and whether THIS lane's pixel does
+    // there is a lane constant: bit 0 / 1 = outside when the stage holds the image's top / bottom rows, bit 2 / 3 = outside when
+    // it holds its left / right columns, bit 4 = a filter column beyond K (always outside).  Per stage the scalar side forms the
+    // same five flags from (oy_s, ox_s); a slot is valid iff (bits & flags) == 0: v_and + v_cmp + v_add + v_cndmask per slot,
+    // no condition arithmetic on the scalar unit.
+    const int c_x = p.OW < STEP ? p.OW : STEP;                                   // columns of a row one stage covers
+    const int r_y = p.OH * p.OW <= STEP ? p.OH : (p.OW >= STEP ? 1 : STEP / p.OW);   // rows of an image one stage covers
+    const bool bits_ok = MODE == 1 && -p.off <= p.o_mul && (p.KH - 1) * p.k_mul + p.off <= p.o_mul &&
+                         (p.KW - 1) * p.k_mul + p.off <= p.o_mul;                // (uniform: padding / filter reach <= stride)
+    int p_bits[P_DMA], q_bits[Q_DMA];
+#pragma unroll
+    for (int j = 0; j < P_DMA; ++j) p_bits[j] = p_col[j] == EVE_OOB ? 16 : 0;
+#pragma unroll
+    for (int j = 0; j < Q_DMA; ++j) {
+        const uint32_t r = (uint32_t)q_row[j];
+        const int oy_t = (int)((r >> sh_w) & (uint32_t)(p.OH - 1)), ox_t = (int)(r & (uint32_t)(p.OW - 1));
+        int b = q_col[j] == EVE_OOB ? 16 : 0;
+        b |= (oy_t * p.o_mul + q_dy[j] < 0) ? 1 : 0;
+        b |= ((p.OH - r_y + oy_t) * p.o_mul + q_dy[j] >= p.IH) ? 2 : 0;
+        b |= (ox_t * p.o_mul + q_dx[j] < 0) ? 4 : 0;
+        b |= ((p.OW - c_x + ox_t) * p.o_mul + q_dx[j] >= p.IW) ? 8 : 0;
+        q_bits[j] = b;
+    }
     auto offsets = [&](uint32_t mbase, int* vp, int* vq) {   // branch-free: selects only
         if (MODE == 1) {
             const uint32_t left = m_end > mbase ? m_end - mbase : 0u;          // rows of this stage still in range
@@ -490,6 +517,15 @@ __global__ __launch_bounds__(64 * WCO * WK) void wgrad_tr_kernel(const GatherPar
             const uint32_t n_s = mbase >> sh_hw, oy_s = (mbase >> sh_w) & (uint32_t)(p.OH - 1), ox_s = mbase & (uint32_t)(p.OW - 1);
             const int sy0 = (int)oy_s * p.o_mul, sx0 = (int)ox_s * p.o_mul;
             const int qbase = (((int)n_s * p.IH + sy0) * p.IW + sx0) * cin2;
+            if (bits_ok && left >= (uint32_t)STEP) {                            // (uniform) every row of the stage is in range
+                const int flags = 16 | (oy_s == 0u ? 1 : 0) | (oy_s == (uint32_t)(p.OH - r_y) ? 2 : 0) | (ox_s == 0u ? 4 : 0) |
+                                  (ox_s == (uint32_t)(p.OW - c_x) ? 8 : 0);
+#pragma unroll
+                for (int j = 0; j < P_DMA; ++j) vp[j] = (p_bits[j] & flags) == 0 ? pbase + p_const[j] : EVE_OOB;
+#pragma unroll
+                for (int j = 0; j < Q_DMA; ++j) vq[j] = (q_bits[j] & flags) == 0 ? qbase + q_const[j] : EVE_OOB;
+                return;
+            }
 #pragma unroll
             for (int j = 0; j < P_DMA; ++j)
                 vp[j] = ((uint32_t)p_row[j] < left) & (p_const[j] != EVE_OOB) ? pbase + p_const[j] : EVE_OOB;
@@ -587,7 +623,13 @@ __global__ __launch_bounds__(64 * WCO * WK) void wgrad_tr_kernel(const GatherPar
             issue(pre, vp, vq);
         }
         offsets(m_begin + (RING - 1) * STEP, vp, vq);
-        auto do_step = [&](int st) {
+        // One step on ring slot `slot` with the fragments' base addresses pbs / qbs.  MODE 1 (round 6): the loop is unrolled over
+        // the ring, `slot` is a compile-time constant, pbs / qbs are lane constants with the LDS base folded in and the slot's
+        // displacement (SB) is an IMMEDIATE of the transposing reads -- a run-time slot cost a modulo, a multiply and one v_add per
+        // read.  Other modes (RefineNet's planes) and the BIAS variants keep the run-time slot: unrolled they need > 168 registers
+        // (two workgroups per CU instead of three).
+        auto step_body = [&](int st, int slot, auto sb_c, const uint32_t (&pbs)[4], const uint32_t (&qbs)[4]) {
+            constexpr int SB = decltype(sb_c)::value;
             // stage st has landed once at most the RING-2 newer stages are outstanding (loads return in order)
             static_assert((RING == 3 && (NDMA == 4 || NDMA == 5 || NDMA == 6)) || (RING == 4 && (NDMA == 4 || NDMA == 5 || NDMA == 6)), "immediates below");
             if (RING == 3 && NDMA == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
@@ -597,21 +639,20 @@ __global__ __launch_bounds__(64 * WCO * WK) void wgrad_tr_kernel(const GatherPar
             else if (NDMA == 5) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
             else           asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
             __builtin_amdgcn_s_barrier();
-            issue((st + RING - 1) % RING, vp, vq);            // stage st+RING-1 recycles the slot read in step st-1
-            const uint32_t sb = lds0 + (st % RING) * BUF;
+            issue((slot + RING - 1) % RING, vp, vq);          // stage st+RING-1 recycles the slot read in step st-1
             if (MT == 4 || k_live) {                          // (a wave whose 64 columns all lie beyond K only fetches)
                 uint4 fp[4], fq[4];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     if (i < MT) {
-                        const uint2 a0 = lds_tr_read(sb + poff[i]);
-                        const uint2 a1 = lds_tr_read<4 * PROW>(sb + poff[i]);
+                        const uint2 a0 = lds_tr_read<SB>(pbs[i]);
+                        const uint2 a1 = lds_tr_read<SB + 4 * PROW>(pbs[i]);
                         fp[i] = make_uint4(a0.x, a0.y, a1.x, a1.y);
                     } else {
                         fp[i] = make_uint4(0u, 0u, 0u, 0u);
                     }
-                    const uint2 b0 = lds_tr_read(sb + qoff[i]);
-                    const uint2 b1 = lds_tr_read<4 * QROW>(sb + qoff[i]);
+                    const uint2 b0 = lds_tr_read<SB>(qbs[i]);
+                    const uint2 b1 = lds_tr_read<SB + 4 * QROW>(qbs[i]);
                     fq[i] = make_uint4(b0.x, b0.y, b1.x, b1.y);
                 }
                 if (MT == 4) {
@@ -623,15 +664,36 @@ __global__ __launch_bounds__(64 * WCO * WK) void wgrad_tr_kernel(const GatherPar
                 }
                 if (BIAS && do_bias) mma4_inplace_b<H>(accb, fp, ones);   // every column = sum over the 32 pixels
             }
-            // address arithmetic of stage st+4: independent VALU work the scheduler can slot between the MFMAs
+            // address arithmetic of stage st+RING: independent VALU work the scheduler can slot between the MFMAs
             offsets(m_begin + (uint32_t)(st + RING) * STEP, vp, vq);
         };
-        // two stages per trip: with ONE MFMA per accumulator and trip hipcc ping-pongs every accumulator between two
-        // register sets and copies all 64 back at the loop edge (64 v_accvgpr_mov per 16 MFMAs); an even count
-        // returns in place.  An odd tail stage is all out-of-range, i.e. adds zeros.
-        for (int st = 0; st < nsteps; st += 2) {
-            do_step(st);
-            do_step(st + 1);
+        if constexpr (MODE == 1 && !BIAS) {
+            static_assert((RING - 1) * BUF + 4 * (PROW > QROW ? PROW : QROW) < 65536, "slot displacement must fit the DS offset field");
+            uint32_t pa[4], qa[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { pa[i] = lds0 + (uint32_t)poff[i]; qa[i] = lds0 + (uint32_t)qoff[i]; }
+            // the accumulators are updated in place by the asm MFMA groups, so any step count returns them where they were; a
+            // tail of < RING steps follows with its slots known
+            int st = 0;
+            for (; st + RING <= nsteps; st += RING)
+                static_for<RING>([&](auto i) { step_body(st + decltype(i)::value, decltype(i)::value, std::integral_constant<int, decltype(i)::value * BUF>{}, pa, qa); });
+            static_for<RING - 1>([&](auto i) {
+                if (st + decltype(i)::value < nsteps)
+                    step_body(st + decltype(i)::value, decltype(i)::value, std::integral_constant<int, decltype(i)::value * BUF>{}, pa, qa);
+            });
+        } else {
+            // two stages per trip (an odd tail stage is all out-of-range, i.e. adds zeros)
+            auto do_step = [&](int st) {
+                const uint32_t sb = lds0 + (st % RING) * BUF;
+                uint32_t pa[4], qa[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { pa[i] = sb + (uint32_t)poff[i]; qa[i] = sb + (uint32_t)qoff[i]; }
+                step_body(st, st % RING, std::integral_constant<int, 0>{}, pa, qa);
+            };
+            for (int st = 0; st < nsteps; st += 2) {
+                do_step(st);
+                do_step(st + 1);
+            }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // drain the zero-fill DMAs before LDS is released
         mma_drain();

@@ -24,11 +24,6 @@
 
 namespace eve {
 
-// f(std::integral_constant<int, 0>{}), ..., f(std::integral_constant<int, N - 1>{}): a loop whose index is a compile-time constant
-template <typename F, int... I>
-__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
-template <int N, typename F>
-__device__ __forceinline__ void static_for(F&& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
 
 constexpr int SF_ROWB = 1280;                    // bytes staged per input row: padded pixels 1..160
 constexpr int SF_RING = 12;                      // rows per wave: 7 live + 2 x 2 in flight (+1 spare)
