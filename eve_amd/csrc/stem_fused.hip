@@ -641,8 +641,10 @@ __device__ __forceinline__ void sf_chunk(const SfPooledRow& P, int j, int nt, ui
     ncd = sf_dpp<0x101>(edge, cd);
 }
 
+// (fallback / test reference since round 4: four-wave workgroups, one wave per SIMD -- with eight the 256-register budget spilled)
+constexpr int SD_WAVES = 4;
 template <typename H>
-__global__ __launch_bounds__(64 * SF_WAVES) void stem_bwd_dx_kernel(const int N, const int IH,
+__global__ __launch_bounds__(64 * SD_WAVES) void stem_bwd_dx_kernel(const int N, const int IH,
                                                                     const H* __restrict__ xp, const uint32_t xp_bytes,
                                                                     const H* __restrict__ w8, const float* __restrict__ mr,
                                                                     const H* __restrict__ dyp, const H* __restrict__ dyp2,
@@ -650,9 +652,9 @@ __global__ __launch_bounds__(64 * SF_WAVES) void stem_bwd_dx_kernel(const int N,
                                                                     const uint8_t* __restrict__ idx, H* __restrict__ dx,
                                                                     const int halves) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* const sW = smem + SF_WAVES * SF_RING * SF_ROWB;
+    char* const sW = smem + SD_WAVES * SF_RING * SF_ROWB;
     const int tid = threadIdx.x;
-    sf_fill_weights<H>(sW, w8, tid, 64 * SF_WAVES);
+    sf_fill_weights<H>(sW, w8, tid, 64 * SD_WAVES);
     __syncthreads();
 
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -670,7 +672,7 @@ __global__ __launch_bounds__(64 * SF_WAVES) void stem_bwd_dx_kernel(const int N,
     // halves == 2 (small batches: fewer images than wave slots): an image is TWO work items, the upper and the lower half of its
     // rows.  The halves share nothing but the plane sums of phase A, which are taken over the small pooled tensors and simply
     // computed by both; with one wave per image the kernel's duration is the latency of one image whatever the batch.
-    for (int item = wave * gridDim.x + blockIdx.x; item < N * halves; item += gridDim.x * SF_WAVES) {
+    for (int item = wave * gridDim.x + blockIdx.x; item < N * halves; item += gridDim.x * SD_WAVES) {
         const int n = halves == 2 ? item >> 1 : item;
         const int py0 = halves == 2 ? (item & 1) * (PH / 2) : 0, py1 = halves == 2 ? py0 + PH / 2 : PH;
         const int img_off = n * rows * SF_XROW;
@@ -802,39 +804,20 @@ struct SbPooledRow {               // one pooled row, the lane's 8 channels: col
     uint32_t eg[2][4];
     uint32_t code[2][2];
 };
-template <typename H, bool PREP>
-__device__ __forceinline__ void sb_load_pooled(SbPooledRow& P, const H* __restrict__ dyp, const H* __restrict__ dyp2,
-                                               const H* __restrict__ yp, const uint8_t* __restrict__ idx, size_t row_base,
+// one pooled row of stem_grad_prep_kernel's output (the summed, ReLU-masked gradient) and of the arg-max codes
+template <typename H>
+__device__ __forceinline__ void sb_load_pooled(SbPooledRow& P, const H* __restrict__ eg, const uint8_t* __restrict__ idx, size_t row_base,
                                                int li, int ch0, bool live) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const size_t o = (row_base + li + 16 * j) * 64 + ch0;
-        uint4 d0 = make_uint4(0, 0, 0, 0), y0 = d0;
+        uint4 d0 = make_uint4(0, 0, 0, 0);
         uint2 c = make_uint2(0, 0);
-        if (PREP) {                              // dyp is stem_grad_prep_kernel's output: summed and masked already
-            if (live) {
-                d0 = *reinterpret_cast<const uint4*>(dyp + o);
-                c = *reinterpret_cast<const uint2*>(idx + o);
-            }
-            P.eg[j][0] = d0.x; P.eg[j][1] = d0.y; P.eg[j][2] = d0.z; P.eg[j][3] = d0.w;
-            P.code[j][0] = c.x; P.code[j][1] = c.y;
-            continue;
-        }
         if (live) {
-            d0 = *reinterpret_cast<const uint4*>(dyp + o);
-            y0 = *reinterpret_cast<const uint4*>(yp + o);
+            d0 = *reinterpret_cast<const uint4*>(eg + o);
             c = *reinterpret_cast<const uint2*>(idx + o);
-            if (dyp2) {
-                const uint4 e0 = *reinterpret_cast<const uint4*>(dyp2 + o);
-                d0 = make_uint4(sf_add_pairs<H>(d0.x, e0.x), sf_add_pairs<H>(d0.y, e0.y), sf_add_pairs<H>(d0.z, e0.z), sf_add_pairs<H>(d0.w, e0.w));
-            }
         }
-        const uint32_t dd[4] = {d0.x, d0.y, d0.z, d0.w}, yy[4] = {y0.x, y0.y, y0.z, y0.w};
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const uint32_t m = ((int)(yy[k] << 16) > 0 ? 0xffffu : 0u) | ((int)(yy[k] & 0xffff0000u) > 0 ? 0xffff0000u : 0u);
-            P.eg[j][k] = dd[k] & m;
-        }
+        P.eg[j][0] = d0.x; P.eg[j][1] = d0.y; P.eg[j][2] = d0.z; P.eg[j][3] = d0.w;
         P.code[j][0] = c.x; P.code[j][1] = c.y;
     }
 }
@@ -918,12 +901,13 @@ __global__ __launch_bounds__(256) void stem_grad_prep_kernel(const int N, const 
     }
 }
 
-// PREP: dyp = stem_grad_prep_kernel's eg, mr = its constants [N][64][{rstd, B, C}]; dyp2 / yp are not read
-template <typename H, int PAIRS, bool PREP>
+// dyp = stem_grad_prep_kernel's eg (the summed, masked gradient), mr = its constants [N][64][{rstd, B, C}].  (Rounds 4-5 also had
+// a one-launch form that read the three pooled tensors twice and formed the plane sums itself -- "phase A"; it spilled 84-100
+// bytes per lane and was only reachable without scratch.  Round 6: the scratch is required, that form is gone.)
+template <typename H, int PAIRS>
 __global__ __launch_bounds__(128 * PAIRS, 2) void stem_bwd_wgrad_kernel(const int N, const int IH, const H* __restrict__ xp, const uint32_t xp_bytes,
                                                              const H* __restrict__ w8, const float* __restrict__ mr,
-                                                             const H* __restrict__ dyp, const H* __restrict__ dyp2,
-                                                             const H* __restrict__ yp, const uint8_t* __restrict__ idx,
+                                                             const H* __restrict__ dyp, const uint8_t* __restrict__ idx,
                                                              float* __restrict__ dw) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NT = 128 * PAIRS;
@@ -967,68 +951,29 @@ __global__ __launch_bounds__(128 * PAIRS, 2) void stem_bwd_wgrad_kernel(const in
         const size_t pool_base = (size_t)nn * PH * 32;
         // rows 0 .. 8 of the image: wave h stages the rows of its parity
         for (int r = h; r < 9; r += 2) sf_stage_row(rs, ring, r, live ? rows : 0, img_off, lane);
-        // ---- phase A: the two plane sums over the pooled tensors -> {rstd, B, C} of the lane's channels ----
-        if (PREP) {
-            if (live && li < 8) {                                 // taken from the prep pass: channel ch0 + li
-                const float* kg = mr + ((size_t)nn * 64 + ch0 + li) * 3;
-                float* kc = reinterpret_cast<float*>(sK + ((lg * 2 + (li >> 2)) * 3) * 16) + (li & 3);
-                kc[0] = kg[0]; kc[4] = kg[1]; kc[8] = kg[2];
-            }
-        } else if (live) {
-            float s1[8], s2[8];
-#pragma unroll
-            for (int c = 0; c < 8; ++c) { s1[c] = 0.f; s2[c] = 0.f; }
-#pragma unroll 4
-            for (int py = 0; py < PH; ++py)                       // (four rows of loads in flight: the chain of 32 round trips showed)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const size_t o = (pool_base + (size_t)py * 32 + li + 16 * j) * 64 + ch0;
-                    float d[8], y[8];
-                    Elem<H>::unpack(*reinterpret_cast<const uint4*>(dyp + o), d);
-                    if (dyp2) {                                   // same rounding of the sum as sb_load_pooled
-                        float d2[8];
-                        Elem<H>::unpack(*reinterpret_cast<const uint4*>(dyp2 + o), d2);
-#pragma unroll
-                        for (int c = 0; c < 8; ++c) d[c] = Elem<H>::round(d[c] + d2[c]);
-                    }
-                    Elem<H>::unpack(*reinterpret_cast<const uint4*>(yp + o), y);
-#pragma unroll
-                    for (int c = 0; c < 8; ++c) {
-                        const float g = y[c] > 0.f ? d[c] : 0.f;
-                        s1[c] += g; s2[c] += g * y[c];
-                    }
-                }
-            const float* m = mr + ((size_t)nn * 64 + ch0) * 2;
-#pragma unroll
-            for (int c = 0; c < 8; ++c) {
-                const float a = sf_row_sum16(s1[c]) * inv_hw, b = sf_row_sum16(s2[c]) * inv_hw;
-                const float mean = m[2 * c], r = m[2 * c + 1];
-                const float B = r * r * b, C = mean * B - r * a;
-                if (li == 0) {                                   // [lg][ntl][{rstd, B, C}][r]
-                    float* kc = reinterpret_cast<float*>(sK + ((lg * 2 + (c >> 2)) * 3) * 16) + (c & 3);
-                    kc[0] = r; kc[4] = B; kc[8] = C;
-                }
-            }
+        // ---- the folded constants {rstd, B, C} of the lane's channels, from the prep pass: channel ch0 + li ----
+        if (live && li < 8) {
+            const float* kg = mr + ((size_t)nn * 64 + ch0 + li) * 3;
+            float* kc = reinterpret_cast<float*>(sK + ((lg * 2 + (li >> 2)) * 3) * 16) + (li & 3);
+            kc[0] = kg[0]; kc[4] = kg[1]; kc[8] = kg[2];
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the nine rows (and phase A's loads)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the nine rows (and the constants' loads)
         __syncthreads();                                          // ... and the partner's (sK is this wave's own)
         // ---- phase B: recompute the convolution row by row; d(conv out) -> LDS tile -> weight-gradient MFMAs ----
         SbPooledRow P0, P1;
-        sb_load_pooled<H, PREP>(P0, dyp, dyp2, yp, idx, pool_base, li, ch0, live);
+        sb_load_pooled<H>(P0, dyp, idx, pool_base, li, ch0, live);
         int slot0 = 0;
         for (int py = 0; py < PH; ++py) {
-            sb_load_pooled<H, PREP>(P1, dyp, dyp2, yp, idx, pool_base + (size_t)(py + 1) * 32, li, ch0, live && py + 1 < PH);
+            sb_load_pooled<H>(P1, dyp, idx, pool_base + (size_t)(py + 1) * 32, li, ch0, live && py + 1 < PH);
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
                 const int oy = 2 * py + half;
                 // this wave's row of two iterations ago has landed once at most the newer operations are outstanding:
-                // half 0: one row (2 DMAs) + the 6 .. 8 (PREP: 4) pooled loads just issued; half 1: one row
+                // half 0: one row (2 DMAs) + the 4 pooled loads just issued; half 1: one row
                 // (the last pooled row issues no pooled loads: one row only there too)
                 if (oy >= 2) {
-                    if (half == 0 && py + 1 < PH) {
-                        if (PREP) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-                        else      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-                    } else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                    if (half == 0 && py + 1 < PH) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+                    else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
                 }
                 // ... and the partner's.  (A rendezvous of just the two waves through LDS flags, which lets the pairs drift apart so
                 //  that the two waves of a SIMD are not in the same phase, was built and measured: with its extra registers the
@@ -1221,7 +1166,7 @@ extern "C" int eve_stem_bwd_dx(int dtype, int N, int IH, int IW, const void* x_p
         return set_error_msg("stem_bwd_dx: needs IW == 128 and IH a multiple of 4");
     const unsigned long long xb = (unsigned long long)N * (IH + 6) * SF_XROW;
     if (xb >= (1ull << 31)) return set_error_msg("stem_bwd_dx: packed input must stay below 2 GiB");
-    const size_t lds = (size_t)SF_WAVES * SF_RING * SF_ROWB + SF_WBYTES + SF_WAVES * SF_KBYTES;
+    const size_t lds = (size_t)SD_WAVES * SF_RING * SF_ROWB + SF_WBYTES + SD_WAVES * SF_KBYTES;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)stem_bwd_dx_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -1230,9 +1175,9 @@ extern "C" int eve_stem_bwd_dx(int dtype, int N, int IH, int IW, const void* x_p
     }
     // two work items per image while that still fits the 256 x 8 wave slots (B <= 16 clips per GPU): see the kernel
     const int split = g_cfg.stem_split;
-    const int halves = (split && 2 * N <= 256 * SF_WAVES && (IH & 7) == 0) ? 2 : 1;
+    const int halves = (split && 2 * N <= 256 * SD_WAVES && (IH & 7) == 0) ? 2 : 1;
     unsigned blocks = N * halves < 256 ? (unsigned)(N * halves) : 256u;
-    EVE_DISPATCH_H16(dtype, EVE_LAUNCH(EVE_HNAME(H, "stem_bwd_dx_kernel<", ">"), stem_bwd_dx_kernel<H>, dim3(blocks), dim3(64 * SF_WAVES), lds,
+    EVE_DISPATCH_H16(dtype, EVE_LAUNCH(EVE_HNAME(H, "stem_bwd_dx_kernel<", ">"), stem_bwd_dx_kernel<H>, dim3(blocks), dim3(64 * SD_WAVES), lds,
                                        (hipStream_t)stream, N, IH, (const H*)x_padded, (uint32_t)xb, (const H*)w_ohwi8, mean_rstd, (const H*)dy_pool,
                                        (const H*)dy_pool2, (const H*)y_pool, idx, (H*)dx, halves));
     EVE_CHECK_LAUNCH();
@@ -1251,10 +1196,8 @@ extern "C" int eve_stem_bwd_wgrad(int dtype, int N, int IH, int IW, const void* 
     if (xb >= (1ull << 31)) return set_error_msg("stem_bwd_wgrad: packed input must stay below 2 GiB");
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)stem_bwd_wgrad_kernel<bf16_t, SB_PAIRS, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)stem_bwd_wgrad_kernel<f16_t, SB_PAIRS, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)stem_bwd_wgrad_kernel<bf16_t, SB_PAIRS, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)stem_bwd_wgrad_kernel<f16_t, SB_PAIRS, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)stem_bwd_wgrad_kernel<bf16_t, SB_PAIRS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)stem_bwd_wgrad_kernel<f16_t, SB_PAIRS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
     // Two workgroups of two pairs per CU (2 x 77 KB of LDS): the per-row barrier only ties the four waves of a workgroup, so the two
@@ -1263,28 +1206,23 @@ extern "C" int eve_stem_bwd_wgrad(int dtype, int N, int IH, int IW, const void* 
     // workgroup b takes image p * grid + b): a small batch puts one pair on every CU before it puts two on any.
     const size_t lds = (size_t)SB_PAIRS * SF_RING * SF_ROWB + SF_WBYTES + 2 * SB_PAIRS * SB_KBYTES + 2 * SB_PAIRS * SB_DTILE;
     const unsigned blocks = (N + SB_PAIRS - 1) / SB_PAIRS < 512 ? (unsigned)((N + SB_PAIRS - 1) / SB_PAIRS) : 512u;
-    // With scratch for it (workspace: eve_stem_bwd_wgrad_workspace(dtype, N, IH) bytes), the plane sums and the masked gradient
-    // come from a streaming pass of their own and the fused kernel reads one pooled tensor + the codes, once.
+    // The plane sums and the masked gradient come from a streaming pass of their own into the caller's scratch
+    // (eve_stem_bwd_wgrad_workspace(dtype, N, IH) bytes); the fused kernel reads one pooled tensor + the codes, once.
     const int PH = IH / 4;
     const unsigned long long eg_bytes = ((unsigned long long)N * PH * 32 * 64 * 2 + 255) & ~255ull, k_bytes = (unsigned long long)N * 64 * 3 * 4;
-    if (workspace && workspace_bytes >= eg_bytes + k_bytes && !((uintptr_t)workspace & 15)) {
-        float* const kc = reinterpret_cast<float*>((char*)workspace + eg_bytes);
-        EVE_DISPATCH_H16(dtype, EVE_LAUNCH(EVE_HNAME(H, "stem_grad_prep_kernel<", ">"), stem_grad_prep_kernel<H>, dim3(N), dim3(256), 0,
-                                           (hipStream_t)stream, N, PH, (const H*)dy_pool, (const H*)dy_pool2, (const H*)y_pool, mean_rstd, (H*)workspace, kc));
-        EVE_CHECK_LAUNCH();
-        EVE_DISPATCH_H16(dtype, EVE_LAUNCH(EVE_HNAME(H, "stem_bwd_wgrad_kernel<", ", 2, true>"), (stem_bwd_wgrad_kernel<H, SB_PAIRS, true>), dim3(blocks), dim3(128 * SB_PAIRS), lds,
-                                           (hipStream_t)stream, N, IH, (const H*)x_padded, (uint32_t)xb, (const H*)w_ohwi8, (const float*)kc, (const H*)workspace,
-                                           (const H*)nullptr, (const H*)nullptr, idx, dw));
-        EVE_CHECK_LAUNCH();
-        return 0;
-    }
-    EVE_DISPATCH_H16(dtype, EVE_LAUNCH(EVE_HNAME(H, "stem_bwd_wgrad_kernel<", ", 2, false>"), (stem_bwd_wgrad_kernel<H, SB_PAIRS, false>), dim3(blocks), dim3(128 * SB_PAIRS), lds,
-                                       (hipStream_t)stream, N, IH, (const H*)x_padded, (uint32_t)xb, (const H*)w_ohwi8, mean_rstd, (const H*)dy_pool,
-                                       (const H*)dy_pool2, (const H*)y_pool, idx, dw));
+    if (!workspace || workspace_bytes < eg_bytes + k_bytes || ((uintptr_t)workspace & 15))
+        return set_error_msg("stem_bwd_wgrad: needs 16-byte aligned scratch of eve_stem_bwd_wgrad_workspace(dtype, N, IH) bytes");
+    float* const kc = reinterpret_cast<float*>((char*)workspace + eg_bytes);
+    EVE_DISPATCH_H16(dtype, EVE_LAUNCH(EVE_HNAME(H, "stem_grad_prep_kernel<", ">"), stem_grad_prep_kernel<H>, dim3(N), dim3(256), 0,
+                                       (hipStream_t)stream, N, PH, (const H*)dy_pool, (const H*)dy_pool2, (const H*)y_pool, mean_rstd, (H*)workspace, kc));
+    EVE_CHECK_LAUNCH();
+    EVE_DISPATCH_H16(dtype, EVE_LAUNCH(EVE_HNAME(H, "stem_bwd_wgrad_kernel<", ", 2>"), (stem_bwd_wgrad_kernel<H, SB_PAIRS>), dim3(blocks), dim3(128 * SB_PAIRS), lds,
+                                       (hipStream_t)stream, N, IH, (const H*)x_padded, (uint32_t)xb, (const H*)w_ohwi8, (const float*)kc, (const H*)workspace,
+                                       idx, dw));
     EVE_CHECK_LAUNCH();
     return 0;
 }
-/* bytes of scratch with which eve_stem_bwd_wgrad takes its two-launch form (masked gradient [N][IH/4][32][64] + constants) */
+/* bytes of scratch eve_stem_bwd_wgrad needs (masked gradient [N][IH/4][32][64] + constants) */
 extern "C" unsigned long long eve_stem_bwd_wgrad_workspace(int dtype, int N, int IH) {
     (void)dtype;
     if (N <= 0 || IH <= 0) return 0;

@@ -325,7 +325,7 @@ class HipKernels(object):
             self._p(dy_pool2), self._p(y_pool), self._p(idx), self._p(dx), self._stream())))
         return dx
 
-    def stem_bwd_wgrad(self, x_padded, w_ohwi8, mr, dy_pool, y_pool, idx, dw, dy_pool2=None, prep=True):
+    def stem_bwd_wgrad(self, x_padded, w_ohwi8, mr, dy_pool, y_pool, idx, dw, dy_pool2=None):
         """dw [64, 7, 8, 4] float32 += the stem's weight gradient straight from d(pooled output): backward of the fused stem and
         its weight gradient in one launch, d(conv1 out) never written (include/eve_hip.h eve_stem_bwd_wgrad)."""
         N, Hp, Wp, _ = x_padded.shape
@@ -334,10 +334,10 @@ class HipKernels(object):
         assert dy_pool.dtype == x_padded.dtype and dy_pool.is_contiguous() and dy_pool.shape == y_pool.shape == idx.shape
         # the weight gradient's FLOPs are algorithmic; the recomputed convolution is not credited
         flops = 2.0 * N * (IH // 2) * (IW // 2) * 64 * 147
-        # scratch for the two-launch form (the masked, summed gradient + the per-plane constants: 252 MB at N = 1 920), from
-        # torch's allocator like any activation: stream-ordered, and part of the graph's pool under capture
-        nbytes = int(self.lib.eve_stem_bwd_wgrad_workspace(dt_code(x_padded.dtype), N, IH)) if prep else 0
-        ws = torch.empty((nbytes,), dtype=torch.uint8, device=x_padded.device) if nbytes else None
+        # the call's scratch (the masked, summed gradient + the per-plane constants: 252 MB at N = 1 920), from torch's allocator
+        # like any activation: stream-ordered, and part of the graph's pool under capture
+        nbytes = int(self.lib.eve_stem_bwd_wgrad_workspace(dt_code(x_padded.dtype), N, IH))
+        ws = torch.empty((nbytes,), dtype=torch.uint8, device=x_padded.device)
         self._timed('conv_wgrad', flops, lambda: self._ck(self.lib.eve_stem_bwd_wgrad(
             dt_code(x_padded.dtype), N, IH, IW, self._p(x_padded), self._p(w_ohwi8), self._p(self._f32(mr, 'mean_rstd')), self._p(dy_pool),
             self._p(dy_pool2), self._p(y_pool), self._p(idx), self._p(dw), self._p(ws), nbytes, self._stream())),

@@ -172,11 +172,10 @@ int eve_stem_fwd_fused(int dtype, int N, int IH, int IW, const void* x_padded, c
 int eve_stem_bwd_wgrad(int dtype, int N, int IH, int IW, const void* x_padded, const void* w_ohwi8, const float* mean_rstd,
                        const void* dy_pool, const void* dy_pool2, const void* y_pool, const uint8_t* idx, float* dw,
                        void* workspace, unsigned long long workspace_bytes, eve_stream_t stream);
-/* v8: with `workspace` of at least eve_stem_bwd_wgrad_workspace(dtype, N, IH) bytes (caller-owned, used on `stream` by this call
- * only) the two InstanceNorm plane sums and the masked, summed gradient are formed by a streaming pass of their own
- * (stem_grad_prep_kernel) and the fused kernel reads one pooled tensor and the arg-max codes, once (the sums in another
- * float order: the filter gradient differs from the one-launch form's at the 1e-5 level).
- * NULL / too small: the one-launch form, which reads the three pooled tensors twice.                                           */
+/* `workspace`: at least eve_stem_bwd_wgrad_workspace(dtype, N, IH) bytes, 16-byte aligned, caller-owned, used on `stream` by this
+ * call only: the two InstanceNorm plane sums and the masked, summed gradient are formed by a streaming pass of their own
+ * (stem_grad_prep_kernel) and the fused kernel reads one pooled tensor and the arg-max codes, once.  REQUIRED since ABI v9 (v8
+ * fell back to a one-launch form that read the three pooled tensors twice and spilled registers): NULL / too small is an error. */
 unsigned long long eve_stem_bwd_wgrad_workspace(int dtype, int N, int IH);
 /* ... and the stem's weight gradient from the same packed patches: dw [64][7][8][4] float (accumulated; filter
  * column 7 and channel 3 do not exist and are ignored by the caller).  Replaces autograd of conv1 (eye_net.py:106). */

@@ -247,14 +247,13 @@ def test_stem_fused_backward_matches_unfused(hip, N, hdt):
 
 
 @HALVES
-@pytest.mark.parametrize('prep', [True, False], ids=['sums-by-the-prep-pass', 'one-launch'])
 @pytest.mark.parametrize('N,two', [(2, False), (17, True), (1100, True)], ids=['N2', 'N17-two-summands', 'N1100-second-turn'])
-def test_stem_backward_and_weight_gradient_in_one_launch(hip, N, two, hdt, prep):
+def test_stem_backward_and_weight_gradient_in_one_launch(hip, N, two, hdt):
     """eve_stem_bwd_wgrad (d(conv1 out) stays in LDS: wave pairs, 32 channels each, weight-gradient MFMAs on the recomputed
     rows) == eve_stem_bwd_dx followed by eve_stem_wgrad on the stored tensor -- same rounding of d(conv1 out) to the storage
     format, float summation order aside -- and == torch's conv2d_weight on that tensor; accumulates onto existing values; the
-    gradient delivered as two summands; N = 1 100 > 1 024 image slots: a second turn with idle wave pairs in it.  Both forms:
-    the plane sums and the masked gradient from stem_grad_prep_kernel (scratch given), and everything in the one launch."""
+    gradient delivered as two summands; N = 1 100 > 1 024 image slots: a second turn with idle wave pairs in it.  The plane sums and
+    the masked gradient come from stem_grad_prep_kernel (the call's scratch; required since ABI v9)."""
     src = rnd((N, 3, 128, 128), torch.float32, 64) + 0.2
     w = rnd((64, 7, 7, 8), hdt, 65, scale=0.08)
     w[..., 3:] = 0
@@ -267,9 +266,8 @@ def test_stem_backward_and_weight_gradient_in_one_launch(hip, N, two, hdt, prep)
     hip.stem_wgrad(xp, dconv, want)
     base = dev(rnd((64, 7, 8, 4), torch.float32, 70))
     got = base.clone()
-    hip.stem_bwd_wgrad(xp, dev(w), mr, dy, y, idx, got, dy_pool2=dy2, prep=prep)
+    hip.stem_bwd_wgrad(xp, dev(w), mr, dy, y, idx, got, dy_pool2=dy2)
     assert hip.lib.eve_last_kernel().decode().startswith('stem_bwd_wgrad_kernel')
-    assert hip.lib.eve_last_kernel().decode().endswith(', true>') == prep
     got = (got - base)[:, :, :7, :3]
     assert torch.isfinite(got).all()
     rel = ((got - want[:, :, :7, :3]).norm() / want[:, :, :7, :3].norm()).item()

@@ -47,7 +47,6 @@ if hasattr(k.lib, 'eve_stem_bwd_dx'):
 if hasattr(k.lib, 'eve_stem_bwd_wgrad'):
     dw = torch.zeros((64, 7, 8, 4), device='cuda')
     dyp2 = torch.randn_like(yp)
-    for prep in (False, True):
-        print(f"stem bwd+wgrad  prep={prep}  {timeit(lambda: k.stem_bwd_wgrad(xp, w8, mrf, dyp, yf, idf, dw, prep=prep)):.3f} ms (one summand)")
-        print(f"stem bwd+wgrad  prep={prep}  {timeit(lambda: k.stem_bwd_wgrad(xp, w8, mrf, dyp, yf, idf, dw, dy_pool2=dyp2, prep=prep)):.3f} ms (two summands, as in the training step)")
+    print(f"stem bwd+wgrad  {timeit(lambda: k.stem_bwd_wgrad(xp, w8, mrf, dyp, yf, idf, dw)):.3f} ms (one summand)")
+    print(f"stem bwd+wgrad  {timeit(lambda: k.stem_bwd_wgrad(xp, w8, mrf, dyp, yf, idf, dw, dy_pool2=dyp2)):.3f} ms (two summands, as in the training step)")
     print('kernel', k.lib.eve_last_kernel().decode())
