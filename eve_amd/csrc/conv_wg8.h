@@ -39,6 +39,8 @@
 // 4 x 16-lane read groups (tools/lds_banks32.py).  The key is applied to the SOURCE chunk a DMA lane fetches (LDS-DMA
 // writes lane-linearly) and to the read address.  Weight rows are permuted in LDS so that a lane's 2 x 16 accumulator
 // rows are 32 CONSECUTIVE output channels of its pixel: four 16-byte stores per pixel.
+// (Producer-side InstanceNorm from this kernel's epilogue was built and measured in round 6: 0.156 -> 0.209 ms on layer 3, 0.129 ->
+// 0.244 ms on layer 4 against the separate launch; profiles/r06_in_epilogue.md.)
 #pragma once
 #include <type_traits>
 #include "common.h"
@@ -129,28 +131,10 @@ template <int WM, int WN, int W, int BANDS = 1> struct Wg8Geom {
 // 2 x 2 (py = 1) window over the SAME halo tile, whose 2 x Cin "output channels" are the column parities px = 0 | 1 of d(x)
 // (px = 0 uses half of those taps: its other weights are zero, 12 of 16 tap-classes do real work).  The launch pair reads dy
 // twice in total (the per-tap kernel: four launches, nine tap passes) and the epilogue scatters depth-to-space.
-// EPI_IN (round 6 experiment, tools/probes/in_epilogue.hip; not instantiated by the library): producer-side InstanceNorm for the
-// shapes whose image lies inside ONE wave's pixel tiles (W = 8: two 32-pixel tiles, W = 4: 16 lanes of a tile) -- the plane sums are
-// taken on the float accumulators (DPP butterfly over the 16 lanes of a row, ds_swizzle across the two rows of a 32-lane half),
-// out = relu((y - mean) * rstd) and in_stats[n][c] = (mean, rstd) leave the kernel, the raw convolution output does not.
-template <int GROUP>
-__device__ __forceinline__ float wg8_group_sum(float v) {
-    auto dpp = [](float f, auto ctrl) {
-        return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, f), decltype(ctrl)::value, 0xf, 0xf, false));
-    };
-    v += dpp(v, std::integral_constant<int, 0xb1>{});      // quad_perm [1,0,3,2]
-    v += dpp(v, std::integral_constant<int, 0x4e>{});      // quad_perm [2,3,0,1]
-    v += dpp(v, std::integral_constant<int, 0x141>{});     // row_half_mirror
-    v += dpp(v, std::integral_constant<int, 0x140>{});     // row_mirror
-    if (GROUP == 32) v += __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), 0x401F));   // lane ^ 16
-    return v;
-}
-
-template <typename H, int WM, int WN, int W, int NT = 9, int BANDS = 1, bool EPI_IN = false>
+template <typename H, int WM, int WN, int W, int NT = 9, int BANDS = 1>
 __global__ __launch_bounds__(512, 2) void conv3x3_wg8_kernel(const Wg8Params p, const H* __restrict__ x,
                                                              const H* __restrict__ w, const float* __restrict__ bias,
-                                                             const int epi_act, H* __restrict__ out, float* __restrict__ in_stats = nullptr,
-                                                             const float in_eps = 1e-5f) {
+                                                             const int epi_act, H* __restrict__ out) {
     using G = Wg8Geom<WM, WN, W, BANDS>;
     static_assert(BANDS == 1 || (NT == 9 && W >= 8), "row bands: the 3x3 convolution on W >= 8");
     constexpr int W2 = G::W2, HPI = G::HPI, HP = G::HP, AP = G::AP, BP = G::BP, ASTAGE = G::ASTAGE, BSLOT = G::BSLOT;
@@ -328,32 +312,6 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wg8_kernel(const Wg8Params p, 
 
     // ---- epilogue: the lane owns 32 consecutive channels (64 bytes) of each of its four pixels ----
     const uint32_t co = co0 + wn * 64 + l5 * 32;
-    if constexpr (EPI_IN) {
-        static_assert(NT == 9 && BANDS == 1 && (W == 8 || W == 4), "whole images inside one wave's tiles");
-        constexpr int GROUP = W == 8 ? 32 : 16, SPAN = W == 8 ? 2 : 1;     // lanes / pixel tiles an image spans
-        constexpr float INV = 1.f / (float)(W * W);
-#pragma unroll
-        for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-#pragma unroll
-                for (int g0 = 0; g0 < 4; g0 += SPAN) {
-                    float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-                    for (int pt = g0; pt < g0 + SPAN; ++pt) { const float v = acc[ct][pt][r]; s1 += v; s2 = __builtin_fmaf(v, v, s2); }
-                    s1 = wg8_group_sum<GROUP>(s1);
-                    s2 = wg8_group_sum<GROUP>(s2);
-                    const float mean = s1 * INV, rstd = rsqrtf(fmaxf(s2 * INV - mean * mean, 0.f) + in_eps);
-#pragma unroll
-                    for (int pt = g0; pt < g0 + SPAN; ++pt) acc[ct][pt][r] = (acc[ct][pt][r] - mean) * rstd;
-                    const int m0 = wm * 128 + g0 * 32 + l31;
-                    const uint32_t n = n0 + (uint32_t)(m0 / UPIX);
-                    if ((l31 & (GROUP - 1)) == 0 && n < (uint32_t)p.N) {
-                        float* st = in_stats + ((size_t)n * p.Cout + co + ct * 16 + r) * 2;
-                        st[0] = mean; st[1] = rstd;
-                    }
-                }
-    }
     const bool relu = (epi_act & 0xff) == EVE_ACT_RELU;
     float bv[32];
 #pragma unroll
