@@ -25,7 +25,7 @@ python tools/pmc_hbm_summary.py $O/pmc_b_FETCH_SIZE $O/pmc_b_WRITE_SIZE bench.py
 python tools/pmc_hbm_summary.py $O/pmc_c_FETCH_SIZE $O/pmc_c_WRITE_SIZE tools/bench_eve.py --steps 2 > $O/c3_pmc_hbm_per_kernel.json
 rm -rf $O/pmc_b_* $O/pmc_c_*
 # the bench lines proper (un-profiled); the fresh PMC summaries are put where bench.py looks for them
-RN=${ROUND:-r05}
+RN=${ROUND:-r06}
 cp $O/pmc_hbm_per_kernel.json profiles/${RN}_pmc_hbm_per_kernel.json
 cp $O/c3_pmc_hbm_per_kernel.json profiles/${RN}_c3_pmc_hbm_per_kernel.json
 python bench.py > $O/bench.json 2> $O/bench.err
