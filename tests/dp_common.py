@@ -177,12 +177,12 @@ def worker_gate_timeout(rank, port, tmp):
     plain_launch = tr.sync._launch
     slept = []
 
-    def launch(b):
+    def launch(b, inline=False):
         # the SECOND bucket whose ready point is captured gets the stall in front of its gate-signal node
         if tr.sync._marking and not b['launched'] and b['hi'] > b['lo'] and len(tr.sync._gated) == 1:
             torch.cuda._sleep(300_000_000)                  # ~0.15 s, every replay
             slept.append(tr.sync.buckets.index(b))
-        plain_launch(b)
+        plain_launch(b, inline=inline)
     tr.sync._launch = launch
     batch = {kk: v.to('cuda') for kk, v in full.items()}
     rec = {}

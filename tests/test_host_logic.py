@@ -638,7 +638,7 @@ def test_gated_launch_order_puts_the_poison_bucket_last():
     sync.active = True
     sync._flags = None
     sync._comm = None
-    sync._launch = lambda b: (calls.append(sync.buckets.index(b)), b.__setitem__('launched', True))
+    sync._launch = lambda b, inline=False: (calls.append((sync.buckets.index(b), inline)), b.__setitem__('launched', True))
 
     class _Ctx(object):
         def __enter__(self): return self
@@ -649,9 +649,9 @@ def test_gated_launch_order_puts_the_poison_bucket_last():
         sync._gated = [sync.buckets[2], sync.buckets[0]]          # captured order: the poison bucket reported FIRST
         sync.launch_gated()
     # gated buckets first, the poison bucket behind the other GATED one; bucket 1 never reported, follows the whole replay ungated
-    assert calls == [0, 2, 1], calls
+    assert calls == [(0, True), (2, True), (1, True)], calls        # (inline: the collectives go onto the communication stream itself)
     calls.clear()
     with um.patch('torch.cuda.stream', lambda s: _Ctx()), um.patch('torch.cuda.current_stream', lambda: um.MagicMock()):
         sync.disable_gating()                                     # the fall-back: self.buckets order, poison bucket last
         sync.launch_gated()
-    assert calls == [0, 1, 2], calls
+    assert [c[0] for c in calls] == [0, 1, 2], calls
