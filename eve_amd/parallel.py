@@ -80,6 +80,8 @@ class GradSync(object):
         self._flags = None           # one gate word per bucket (device int32), incremented once per replay by the bucket's node
         self._timeouts = None
         self._replays = 0
+        self._fwd_event = None       # recorded between the forward graph and the backward graph of a split replay (forward_done)
+        self._fwd_recorded = False
         self.overlaps = None         # does the communication stream run beside the replay's stream on this box (prepare_marks)
         self.launch_counts = []
         # a one-rank group has nothing to exchange; EVE_AMD_FORCE_DIST=1 runs the collectives anyway (transport test)
@@ -170,6 +172,14 @@ class GradSync(object):
         self._marking = True
         self._gated = []
 
+    def forward_done(self):
+        """The trainer replays the forward and the backward as two graphs: called between them, on the replay's stream."""
+        if self.flat_grad.is_cuda:
+            if self._fwd_event is None:
+                self._fwd_event = torch.cuda.Event()
+            self._fwd_event.record()
+            self._fwd_recorded = True
+
     def end_marks(self):
         self._marking = False
         self._armed = False
@@ -191,6 +201,9 @@ class GradSync(object):
             # the bucket that carries the poison word (lo == 0: the last one) goes last, behind every gate that could poison
             last = self.buckets[-1]
             order = [b for b in self._gated if b is not last] + [b for b in self._gated if b is last]
+            if self._fwd_recorded:
+                self._comm.wait_event(self._fwd_event)        # no gate-wait wave on the device while the forward runs
+                self._fwd_recorded = False
             with torch.cuda.stream(self._comm):
                 for b in order:
                     if self._flags is not None:

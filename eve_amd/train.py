@@ -128,6 +128,10 @@ class Trainer(object):
         self.graph_collectives = bool(graph_collectives) and self.sync is not None and dist.is_initialized() and \
             dist.get_backend() == 'nccl'
         self._graph = None
+        self._graph_bwd = None
+        # gated mode: replay the forward and the backward as two graphs with an event between them (see _capture); the
+        # EVE_AMD_SPLIT_REPLAY=0 escape keeps the one-graph form measurable
+        self.split_replay = os.environ.get('EVE_AMD_SPLIT_REPLAY', '1') == '1'
         self._gate_checks = 2         # replays after a capture whose gate outcome is read back (a host sync each) ...
         self.gate_check_every = 64    # ... and then every this many steps
         self._gate_skips_seen = 0
@@ -143,12 +147,18 @@ class Trainer(object):
                 m.invalidate_packs()
 
     # ---- the two halves of a step ----
-    def _forward_backward(self, batch):
+    def _forward(self, batch):
         self.fp.zero_grad()
-        terms = self.loss_fn(batch)
+        return self.loss_fn(batch)
+
+    def _backward(self, terms):
         loss = terms['full_loss']
         # (the scale is read from the device: it may have backed off, and a captured graph must follow it)
         (loss if not self.check_overflow else loss * self.loss_scale_dev[0]).backward()
+
+    def _forward_backward(self, batch):
+        terms = self._forward(batch)
+        self._backward(terms)
         return terms
 
     def _update(self, gscale):
@@ -252,13 +262,26 @@ class Trainer(object):
                 self._static_terms = self._forward_backward(self._static_batch)
                 self._update(self.sync.finish_step())
             elif self.sync is not None:
-                # forward + backward in the graph, every bucket's ready point as a gate-signal node (csrc/optim.hip)
+                # forward + backward captured, every bucket's ready point as a gate-signal node (csrc/optim.hip).  The FORWARD
+                # is a graph of its own (split_replay): an ordinary event between the two replays keeps the communication stream's
+                # first gate-wait wave off the device until the backward begins -- any wave resident beside the replay costs
+                # stem_fwd_pairs_kernel +40 % and the layer-1 forward convolutions +9 % (profiles/r06_notes.md section 9), and
+                # no backward kernel anything
                 self.sync.begin_marks()
-                self._static_terms = self._forward_backward(self._static_batch)
-                self.sync.end_marks()
+                self._static_terms = self._forward(self._static_batch)
+                if not self.split_replay:
+                    self._backward(self._static_terms)
+                    self.sync.end_marks()
             else:
                 self._static_terms = self._forward_backward(self._static_batch)
                 self._update(1.0)
+
+        self._graph_bwd = None
+        if self.sync is not None and not self.graph_collectives and self.split_replay:
+            self._graph_bwd = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self._graph_bwd, pool=self._graph.pool(), capture_error_mode=mode):
+                self._backward(self._static_terms)
+                self.sync.end_marks()
 
     def _collective_and_update(self):
         self.sync.start_step()
@@ -285,6 +308,9 @@ class Trainer(object):
                     if isinstance(v, torch.Tensor) and v.data_ptr() != self._static_batch[k].data_ptr():
                         self._static_batch[k].copy_(v, non_blocking=True)
             self._graph.replay()
+            if self._graph_bwd is not None:
+                self.sync.forward_done()                 # (an event on this stream: the communication stream starts behind it)
+                self._graph_bwd.replay()
             if self.sync is not None and not self.graph_collectives:
                 self._gated_collective_and_update()
                 if self._gate_checks > 0 or (self.gate_check_every and (self.step_count + 1) % self.gate_check_every == 0):
