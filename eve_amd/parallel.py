@@ -41,7 +41,7 @@ class GradSync(object):
 
     def __init__(self, flat_grad, entries, bucket_elems=None, group=None, poison=None):
         """entries: list of (param, offset, numel) in flat order (forward order of the network).
-        poison: a one-element float view INSIDE flat_grad below the first entry (train.FlatParameters keeps four leading pad
+        poison: a one-element float view INSIDE flat_grad below the first entry (train.FlatParameters keeps 64 leading pad
         floats) -- it travels with the last bucket's all-reduce; a gate that times out writes +inf there (launch_gated)."""
         self.flat_grad = flat_grad
         self.group = group

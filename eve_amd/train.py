@@ -21,9 +21,14 @@ from .parallel import GradSync
 class FlatParameters(object):
     """Moves every parameter of `modules` into one flat buffer (and its gradient into another).  The buffers start with LEAD
     pad floats (zero weights with zero gradients): grad[0] is the data-parallel exchange's POISON word -- inside the last
-    gradient bucket, written by a stream gate that timed out, read by the Adam guard (parallel.GradSync.launch_gated)."""
+    gradient bucket, written by a stream gate that timed out, read by the Adam guard (parallel.GradSync.launch_gated).
+    LEAD is 64 floats = 256 bytes so that the parameters keep the alignment they would have without it: the convolution filters
+    are multiples of 64 floats, and the weight-gradient kernels' float atomics / 16-byte slab stores into `grad` go by cache line
+    (with the 16-byte lead this class had for half of round 6, every wave's 256 contiguous bytes straddled three 128-byte lines
+    instead of two: wgrad_tr_kernel 0.143 instead of 0.121 ms per layer-2 launch, the step -1.6 % at B = 32 and -5.5 % at B = 8;
+    profiles/r06_notes.md section 10)."""
 
-    LEAD = 4
+    LEAD = 64
 
     def __init__(self, modules, device=None):
         params, seen = [], set()

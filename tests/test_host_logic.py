@@ -614,7 +614,7 @@ def test_trainer_factories_take_the_reference_schedule_and_the_fp16_loss_scale(f
     # ---- a POISONED gradient exchange (a stream gate of the data-parallel replay timed out: parallel.GradSync.launch_gated) is
     # skipped the same way, without touching the loss scale: the poison word is the first of FlatParameters' leading pad floats,
     # inside the last bucket, so every rank reads it after the all-reduce (stand-in semantics = csrc/optim.hip adam_prepare_kernel)
-    assert train.FlatParameters.LEAD == 4 and t3.fp.entries[0][1] == 4 and t3.fp.poison.data_ptr() == t3.fp.grad.data_ptr()
+    assert train.FlatParameters.LEAD == 64 and t3.fp.entries[0][1] == 64 and t3.fp.poison.data_ptr() == t3.fp.grad.data_ptr()
     k = kernels.default_kernels()
     w2, st = t3.fp.flat.clone(), t3.optimizer_state()
     t3.fp.poison.fill_(float('inf'))
