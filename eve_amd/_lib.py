@@ -46,7 +46,7 @@ F = c_float
 # name -> argtypes; every function returns int (0 = ok) except the two noted below
 class PackItem(Structure):
     _fields_ = [('w_ohwi', c_void_p), ('dst_ohwi', c_void_p), ('dst_ihwo', c_void_p),
-                ('Cout', c_int), ('taps', c_int), ('Cin', c_int)]
+                ('Cout', c_int), ('taps', c_int), ('Cin', c_int), ('src_Cout', c_int), ('src_Cin', c_int)]
 
 
 class VecTerm(Structure):
@@ -56,7 +56,7 @@ class VecTerm(Structure):
 
 VEC_TERMS_MAX = 32
 PACK_BATCH_MAX = 48
-ABI_VERSION = 9          # include/eve_hip.h EVE_ABI_VERSION
+ABI_VERSION = 10         # include/eve_hip.h EVE_ABI_VERSION
 
 SIGNATURES = {
     'eve_conv2d_fwd': [POINTER(ConvDesc), P, P, P, I, P, I, P, P],
@@ -125,6 +125,8 @@ SIGNATURES = {
     'eve_in_relu_maxpool_bwd': [I, I, I, I, I, P, P, P, P, P, P, P],
     'eve_avgpool_fwd': [I, I, I, I, P, P, P],
     'eve_avgpool_bwd': [I, I, I, I, P, P, P],
+    'eve_avgpool_fwd_f32': [I, I, I, I, P, P, P],
+    'eve_avgpool_bwd_f32': [I, I, I, I, P, P, P],
     'eve_adaptive_maxpool_fwd': [I, I, I, I, I, I, I, P, P, P, P],
     'eve_adaptive_maxpool_bwd': [I, I, I, I, I, I, I, P, P, P, P, P],
     'eve_bilinear_fwd': [I, I, I, I, I, I, I, P, P, P],

@@ -84,8 +84,11 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* __restrict__ 
 }
 
 // ---------------- global average pool ----------------
-template <typename T>
-__global__ __launch_bounds__(256) void avgpool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int HW,
+// F32SIDE: the pooled side ([N][C]: y of the forward, dy of the backward) is FLOAT32 memory holding values of format T -- the
+// EyeNet trunk hands its features to a float32 tail, and the cast was a launch of its own in each direction (5 us each in a
+// 4 ms step).  Bit-identical to pooling in T and casting: the forward rounds to T before widening, the backward rounds dy to T.
+template <typename T, bool F32SIDE = false>
+__global__ __launch_bounds__(256) void avgpool_fwd_kernel(const T* __restrict__ x, void* __restrict__ y_, int HW,
                                                           int C, long long items) {
     constexpr int VEC = Elem<T>::VEC;
     const int cvecs = C / VEC;
@@ -103,11 +106,20 @@ __global__ __launch_bounds__(256) void avgpool_fwd_kernel(const T* __restrict__ 
         }
 #pragma unroll
         for (int e = 0; e < VEC; ++e) s[e] /= (float)HW;
-        reinterpret_cast<uint4*>(y)[i] = Elem<T>::pack(s);
+        const uint4 packed = Elem<T>::pack(s);
+        if (F32SIDE) {
+            float r[VEC];
+            Elem<T>::unpack(packed, r);
+            float* y = reinterpret_cast<float*>(y_) + i * VEC;
+#pragma unroll
+            for (int e = 0; e < VEC; e += 4) *reinterpret_cast<float4*>(y + e) = make_float4(r[e], r[e + 1], r[e + 2], r[e + 3]);
+        } else {
+            reinterpret_cast<uint4*>(y_)[i] = packed;
+        }
     }
 }
-template <typename T>
-__global__ __launch_bounds__(256) void avgpool_bwd_kernel(const T* __restrict__ dy, T* __restrict__ dx, int HW,
+template <typename T, bool F32SIDE = false>
+__global__ __launch_bounds__(256) void avgpool_bwd_kernel(const void* __restrict__ dy_, T* __restrict__ dx, int HW,
                                                           int C, long long items) {
     constexpr int VEC = Elem<T>::VEC;
     const int cvecs = C / VEC;
@@ -115,7 +127,18 @@ __global__ __launch_bounds__(256) void avgpool_bwd_kernel(const T* __restrict__ 
         const int cv = (int)(i % cvecs);
         const long long n = i / ((long long)HW * cvecs);
         float g[VEC];
-        Elem<T>::unpack(*reinterpret_cast<const uint4*>(dy + n * C + cv * VEC), g);
+        if (F32SIDE) {
+            const float* dy = reinterpret_cast<const float*>(dy_) + n * C + cv * VEC;
+            float r[VEC];
+#pragma unroll
+            for (int e = 0; e < VEC; e += 4) {
+                const float4 v = *reinterpret_cast<const float4*>(dy + e);
+                r[e] = v.x; r[e + 1] = v.y; r[e + 2] = v.z; r[e + 3] = v.w;
+            }
+            Elem<T>::unpack(Elem<T>::pack(r), g);             // rounded to T, as the separate cast did
+        } else {
+            Elem<T>::unpack(*reinterpret_cast<const uint4*>(reinterpret_cast<const T*>(dy_) + n * C + cv * VEC), g);
+        }
 #pragma unroll
         for (int e = 0; e < VEC; ++e) g[e] /= (float)HW;
         reinterpret_cast<uint4*>(dx)[i] = Elem<T>::pack(g);
@@ -354,7 +377,7 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const float* __restri
 
 // all conv weights of a model in one launch (the packs are rebuilt after every optimiser step: 20 launches of a few
 // microseconds each were 0.14 ms of a 15 ms step)
-struct PackItem { const float* w; void* ohwi; void* ihwo; int Cout, taps, Cin; long long start; };   // start = first tile
+struct PackItem { const float* w; void* ohwi; void* ihwo; int Cout, taps, Cin, sCout, sCin; long long start; };   // start = first tile
 struct PackTable { PackItem it[EVE_PACK_BATCH_MAX]; int count; long long total; };                   // total tiles
 
 // One workgroup = one 32 (output channels) x 32 (input channels) tile of one filter tap: rows are read and written
@@ -379,9 +402,9 @@ __global__ __launch_bounds__(256) void pack_weights_batch_kernel(const PackTable
             const int co = co0 + r, ci = ci0 + tx;
             float v = 0.f;
             if (co < q.Cout && ci < q.Cin) {
-                const long long i = ((long long)co * q.taps + tap) * q.Cin + ci;
-                v = q.w[i];
-                if (q.ohwi) Elem<T>::st((T*)q.ohwi + i, v);
+                // (the source may be narrower than the packed copies: padding channels are written as zeros)
+                if (co < q.sCout && ci < q.sCin) v = q.w[((long long)co * q.taps + tap) * q.sCin + ci];
+                if (q.ohwi) Elem<T>::st((T*)q.ohwi + ((long long)co * q.taps + tap) * q.Cin + ci, v);
             }
             tile[r][tx] = v;
         }
@@ -458,6 +481,29 @@ extern "C" int eve_avgpool_bwd(int dtype, int N, int HW, int C, const void* dy, 
     if (dtype == EVE_DT_BF16) hipLaunchKernelGGL(avgpool_bwd_kernel<bf16_t>, dim3(sgrid(items)), dim3(256), 0, s, (const bf16_t*)dy, (bf16_t*)dx, HW, C, items);
     else if (dtype == EVE_DT_F16) hipLaunchKernelGGL(avgpool_bwd_kernel<f16_t>, dim3(sgrid(items)), dim3(256), 0, s, (const f16_t*)dy, (f16_t*)dx, HW, C, items);
     else                      hipLaunchKernelGGL(avgpool_bwd_kernel<float>, dim3(sgrid(items)), dim3(256), 0, s, (const float*)dy, (float*)dx, HW, C, items);
+    EVE_CHECK_LAUNCH();
+    return 0;
+}
+// the same with the pooled side in float32 memory (see the kernels): dtype is the format of the [N][HW][C] side
+extern "C" int eve_avgpool_fwd_f32(int dtype, int N, int HW, int C, const void* x, float* y, eve_stream_t stream) {
+    if (int e = chk(dtype, C, "avgpool_fwd_f32: bad dtype / C")) return e;
+    if (N <= 0 || HW <= 0 || !x || !y) return set_error_msg("avgpool_fwd_f32: bad arguments");
+    if (dtype == EVE_DT_F32) return eve_avgpool_fwd(dtype, N, HW, C, x, y, stream);
+    const long long items = (long long)N * (C / 8);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == EVE_DT_BF16) hipLaunchKernelGGL((avgpool_fwd_kernel<bf16_t, true>), dim3(sgrid(items)), dim3(256), 0, s, (const bf16_t*)x, (void*)y, HW, C, items);
+    else                      hipLaunchKernelGGL((avgpool_fwd_kernel<f16_t, true>), dim3(sgrid(items)), dim3(256), 0, s, (const f16_t*)x, (void*)y, HW, C, items);
+    EVE_CHECK_LAUNCH();
+    return 0;
+}
+extern "C" int eve_avgpool_bwd_f32(int dtype, int N, int HW, int C, const float* dy, void* dx, eve_stream_t stream) {
+    if (int e = chk(dtype, C, "avgpool_bwd_f32: bad dtype / C")) return e;
+    if (N <= 0 || HW <= 0 || !dy || !dx) return set_error_msg("avgpool_bwd_f32: bad arguments");
+    if (dtype == EVE_DT_F32) return eve_avgpool_bwd(dtype, N, HW, C, dy, dx, stream);
+    const long long items = (long long)N * HW * (C / 8);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == EVE_DT_BF16) hipLaunchKernelGGL((avgpool_bwd_kernel<bf16_t, true>), dim3(sgrid(items)), dim3(256), 0, s, (const void*)dy, (bf16_t*)dx, HW, C, items);
+    else                      hipLaunchKernelGGL((avgpool_bwd_kernel<f16_t, true>), dim3(sgrid(items)), dim3(256), 0, s, (const void*)dy, (f16_t*)dx, HW, C, items);
     EVE_CHECK_LAUNCH();
     return 0;
 }
@@ -567,7 +613,9 @@ extern "C" int eve_pack_weights_batch(int dtype_dst, int count, const eve_pack_i
         const eve_pack_item& q = items[i];
         if (q.Cout <= 0 || q.taps <= 0 || q.Cin <= 0 || !q.w_ohwi || (!q.dst_ohwi && !q.dst_ihwo))
             return set_error_msg("pack_weights_batch: bad item");
-        tb.it[i] = PackItem{q.w_ohwi, q.dst_ohwi, q.dst_ihwo, q.Cout, q.taps, q.Cin, total};
+        if (q.src_Cout < 0 || q.src_Cout > q.Cout || q.src_Cin < 0 || q.src_Cin > q.Cin) return set_error_msg("pack_weights_batch: bad source shape");
+        tb.it[i] = PackItem{q.w_ohwi, q.dst_ohwi, q.dst_ihwo, q.Cout, q.taps, q.Cin, q.src_Cout ? q.src_Cout : q.Cout,
+                            q.src_Cin ? q.src_Cin : q.Cin, total};
         total += (long long)((q.Cout + 31) / 32) * q.taps * ((q.Cin + 31) / 32);
     }
     tb.count = count; tb.total = total;

@@ -163,8 +163,10 @@ class EyeNet(nn.Module):
     def _trunk(self, x, P, x_padded=None):
         """x: [N, H, W, Cpad] NHWC compute dtype -> [N, 512] float32 (torchvision ResNet._forward_impl).
         x_padded: optional [N, H+6, W+8, 4] bf16 repack for the dedicated stem kernel."""
-        feats = ops.AvgPoolFn.apply(self._trunk_layers(x, P, x_padded))
-        return ops.cast(feats, torch.float32)
+        y = self._trunk_layers(x, P, x_padded)
+        if hasattr(ops.default_kernels(), 'avgpool_fwd_f32'):
+            return ops.AvgPoolF32Fn.apply(y)                  # pool + cast in one launch each way (same bits)
+        return ops.cast(ops.AvgPoolFn.apply(y), torch.float32)
 
     def _trunk_layers(self, x, P, x_padded=None):
         """conv1 .. layer4 of the trunk: -> [N, H/32, W/32, 512] NHWC compute dtype."""

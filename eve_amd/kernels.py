@@ -809,6 +809,21 @@ class HipKernels(object):
                                           self._stream()))
         return y
 
+    def avgpool_fwd_f32(self, x):
+        """avgpool_fwd with a float32 result holding the x.dtype-rounded means (= avgpool_fwd + cast, one launch)."""
+        N, H, W, C = x.shape
+        y = torch.empty((N, C), dtype=torch.float32, device=x.device)
+        self._ck(self.lib.eve_avgpool_fwd_f32(dt_code(x.dtype), N, H * W, C, self._p(x), self._p(y), self._stream()))
+        return y
+
+    def avgpool_bwd_f32(self, dy, hw, dtype):
+        """dy float32 [N, C] -> dx [N, H, W, C] in `dtype` (= cast + avgpool_bwd, one launch)."""
+        N, C = dy.shape
+        assert dy.dtype == torch.float32 and dy.is_contiguous()
+        dx = torch.empty((N, hw[0], hw[1], C), dtype=dtype, device=dy.device)
+        self._ck(self.lib.eve_avgpool_bwd_f32(dt_code(dtype), N, hw[0] * hw[1], C, self._p(dy), self._p(dx), self._stream()))
+        return dx
+
     def avgpool_bwd(self, dy, hw):
         N, C = dy.shape
         dx = torch.empty((N, hw[0], hw[1], C), dtype=dy.dtype, device=dy.device)
@@ -886,18 +901,22 @@ class HipKernels(object):
                                            self._p(ihwo), self._stream()))
         return ohwi, ihwo
 
-    def pack_weights_batch(self, ws_ohwi_f32, dtype, want_ihwo):
+    def pack_weights_batch(self, ws_ohwi_f32, dtype, want_ihwo, padded=None):
         """pack_weights for a list of OHWI float32 weights (and per-weight want_ihwo flags) in ONE launch per
-        EVE_PACK_BATCH_MAX weights.  Returns [(ohwi, ihwo)]."""
+        EVE_PACK_BATCH_MAX weights.  padded: per weight None or (Cout_padded, Cin_padded) -- the packed copies are that wide, the
+        extra channels zero (written by the same launch).  Returns [(ohwi, ihwo)]."""
         out, items, keep = [], [], []
-        for w, wi in zip(ws_ohwi_f32, want_ihwo):
-            Cout, KH, KW, Cin = w.shape
+        padded = padded if padded is not None else [None] * len(ws_ohwi_f32)
+        for w, wi, pd in zip(ws_ohwi_f32, want_ihwo, padded):
+            sCout, KH, KW, sCin = w.shape
+            Cout, Cin = pd if pd is not None else (sCout, sCin)
+            assert Cout >= sCout and Cin >= sCin
             w = self._f32(w, 'weights')
             self._p(w)                                 # (raises for a tensor that is not on the GPU)
             ohwi = torch.empty((Cout, KH, KW, Cin), dtype=dtype, device=w.device)
             ihwo = torch.empty((Cin, KH, KW, Cout), dtype=dtype, device=w.device) if wi else None
             keep.append(w)
-            items.append(_lib.PackItem(w.data_ptr(), ohwi.data_ptr(), ihwo.data_ptr() if wi else None, Cout, KH * KW, Cin))
+            items.append(_lib.PackItem(w.data_ptr(), ohwi.data_ptr(), ihwo.data_ptr() if wi else None, Cout, KH * KW, Cin, sCout, sCin))
             out.append((ohwi, ihwo))
         for i in range(0, len(items), _lib.PACK_BATCH_MAX):
             chunk = items[i:i + _lib.PACK_BATCH_MAX]

@@ -50,15 +50,19 @@ class PackedWeight(object):
         self.shape_oihw = tuple(w.shape)
         self.algo = (w.shape[0], w.shape[1] * w.shape[2] * w.shape[3])     # true Cout, true K
         w = w.permute(0, 2, 3, 1)                      # OHWI view
+        self.pair_fwd = self.pair_dgrad = None
+        self._pairs_for = (dtype, param.dim(), want_ihwo)
+        if defer and hasattr(k, 'dispatch_config'):   # packed later, together with others (pack_many); the batched launch writes
+            padded = (cout_pad or w.shape[0], cin_pad or w.shape[3])         # the padding channels itself (no fill + copy per weight)
+            self.ohwi, self.ihwo = (w.contiguous().float(), want_ihwo, padded), None
+            return
         if cin_pad is not None and cin_pad != w.shape[3]:
             w = torch.nn.functional.pad(w, (0, cin_pad - w.shape[3]))
         if cout_pad is not None and cout_pad != w.shape[0]:
             w = torch.nn.functional.pad(w, (0, 0, 0, 0, 0, 0, 0, cout_pad - w.shape[0]))
         w = w.contiguous().float()
-        self.pair_fwd = self.pair_dgrad = None
-        self._pairs_for = (dtype, param.dim(), want_ihwo)
-        if defer:                                     # packed later, together with others (pack_many)
-            self.ohwi, self.ihwo = (w, want_ihwo), None
+        if defer:
+            self.ohwi, self.ihwo = (w, want_ihwo, None), None
         else:
             self.ohwi, self.ihwo = k.pack_weights(w, dtype, want_ihwo=want_ihwo)
             self._make_pairs()
@@ -84,7 +88,11 @@ class PackedWeight(object):
         todo = [p for p in packs if isinstance(p.ohwi, tuple)]
         if not todo:
             return
-        res = default_kernels().pack_weights_batch([p.ohwi[0] for p in todo], dtype, [p.ohwi[1] for p in todo])
+        k = default_kernels()
+        if any(p.ohwi[2] is not None for p in todo):
+            res = k.pack_weights_batch([p.ohwi[0] for p in todo], dtype, [p.ohwi[1] for p in todo], padded=[p.ohwi[2] for p in todo])
+        else:
+            res = k.pack_weights_batch([p.ohwi[0] for p in todo], dtype, [p.ohwi[1] for p in todo])
         for p, (ohwi, ihwo) in zip(todo, res):
             p.ohwi, p.ihwo = ohwi, ihwo
             p._make_pairs()
@@ -1015,6 +1023,18 @@ class AvgPoolFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         return default_kernels().avgpool_bwd(dy.contiguous(), ctx.hw)
+
+
+class AvgPoolF32Fn(torch.autograd.Function):
+    """AvgPoolFn followed by a cast to float32 (and the cast back in the backward) as one launch each way; same bits."""
+    @staticmethod
+    def forward(ctx, x):
+        ctx.hw, ctx.src = (x.shape[1], x.shape[2]), x.dtype
+        return default_kernels().avgpool_fwd_f32(x)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return default_kernels().avgpool_bwd_f32(dy.contiguous(), ctx.hw, ctx.src)
 
 
 class AdaptiveMaxPoolFn(torch.autograd.Function):

@@ -158,8 +158,19 @@ class Trainer(object):
 
     def _backward(self, terms):
         loss = terms['full_loss']
-        # (the scale is read from the device: it may have backed off, and a captured graph must follow it)
-        (loss if not self.check_overflow else loss * self.loss_scale_dev[0]).backward()
+        # The root gradient is a resident tensor instead of autograd's ones_like (a fill launch per step) -- and under a loss
+        # scale it IS the scale, read from the device (it may have backed off, and a captured graph must follow it): the same
+        # d(loss * scale) without the multiply launch.
+        if self.check_overflow and loss.dim() == 0 and loss.dtype == torch.float32:
+            loss.backward(gradient=self.loss_scale_dev[0])
+        elif self.check_overflow:
+            (loss * self.loss_scale_dev[0]).backward()
+        elif loss.dim() == 0 and loss.dtype == torch.float32:
+            if getattr(self, '_grad_one', None) is None or self._grad_one.device != loss.device:
+                self._grad_one = torch.ones((), dtype=torch.float32, device=loss.device)
+            loss.backward(gradient=self._grad_one)
+        else:
+            loss.backward()
 
     def _forward_backward(self, batch):
         terms = self._forward(batch)

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define EVE_ABI_VERSION 9
+#define EVE_ABI_VERSION 10
 
 typedef void* eve_stream_t; /* hipStream_t */
 
@@ -355,6 +355,10 @@ int eve_in_relu_maxpool_bwd(int dtype, int N, int IH, int IW, int C, const void*
 /* mean over the HW plane: y[N][C]; and its gradient dx[n][hw][c] = dy[n][c] / HW                  */
 int eve_avgpool_fwd(int dtype, int N, int HW, int C, const void* x, void* y, eve_stream_t stream);
 int eve_avgpool_bwd(int dtype, int N, int HW, int C, const void* dy, void* dx, eve_stream_t stream);
+/* ABI v10: the same with the pooled [N][C] side in FLOAT32 memory (values of format `dtype`, widened): EyeNet's trunk -> tail
+ * hand-over (eye_net.py:52-56: avgpool -> flatten -> fc) without the two cast launches; bit-identical to pool + cast.          */
+int eve_avgpool_fwd_f32(int dtype, int N, int HW, int C, const void* x, float* y, eve_stream_t stream);
+int eve_avgpool_bwd_f32(int dtype, int N, int HW, int C, const float* dy, void* dx, eve_stream_t stream);
 /* adaptive max-pool, window i = [floor(i*I/O), ceil((i+1)*I/O)); idx = flat ih*IW+iw (int32)       */
 int eve_adaptive_maxpool_fwd(int dtype, int N, int IH, int IW, int OH, int OW, int C, const void* x,
                              void* y, int32_t* idx, eve_stream_t stream);
@@ -388,6 +392,9 @@ int eve_pack_weights(int dtype_dst, int Cout, int taps, int Cin, const float* w_
 typedef struct eve_pack_item {
     const float* w_ohwi; void* dst_ohwi; void* dst_ihwo;      /* either destination may be NULL */
     int Cout, taps, Cin;
+    int src_Cout, src_Cin;   /* ABI v10: the SOURCE is [src_Cout][taps][src_Cin] (0 = Cout / Cin); the destinations' extra output /
+                              * input channels are written as zeros -- conv1's 3 -> 4/8 input channels, the 130 -> 132 wide
+                              * fc_common.0, the 2- and 1-wide heads padded to 4 were a fill + a copy launch each, every step */
 } eve_pack_item;
 int eve_pack_weights_batch(int dtype_dst, int count, const eve_pack_item* items /* host array */, eve_stream_t stream);
 

@@ -39,7 +39,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), name
     lib.eve_abi_version.restype = ctypes.c_int
-    assert lib.eve_abi_version() == _lib.ABI_VERSION == 9
+    assert lib.eve_abi_version() == _lib.ABI_VERSION == 10
     # kernel selection is resolved once at load (include/eve_hip.h eve_dispatch_config): with a clean environment the loaded
     # table IS the default table, the Python mirror of the struct has the library's size, and a wrong-sized struct is refused
     for n in ('eve_get_dispatch_config', 'eve_get_default_dispatch_config', 'eve_set_dispatch_config'):
