@@ -86,8 +86,8 @@ def offset_augmentation(g, head_R, kappa):       # common.py:190-229 (inverse_ka
 # ---------------------------------------------------------------------------------------------- maps
 def make_heatmaps(centres_px, sigma, config):    # common.py:236-250, centres N x 2 (px) -> N x 1 x H x W
     w, h = config.gaze_heatmap_size
-    xs = torch.arange(w, dtype=torch.float32).view(1, 1, w)
-    ys = torch.arange(h, dtype=torch.float32).view(1, h, 1)
+    xs = torch.arange(w, dtype=centres_px.dtype).view(1, 1, w)          # (float32 in the parity tests; float64 when the
+    ys = torch.arange(h, dtype=centres_px.dtype).view(1, h, 1)          #  oracle is evaluated as its own error bar)
     cx = (w / config.actual_screen_size[0]) * centres_px[:, 0].view(-1, 1, 1)
     cy = (h / config.actual_screen_size[1]) * centres_px[:, 1].view(-1, 1, 1)
     alpha = -0.5 / (sigma ** 2)
@@ -107,8 +107,9 @@ def gaze_history_maps(timestamps, heatmaps, validity, config):
         for t in range(L):
             if ts[t] == 0:
                 continue
-            w = torch.pow(torch.tensor(config.gaze_history_map_decay_per_ms), (target - ts[t]) * 1e-6).view(1, 1)
-            acc = acc + validity[b, t].float() * w * heatmaps[b, t]
+            w = torch.pow(torch.tensor(config.gaze_history_map_decay_per_ms, dtype=heatmaps.dtype),
+                          (target - ts[t]).to(heatmaps.dtype) * 1e-6).view(1, 1)
+            acc = acc + validity[b, t].to(heatmaps.dtype) * w * heatmaps[b, t]
         out.append(acc)
     return torch.stack(out, dim=0)
 
@@ -117,8 +118,8 @@ def soft_argmax(heatmaps, config):               # common.py:304-333, N x 1 x H 
     n, _, h, w = heatmaps.shape
     ref_xs, ref_ys = np.meshgrid(np.linspace(0, 1.0, num=w, endpoint=True), np.linspace(0, 1.0, num=h, endpoint=True),
                                  indexing='xy')
-    ref_xs = torch.tensor(ref_xs.reshape(1, h * w).astype(np.float32))
-    ref_ys = torch.tensor(ref_ys.reshape(1, h * w).astype(np.float32))
+    ref_xs = torch.tensor(ref_xs.reshape(1, h * w).astype(np.float32)).to(heatmaps.dtype)
+    ref_ys = torch.tensor(ref_ys.reshape(1, h * w).astype(np.float32)).to(heatmaps.dtype)
     p = F.softmax(1e2 * heatmaps.reshape(n, h * w), dim=-1)
     sw, sh = config.actual_screen_size
     return torch.stack([torch.clamp(sw * torch.sum(ref_xs * p, dim=-1), 0.0, sw),
@@ -140,7 +141,7 @@ def synthesise_labels(batch, config, training, kappa=None):
         if kappa is None:
             kappa = (np.random.normal(size=(B, 2), loc=0.0, scale=std), np.random.normal(size=(B, 2), loc=0.0, scale=std))
         for side, k in zip(('left', 'right'), kappa):
-            d[side + '_kappa_fake'] = torch.tensor(np.repeat(np.asarray(k)[:, None], T, axis=1).astype(np.float32))
+            d[side + '_kappa_fake'] = torch.tensor(np.repeat(np.asarray(k)[:, None], T, axis=1).astype(np.float32)).to(d['left_o'].dtype)
     d['o'] = 0.5 * (d['left_o'] + d['right_o'])
     d['o_validity'] = d['left_o_validity']
     d['PoG_px_tobii'] = torch.stack([d['left_PoG_tobii'], d['right_PoG_tobii']], dim=-1).mean(dim=-1)
@@ -152,7 +153,7 @@ def synthesise_labels(batch, config, training, kappa=None):
         for name, sigma in (('initial', config.gaze_heatmap_sigma_initial), ('history', config.gaze_heatmap_sigma_history),
                             ('final', config.gaze_heatmap_sigma_final)):
             m = make_heatmaps(flat, sigma, config).view(B, T, 1, *reversed(config.gaze_heatmap_size))
-            d['heatmap_' + name] = m * valid.float().view(B, T, 1, 1, 1)
+            d['heatmap_' + name] = m * valid.to(m.dtype).view(B, T, 1, 1, 1)
             d['heatmap_%s_validity' % name] = valid
     d['g'] = combined_gaze_direction(d['o'].reshape(-1, 3), 10.0 * d['PoG_cm_tobii'].reshape(-1, 2),
                                      d['left_R'].reshape(-1, 3, 3), d['camera_transformation'].reshape(-1, 4, 4)).view(B, T, 2)

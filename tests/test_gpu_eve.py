@@ -283,6 +283,23 @@ def test_full_size_round_trips(hip):
     assert float((got.cpu() - px).abs().max()) < 16.0                     # within one heat-map cell of the centre itself
 
 
+def _oracle_gaze_float64(ocfg, batch, seed):
+    """g_initial / g_final of the CPU oracle evaluated in float64 on the same float32-representable inputs and weights."""
+    from oracle.eye_net import EyeNet as OracleEyeNet
+    from oracle.refine_net import RefineNet as OracleRefineNet
+    torch.set_default_dtype(torch.float64)
+    try:
+        oeye = detweights.fill_module(OracleEyeNet(ocfg), 0).double()
+        oref = detweights.fill_module(OracleRefineNet(ocfg), 1).double()
+        b64 = {k: (v.double() if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in batch.items()}
+        np.random.seed(seed)
+        with torch.no_grad():
+            _, inter, _ = oracle_eve.eve_forward(oeye, oref, dict(b64), ocfg, True)
+        return {k: inter[k].detach().double() for k in ('g_initial', 'g_final')}
+    finally:
+        torch.set_default_dtype(torch.float32)
+
+
 @pytest.mark.parametrize('over', [dict(refine_net_rnn_type='CLSTM'), dict(refine_net_rnn_type='CRNN'),
                                   dict(refine_net_rnn_type='CGRU', refine_net_use_skip_connections=False),
                                   dict(refine_net_rnn_type='CGRU', refine_net_do_offset_augmentation=False)],
@@ -307,13 +324,23 @@ def test_eve_config_variants_match_oracle(over):
     batch = detweights.eve_batch(2, 3, seed=23, invalid_fraction=0.2)
     np.random.seed(2)
     want, winter, _ = oracle_eve.eve_forward(oeye, oref, dict(batch), ocfg, True)
+    # The oracle's own error bar: the same algorithm on the same (float32-representable) inputs and weights in float64.  The
+    # refinement amplifies a perturbation of g_initial ~20 x into g_final (soft-argmax at temperature 100 through a recurrent cell):
+    # the float32 CPU evaluation itself sits up to 3.3e-5 rad from its float64 evaluation (no-skip variant), a third of the
+    # tolerance, so the GPU result is held to 1e-4 against the float64 evaluation, and against the float32 one with that
+    # evaluation's own deviation as slack (profiles/r06_notes.md 13).
+    winter64 = _oracle_gaze_float64(ocfg, batch, seed=2)
     np.random.seed(2)
     got = model({'s': {k: v.cuda() for k, v in batch.items()}}, current_epoch=0.0)
     assert {k for k in got if k.startswith(('loss_', 'metric_'))} == set(want.keys()) - {'full_loss'}
     for k, v in want.items():
         assert abs(float(got[k].detach()) - float(v.detach())) <= 5e-4 * abs(float(v.detach())) + 1e-4, (k, float(got[k].detach()), float(v.detach()))
     for k in ('g_initial', 'g_final'):
-        assert float((got[k].detach().cpu() - winter[k].detach()).abs().max()) < 1e-4, k
+        g = got[k].detach().cpu().double()
+        bar = float((winter[k].detach().double() - winter64[k]).abs().max())
+        assert bar < 5e-5, (k, bar)
+        assert float((g - winter64[k]).abs().max()) < 1e-4, k
+        assert float((g - winter[k].detach().double()).abs().max()) < 1e-4 + bar, k
     got['full_loss'].backward()
     # gradients: against the REFERENCE's float64 evaluation of this variant (eve_grads_f64.npz), bounded per parameter by the
     # reference's own float32 deviation (round 4; 1e-1 against the float32 CPU oracle before).  CLSTM: the cell's gates get no
