@@ -365,7 +365,7 @@ class HipKernels(object):
             q.ldX = X.shape[1] if X.shape[1] != q.K1 else 0           # the leading K1 columns of a wider X
             q.ldW, q.x_shift_T, q.reserved = 0, int(pr.get('x_shift_T', 0)), 0
             assert dY.shape[1] >= q.N and q.K1 + q.K2 <= q.K and X.shape[0] == q.M and X.shape[1] >= q.K1
-            assert not q.x_shift_T or (q.K2 == 0 and q.M % q.x_shift_T == 0)
+            assert not q.x_shift_T or (q.K2 == 0 and q.K1 == q.K and q.M % q.x_shift_T == 0)    # (the kernel reads column k of X for every k < K)
             assert pr.get('Y') is None or pr['Y'].shape == dY.shape
         self._timed('tail', 0.0, lambda: self._ck(self.lib.eve_linear_wgrad_batch(arr, n, self._stream())))
 

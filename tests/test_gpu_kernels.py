@@ -872,6 +872,53 @@ def test_layout_and_pack(hip, ref, dtype):
         if wi:
             assert torch.equal(b.cpu(), w_.permute(3, 1, 2, 0).contiguous().to(dtype))
 
+    # ABI v10: a narrower source, the packed copies' extra output / input channels written as zeros by the same launch
+    padded = [(16, 8), (40, 72), (64, 8), (4, 128), (132, 36)]
+    srcs = [w_[:co - (2 if i in (0, 4) else 0), :, :, :ci - (3 if i in (0, 4) else 0)].contiguous()
+            for i, (w_, (co, ci)) in enumerate(zip(ws, [(16, 8), (40, 72), (64, 8), (4, 128), (130, 33)]))]
+    res = hip.pack_weights_batch([dev(w_) for w_ in srcs], dtype, want_ihwo, padded=padded)
+    for w_, wi, (co, ci), (a, b) in zip(srcs, want_ihwo, padded, res):
+        want = torch.nn.functional.pad(w_, (0, ci - w_.shape[3], 0, 0, 0, 0, 0, co - w_.shape[0])).to(dtype)
+        assert tuple(a.shape) == (co, w_.shape[1], w_.shape[2], ci) and torch.equal(a.cpu(), want)
+        if wi:
+            assert torch.equal(b.cpu(), want.permute(3, 1, 2, 0).contiguous())
+
+
+@HALVES
+def test_avgpool_with_a_float32_pooled_side_equals_pool_plus_cast(hip, hdt):
+    """eve_avgpool_{fwd,bwd}_f32 (ABI v10: the trunk -> tail hand-over in one launch each way) == pool in the 16-bit format + cast,
+    bit for bit; float32 input: the plain kernels."""
+    x = rnd((7, 4, 4, 512), torch.float32, 310)
+    xh = dev(x).to(hdt)
+    y = hip.avgpool_fwd_f32(xh)
+    assert y.dtype == torch.float32 and torch.equal(y, hip.avgpool_fwd(xh).float())
+    dy = dev(rnd((7, 512), torch.float32, 311))
+    dx = hip.avgpool_bwd_f32(dy, (4, 4), hdt)
+    assert dx.dtype == hdt and torch.equal(dx, hip.avgpool_bwd(dy.to(hdt), (4, 4)))
+    xf = dev(x)
+    assert torch.equal(hip.avgpool_fwd_f32(xf), hip.avgpool_fwd(xf))
+    assert torch.equal(hip.avgpool_bwd_f32(dy, (4, 4), torch.float32), hip.avgpool_bwd(dy, (4, 4)))
+
+
+def test_strided_accumulating_linear_kernels(hip, ref):
+    """eve_linear_{fwd,dgrad}_ex: a column range of a wider output, a short bias, the data gradient added onto an existing one, and
+    the act'(y) prologue read with the wide row stride -- what ops.EyeTailLossFn launches (odd sizes: the masked scalar path)."""
+    for M, K, N, ld in ((45, 128, 4, 8), (33, 512, 128, 132), (19, 6, 10, 12)):
+        x = rnd((M, K), torch.float32, 320)
+        w = rnd((N, K), torch.float32, 321, scale=K ** -0.5)
+        b = rnd((N - 1,), torch.float32, 322)
+        wide = torch.full((M, ld), 7.0, device='cuda')
+        hip.linear_fwd_ex(dev(x), K, dev(w.t().contiguous()), dev(b), 3, wide)
+        bfull = torch.cat([b, torch.zeros(1)])
+        want = ref.linear_fwd(x, w.t().contiguous(), bfull, 3)
+        assert torch.allclose(wide[:, :N].cpu(), want, rtol=2e-5, atol=2e-5) and bool((wide[:, N:] == 7.0).all())
+        dyw = dev(rnd((M, ld), torch.float32, 323))
+        base = dev(rnd((M, K), torch.float32, 324))
+        dx = base.clone()
+        hip.linear_dgrad_ex(dyw, N, wide, 3, dev(w), dx, accumulate=True)
+        dx_want = ref.linear_dgrad(dyw[:, :N].cpu().contiguous(), want, 3, w) + base.cpu()
+        assert torch.allclose(dx.cpu(), dx_want, rtol=1e-4, atol=5e-5)
+
 
 @pytest.mark.parametrize('H', [128, 96], ids=['h128_register_resident', 'h96_generic'])
 def test_gru_scan(hip, ref, H):
